@@ -1,0 +1,945 @@
+// ks_oracle.cpp — CPU ORACLE (test infrastructure; see ks_oracle.h for the contract).
+//
+// Dependency-free C++17 restatement of the semantic TSDF integration hot path.
+// Build: g++ -O2 -std=c++17 -ffp-contract=off -fPIC -shared (oracle/Makefile).
+// Every function cites what it follows:
+//   [K:file:line]  = a file under /root/reference/kimera_semantics/
+//   [V:...]        = upstream ethz-asl/voxblox (NOT in /root/reference; un-pinned)
+//   [M:...], [E:...] = minkindr / Eigen 3.3 (likewise external)
+// Float arithmetic is f32 without FMA contraction, evaluated in the association order the
+// upstream expression templates produce (Eigen's 3-element redux is  a0 + (a1 + a2) ).
+
+#include "ks_oracle.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------
+// Types [V:core/common.h], [V:core/voxel.h], [K:semantic_voxel.h:14-27]
+// ---------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+struct I3 {
+  int64_t x, y, z;
+  bool operator==(const I3& o) const { return x == o.x && y == o.y && z == o.z; }
+  bool operator!=(const I3& o) const { return !(*this == o); }
+};
+struct B3 {
+  int32_t x, y, z;
+  bool operator==(const B3& o) const { return x == o.x && y == o.y && z == o.z; }
+  bool operator!=(const B3& o) const { return !(*this == o); }
+};
+struct Rgba { uint8_t r, g, b, a; };
+
+constexpr float kEpsilon = 1e-6f;            // [V:core/common.h] kEpsilon
+constexpr float kCoordinateEpsilon = 1e-6f;  // [V:core/common.h] kCoordinateEpsilon
+constexpr float kFloatEpsilon = 1e-6f;       // [V:core/common.h] kFloatEpsilon
+constexpr int kNumLabels = KO_NUM_LABELS;    // [K:common.h:26]
+
+#pragma pack(push, 1)
+struct TsdfVoxel {  // 12 B [V:core/voxel.h]
+  float distance = 0.0f;
+  float weight = 0.0f;
+  Rgba color = {0, 0, 0, 0};
+};
+struct SemanticVoxel {  // 92 B [K:semantic_voxel.h:14-27]
+  uint8_t semantic_label = 0;
+  uint8_t pad[3] = {0, 0, 0};
+  float semantic_priors[kNumLabels];
+  Rgba color = {127, 127, 127, 255};  // HashableColor::Gray()
+  SemanticVoxel() {
+    for (int i = 0; i < kNumLabels; ++i) semantic_priors[i] = -0.60205999132f;  // [K:semantic_voxel.h:23]
+  }
+};
+#pragma pack(pop)
+static_assert(sizeof(TsdfVoxel) == 12, "TsdfVoxel layout");
+static_assert(sizeof(SemanticVoxel) == 92, "SemanticVoxel layout");
+
+// [V:core/block_hash.h] AnyIndexHash / LongIndexHash: truncated to 32 bits.
+inline uint32_t index_hash(int64_t x, int64_t y, int64_t z) {
+  constexpr uint64_t sl = 17191;
+  constexpr uint64_t sl2 = sl * sl;
+  return static_cast<uint32_t>(static_cast<uint64_t>(x) + static_cast<uint64_t>(y) * sl +
+                               static_cast<uint64_t>(z) * sl2);
+}
+struct LongIndexHash {
+  size_t operator()(const I3& i) const { return index_hash(i.x, i.y, i.z); }
+};
+struct AnyIndexHash {
+  size_t operator()(const B3& i) const { return index_hash(i.x, i.y, i.z); }
+};
+
+// ---------------------------------------------------------------------------------------
+// Small vector math in Eigen's evaluation order
+// ---------------------------------------------------------------------------------------
+inline V3 sub(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 add(const V3& a, const V3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline V3 mul(const V3& a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+// [E:Core/Redux.h] redux_novec_unroller<.,.,0,3>: func(c0, func(c1, c2))
+inline float dot(const V3& a, const V3& b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+inline float squared_norm(const V3& a) { return dot(a, a); }
+inline float norm(const V3& a) { return std::sqrt(squared_norm(a)); }
+// [E:Core/Dot.h] MatrixBase::normalized(): z>0 ? n / sqrt(z) : n
+inline V3 normalized(const V3& a) {
+  const float z = squared_norm(a);
+  if (z > 0.0f) {
+    const float s = std::sqrt(z);
+    return {a.x / s, a.y / s, a.z / s};
+  }
+  return a;
+}
+inline V3 cross(const V3& a, const V3& b) {  // [E:Geometry/OrthoMethods.h]
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+
+struct Transform {  // [M:quat-transformation.h] q_A_B (w,x,y,z) + A_t_A_B
+  float w;
+  V3 v;
+  V3 t;
+};
+// [M:QuatTransformationTemplate::transform] = q.rotate(p) + t ;
+// [E:Geometry/Quaternion.h] _transformVector: uv = q.vec x p; uv += uv; p + w*uv + q.vec x uv
+inline V3 transform_point(const Transform& T, const V3& p) {
+  V3 uv = cross(T.v, p);
+  uv = add(uv, uv);
+  const V3 c2 = cross(T.v, uv);
+  V3 r;
+  r.x = (p.x + T.w * uv.x) + c2.x;
+  r.y = (p.y + T.w * uv.y) + c2.y;
+  r.z = (p.z + T.w * uv.z) + c2.z;
+  return add(r, T.t);
+}
+
+// [V:core/common.h] getGridIndexFromPoint(point, grid_size_inv)
+inline I3 grid_index_from_point(const V3& p, float inv) {
+  return {static_cast<int64_t>(std::floor(p.x * inv + kCoordinateEpsilon)),
+          static_cast<int64_t>(std::floor(p.y * inv + kCoordinateEpsilon)),
+          static_cast<int64_t>(std::floor(p.z * inv + kCoordinateEpsilon))};
+}
+// [V:core/common.h] getGridIndexFromPoint(scaled_point)
+inline I3 grid_index_from_scaled_point(const V3& p) {
+  return {static_cast<int64_t>(std::floor(p.x + kCoordinateEpsilon)),
+          static_cast<int64_t>(std::floor(p.y + kCoordinateEpsilon)),
+          static_cast<int64_t>(std::floor(p.z + kCoordinateEpsilon))};
+}
+// [V:core/common.h] getCenterPointFromGridIndex: (float(i) + 0.5) * grid_size, evaluated in
+// double (0.5 is a double literal) and rounded to float on construction of the Point.
+inline V3 center_point_from_grid_index(const I3& i, float grid_size) {
+  return {static_cast<float>((static_cast<double>(static_cast<float>(i.x)) + 0.5) * static_cast<double>(grid_size)),
+          static_cast<float>((static_cast<double>(static_cast<float>(i.y)) + 0.5) * static_cast<double>(grid_size)),
+          static_cast<float>((static_cast<double>(static_cast<float>(i.z)) + 0.5) * static_cast<double>(grid_size))};
+}
+// [V:core/common.h] getBlockIndexFromGlobalVoxelIndex: floor(float(v) * vps_inv)
+inline B3 block_index_from_global_voxel_index(const I3& v, float vps_inv) {
+  return {static_cast<int32_t>(std::floor(static_cast<float>(v.x) * vps_inv)),
+          static_cast<int32_t>(std::floor(static_cast<float>(v.y) * vps_inv)),
+          static_cast<int32_t>(std::floor(static_cast<float>(v.z) * vps_inv))};
+}
+// [V:core/common.h] getLocalFromGlobalVoxelIndex: v & (vps-1) per axis (vps power of two)
+inline size_t local_linear_index(const I3& v, int vps) {
+  const int64_t m = vps - 1;
+  const int64_t lx = v.x & m, ly = v.y & m, lz = v.z & m;
+  return static_cast<size_t>(lx + vps * (ly + vps * lz));  // [V:core/block_inl.h]
+}
+
+// [V:core/color.h] Color::blendTwoColors
+inline Rgba blend_two_colors(const Rgba& c1, float w1, const Rgba& c2, float w2) {
+  const float total = w1 + w2;
+  w1 /= total;
+  w2 /= total;
+  Rgba o;
+  o.r = static_cast<uint8_t>(std::round(c1.r * w1 + c2.r * w2));
+  o.g = static_cast<uint8_t>(std::round(c1.g * w1 + c2.g * w2));
+  o.b = static_cast<uint8_t>(std::round(c1.b * w1 + c2.b * w2));
+  o.a = static_cast<uint8_t>(std::round(c1.a * w1 + c2.a * w2));
+  return o;
+}
+
+// [V:core/color.h] rainbowColorMap(double h)
+inline Rgba rainbow_color_map(double h) {
+  Rgba c;
+  c.a = 255;
+  const double s = 1.0, v = 1.0;
+  h -= std::floor(h);
+  h *= 6;
+  const int i = static_cast<int>(std::floor(h));
+  double f = h - i;
+  if (!(i & 1)) f = 1 - f;
+  const double m = v * (1 - s);
+  const double n = v * (1 - s * f);
+  switch (i) {
+    case 6:
+    case 0: c.r = static_cast<uint8_t>(255 * v); c.g = static_cast<uint8_t>(255 * n); c.b = static_cast<uint8_t>(255 * m); break;
+    case 1: c.r = static_cast<uint8_t>(255 * n); c.g = static_cast<uint8_t>(255 * v); c.b = static_cast<uint8_t>(255 * m); break;
+    case 2: c.r = static_cast<uint8_t>(255 * m); c.g = static_cast<uint8_t>(255 * v); c.b = static_cast<uint8_t>(255 * n); break;
+    case 3: c.r = static_cast<uint8_t>(255 * m); c.g = static_cast<uint8_t>(255 * n); c.b = static_cast<uint8_t>(255 * v); break;
+    case 4: c.r = static_cast<uint8_t>(255 * n); c.g = static_cast<uint8_t>(255 * m); c.b = static_cast<uint8_t>(255 * v); break;
+    case 5: c.r = static_cast<uint8_t>(255 * v); c.g = static_cast<uint8_t>(255 * m); c.b = static_cast<uint8_t>(255 * n); break;
+    default: c.r = 255; c.g = 127; c.b = 127; break;
+  }
+  return c;
+}
+
+// ---------------------------------------------------------------------------------------
+// RayCaster [V:integrator/integrator_utils.{h,cc}]
+// ---------------------------------------------------------------------------------------
+inline int signum(float v) { return (0.0f < v) - (v < 0.0f); }
+
+struct RayCaster {
+  I3 curr;
+  int sign[3];
+  float t_to_next[3];
+  float t_step[3];
+  int64_t current_step = 0;
+  int64_t length_in_steps = 0;
+
+  RayCaster(const V3& origin, const V3& point_G, bool is_clearing, bool carving,
+            float max_ray_length_m, float voxel_size_inv, float truncation,
+            bool cast_from_origin = true) {
+    const V3 d = sub(point_G, origin);
+    const V3 unit_ray = normalized(d);
+    V3 ray_start, ray_end;
+    if (is_clearing) {
+      float ray_length = norm(d);
+      ray_length = std::min(std::max(ray_length - truncation, 0.0f), max_ray_length_m);
+      ray_end = add(origin, mul(unit_ray, ray_length));
+      ray_start = carving ? origin : ray_end;
+    } else {
+      ray_end = add(point_G, mul(unit_ray, truncation));
+      ray_start = carving ? origin : sub(point_G, mul(unit_ray, truncation));
+    }
+    const V3 start_scaled = mul(ray_start, voxel_size_inv);
+    const V3 end_scaled = mul(ray_end, voxel_size_inv);
+    if (cast_from_origin) setup(start_scaled, end_scaled);
+    else setup(end_scaled, start_scaled);
+  }
+
+  void setup(const V3& start_scaled, const V3& end_scaled) {
+    if (std::isnan(start_scaled.x) || std::isnan(start_scaled.y) || std::isnan(start_scaled.z) ||
+        std::isnan(end_scaled.x) || std::isnan(end_scaled.y) || std::isnan(end_scaled.z)) {
+      length_in_steps = 0;
+      // upstream leaves curr_index_ uninitialised here and still emits one index; the
+      // oracle pins it to 0 (callers never pass NaN points: they are dropped upstream of
+      // integratePointCloud).
+      curr = {0, 0, 0};
+      sign[0] = sign[1] = sign[2] = 0;
+      t_to_next[0] = t_to_next[1] = t_to_next[2] = 0.f;
+      t_step[0] = t_step[1] = t_step[2] = 0.f;
+      return;
+    }
+    curr = grid_index_from_scaled_point(start_scaled);
+    const I3 end_index = grid_index_from_scaled_point(end_scaled);
+    const int64_t dx = end_index.x - curr.x, dy = end_index.y - curr.y, dz = end_index.z - curr.z;
+    current_step = 0;
+    length_in_steps = std::abs(dx) + std::abs(dy) + std::abs(dz);
+    const V3 ray_scaled = sub(end_scaled, start_scaled);
+    sign[0] = signum(ray_scaled.x);
+    sign[1] = signum(ray_scaled.y);
+    sign[2] = signum(ray_scaled.z);
+    const float corr[3] = {static_cast<float>(std::max(0, sign[0])), static_cast<float>(std::max(0, sign[1])),
+                           static_cast<float>(std::max(0, sign[2]))};
+    const V3 shifted = {start_scaled.x - static_cast<float>(curr.x), start_scaled.y - static_cast<float>(curr.y),
+                        start_scaled.z - static_cast<float>(curr.z)};
+    const float dist[3] = {corr[0] - shifted.x, corr[1] - shifted.y, corr[2] - shifted.z};
+    const float rs[3] = {ray_scaled.x, ray_scaled.y, ray_scaled.z};
+    for (int k = 0; k < 3; ++k) {
+      // upstream: (std::abs(r) < 0.0) ? 2.0 : dist / r  — the guard is dead code, so a zero
+      // component divides by zero (inf / NaN) exactly like upstream.
+      t_to_next[k] = dist[k] / rs[k];
+      t_step[k] = static_cast<float>(sign[k]) / rs[k];
+    }
+  }
+
+  bool next(I3* out) {
+    if (current_step++ > length_in_steps) return false;
+    *out = curr;
+    // [E:Core/Visitor.h] minCoeff(&idx): first strict minimum, NaN never replaces.
+    int k = 0;
+    float m = t_to_next[0];
+    if (t_to_next[1] < m) { k = 1; m = t_to_next[1]; }
+    if (t_to_next[2] < m) { k = 2; }
+    if (k == 0) curr.x += sign[0];
+    else if (k == 1) curr.y += sign[1];
+    else curr.z += sign[2];
+    t_to_next[k] += t_step[k];
+    return true;
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// ApproxHashSet<20, 10000, GlobalIndex, LongIndexHash> [V:utils/approx_hash_array.h]
+// ---------------------------------------------------------------------------------------
+struct ApproxHashSet {
+  static constexpr size_t kBits = 20;            // [K:semantic_tsdf_integrator_fast.h:102]
+  static constexpr size_t kFullReset = 10000;    // [K:semantic_tsdf_integrator_fast.h:107]
+  static constexpr size_t kMask = (size_t(1) << kBits) - 1;
+  std::vector<std::atomic<size_t>> slots;
+  size_t offset = 0;
+  ApproxHashSet() : slots(size_t(1) << kBits) {
+    for (auto& s : slots) s.store(0, std::memory_order_relaxed);
+    slots[offset].store(std::numeric_limits<size_t>::max(), std::memory_order_relaxed);
+  }
+  // returns true if the hash was NOT present (and is now stored)
+  bool replace_hash(size_t hash) {
+    const size_t idx = (hash + offset) & kMask;
+    if (slots[idx].load(std::memory_order_relaxed) == hash + offset) return false;
+    slots[idx].store(hash + offset, std::memory_order_relaxed);
+    return true;
+  }
+  void reset() {
+    if (++offset >= kFullReset) {
+      for (auto& s : slots) s.store(0, std::memory_order_relaxed);
+      offset = 0;
+      slots[offset].store(std::numeric_limits<size_t>::max(), std::memory_order_relaxed);
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// Layer / Block [V:core/layer.h, core/block.h]
+// ---------------------------------------------------------------------------------------
+template <typename Voxel>
+struct Block {
+  std::vector<Voxel> voxels;
+  bool updated = false;
+  explicit Block(int vps) : voxels(static_cast<size_t>(vps) * vps * vps) {}
+};
+template <typename Voxel>
+struct Layer {
+  using BlockPtr = std::shared_ptr<Block<Voxel>>;
+  using Map = std::unordered_map<B3, BlockPtr, AnyIndexHash>;
+  Map blocks;
+  BlockPtr get(const B3& idx) const {
+    auto it = blocks.find(idx);
+    return it == blocks.end() ? nullptr : it->second;
+  }
+};
+
+// [V:integrator/integrator_utils.h] ThreadSafeIndex ("mixed" / "sorted")
+struct IndexGetter {
+  std::atomic<size_t> atomic_idx{0};
+  size_t n = 0;
+  bool sorted = false;
+  std::vector<size_t> sorted_indices;
+  static constexpr size_t kGroups = 1024;
+
+  static size_t mixed_index(size_t s, size_t n) {
+    const size_t per_group = n / kGroups;
+    if (kGroups * per_group <= s) return s;
+    return (s % kGroups) * per_group + s / kGroups;
+  }
+  void init(int mode, const float* xyz, size_t num) {
+    n = num;
+    sorted = (mode == KO_ORDER_SORTED);
+    if (sorted) {
+      // upstream uses std::sort on (idx, squaredNorm) by norm; ties are unspecified
+      // there — the oracle breaks ties by ascending index (stable).
+      std::vector<std::pair<float, size_t>> v(num);
+      for (size_t i = 0; i < num; ++i) {
+        const V3 p = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        v[i] = {squared_norm(p), i};
+      }
+      std::stable_sort(v.begin(), v.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+      sorted_indices.resize(num);
+      for (size_t i = 0; i < num; ++i) sorted_indices[i] = v[i].second;
+    }
+  }
+  bool next(size_t* idx) {
+    const size_t s = atomic_idx.fetch_add(1);
+    if (s >= n) return false;
+    *idx = sorted ? sorted_indices[s] : mixed_index(s, n);
+    return true;
+  }
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// The integrator context
+// ---------------------------------------------------------------------------------------
+struct ko_ctx {
+  ko_config cfg;
+  std::string err;
+
+  // cached geometry [V:TsdfIntegratorBase::setLayer], [K:semantic_integrator_base.cpp:78-91]
+  float voxel_size, block_size, voxel_size_inv, vps_inv;
+  int vps;
+
+  Layer<TsdfVoxel> tsdf_layer;
+  Layer<SemanticVoxel> semantic_layer;
+  Layer<TsdfVoxel>::Map temp_tsdf;
+  Layer<SemanticVoxel>::Map temp_sem;
+  std::mutex temp_tsdf_mutex, temp_sem_mutex;
+  std::vector<std::mutex> mutexes{4096};  // ApproxHashArray<12, std::mutex, ...> [K:semantic_integrator_base.h:64-66]
+
+  float log_match, log_non_match;
+  float L[kNumLabels][kNumLabels];  // L[i][j]: row i = voxel label, column j = measured label
+
+  ApproxHashSet start_voxel_set, voxel_observed_set;
+  int64_t reset_counter = 0;  // function-static in the reference (fast.cpp:165); per-context here
+
+  std::atomic<uint64_t> n_updates{0};
+  std::atomic<uint64_t> n_rays{0};
+  std::atomic<uint64_t> n_valid{0};
+
+  // ---- [K:semantic_integrator_base.cpp:93-128] setSemanticProbabilities ----
+  bool set_semantic_probabilities() {
+    const float match = cfg.semantic_measurement_probability;
+    const float non_match = 1.0f - cfg.semantic_measurement_probability;
+    if (!(match > 0.0f) || !(non_match > 0.0f) || !(match < 1.0f) || !(non_match < 1.0f)) {
+      err = "semantic_measurement_probability must be in (0,1)";
+      return false;
+    }
+    log_match = std::log(match);          // std::log(float) -> logf
+    log_non_match = std::log(non_match);
+    if (!(log_match > log_non_match)) {
+      err = "Your probabilities do not make sense (log p <= log(1-p))";
+      return false;
+    }
+    for (int i = 0; i < kNumLabels; ++i)
+      for (int j = 0; j < kNumLabels; ++j) L[i][j] = (i == j) ? log_match : log_non_match;
+    for (int i = 0; i < kNumLabels; ++i) L[i][0] = 0.0f;  // .col(kUnknownSemanticLabelId).setZero()
+    return true;
+  }
+
+  // ---- [V:tsdf_integrator.cc] ----
+  bool is_point_valid(const V3& p, bool freespace, bool* is_clearing) const {
+    const float ray_distance = norm(p);
+    if (ray_distance < cfg.min_ray_length_m) return false;
+    if (ray_distance > cfg.max_ray_length_m) {
+      if (cfg.allow_clear || freespace) {
+        *is_clearing = true;
+        return true;
+      }
+      return false;
+    }
+    *is_clearing = freespace;
+    return true;
+  }
+  float get_voxel_weight(const V3& p) const {
+    if (cfg.use_const_weight) return 1.0f;
+    const float dist_z = std::abs(p.z);
+    if (dist_z > kEpsilon) return 1.0f / (dist_z * dist_z);
+    return 0.0f;
+  }
+  bool is_semantic_label_valid(uint8_t label) const {  // [K:semantic_integrator_base.h:170-175]
+    for (int i = 0; i < cfg.n_dynamic_labels; ++i)
+      if (cfg.dynamic_labels[i] == label) return false;
+    return true;
+  }
+  std::mutex& mutex_for(const I3& v) { return mutexes[index_hash(v.x, v.y, v.z) & 4095]; }
+
+  static float compute_distance(const V3& origin, const V3& point_G, const V3& voxel_center) {
+    const V3 v_voxel_origin = sub(voxel_center, origin);
+    const V3 v_point_origin = sub(point_G, origin);
+    const float dist_G = norm(v_point_origin);
+    const float dist_G_V = dot(v_voxel_origin, v_point_origin) / dist_G;
+    return dist_G - dist_G_V;
+  }
+
+  // [V:tsdf_integrator.cc] TsdfIntegratorBase::updateTsdfVoxel (lock taken by caller)
+  static void update_tsdf_voxel_nolock(const ko_config& c, float voxel_size, const V3& origin,
+                                       const V3& point_G, const I3& v, const Rgba& color,
+                                       float weight, TsdfVoxel* voxel) {
+    const V3 center = center_point_from_grid_index(v, voxel_size);
+    const float sdf = compute_distance(origin, point_G, center);
+    float updated_weight = weight;
+    const float dropoff_epsilon = voxel_size;
+    if (c.use_weight_dropoff && sdf < -dropoff_epsilon) {
+      updated_weight = weight * (c.truncation_distance + sdf) / (c.truncation_distance - dropoff_epsilon);
+      updated_weight = std::max(updated_weight, 0.0f);
+    }
+    if (c.use_sparsity_compensation_factor) {
+      if (std::abs(sdf) < c.truncation_distance) updated_weight *= c.sparsity_compensation_factor;
+    }
+    const float new_weight = voxel->weight + updated_weight;
+    if (new_weight < kFloatEpsilon) return;
+    const float new_sdf = (sdf * updated_weight + voxel->distance * voxel->weight) / new_weight;
+    if (std::abs(sdf) < c.truncation_distance) {
+      voxel->color = blend_two_colors(voxel->color, voxel->weight, color, updated_weight);
+    }
+    voxel->distance = (new_sdf > 0.0f) ? std::min(c.truncation_distance, new_sdf)
+                                        : std::max(-c.truncation_distance, new_sdf);
+    voxel->weight = std::min(c.max_weight, new_weight);
+  }
+
+  // [K:semantic_integrator_base.cpp:136-194] updateSemanticVoxel (lock taken by caller)
+  void update_semantic_voxel_nolock(const float* freq, TsdfVoxel* tsdf_voxel, SemanticVoxel* sv) const {
+    // [K:...:283-314] priors += L * freq.  Eigen's fixed-size GEMV association is
+    // version-dependent; the oracle pins it: j ascending, no FMA,
+    // product evaluated into a temporary and then added.
+    for (int i = 0; i < kNumLabels; ++i) {
+      float acc = 0.0f;
+      for (int j = 0; j < kNumLabels; ++j) acc += L[i][j] * freq[j];
+      sv->semantic_priors[i] += acc;
+    }
+    // [K:...:352-367] maxCoeff: first strict maximum
+    int best = 0;
+    float m = sv->semantic_priors[0];
+    for (int i = 1; i < kNumLabels; ++i)
+      if (sv->semantic_priors[i] > m) { m = sv->semantic_priors[i]; best = i; }
+    sv->semantic_label = static_cast<uint8_t>(best);
+    // [K:...:370-380] label -> colour
+    const uint8_t* c = cfg.label_rgba[sv->semantic_label];
+    sv->color = {c[0], c[1], c[2], c[3]};
+    switch (cfg.color_mode) {  // [K:...:174-191]
+      case KO_COLOR_MODE_COLOR: break;
+      case KO_COLOR_MODE_SEMANTIC: tsdf_voxel->color = sv->color; break;
+      case KO_COLOR_MODE_SEMANTIC_PROBABILITY:
+        tsdf_voxel->color = rainbow_color_map(std::exp(sv->semantic_priors[sv->semantic_label]));
+        break;
+      default: break;
+    }
+  }
+
+  // [V:tsdf_integrator.cc allocateStorageAndGetVoxelPtr] / [K:semantic_integrator_base.cpp:205-254]
+  template <typename Voxel>
+  Voxel* allocate_and_get(const I3& v, Layer<Voxel>& layer, typename Layer<Voxel>::Map& temp,
+                          std::mutex& temp_mutex, std::shared_ptr<Block<Voxel>>* last_block,
+                          B3* last_idx) {
+    const B3 block_idx = block_index_from_global_voxel_index(v, vps_inv);
+    if (block_idx != *last_idx || *last_block == nullptr) {
+      *last_block = layer.get(block_idx);
+      *last_idx = block_idx;
+    }
+    if (*last_block == nullptr) {
+      std::lock_guard<std::mutex> lock(temp_mutex);
+      auto it = temp.find(block_idx);
+      if (it != temp.end()) {
+        *last_block = it->second;
+      } else {
+        auto ins = temp.emplace(block_idx, std::make_shared<Block<Voxel>>(vps));
+        *last_block = ins.first->second;
+      }
+    }
+    (*last_block)->updated = true;
+    return &(*last_block)->voxels[local_linear_index(v, vps)];
+  }
+  uint64_t insert_temp_blocks() {  // updateLayerWithStoredBlocks + updateSemanticLayerWithStoredBlocks
+    const uint64_t n = temp_tsdf.size();
+    for (auto& kv : temp_tsdf) tsdf_layer.blocks.insert(kv);
+    temp_tsdf.clear();
+    for (auto& kv : temp_sem) semantic_layer.blocks.insert(kv);
+    temp_sem.clear();
+    return n;
+  }
+
+  // per-(ray,voxel) body shared by fast and merged:
+  // [K:fast.cpp:124-140], [K:merged.cpp:315-327]
+  struct BlockCache {
+    std::shared_ptr<Block<TsdfVoxel>> block;
+    B3 block_idx{0, 0, 0};
+    std::shared_ptr<Block<SemanticVoxel>> sem_block;
+    B3 sem_block_idx{0, 0, 0};
+  };
+  void update_voxel(const V3& origin, const V3& point_G, const I3& v, const Rgba& color, float weight,
+                    const float* freq, BlockCache* bc) {
+    TsdfVoxel* voxel = allocate_and_get<TsdfVoxel>(v, tsdf_layer, temp_tsdf, temp_tsdf_mutex, &bc->block, &bc->block_idx);
+    {
+      std::lock_guard<std::mutex> lock(mutex_for(v));
+      update_tsdf_voxel_nolock(cfg, voxel_size, origin, point_G, v, color, weight, voxel);
+    }
+    SemanticVoxel* sv = allocate_and_get<SemanticVoxel>(v, semantic_layer, temp_sem, temp_sem_mutex, &bc->sem_block, &bc->sem_block_idx);
+    {
+      std::lock_guard<std::mutex> lock(mutex_for(v));
+      update_semantic_voxel_nolock(freq, voxel, sv);
+    }
+  }
+
+  // ---- fast: [K:semantic_tsdf_integrator_fast.cpp:57-143] ----
+  void integrate_semantic_function(const Transform& T, const float* xyz, const uint8_t* rgba,
+                                   const uint8_t* labels, bool freespace, IndexGetter* getter) {
+    size_t point_idx;
+    uint64_t updates = 0, rays = 0, valid = 0;
+    while (getter->next(&point_idx)) {
+      const V3 point_C = {xyz[3 * point_idx], xyz[3 * point_idx + 1], xyz[3 * point_idx + 2]};
+      const Rgba color = rgba ? Rgba{rgba[4 * point_idx], rgba[4 * point_idx + 1], rgba[4 * point_idx + 2], rgba[4 * point_idx + 3]}
+                              : Rgba{0, 0, 0, 0};
+      const uint8_t label = labels[point_idx];
+      bool is_clearing;
+      if (!is_point_valid(point_C, freespace, &is_clearing) || !is_semantic_label_valid(label)) continue;
+      ++valid;
+      const V3 origin = T.t;
+      const V3 point_G = transform_point(T, point_C);
+      I3 gvi = grid_index_from_point(point_G, cfg.start_voxel_subsampling_factor * voxel_size_inv);
+      if (!start_voxel_set.replace_hash(LongIndexHash()(gvi))) continue;
+      ++rays;
+      RayCaster caster(origin, point_G, is_clearing, cfg.voxel_carving_enabled != 0, cfg.max_ray_length_m,
+                       voxel_size_inv, cfg.truncation_distance, /*cast_from_origin=*/false);
+      int64_t consecutive = 0;
+      BlockCache bc;
+      while (caster.next(&gvi)) {
+        if (!voxel_observed_set.replace_hash(LongIndexHash()(gvi))) ++consecutive;
+        else consecutive = 0;
+        if (consecutive > cfg.max_consecutive_ray_collisions) break;
+        const float weight = get_voxel_weight(point_C);
+        float freq[kNumLabels];
+        for (int i = 0; i < kNumLabels; ++i) freq[i] = 0.0f;
+        freq[label] += 1.0f;
+        update_voxel(origin, point_G, gvi, color, weight, freq, &bc);
+        ++updates;
+      }
+    }
+    n_updates += updates;
+    n_rays += rays;
+    n_valid += valid;
+  }
+
+  // [K:semantic_tsdf_integrator_fast.cpp:145-199]
+  void integrate_fast(const Transform& T, const float* xyz, const uint8_t* rgba, const uint8_t* labels,
+                      size_t n, bool freespace) {
+    if ((++reset_counter) >= cfg.clear_checks_every_n_frames) {
+      reset_counter = 0;
+      start_voxel_set.reset();
+      voxel_observed_set.reset();
+    }
+    IndexGetter getter;
+    getter.init(cfg.integration_order_mode, xyz, n);
+    const int threads = std::max(1, cfg.integrator_threads);
+    if (threads == 1) {
+      integrate_semantic_function(T, xyz, rgba, labels, freespace, &getter);
+    } else {
+      std::list<std::thread> pool;
+      for (int i = 0; i < threads; ++i)
+        pool.emplace_back(&ko_ctx::integrate_semantic_function, this, T, xyz, rgba, labels, freespace, &getter);
+      for (auto& t : pool) t.join();
+    }
+  }
+
+  // ---- merged ----
+  using VoxelMap = std::unordered_map<I3, std::vector<size_t>, LongIndexHash>;  // [K:common.h:37]
+  struct Bundle {
+    I3 key;
+    const std::vector<size_t>* pts;
+  };
+
+  // [V:tsdf_integrator.cc MergedTsdfIntegrator::bundleRays]
+  void bundle_rays(const Transform& T, const float* xyz, bool freespace, IndexGetter* getter,
+                   VoxelMap* voxel_map, VoxelMap* clear_map, std::vector<I3>* voxel_order,
+                   std::vector<I3>* clear_order) {
+    size_t point_idx;
+    uint64_t valid = 0;
+    while (getter->next(&point_idx)) {
+      const V3 point_C = {xyz[3 * point_idx], xyz[3 * point_idx + 1], xyz[3 * point_idx + 2]};
+      bool is_clearing;
+      if (!is_point_valid(point_C, freespace, &is_clearing)) continue;
+      ++valid;
+      const V3 point_G = transform_point(T, point_C);
+      const I3 key = grid_index_from_point(point_G, voxel_size_inv);
+      VoxelMap* m = is_clearing ? clear_map : voxel_map;
+      std::vector<I3>* order = is_clearing ? clear_order : voxel_order;
+      auto& vec = (*m)[key];
+      if (vec.empty()) order->push_back(key);  // first insertion (CANONICAL order)
+      vec.push_back(point_idx);
+    }
+    n_valid += valid;
+  }
+
+  // [K:semantic_tsdf_integrator_merged.cpp:235-329]
+  void integrate_voxel(const Transform& T, const float* xyz, const uint8_t* rgba, const uint8_t* labels,
+                       bool enable_anti_grazing, bool clearing_ray, const I3& key,
+                       const std::vector<size_t>& pts, const VoxelMap& voxel_map) {
+    if (pts.empty()) return;
+    const V3 origin = T.t;
+    Rgba merged_color = {0, 0, 0, 0};
+    V3 merged_point_C = {0.f, 0.f, 0.f};
+    float merged_weight = 0.0f;
+    float freq[kNumLabels];
+    for (int i = 0; i < kNumLabels; ++i) freq[i] = 0.0f;
+    for (const size_t pt_idx : pts) {
+      const V3 point_C = {xyz[3 * pt_idx], xyz[3 * pt_idx + 1], xyz[3 * pt_idx + 2]};
+      const Rgba color = rgba ? Rgba{rgba[4 * pt_idx], rgba[4 * pt_idx + 1], rgba[4 * pt_idx + 2], rgba[4 * pt_idx + 3]}
+                              : Rgba{0, 0, 0, 0};
+      const float point_weight = get_voxel_weight(point_C);
+      if (point_weight < kEpsilon) continue;
+      const float denom = merged_weight + point_weight;
+      merged_point_C.x = (merged_point_C.x * merged_weight + point_C.x * point_weight) / denom;
+      merged_point_C.y = (merged_point_C.y * merged_weight + point_C.y * point_weight) / denom;
+      merged_point_C.z = (merged_point_C.z * merged_weight + point_C.z * point_weight) / denom;
+      merged_color = blend_two_colors(merged_color, merged_weight, color, point_weight);
+      merged_weight += point_weight;
+      freq[labels[pt_idx]] += 1.0f;
+      if (clearing_ray) break;
+    }
+    const V3 merged_point_G = transform_point(T, merged_point_C);
+    RayCaster caster(origin, merged_point_G, clearing_ray, cfg.voxel_carving_enabled != 0,
+                     cfg.max_ray_length_m, voxel_size_inv, cfg.truncation_distance);
+    I3 gvi;
+    BlockCache bc;
+    uint64_t updates = 0;
+    while (caster.next(&gvi)) {
+      if (enable_anti_grazing) {
+        if ((clearing_ray || gvi != key) && voxel_map.find(gvi) != voxel_map.end()) continue;
+      }
+      update_voxel(origin, merged_point_G, gvi, merged_color, merged_weight, freq, &bc);
+      ++updates;
+    }
+    n_updates += updates;
+    ++n_rays;
+  }
+
+  // [K:semantic_tsdf_integrator_merged.cpp:151-232] integrateRays/integrateVoxels
+  void integrate_rays(const Transform& T, const float* xyz, const uint8_t* rgba, const uint8_t* labels,
+                      bool clearing_ray, const VoxelMap& voxel_map, const VoxelMap& clear_map,
+                      const std::vector<I3>& voxel_order, const std::vector<I3>& clear_order) {
+    const VoxelMap& m = clearing_ray ? clear_map : voxel_map;
+    std::vector<Bundle> bundles;
+    bundles.reserve(m.size());
+    if (cfg.bundle_order == KO_BUNDLE_ORDER_REFERENCE) {
+      for (const auto& kv : m) bundles.push_back({kv.first, &kv.second});
+    } else {
+      const std::vector<I3>& order = clearing_ray ? clear_order : voxel_order;
+      for (const I3& k : order) bundles.push_back({k, &m.find(k)->second});
+    }
+    const size_t threads = static_cast<size_t>(std::max(1, cfg.integrator_threads));
+    auto worker = [&](size_t thread_idx) {
+      for (size_t i = 0; i < bundles.size(); ++i) {
+        if (((i + thread_idx + 1) % threads) == 0u) {
+          integrate_voxel(T, xyz, rgba, labels, cfg.enable_anti_grazing != 0, clearing_ray,
+                          bundles[i].key, *bundles[i].pts, voxel_map);
+        }
+      }
+    };
+    if (threads == 1) {
+      worker(0);
+    } else {
+      std::list<std::thread> pool;
+      for (size_t i = 0; i < threads; ++i) pool.emplace_back(worker, i);
+      for (auto& t : pool) t.join();
+    }
+  }
+
+  // [K:semantic_tsdf_integrator_merged.cpp:97-149]
+  uint64_t integrate_merged(const Transform& T, const float* xyz, const uint8_t* rgba, const uint8_t* labels,
+                            size_t n, bool freespace) {
+    VoxelMap voxel_map, clear_map;
+    std::vector<I3> voxel_order, clear_order;
+    IndexGetter getter;
+    getter.init(cfg.integration_order_mode, xyz, n);
+    bundle_rays(T, xyz, freespace, &getter, &voxel_map, &clear_map, &voxel_order, &clear_order);
+    integrate_rays(T, xyz, rgba, labels, false, voxel_map, clear_map, voxel_order, clear_order);
+    uint64_t new_blocks = insert_temp_blocks();
+    integrate_rays(T, xyz, rgba, labels, true, voxel_map, clear_map, voxel_order, clear_order);
+    new_blocks += insert_temp_blocks();
+    return new_blocks;
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+// C API
+// ---------------------------------------------------------------------------------------
+template <typename Map>
+static void sorted_indices(const Map& m, int32_t* out) {
+  std::vector<B3> v;
+  v.reserve(m.size());
+  for (const auto& kv : m) v.push_back(kv.first);
+  std::sort(v.begin(), v.end(), [](const B3& a, const B3& b) {
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    return a.z < b.z;
+  });
+  for (size_t i = 0; i < v.size(); ++i) {
+    out[3 * i] = v[i].x;
+    out[3 * i + 1] = v[i].y;
+    out[3 * i + 2] = v[i].z;
+  }
+}
+extern "C" {
+
+void ko_default_config(ko_config* c) {
+  std::memset(c, 0, sizeof(*c));
+  // [V:TsdfIntegratorBase::Config], [V:voxblox_ros/ros_params.h]
+  c->voxel_size = 0.05f;
+  c->voxels_per_side = 16;
+  c->truncation_distance = 4 * 0.05f;
+  c->max_weight = 10000.0f;
+  c->min_ray_length_m = 0.1f;
+  c->max_ray_length_m = 5.0f;
+  c->voxel_carving_enabled = 1;
+  c->use_const_weight = 0;
+  c->allow_clear = 1;
+  c->use_weight_dropoff = 1;
+  c->use_sparsity_compensation_factor = 0;
+  c->sparsity_compensation_factor = 1.0f;
+  c->enable_anti_grazing = 0;
+  c->start_voxel_subsampling_factor = 2.0f;
+  c->max_consecutive_ray_collisions = 2;
+  c->clear_checks_every_n_frames = 1;
+  c->integration_order_mode = KO_ORDER_MIXED;
+  c->integrator_threads = 1;
+  c->method = KO_METHOD_FAST;
+  c->bundle_order = KO_BUNDLE_ORDER_CANONICAL;
+  c->semantic_measurement_probability = 0.9f;  // [K:semantic_integrator_base.h:77]
+  c->color_mode = KO_COLOR_MODE_SEMANTIC;      // [K:semantic_integrator_base.h:80]
+  c->n_dynamic_labels = 0;
+}
+
+int ko_create(const ko_config* cfg, ko_ctx** out) {
+  if (!cfg || !out) return -1;
+  auto* ctx = new ko_ctx();
+  ctx->cfg = *cfg;
+  const int vps = cfg->voxels_per_side;
+  if (vps <= 0 || (vps & (vps - 1)) != 0) {
+    delete ctx;
+    return -1;
+  }
+  ctx->vps = vps;
+  ctx->voxel_size = cfg->voxel_size;
+  ctx->block_size = cfg->voxel_size * static_cast<float>(vps);        // [V:core/layer.h]
+  ctx->voxel_size_inv = static_cast<float>(1.0 / cfg->voxel_size);    // [V:TsdfIntegratorBase::setLayer]
+  ctx->vps_inv = static_cast<float>(1.0 / static_cast<double>(vps));
+  if (!ctx->set_semantic_probabilities()) {
+    delete ctx;
+    return -3;
+  }
+  *out = ctx;
+  return 0;
+}
+
+void ko_destroy(ko_ctx* ctx) { delete ctx; }
+const char* ko_last_error(ko_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int ko_integrate_points(ko_ctx* ctx, const float Tq[7], const float* xyz, const uint8_t* rgba,
+                        const uint8_t* labels, size_t n, int freespace, ko_frame_stats* stats) {
+  if (!ctx || !Tq || (n && (!xyz || !labels))) return -1;
+  for (size_t i = 0; i < n; ++i) {
+    if (labels[i] >= kNumLabels) {  // CHECK_LT(label, 21) [K:fast.cpp:134], [K:merged.cpp:278]
+      ctx->err = "semantic label >= 21";
+      return -2;
+    }
+  }
+  Transform T;
+  T.w = Tq[0];
+  T.v = {Tq[1], Tq[2], Tq[3]};
+  T.t = {Tq[4], Tq[5], Tq[6]};
+  ctx->n_updates = 0;
+  ctx->n_rays = 0;
+  ctx->n_valid = 0;
+  uint64_t new_blocks = 0;
+  if (ctx->cfg.method == KO_METHOD_FAST) {
+    ctx->integrate_fast(T, xyz, rgba, labels, n, freespace != 0);
+    new_blocks = ctx->insert_temp_blocks();
+  } else {
+    new_blocks = ctx->integrate_merged(T, xyz, rgba, labels, n, freespace != 0);
+  }
+  if (stats) {
+    stats->n_points = n;
+    stats->n_valid_points = ctx->n_valid;
+    stats->n_rays_cast = ctx->n_rays;
+    stats->n_voxel_updates = ctx->n_updates;
+    stats->n_blocks_allocated = new_blocks;
+  }
+  return 0;
+}
+
+size_t ko_num_blocks(ko_ctx* ctx) { return ctx->tsdf_layer.blocks.size(); }
+size_t ko_num_semantic_blocks(ko_ctx* ctx) { return ctx->semantic_layer.blocks.size(); }
+
+void ko_get_block_indices(ko_ctx* ctx, int32_t* out) { sorted_indices(ctx->tsdf_layer.blocks, out); }
+void ko_get_semantic_block_indices(ko_ctx* ctx, int32_t* out) { sorted_indices(ctx->semantic_layer.blocks, out); }
+
+int ko_get_block(ko_ctx* ctx, const int32_t idx[3], void* tsdf_out, void* sem_out) {
+  const B3 b = {idx[0], idx[1], idx[2]};
+  const size_t nvox = static_cast<size_t>(ctx->vps) * ctx->vps * ctx->vps;
+  int absent = 0;
+  if (tsdf_out) {
+    auto blk = ctx->tsdf_layer.get(b);
+    if (blk) {
+      std::memcpy(tsdf_out, blk->voxels.data(), nvox * sizeof(TsdfVoxel));
+    } else {
+      absent = 1;
+      TsdfVoxel d;
+      for (size_t i = 0; i < nvox; ++i) std::memcpy(static_cast<char*>(tsdf_out) + i * sizeof(TsdfVoxel), &d, sizeof(d));
+    }
+  }
+  if (sem_out) {
+    auto blk = ctx->semantic_layer.get(b);
+    if (blk) {
+      std::memcpy(sem_out, blk->voxels.data(), nvox * sizeof(SemanticVoxel));
+    } else {
+      absent = 1;
+      SemanticVoxel d;
+      for (size_t i = 0; i < nvox; ++i) std::memcpy(static_cast<char*>(sem_out) + i * sizeof(SemanticVoxel), &d, sizeof(d));
+    }
+  }
+  return absent;
+}
+
+// ---- pure functions for KATs ----
+void ko_transform_point(const float Tq[7], const float p[3], float out[3]) {
+  Transform T;
+  T.w = Tq[0];
+  T.v = {Tq[1], Tq[2], Tq[3]};
+  T.t = {Tq[4], Tq[5], Tq[6]};
+  const V3 r = transform_point(T, {p[0], p[1], p[2]});
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void ko_grid_index_from_point(const float p[3], float inv, int64_t out[3]) {
+  const I3 i = grid_index_from_point({p[0], p[1], p[2]}, inv);
+  out[0] = i.x; out[1] = i.y; out[2] = i.z;
+}
+size_t ko_cast_ray(const float origin[3], const float point_G[3], int is_clearing, int carving,
+                   float max_ray_length_m, float voxel_size_inv, float truncation, int cast_from_origin,
+                   int64_t* out_xyz, size_t cap) {
+  RayCaster c({origin[0], origin[1], origin[2]}, {point_G[0], point_G[1], point_G[2]}, is_clearing != 0,
+              carving != 0, max_ray_length_m, voxel_size_inv, truncation, cast_from_origin != 0);
+  size_t n = 0;
+  I3 v;
+  while (c.next(&v)) {
+    if (n < cap) {
+      out_xyz[3 * n] = v.x; out_xyz[3 * n + 1] = v.y; out_xyz[3 * n + 2] = v.z;
+    }
+    ++n;
+  }
+  return n;
+}
+void ko_log_likelihood(float p_match, float* out) {
+  ko_config c;
+  ko_default_config(&c);
+  c.semantic_measurement_probability = p_match;
+  ko_ctx tmp;
+  tmp.cfg = c;
+  if (!tmp.set_semantic_probabilities()) {
+    for (int i = 0; i < kNumLabels * kNumLabels; ++i) out[i] = std::numeric_limits<float>::quiet_NaN();
+    return;
+  }
+  for (int i = 0; i < kNumLabels; ++i)
+    for (int j = 0; j < kNumLabels; ++j) out[i * kNumLabels + j] = tmp.L[i][j];
+}
+uint32_t ko_long_index_hash(const int64_t idx[3]) { return index_hash(idx[0], idx[1], idx[2]); }
+size_t ko_mixed_index(size_t s, size_t n) { return IndexGetter::mixed_index(s, n); }
+void ko_update_tsdf_voxel(const ko_config* cfg, const float origin[3], const float point_G[3],
+                          const int64_t vi[3], const uint8_t rgba[4], float weight, float* distance,
+                          float* voxel_weight, uint8_t voxel_rgba[4]) {
+  TsdfVoxel v;
+  v.distance = *distance;
+  v.weight = *voxel_weight;
+  v.color = {voxel_rgba[0], voxel_rgba[1], voxel_rgba[2], voxel_rgba[3]};
+  ko_ctx::update_tsdf_voxel_nolock(*cfg, cfg->voxel_size, {origin[0], origin[1], origin[2]},
+                                   {point_G[0], point_G[1], point_G[2]}, {vi[0], vi[1], vi[2]},
+                                   {rgba[0], rgba[1], rgba[2], rgba[3]}, weight, &v);
+  *distance = v.distance;
+  *voxel_weight = v.weight;
+  voxel_rgba[0] = v.color.r; voxel_rgba[1] = v.color.g; voxel_rgba[2] = v.color.b; voxel_rgba[3] = v.color.a;
+}
+void ko_blend_two_colors(const uint8_t c1[4], float w1, const uint8_t c2[4], float w2, uint8_t out[4]) {
+  const Rgba o = blend_two_colors({c1[0], c1[1], c1[2], c1[3]}, w1, {c2[0], c2[1], c2[2], c2[3]}, w2);
+  out[0] = o.r; out[1] = o.g; out[2] = o.b; out[3] = o.a;
+}
+void ko_rainbow_color_map(double h, uint8_t out[4]) {
+  const Rgba o = rainbow_color_map(h);
+  out[0] = o.r; out[1] = o.g; out[2] = o.b; out[3] = o.a;
+}
+
+}  // extern "C"
