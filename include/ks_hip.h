@@ -1,0 +1,151 @@
+/*
+ * ks_hip.h — C ABI of the MI355X-native semantic TSDF integrator (libks_hip.so).
+ *
+ * This is the drop-in boundary underneath the reference's plugin surface.  The only caller
+ * in a Kimera-Semantics deployment is the host adapter class
+ * (kimera_semantics_amd/host/hip_semantic_tsdf_integrator.h) which derives from
+ * voxblox::TsdfIntegratorBase + kimera::SemanticIntegratorBase exactly like the two CPU
+ * integrators it replaces, and is returned by SemanticTsdfIntegratorFactory::create
+ * (kimera_semantics/src/semantic_tsdf_integrator_factory.cpp:43-88).  Plain pointers and
+ * sizes only; no C++/torch types.  One ks_ctx per GPU; a ks_ctx is NOT thread-safe (the
+ * reference calls integratePointCloud from one ROS spinner thread).
+ *
+ * All functions return 0 on success or a negative KS_ERR_* code; ks_last_error() gives
+ * text.  Where the reference would CHECK-abort (glog), the C ABI returns an error and the
+ * adapter turns it back into LOG(FATAL) to preserve the convention.
+ */
+#ifndef KS_HIP_H_
+#define KS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KS_NUM_LABELS 21 /* kimera::kTotalNumberOfLabels, kimera_semantics/include/kimera_semantics/common.h:26 */
+
+enum {
+  KS_OK = 0,
+  KS_ERR_INVALID_ARG = -1,
+  KS_ERR_LABEL_RANGE = -2,   /* label >= 21: CHECK_LT at semantic_tsdf_integrator_fast.cpp:134 / merged.cpp:278 */
+  KS_ERR_PROBABILITY = -3,   /* CHECKs of semantic_integrator_base.cpp:98-107 */
+  KS_ERR_HIP = -4,           /* HIP runtime failure */
+  KS_ERR_POOL_FULL = -5,     /* voxel-tile pool exhausted (raise ks_config.max_tiles) */
+  KS_ERR_INDEX_RANGE = -6,   /* a voxel index left the +-2^23 range the device packs */
+  KS_ERR_NO_DEVICE = -7,
+  KS_ERR_UNSUPPORTED = -8
+};
+
+enum { KS_METHOD_FAST = 0, KS_METHOD_MERGED = 1 };          /* factory names "fast"/"merged", semantic_tsdf_integrator_factory.h:49-54 */
+enum { KS_COLOR_MODE_COLOR = 0, KS_COLOR_MODE_SEMANTIC = 1, KS_COLOR_MODE_SEMANTIC_PROBABILITY = 2 }; /* ColorMode, semantic_integrator_base.h:54-58 */
+enum { KS_ORDER_MIXED = 0, KS_ORDER_SORTED = 1 };           /* voxblox integration_order_mode */
+
+/* voxblox::TsdfIntegratorBase::Config + kimera SemanticIntegratorBase::SemanticConfig
+ * (semantic_integrator_base.h:68-87) + layer geometry + device sizing, as one POD.
+ * The first block of fields is laid out exactly like the oracle's ko_config so tests can
+ * fill both from one dict. */
+typedef struct ks_config {
+  float voxel_size;
+  int32_t voxels_per_side;          /* host Layer block edge (8, 16 or 32); device tiles are always 8^3 */
+  float truncation_distance;
+  float max_weight;
+  float min_ray_length_m;
+  float max_ray_length_m;
+  int32_t voxel_carving_enabled;
+  int32_t use_const_weight;
+  int32_t allow_clear;
+  int32_t use_weight_dropoff;
+  int32_t use_sparsity_compensation_factor;
+  float sparsity_compensation_factor;
+  int32_t enable_anti_grazing;
+  float start_voxel_subsampling_factor;
+  int32_t max_consecutive_ray_collisions;
+  int32_t clear_checks_every_n_frames;
+  int32_t integration_order_mode;
+  int32_t integrator_threads;       /* ignored on the GPU (kept for config compatibility) */
+  int32_t method;
+  int32_t bundle_order;             /* ignored: the GPU always integrates bundles in first-insertion order */
+  float semantic_measurement_probability;
+  int32_t color_mode;
+  int32_t n_dynamic_labels;
+  uint8_t dynamic_labels[32];
+  uint8_t label_rgba[256][4];       /* label -> colour (SemanticLabel2Color::semantic_label_to_color_map_) */
+  /* ---- device sizing ---- */
+  int32_t device_id;                /* HIP device ordinal */
+  uint32_t max_tiles;               /* capacity of the 8^3-voxel tile pool (49.7 KB each) */
+  uint32_t max_points;              /* largest cloud per call (buffers grow on demand if exceeded) */
+} ks_config;
+
+typedef struct ks_frame_stats {
+  uint64_t n_points;
+  uint64_t n_valid_points;
+  uint64_t n_rays_cast;        /* fast: points surviving start-voxel dedup; merged: bundles */
+  uint64_t n_voxel_updates;    /* (ray, voxel) pairs applied = reference updateTsdfVoxel+updateSemanticVoxel calls */
+  uint64_t n_blocks_allocated; /* new 8^3 device tiles this frame */
+} ks_frame_stats;
+
+/* Accumulated HIP-event timings per pipeline stage (enabled with ks_profile_enable). */
+enum {
+  KS_STAGE_POINTS = 0,   /* per-point validity/transform/keys */
+  KS_STAGE_SORT_POINTS,  /* dedup / bundling sort */
+  KS_STAGE_RAYS,         /* dedup decision or bundle merge */
+  KS_STAGE_MARCH,        /* DDA count + tile allocation (+ observed-set early-out) */
+  KS_STAGE_EMIT,         /* DDA emit of (voxel, ray) pairs */
+  KS_STAGE_SORT_PAIRS,   /* group pairs by voxel in ray order */
+  KS_STAGE_APPLY,        /* per-voxel TSDF + semantic log-likelihood update */
+  KS_STAGE_COUNT
+};
+typedef struct ks_profile {
+  double ms[KS_STAGE_COUNT];       /* summed over profiled frames */
+  uint64_t launches[KS_STAGE_COUNT];
+  uint64_t frames;
+  uint64_t updates;                /* voxel updates over profiled frames */
+  uint64_t points;
+} ks_profile;
+
+typedef struct ks_ctx ks_ctx;
+
+int ks_default_config(ks_config* cfg);
+int ks_create(const ks_config* cfg, ks_ctx** out);
+void ks_destroy(ks_ctx* ctx);
+const char* ks_last_error(ks_ctx* ctx); /* ctx may be NULL: returns the last create-time error */
+
+/* colour -> label map (SemanticLabel2Color::color_to_semantic_label_, color.cpp:57-66);
+ * keys are RGBA with the alpha the CSV holds.  Lookups force alpha to 255 like
+ * semantic_tsdf_integrator_fast.cpp:157 / merged.cpp:87; unknown colours map to label 0
+ * (color.cpp:72-81). */
+int ks_set_color_to_label(ks_ctx* ctx, const uint8_t* rgba_keys, const uint8_t* labels, size_t n);
+
+/* vxb::TsdfIntegratorBase::integratePointCloud(T_G_C, points_C, colors, freespace)
+ * (override at semantic_tsdf_integrator_fast.h:82-86 / merged.h:70-73) and the label-aware
+ * overload merged.h:82-86.  Host pointers.  T_G_C = {qw,qx,qy,qz,tx,ty,tz}.
+ * labels == NULL -> labels are derived from rgba through the colour map (the reference's
+ * serial host loop, fast.cpp:150-158).  rgba == NULL -> colours are (0,0,0,0) (what the
+ * reference's merged colour overload effectively integrates, merged.cpp:70,92-93). */
+int ks_integrate_points(ks_ctx* ctx, const float T_G_C[7], const float* xyz, const uint8_t* rgba,
+                        const uint8_t* labels, size_t n, int freespace, ks_frame_stats* stats);
+/* Same, but xyz/rgba/labels are DEVICE pointers already resident in HBM (bench timed region). */
+int ks_integrate_points_device(ks_ctx* ctx, const float T_G_C[7], const float* d_xyz, const uint8_t* d_rgba,
+                               const uint8_t* d_labels, size_t n, int freespace, ks_frame_stats* stats);
+
+/* Layer views (host Layer<TsdfVoxel> / Layer<SemanticVoxel> contract, block edge = voxels_per_side). */
+int ks_num_blocks(ks_ctx* ctx, size_t* n);
+int ks_get_block_indices(ks_ctx* ctx, int32_t* out_xyz, size_t cap, size_t* n); /* sorted (x,y,z) */
+/* Blocks touched since the last call with reset=1 (Block::updated(), semantic_integrator_base.cpp:248). */
+int ks_get_updated_block_indices(ks_ctx* ctx, int32_t* out_xyz, size_t cap, size_t* n, int reset);
+/* tsdf_out: n * vps^3 * 12 B {f32 distance, f32 weight, u8 rgba[4]};
+ * sem_out:  n * vps^3 * 92 B {u8 label, 3 pad, f32 priors[21], u8 rgba[4]} (semantic_voxel.h:14-27).
+ * Either may be NULL.  Absent blocks yield default-constructed voxels. */
+int ks_download_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, void* tsdf_out, void* sem_out);
+
+int ks_synchronize(ks_ctx* ctx);
+void* ks_stream(ks_ctx* ctx); /* the hipStream_t all kernels are launched on */
+int ks_profile_enable(ks_ctx* ctx, int on);
+int ks_profile_get(ks_ctx* ctx, ks_profile* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KS_HIP_H_ */

@@ -1,0 +1,236 @@
+"""ctypes binding of the C ABI in include/ks_hip.h (libks_hip.so).
+
+Plumbing for tests and bench.py; the product boundary is the C ABI itself and the C++
+adapter in kimera_semantics_amd/host/.  There is NO CPU fallback: if the HIP library is
+missing or no GPU is present, constructing an integrator raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libks_hip.so")
+NUM_LABELS = 21
+
+KS_METHOD_FAST, KS_METHOD_MERGED = 0, 1
+KS_COLOR_MODE_COLOR, KS_COLOR_MODE_SEMANTIC, KS_COLOR_MODE_SEMANTIC_PROBABILITY = 0, 1, 2
+KS_ORDER_MIXED, KS_ORDER_SORTED = 0, 1
+KS_ERR_LABEL_RANGE, KS_ERR_PROBABILITY, KS_ERR_POOL_FULL, KS_ERR_NO_DEVICE, KS_ERR_UNSUPPORTED = -2, -3, -5, -7, -8
+
+STAGES = ["points", "sort_points", "rays", "march", "emit", "sort_pairs", "apply"]
+
+TSDF_DTYPE = np.dtype([("distance", "<f4"), ("weight", "<f4"), ("color", "u1", (4,))])
+SEM_DTYPE = np.dtype([("label", "u1"), ("pad", "u1", (3,)), ("priors", "<f4", (NUM_LABELS,)),
+                      ("color", "u1", (4,))])
+
+# Every symbol include/ks_hip.h declares (checked by tests/test_abi.py).
+ABI_SYMBOLS = [
+    "ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_set_color_to_label",
+    "ks_integrate_points", "ks_integrate_points_device", "ks_num_blocks", "ks_get_block_indices",
+    "ks_get_updated_block_indices", "ks_download_blocks", "ks_synchronize", "ks_stream",
+    "ks_profile_enable", "ks_profile_get",
+]
+
+
+class KsConfig(C.Structure):
+    _fields_ = [
+        ("voxel_size", C.c_float), ("voxels_per_side", C.c_int32),
+        ("truncation_distance", C.c_float), ("max_weight", C.c_float),
+        ("min_ray_length_m", C.c_float), ("max_ray_length_m", C.c_float),
+        ("voxel_carving_enabled", C.c_int32), ("use_const_weight", C.c_int32),
+        ("allow_clear", C.c_int32), ("use_weight_dropoff", C.c_int32),
+        ("use_sparsity_compensation_factor", C.c_int32), ("sparsity_compensation_factor", C.c_float),
+        ("enable_anti_grazing", C.c_int32), ("start_voxel_subsampling_factor", C.c_float),
+        ("max_consecutive_ray_collisions", C.c_int32), ("clear_checks_every_n_frames", C.c_int32),
+        ("integration_order_mode", C.c_int32), ("integrator_threads", C.c_int32),
+        ("method", C.c_int32), ("bundle_order", C.c_int32),
+        ("semantic_measurement_probability", C.c_float), ("color_mode", C.c_int32),
+        ("n_dynamic_labels", C.c_int32), ("dynamic_labels", C.c_uint8 * 32),
+        ("label_rgba", (C.c_uint8 * 4) * 256),
+        ("device_id", C.c_int32), ("max_tiles", C.c_uint32), ("max_points", C.c_uint32),
+    ]
+
+
+class KsFrameStats(C.Structure):
+    _fields_ = [("n_points", C.c_uint64), ("n_valid_points", C.c_uint64), ("n_rays_cast", C.c_uint64),
+                ("n_voxel_updates", C.c_uint64), ("n_blocks_allocated", C.c_uint64)]
+
+
+class KsProfile(C.Structure):
+    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_uint64 * 7), ("frames", C.c_uint64),
+                ("updates", C.c_uint64), ("points", C.c_uint64)]
+
+
+def build(force: bool = False) -> str:
+    """Compile libks_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    srcs = [os.path.join(src_dir, f) for f in ("ks_hip.hip", "ks_device_math.h")]
+    srcs.append(os.path.join(_HERE, "..", "include", "ks_hip.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", src_dir])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Loads libks_hip.so.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(the HIP path has no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.ks_default_config.argtypes = [C.POINTER(KsConfig)]
+        L.ks_create.argtypes = [C.POINTER(KsConfig), C.POINTER(vp)]
+        L.ks_destroy.argtypes = [vp]
+        L.ks_destroy.restype = None
+        L.ks_last_error.argtypes = [vp]
+        L.ks_last_error.restype = C.c_char_p
+        L.ks_set_color_to_label.argtypes = [vp, vp, vp, C.c_size_t]
+        L.ks_integrate_points.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(KsFrameStats)]
+        L.ks_integrate_points_device.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(KsFrameStats)]
+        L.ks_num_blocks.argtypes = [vp, C.POINTER(C.c_size_t)]
+        L.ks_get_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.ks_get_updated_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
+        L.ks_download_blocks.argtypes = [vp, vp, C.c_size_t, vp, vp]
+        L.ks_synchronize.argtypes = [vp]
+        L.ks_stream.argtypes = [vp]
+        L.ks_stream.restype = vp
+        L.ks_profile_enable.argtypes = [vp, C.c_int]
+        L.ks_profile_get.argtypes = [vp, C.POINTER(KsProfile), C.c_int]
+        _lib = L
+    return _lib
+
+
+def default_config(**overrides) -> KsConfig:
+    cfg = KsConfig()
+    lib().ks_default_config(C.byref(cfg))
+    apply_overrides(cfg, **overrides)
+    return cfg
+
+
+def apply_overrides(cfg, **overrides):
+    for k, v in overrides.items():
+        if k == "dynamic_labels":
+            cfg.n_dynamic_labels = len(v)
+            for i, lab in enumerate(v):
+                cfg.dynamic_labels[i] = int(lab)
+        elif k == "label_rgba":
+            arr = np.ascontiguousarray(np.asarray(v, dtype=np.uint8).reshape(256, 4))
+            C.memmove(cfg.label_rgba, arr.ctypes.data, 1024)
+        else:
+            if not hasattr(cfg, k):
+                raise AttributeError(k)
+            setattr(cfg, k, v)
+    return cfg
+
+
+class KsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ks error {code}: {msg}")
+        self.code = code
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+class HipIntegrator:
+    """Thin RAII wrapper of ks_ctx."""
+
+    def __init__(self, cfg: KsConfig):
+        self.cfg = cfg
+        self.vps = cfg.voxels_per_side
+        self._h = C.c_void_p()
+        rc = lib().ks_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            raise KsError(rc, lib().ks_last_error(None).decode())
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise KsError(rc, lib().ks_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().ks_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_color_to_label(self, rgba_keys, labels):
+        k = np.ascontiguousarray(rgba_keys, dtype=np.uint8).reshape(-1, 4)
+        l = np.ascontiguousarray(labels, dtype=np.uint8)
+        self._chk(lib().ks_set_color_to_label(self._h, _ptr(k), _ptr(l), len(l)))
+
+    def integrate(self, T_G_C, xyz, rgba, labels, freespace=False) -> KsFrameStats:
+        T = np.ascontiguousarray(T_G_C, dtype=np.float32)
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        labels = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint8)
+        rgba = None if rgba is None else np.ascontiguousarray(rgba, dtype=np.uint8)
+        st = KsFrameStats()
+        self._chk(lib().ks_integrate_points(self._h, _ptr(T), _ptr(xyz), _ptr(rgba), _ptr(labels), xyz.shape[0],
+                                            int(freespace), C.byref(st)))
+        return st
+
+    def integrate_device(self, T_G_C, d_xyz: int, d_rgba: int, d_labels: int, n: int, freespace=False) -> KsFrameStats:
+        """d_* are raw device addresses (e.g. torch.Tensor.data_ptr()); 0/None = NULL."""
+        T = np.ascontiguousarray(T_G_C, dtype=np.float32)
+        st = KsFrameStats()
+        self._chk(lib().ks_integrate_points_device(self._h, _ptr(T), d_xyz or None, d_rgba or None, d_labels or None, n,
+                                                   int(freespace), C.byref(st)))
+        return st
+
+    def block_indices(self) -> np.ndarray:
+        n = C.c_size_t()
+        self._chk(lib().ks_get_block_indices(self._h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 3), dtype=np.int32)
+        if n.value:
+            self._chk(lib().ks_get_block_indices(self._h, _ptr(out), n.value, C.byref(n)))
+        return out
+
+    def updated_block_indices(self, reset=True) -> np.ndarray:
+        n = C.c_size_t()
+        self._chk(lib().ks_get_updated_block_indices(self._h, None, 0, C.byref(n), 0))
+        out = np.zeros((n.value, 3), dtype=np.int32)
+        self._chk(lib().ks_get_updated_block_indices(self._h, _ptr(out), n.value, C.byref(n), int(reset)))
+        return out
+
+    def download(self, indices=None):
+        if indices is None:
+            indices = self.block_indices()
+        indices = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1, 3)
+        nv = self.vps ** 3
+        t = np.zeros((len(indices), nv), dtype=TSDF_DTYPE)
+        s = np.zeros((len(indices), nv), dtype=SEM_DTYPE)
+        if len(indices):
+            self._chk(lib().ks_download_blocks(self._h, _ptr(indices), len(indices), _ptr(t), _ptr(s)))
+        return indices, t, s
+
+    def synchronize(self):
+        self._chk(lib().ks_synchronize(self._h))
+
+    @property
+    def stream(self) -> int:
+        return lib().ks_stream(self._h) or 0
+
+    def profile_enable(self, on=True):
+        self._chk(lib().ks_profile_enable(self._h, int(on)))
+
+    def profile(self, reset=False) -> dict:
+        p = KsProfile()
+        self._chk(lib().ks_profile_get(self._h, C.byref(p), int(reset)))
+        return {"ms": {STAGES[i]: p.ms[i] for i in range(7)}, "launches": {STAGES[i]: p.launches[i] for i in range(7)},
+                "frames": p.frames, "updates": p.updates, "points": p.points}

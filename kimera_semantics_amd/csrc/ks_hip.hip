@@ -1,0 +1,1247 @@
+// ks_hip.hip — MI355X (gfx950) semantic TSDF integrator: HIP kernels + the C ABI of include/ks_hip.h.
+//
+// Replaces, behind the reference's plugin surface, the CPU hot path
+//   kimera::FastSemanticTsdfIntegrator::integratePointCloud    [K:src/semantic_tsdf_integrator_fast.cpp:57-199]
+//   kimera::MergedSemanticTsdfIntegrator::integratePointCloud  [K:src/semantic_tsdf_integrator_merged.cpp:65-329]
+//   kimera::SemanticIntegratorBase::updateSemanticVoxel         [K:src/semantic_integrator_base.cpp:136-194, 283-380]
+// ([K:...] = path under /root/reference/kimera_semantics/).
+//
+// Pipeline per frame (all on one HIP stream; no CPU fallback exists):
+//   points  : one lane per point — validity, T_G_C * p, start-voxel / end-voxel key          (k_points_*)
+//   sort    : radix sort of point keys (start-voxel dedup slots | end-voxel bundles)
+//   rays    : exact sequential-equivalent dedup (fast) or per-bundle merge (merged)           (k_dedup / k_bundles)
+//   march   : one lane per ray — DDA walk, tile allocation in the spatial hash, step count     (k_march)
+//   emit    : one lane per ray — DDA walk again, write (voxel slot, ray seq) pairs             (k_emit)
+//   sort    : radix sort of pairs => every voxel's updates contiguous, in reference order
+//   apply   : one lane per voxel run — sequential TSDF + log-likelihood update, one RMW        (k_apply)
+// Ordering contract: per voxel, updates are applied in exactly the order the reference's
+// single-threaded integrator would apply them, which makes labels bit-exact.
+//
+// Data layout in HBM: 8x8x8-voxel tiles, struct-of-arrays per tile
+//   dist f32[512] | weight f32[512] | color u32[512] | label u8[512] | priors f32[21][512]
+// addressed through an open-addressing hash table keyed by the packed tile index.
+
+#include <cstring>
+#include <string.h>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <set>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/ks_hip.h"
+#include "ks_device_math.h"
+
+using namespace ksd;
+
+namespace {
+
+constexpr uint64_t kEmpty64 = ~0ull;
+constexpr int kSetBits = 20;                                   // [K:semantic_tsdf_integrator_fast.h:102]
+constexpr uint64_t kSetMask = (1ull << kSetBits) - 1;
+constexpr uint64_t kFullResetThreshold = 10000;                // [K:semantic_tsdf_integrator_fast.h:107]
+constexpr int kSeqBits = 24;                                   // low bits of a pair key: ray sequence
+constexpr uint32_t kSeqMask = (1u << kSeqBits) - 1;
+constexpr uint32_t kPointMask = (1u << 23) - 1;                // seq = clearing<<23 | first point position
+constexpr float kPriorInit = -0.60205999132f;                  // [K:include/kimera_semantics/semantic_voxel.h:23]
+constexpr int kCoordBias = 1 << 20;                            // voxel coordinates packed as 21-bit fields
+constexpr int kTileBias = 1 << 17;                             // tile coordinates packed as 18-bit fields
+
+// error bits raised by kernels
+enum : uint32_t { kErrLabel = 1u, kErrPool = 2u, kErrIndex = 4u, kErrTable = 8u };
+
+struct Counters {
+  unsigned long long n_pairs;
+  uint32_t n_valid;
+  uint32_t n_rays;
+  uint32_t n_tiles;   // persistent: tiles allocated so far
+  uint32_t err;
+  uint32_t pad[2];
+};
+
+struct RayDesc {  // 32 B, indexed by point position p (fast) / bundle first-point position (merged)
+  float px, py, pz;   // point_G
+  float weight;
+  uint32_t color;
+  float d_match, d_non;  // pure-label log-likelihood increments
+  uint32_t info;         // [7:0] label, [9:8] kind (0 none, 1 pure, 2 mixed), [10] clearing
+};
+
+struct TileTable {
+  uint64_t* keys;      // open addressing, kEmpty64 = free
+  uint32_t* vals;      // pool slot
+  uint64_t* slot_keys; // slot -> packed tile key
+  uint32_t mask;       // capacity - 1
+  uint32_t max_tiles;
+};
+
+struct Pool {
+  float* dist;
+  float* weight;
+  uint32_t* color;
+  uint8_t* label;      // 255 = never updated (label 0, colour Gray on download)
+  float* priors;       // [tile][21][512]
+  uint8_t* updated;    // per tile
+};
+
+struct FrameParams {
+  Pose T;
+  float voxel_size_inv;
+  float min_ray, max_ray, trunc;
+  float start_inv;           // start_voxel_subsampling_factor * voxel_size_inv
+  float log_match, log_non_match;
+  TsdfParams tsdf;
+  uint64_t start_offset, observed_offset;
+  int32_t max_collisions;
+  uint32_t n;                // points this frame
+  uint32_t per_group;        // n / 1024 (mixed order)
+  int carving, allow_clear, freespace, use_const_weight;
+  int method, color_mode, early_out, sorted_order;
+  int n_dynamic;
+  uint8_t dynamic_labels[32];
+};
+
+__device__ __forceinline__ uint32_t point_order(const FrameParams& F, const uint32_t* order, uint32_t p) {
+  // vxb::MixedThreadSafeIndex — [K:src/semantic_tsdf_integrator_fast.cpp:172-174]
+  if (F.sorted_order) return order[p];
+  if (1024u * F.per_group <= p) return p;
+  return (p % 1024u) * F.per_group + p / 1024u;
+}
+
+__device__ __forceinline__ uint64_t pack_tile(int tx, int ty, int tz) {
+  return ((uint64_t)(uint32_t)(tx + kTileBias) << 36) | ((uint64_t)(uint32_t)(ty + kTileBias) << 18) |
+         (uint64_t)(uint32_t)(tz + kTileBias);
+}
+__device__ __forceinline__ void unpack_tile(uint64_t k, int& tx, int& ty, int& tz) {
+  tx = (int)((k >> 36) & 0x3ffffu) - kTileBias;
+  ty = (int)((k >> 18) & 0x3ffffu) - kTileBias;
+  tz = (int)(k & 0x3ffffu) - kTileBias;
+}
+__host__ __device__ __forceinline__ uint32_t mix64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ull;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+// Allocation of a voxel tile on first touch: CAS on the key claims the table entry, an
+// atomic bump of the pool counter assigns the slot.  Replaces the reference's temp-block map
+// under a global mutex, [K:src/semantic_integrator_base.cpp:205-265].
+__device__ __forceinline__ void tile_insert(const TileTable& T, Counters* C, uint64_t key) {
+  uint32_t h = mix64(key) & T.mask;
+  for (uint32_t probes = 0; probes <= T.mask; ++probes) {
+    const uint64_t k = __hip_atomic_load(&T.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == key) return;
+    if (k == kEmpty64) {
+      const uint64_t old = atomicCAS((unsigned long long*)&T.keys[h], (unsigned long long)kEmpty64, (unsigned long long)key);
+      if (old == kEmpty64) {
+        const uint32_t slot = atomicAdd(&C->n_tiles, 1u);
+        if (slot < T.max_tiles) {
+          T.vals[h] = slot;
+          T.slot_keys[slot] = key;
+        } else {
+          atomicOr(&C->err, kErrPool);
+        }
+        return;
+      }
+      if (old == key) return;
+    }
+    h = (h + 1) & T.mask;
+  }
+  atomicOr(&C->err, kErrTable);
+}
+
+__device__ __forceinline__ uint32_t tile_lookup(const TileTable& T, uint64_t key) {
+  uint32_t h = mix64(key) & T.mask;
+  for (uint32_t probes = 0; probes <= T.mask; ++probes) {
+    const uint64_t k = T.keys[h];
+    if (k == key) return T.vals[h];
+    if (k == kEmpty64) return 0xffffffffu;
+    h = (h + 1) & T.mask;
+  }
+  return 0xffffffffu;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1/K2 (fast): per point — label, validity, dynamic-label filter, point_G, start-voxel slot.
+// [K:src/semantic_tsdf_integrator_fast.cpp:71-92, 150-158]
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_points_fast(FrameParams F, const float* __restrict__ xyz,
+                                                     const uint8_t* __restrict__ rgba,
+                                                     const uint8_t* __restrict__ labels,
+                                                     const uint8_t* __restrict__ color_lut,
+                                                     const uint32_t* __restrict__ order, RayDesc* __restrict__ rays,
+                                                     uint64_t* __restrict__ hv_out, uint64_t* __restrict__ keys,
+                                                     Counters* C) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= F.n) return;
+  const uint32_t idx = point_order(F, order, p);
+  const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+  uint32_t color = 0;
+  if (rgba) color = ((const uint32_t*)rgba)[idx];
+  uint32_t label;
+  if (labels) label = labels[idx];
+  else label = color_lut ? color_lut[color & 0xffffffu] : 0u;
+  uint64_t key = kEmpty64;
+  if (label >= (uint32_t)kNumLabels) {
+    atomicOr(&C->err, kErrLabel);
+  } else {
+    int valid = point_validity(pc, F.min_ray, F.max_ray, F.allow_clear != 0, F.freespace != 0);
+    for (int i = 0; i < F.n_dynamic; ++i)
+      if (F.dynamic_labels[i] == label) valid = 0;
+    if (valid) {
+      const f3 pg = transform_point(F.T, pc);
+      const float gx = grid_coord(pg.x, F.start_inv), gy = grid_coord(pg.y, F.start_inv), gz = grid_coord(pg.z, F.start_inv);
+      const float lim = 2.0f * (float)kCoordBias;  // start set runs at a finer resolution; only the hash is used
+      if (!(fabsf(gx) < lim && fabsf(gy) < lim && fabsf(gz) < lim)) {
+        atomicOr(&C->err, kErrIndex);
+      } else {
+        const uint64_t hv = (uint64_t)index_hash((int)gx, (int)gy, (int)gz) + F.start_offset;
+        hv_out[p] = hv;
+        key = ((hv & kSetMask) << kSeqBits) | p;
+        RayDesc d;
+        d.px = pg.x; d.py = pg.y; d.pz = pg.z;
+        d.weight = voxel_weight(pc.z, F.use_const_weight != 0);
+        d.color = color;
+        d.d_match = F.log_match;
+        d.d_non = F.log_non_match;
+        d.info = label | ((label != 0u ? 1u : 0u) << 8) | ((valid == 2 ? 1u : 0u) << 10);
+        rays[p] = d;
+        atomicAdd(&C->n_valid, 1u);
+      }
+    }
+  }
+  keys[p] = key;
+}
+
+// Start-voxel dedup, exactly as the serial reference: within one slot of the approximate
+// set, a point is kept iff the value left in the slot by its predecessor differs from its
+// own hash+offset.  Keys are sorted by (slot, position); the first lane of each slot run
+// replays the run.  [K:src/semantic_tsdf_integrator_fast.cpp:87-92], ApproxHashSet::replaceHash.
+__global__ void __launch_bounds__(256) k_dedup(uint32_t n, const uint64_t* __restrict__ sorted,
+                                               const uint64_t* __restrict__ hv, uint64_t* __restrict__ start_set,
+                                               uint32_t* __restrict__ ray_list, Counters* C) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t key = sorted[i];
+  if (key == kEmpty64) return;
+  const uint64_t slot = key >> kSeqBits;
+  if (i > 0 && (sorted[i - 1] >> kSeqBits) == slot) return;
+  uint64_t cur = start_set[slot];
+  uint32_t j = i;
+  uint64_t k = key;
+  do {
+    const uint32_t p = (uint32_t)k & kSeqMask;
+    const uint64_t h = hv[p];
+    if (cur != h) {
+      cur = h;
+      ray_list[atomicAdd(&C->n_rays, 1u)] = p;
+    }
+    ++j;
+    if (j >= n) break;
+    k = sorted[j];
+  } while (k != kEmpty64 && (k >> kSeqBits) == slot);
+  start_set[slot] = cur;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4 (merged): per point — validity, point_G, end-voxel key.  vxb::MergedTsdfIntegrator::bundleRays,
+// called at [K:src/semantic_tsdf_integrator_merged.cpp:119-124].
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_points_merged(FrameParams F, const float* __restrict__ xyz,
+                                                       const uint8_t* __restrict__ rgba,
+                                                       const uint8_t* __restrict__ labels,
+                                                       const uint8_t* __restrict__ color_lut,
+                                                       const uint32_t* __restrict__ order, uint8_t* __restrict__ label_out,
+                                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                       Counters* C) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= F.n) return;
+  const uint32_t idx = point_order(F, order, p);
+  const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+  uint32_t label;
+  if (labels) label = labels[idx];
+  else label = (color_lut && rgba) ? color_lut[((const uint32_t*)rgba)[idx] & 0xffffffu] : 0u;
+  uint64_t key = kEmpty64;
+  if (label >= (uint32_t)kNumLabels) {
+    atomicOr(&C->err, kErrLabel);
+    label = 0;
+  } else {
+    const int valid = point_validity(pc, F.min_ray, F.max_ray, F.allow_clear != 0, F.freespace != 0);
+    if (valid) {
+      const f3 pg = transform_point(F.T, pc);
+      const float gx = grid_coord(pg.x, F.voxel_size_inv), gy = grid_coord(pg.y, F.voxel_size_inv),
+                  gz = grid_coord(pg.z, F.voxel_size_inv);
+      const float lim = (float)(kCoordBias - 1);
+      if (!(fabsf(gx) < lim && fabsf(gy) < lim && fabsf(gz) < lim)) {
+        atomicOr(&C->err, kErrIndex);
+      } else {
+        key = ((uint64_t)(valid == 2 ? 1u : 0u) << 63) | ((uint64_t)(uint32_t)((int)gx + kCoordBias) << 42) |
+              ((uint64_t)(uint32_t)((int)gy + kCoordBias) << 21) | (uint64_t)(uint32_t)((int)gz + kCoordBias);
+        atomicAdd(&C->n_valid, 1u);
+      }
+    }
+  }
+  label_out[p] = (uint8_t)label;
+  keys[p] = key;
+  vals[p] = p;
+}
+
+// K5 (merged): one lane per bundle head — running weighted mean of point_C, colour blend,
+// label histogram, log-likelihood increment.  [K:src/semantic_tsdf_integrator_merged.cpp:248-287]
+__global__ void __launch_bounds__(128) k_bundles(FrameParams F, const float* __restrict__ xyz,
+                                                 const uint8_t* __restrict__ rgba, const uint32_t* __restrict__ order,
+                                                 const uint8_t* __restrict__ label_p,
+                                                 const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
+                                                 RayDesc* __restrict__ rays, float* __restrict__ deltas,
+                                                 uint32_t* __restrict__ ray_list, Counters* C) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n) return;
+  const uint64_t key = skeys[i];
+  if (key == kEmpty64) return;
+  if (i > 0 && skeys[i - 1] == key) return;
+  const bool clearing = (key >> 63) != 0;
+  uint32_t merged_color = 0;
+  f3 mp = {0.f, 0.f, 0.f};
+  float mw = 0.0f;
+  float freq[kNumLabels];
+#pragma unroll
+  for (int l = 0; l < kNumLabels; ++l) freq[l] = 0.0f;
+  uint32_t j = i;
+  do {
+    const uint32_t p = svals[j];
+    const uint32_t idx = point_order(F, order, p);
+    const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+    const float pw = voxel_weight(pc.z, F.use_const_weight != 0);
+    if (!(pw < kEps)) {
+      const uint32_t color = rgba ? ((const uint32_t*)rgba)[idx] : 0u;
+      const float denom = mw + pw;
+      mp.x = (mp.x * mw + pc.x * pw) / denom;
+      mp.y = (mp.y * mw + pc.y * pw) / denom;
+      mp.z = (mp.z * mw + pc.z * pw) / denom;
+      merged_color = blend_two_colors(merged_color, mw, color, pw);
+      mw += pw;
+      const uint32_t lab = label_p[p];
+#pragma unroll
+      for (int l = 0; l < kNumLabels; ++l) freq[l] += (lab == (uint32_t)l) ? 1.0f : 0.0f;
+      if (clearing) break;
+    }
+    ++j;
+  } while (j < F.n && skeys[j] == key);
+
+  const uint32_t first_p = svals[i];
+  const f3 pg = transform_point(F.T, mp);
+  // priors += L * freq with L[i][j] = (j == 0) ? 0 : (i == j ? log p : log(1-p)), j ascending, no FMA
+  // [K:src/semantic_integrator_base.cpp:93-128, 306-307]
+  int n_labels = 0, the_label = 0;
+#pragma unroll
+  for (int l = 1; l < kNumLabels; ++l)
+    if (freq[l] > 0.0f) { ++n_labels; the_label = l; }
+  RayDesc d;
+  d.px = pg.x; d.py = pg.y; d.pz = pg.z;
+  d.weight = mw;
+  d.color = merged_color;
+  d.d_match = 0.0f;
+  d.d_non = 0.0f;
+  uint32_t kind = 0;
+  if (n_labels == 1) {
+    kind = 1;
+    float c = 0.0f;
+#pragma unroll
+    for (int l = 1; l < kNumLabels; ++l) if (l == the_label) c = freq[l];
+    d.d_match = F.log_match * c;
+    d.d_non = F.log_non_match * c;
+  } else if (n_labels > 1) {
+    kind = 2;
+#pragma unroll
+    for (int r = 0; r < kNumLabels; ++r) {
+      float acc = 0.0f;
+      acc += 0.0f * freq[0];
+#pragma unroll
+      for (int l = 1; l < kNumLabels; ++l) acc += ((r == l) ? F.log_match : F.log_non_match) * freq[l];
+      deltas[(size_t)first_p * kNumLabels + r] = acc;
+    }
+  }
+  d.info = (uint32_t)the_label | (kind << 8) | ((clearing ? 1u : 0u) << 10);
+  rays[first_p] = d;
+  ray_list[atomicAdd(&C->n_rays, 1u)] = first_p;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3a: march — DDA walk per ray, tile allocation, optional observed-set early-out, step count.
+// [K:src/semantic_tsdf_integrator_fast.cpp:94-141], [K:src/semantic_tsdf_integrator_merged.cpp:288-328]
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_march(FrameParams F, uint32_t n_rays, const uint32_t* __restrict__ ray_list,
+                                               const RayDesc* __restrict__ rays, TileTable T,
+                                               uint64_t* __restrict__ observed_set, uint32_t* __restrict__ nsteps,
+                                               unsigned long long* __restrict__ pair_off, Counters* C) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  const uint32_t p = ray_list[r];
+  const RayDesc d = rays[p];
+  Dda dda;
+  dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
+            /*cast_from_origin=*/F.method == KS_METHOD_MERGED);
+  uint32_t count = 0;
+  if (!dda.in_range) {
+    atomicOr(&C->err, kErrIndex);
+  } else {
+    uint64_t last_tile = kEmpty64;
+    int consecutive = 0;
+    for (int s = 0; s <= dda.steps; ++s) {
+      if (F.early_out) {
+        // ApproxHashSet::replaceHash on voxel_observed_approx_set_ — racy by design in the
+        // multi-threaded reference; here one atomic exchange per step.
+        const uint64_t hv = (uint64_t)index_hash(dda.cx, dda.cy, dda.cz) + F.observed_offset;
+        const uint64_t old = atomicExch((unsigned long long*)&observed_set[hv & kSetMask], (unsigned long long)hv);
+        if (old == hv) ++consecutive;
+        else consecutive = 0;
+        if (consecutive > F.max_collisions) break;
+      }
+      const uint64_t tk = pack_tile(dda.cx >> 3, dda.cy >> 3, dda.cz >> 3);
+      if (tk != last_tile) {
+        tile_insert(T, C, tk);
+        last_tile = tk;
+      }
+      ++count;
+      dda.advance();
+    }
+  }
+  nsteps[r] = count;
+  pair_off[r] = atomicAdd(&C->n_pairs, (unsigned long long)count);
+}
+
+__global__ void __launch_bounds__(512) k_init_tiles(Pool P, uint32_t first_slot) {
+  const size_t slot = (size_t)first_slot + blockIdx.x;
+  const uint32_t v = threadIdx.x;
+  P.dist[slot * kTileVoxels + v] = 0.0f;
+  P.weight[slot * kTileVoxels + v] = 0.0f;
+  P.color[slot * kTileVoxels + v] = 0u;
+  P.label[slot * kTileVoxels + v] = 255;
+#pragma unroll
+  for (int l = 0; l < kNumLabels; ++l) P.priors[(slot * kNumLabels + l) * kTileVoxels + v] = kPriorInit;
+  if (v == 0) P.updated[slot] = 1;
+}
+
+// K3b: emit — same walk, write one (voxel slot id, ray sequence) key per update.
+__global__ void __launch_bounds__(256) k_emit(FrameParams F, uint32_t n_rays, const uint32_t* __restrict__ ray_list,
+                                              const RayDesc* __restrict__ rays, TileTable T, Pool P,
+                                              const uint32_t* __restrict__ nsteps,
+                                              const unsigned long long* __restrict__ pair_off,
+                                              uint64_t* __restrict__ pairs) {
+  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n_rays) return;
+  const uint32_t count = nsteps[r];
+  if (count == 0) return;
+  const uint32_t p = ray_list[r];
+  const RayDesc d = rays[p];
+  const bool clearing = ((d.info >> 10) & 1u) != 0;
+  Dda dda;
+  dda.setup(F.T.t, {d.px, d.py, d.pz}, clearing, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
+            F.method == KS_METHOD_MERGED);
+  // merged: normal bundles integrate before clearing bundles ([K:src/semantic_tsdf_integrator_merged.cpp:126-144])
+  const uint32_t seq = (F.method == KS_METHOD_MERGED && clearing) ? (p | (1u << 23)) : p;
+  uint64_t* out = pairs + pair_off[r];
+  uint64_t last_tile = kEmpty64;
+  uint32_t slot = 0;
+  for (uint32_t s = 0; s < count; ++s) {
+    const uint64_t tk = pack_tile(dda.cx >> 3, dda.cy >> 3, dda.cz >> 3);
+    if (tk != last_tile) {
+      slot = tile_lookup(T, tk);
+      last_tile = tk;
+      P.updated[slot] = 1;
+    }
+    const uint32_t local = (uint32_t)(dda.cx & 7) + 8u * ((uint32_t)(dda.cy & 7) + 8u * (uint32_t)(dda.cz & 7));
+    out[s] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << kSeqBits) | seq;
+    dda.advance();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3c: apply — the per-voxel update.  Pairs are sorted by (voxel, ray sequence); the lane
+// that owns the first pair of a voxel replays all of that voxel's updates in order:
+//   updateTsdfVoxel  (Voxblox; called at [K:fast.cpp:128], [K:merged.cpp:317-319])
+//   updateSemanticVoxel: priors += L*freq, argmax, colour  ([K:src/semantic_integrator_base.cpp:136-194])
+// One read-modify-write of the voxel per frame however many rays crossed it.
+// ------------------------------------------------------------------------------------------
+template <int COLOR_MODE>
+__global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long n_pairs,
+                                               const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
+                                               const float* __restrict__ deltas, TileTable T, Pool P,
+                                               const uint32_t* __restrict__ label_lut) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const uint64_t key = pairs[i];
+  const uint32_t vox = (uint32_t)(key >> kSeqBits);
+  if (i > 0 && (uint32_t)(pairs[i - 1] >> kSeqBits) == vox) return;
+
+  const uint32_t slot = vox >> 9, local = vox & 511u;
+  int tx, ty, tz;
+  unpack_tile(T.slot_keys[slot], tx, ty, tz);
+  const int vx = tx * 8 + (int)(local & 7u), vy = ty * 8 + (int)((local >> 3) & 7u), vz = tz * 8 + (int)(local >> 6);
+  const size_t vbase = (size_t)slot * kTileVoxels + local;
+  float dist = P.dist[vbase], weight = P.weight[vbase];
+  uint32_t color = P.color[vbase];
+  float pri[kNumLabels];
+  const size_t pbase = (size_t)slot * kNumLabels * kTileVoxels + local;
+#pragma unroll
+  for (int l = 0; l < kNumLabels; ++l) pri[l] = P.priors[pbase + (size_t)l * kTileVoxels];
+
+  unsigned long long j = i;
+  uint64_t k = key;
+  do {
+    const uint32_t rp = (uint32_t)k & kPointMask;
+    const RayDesc d = rays[rp];
+    update_tsdf_voxel<COLOR_MODE == KS_COLOR_MODE_COLOR>(F.tsdf, F.T.t, {d.px, d.py, d.pz}, vx, vy, vz, d.color, d.weight,
+                                                         dist, weight, color);
+    const uint32_t kind = (d.info >> 8) & 3u;
+    if (kind == 1u) {
+      const uint32_t lab = d.info & 0xffu;
+#pragma unroll
+      for (int l = 0; l < kNumLabels; ++l) pri[l] += ((uint32_t)l == lab) ? d.d_match : d.d_non;
+    } else if (kind == 2u) {
+      const float* dl = deltas + (size_t)rp * kNumLabels;
+#pragma unroll
+      for (int l = 0; l < kNumLabels; ++l) pri[l] += dl[l];
+    }
+    ++j;
+    if (j >= n_pairs) break;
+    k = pairs[j];
+  } while ((uint32_t)(k >> kSeqBits) == vox);
+
+  // calculateMaximumLikelihoodLabel: first strict maximum [K:src/semantic_integrator_base.cpp:352-367]
+  int best = 0;
+  float m = pri[0];
+#pragma unroll
+  for (int l = 1; l < kNumLabels; ++l)
+    if (pri[l] > m) { m = pri[l]; best = l; }
+  if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = label_lut[best];
+  else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY)
+    color = rainbow_color_map((double)(float)exp((double)m));
+
+  P.dist[vbase] = dist;
+  P.weight[vbase] = weight;
+  P.color[vbase] = color;
+  P.label[vbase] = (uint8_t)best;
+#pragma unroll
+  for (int l = 0; l < kNumLabels; ++l) P.priors[pbase + (size_t)l * kTileVoxels] = pri[l];
+}
+
+// sorted integration order: key = bits of squared norm (non-negative float => monotone as u32)
+__global__ void __launch_bounds__(256) k_sqnorm(uint32_t n, const float* __restrict__ xyz, uint32_t* __restrict__ keys,
+                                                uint32_t* __restrict__ vals) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const f3 p = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+  keys[i] = __float_as_uint(dot3(p, p));
+  vals[i] = i;
+}
+
+// Host-layout export: one lane per voxel of a requested host block (edge vps), AoS records.
+__global__ void __launch_bounds__(256) k_download(TileTable T, Pool P, const int32_t* __restrict__ block_idx, int vps,
+                                                  const uint32_t* __restrict__ label_lut, uint8_t* __restrict__ tsdf_out,
+                                                  uint8_t* __restrict__ sem_out) {
+  const uint32_t b = blockIdx.y;
+  const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nv = (uint32_t)(vps * vps * vps);
+  if (l >= nv) return;
+  const int lx = (int)(l % (uint32_t)vps), ly = (int)((l / (uint32_t)vps) % (uint32_t)vps), lz = (int)(l / (uint32_t)(vps * vps));
+  const int vx = block_idx[3 * b] * vps + lx, vy = block_idx[3 * b + 1] * vps + ly, vz = block_idx[3 * b + 2] * vps + lz;
+  const uint32_t slot = tile_lookup(T, pack_tile(vx >> 3, vy >> 3, vz >> 3));
+  float dist = 0.0f, weight = 0.0f;
+  uint32_t color = 0, label = 255;
+  float pri[kNumLabels];
+#pragma unroll
+  for (int k = 0; k < kNumLabels; ++k) pri[k] = kPriorInit;
+  if (slot != 0xffffffffu) {
+    const uint32_t local = (uint32_t)(vx & 7) + 8u * ((uint32_t)(vy & 7) + 8u * (uint32_t)(vz & 7));
+    const size_t vbase = (size_t)slot * kTileVoxels + local;
+    dist = P.dist[vbase];
+    weight = P.weight[vbase];
+    color = P.color[vbase];
+    label = P.label[vbase];
+    const size_t pbase = (size_t)slot * kNumLabels * kTileVoxels + local;
+#pragma unroll
+    for (int k = 0; k < kNumLabels; ++k) pri[k] = P.priors[pbase + (size_t)k * kTileVoxels];
+  }
+  const size_t o = (size_t)b * nv + l;
+  if (tsdf_out) {
+    uint32_t* t = (uint32_t*)(tsdf_out + o * 12);
+    t[0] = __float_as_uint(dist);
+    t[1] = __float_as_uint(weight);
+    t[2] = color;
+  }
+  if (sem_out) {
+    uint32_t* s = (uint32_t*)(sem_out + o * 92);
+    const bool touched = label != 255u;
+    s[0] = touched ? label : 0u;
+#pragma unroll
+    for (int k = 0; k < kNumLabels; ++k) s[1 + k] = __float_as_uint(pri[k]);
+    // never-updated voxel: HashableColor::Gray() [K:include/kimera_semantics/semantic_voxel.h:26]
+    s[22] = touched ? label_lut[label] : (127u | (127u << 8) | (127u << 16) | (255u << 24));
+  }
+}
+
+__global__ void k_fill_u64(uint64_t* p, size_t n, uint64_t v) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+std::string g_create_error;
+
+}  // namespace
+
+// ==========================================================================================
+// Host side of the C ABI
+// ==========================================================================================
+struct ks_ctx {
+  ks_config cfg{};
+  std::string err;
+  hipStream_t stream = nullptr;
+  float voxel_size_inv = 0.f, log_match = 0.f, log_non_match = 0.f;
+  int vps_shift = 1;  // log2(vps / 8)
+
+  TileTable table{};
+  Pool pool{};
+  uint64_t* d_start_set = nullptr;
+  uint64_t* d_observed_set = nullptr;
+  uint64_t start_offset = 0, observed_offset = 0;
+  int64_t reset_counter = 0;
+  uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
+  uint32_t* d_label_lut = nullptr;  // 256 label -> rgba
+  uint32_t tiles_initialised = 0;
+
+  // per-frame buffers
+  size_t cap_points = 0;
+  float* d_xyz = nullptr;
+  uint8_t* d_rgba = nullptr;
+  uint8_t* d_labels = nullptr;
+  RayDesc* d_rays = nullptr;
+  float* d_deltas = nullptr;
+  uint64_t* d_hv = nullptr;
+  uint64_t *d_pkeys = nullptr, *d_pkeys2 = nullptr;
+  uint32_t *d_pvals = nullptr, *d_pvals2 = nullptr;
+  uint8_t* d_label_p = nullptr;
+  uint32_t* d_order = nullptr;
+  uint32_t *d_okeys = nullptr, *d_okeys2 = nullptr, *d_ovals = nullptr;
+  uint32_t* d_ray_list = nullptr;
+  uint32_t* d_nsteps = nullptr;
+  unsigned long long* d_pair_off = nullptr;
+  size_t cap_pairs = 0;
+  uint64_t *d_pairs = nullptr, *d_pairs2 = nullptr;
+  void* d_sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
+  Counters* d_counters = nullptr;
+  Counters* h_counters = nullptr;  // pinned
+  int32_t* d_block_idx = nullptr;
+  size_t cap_block_idx = 0;
+  uint8_t *d_tsdf_out = nullptr, *d_sem_out = nullptr;
+  size_t cap_out_blocks = 0;
+
+  bool profiling = false;
+  ks_profile prof{};
+  hipEvent_t ev[KS_STAGE_COUNT + 1]{};
+  bool fatal = false;
+};
+
+#define HIPCHK(ctx, expr)                                                                         \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                             \
+      return KS_ERR_HIP;                                                                          \
+    }                                                                                             \
+  } while (0)
+
+namespace {
+
+template <typename T>
+int dev_alloc(ks_ctx* c, T** p, size_t n) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  HIPCHK(c, hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(T)));
+  return KS_OK;
+}
+
+int ensure_points(ks_ctx* c, size_t n) {
+  if (n <= c->cap_points) return KS_OK;
+  const size_t cap = std::max<size_t>(n, 1024);
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_xyz, cap * 3))) return rc;
+  if ((rc = dev_alloc(c, &c->d_rgba, cap * 4))) return rc;
+  if ((rc = dev_alloc(c, &c->d_labels, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_rays, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_hv, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_pkeys, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_pkeys2, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_pvals, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_pvals2, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_label_p, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_order, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_okeys, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_okeys2, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_ovals, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_ray_list, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_nsteps, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_pair_off, cap))) return rc;
+  if (c->cfg.method == KS_METHOD_MERGED) {
+    if ((rc = dev_alloc(c, &c->d_deltas, cap * kNumLabels))) return rc;
+  }
+  c->cap_points = cap;
+  return KS_OK;
+}
+
+int ensure_pairs(ks_ctx* c, size_t n) {
+  if (n <= c->cap_pairs) return KS_OK;
+  const size_t cap = std::max<size_t>(n + n / 4, 1 << 20);
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_pairs, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_pairs2, cap))) return rc;
+  c->cap_pairs = cap;
+  return KS_OK;
+}
+
+int ensure_sort_tmp(ks_ctx* c, size_t bytes) {
+  if (bytes <= c->sort_tmp_bytes) return KS_OK;
+  if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
+  c->d_sort_tmp = nullptr;
+  HIPCHK(c, hipMalloc(&c->d_sort_tmp, bytes));
+  c->sort_tmp_bytes = bytes;
+  return KS_OK;
+}
+
+template <typename K>
+int sort_keys(ks_ctx* c, K* in, K* out, size_t n, unsigned begin_bit, unsigned end_bit) {
+  size_t bytes = 0;
+  HIPCHK(c, rocprim::radix_sort_keys(nullptr, bytes, in, out, n, begin_bit, end_bit, c->stream));
+  int rc = ensure_sort_tmp(c, bytes);
+  if (rc) return rc;
+  HIPCHK(c, rocprim::radix_sort_keys(c->d_sort_tmp, bytes, in, out, n, begin_bit, end_bit, c->stream));
+  return KS_OK;
+}
+template <typename K, typename V>
+int sort_pairs(ks_ctx* c, K* kin, K* kout, V* vin, V* vout, size_t n, unsigned begin_bit, unsigned end_bit) {
+  size_t bytes = 0;
+  HIPCHK(c, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+  int rc = ensure_sort_tmp(c, bytes);
+  if (rc) return rc;
+  HIPCHK(c, rocprim::radix_sort_pairs(c->d_sort_tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+  return KS_OK;
+}
+
+inline unsigned bits_for(uint64_t n) {  // number of bits needed to represent values < n
+  unsigned b = 1;
+  while (b < 64 && (1ull << b) < n) ++b;
+  return b;
+}
+
+// ApproxHashSet::resetApproxSet
+int reset_set(ks_ctx* c, uint64_t* d_set, uint64_t* offset) {
+  if (++(*offset) >= kFullResetThreshold) {
+    HIPCHK(c, hipMemsetAsync(d_set, 0, sizeof(uint64_t) << kSetBits, c->stream));
+    *offset = 0;
+    const uint64_t poison = ~0ull;
+    HIPCHK(c, hipMemcpyAsync(d_set, &poison, sizeof(poison), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return KS_OK;
+}
+
+inline void stage_mark(ks_ctx* c, int stage) {
+  if (c->profiling) (void)hipEventRecord(c->ev[stage], c->stream);
+}
+
+int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba, const uint8_t* d_labels,
+                     size_t n, int freespace, ks_frame_stats* stats) {
+  if (c->fatal) {
+    c->err = "context is in a failed state (earlier pool/index error)";
+    return KS_ERR_INVALID_ARG;
+  }
+  if (n >= (1u << 23)) {
+    c->err = "more than 2^23-1 points per call";
+    return KS_ERR_INVALID_ARG;
+  }
+  const ks_config& cfg = c->cfg;
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (stats) stats->n_points = n;
+
+  // frame-level bookkeeping of the fast integrator [K:src/semantic_tsdf_integrator_fast.cpp:165-170]
+  if (cfg.method == KS_METHOD_FAST) {
+    if ((++c->reset_counter) >= cfg.clear_checks_every_n_frames) {
+      c->reset_counter = 0;
+      int rc;
+      if ((rc = reset_set(c, c->d_start_set, &c->start_offset))) return rc;
+      if ((rc = reset_set(c, c->d_observed_set, &c->observed_offset))) return rc;
+    }
+  }
+  if (n == 0) return KS_OK;
+  int rc = ensure_points(c, n);
+  if (rc) return rc;
+
+  FrameParams F{};
+  F.T.w = Tq[0];
+  F.T.v = {Tq[1], Tq[2], Tq[3]};
+  F.T.t = {Tq[4], Tq[5], Tq[6]};
+  F.voxel_size_inv = c->voxel_size_inv;
+  F.min_ray = cfg.min_ray_length_m;
+  F.max_ray = cfg.max_ray_length_m;
+  F.trunc = cfg.truncation_distance;
+  F.start_inv = cfg.start_voxel_subsampling_factor * c->voxel_size_inv;
+  F.log_match = c->log_match;
+  F.log_non_match = c->log_non_match;
+  F.tsdf.voxel_size = cfg.voxel_size;
+  F.tsdf.trunc = cfg.truncation_distance;
+  F.tsdf.max_weight = cfg.max_weight;
+  F.tsdf.dropoff_denominator = cfg.truncation_distance - cfg.voxel_size;
+  F.tsdf.sparsity_factor = cfg.sparsity_compensation_factor;
+  F.tsdf.use_dropoff = cfg.use_weight_dropoff;
+  F.tsdf.use_sparsity = cfg.use_sparsity_compensation_factor;
+  F.start_offset = c->start_offset;
+  F.observed_offset = c->observed_offset;
+  F.max_collisions = cfg.max_consecutive_ray_collisions;
+  F.n = (uint32_t)n;
+  F.per_group = (uint32_t)(n / 1024);
+  F.carving = cfg.voxel_carving_enabled;
+  F.allow_clear = cfg.allow_clear;
+  F.freespace = freespace;
+  F.use_const_weight = cfg.use_const_weight;
+  F.method = cfg.method;
+  F.color_mode = cfg.color_mode;
+  F.sorted_order = cfg.integration_order_mode == KS_ORDER_SORTED;
+  F.n_dynamic = cfg.n_dynamic_labels;
+  std::memcpy(F.dynamic_labels, cfg.dynamic_labels, 32);
+  // the early-out can never fire if the threshold exceeds the longest possible ray
+  const double max_steps = 3.0 * ((double)cfg.max_ray_length_m + 2.0 * cfg.truncation_distance) * c->voxel_size_inv + 8.0;
+  F.early_out = (cfg.method == KS_METHOD_FAST) && ((double)cfg.max_consecutive_ray_collisions < max_steps);
+
+  hipStream_t st = c->stream;
+  const uint32_t old_tiles = c->h_counters->n_tiles;
+  // reset per-frame counters, keep n_tiles
+  Counters zero{};
+  zero.n_tiles = old_tiles;
+  *c->h_counters = zero;
+  HIPCHK(c, hipMemcpyAsync(c->d_counters, c->h_counters, sizeof(Counters), hipMemcpyHostToDevice, st));
+
+  const uint32_t nb = (uint32_t)((n + 255) / 256);
+  stage_mark(c, 0);
+
+  if (F.sorted_order) {
+    hipLaunchKernelGGL(k_sqnorm, dim3(nb), dim3(256), 0, st, (uint32_t)n, d_xyz, c->d_okeys, c->d_ovals);
+    if ((rc = sort_pairs(c, c->d_okeys, c->d_okeys2, c->d_ovals, c->d_order, n, 0, 32))) return rc;
+  }
+
+  if (cfg.method == KS_METHOD_FAST) {
+    hipLaunchKernelGGL(k_points_fast, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut, c->d_order,
+                       c->d_rays, c->d_hv, c->d_pkeys, c->d_counters);
+    stage_mark(c, 1);
+    if ((rc = sort_keys(c, c->d_pkeys, c->d_pkeys2, n, 0, kSeqBits + kSetBits))) return rc;
+    stage_mark(c, 2);
+    hipLaunchKernelGGL(k_dedup, dim3(nb), dim3(256), 0, st, (uint32_t)n, c->d_pkeys2, c->d_hv, c->d_start_set,
+                       c->d_ray_list, c->d_counters);
+  } else {
+    hipLaunchKernelGGL(k_points_merged, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
+                       c->d_order, c->d_label_p, c->d_pkeys, c->d_pvals, c->d_counters);
+    stage_mark(c, 1);
+    if ((rc = sort_pairs(c, c->d_pkeys, c->d_pkeys2, c->d_pvals, c->d_pvals2, n, 0, 64))) return rc;
+    stage_mark(c, 2);
+    hipLaunchKernelGGL(k_bundles, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, st, F, d_xyz, d_rgba, c->d_order,
+                       c->d_label_p, c->d_pkeys2, c->d_pvals2, c->d_rays, c->d_deltas, c->d_ray_list, c->d_counters);
+  }
+  // need n_rays on the host to size the ray launches
+  HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  if (c->h_counters->err & kErrLabel) {
+    c->h_counters->n_tiles = old_tiles;
+    c->err = "semantic label >= 21 (CHECK_LT in the reference)";
+    return KS_ERR_LABEL_RANGE;
+  }
+  if (c->h_counters->err & kErrIndex) {
+    c->h_counters->n_tiles = old_tiles;
+    c->err = "voxel index out of the packed range";
+    return KS_ERR_INDEX_RANGE;
+  }
+  const uint32_t n_rays = c->h_counters->n_rays;
+  stage_mark(c, 3);
+  if (n_rays > 0) {
+    const uint32_t rb = (n_rays + 255) / 256;
+    hipLaunchKernelGGL(k_march, dim3(rb), dim3(256), 0, st, F, n_rays, c->d_ray_list, c->d_rays, c->table,
+                       c->d_observed_set, c->d_nsteps, c->d_pair_off, c->d_counters);
+    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (c->h_counters->err) {
+      c->fatal = true;
+      if (c->h_counters->err & kErrPool) {
+        c->err = "voxel tile pool exhausted: raise ks_config.max_tiles";
+        return KS_ERR_POOL_FULL;
+      }
+      c->err = "voxel index out of range / tile table full";
+      return KS_ERR_INDEX_RANGE;
+    }
+  }
+  const uint32_t new_tiles = c->h_counters->n_tiles;
+  const unsigned long long n_pairs = c->h_counters->n_pairs;
+  stage_mark(c, 4);
+  if (new_tiles > c->tiles_initialised) {
+    hipLaunchKernelGGL(k_init_tiles, dim3(new_tiles - c->tiles_initialised), dim3(512), 0, st, c->pool,
+                       c->tiles_initialised);
+    c->tiles_initialised = new_tiles;
+  }
+  if (n_pairs > 0) {
+    if ((rc = ensure_pairs(c, n_pairs))) return rc;
+    const uint32_t rb = (n_rays + 255) / 256;
+    hipLaunchKernelGGL(k_emit, dim3(rb), dim3(256), 0, st, F, n_rays, c->d_ray_list, c->d_rays, c->table, c->pool,
+                       c->d_nsteps, c->d_pair_off, c->d_pairs);
+    stage_mark(c, 5);
+    const unsigned end_bit = kSeqBits + 9 + bits_for(new_tiles);
+    if ((rc = sort_keys(c, c->d_pairs, c->d_pairs2, n_pairs, 0, std::min(64u, end_bit)))) return rc;
+    stage_mark(c, 6);
+    const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
+    switch (cfg.color_mode) {
+      case KS_COLOR_MODE_COLOR:
+        hipLaunchKernelGGL(k_apply<KS_COLOR_MODE_COLOR>, dim3(ab), dim3(256), 0, st, F, n_pairs, c->d_pairs2, c->d_rays,
+                           c->d_deltas, c->table, c->pool, c->d_label_lut);
+        break;
+      case KS_COLOR_MODE_SEMANTIC:
+        hipLaunchKernelGGL(k_apply<KS_COLOR_MODE_SEMANTIC>, dim3(ab), dim3(256), 0, st, F, n_pairs, c->d_pairs2,
+                           c->d_rays, c->d_deltas, c->table, c->pool, c->d_label_lut);
+        break;
+      default:
+        hipLaunchKernelGGL(k_apply<KS_COLOR_MODE_SEMANTIC_PROBABILITY>, dim3(ab), dim3(256), 0, st, F, n_pairs,
+                           c->d_pairs2, c->d_rays, c->d_deltas, c->table, c->pool, c->d_label_lut);
+        break;
+    }
+  } else {
+    stage_mark(c, 5);
+    stage_mark(c, 6);
+  }
+  stage_mark(c, 7);
+  HIPCHK(c, hipGetLastError());
+  if (c->profiling) {
+    HIPCHK(c, hipEventSynchronize(c->ev[KS_STAGE_COUNT]));
+    for (int s = 0; s < KS_STAGE_COUNT; ++s) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, c->ev[s], c->ev[s + 1]) == hipSuccess) {
+        c->prof.ms[s] += ms;
+        c->prof.launches[s] += 1;
+      }
+    }
+    c->prof.frames += 1;
+    c->prof.updates += n_pairs;
+    c->prof.points += n;
+  }
+  if (stats) {
+    stats->n_valid_points = c->h_counters->n_valid;
+    stats->n_rays_cast = n_rays;
+    stats->n_voxel_updates = n_pairs;
+    stats->n_blocks_allocated = new_tiles - old_tiles;
+  }
+  return KS_OK;
+}
+
+int collect_block_indices(ks_ctx* c, bool only_updated, bool reset, std::vector<int32_t>* out) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const uint32_t nt = c->tiles_initialised;
+  std::vector<uint64_t> keys(nt);
+  std::vector<uint8_t> upd(nt);
+  if (nt) {
+    HIPCHK(c, hipMemcpy(keys.data(), c->table.slot_keys, nt * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(upd.data(), c->pool.updated, nt, hipMemcpyDeviceToHost));
+    if (only_updated && reset) HIPCHK(c, hipMemset(c->pool.updated, 0, nt));
+  }
+  std::set<std::tuple<int32_t, int32_t, int32_t>> s;
+  for (uint32_t i = 0; i < nt; ++i) {
+    if (only_updated && !upd[i]) continue;
+    const uint64_t k = keys[i];
+    const int tx = (int)((k >> 36) & 0x3ffffu) - kTileBias, ty = (int)((k >> 18) & 0x3ffffu) - kTileBias,
+              tz = (int)(k & 0x3ffffu) - kTileBias;
+    s.insert({tx >> c->vps_shift, ty >> c->vps_shift, tz >> c->vps_shift});
+  }
+  out->clear();
+  for (const auto& t : s) {
+    out->push_back(std::get<0>(t));
+    out->push_back(std::get<1>(t));
+    out->push_back(std::get<2>(t));
+  }
+  return KS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ks_default_config(ks_config* c) {
+  if (!c) return KS_ERR_INVALID_ARG;
+  std::memset(c, 0, sizeof(*c));
+  c->voxel_size = 0.05f;
+  c->voxels_per_side = 16;
+  c->truncation_distance = 4 * 0.05f;
+  c->max_weight = 10000.0f;
+  c->min_ray_length_m = 0.1f;
+  c->max_ray_length_m = 5.0f;
+  c->voxel_carving_enabled = 1;
+  c->use_const_weight = 0;
+  c->allow_clear = 1;
+  c->use_weight_dropoff = 1;
+  c->use_sparsity_compensation_factor = 0;
+  c->sparsity_compensation_factor = 1.0f;
+  c->enable_anti_grazing = 0;
+  c->start_voxel_subsampling_factor = 2.0f;
+  c->max_consecutive_ray_collisions = 2;
+  c->clear_checks_every_n_frames = 1;
+  c->integration_order_mode = KS_ORDER_MIXED;
+  c->integrator_threads = 1;
+  c->method = KS_METHOD_FAST;
+  c->bundle_order = 1;
+  c->semantic_measurement_probability = 0.9f;
+  c->color_mode = KS_COLOR_MODE_SEMANTIC;
+  c->n_dynamic_labels = 0;
+  c->device_id = 0;
+  c->max_tiles = 1u << 16;
+  c->max_points = 1u << 20;
+  return KS_OK;
+}
+
+int ks_create(const ks_config* cfg, ks_ctx** out) {
+  if (!cfg || !out) {
+    g_create_error = "null argument";
+    return KS_ERR_INVALID_ARG;
+  }
+  const int vps = cfg->voxels_per_side;
+  if (!(vps == 8 || vps == 16 || vps == 32 || vps == 64)) {
+    g_create_error = "voxels_per_side must be 8, 16, 32 or 64";
+    return KS_ERR_INVALID_ARG;
+  }
+  if (cfg->enable_anti_grazing) {
+    g_create_error = "enable_anti_grazing is not supported by the HIP integrator yet";
+    return KS_ERR_UNSUPPORTED;
+  }
+  if (cfg->n_dynamic_labels < 0 || cfg->n_dynamic_labels > 32 || cfg->max_tiles == 0 || cfg->max_tiles >= (1u << 23)) {
+    g_create_error = "bad n_dynamic_labels / max_tiles";
+    return KS_ERR_INVALID_ARG;
+  }
+  // setSemanticProbabilities CHECKs [K:src/semantic_integrator_base.cpp:93-107]
+  const float match = cfg->semantic_measurement_probability;
+  const float non_match = 1.0f - cfg->semantic_measurement_probability;
+  if (!(match > 0.0f) || !(non_match > 0.0f) || !(match < 1.0f) || !(non_match < 1.0f)) {
+    g_create_error = "semantic_measurement_probability must be in (0,1)";
+    return KS_ERR_PROBABILITY;
+  }
+  const float lm = std::log(match), lnm = std::log(non_match);  // host libm, as the reference
+  if (!(lm > lnm)) {
+    g_create_error = "log(p) must exceed log(1-p)";
+    return KS_ERR_PROBABILITY;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device_id >= ndev) {
+    g_create_error = "no HIP device (the MI355X path has no CPU fallback)";
+    return KS_ERR_NO_DEVICE;
+  }
+  ks_ctx* c = new ks_ctx();
+  c->cfg = *cfg;
+  c->log_match = lm;
+  c->log_non_match = lnm;
+  c->voxel_size_inv = (float)(1.0 / cfg->voxel_size);  // TsdfIntegratorBase::setLayer
+  c->vps_shift = vps == 8 ? 0 : vps == 16 ? 1 : vps == 32 ? 2 : 3;
+#define CRCHK(expr)                                                        \
+  do {                                                                     \
+    hipError_t e_ = (expr);                                                \
+    if (e_ != hipSuccess) {                                                \
+      g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_);  \
+      ks_destroy(c);                                                       \
+      return KS_ERR_HIP;                                                   \
+    }                                                                      \
+  } while (0)
+  CRCHK(hipSetDevice(cfg->device_id));
+  CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (auto& e : c->ev) CRCHK(hipEventCreate(&e));
+  uint32_t cap = 1024;
+  while (cap < 2u * cfg->max_tiles) cap <<= 1;
+  c->table.mask = cap - 1;
+  c->table.max_tiles = cfg->max_tiles;
+  const size_t mt = cfg->max_tiles;
+  CRCHK(hipMalloc((void**)&c->table.keys, cap * sizeof(uint64_t)));
+  CRCHK(hipMalloc((void**)&c->table.vals, cap * sizeof(uint32_t)));
+  CRCHK(hipMalloc((void**)&c->table.slot_keys, mt * sizeof(uint64_t)));
+  CRCHK(hipMemset(c->table.keys, 0xff, cap * sizeof(uint64_t)));
+  CRCHK(hipMalloc((void**)&c->pool.dist, mt * kTileVoxels * sizeof(float)));
+  CRCHK(hipMalloc((void**)&c->pool.weight, mt * kTileVoxels * sizeof(float)));
+  CRCHK(hipMalloc((void**)&c->pool.color, mt * kTileVoxels * sizeof(uint32_t)));
+  CRCHK(hipMalloc((void**)&c->pool.label, mt * kTileVoxels));
+  CRCHK(hipMalloc((void**)&c->pool.priors, mt * kTileVoxels * kNumLabels * sizeof(float)));
+  CRCHK(hipMalloc((void**)&c->pool.updated, mt));
+  CRCHK(hipMemset(c->pool.updated, 0, mt));
+  CRCHK(hipMalloc((void**)&c->d_start_set, sizeof(uint64_t) << kSetBits));
+  CRCHK(hipMalloc((void**)&c->d_observed_set, sizeof(uint64_t) << kSetBits));
+  CRCHK(hipMemset(c->d_start_set, 0, sizeof(uint64_t) << kSetBits));
+  CRCHK(hipMemset(c->d_observed_set, 0, sizeof(uint64_t) << kSetBits));
+  const uint64_t poison = ~0ull;  // ApproxHashSet ctor: slot[offset_=0] = SIZE_MAX
+  CRCHK(hipMemcpy(c->d_start_set, &poison, 8, hipMemcpyHostToDevice));
+  CRCHK(hipMemcpy(c->d_observed_set, &poison, 8, hipMemcpyHostToDevice));
+  CRCHK(hipMalloc((void**)&c->d_label_lut, 256 * sizeof(uint32_t)));
+  CRCHK(hipMemcpy(c->d_label_lut, cfg->label_rgba, 1024, hipMemcpyHostToDevice));
+  CRCHK(hipMalloc((void**)&c->d_counters, sizeof(Counters)));
+  CRCHK(hipHostMalloc((void**)&c->h_counters, sizeof(Counters)));
+  std::memset(c->h_counters, 0, sizeof(Counters));
+  CRCHK(hipMemset(c->d_counters, 0, sizeof(Counters)));
+#undef CRCHK
+  if (ensure_points(c, cfg->max_points) != KS_OK) {
+    g_create_error = c->err;
+    ks_destroy(c);
+    return KS_ERR_HIP;
+  }
+  *out = c;
+  return KS_OK;
+}
+
+void ks_destroy(ks_ctx* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void* ptrs[] = {c->table.keys, c->table.vals, c->table.slot_keys, c->pool.dist, c->pool.weight, c->pool.color,
+                  c->pool.label, c->pool.priors, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
+                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_rays, c->d_deltas, c->d_hv, c->d_pkeys,
+                  c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_label_p, c->d_order, c->d_okeys, c->d_okeys2, c->d_ovals,
+                  c->d_ray_list, c->d_nsteps, c->d_pair_off, c->d_pairs, c->d_pairs2, c->d_sort_tmp, c->d_counters,
+                  c->d_block_idx, c->d_tsdf_out, c->d_sem_out};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  if (c->h_counters) (void)hipHostFree(c->h_counters);
+  for (auto& e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* ks_last_error(ks_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int ks_set_color_to_label(ks_ctx* c, const uint8_t* rgba_keys, const uint8_t* labels, size_t n) {
+  if (!c || (n && (!rgba_keys || !labels))) return KS_ERR_INVALID_ARG;
+  // 16 MiB direct-mapped rgb -> label table; lookups force alpha = 255
+  // ([K:src/semantic_tsdf_integrator_fast.cpp:157]), so only keys with alpha 255 can match
+  // (HashableColor::operator== compares alpha, [K:src/color.cpp:25-27]); unknown -> 0.
+  std::vector<uint8_t> lut(1u << 24, 0);
+  for (size_t i = 0; i < n; ++i) {
+    if (rgba_keys[4 * i + 3] != 255) continue;
+    const uint32_t rgb = rgba_keys[4 * i] | (rgba_keys[4 * i + 1] << 8) | (rgba_keys[4 * i + 2] << 16);
+    lut[rgb] = labels[i];
+  }
+  if (!c->d_color_lut) HIPCHK(c, hipMalloc((void**)&c->d_color_lut, 1u << 24));
+  HIPCHK(c, hipMemcpy(c->d_color_lut, lut.data(), 1u << 24, hipMemcpyHostToDevice));
+  return KS_OK;
+}
+
+int ks_integrate_points_device(ks_ctx* c, const float T[7], const float* d_xyz, const uint8_t* d_rgba,
+                               const uint8_t* d_labels, size_t n, int freespace, ks_frame_stats* stats) {
+  if (!c || !T || (n && !d_xyz)) return KS_ERR_INVALID_ARG;
+  if (!d_labels && !(d_rgba && c->d_color_lut)) {
+    c->err = "labels == NULL requires rgba and a colour map (ks_set_color_to_label)";
+    return KS_ERR_INVALID_ARG;
+  }
+  return integrate_device(c, T, d_xyz, d_rgba, d_labels, n, freespace, stats);
+}
+
+int ks_integrate_points(ks_ctx* c, const float T[7], const float* xyz, const uint8_t* rgba, const uint8_t* labels,
+                        size_t n, int freespace, ks_frame_stats* stats) {
+  if (!c || !T || (n && !xyz)) return KS_ERR_INVALID_ARG;
+  if (!labels && !(rgba && c->d_color_lut)) {
+    c->err = "labels == NULL requires rgba and a colour map (ks_set_color_to_label)";
+    return KS_ERR_INVALID_ARG;
+  }
+  int rc = ensure_points(c, n);
+  if (rc) return rc;
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(c->d_xyz, xyz, n * 12, hipMemcpyHostToDevice, c->stream));
+    if (rgba) HIPCHK(c, hipMemcpyAsync(c->d_rgba, rgba, n * 4, hipMemcpyHostToDevice, c->stream));
+    if (labels) HIPCHK(c, hipMemcpyAsync(c->d_labels, labels, n, hipMemcpyHostToDevice, c->stream));
+  }
+  return integrate_device(c, T, c->d_xyz, rgba ? c->d_rgba : nullptr, labels ? c->d_labels : nullptr, n, freespace, stats);
+}
+
+int ks_num_blocks(ks_ctx* c, size_t* n) {
+  if (!c || !n) return KS_ERR_INVALID_ARG;
+  std::vector<int32_t> v;
+  int rc = collect_block_indices(c, false, false, &v);
+  if (rc) return rc;
+  *n = v.size() / 3;
+  return KS_OK;
+}
+
+int ks_get_block_indices(ks_ctx* c, int32_t* out, size_t cap, size_t* n) {
+  if (!c || !n) return KS_ERR_INVALID_ARG;
+  std::vector<int32_t> v;
+  int rc = collect_block_indices(c, false, false, &v);
+  if (rc) return rc;
+  *n = v.size() / 3;
+  if (out) std::memcpy(out, v.data(), std::min(cap, *n) * 3 * sizeof(int32_t));
+  return KS_OK;
+}
+
+int ks_get_updated_block_indices(ks_ctx* c, int32_t* out, size_t cap, size_t* n, int reset) {
+  if (!c || !n) return KS_ERR_INVALID_ARG;
+  std::vector<int32_t> v;
+  int rc = collect_block_indices(c, true, reset != 0, &v);
+  if (rc) return rc;
+  *n = v.size() / 3;
+  if (out) std::memcpy(out, v.data(), std::min(cap, *n) * 3 * sizeof(int32_t));
+  return KS_OK;
+}
+
+int ks_download_blocks(ks_ctx* c, const int32_t* idx, size_t n, void* tsdf_out, void* sem_out) {
+  if (!c || (n && !idx)) return KS_ERR_INVALID_ARG;
+  if (n == 0) return KS_OK;
+  const int vps = c->cfg.voxels_per_side;
+  const size_t nv = (size_t)vps * vps * vps;
+  // chunk so staging buffers stay bounded (<= ~256 MiB of semantic voxels)
+  const size_t chunk = std::max<size_t>(1, (size_t(256) << 20) / (nv * 92));
+  if (c->cap_out_blocks < std::min(chunk, n)) {
+    const size_t cb = std::min(chunk, std::max<size_t>(n, 16));
+    int rc;
+    if ((rc = dev_alloc(c, &c->d_tsdf_out, cb * nv * 12))) return rc;
+    if ((rc = dev_alloc(c, &c->d_sem_out, cb * nv * 92))) return rc;
+    if ((rc = dev_alloc(c, &c->d_block_idx, cb * 3))) return rc;
+    c->cap_out_blocks = cb;
+  }
+  for (size_t off = 0; off < n; off += c->cap_out_blocks) {
+    const size_t m = std::min(c->cap_out_blocks, n - off);
+    HIPCHK(c, hipMemcpyAsync(c->d_block_idx, idx + 3 * off, m * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_download, dim3((uint32_t)((nv + 255) / 256), (uint32_t)m), dim3(256), 0, c->stream, c->table,
+                       c->pool, c->d_block_idx, vps, c->d_label_lut, tsdf_out ? c->d_tsdf_out : nullptr,
+                       sem_out ? c->d_sem_out : nullptr);
+    if (tsdf_out)
+      HIPCHK(c, hipMemcpyAsync((uint8_t*)tsdf_out + off * nv * 12, c->d_tsdf_out, m * nv * 12, hipMemcpyDeviceToHost, c->stream));
+    if (sem_out)
+      HIPCHK(c, hipMemcpyAsync((uint8_t*)sem_out + off * nv * 92, c->d_sem_out, m * nv * 92, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return KS_OK;
+}
+
+int ks_synchronize(ks_ctx* c) {
+  if (!c) return KS_ERR_INVALID_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return KS_OK;
+}
+
+void* ks_stream(ks_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+int ks_profile_enable(ks_ctx* c, int on) {
+  if (!c) return KS_ERR_INVALID_ARG;
+  c->profiling = on != 0;
+  return KS_OK;
+}
+
+int ks_profile_get(ks_ctx* c, ks_profile* out, int reset) {
+  if (!c || !out) return KS_ERR_INVALID_ARG;
+  *out = c->prof;
+  if (reset) c->prof = ks_profile{};
+  return KS_OK;
+}
+
+}  // extern "C"
