@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — semantic TSDF integration throughput on MI355X.
+
+Workload (BASELINE.json configs[1], the config the metric is quoted on): replay of a
+640x480 depth+label trajectory ("kimera_semantics_demo.bag" stand-in, synthetic — the bag
+is not in the reference repository), `fast` integrator with the reference's default
+parameters (5 cm voxels, 5 m rays, truncation 4 voxels, early-out after 2 consecutive
+already-observed voxels, p=0.8, dynamic label 20).  One step = one frame integrated into
+the GPU-resident map through the C ABI, inputs already resident in HBM.
+
+Prints ONE JSON line (rank 0).  value = voxel updates/s over the whole job (all ranks),
+where a voxel update is one (ray, voxel) pair for which the reference runs
+updateTsdfVoxel + updateSemanticVoxel (semantic_tsdf_integrator_fast.cpp:128-140).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_UPDATE = 208         # R+W of TsdfVoxel (12 B) + SemanticVoxel (92 B), SURVEY.md §8d
+BYTES_PER_POINT = 17           # xyz 12 B + rgba 4 B + label 1 B
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--method", default="fast", choices=["fast", "merged"])
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=6)
+    return ap.parse_args()
+
+
+def common_cfg(method):
+    from kimera_semantics_amd import synth
+    return dict(method=0 if method == "fast" else 1, voxel_size=0.05, voxels_per_side=16,
+                truncation_distance=0.2, max_ray_length_m=5.0, semantic_measurement_probability=0.8,
+                dynamic_labels=[20], label_rgba=synth.default_label_colors())
+
+
+def cpu_baseline(args, frames):
+    """Oracle (a restatement of the reference: kind 'port') timed on this host's cores on a
+    bounded sample of the same workload."""
+    from oracle import oracle_py as O
+    cores = os.cpu_count() or 1
+    n = min(args.cpu_frames, len(frames))
+    out = {}
+    for label, threads, nf in (("mt", cores, n), ("st", 1, max(1, n // 3))):
+        o = O.Oracle(O.default_config(integrator_threads=threads, **common_cfg(args.method)))
+        upd = 0
+        t0 = time.perf_counter()
+        for f in frames[:nf]:
+            st = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+            upd += st.n_voxel_updates
+        dt = time.perf_counter() - t0
+        out[label] = (upd / dt / 1e6, nf / dt, nf, upd)
+        o.close()
+    return {"value": round(out["mt"][0], 4), "unit": "Mvoxel-updates/s", "cores": cores, "kind": "port",
+            "frames_per_s": round(out["mt"][1], 3),
+            "single_thread_value": round(out["st"][0], 4),
+            "sample": f"first {out['mt'][2]} frames of the same trajectory, oracle with integrator_threads={cores} "
+                      f"('mixed' order, reference defaults); single-thread value from the first {out['st'][2]} frames"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from kimera_semantics_amd import binding as B
+    from kimera_semantics_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    K, W = args.steps, args.warmup
+    # frame-sharded: rank r integrates trajectory frames r, r+world, ... (weak scaling: K+W frames per GPU)
+    scene = synth.make_scene("room")
+    frames = []
+    for k in range(K + W):
+        gk = rank + world * k
+        frames.append(synth.render_frame(scene, synth.trajectory_pose(gk), args.width, args.height, seed=gk))
+    d_frames = []
+    for f in frames:
+        d_frames.append((torch.from_numpy(f.xyz).to(dev), torch.from_numpy(f.rgba).to(dev),
+                         torch.from_numpy(f.labels).to(dev)))
+    cfg = B.default_config(device_id=local_rank, max_tiles=1 << 13, max_points=args.width * args.height,
+                           **common_cfg(args.method))
+    integ = B.HipIntegrator(cfg)
+
+    def step(i):
+        x, c, l = d_frames[i]
+        return integ.integrate_device(frames[i].T_G_C, x.data_ptr(), c.data_ptr(), l.data_ptr(), x.shape[0])
+
+    for i in range(W):
+        step(i)
+    integ.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    integ.profile_enable(True)
+    integ.profile(reset=True)
+    t0 = time.perf_counter()
+    updates = 0
+    points = 0
+    for i in range(W, W + K):
+        st = step(i)
+        updates += st.n_voxel_updates
+        points += st.n_points
+    integ.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = integ.profile()
+
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        u = torch.tensor([updates, points], device=dev, dtype=torch.float64)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        updates_all, points_all = int(u[0].item()), int(u[1].item())
+    else:
+        updates_all, points_all = updates, points
+
+    if rank == 0:
+        # roofline of the dominant kernel (k_apply: the per-voxel TSDF + semantic RMW), from
+        # HIP events recorded on the integrator's own stream inside the timed region.
+        apply_ms = prof["ms"]["apply"] / max(1, prof["launches"]["apply"])
+        upd_per_launch = prof["updates"] / max(1, prof["frames"])
+        pts_per_launch = prof["points"] / max(1, prof["frames"])
+        alg_bytes = BYTES_PER_UPDATE * upd_per_launch
+        achieved = alg_bytes / (apply_ms * 1e-3) / 1e9 if apply_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_apply.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        stage_ms = {k: round(v / max(1, prof["frames"]), 4) for k, v in prof["ms"].items()}
+        whole_frame_alg = BYTES_PER_UPDATE * upd_per_launch + BYTES_PER_POINT * pts_per_launch
+        out = {
+            "metric": "Mvoxel-updates/s + frames/s, 640x480 @5cm voxels",
+            "value": round(updates_all / dt / 1e6, 3),
+            "unit": "Mvoxel-updates/s",
+            "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "frames_per_s": round(world * K / dt, 2),
+            "config": {"workload": f"bag-replay stand-in: {args.width}x{args.height} depth+label trajectory, "
+                                   f"'{args.method}' integrator, 5 cm voxels, 5 m rays, trunc 0.2 m, p=0.8",
+                       "frames_per_gpu": K, "points_per_frame": int(points_all / max(1, world * K)),
+                       "updates_per_frame": int(updates_all / max(1, world * K)),
+                       "parallelism": f"frame-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_apply", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(apply_ms, 5),
+                         "whole_frame_frac": round(whole_frame_alg / (dt / K) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stage_ms_per_frame": stage_ms,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, frames[W:])
+        print(json.dumps(out), flush=True)
+    integ.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

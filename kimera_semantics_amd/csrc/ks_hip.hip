@@ -63,8 +63,29 @@ struct Counters {
   uint32_t n_rays;
   uint32_t n_tiles;   // persistent: tiles allocated so far
   uint32_t err;
-  uint32_t pad[2];
+  uint32_t n_long;    // voxel runs handed to the wave-per-run apply kernel
+  uint32_t n_long_bundles;
 };
+
+constexpr uint32_t kLongRun = 32;        // runs of >= kLongRun updates get a whole wavefront
+constexpr uint32_t kInvalidSlot = 1u << kSetBits;  // sort key of dropped points (sorts last)
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Compaction slot for lanes with pred == true: one atomic per wavefront (a same-address
+// returning atomic per lane saturates at ~88/us on MI355X).  Must be called converged.
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
+  const unsigned long long m = __ballot(pred);
+  const uint32_t lane = lane_id();
+  uint32_t base = 0;
+  if (lane == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m));
+  base = __shfl(base, 0);
+  return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+__device__ __forceinline__ void wave_count(bool pred, uint32_t* counter) {
+  const unsigned long long m = __ballot(pred);
+  if (lane_id() == 0 && m) atomicAdd(counter, (uint32_t)__popcll(m));
+}
 
 struct RayDesc {  // 32 B, indexed by point position p (fast) / bundle first-point position (merged)
   float px, py, pz;   // point_G
@@ -171,6 +192,24 @@ __device__ __forceinline__ uint32_t tile_lookup(const TileTable& T, uint64_t key
   return 0xffffffffu;
 }
 
+__device__ __forceinline__ float bcast_f(float x, int k) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), k));
+}
+__device__ __forceinline__ uint32_t bcast_u(uint32_t x, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)x, k); }
+
+// Correctly rounded a / b given r = RN(1/b) (Markstein): q0 = RN(a r); rem = a - q0 b (exact
+// with FMA); q = RN(q0 + rem r).  Outside a comfortable exponent window fall back to the
+// hardware IEEE division so subnormal remainders cannot perturb the result.
+__device__ __forceinline__ float div_by_recip(float a, float b, float r) {
+  const float aa = fabsf(a);
+  if (aa >= 1e-20f && aa <= 1e20f) {
+    const float q0 = a * r;
+    const float rem = __builtin_fmaf(-q0, b, a);
+    return __builtin_fmaf(rem, r, q0);
+  }
+  return a / b;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1/K2 (fast): per point — label, validity, dynamic-label filter, point_G, start-voxel slot.
 // [K:src/semantic_tsdf_integrator_fast.cpp:71-92, 150-158]
@@ -180,77 +219,89 @@ __global__ void __launch_bounds__(256) k_points_fast(FrameParams F, const float*
                                                      const uint8_t* __restrict__ labels,
                                                      const uint8_t* __restrict__ color_lut,
                                                      const uint32_t* __restrict__ order, RayDesc* __restrict__ rays,
-                                                     uint64_t* __restrict__ hv_out, uint64_t* __restrict__ keys,
-                                                     Counters* C) {
+                                                     uint32_t* __restrict__ hash_out, uint32_t* __restrict__ keys,
+                                                     uint32_t* __restrict__ vals, Counters* C) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= F.n) return;
-  const uint32_t idx = point_order(F, order, p);
-  const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
-  uint32_t color = 0;
-  if (rgba) color = ((const uint32_t*)rgba)[idx];
-  uint32_t label;
-  if (labels) label = labels[idx];
-  else label = color_lut ? color_lut[color & 0xffffffu] : 0u;
-  uint64_t key = kEmpty64;
-  if (label >= (uint32_t)kNumLabels) {
-    atomicOr(&C->err, kErrLabel);
-  } else {
-    int valid = point_validity(pc, F.min_ray, F.max_ray, F.allow_clear != 0, F.freespace != 0);
-    for (int i = 0; i < F.n_dynamic; ++i)
-      if (F.dynamic_labels[i] == label) valid = 0;
-    if (valid) {
-      const f3 pg = transform_point(F.T, pc);
-      const float gx = grid_coord(pg.x, F.start_inv), gy = grid_coord(pg.y, F.start_inv), gz = grid_coord(pg.z, F.start_inv);
-      const float lim = 2.0f * (float)kCoordBias;  // start set runs at a finer resolution; only the hash is used
-      if (!(fabsf(gx) < lim && fabsf(gy) < lim && fabsf(gz) < lim)) {
-        atomicOr(&C->err, kErrIndex);
-      } else {
-        const uint64_t hv = (uint64_t)index_hash((int)gx, (int)gy, (int)gz) + F.start_offset;
-        hv_out[p] = hv;
-        key = ((hv & kSetMask) << kSeqBits) | p;
-        RayDesc d;
-        d.px = pg.x; d.py = pg.y; d.pz = pg.z;
-        d.weight = voxel_weight(pc.z, F.use_const_weight != 0);
-        d.color = color;
-        d.d_match = F.log_match;
-        d.d_non = F.log_non_match;
-        d.info = label | ((label != 0u ? 1u : 0u) << 8) | ((valid == 2 ? 1u : 0u) << 10);
-        rays[p] = d;
-        atomicAdd(&C->n_valid, 1u);
+  const bool live = p < F.n;
+  uint32_t key = kInvalidSlot;
+  bool counted = false;
+  if (live) {
+    const uint32_t idx = point_order(F, order, p);
+    const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+    uint32_t color = 0;
+    if (rgba) color = ((const uint32_t*)rgba)[idx];
+    uint32_t label;
+    if (labels) label = labels[idx];
+    else label = color_lut ? color_lut[color & 0xffffffu] : 0u;
+    if (label >= (uint32_t)kNumLabels) {
+      atomicOr(&C->err, kErrLabel);
+    } else {
+      int valid = point_validity(pc, F.min_ray, F.max_ray, F.allow_clear != 0, F.freespace != 0);
+      for (int i = 0; i < F.n_dynamic; ++i)
+        if (F.dynamic_labels[i] == label) valid = 0;
+      if (valid) {
+        const f3 pg = transform_point(F.T, pc);
+        const float gx = grid_coord(pg.x, F.start_inv), gy = grid_coord(pg.y, F.start_inv),
+                    gz = grid_coord(pg.z, F.start_inv);
+        const float lim = 2.0f * (float)kCoordBias;  // finer grid; only the hash of the index is used
+        if (!(fabsf(gx) < lim && fabsf(gy) < lim && fabsf(gz) < lim)) {
+          atomicOr(&C->err, kErrIndex);
+        } else {
+          const uint32_t h = index_hash((int)gx, (int)gy, (int)gz);
+          hash_out[p] = h;
+          key = (uint32_t)(((uint64_t)h + F.start_offset) & kSetMask);
+          RayDesc d;
+          d.px = pg.x; d.py = pg.y; d.pz = pg.z;
+          d.weight = voxel_weight(pc.z, F.use_const_weight != 0);
+          d.color = color;
+          d.d_match = F.log_match;
+          d.d_non = F.log_non_match;
+          d.info = label | ((label != 0u ? 1u : 0u) << 8) | ((valid == 2 ? 1u : 0u) << 10);
+          rays[p] = d;
+          counted = true;
+        }
       }
     }
+    keys[p] = key;
+    vals[p] = p;
   }
-  keys[p] = key;
+  wave_count(counted, &C->n_valid);
 }
 
-// Start-voxel dedup, exactly as the serial reference: within one slot of the approximate
-// set, a point is kept iff the value left in the slot by its predecessor differs from its
-// own hash+offset.  Keys are sorted by (slot, position); the first lane of each slot run
-// replays the run.  [K:src/semantic_tsdf_integrator_fast.cpp:87-92], ApproxHashSet::replaceHash.
-__global__ void __launch_bounds__(256) k_dedup(uint32_t n, const uint64_t* __restrict__ sorted,
-                                               const uint64_t* __restrict__ hv, uint64_t* __restrict__ start_set,
-                                               uint32_t* __restrict__ ray_list, Counters* C) {
+// Start-voxel dedup, exactly as the serial reference.  ApproxHashSet::replaceHash leaves the
+// caller's hash in the slot whether or not it was already there, so a point is kept iff the
+// previous point that mapped to the same slot (in integration order) had a different hash —
+// or, for the first point of a slot this frame, iff the slot's persistent content differs.
+// Input is stably sorted by slot (so position order is preserved inside a slot).
+// [K:src/semantic_tsdf_integrator_fast.cpp:87-92]
+__global__ void __launch_bounds__(256) k_dedup(uint32_t n, const uint32_t* __restrict__ skeys,
+                                               const uint32_t* __restrict__ svals, const uint32_t* __restrict__ hash,
+                                               uint64_t* __restrict__ start_set, uint32_t* __restrict__ ray_list,
+                                               Counters* C) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const uint64_t key = sorted[i];
-  if (key == kEmpty64) return;
-  const uint64_t slot = key >> kSeqBits;
-  if (i > 0 && (sorted[i - 1] >> kSeqBits) == slot) return;
-  uint64_t cur = start_set[slot];
-  uint32_t j = i;
-  uint64_t k = key;
-  do {
-    const uint32_t p = (uint32_t)k & kSeqMask;
-    const uint64_t h = hv[p];
-    if (cur != h) {
-      cur = h;
-      ray_list[atomicAdd(&C->n_rays, 1u)] = p;
+  bool kept = false;
+  uint32_t p = 0;
+  if (i < n && C->err == 0) {
+    const uint32_t slot = skeys[i];
+    if (slot != kInvalidSlot) {
+      p = svals[i];
+      const uint64_t h = hash[p];
+      const bool first = (i == 0) || (skeys[i - 1] != slot);
+      uint64_t prev;
+      if (first) {
+        prev = start_set[slot];
+        // this lane alone owns the slot this frame: leave the run's last hash behind
+        uint32_t j = i;
+        while (j + 1 < n && skeys[j + 1] == slot) ++j;
+        start_set[slot] = (uint64_t)hash[svals[j]];
+      } else {
+        prev = hash[svals[i - 1]];
+      }
+      kept = prev != h;
     }
-    ++j;
-    if (j >= n) break;
-    k = sorted[j];
-  } while (k != kEmpty64 && (k >> kSeqBits) == slot);
-  start_set[slot] = cur;
+  }
+  const uint32_t pos = wave_append(kept, &C->n_rays);
+  if (kept) ray_list[pos] = p;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -261,91 +312,72 @@ __global__ void __launch_bounds__(256) k_points_merged(FrameParams F, const floa
                                                        const uint8_t* __restrict__ rgba,
                                                        const uint8_t* __restrict__ labels,
                                                        const uint8_t* __restrict__ color_lut,
-                                                       const uint32_t* __restrict__ order, uint8_t* __restrict__ label_out,
-                                                       uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                       Counters* C) {
+                                                       const uint32_t* __restrict__ order, uint64_t* __restrict__ keys,
+                                                       uint32_t* __restrict__ vals, Counters* C) {
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= F.n) return;
-  const uint32_t idx = point_order(F, order, p);
-  const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
-  uint32_t label;
-  if (labels) label = labels[idx];
-  else label = (color_lut && rgba) ? color_lut[((const uint32_t*)rgba)[idx] & 0xffffffu] : 0u;
-  uint64_t key = kEmpty64;
-  if (label >= (uint32_t)kNumLabels) {
-    atomicOr(&C->err, kErrLabel);
-    label = 0;
-  } else {
-    const int valid = point_validity(pc, F.min_ray, F.max_ray, F.allow_clear != 0, F.freespace != 0);
-    if (valid) {
-      const f3 pg = transform_point(F.T, pc);
-      const float gx = grid_coord(pg.x, F.voxel_size_inv), gy = grid_coord(pg.y, F.voxel_size_inv),
-                  gz = grid_coord(pg.z, F.voxel_size_inv);
-      const float lim = (float)(kCoordBias - 1);
-      if (!(fabsf(gx) < lim && fabsf(gy) < lim && fabsf(gz) < lim)) {
-        atomicOr(&C->err, kErrIndex);
-      } else {
-        key = ((uint64_t)(valid == 2 ? 1u : 0u) << 63) | ((uint64_t)(uint32_t)((int)gx + kCoordBias) << 42) |
-              ((uint64_t)(uint32_t)((int)gy + kCoordBias) << 21) | (uint64_t)(uint32_t)((int)gz + kCoordBias);
-        atomicAdd(&C->n_valid, 1u);
-      }
-    }
-  }
-  label_out[p] = (uint8_t)label;
-  keys[p] = key;
-  vals[p] = p;
-}
-
-// K5 (merged): one lane per bundle head — running weighted mean of point_C, colour blend,
-// label histogram, log-likelihood increment.  [K:src/semantic_tsdf_integrator_merged.cpp:248-287]
-__global__ void __launch_bounds__(128) k_bundles(FrameParams F, const float* __restrict__ xyz,
-                                                 const uint8_t* __restrict__ rgba, const uint32_t* __restrict__ order,
-                                                 const uint8_t* __restrict__ label_p,
-                                                 const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ svals,
-                                                 RayDesc* __restrict__ rays, float* __restrict__ deltas,
-                                                 uint32_t* __restrict__ ray_list, Counters* C) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= F.n) return;
-  const uint64_t key = skeys[i];
-  if (key == kEmpty64) return;
-  if (i > 0 && skeys[i - 1] == key) return;
-  const bool clearing = (key >> 63) != 0;
-  uint32_t merged_color = 0;
-  f3 mp = {0.f, 0.f, 0.f};
-  float mw = 0.0f;
-  float freq[kNumLabels];
-#pragma unroll
-  for (int l = 0; l < kNumLabels; ++l) freq[l] = 0.0f;
-  uint32_t j = i;
-  do {
-    const uint32_t p = svals[j];
+  bool counted = false;
+  if (p < F.n) {
     const uint32_t idx = point_order(F, order, p);
     const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
-    const float pw = voxel_weight(pc.z, F.use_const_weight != 0);
-    if (!(pw < kEps)) {
-      const uint32_t color = rgba ? ((const uint32_t*)rgba)[idx] : 0u;
-      const float denom = mw + pw;
-      mp.x = (mp.x * mw + pc.x * pw) / denom;
-      mp.y = (mp.y * mw + pc.y * pw) / denom;
-      mp.z = (mp.z * mw + pc.z * pw) / denom;
-      merged_color = blend_two_colors(merged_color, mw, color, pw);
-      mw += pw;
-      const uint32_t lab = label_p[p];
-#pragma unroll
-      for (int l = 0; l < kNumLabels; ++l) freq[l] += (lab == (uint32_t)l) ? 1.0f : 0.0f;
-      if (clearing) break;
+    uint32_t label;
+    if (labels) label = labels[idx];
+    else label = (color_lut && rgba) ? color_lut[((const uint32_t*)rgba)[idx] & 0xffffffu] : 0u;
+    uint64_t key = kEmpty64;
+    if (label >= (uint32_t)kNumLabels) {
+      atomicOr(&C->err, kErrLabel);
+    } else {
+      const int valid = point_validity(pc, F.min_ray, F.max_ray, F.allow_clear != 0, F.freespace != 0);
+      if (valid) {
+        const f3 pg = transform_point(F.T, pc);
+        const float gx = grid_coord(pg.x, F.voxel_size_inv), gy = grid_coord(pg.y, F.voxel_size_inv),
+                    gz = grid_coord(pg.z, F.voxel_size_inv);
+        const float lim = (float)(kCoordBias - 1);
+        if (!(fabsf(gx) < lim && fabsf(gy) < lim && fabsf(gz) < lim)) {
+          atomicOr(&C->err, kErrIndex);
+        } else {
+          key = ((uint64_t)(valid == 2 ? 1u : 0u) << 63) | ((uint64_t)(uint32_t)((int)gx + kCoordBias) << 42) |
+                ((uint64_t)(uint32_t)((int)gy + kCoordBias) << 21) | (uint64_t)(uint32_t)((int)gz + kCoordBias);
+          counted = true;
+        }
+      }
     }
-    ++j;
-  } while (j < F.n && skeys[j] == key);
+    keys[p] = key;
+    vals[p] = p;
+  }
+  wave_count(counted, &C->n_valid);
+}
 
-  const uint32_t first_p = svals[i];
+// Gather the per-point operands of the bundle merge into bundle (sorted) order, so that the
+// sequential merge below streams contiguous memory: {x, y, z, weight} and {label, colour}.
+__global__ void __launch_bounds__(256) k_gather_sorted(FrameParams F, const float* __restrict__ xyz,
+                                                       const uint8_t* __restrict__ rgba,
+                                                       const uint8_t* __restrict__ labels,
+                                                       const uint8_t* __restrict__ color_lut,
+                                                       const uint32_t* __restrict__ order,
+                                                       const uint64_t* __restrict__ skeys,
+                                                       const uint32_t* __restrict__ svals, float4* __restrict__ g_pw,
+                                                       uint2* __restrict__ g_lc) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n) return;
+  if (skeys[i] == kEmpty64) return;
+  const uint32_t idx = point_order(F, order, svals[i]);
+  const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+  const uint32_t color = rgba ? ((const uint32_t*)rgba)[idx] : 0u;
+  uint32_t label;
+  if (labels) label = labels[idx];
+  else label = (color_lut && rgba) ? color_lut[color & 0xffffffu] : 0u;
+  g_pw[i] = make_float4(pc.x, pc.y, pc.z, voxel_weight(pc.z, F.use_const_weight != 0));
+  g_lc[i] = make_uint2(label, color);
+}
+
+// K5 (merged): bundle merge — running weighted mean of point_C, colour blend, label histogram,
+// log-likelihood increment.  [K:src/semantic_tsdf_integrator_merged.cpp:248-287]
+//   k_bundles      : one lane per bundle of < kLongRun points
+//   k_bundles_long : one wavefront per larger bundle (a surface close to the sensor puts
+//                    thousands of pixels into one 5 cm voxel)
+__device__ __forceinline__ void finish_bundle(const FrameParams& F, f3 mp, float mw, uint32_t merged_color,
+                                              bool clearing, int n_labels, int the_label, float c, RayDesc* out) {
   const f3 pg = transform_point(F.T, mp);
-  // priors += L * freq with L[i][j] = (j == 0) ? 0 : (i == j ? log p : log(1-p)), j ascending, no FMA
-  // [K:src/semantic_integrator_base.cpp:93-128, 306-307]
-  int n_labels = 0, the_label = 0;
-#pragma unroll
-  for (int l = 1; l < kNumLabels; ++l)
-    if (freq[l] > 0.0f) { ++n_labels; the_label = l; }
   RayDesc d;
   d.px = pg.x; d.py = pg.y; d.pz = pg.z;
   d.weight = mw;
@@ -355,69 +387,234 @@ __global__ void __launch_bounds__(128) k_bundles(FrameParams F, const float* __r
   uint32_t kind = 0;
   if (n_labels == 1) {
     kind = 1;
-    float c = 0.0f;
-#pragma unroll
-    for (int l = 1; l < kNumLabels; ++l) if (l == the_label) c = freq[l];
     d.d_match = F.log_match * c;
     d.d_non = F.log_non_match * c;
   } else if (n_labels > 1) {
     kind = 2;
-#pragma unroll
-    for (int r = 0; r < kNumLabels; ++r) {
-      float acc = 0.0f;
-      acc += 0.0f * freq[0];
-#pragma unroll
-      for (int l = 1; l < kNumLabels; ++l) acc += ((r == l) ? F.log_match : F.log_non_match) * freq[l];
-      deltas[(size_t)first_p * kNumLabels + r] = acc;
-    }
   }
   d.info = (uint32_t)the_label | (kind << 8) | ((clearing ? 1u : 0u) << 10);
-  rays[first_p] = d;
-  ray_list[atomicAdd(&C->n_rays, 1u)] = first_p;
+  *out = d;
+}
+
+__global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* __restrict__ skeys,
+                                                 const uint32_t* __restrict__ svals, const float4* __restrict__ g_pw,
+                                                 const uint2* __restrict__ g_lc, RayDesc* __restrict__ rays,
+                                                 float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
+                                                 uint32_t* __restrict__ long_list, Counters* C) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool head = false, is_long = false;
+  uint32_t first_p = 0;
+  uint64_t key = 0;
+  if (i < F.n && C->err == 0) {
+    key = skeys[i];
+    head = (key != kEmpty64) && (i == 0 || skeys[i - 1] != key);
+    if (head) is_long = (i + kLongRun < F.n) && (skeys[i + kLongRun] == key);
+  }
+  const uint32_t lpos = wave_append(head && is_long, &C->n_long_bundles);
+  if (head && is_long) long_list[lpos] = i;
+  const bool work = head && !is_long;
+  if (work) {
+    const bool clearing = (key >> 63) != 0;
+    uint32_t merged_color = 0;
+    f3 mp = {0.f, 0.f, 0.f};
+    float mw = 0.0f;
+    float freq[kNumLabels];
+#pragma unroll
+    for (int l = 0; l < kNumLabels; ++l) freq[l] = 0.0f;
+    uint32_t j = i;
+    do {
+      const float4 q = g_pw[j];
+      const float pw = q.w;
+      if (!(pw < kEps)) {
+        const uint2 lc = g_lc[j];
+        const float denom = mw + pw;
+        mp.x = (mp.x * mw + q.x * pw) / denom;
+        mp.y = (mp.y * mw + q.y * pw) / denom;
+        mp.z = (mp.z * mw + q.z * pw) / denom;
+        if (F.color_mode == KS_COLOR_MODE_COLOR) merged_color = blend_two_colors(merged_color, mw, lc.y, pw);
+        mw += pw;
+#pragma unroll
+        for (int l = 0; l < kNumLabels; ++l) freq[l] += (lc.x == (uint32_t)l) ? 1.0f : 0.0f;
+        if (clearing) break;
+      }
+      ++j;
+    } while (j < F.n && skeys[j] == key);
+
+    first_p = svals[i];
+    // priors += L * freq with L[i][j] = (j == 0) ? 0 : (i == j ? log p : log(1-p)), j ascending, no FMA
+    // [K:src/semantic_integrator_base.cpp:93-128, 306-307]
+    int n_labels = 0, the_label = 0;
+    float c = 0.0f;
+#pragma unroll
+    for (int l = 1; l < kNumLabels; ++l)
+      if (freq[l] > 0.0f) { ++n_labels; the_label = l; c = freq[l]; }
+    if (n_labels > 1) {
+#pragma unroll
+      for (int r = 0; r < kNumLabels; ++r) {
+        float acc = 0.0f;
+        acc += 0.0f * freq[0];
+#pragma unroll
+        for (int l = 1; l < kNumLabels; ++l) acc += ((r == l) ? F.log_match : F.log_non_match) * freq[l];
+        deltas[(size_t)first_p * kNumLabels + r] = acc;
+      }
+    }
+    finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p]);
+  }
+  const uint32_t pos = wave_append(work, &C->n_rays);
+  if (work) ray_list[pos] = first_p;
+}
+
+__global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64_t* __restrict__ skeys,
+                                                     const uint32_t* __restrict__ svals,
+                                                     const float4* __restrict__ g_pw, const uint2* __restrict__ g_lc,
+                                                     RayDesc* __restrict__ rays, float* __restrict__ deltas,
+                                                     uint32_t* __restrict__ ray_list,
+                                                     const uint32_t* __restrict__ long_list, Counters* C) {
+  const uint32_t n_long = C->n_long_bundles;
+  const int lane = (int)lane_id();
+  for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
+    const uint32_t start = long_list[run];
+    const uint64_t key = skeys[start];
+    const bool clearing = (key >> 63) != 0;
+    f3 mp = {0.f, 0.f, 0.f};
+    float mw = 0.0f;
+    uint32_t merged_color = 0;
+    float freq = 0.0f;  // lane l < 21 counts label l
+    bool done = false;
+    uint32_t base = start;
+    // prefetch one batch ahead (contiguous, coalesced)
+    uint32_t j = base + (uint32_t)lane;
+    bool in = (j < F.n) && (skeys[j] == key);
+    float4 q = in ? g_pw[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 lc = in ? g_lc[j] : make_uint2(0u, 0u);
+    while (!done) {
+      const int cnt = (int)__popcll(__ballot(in));
+      if (cnt == 0) break;
+      const uint32_t jn = base + 64u + (uint32_t)lane;
+      const bool in_n = (jn < F.n) && (skeys[jn] == key);
+      const float4 q_n = in_n ? g_pw[jn] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint2 lc_n = in_n ? g_lc[jn] : make_uint2(0u, 0u);
+
+      const bool valid = in && !(q.w < kEps);
+      unsigned long long vmask = __ballot(valid);
+      if (clearing && vmask) {  // only the first usable point of a clearing bundle is integrated
+        vmask &= (~vmask + 1ull);
+        done = true;
+      }
+      const bool use = valid && ((vmask >> lane) & 1ull);
+      // pass 1: weight recurrence; lane k keeps (weight before, denominator)
+      float my_mw = 0.0f, my_den = 1.0f;
+      for (unsigned long long m = vmask; m; m &= m - 1ull) {
+        const int k = __ffsll((long long)m) - 1;
+        const float den = mw + bcast_f(q.w, k);
+        if (lane == k) { my_mw = mw; my_den = den; }
+        mw = den;
+      }
+      const float my_r = 1.0f / my_den;
+      const float ax = q.x * q.w, ay = q.y * q.w, az = q.z * q.w;
+      // pass 2: weighted-mean recurrence, three independent component chains
+      for (unsigned long long m = vmask; m; m &= m - 1ull) {
+        const int k = __ffsll((long long)m) - 1;
+        const float mw_k = bcast_f(my_mw, k), den_k = bcast_f(my_den, k), r_k = bcast_f(my_r, k);
+        mp.x = div_by_recip(mp.x * mw_k + bcast_f(ax, k), den_k, r_k);
+        mp.y = div_by_recip(mp.y * mw_k + bcast_f(ay, k), den_k, r_k);
+        mp.z = div_by_recip(mp.z * mw_k + bcast_f(az, k), den_k, r_k);
+        if (F.color_mode == KS_COLOR_MODE_COLOR)
+          merged_color = blend_two_colors(merged_color, mw_k, bcast_u(lc.y, k), bcast_f(q.w, k));
+      }
+      // label histogram: counts are order independent and exact in f32
+#pragma unroll
+      for (int l = 0; l < kNumLabels; ++l) {
+        const unsigned long long lm = __ballot(use && lc.x == (uint32_t)l);
+        if (lane == l) freq += (float)__popcll(lm);
+      }
+      if (cnt < 64) break;
+      in = in_n;
+      q = q_n;
+      lc = lc_n;
+      base += 64u;
+    }
+    const uint32_t first_p = svals[start];
+    const unsigned long long present = __ballot(lane >= 1 && lane < kNumLabels && freq > 0.0f);
+    const int n_labels = (int)__popcll(present);
+    const int the_label = present ? (63 - __clzll((long long)present)) : 0;
+    const float c = bcast_f(freq, the_label);
+    if (n_labels > 1 && lane < kNumLabels) {
+      float acc = 0.0f;
+      acc += 0.0f * bcast_f(freq, 0);
+#pragma unroll
+      for (int l = 1; l < kNumLabels; ++l) acc += ((lane == l) ? F.log_match : F.log_non_match) * bcast_f(freq, l);
+      deltas[(size_t)first_p * kNumLabels + lane] = acc;
+    }
+    if (lane == 0) {
+      finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p]);
+      ray_list[atomicAdd(&C->n_rays, 1u)] = first_p;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------
 // K3a: march — DDA walk per ray, tile allocation, optional observed-set early-out, step count.
+// Launched over an upper bound of rays; the live count is read from device memory so the
+// host does not have to synchronise between the ray stage and the march.
 // [K:src/semantic_tsdf_integrator_fast.cpp:94-141], [K:src/semantic_tsdf_integrator_merged.cpp:288-328]
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_march(FrameParams F, uint32_t n_rays, const uint32_t* __restrict__ ray_list,
+__global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __restrict__ ray_list,
                                                const RayDesc* __restrict__ rays, TileTable T,
                                                uint64_t* __restrict__ observed_set, uint32_t* __restrict__ nsteps,
                                                unsigned long long* __restrict__ pair_off, Counters* C) {
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_rays) return;
-  const uint32_t p = ray_list[r];
-  const RayDesc d = rays[p];
-  Dda dda;
-  dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
-            /*cast_from_origin=*/F.method == KS_METHOD_MERGED);
+  const uint32_t n_rays = C->n_rays;
+  if (blockIdx.x * blockDim.x >= n_rays) return;  // whole block idle (uniform)
   uint32_t count = 0;
-  if (!dda.in_range) {
-    atomicOr(&C->err, kErrIndex);
-  } else {
-    uint64_t last_tile = kEmpty64;
-    int consecutive = 0;
-    for (int s = 0; s <= dda.steps; ++s) {
-      if (F.early_out) {
-        // ApproxHashSet::replaceHash on voxel_observed_approx_set_ — racy by design in the
-        // multi-threaded reference; here one atomic exchange per step.
-        const uint64_t hv = (uint64_t)index_hash(dda.cx, dda.cy, dda.cz) + F.observed_offset;
-        const uint64_t old = atomicExch((unsigned long long*)&observed_set[hv & kSetMask], (unsigned long long)hv);
-        if (old == hv) ++consecutive;
-        else consecutive = 0;
-        if (consecutive > F.max_collisions) break;
+  if (r < n_rays && (C->err & (kErrLabel | kErrIndex)) == 0) {
+    const uint32_t p = ray_list[r];
+    const RayDesc d = rays[p];
+    Dda dda;
+    dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv,
+              F.trunc, /*cast_from_origin=*/F.method == KS_METHOD_MERGED);
+    if (!dda.in_range) {
+      atomicOr(&C->err, kErrIndex);
+    } else {
+      uint64_t last_tile = kEmpty64;
+      int consecutive = 0;
+      for (int s = 0; s <= dda.steps; ++s) {
+        if (F.early_out) {
+          // ApproxHashSet::replaceHash on voxel_observed_approx_set_ — racy by design in the
+          // multi-threaded reference; here one atomic exchange per step.
+          const uint64_t h = (uint64_t)index_hash(dda.cx, dda.cy, dda.cz);
+          const uint64_t old =
+              atomicExch((unsigned long long*)&observed_set[(h + F.observed_offset) & kSetMask], (unsigned long long)h);
+          if (old == h) ++consecutive;
+          else consecutive = 0;
+          if (consecutive > F.max_collisions) break;
+        }
+        const uint64_t tk = pack_tile(dda.cx >> 3, dda.cy >> 3, dda.cz >> 3);
+        if (tk != last_tile) {
+          tile_insert(T, C, tk);
+          last_tile = tk;
+        }
+        ++count;
+        dda.advance();
       }
-      const uint64_t tk = pack_tile(dda.cx >> 3, dda.cy >> 3, dda.cz >> 3);
-      if (tk != last_tile) {
-        tile_insert(T, C, tk);
-        last_tile = tk;
-      }
-      ++count;
-      dda.advance();
     }
   }
-  nsteps[r] = count;
-  pair_off[r] = atomicAdd(&C->n_pairs, (unsigned long long)count);
+  // wave-level exclusive scan of the step counts, one atomic per wavefront for the base
+  const uint32_t lane = lane_id();
+  uint32_t x = count;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o);
+    if (lane >= (uint32_t)o) x += y;
+  }
+  const uint32_t total = __shfl(x, 63);
+  unsigned long long base = 0;
+  if (lane == 0 && total) base = atomicAdd(&C->n_pairs, (unsigned long long)total);
+  base = __shfl(base, 0);
+  if (r < n_rays) {
+    nsteps[r] = count;
+    pair_off[r] = base + (x - count);
+  }
 }
 
 __global__ void __launch_bounds__(512) k_init_tiles(Pool P, uint32_t first_slot) {
@@ -467,42 +664,72 @@ __global__ void __launch_bounds__(256) k_emit(FrameParams F, uint32_t n_rays, co
 }
 
 // ------------------------------------------------------------------------------------------
-// K3c: apply — the per-voxel update.  Pairs are sorted by (voxel, ray sequence); the lane
-// that owns the first pair of a voxel replays all of that voxel's updates in order:
+// K3c: apply — the per-voxel update.  Pairs are sorted by (voxel, ray sequence); one voxel's
+// updates form a contiguous run that is replayed in order:
 //   updateTsdfVoxel  (Voxblox; called at [K:fast.cpp:128], [K:merged.cpp:317-319])
 //   updateSemanticVoxel: priors += L*freq, argmax, colour  ([K:src/semantic_integrator_base.cpp:136-194])
 // One read-modify-write of the voxel per frame however many rays crossed it.
+//   k_apply      : one lane per short run (< kLongRun updates); long runs are queued
+//   k_apply_long : one wavefront per long run (voxels near the sensor collect thousands of
+//                  updates): lanes fetch 64 updates at once and pre-compute the voxel-state-
+//                  independent part (sdf, updated weight); the state recurrence is then walked
+//                  in order with lane broadcasts; lanes 0..20 own one class prior each.
 // ------------------------------------------------------------------------------------------
+struct VoxelRef {
+  uint32_t slot, local;
+  int vx, vy, vz;
+  size_t vbase, pbase;
+};
+__device__ __forceinline__ VoxelRef voxel_ref(const TileTable& T, uint32_t vox) {
+  VoxelRef v;
+  v.slot = vox >> 9;
+  v.local = vox & 511u;
+  int tx, ty, tz;
+  unpack_tile(T.slot_keys[v.slot], tx, ty, tz);
+  v.vx = tx * 8 + (int)(v.local & 7u);
+  v.vy = ty * 8 + (int)((v.local >> 3) & 7u);
+  v.vz = tz * 8 + (int)(v.local >> 6);
+  v.vbase = (size_t)v.slot * kTileVoxels + v.local;
+  v.pbase = (size_t)v.slot * kNumLabels * kTileVoxels + v.local;
+  return v;
+}
+
 template <int COLOR_MODE>
 __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long n_pairs,
                                                const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
                                                const float* __restrict__ deltas, TileTable T, Pool P,
-                                               const uint32_t* __restrict__ label_lut) {
+                                               const uint32_t* __restrict__ label_lut,
+                                               unsigned long long* __restrict__ long_list, Counters* C) {
   const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_pairs) return;
-  const uint64_t key = pairs[i];
-  const uint32_t vox = (uint32_t)(key >> kSeqBits);
-  if (i > 0 && (uint32_t)(pairs[i - 1] >> kSeqBits) == vox) return;
-
-  const uint32_t slot = vox >> 9, local = vox & 511u;
-  int tx, ty, tz;
-  unpack_tile(T.slot_keys[slot], tx, ty, tz);
-  const int vx = tx * 8 + (int)(local & 7u), vy = ty * 8 + (int)((local >> 3) & 7u), vz = tz * 8 + (int)(local >> 6);
-  const size_t vbase = (size_t)slot * kTileVoxels + local;
-  float dist = P.dist[vbase], weight = P.weight[vbase];
-  uint32_t color = P.color[vbase];
+  bool head = false, is_long = false;
+  uint64_t key = 0;
+  uint32_t vox = 0;
+  if (i < n_pairs) {
+    key = pairs[i];
+    vox = (uint32_t)(key >> kSeqBits);
+    head = (i == 0) || ((uint32_t)(pairs[i - 1] >> kSeqBits) != vox);
+    if (head) is_long = (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> kSeqBits) == vox);
+  }
+  const uint32_t lpos = wave_append(head && is_long, &C->n_long);
+  if (!head) return;
+  if (is_long) {
+    long_list[lpos] = i;
+    return;
+  }
+  const VoxelRef v = voxel_ref(T, vox);
+  float dist = P.dist[v.vbase], weight = P.weight[v.vbase];
+  uint32_t color = P.color[v.vbase];
   float pri[kNumLabels];
-  const size_t pbase = (size_t)slot * kNumLabels * kTileVoxels + local;
 #pragma unroll
-  for (int l = 0; l < kNumLabels; ++l) pri[l] = P.priors[pbase + (size_t)l * kTileVoxels];
+  for (int l = 0; l < kNumLabels; ++l) pri[l] = P.priors[v.pbase + (size_t)l * kTileVoxels];
 
   unsigned long long j = i;
   uint64_t k = key;
   do {
     const uint32_t rp = (uint32_t)k & kPointMask;
     const RayDesc d = rays[rp];
-    update_tsdf_voxel<COLOR_MODE == KS_COLOR_MODE_COLOR>(F.tsdf, F.T.t, {d.px, d.py, d.pz}, vx, vy, vz, d.color, d.weight,
-                                                         dist, weight, color);
+    update_tsdf_voxel<COLOR_MODE == KS_COLOR_MODE_COLOR>(F.tsdf, F.T.t, {d.px, d.py, d.pz}, v.vx, v.vy, v.vz, d.color,
+                                                         d.weight, dist, weight, color);
     const uint32_t kind = (d.info >> 8) & 3u;
     if (kind == 1u) {
       const uint32_t lab = d.info & 0xffu;
@@ -528,12 +755,150 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
   else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY)
     color = rainbow_color_map((double)(float)exp((double)m));
 
-  P.dist[vbase] = dist;
-  P.weight[vbase] = weight;
-  P.color[vbase] = color;
-  P.label[vbase] = (uint8_t)best;
+  P.dist[v.vbase] = dist;
+  P.weight[v.vbase] = weight;
+  P.color[v.vbase] = color;
+  P.label[v.vbase] = (uint8_t)best;
 #pragma unroll
-  for (int l = 0; l < kNumLabels; ++l) P.priors[pbase + (size_t)l * kTileVoxels] = pri[l];
+  for (int l = 0; l < kNumLabels; ++l) P.priors[v.pbase + (size_t)l * kTileVoxels] = pri[l];
+}
+
+template <int COLOR_MODE>
+__global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long long n_pairs,
+                                                   const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
+                                                   const float* __restrict__ deltas, TileTable T, Pool P,
+                                                   const uint32_t* __restrict__ label_lut,
+                                                   const unsigned long long* __restrict__ long_list, const Counters* C) {
+  // One wavefront per block: LDS traffic below is ordered by program order (DS operations of
+  // a wave execute in order), no s_barrier needed; wave_barrier() only pins the compiler.
+  __shared__ float s_inc[64][kNumLabels];  // class increments of the 64 updates in flight
+  __shared__ float s_uw[64];               // their TSDF weights
+  const uint32_t n_long = C->n_long;
+  const int lane = (int)lane_id();
+  const int cls = lane < kNumLabels ? lane : 0;
+  const TsdfParams& Pm = F.tsdf;
+  for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
+    const unsigned long long start = long_list[run];
+    const uint32_t vox = (uint32_t)(pairs[start] >> kSeqBits);
+    const VoxelRef v = voxel_ref(T, vox);
+    float dist = P.dist[v.vbase], weight = P.weight[v.vbase];
+    uint32_t color = P.color[v.vbase];
+    float pri = (lane < kNumLabels) ? P.priors[v.pbase + (size_t)lane * kTileVoxels] : 0.0f;
+    // voxel centre and the origin->centre vector are constant over the run
+    const f3 c = {((float)v.vx + 0.5f) * Pm.voxel_size, ((float)v.vy + 0.5f) * Pm.voxel_size,
+                  ((float)v.vz + 0.5f) * Pm.voxel_size};
+    const f3 v_voxel_origin = sub3(c, F.T.t);
+
+    // software pipeline: rays of batch b+1 and pair keys of batch b+2 are in flight while batch b is applied
+    unsigned long long base = start;
+    uint64_t key_cur = (base + lane < n_pairs) ? pairs[base + lane] : kEmpty64;
+    uint64_t key_nxt = (base + 64 + lane < n_pairs) ? pairs[base + 64 + lane] : kEmpty64;
+    bool in = ((uint32_t)(key_cur >> kSeqBits) == vox);
+    RayDesc d{};
+    if (in) d = rays[(uint32_t)key_cur & kPointMask];
+    for (;;) {
+      const int cnt = (int)__popcll(__ballot(in));  // sorted => the in-lanes form a prefix
+      if (cnt == 0) break;
+      const bool in_n = ((uint32_t)(key_nxt >> kSeqBits) == vox);
+      RayDesc d_n{};
+      if (in_n) d_n = rays[(uint32_t)key_nxt & kPointMask];
+      const uint64_t key_nn = (base + 128 + lane < n_pairs) ? pairs[base + 128 + lane] : kEmpty64;
+
+      // ---- per-lane, voxel-state-independent part: computeDistance + weight drop-off ----
+      float sdf = 0.f, uw = 0.f;
+      if (in) {
+        const f3 v_point_origin = sub3({d.px, d.py, d.pz}, F.T.t);
+        const float dist_G = norm3(v_point_origin);
+        const float dist_G_V = dot3(v_voxel_origin, v_point_origin) / dist_G;
+        sdf = dist_G - dist_G_V;
+        uw = d.weight;
+        if (Pm.use_dropoff && sdf < -Pm.voxel_size) {
+          uw = d.weight * (Pm.trunc + sdf) / Pm.dropoff_denominator;
+          uw = std_max(uw, 0.0f);
+        }
+        if (Pm.use_sparsity) {
+          if (fabsf(sdf) < Pm.trunc) uw *= Pm.sparsity_factor;
+        }
+        const uint32_t kind = (d.info >> 8) & 3u;
+        const uint32_t lab = d.info & 0xffu;
+        if (kind == 2u) {
+          const float* dl = deltas + (size_t)((uint32_t)key_cur & kPointMask) * kNumLabels;
+#pragma unroll
+          for (int l = 0; l < kNumLabels; ++l) s_inc[lane][l] = dl[l];
+        } else {
+          const float a = (kind == 1u) ? d.d_match : 0.0f, b = (kind == 1u) ? d.d_non : 0.0f;
+#pragma unroll
+          for (int l = 0; l < kNumLabels; ++l) s_inc[lane][l] = ((uint32_t)l == lab) ? a : b;
+        }
+        s_uw[lane] = uw;
+      }
+      __builtin_amdgcn_wave_barrier();
+
+      // ---- pass 1: the weight recurrence (independent of the distance) ----
+      // w' = min(max_weight, w + uw) unless w + uw < 1e-6 (then the TSDF update is a no-op).
+      float my_w = 0.0f, my_nw = 1.0f;
+      {
+        float w_run = weight;
+        for (int k = 0; k < cnt; ++k) {
+          const float nw = w_run + s_uw[k];
+          if (lane == k) { my_w = w_run; my_nw = nw; }
+          if (!(nw < kEps)) w_run = std_min(Pm.max_weight, nw);
+        }
+        weight = w_run;
+      }
+      const bool my_skip = my_nw < kEps;
+      const float my_r = 1.0f / my_nw;  // correctly rounded reciprocal, off the critical path
+      const float my_p = sdf * uw;      // fl(sdf * uw)
+      // Saturation: with dist == +trunc on entry, an update whose exact weighted mean exceeds
+      // trunc by more than the rounding slack of the f32 operations leaves dist == +trunc (the
+      // clamp).  If that holds for every update of the batch the distance recurrence is skipped.
+      const bool my_sat = my_skip || ((sdf - Pm.trunc) * uw >= 1e-6f * Pm.trunc * my_nw);
+      const bool all_sat = (__ballot(in && !my_sat) == 0ull);
+      if (!(all_sat && dist == Pm.trunc && COLOR_MODE != KS_COLOR_MODE_COLOR)) {
+        // ---- pass 2: the distance recurrence ----
+        for (int k = 0; k < cnt; ++k) {
+          if (bcast_u(my_skip ? 1u : 0u, k)) continue;
+          const float w_k = bcast_f(my_w, k), nw_k = bcast_f(my_nw, k), r_k = bcast_f(my_r, k);
+          const float num = bcast_f(my_p, k) + dist * w_k;
+          const float q = div_by_recip(num, nw_k, r_k);
+          if (COLOR_MODE == KS_COLOR_MODE_COLOR) {
+            if (fabsf(bcast_f(sdf, k)) < Pm.trunc)
+              color = blend_two_colors(color, w_k, bcast_u(d.color, k), bcast_f(uw, k));
+          }
+          dist = (q > 0.0f) ? std_min(Pm.trunc, q) : std_max(-Pm.trunc, q);
+        }
+      }
+      // ---- pass 3: semantic log-likelihood, lane l owns class l; increments stream from LDS ----
+#pragma unroll 8
+      for (int k = 0; k < cnt; ++k) pri += s_inc[k][cls];
+      __builtin_amdgcn_wave_barrier();
+      if (cnt < 64) break;
+      d = d_n;
+      in = in_n;
+      key_cur = key_nxt;
+      key_nxt = key_nn;
+      base += 64;
+    }
+    // argmax over lanes 0..20, first strict maximum
+    int best = 0;
+    float m = bcast_f(pri, 0);
+#pragma unroll
+    for (int l = 1; l < kNumLabels; ++l) {
+      const float x = bcast_f(pri, l);
+      if (x > m) { m = x; best = l; }
+    }
+    if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = label_lut[best];
+    else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY)
+      color = rainbow_color_map((double)(float)exp((double)m));
+    if (lane < kNumLabels) P.priors[v.pbase + (size_t)lane * kTileVoxels] = pri;
+    if (lane == 0) {
+      P.dist[v.vbase] = dist;
+      P.weight[v.vbase] = weight;
+      P.color[v.vbase] = color;
+      P.label[v.vbase] = (uint8_t)best;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 // sorted integration order: key = bits of squared norm (non-negative float => monotone as u32)
@@ -627,10 +992,14 @@ struct ks_ctx {
   uint8_t* d_labels = nullptr;
   RayDesc* d_rays = nullptr;
   float* d_deltas = nullptr;
-  uint64_t* d_hv = nullptr;
+  uint32_t* d_hash = nullptr;
+  uint32_t *d_skeys32 = nullptr, *d_skeys32b = nullptr;
+  float4* d_gpw = nullptr;
+  uint2* d_glc = nullptr;
+  unsigned long long* d_long_list = nullptr;
+  uint32_t* d_blong = nullptr;
   uint64_t *d_pkeys = nullptr, *d_pkeys2 = nullptr;
   uint32_t *d_pvals = nullptr, *d_pvals2 = nullptr;
-  uint8_t* d_label_p = nullptr;
   uint32_t* d_order = nullptr;
   uint32_t *d_okeys = nullptr, *d_okeys2 = nullptr, *d_ovals = nullptr;
   uint32_t* d_ray_list = nullptr;
@@ -679,12 +1048,13 @@ int ensure_points(ks_ctx* c, size_t n) {
   if ((rc = dev_alloc(c, &c->d_rgba, cap * 4))) return rc;
   if ((rc = dev_alloc(c, &c->d_labels, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_rays, cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_hv, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_hash, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_skeys32, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_skeys32b, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_pkeys, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_pkeys2, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_pvals, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_pvals2, cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_label_p, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_order, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_okeys, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_okeys2, cap))) return rc;
@@ -694,6 +1064,9 @@ int ensure_points(ks_ctx* c, size_t n) {
   if ((rc = dev_alloc(c, &c->d_pair_off, cap))) return rc;
   if (c->cfg.method == KS_METHOD_MERGED) {
     if ((rc = dev_alloc(c, &c->d_deltas, cap * kNumLabels))) return rc;
+    if ((rc = dev_alloc(c, &c->d_gpw, cap))) return rc;
+    if ((rc = dev_alloc(c, &c->d_glc, cap))) return rc;
+    if ((rc = dev_alloc(c, &c->d_blong, cap / kLongRun + 64))) return rc;
   }
   c->cap_points = cap;
   return KS_OK;
@@ -705,6 +1078,7 @@ int ensure_pairs(ks_ctx* c, size_t n) {
   int rc;
   if ((rc = dev_alloc(c, &c->d_pairs, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_pairs2, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_long_list, cap / kLongRun + 64))) return rc;
   c->cap_pairs = cap;
   return KS_OK;
 }
@@ -840,22 +1214,32 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
 
   if (cfg.method == KS_METHOD_FAST) {
     hipLaunchKernelGGL(k_points_fast, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut, c->d_order,
-                       c->d_rays, c->d_hv, c->d_pkeys, c->d_counters);
+                       c->d_rays, c->d_hash, c->d_skeys32, c->d_pvals, c->d_counters);
     stage_mark(c, 1);
-    if ((rc = sort_keys(c, c->d_pkeys, c->d_pkeys2, n, 0, kSeqBits + kSetBits))) return rc;
+    // stable sort by slot only: position order inside a slot is preserved
+    if ((rc = sort_pairs(c, c->d_skeys32, c->d_skeys32b, c->d_pvals, c->d_pvals2, n, 0, kSetBits + 1))) return rc;
     stage_mark(c, 2);
-    hipLaunchKernelGGL(k_dedup, dim3(nb), dim3(256), 0, st, (uint32_t)n, c->d_pkeys2, c->d_hv, c->d_start_set,
-                       c->d_ray_list, c->d_counters);
+    hipLaunchKernelGGL(k_dedup, dim3(nb), dim3(256), 0, st, (uint32_t)n, c->d_skeys32b, c->d_pvals2, c->d_hash,
+                       c->d_start_set, c->d_ray_list, c->d_counters);
   } else {
     hipLaunchKernelGGL(k_points_merged, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       c->d_order, c->d_label_p, c->d_pkeys, c->d_pvals, c->d_counters);
+                       c->d_order, c->d_pkeys, c->d_pvals, c->d_counters);
     stage_mark(c, 1);
     if ((rc = sort_pairs(c, c->d_pkeys, c->d_pkeys2, c->d_pvals, c->d_pvals2, n, 0, 64))) return rc;
     stage_mark(c, 2);
-    hipLaunchKernelGGL(k_bundles, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, st, F, d_xyz, d_rgba, c->d_order,
-                       c->d_label_p, c->d_pkeys2, c->d_pvals2, c->d_rays, c->d_deltas, c->d_ray_list, c->d_counters);
+    hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
+                       c->d_order, c->d_pkeys2, c->d_pvals2, c->d_gpw, c->d_glc);
+    hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, c->d_pkeys2, c->d_pvals2, c->d_gpw, c->d_glc,
+                       c->d_rays, c->d_deltas, c->d_ray_list, c->d_blong, c->d_counters);
+    hipLaunchKernelGGL(k_bundles_long, dim3((uint32_t)std::min<size_t>(n / kLongRun + 1, 2048)), dim3(64), 0, st, F,
+                       c->d_pkeys2, c->d_pvals2, c->d_gpw, c->d_glc, c->d_rays, c->d_deltas, c->d_ray_list, c->d_blong,
+                       c->d_counters);
   }
-  // need n_rays on the host to size the ray launches
+  stage_mark(c, 3);
+  // march over an upper bound of rays (<= n); the live ray count stays on the device
+  hipLaunchKernelGGL(k_march, dim3(nb), dim3(256), 0, st, F, c->d_ray_list, c->d_rays, c->table, c->d_observed_set,
+                     c->d_nsteps, c->d_pair_off, c->d_counters);
+  // the only host synchronisation of the frame: pair / tile / ray counts and error flags
   HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   if (c->h_counters->err & kErrLabel) {
@@ -863,29 +1247,16 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
     c->err = "semantic label >= 21 (CHECK_LT in the reference)";
     return KS_ERR_LABEL_RANGE;
   }
-  if (c->h_counters->err & kErrIndex) {
-    c->h_counters->n_tiles = old_tiles;
-    c->err = "voxel index out of the packed range";
+  if (c->h_counters->err) {
+    c->fatal = true;
+    if (c->h_counters->err & kErrPool) {
+      c->err = "voxel tile pool exhausted: raise ks_config.max_tiles";
+      return KS_ERR_POOL_FULL;
+    }
+    c->err = "voxel index out of the packed range / tile table full";
     return KS_ERR_INDEX_RANGE;
   }
   const uint32_t n_rays = c->h_counters->n_rays;
-  stage_mark(c, 3);
-  if (n_rays > 0) {
-    const uint32_t rb = (n_rays + 255) / 256;
-    hipLaunchKernelGGL(k_march, dim3(rb), dim3(256), 0, st, F, n_rays, c->d_ray_list, c->d_rays, c->table,
-                       c->d_observed_set, c->d_nsteps, c->d_pair_off, c->d_counters);
-    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    if (c->h_counters->err) {
-      c->fatal = true;
-      if (c->h_counters->err & kErrPool) {
-        c->err = "voxel tile pool exhausted: raise ks_config.max_tiles";
-        return KS_ERR_POOL_FULL;
-      }
-      c->err = "voxel index out of range / tile table full";
-      return KS_ERR_INDEX_RANGE;
-    }
-  }
   const uint32_t new_tiles = c->h_counters->n_tiles;
   const unsigned long long n_pairs = c->h_counters->n_pairs;
   stage_mark(c, 4);
@@ -904,20 +1275,18 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
     if ((rc = sort_keys(c, c->d_pairs, c->d_pairs2, n_pairs, 0, std::min(64u, end_bit)))) return rc;
     stage_mark(c, 6);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
+    const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
+#define KS_LAUNCH_APPLY(MODE)                                                                                        \
+  hipLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, F, n_pairs, c->d_pairs2, c->d_rays, c->d_deltas,      \
+                     c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters);                               \
+  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(64), 0, st, F, n_pairs, c->d_pairs2, c->d_rays, c->d_deltas,  \
+                     c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters)
     switch (cfg.color_mode) {
-      case KS_COLOR_MODE_COLOR:
-        hipLaunchKernelGGL(k_apply<KS_COLOR_MODE_COLOR>, dim3(ab), dim3(256), 0, st, F, n_pairs, c->d_pairs2, c->d_rays,
-                           c->d_deltas, c->table, c->pool, c->d_label_lut);
-        break;
-      case KS_COLOR_MODE_SEMANTIC:
-        hipLaunchKernelGGL(k_apply<KS_COLOR_MODE_SEMANTIC>, dim3(ab), dim3(256), 0, st, F, n_pairs, c->d_pairs2,
-                           c->d_rays, c->d_deltas, c->table, c->pool, c->d_label_lut);
-        break;
-      default:
-        hipLaunchKernelGGL(k_apply<KS_COLOR_MODE_SEMANTIC_PROBABILITY>, dim3(ab), dim3(256), 0, st, F, n_pairs,
-                           c->d_pairs2, c->d_rays, c->d_deltas, c->table, c->pool, c->d_label_lut);
-        break;
+      case KS_COLOR_MODE_COLOR: KS_LAUNCH_APPLY(KS_COLOR_MODE_COLOR); break;
+      case KS_COLOR_MODE_SEMANTIC: KS_LAUNCH_APPLY(KS_COLOR_MODE_SEMANTIC); break;
+      default: KS_LAUNCH_APPLY(KS_COLOR_MODE_SEMANTIC_PROBABILITY); break;
     }
+#undef KS_LAUNCH_APPLY
   } else {
     stage_mark(c, 5);
     stage_mark(c, 6);
@@ -1106,8 +1475,8 @@ void ks_destroy(ks_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->table.keys, c->table.vals, c->table.slot_keys, c->pool.dist, c->pool.weight, c->pool.color,
                   c->pool.label, c->pool.priors, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
-                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_rays, c->d_deltas, c->d_hv, c->d_pkeys,
-                  c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_label_p, c->d_order, c->d_okeys, c->d_okeys2, c->d_ovals,
+                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_rays, c->d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_long_list, c->d_blong, c->d_pkeys,
+                  c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_ray_list, c->d_nsteps, c->d_pair_off, c->d_pairs, c->d_pairs2, c->d_sort_tmp, c->d_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out};
   for (void* p : ptrs)

@@ -290,11 +290,15 @@ struct ApproxHashSet {
     for (auto& s : slots) s.store(0, std::memory_order_relaxed);
     slots[offset].store(std::numeric_limits<size_t>::max(), std::memory_order_relaxed);
   }
-  // returns true if the hash was NOT present (and is now stored)
+  // returns true if the hash was NOT present (and is now stored).  The slot index is
+  // offset-dependent, the stored value is the bare hash: an entry left by an earlier frame
+  // (different offset) can therefore never match, which is what makes the cheap reset
+  // (++offset) equivalent to clearing.  Side effect kept as upstream: a
+  // zero-initialised slot matches hash 0 once offset > 0.
   bool replace_hash(size_t hash) {
     const size_t idx = (hash + offset) & kMask;
-    if (slots[idx].load(std::memory_order_relaxed) == hash + offset) return false;
-    slots[idx].store(hash + offset, std::memory_order_relaxed);
+    if (slots[idx].load(std::memory_order_relaxed) == hash) return false;
+    slots[idx].store(hash, std::memory_order_relaxed);
     return true;
   }
   void reset() {
