@@ -47,9 +47,6 @@ constexpr uint64_t kEmpty64 = ~0ull;
 constexpr int kSetBits = 20;                                   // [K:semantic_tsdf_integrator_fast.h:102]
 constexpr uint64_t kSetMask = (1ull << kSetBits) - 1;
 constexpr uint64_t kFullResetThreshold = 10000;                // [K:semantic_tsdf_integrator_fast.h:107]
-constexpr int kSeqBits = 24;                                   // low bits of a pair key: ray sequence
-constexpr uint32_t kSeqMask = (1u << kSeqBits) - 1;
-constexpr uint32_t kPointMask = (1u << 23) - 1;                // seq = clearing<<23 | first point position
 constexpr float kPriorInit = -0.60205999132f;                  // [K:include/kimera_semantics/semantic_voxel.h:23]
 constexpr int kCoordBias = 1 << 20;                            // voxel coordinates packed as 21-bit fields
 constexpr int kTileBias = 1 << 17;                             // tile coordinates packed as 18-bit fields
@@ -85,6 +82,37 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
 __device__ __forceinline__ void wave_count(bool pred, uint32_t* counter) {
   const unsigned long long m = __ballot(pred);
   if (lane_id() == 0 && m) atomicAdd(counter, (uint32_t)__popcll(m));
+}
+// Block-level variants: ONE atomic per workgroup (every thread of the block must call).
+__device__ __forceinline__ uint32_t block_append(bool pred, uint32_t* counter) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_base;
+  const unsigned long long m = __ballot(pred);
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < nwaves; ++w) {
+      const uint32_t t = s_wave[w];
+      s_wave[w] = total;
+      total += t;
+    }
+    s_base = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  const uint32_t pos = s_base + s_wave[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+  __syncthreads();
+  return pos;
+}
+__device__ __forceinline__ void block_count(bool pred, uint32_t* counter) {
+  __shared__ uint32_t s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const unsigned long long m = __ballot(pred);
+  if (lane_id() == 0 && m) atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+  __syncthreads();
+  if (threadIdx.x == 0 && s_cnt) atomicAdd(counter, s_cnt);
 }
 
 struct RayDesc {  // 32 B, indexed by point position p (fast) / bundle first-point position (merged)
@@ -126,6 +154,11 @@ struct FrameParams {
   int carving, allow_clear, freespace, use_const_weight;
   int method, color_mode, early_out, sorted_order;
   int n_dynamic;
+  const uint32_t* order;     // sorted mode: position -> index (nullptr in mixed mode)
+  const uint32_t* inv_order; // sorted mode: index -> position
+  uint32_t seq_bits;         // low bits of a pair key hold the ray sequence
+  uint32_t point_mask;       // (1 << bits_for(n)) - 1
+  uint32_t clear_bit;        // merged: sequence bit that orders clearing bundles last
   uint8_t dynamic_labels[32];
 };
 
@@ -134,6 +167,19 @@ __device__ __forceinline__ uint32_t point_order(const FrameParams& F, const uint
   if (F.sorted_order) return order[p];
   if (1024u * F.per_group <= p) return p;
   return (p % 1024u) * F.per_group + p / 1024u;
+}
+
+// Ray descriptors: fast = one per point, stored at the point's memory index; merged = one
+// per bundle, stored at the bundle's first position.
+__device__ __forceinline__ uint32_t ray_index(const FrameParams& F, uint32_t p) {
+  return (F.method == KS_METHOD_FAST) ? point_order(F, F.order, p) : p;
+}
+
+// inverse of point_order: integration position of the point stored at index idx
+__device__ __forceinline__ uint32_t point_position(const FrameParams& F, const uint32_t* inv_order, uint32_t idx) {
+  if (F.sorted_order) return inv_order[idx];
+  if (1024u * F.per_group <= idx) return idx;
+  return (idx % F.per_group) * 1024u + idx / F.per_group;
 }
 
 __device__ __forceinline__ uint64_t pack_tile(int tx, int ty, int tz) {
@@ -214,19 +260,19 @@ __device__ __forceinline__ float div_by_recip(float a, float b, float r) {
 // K1/K2 (fast): per point — label, validity, dynamic-label filter, point_G, start-voxel slot.
 // [K:src/semantic_tsdf_integrator_fast.cpp:71-92, 150-158]
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_points_fast(FrameParams F, const float* __restrict__ xyz,
-                                                     const uint8_t* __restrict__ rgba,
-                                                     const uint8_t* __restrict__ labels,
-                                                     const uint8_t* __restrict__ color_lut,
-                                                     const uint32_t* __restrict__ order, RayDesc* __restrict__ rays,
-                                                     uint32_t* __restrict__ hash_out, uint32_t* __restrict__ keys,
-                                                     uint32_t* __restrict__ vals, Counters* C) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = p < F.n;
-  uint32_t key = kInvalidSlot;
+__global__ void __launch_bounds__(1024) k_points_fast(FrameParams F, const float* __restrict__ xyz,
+                                                      const uint8_t* __restrict__ rgba,
+                                                      const uint8_t* __restrict__ labels,
+                                                      const uint8_t* __restrict__ color_lut,
+                                                      RayDesc* __restrict__ rays, uint32_t* __restrict__ hash_out,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                      Counters* C) {
+  // One lane per point in MEMORY order (coalesced reads, coalesced descriptor writes); the
+  // integration position p of the point is arithmetic, only the 4-byte sort key is scattered.
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   bool counted = false;
-  if (live) {
-    const uint32_t idx = point_order(F, order, p);
+  if (idx < F.n) {
+    uint32_t key = kInvalidSlot;
     const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
     uint32_t color = 0;
     if (rgba) color = ((const uint32_t*)rgba)[idx];
@@ -248,7 +294,7 @@ __global__ void __launch_bounds__(256) k_points_fast(FrameParams F, const float*
           atomicOr(&C->err, kErrIndex);
         } else {
           const uint32_t h = index_hash((int)gx, (int)gy, (int)gz);
-          hash_out[p] = h;
+          hash_out[idx] = h;
           key = (uint32_t)(((uint64_t)h + F.start_offset) & kSetMask);
           RayDesc d;
           d.px = pg.x; d.py = pg.y; d.pz = pg.z;
@@ -257,15 +303,15 @@ __global__ void __launch_bounds__(256) k_points_fast(FrameParams F, const float*
           d.d_match = F.log_match;
           d.d_non = F.log_non_match;
           d.info = label | ((label != 0u ? 1u : 0u) << 8) | ((valid == 2 ? 1u : 0u) << 10);
-          rays[p] = d;
+          rays[idx] = d;
           counted = true;
         }
       }
     }
-    keys[p] = key;
-    vals[p] = p;
+    keys[point_position(F, F.inv_order, idx)] = key;
+    vals[idx] = idx;  // identity: vals[p] = p
   }
-  wave_count(counted, &C->n_valid);
+  block_count(counted, &C->n_valid);
 }
 
 // Start-voxel dedup, exactly as the serial reference.  ApproxHashSet::replaceHash leaves the
@@ -274,50 +320,58 @@ __global__ void __launch_bounds__(256) k_points_fast(FrameParams F, const float*
 // or, for the first point of a slot this frame, iff the slot's persistent content differs.
 // Input is stably sorted by slot (so position order is preserved inside a slot).
 // [K:src/semantic_tsdf_integrator_fast.cpp:87-92]
-__global__ void __launch_bounds__(256) k_dedup(uint32_t n, const uint32_t* __restrict__ skeys,
-                                               const uint32_t* __restrict__ svals, const uint32_t* __restrict__ hash,
-                                               uint64_t* __restrict__ start_set, uint32_t* __restrict__ ray_list,
-                                               Counters* C) {
+__global__ void __launch_bounds__(1024) k_dedup(FrameParams F, const uint32_t* __restrict__ skeys,
+                                                const uint32_t* __restrict__ svals, const uint32_t* __restrict__ hash,
+                                                uint64_t* __restrict__ start_set, uint32_t* __restrict__ ray_list,
+                                                Counters* C) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = F.n;
   bool kept = false;
   uint32_t p = 0;
   if (i < n && C->err == 0) {
     const uint32_t slot = skeys[i];
     if (slot != kInvalidSlot) {
       p = svals[i];
-      const uint64_t h = hash[p];
+      const uint64_t h = hash[point_order(F, F.order, p)];
       const bool first = (i == 0) || (skeys[i - 1] != slot);
       uint64_t prev;
-      if (first) {
-        prev = start_set[slot];
-        // this lane alone owns the slot this frame: leave the run's last hash behind
-        uint32_t j = i;
-        while (j + 1 < n && skeys[j + 1] == slot) ++j;
-        start_set[slot] = (uint64_t)hash[svals[j]];
-      } else {
-        prev = hash[svals[i - 1]];
-      }
+      // the slot's persistent content is only READ here; k_dedup_commit writes it afterwards
+      if (first) prev = start_set[slot];
+      else prev = hash[point_order(F, F.order, svals[i - 1])];
       kept = prev != h;
     }
   }
-  const uint32_t pos = wave_append(kept, &C->n_rays);
+  const uint32_t pos = block_append(kept, &C->n_rays);
   if (kept) ray_list[pos] = p;
+}
+
+// Leaves the last hash of every slot run in the persistent approximate set (what
+// replaceHash would have left behind after the frame).
+__global__ void __launch_bounds__(1024) k_dedup_commit(FrameParams F, const uint32_t* __restrict__ skeys,
+                                                       const uint32_t* __restrict__ svals,
+                                                       const uint32_t* __restrict__ hash, uint64_t* __restrict__ start_set,
+                                                       const Counters* C) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n || C->err != 0) return;
+  const uint32_t slot = skeys[i];
+  if (slot == kInvalidSlot) return;
+  if (i + 1 < F.n && skeys[i + 1] == slot) return;
+  start_set[slot] = (uint64_t)hash[point_order(F, F.order, svals[i])];
 }
 
 // ------------------------------------------------------------------------------------------
 // K4 (merged): per point — validity, point_G, end-voxel key.  vxb::MergedTsdfIntegrator::bundleRays,
 // called at [K:src/semantic_tsdf_integrator_merged.cpp:119-124].
 // ------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_points_merged(FrameParams F, const float* __restrict__ xyz,
-                                                       const uint8_t* __restrict__ rgba,
-                                                       const uint8_t* __restrict__ labels,
-                                                       const uint8_t* __restrict__ color_lut,
-                                                       const uint32_t* __restrict__ order, uint64_t* __restrict__ keys,
-                                                       uint32_t* __restrict__ vals, Counters* C) {
-  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(1024) k_points_merged(FrameParams F, const float* __restrict__ xyz,
+                                                        const uint8_t* __restrict__ rgba,
+                                                        const uint8_t* __restrict__ labels,
+                                                        const uint8_t* __restrict__ color_lut,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                        Counters* C) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   bool counted = false;
-  if (p < F.n) {
-    const uint32_t idx = point_order(F, order, p);
+  if (idx < F.n) {
     const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
     uint32_t label;
     if (labels) label = labels[idx];
@@ -341,10 +395,10 @@ __global__ void __launch_bounds__(256) k_points_merged(FrameParams F, const floa
         }
       }
     }
-    keys[p] = key;
-    vals[p] = p;
+    keys[point_position(F, F.inv_order, idx)] = key;
+    vals[idx] = idx;  // identity: vals[p] = p
   }
-  wave_count(counted, &C->n_valid);
+  block_count(counted, &C->n_valid);
 }
 
 // Gather the per-point operands of the bundle merge into bundle (sorted) order, so that the
@@ -410,7 +464,7 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
     head = (key != kEmpty64) && (i == 0 || skeys[i - 1] != key);
     if (head) is_long = (i + kLongRun < F.n) && (skeys[i + kLongRun] == key);
   }
-  const uint32_t lpos = wave_append(head && is_long, &C->n_long_bundles);
+  const uint32_t lpos = block_append(head && is_long, &C->n_long_bundles);
   if (head && is_long) long_list[lpos] = i;
   const bool work = head && !is_long;
   if (work) {
@@ -460,7 +514,7 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
     }
     finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p]);
   }
-  const uint32_t pos = wave_append(work, &C->n_rays);
+  const uint32_t pos = block_append(work, &C->n_rays);
   if (work) ray_list[pos] = first_p;
 }
 
@@ -569,7 +623,7 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
   uint32_t count = 0;
   if (r < n_rays && (C->err & (kErrLabel | kErrIndex)) == 0) {
     const uint32_t p = ray_list[r];
-    const RayDesc d = rays[p];
+    const RayDesc d = rays[ray_index(F, p)];
     Dda dda;
     dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv,
               F.trunc, /*cast_from_origin=*/F.method == KS_METHOD_MERGED);
@@ -599,21 +653,31 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
       }
     }
   }
-  // wave-level exclusive scan of the step counts, one atomic per wavefront for the base
-  const uint32_t lane = lane_id();
+  // exclusive scan of the step counts inside the block, one atomic per workgroup for the base
+  __shared__ uint32_t s_wave[4];
+  __shared__ unsigned long long s_base;
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
   uint32_t x = count;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
     const uint32_t y = __shfl_up(x, o);
     if (lane >= (uint32_t)o) x += y;
   }
-  const uint32_t total = __shfl(x, 63);
-  unsigned long long base = 0;
-  if (lane == 0 && total) base = atomicAdd(&C->n_pairs, (unsigned long long)total);
-  base = __shfl(base, 0);
+  if (lane == 63) s_wave[wave] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t t = s_wave[w];
+      s_wave[w] = total;
+      total += t;
+    }
+    s_base = total ? atomicAdd(&C->n_pairs, (unsigned long long)total) : 0ull;
+  }
+  __syncthreads();
   if (r < n_rays) {
     nsteps[r] = count;
-    pair_off[r] = base + (x - count);
+    pair_off[r] = s_base + s_wave[wave] + (x - count);
   }
 }
 
@@ -640,13 +704,13 @@ __global__ void __launch_bounds__(256) k_emit(FrameParams F, uint32_t n_rays, co
   const uint32_t count = nsteps[r];
   if (count == 0) return;
   const uint32_t p = ray_list[r];
-  const RayDesc d = rays[p];
+  const RayDesc d = rays[ray_index(F, p)];
   const bool clearing = ((d.info >> 10) & 1u) != 0;
   Dda dda;
   dda.setup(F.T.t, {d.px, d.py, d.pz}, clearing, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
             F.method == KS_METHOD_MERGED);
   // merged: normal bundles integrate before clearing bundles ([K:src/semantic_tsdf_integrator_merged.cpp:126-144])
-  const uint32_t seq = (F.method == KS_METHOD_MERGED && clearing) ? (p | (1u << 23)) : p;
+  const uint32_t seq = (F.method == KS_METHOD_MERGED && clearing) ? (p | F.clear_bit) : p;
   uint64_t* out = pairs + pair_off[r];
   uint64_t last_tile = kEmpty64;
   uint32_t slot = 0;
@@ -658,7 +722,7 @@ __global__ void __launch_bounds__(256) k_emit(FrameParams F, uint32_t n_rays, co
       P.updated[slot] = 1;
     }
     const uint32_t local = (uint32_t)(dda.cx & 7) + 8u * ((uint32_t)(dda.cy & 7) + 8u * (uint32_t)(dda.cz & 7));
-    out[s] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << kSeqBits) | seq;
+    out[s] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | seq;
     dda.advance();
   }
 }
@@ -706,9 +770,9 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
   uint32_t vox = 0;
   if (i < n_pairs) {
     key = pairs[i];
-    vox = (uint32_t)(key >> kSeqBits);
-    head = (i == 0) || ((uint32_t)(pairs[i - 1] >> kSeqBits) != vox);
-    if (head) is_long = (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> kSeqBits) == vox);
+    vox = (uint32_t)(key >> F.seq_bits);
+    head = (i == 0) || ((uint32_t)(pairs[i - 1] >> F.seq_bits) != vox);
+    if (head) is_long = (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> F.seq_bits) == vox);
   }
   const uint32_t lpos = wave_append(head && is_long, &C->n_long);
   if (!head) return;
@@ -726,8 +790,8 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
   unsigned long long j = i;
   uint64_t k = key;
   do {
-    const uint32_t rp = (uint32_t)k & kPointMask;
-    const RayDesc d = rays[rp];
+    const uint32_t rp = (uint32_t)k & F.point_mask;
+    const RayDesc d = rays[ray_index(F, rp)];
     update_tsdf_voxel<COLOR_MODE == KS_COLOR_MODE_COLOR>(F.tsdf, F.T.t, {d.px, d.py, d.pz}, v.vx, v.vy, v.vz, d.color,
                                                          d.weight, dist, weight, color);
     const uint32_t kind = (d.info >> 8) & 3u;
@@ -743,7 +807,7 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
     ++j;
     if (j >= n_pairs) break;
     k = pairs[j];
-  } while ((uint32_t)(k >> kSeqBits) == vox);
+  } while ((uint32_t)(k >> F.seq_bits) == vox);
 
   // calculateMaximumLikelihoodLabel: first strict maximum [K:src/semantic_integrator_base.cpp:352-367]
   int best = 0;
@@ -779,7 +843,7 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
   const TsdfParams& Pm = F.tsdf;
   for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
     const unsigned long long start = long_list[run];
-    const uint32_t vox = (uint32_t)(pairs[start] >> kSeqBits);
+    const uint32_t vox = (uint32_t)(pairs[start] >> F.seq_bits);
     const VoxelRef v = voxel_ref(T, vox);
     float dist = P.dist[v.vbase], weight = P.weight[v.vbase];
     uint32_t color = P.color[v.vbase];
@@ -793,15 +857,15 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
     unsigned long long base = start;
     uint64_t key_cur = (base + lane < n_pairs) ? pairs[base + lane] : kEmpty64;
     uint64_t key_nxt = (base + 64 + lane < n_pairs) ? pairs[base + 64 + lane] : kEmpty64;
-    bool in = ((uint32_t)(key_cur >> kSeqBits) == vox);
+    bool in = ((uint32_t)(key_cur >> F.seq_bits) == vox);
     RayDesc d{};
-    if (in) d = rays[(uint32_t)key_cur & kPointMask];
+    if (in) d = rays[ray_index(F, (uint32_t)key_cur & F.point_mask)];
     for (;;) {
       const int cnt = (int)__popcll(__ballot(in));  // sorted => the in-lanes form a prefix
       if (cnt == 0) break;
-      const bool in_n = ((uint32_t)(key_nxt >> kSeqBits) == vox);
+      const bool in_n = ((uint32_t)(key_nxt >> F.seq_bits) == vox);
       RayDesc d_n{};
-      if (in_n) d_n = rays[(uint32_t)key_nxt & kPointMask];
+      if (in_n) d_n = rays[ray_index(F, (uint32_t)key_nxt & F.point_mask)];
       const uint64_t key_nn = (base + 128 + lane < n_pairs) ? pairs[base + 128 + lane] : kEmpty64;
 
       // ---- per-lane, voxel-state-independent part: computeDistance + weight drop-off ----
@@ -822,7 +886,7 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
         const uint32_t kind = (d.info >> 8) & 3u;
         const uint32_t lab = d.info & 0xffu;
         if (kind == 2u) {
-          const float* dl = deltas + (size_t)((uint32_t)key_cur & kPointMask) * kNumLabels;
+          const float* dl = deltas + (size_t)((uint32_t)key_cur & F.point_mask) * kNumLabels;
 #pragma unroll
           for (int l = 0; l < kNumLabels; ++l) s_inc[lane][l] = dl[l];
         } else {
@@ -909,6 +973,11 @@ __global__ void __launch_bounds__(256) k_sqnorm(uint32_t n, const float* __restr
   const f3 p = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
   keys[i] = __float_as_uint(dot3(p, p));
   vals[i] = i;
+}
+
+__global__ void __launch_bounds__(256) k_invert(uint32_t n, const uint32_t* __restrict__ order, uint32_t* __restrict__ inv) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) inv[order[p]] = p;
 }
 
 // Host-layout export: one lane per voxel of a requested host block (edge vps), AoS records.
@@ -1001,6 +1070,7 @@ struct ks_ctx {
   uint64_t *d_pkeys = nullptr, *d_pkeys2 = nullptr;
   uint32_t *d_pvals = nullptr, *d_pvals2 = nullptr;
   uint32_t* d_order = nullptr;
+  uint32_t* d_inv_order = nullptr;
   uint32_t *d_okeys = nullptr, *d_okeys2 = nullptr, *d_ovals = nullptr;
   uint32_t* d_ray_list = nullptr;
   uint32_t* d_nsteps = nullptr;
@@ -1056,6 +1126,7 @@ int ensure_points(ks_ctx* c, size_t n) {
   if ((rc = dev_alloc(c, &c->d_pvals, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_pvals2, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_order, cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_inv_order, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_okeys, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_okeys2, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_ovals, cap))) return rc;
@@ -1191,6 +1262,14 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
   F.color_mode = cfg.color_mode;
   F.sorted_order = cfg.integration_order_mode == KS_ORDER_SORTED;
   F.n_dynamic = cfg.n_dynamic_labels;
+  {
+    const unsigned pb = bits_for(n);
+    F.point_mask = (1u << pb) - 1u;
+    F.clear_bit = (cfg.method == KS_METHOD_MERGED) ? (1u << pb) : 0u;
+    F.seq_bits = pb + (cfg.method == KS_METHOD_MERGED ? 1u : 0u);
+  }
+  F.order = F.sorted_order ? c->d_order : nullptr;
+  F.inv_order = F.sorted_order ? c->d_inv_order : nullptr;
   std::memcpy(F.dynamic_labels, cfg.dynamic_labels, 32);
   // the early-out can never fire if the threshold exceeds the longest possible ray
   const double max_steps = 3.0 * ((double)cfg.max_ray_length_m + 2.0 * cfg.truncation_distance) * c->voxel_size_inv + 8.0;
@@ -1205,25 +1284,29 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
   HIPCHK(c, hipMemcpyAsync(c->d_counters, c->h_counters, sizeof(Counters), hipMemcpyHostToDevice, st));
 
   const uint32_t nb = (uint32_t)((n + 255) / 256);
+  const uint32_t nb1k = (uint32_t)((n + 1023) / 1024);
   stage_mark(c, 0);
 
   if (F.sorted_order) {
     hipLaunchKernelGGL(k_sqnorm, dim3(nb), dim3(256), 0, st, (uint32_t)n, d_xyz, c->d_okeys, c->d_ovals);
     if ((rc = sort_pairs(c, c->d_okeys, c->d_okeys2, c->d_ovals, c->d_order, n, 0, 32))) return rc;
+    hipLaunchKernelGGL(k_invert, dim3(nb), dim3(256), 0, st, (uint32_t)n, c->d_order, c->d_inv_order);
   }
 
   if (cfg.method == KS_METHOD_FAST) {
-    hipLaunchKernelGGL(k_points_fast, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut, c->d_order,
+    hipLaunchKernelGGL(k_points_fast, dim3(nb1k), dim3(1024), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
                        c->d_rays, c->d_hash, c->d_skeys32, c->d_pvals, c->d_counters);
     stage_mark(c, 1);
     // stable sort by slot only: position order inside a slot is preserved
     if ((rc = sort_pairs(c, c->d_skeys32, c->d_skeys32b, c->d_pvals, c->d_pvals2, n, 0, kSetBits + 1))) return rc;
     stage_mark(c, 2);
-    hipLaunchKernelGGL(k_dedup, dim3(nb), dim3(256), 0, st, (uint32_t)n, c->d_skeys32b, c->d_pvals2, c->d_hash,
+    hipLaunchKernelGGL(k_dedup, dim3(nb1k), dim3(1024), 0, st, F, c->d_skeys32b, c->d_pvals2, c->d_hash,
                        c->d_start_set, c->d_ray_list, c->d_counters);
+    hipLaunchKernelGGL(k_dedup_commit, dim3(nb1k), dim3(1024), 0, st, F, c->d_skeys32b, c->d_pvals2, c->d_hash,
+                       c->d_start_set, c->d_counters);
   } else {
-    hipLaunchKernelGGL(k_points_merged, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       c->d_order, c->d_pkeys, c->d_pvals, c->d_counters);
+    hipLaunchKernelGGL(k_points_merged, dim3(nb1k), dim3(1024), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
+                       c->d_pkeys, c->d_pvals, c->d_counters);
     stage_mark(c, 1);
     if ((rc = sort_pairs(c, c->d_pkeys, c->d_pkeys2, c->d_pvals, c->d_pvals2, n, 0, 64))) return rc;
     stage_mark(c, 2);
@@ -1271,7 +1354,7 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
     hipLaunchKernelGGL(k_emit, dim3(rb), dim3(256), 0, st, F, n_rays, c->d_ray_list, c->d_rays, c->table, c->pool,
                        c->d_nsteps, c->d_pair_off, c->d_pairs);
     stage_mark(c, 5);
-    const unsigned end_bit = kSeqBits + 9 + bits_for(new_tiles);
+    const unsigned end_bit = F.seq_bits + 9 + bits_for(new_tiles);
     if ((rc = sort_keys(c, c->d_pairs, c->d_pairs2, n_pairs, 0, std::min(64u, end_bit)))) return rc;
     stage_mark(c, 6);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
@@ -1476,7 +1559,7 @@ void ks_destroy(ks_ctx* c) {
   void* ptrs[] = {c->table.keys, c->table.vals, c->table.slot_keys, c->pool.dist, c->pool.weight, c->pool.color,
                   c->pool.label, c->pool.priors, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_rays, c->d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_long_list, c->d_blong, c->d_pkeys,
-                  c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_okeys, c->d_okeys2, c->d_ovals,
+                  c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_ray_list, c->d_nsteps, c->d_pair_off, c->d_pairs, c->d_pairs2, c->d_sort_tmp, c->d_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out};
   for (void* p : ptrs)

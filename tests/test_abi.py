@@ -1,0 +1,66 @@
+"""The C-ABI library loads and exports every symbol include/ks_hip.h declares (no compute
+calls: there is no GPU in the CPU test tier)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from kimera_semantics_amd import binding as B
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "ks_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ks_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_match_binding_list():
+    assert _declared() == sorted(B.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(B.LIB_PATH):
+        B.build()
+    lib = ctypes.CDLL(B.LIB_PATH)
+    for sym in _declared():
+        assert hasattr(lib, sym), sym
+
+
+def test_config_struct_layout_and_defaults():
+    cfg = B.default_config()
+    assert ctypes.sizeof(B.KsConfig) == 4 * 23 + 32 + 1024 + 12
+    assert abs(cfg.voxel_size - 0.05) < 1e-9 and cfg.voxels_per_side == 16
+    assert abs(cfg.truncation_distance - 0.2) < 1e-7 and cfg.max_weight == 10000.0
+    assert cfg.max_consecutive_ray_collisions == 2 and abs(cfg.start_voxel_subsampling_factor - 2.0) < 1e-9
+    assert abs(cfg.semantic_measurement_probability - 0.9) < 1e-7 and cfg.color_mode == B.KS_COLOR_MODE_SEMANTIC
+    # the shared prefix is laid out like the oracle's config so one dict drives both
+    from oracle import oracle_py as O
+    for (n1, t1), (n2, t2) in zip(O.KoConfig._fields_, B.KsConfig._fields_):
+        assert n1 == n2 and t1 is t2 or ctypes.sizeof(t1) == ctypes.sizeof(t2)
+        assert getattr(O.KoConfig, n1).offset == getattr(B.KsConfig, n2).offset
+
+
+def test_no_cpu_fallback_without_gpu():
+    """On a machine without a GPU the product path must fail loudly, not compute on the CPU."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:
+        has_gpu = False
+    if has_gpu:
+        pytest.skip("GPU present")
+    with pytest.raises(B.KsError) as e:
+        B.HipIntegrator(B.default_config())
+    assert e.value.code in (B.KS_ERR_NO_DEVICE, -4)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "kimera_semantics_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_py" not in txt and "ks_oracle" not in txt and "libks_oracle" not in txt, f

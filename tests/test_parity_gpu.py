@@ -87,3 +87,13 @@ def test_close_up_long_runs_exact(method, color_mode):
         assert rep["tsdf_color_mismatches"] <= rep["voxels_compared"] * 1e-3
     else:
         compare_maps(o, h, exact=True)
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_sorted_integration_order_exact(method):
+    f = small_frame(seed=5, w=96, h=72)
+    o, h = _pair(method, max_consecutive_ray_collisions=NO_EARLY_OUT, integration_order_mode=1)
+    so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    assert (so.n_rays_cast, so.n_voxel_updates) == (sh.n_rays_cast, sh.n_voxel_updates)
+    compare_maps(o, h, exact=True)
