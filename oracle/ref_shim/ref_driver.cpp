@@ -1,0 +1,103 @@
+// C driver around the REAL reference classes (compiled from /root/reference by build_ref.sh):
+// kimera::SemanticTsdfIntegratorFactory::create(...) -> integratePointCloud(...), exposing the
+// resulting Layers so tests can compare them with the oracle's restatement bit for bit.
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <kimera_semantics/color.h>
+#include <kimera_semantics/semantic_tsdf_integrator_factory.h>
+#include <kimera_semantics/semantic_tsdf_integrator_merged.h>
+#include <kimera_semantics/semantic_voxel.h>
+
+namespace vxb = voxblox;
+
+struct kr_ctx {
+  std::unique_ptr<vxb::Layer<vxb::TsdfVoxel>> tsdf_layer;
+  std::unique_ptr<vxb::Layer<kimera::SemanticVoxel>> semantic_layer;
+  std::unique_ptr<vxb::TsdfIntegratorBase> integrator;
+  int vps;
+  bool merged;
+};
+
+extern "C" {
+
+// label_csv: path of a "name,red,green,blue,alpha,id" file (SemanticLabel2Color input)
+kr_ctx* kr_create(const char* method, float voxel_size, int vps, float truncation, float max_ray, float p_match,
+                  int color_mode, const unsigned char* dynamic_labels, int n_dynamic, int threads,
+                  int max_consecutive_ray_collisions, const char* order_mode, const char* label_csv) {
+  auto* c = new kr_ctx();
+  c->vps = vps;
+  c->merged = std::string(method) == "merged";
+  c->tsdf_layer.reset(new vxb::Layer<vxb::TsdfVoxel>(voxel_size, vps));
+  c->semantic_layer.reset(new vxb::Layer<kimera::SemanticVoxel>(voxel_size, vps));
+  vxb::TsdfIntegratorBase::Config cfg;
+  cfg.default_truncation_distance = truncation;
+  cfg.max_ray_length_m = max_ray;
+  cfg.integrator_threads = threads;
+  cfg.max_consecutive_ray_collisions = max_consecutive_ray_collisions;
+  cfg.integration_order_mode = order_mode;
+  kimera::SemanticIntegratorBase::SemanticConfig sc;
+  sc.semantic_measurement_probability_ = p_match;
+  sc.color_mode = static_cast<kimera::ColorMode>(color_mode);
+  sc.semantic_label_to_color_ = std::make_shared<kimera::SemanticLabel2Color>(std::string(label_csv));
+  for (int i = 0; i < n_dynamic; ++i) sc.dynamic_labels_.push_back(dynamic_labels[i]);
+  c->integrator = kimera::SemanticTsdfIntegratorFactory::create(std::string(method), cfg, sc, c->tsdf_layer.get(),
+                                                                c->semantic_layer.get());
+  return c;
+}
+
+void kr_destroy(kr_ctx* c) { delete c; }
+
+// The virtual the server calls: labels come from the colours through the CSV map.
+void kr_integrate(kr_ctx* c, const float* T, const float* xyz, const unsigned char* rgba, size_t n, int freespace) {
+  vxb::Transformation T_G_C(T[0], T[1], T[2], T[3], vxb::Point(T[4], T[5], T[6]));
+  vxb::Pointcloud pts(n);
+  vxb::Colors cols(n);
+  for (size_t i = 0; i < n; ++i) {
+    pts[i] = vxb::Point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    cols[i] = vxb::Color(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2], rgba[4 * i + 3]);
+  }
+  c->integrator->integratePointCloud(T_G_C, pts, cols, freespace != 0);
+}
+
+size_t kr_num_blocks(kr_ctx* c) { return c->tsdf_layer->getNumberOfAllocatedBlocks(); }
+size_t kr_num_semantic_blocks(kr_ctx* c) { return c->semantic_layer->getNumberOfAllocatedBlocks(); }
+
+void kr_block_indices(kr_ctx* c, int* out) {
+  vxb::BlockIndexList l;
+  c->tsdf_layer->getAllAllocatedBlocks(&l);
+  size_t k = 0;
+  for (const auto& b : l) {
+    out[3 * k] = b.x(); out[3 * k + 1] = b.y(); out[3 * k + 2] = b.z();
+    ++k;
+  }
+}
+
+// tsdf_out: vps^3 * 12 B, sem_out: vps^3 * 92 B (label, 3 pad, priors[21], rgba)
+int kr_get_block(kr_ctx* c, const int* idx, unsigned char* tsdf_out, unsigned char* sem_out) {
+  const vxb::BlockIndex b(idx[0], idx[1], idx[2]);
+  auto tb = c->tsdf_layer->getBlockPtrByIndex(b);
+  auto sb = c->semantic_layer->getBlockPtrByIndex(b);
+  if (!tb || !sb) return 1;
+  const size_t nv = static_cast<size_t>(c->vps) * c->vps * c->vps;
+  for (size_t i = 0; i < nv; ++i) {
+    const vxb::TsdfVoxel& v = tb->getVoxelByLinearIndex(i);
+    std::memcpy(tsdf_out + 12 * i, &v.distance, 4);
+    std::memcpy(tsdf_out + 12 * i + 4, &v.weight, 4);
+    tsdf_out[12 * i + 8] = v.color.r; tsdf_out[12 * i + 9] = v.color.g; tsdf_out[12 * i + 10] = v.color.b; tsdf_out[12 * i + 11] = v.color.a;
+    const kimera::SemanticVoxel& s = sb->getVoxelByLinearIndex(i);
+    unsigned char* o = sem_out + 92 * i;
+    std::memset(o, 0, 92);
+    o[0] = s.semantic_label;
+    for (int l = 0; l < 21; ++l) {
+      const float p = s.semantic_priors[l];
+      std::memcpy(o + 4 + 4 * l, &p, 4);
+    }
+    o[88] = s.color.r; o[89] = s.color.g; o[90] = s.color.b; o[91] = s.color.a;
+  }
+  return 0;
+}
+
+}  // extern "C"
