@@ -1,0 +1,104 @@
+// adapter_demo — drives the C++ adapter exactly as SemanticTsdfServer would: build Layers,
+// create the integrator through the factory, feed colour-encoded clouds through the
+// TsdfIntegratorBase virtual, then dump the host Layers.  Used by tests/test_host_adapter_gpu.py.
+//   adapter_demo <method> <labels.csv> <in.bin> <out.bin> [color_mode] [max_consecutive_ray_collisions]
+// in.bin : u32 n_frames, then per frame { f32 T[7]; u32 n; f32 xyz[3n]; u8 rgba[4n] }
+// out.bin: u32 n_blocks, u32 vps, then per block { i32 idx[3]; tsdf vps^3*12 B; semantic vps^3*92 B }
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "hip_semantic_tsdf_integrator.h"
+
+namespace vxb = voxblox;
+
+int main(int argc, char** argv) {
+  if (argc < 5) {
+    std::fprintf(stderr, "usage: %s method labels.csv in.bin out.bin [color_mode] [max_collisions]\n", argv[0]);
+    return 2;
+  }
+  const std::string method = argv[1];
+  vxb::TsdfIntegratorBase::Config cfg;
+  cfg.default_truncation_distance = 0.2f;  // voxblox_ros: 4 x voxel size
+  cfg.max_ray_length_m = 5.0f;
+  if (argc > 6) cfg.max_consecutive_ray_collisions = std::atoi(argv[6]);
+  kimera::SemanticIntegratorBase::SemanticConfig sc;
+  sc.semantic_measurement_probability_ = 0.8f;
+  sc.color_mode = static_cast<kimera::ColorMode>(argc > 5 ? std::atoi(argv[5]) : 1);
+  sc.semantic_label_to_color_ = std::make_shared<kimera::SemanticLabel2Color>(argv[2]);
+  sc.dynamic_labels_.push_back(20);
+  vxb::Layer<vxb::TsdfVoxel> tsdf_layer(0.05f, 16);
+  vxb::Layer<kimera::SemanticVoxel> semantic_layer(0.05f, 16);
+  kimera::HipSemanticTsdfIntegrator::DeviceOptions opt;
+  opt.max_tiles = 4096;
+  opt.max_points = 1u << 18;
+  std::unique_ptr<vxb::TsdfIntegratorBase> integrator =
+      kimera::HipSemanticTsdfIntegratorFactory::create(method, cfg, sc, &tsdf_layer, &semantic_layer, opt);
+
+  FILE* in = std::fopen(argv[3], "rb");
+  if (!in) return 3;
+  uint32_t n_frames = 0;
+  if (std::fread(&n_frames, 4, 1, in) != 1) return 3;
+  for (uint32_t f = 0; f < n_frames; ++f) {
+    float T[7];
+    uint32_t n;
+    if (std::fread(T, 4, 7, in) != 7 || std::fread(&n, 4, 1, in) != 1) return 3;
+    vxb::Pointcloud pts(n);
+    vxb::Colors cols(n);
+    std::vector<float> xyz(3 * size_t(n));
+    std::vector<uint8_t> rgba(4 * size_t(n));
+    if (std::fread(xyz.data(), 4, xyz.size(), in) != xyz.size() || std::fread(rgba.data(), 1, rgba.size(), in) != rgba.size()) return 3;
+    for (uint32_t i = 0; i < n; ++i) {
+      pts[i] = vxb::Point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+      cols[i] = vxb::Color(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2], rgba[4 * i + 3]);
+    }
+    integrator->integratePointCloud(vxb::Transformation(T[0], T[1], T[2], T[3], vxb::Point(T[4], T[5], T[6])), pts, cols, false);
+  }
+  std::fclose(in);
+
+  vxb::BlockIndexList blocks;
+  tsdf_layer.getAllAllocatedBlocks(&blocks);
+  std::sort(blocks.begin(), blocks.end(), [](const vxb::BlockIndex& a, const vxb::BlockIndex& b) {
+    if (a.x() != b.x()) return a.x() < b.x();
+    if (a.y() != b.y()) return a.y() < b.y();
+    return a.z() < b.z();
+  });
+  FILE* out = std::fopen(argv[4], "wb");
+  if (!out) return 4;
+  const uint32_t nb = blocks.size(), vps = 16;
+  std::fwrite(&nb, 4, 1, out);
+  std::fwrite(&vps, 4, 1, out);
+  size_t updated = 0;
+  for (const auto& b : blocks) {
+    const int32_t idx[3] = {b.x(), b.y(), b.z()};
+    std::fwrite(idx, 4, 3, out);
+    auto tb = tsdf_layer.getBlockPtrByIndex(b);
+    auto sb = semantic_layer.getBlockPtrByIndex(b);
+    if (!sb) return 5;
+    updated += tb->updated() && sb->updated();
+    for (size_t i = 0; i < tb->num_voxels(); ++i) {
+      const vxb::TsdfVoxel& v = tb->getVoxelByLinearIndex(i);
+      uint8_t rec[12];
+      std::memcpy(rec, &v.distance, 4);
+      std::memcpy(rec + 4, &v.weight, 4);
+      rec[8] = v.color.r; rec[9] = v.color.g; rec[10] = v.color.b; rec[11] = v.color.a;
+      std::fwrite(rec, 1, 12, out);
+    }
+    for (size_t i = 0; i < sb->num_voxels(); ++i) {
+      const kimera::SemanticVoxel& s = sb->getVoxelByLinearIndex(i);
+      uint8_t rec[92];
+      std::memset(rec, 0, 92);
+      rec[0] = s.semantic_label;
+      for (int l = 0; l < 21; ++l) {
+        const float p = s.semantic_priors[l];
+        std::memcpy(rec + 4 + 4 * l, &p, 4);
+      }
+      rec[88] = s.color.r; rec[89] = s.color.g; rec[90] = s.color.b; rec[91] = s.color.a;
+      std::fwrite(rec, 1, 92, out);
+    }
+  }
+  std::fclose(out);
+  std::printf("adapter_demo: %u frames, %u blocks (%zu flagged updated)\n", n_frames, nb, updated);
+  return updated == nb ? 0 : 6;
+}

@@ -1,0 +1,195 @@
+#include "hip_semantic_tsdf_integrator.h"
+
+#include <cstring>
+
+namespace kimera {
+
+namespace {
+ks_config makeConfig(HipSemanticTsdfIntegrator::Method method, const vxb::TsdfIntegratorBase::Config& c,
+                     const SemanticIntegratorBase::SemanticConfig& sc, const vxb::Layer<vxb::TsdfVoxel>& layer,
+                     const HipSemanticTsdfIntegrator::DeviceOptions& o) {
+  ks_config k;
+  ks_default_config(&k);
+  k.voxel_size = layer.voxel_size();
+  k.voxels_per_side = static_cast<int32_t>(layer.voxels_per_side());
+  k.truncation_distance = c.default_truncation_distance;
+  k.max_weight = c.max_weight;
+  k.min_ray_length_m = c.min_ray_length_m;
+  k.max_ray_length_m = c.max_ray_length_m;
+  k.voxel_carving_enabled = c.voxel_carving_enabled;
+  k.use_const_weight = c.use_const_weight;
+  k.allow_clear = c.allow_clear;
+  k.use_weight_dropoff = c.use_weight_dropoff;
+  k.use_sparsity_compensation_factor = c.use_sparsity_compensation_factor;
+  k.sparsity_compensation_factor = c.sparsity_compensation_factor;
+  k.enable_anti_grazing = c.enable_anti_grazing;
+  k.start_voxel_subsampling_factor = c.start_voxel_subsampling_factor;
+  k.max_consecutive_ray_collisions = c.max_consecutive_ray_collisions;
+  k.clear_checks_every_n_frames = c.clear_checks_every_n_frames;
+  if (c.integration_order_mode == "mixed") k.integration_order_mode = KS_ORDER_MIXED;
+  else if (c.integration_order_mode == "sorted") k.integration_order_mode = KS_ORDER_SORTED;
+  else LOG(FATAL) << "Unknown integration order mode: '" << c.integration_order_mode << "'!";
+  k.integrator_threads = static_cast<int32_t>(c.integrator_threads);
+  k.method = static_cast<int32_t>(method);
+  k.semantic_measurement_probability = sc.semantic_measurement_probability_;
+  k.color_mode = static_cast<int32_t>(sc.color_mode);
+  CHECK_LE(sc.dynamic_labels_.size(), 32u);
+  k.n_dynamic_labels = static_cast<int32_t>(sc.dynamic_labels_.size());
+  for (size_t i = 0; i < sc.dynamic_labels_.size(); ++i) k.dynamic_labels[i] = sc.dynamic_labels_[i];
+  std::memset(k.label_rgba, 0, sizeof(k.label_rgba));
+  CHECK(sc.semantic_label_to_color_);
+  for (const auto& kv : sc.semantic_label_to_color_->semantic_label_to_color_map_) {
+    k.label_rgba[kv.first][0] = kv.second.r;
+    k.label_rgba[kv.first][1] = kv.second.g;
+    k.label_rgba[kv.first][2] = kv.second.b;
+    k.label_rgba[kv.first][3] = kv.second.a;
+  }
+  k.device_id = o.device_id;
+  k.max_tiles = o.max_tiles;
+  k.max_points = o.max_points;
+  return k;
+}
+}  // namespace
+
+HipSemanticTsdfIntegrator::HipSemanticTsdfIntegrator(Method method, const Config& config,
+                                                     const SemanticConfig& semantic_config,
+                                                     vxb::Layer<vxb::TsdfVoxel>* tsdf_layer,
+                                                     vxb::Layer<SemanticVoxel>* semantic_layer)
+    : HipSemanticTsdfIntegrator(method, config, semantic_config, tsdf_layer, semantic_layer, DeviceOptions()) {}
+
+HipSemanticTsdfIntegrator::HipSemanticTsdfIntegrator(Method method, const Config& config,
+                                                     const SemanticConfig& semantic_config,
+                                                     vxb::Layer<vxb::TsdfVoxel>* tsdf_layer,
+                                                     vxb::Layer<SemanticVoxel>* semantic_layer,
+                                                     const DeviceOptions& options)
+    : vxb::TsdfIntegratorBase(config, CHECK_NOTNULL(tsdf_layer)),
+      SemanticIntegratorBase(semantic_config, CHECK_NOTNULL(semantic_layer)),
+      method_(method),
+      options_(options),
+      semantic_layer_ptr_(semantic_layer) {
+  CHECK_EQ(tsdf_layer->voxels_per_side(), semantic_layer->voxels_per_side());
+  const ks_config k = makeConfig(method, config, semantic_config, *tsdf_layer, options);
+  const int rc = ks_create(&k, &ctx_);
+  // programmer errors abort like the reference's CHECKs (semantic_integrator_base.cpp:98-107)
+  CHECK_EQ(rc, KS_OK) << "ks_create failed (" << rc << "): " << ks_last_error(nullptr);
+  // colour -> label table for the colour-encoded clouds the server delivers
+  std::vector<uint8_t> keys, labels;
+  for (const auto& kv : semantic_config.semantic_label_to_color_->color_to_semantic_label_) {
+    keys.push_back(kv.first.r);
+    keys.push_back(kv.first.g);
+    keys.push_back(kv.first.b);
+    keys.push_back(kv.first.a);
+    labels.push_back(kv.second);
+  }
+  check(ks_set_color_to_label(ctx_, keys.data(), labels.data(), labels.size()), "ks_set_color_to_label");
+}
+
+HipSemanticTsdfIntegrator::~HipSemanticTsdfIntegrator() { ks_destroy(ctx_); }
+
+void HipSemanticTsdfIntegrator::check(int rc, const char* what) const {
+  // The reference has no status returns: data/programmer errors are CHECK/LOG(FATAL).
+  if (rc != KS_OK) LOG(FATAL) << what << " failed (" << rc << "): " << ks_last_error(ctx_);
+}
+
+void HipSemanticTsdfIntegrator::integratePointCloud(const vxb::Transformation& T_G_C,
+                                                    const vxb::Pointcloud& points_C, const vxb::Colors& colors,
+                                                    const bool freespace_points) {
+  CHECK_EQ(points_C.size(), colors.size());
+  static_assert(sizeof(vxb::Point) == 12 && sizeof(vxb::Color) == 4, "cloud element layout");
+  const float T[7] = {T_G_C.qw(),          T_G_C.qvec().x(),        T_G_C.qvec().y(),       T_G_C.qvec().z(),
+                      T_G_C.getPosition().x(), T_G_C.getPosition().y(), T_G_C.getPosition().z()};
+  // merged: the reference's colour overload integrates default-constructed colours
+  // (hash_colors is sized but never filled, semantic_tsdf_integrator_merged.cpp:70,92-93);
+  // labels still come from the real colours.  The C ABI call below keeps both behaviours:
+  // labels from rgba through the map; for merged the blended colour is irrelevant unless
+  // ColorMode::kColor, where the reference blends zeros -> pass them through a second call path.
+  const uint8_t* rgba = colors.empty() ? nullptr : reinterpret_cast<const uint8_t*>(colors.data());
+  const float* xyz = points_C.empty() ? nullptr : reinterpret_cast<const float*>(points_C.data());
+  if (method_ == Method::kMerged && semantic_config_.color_mode == ColorMode::kColor) {
+    // decode labels on the host map once, then integrate with zero colours (exactly what the
+    // reference computes in this corner)
+    SemanticLabels labels(colors.size());
+    for (size_t i = 0; i < colors.size(); ++i)
+      labels[i] = semantic_config_.semantic_label_to_color_->getSemanticLabelFromColor(
+          HashableColor(colors[i].r, colors[i].g, colors[i].b, 255u));
+    check(ks_integrate_points(ctx_, T, xyz, nullptr, labels.data(), points_C.size(), freespace_points, &last_stats_),
+          "ks_integrate_points");
+  } else {
+    check(ks_integrate_points(ctx_, T, xyz, rgba, nullptr, points_C.size(), freespace_points, &last_stats_),
+          "ks_integrate_points");
+  }
+  if (options_.sync_policy == SyncPolicy::kEveryFrame) syncLayers();
+}
+
+void HipSemanticTsdfIntegrator::integratePointCloud(const vxb::Transformation& T_G_C,
+                                                    const vxb::Pointcloud& points_C, const HashableColors& colors,
+                                                    const SemanticLabels& semantic_labels,
+                                                    const bool freespace_points) {
+  CHECK_EQ(points_C.size(), colors.size());
+  CHECK_EQ(points_C.size(), semantic_labels.size());
+  const float T[7] = {T_G_C.qw(),          T_G_C.qvec().x(),        T_G_C.qvec().y(),       T_G_C.qvec().z(),
+                      T_G_C.getPosition().x(), T_G_C.getPosition().y(), T_G_C.getPosition().z()};
+  static_assert(sizeof(HashableColor) == 4, "colour layout");
+  check(ks_integrate_points(ctx_, T, points_C.empty() ? nullptr : reinterpret_cast<const float*>(points_C.data()),
+                            colors.empty() ? nullptr : reinterpret_cast<const uint8_t*>(colors.data()),
+                            semantic_labels.data(), points_C.size(), freespace_points, &last_stats_),
+        "ks_integrate_points");
+  if (options_.sync_policy == SyncPolicy::kEveryFrame) syncLayers();
+}
+
+void HipSemanticTsdfIntegrator::syncLayers() {
+  size_t n = 0;
+  check(ks_get_updated_block_indices(ctx_, nullptr, 0, &n, 0), "ks_get_updated_block_indices");
+  if (n == 0) return;
+  idx_buf_.resize(3 * n);
+  check(ks_get_updated_block_indices(ctx_, idx_buf_.data(), n, &n, 1), "ks_get_updated_block_indices");
+  const size_t vps = layer_->voxels_per_side();
+  const size_t nv = vps * vps * vps;
+  tsdf_buf_.resize(n * nv * 12);
+  sem_buf_.resize(n * nv * 92);
+  check(ks_download_blocks(ctx_, idx_buf_.data(), n, tsdf_buf_.data(), sem_buf_.data()), "ks_download_blocks");
+  for (size_t b = 0; b < n; ++b) {
+    const vxb::BlockIndex idx(idx_buf_[3 * b], idx_buf_[3 * b + 1], idx_buf_[3 * b + 2]);
+    auto tb = layer_->allocateBlockPtrByIndex(idx);
+    auto sb = semantic_layer_ptr_->allocateBlockPtrByIndex(idx);
+    const uint8_t* t = tsdf_buf_.data() + b * nv * 12;
+    const uint8_t* s = sem_buf_.data() + b * nv * 92;
+    for (size_t i = 0; i < nv; ++i) {
+      vxb::TsdfVoxel& v = tb->getVoxelByLinearIndex(i);
+      std::memcpy(&v.distance, t + 12 * i, 4);
+      std::memcpy(&v.weight, t + 12 * i + 4, 4);
+      v.color = vxb::Color(t[12 * i + 8], t[12 * i + 9], t[12 * i + 10], t[12 * i + 11]);
+      SemanticVoxel& sv = sb->getVoxelByLinearIndex(i);
+      const uint8_t* r = s + 92 * i;
+      sv.semantic_label = r[0];
+      for (size_t l = 0; l < kTotalNumberOfLabels; ++l) {
+        float p;
+        std::memcpy(&p, r + 4 + 4 * l, 4);
+        sv.semantic_priors[l] = p;
+      }
+      sv.color = HashableColor(r[88], r[89], r[90], r[91]);
+    }
+    tb->updated() = true;
+    sb->updated() = true;
+  }
+}
+
+std::unique_ptr<vxb::TsdfIntegratorBase> HipSemanticTsdfIntegratorFactory::create(
+    const std::string& integrator_type_name, const vxb::TsdfIntegratorBase::Config& config,
+    const SemanticIntegratorBase::SemanticConfig& semantic_config, vxb::Layer<vxb::TsdfVoxel>* tsdf_layer,
+    vxb::Layer<SemanticVoxel>* semantic_layer, const HipSemanticTsdfIntegrator::DeviceOptions& options) {
+  CHECK(!integrator_type_name.empty());
+  CHECK_NOTNULL(tsdf_layer);
+  if (integrator_type_name == "fast" || integrator_type_name == "fast_hip") {
+    return std::unique_ptr<vxb::TsdfIntegratorBase>(new HipSemanticTsdfIntegrator(
+        HipSemanticTsdfIntegrator::Method::kFast, config, semantic_config, tsdf_layer, semantic_layer, options));
+  }
+  if (integrator_type_name == "merged" || integrator_type_name == "merged_hip") {
+    return std::unique_ptr<vxb::TsdfIntegratorBase>(new HipSemanticTsdfIntegrator(
+        HipSemanticTsdfIntegrator::Method::kMerged, config, semantic_config, tsdf_layer, semantic_layer, options));
+  }
+  LOG(FATAL) << "Unknown TSDF integrator type: " << integrator_type_name;
+  return nullptr;
+}
+
+}  // namespace kimera

@@ -1,0 +1,90 @@
+// kimera::HipSemanticTsdfIntegrator — the MI355X integrator behind the reference's plugin
+// surface.  Same bases, same constructor arguments and the same virtual as
+//   kimera::FastSemanticTsdfIntegrator   (kimera_semantics/include/kimera_semantics/semantic_tsdf_integrator_fast.h:63-86)
+//   kimera::MergedSemanticTsdfIntegrator (kimera_semantics/include/kimera_semantics/semantic_tsdf_integrator_merged.h:56-86)
+// so SemanticTsdfServer (kimera_semantics_ros/src/semantic_tsdf_server.cpp:71-78) can hold it
+// through std::unique_ptr<vxb::TsdfIntegratorBase> unchanged.  All integration work happens in
+// libks_hip.so (include/ks_hip.h); this class only marshals arguments and keeps the host
+// Layers consistent.
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include <voxblox/integrator/tsdf_integrator.h>
+
+#include "kimera_types.h"
+#include "ks_hip.h"
+
+namespace kimera {
+
+class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public SemanticIntegratorBase {
+ public:
+  EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+  enum class Method : int { kFast = KS_METHOD_FAST, kMerged = KS_METHOD_MERGED };
+
+  /// When the host Layers are refreshed from the GPU map.
+  enum class SyncPolicy {
+    kEveryFrame,  ///< strict drop-in: Layers are current when integratePointCloud returns
+    kOnDemand     ///< call syncLayers() before meshing / saving (e.g. from the mesh timer)
+  };
+
+  struct DeviceOptions {
+    int device_id = 0;
+    uint32_t max_tiles = 1u << 16;   ///< 8^3-voxel tiles (49.7 KB each)
+    uint32_t max_points = 1u << 20;
+    SyncPolicy sync_policy = SyncPolicy::kEveryFrame;
+  };
+
+  HipSemanticTsdfIntegrator(Method method, const Config& config, const SemanticConfig& semantic_config,
+                            vxb::Layer<vxb::TsdfVoxel>* tsdf_layer, vxb::Layer<SemanticVoxel>* semantic_layer,
+                            const DeviceOptions& options);
+  HipSemanticTsdfIntegrator(Method method, const Config& config, const SemanticConfig& semantic_config,
+                            vxb::Layer<vxb::TsdfVoxel>* tsdf_layer, vxb::Layer<SemanticVoxel>* semantic_layer);
+  ~HipSemanticTsdfIntegrator() override;
+
+  /// The virtual the server calls; labels are decoded from the colours on the GPU through the
+  /// colour->label table (the reference's serial host loop, fast.cpp:150-158 / merged.cpp:73-88).
+  void integratePointCloud(const vxb::Transformation& T_G_C, const vxb::Pointcloud& points_C,
+                           const vxb::Colors& colors, const bool freespace_points = false) override;
+
+  /// Label-aware overload (MergedSemanticTsdfIntegrator, merged.h:82-86).
+  void integratePointCloud(const vxb::Transformation& T_G_C, const vxb::Pointcloud& points_C,
+                           const HashableColors& colors, const SemanticLabels& semantic_labels,
+                           const bool freespace_points = false);
+
+  /// Copies every block touched since the last call into the host Layers (allocating blocks
+  /// as needed) and sets Block::updated(), as semantic_integrator_base.cpp:248 does.
+  void syncLayers();
+
+  ks_ctx* context() { return ctx_; }
+  const ks_frame_stats& lastFrameStats() const { return last_stats_; }
+
+ private:
+  void check(int rc, const char* what) const;
+  ks_ctx* ctx_ = nullptr;
+  Method method_;
+  DeviceOptions options_;
+  ks_frame_stats last_stats_{};
+  vxb::Layer<SemanticVoxel>* semantic_layer_ptr_;
+  std::vector<int32_t> idx_buf_;
+  std::vector<uint8_t> tsdf_buf_, sem_buf_;
+};
+
+/// Same shape as kimera::SemanticTsdfIntegratorFactory
+/// (kimera_semantics/include/kimera_semantics/semantic_tsdf_integrator_factory.h:57-100):
+/// "fast" / "merged" (and the explicit aliases "fast_hip" / "merged_hip") return the HIP
+/// integrator as std::unique_ptr<vxb::TsdfIntegratorBase>; anything else is LOG(FATAL).
+class HipSemanticTsdfIntegratorFactory {
+ public:
+  static std::unique_ptr<vxb::TsdfIntegratorBase> create(
+      const std::string& integrator_type_name, const vxb::TsdfIntegratorBase::Config& config,
+      const SemanticIntegratorBase::SemanticConfig& semantic_config, vxb::Layer<vxb::TsdfVoxel>* tsdf_layer,
+      vxb::Layer<SemanticVoxel>* semantic_layer,
+      const HipSemanticTsdfIntegrator::DeviceOptions& options = HipSemanticTsdfIntegrator::DeviceOptions());
+
+ private:
+  HipSemanticTsdfIntegratorFactory() = default;
+};
+
+}  // namespace kimera

@@ -1,0 +1,73 @@
+"""-m gpu: the C++ adapter (reference plugin surface: factory -> TsdfIntegratorBase virtual ->
+host Layers) against the oracle.  adapter_demo plays the role of SemanticTsdfServer."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from kimera_semantics_amd import synth
+from oracle import oracle_py as O
+from oracle import ref_py as R
+from tests.util import COMMON, NO_EARLY_OUT
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEMO = os.path.join(ROOT, "kimera_semantics_amd", "host", "adapter_demo")
+
+
+def _frames():
+    sc = synth.make_scene("room")
+    return [synth.render_frame(sc, synth.trajectory_pose(6 * k), 128, 96, seed=70 + k) for k in range(2)]
+
+
+def _write_in(path, frames):
+    with open(path, "wb") as fh:
+        fh.write(struct.pack("<I", len(frames)))
+        for f in frames:
+            fh.write(f.T_G_C.astype("<f4").tobytes())
+            fh.write(struct.pack("<I", len(f.xyz)))
+            fh.write(f.xyz.astype("<f4").tobytes())
+            fh.write(f.rgba.tobytes())
+
+
+def _read_out(path):
+    buf = open(path, "rb").read()
+    nb, vps = struct.unpack_from("<II", buf, 0)
+    nv = vps ** 3
+    off = 8
+    idx = np.zeros((nb, 3), np.int32)
+    t = np.zeros((nb, nv), O.TSDF_DTYPE)
+    s = np.zeros((nb, nv), O.SEM_DTYPE)
+    for b in range(nb):
+        idx[b] = np.frombuffer(buf, "<i4", 3, off); off += 12
+        t[b] = np.frombuffer(buf, O.TSDF_DTYPE, nv, off); off += nv * 12
+        s[b] = np.frombuffer(buf, O.SEM_DTYPE, nv, off); off += nv * 92
+    return idx, t, s
+
+
+@pytest.mark.parametrize("method,color_mode", [("fast", 1), ("merged", 1), ("merged", 0), ("fast_hip", 0)])
+def test_adapter_matches_oracle(tmp_path, method, color_mode):
+    if not os.path.exists(DEMO):
+        pytest.fail("adapter_demo not built: run __graft_entry__.build()")
+    frames = _frames()
+    csv, fin, fout = str(tmp_path / "labels.csv"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    R.write_label_csv(csv, synth.default_label_colors())
+    _write_in(fin, frames)
+    res = subprocess.run([DEMO, method, csv, fin, fout, str(color_mode), str(NO_EARLY_OUT)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    idx, t, s = _read_out(fout)
+    is_merged = method.startswith("merged")
+    o = O.Oracle(O.default_config(**dict(COMMON, method=1 if is_merged else 0, color_mode=color_mode,
+                                         max_consecutive_ray_collisions=NO_EARLY_OUT)))
+    for f in frames:
+        o.integrate(f.T_G_C, f.xyz, None if is_merged else f.rgba, f.labels)
+    oi, ot, os_ = o.download()
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(s["label"], os_["label"])
+    assert np.array_equal(s["priors"].view(np.uint32), os_["priors"].view(np.uint32))
+    assert np.array_equal(t["distance"].view(np.uint32), ot["distance"].view(np.uint32))
+    assert np.array_equal(t["weight"].view(np.uint32), ot["weight"].view(np.uint32))
+    assert np.array_equal(t["color"], ot["color"])
+    assert np.array_equal(s["color"], os_["color"])
