@@ -140,6 +140,10 @@ int ks_get_updated_block_indices(ks_ctx* ctx, int32_t* out_xyz, size_t cap, size
  * Either may be NULL.  Absent blocks yield default-constructed voxels. */
 int ks_download_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, void* tsdf_out, void* sem_out);
 
+/* Diagnostics (used by tests): stable LSD radix sort of n HOST keys (key_bits = 32 or 64, bits
+ * [0,end_bit)) and optional u32 payload with the library's own GPU sort. */
+int ks_debug_radix_sort(ks_ctx* ctx, void* keys, uint32_t* vals, size_t n, int key_bits, unsigned end_bit);
+
 int ks_synchronize(ks_ctx* ctx);
 void* ks_stream(ks_ctx* ctx); /* the hipStream_t all kernels are launched on */
 int ks_profile_enable(ks_ctx* ctx, int on);

@@ -31,7 +31,7 @@ SEM_DTYPE = np.dtype([("label", "u1"), ("pad", "u1", (3,)), ("priors", "<f4", (N
 ABI_SYMBOLS = [
     "ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_set_color_to_label",
     "ks_integrate_points", "ks_integrate_points_device", "ks_num_blocks", "ks_get_block_indices",
-    "ks_get_updated_block_indices", "ks_download_blocks", "ks_synchronize", "ks_stream",
+    "ks_get_updated_block_indices", "ks_download_blocks", "ks_debug_radix_sort", "ks_synchronize", "ks_stream",
     "ks_profile_enable", "ks_profile_get",
 ]
 
@@ -68,7 +68,7 @@ class KsProfile(C.Structure):
 def build(force: bool = False) -> str:
     """Compile libks_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("ks_hip.hip", "ks_device_math.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("ks_hip.hip", "ks_device_math.h", "ks_radix_sort.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "ks_hip.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
@@ -102,6 +102,7 @@ def lib():
         L.ks_get_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.ks_get_updated_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
         L.ks_download_blocks.argtypes = [vp, vp, C.c_size_t, vp, vp]
+        L.ks_debug_radix_sort.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_uint]
         L.ks_synchronize.argtypes = [vp]
         L.ks_stream.argtypes = [vp]
         L.ks_stream.restype = vp
@@ -218,6 +219,14 @@ class HipIntegrator:
         if len(indices):
             self._chk(lib().ks_download_blocks(self._h, _ptr(indices), len(indices), _ptr(t), _ptr(s)))
         return indices, t, s
+
+    def debug_radix_sort(self, keys: np.ndarray, vals=None, end_bit=None):
+        keys = np.ascontiguousarray(keys).copy()
+        bits = keys.dtype.itemsize * 8
+        vals = None if vals is None else np.ascontiguousarray(vals, dtype=np.uint32).copy()
+        self._chk(lib().ks_debug_radix_sort(self._h, _ptr(keys), _ptr(vals), keys.shape[0], bits,
+                                            bits if end_bit is None else end_bit))
+        return keys, vals
 
     def synchronize(self):
         self._chk(lib().ks_synchronize(self._h))

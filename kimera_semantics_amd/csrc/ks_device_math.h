@@ -218,21 +218,22 @@ struct TsdfParams {
 };
 
 // vxb::TsdfIntegratorBase::updateTsdfVoxel (+ computeDistance) —
-// [K:src/semantic_tsdf_integrator_fast.cpp:128], [K:src/semantic_tsdf_integrator_merged.cpp:317-319].
-// Returns the sdf so callers can skip colour work; blend == false skips the colour blend
-// (ColorMode::kSemantic overwrites the colour right after, semantic_integrator_base.cpp:179).
-template <bool BLEND>
-__device__ __forceinline__ void update_tsdf_voxel(const TsdfParams& P, f3 origin, f3 point_G, int vx, int vy, int vz,
-                                                  uint32_t color, float weight, float& distance, float& vweight,
-                                                  uint32_t& vcolor) {
+// [K:src/semantic_tsdf_integrator_fast.cpp:128], [K:src/semantic_tsdf_integrator_merged.cpp:317-319],
+// split in two halves so kernels can evaluate the half that does not depend on the voxel
+// state (sdf, updated weight) for many updates in parallel:
+//   tsdf_operands : computeDistance + weight drop-off + sparsity compensation
+//   tsdf_combine  : the voxel-state recurrence (weighted mean, clamp, optional colour blend)
+// The arithmetic and its order are exactly those of the single function.
+__device__ __forceinline__ void tsdf_operands(const TsdfParams& P, f3 origin, f3 point_G, int vx, int vy, int vz,
+                                              float weight, float& sdf, float& uw) {
   // getCenterPointFromGridIndex: (float(i) + 0.5) * voxel_size (exact in f32 == upstream's double evaluation)
   const f3 c = {((float)vx + 0.5f) * P.voxel_size, ((float)vy + 0.5f) * P.voxel_size, ((float)vz + 0.5f) * P.voxel_size};
   const f3 v_voxel_origin = sub3(c, origin);
   const f3 v_point_origin = sub3(point_G, origin);
   const float dist_G = norm3(v_point_origin);
   const float dist_G_V = dot3(v_voxel_origin, v_point_origin) / dist_G;
-  const float sdf = dist_G - dist_G_V;
-  float uw = weight;
+  sdf = dist_G - dist_G_V;
+  uw = weight;
   if (P.use_dropoff && sdf < -P.voxel_size) {
     uw = weight * (P.trunc + sdf) / P.dropoff_denominator;
     uw = std_max(uw, 0.0f);
@@ -240,6 +241,11 @@ __device__ __forceinline__ void update_tsdf_voxel(const TsdfParams& P, f3 origin
   if (P.use_sparsity) {
     if (fabsf(sdf) < P.trunc) uw *= P.sparsity_factor;
   }
+}
+
+template <bool BLEND>
+__device__ __forceinline__ void tsdf_combine(const TsdfParams& P, float sdf, float uw, uint32_t color, float& distance,
+                                             float& vweight, uint32_t& vcolor) {
   const float new_weight = vweight + uw;
   if (new_weight < kEps) return;
   const float new_sdf = (sdf * uw + distance * vweight) / new_weight;
@@ -248,6 +254,15 @@ __device__ __forceinline__ void update_tsdf_voxel(const TsdfParams& P, f3 origin
   }
   distance = (new_sdf > 0.0f) ? std_min(P.trunc, new_sdf) : std_max(-P.trunc, new_sdf);
   vweight = std_min(P.max_weight, new_weight);
+}
+
+template <bool BLEND>
+__device__ __forceinline__ void update_tsdf_voxel(const TsdfParams& P, f3 origin, f3 point_G, int vx, int vy, int vz,
+                                                  uint32_t color, float weight, float& distance, float& vweight,
+                                                  uint32_t& vcolor) {
+  float sdf, uw;
+  tsdf_operands(P, origin, point_G, vx, vy, vz, weight, sdf, uw);
+  tsdf_combine<BLEND>(P, sdf, uw, color, distance, vweight, vcolor);
 }
 
 }  // namespace ksd

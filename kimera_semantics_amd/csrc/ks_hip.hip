@@ -25,7 +25,6 @@
 #include <string.h>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -38,6 +37,7 @@
 
 #include "../../include/ks_hip.h"
 #include "ks_device_math.h"
+#include "ks_radix_sort.h"
 
 using namespace ksd;
 
@@ -132,11 +132,12 @@ struct TileTable {
 };
 
 struct Pool {
-  float* dist;
-  float* weight;
-  uint32_t* color;
-  uint8_t* label;      // 255 = never updated (label 0, colour Gray on download)
-  float* priors;       // [tile][21][512]
+  // One 128-byte record per voxel (array of structures, 8 x uint4):
+  //   dword 0 distance | 1 weight | 2 colour (rgba) | 3 label (255 = never updated)
+  //   dwords 4..24 the 21 class priors | 25..31 spare
+  // A record is exactly one 128-B line: the 8 lanes that cooperate on a voxel move it with one
+  // coalesced 16-B access each, and a whole tile (512 voxels) is one contiguous 64 KiB range.
+  uint4* vox;          // [tile][512][8]
   uint8_t* updated;    // per tile
 };
 
@@ -683,14 +684,20 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
 
 __global__ void __launch_bounds__(512) k_init_tiles(Pool P, uint32_t first_slot) {
   const size_t slot = (size_t)first_slot + blockIdx.x;
-  const uint32_t v = threadIdx.x;
-  P.dist[slot * kTileVoxels + v] = 0.0f;
-  P.weight[slot * kTileVoxels + v] = 0.0f;
-  P.color[slot * kTileVoxels + v] = 0u;
-  P.label[slot * kTileVoxels + v] = 255;
+  uint4* tile = P.vox + slot * (size_t)kTileVoxels * 8;
+  const uint32_t pi = __float_as_uint(kPriorInit);
 #pragma unroll
-  for (int l = 0; l < kNumLabels; ++l) P.priors[(slot * kNumLabels + l) * kTileVoxels + v] = kPriorInit;
-  if (v == 0) P.updated[slot] = 1;
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t q = r * 512u + threadIdx.x;  // uint4 index inside the tile, coalesced
+    const uint32_t sub = q & 7u;
+    uint4 v;
+    if (sub == 0) v = make_uint4(0u, 0u, 0u, 255u);
+    else if (sub < 6) v = make_uint4(pi, pi, pi, pi);
+    else if (sub == 6) v = make_uint4(pi, 0u, 0u, 0u);
+    else v = make_uint4(0u, 0u, 0u, 0u);
+    tile[q] = v;
+  }
+  if (threadIdx.x == 0) P.updated[slot] = 1;
 }
 
 // K3b: emit — same walk, write one (voxel slot id, ray sequence) key per update.
@@ -742,7 +749,6 @@ __global__ void __launch_bounds__(256) k_emit(FrameParams F, uint32_t n_rays, co
 struct VoxelRef {
   uint32_t slot, local;
   int vx, vy, vz;
-  size_t vbase, pbase;
 };
 __device__ __forceinline__ VoxelRef voxel_ref(const TileTable& T, uint32_t vox) {
   VoxelRef v;
@@ -753,9 +759,33 @@ __device__ __forceinline__ VoxelRef voxel_ref(const TileTable& T, uint32_t vox) 
   v.vx = tx * 8 + (int)(v.local & 7u);
   v.vy = ty * 8 + (int)((v.local >> 3) & 7u);
   v.vz = tz * 8 + (int)(v.local >> 6);
-  v.vbase = (size_t)v.slot * kTileVoxels + v.local;
-  v.pbase = (size_t)v.slot * kNumLabels * kTileVoxels + v.local;
   return v;
+}
+
+// lane permute with every lane of the wave active (ds_bpermute reads 0 from disabled lanes)
+__device__ __forceinline__ uint32_t perm_u(uint32_t x, uint32_t src_lane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)x);
+}
+__device__ __forceinline__ float perm_f(float x, uint32_t src_lane) { return __uint_as_float(perm_u(__float_as_uint(x), src_lane)); }
+
+// Operands of one (voxel, ray) update that do not depend on the voxel state.
+struct UpdateOps {
+  float sdf, uw, dm, dn;
+  uint32_t info, color, rp;
+};
+__device__ __forceinline__ UpdateOps load_update_ops(const FrameParams& F, const RayDesc* __restrict__ rays, uint64_t key,
+                                                     const VoxelRef& v) {
+  UpdateOps u;
+  u.rp = (uint32_t)key & F.point_mask;
+  const uint4* r4 = (const uint4*)rays + (size_t)ray_index(F, u.rp) * 2;
+  const uint4 d0 = r4[0], d1 = r4[1];
+  tsdf_operands(F.tsdf, F.T.t, {__uint_as_float(d0.x), __uint_as_float(d0.y), __uint_as_float(d0.z)}, v.vx, v.vy, v.vz,
+                __uint_as_float(d0.w), u.sdf, u.uw);
+  u.color = d1.x;
+  u.dm = __uint_as_float(d1.y);
+  u.dn = __uint_as_float(d1.z);
+  u.info = d1.w;
+  return u;
 }
 
 template <int COLOR_MODE>
@@ -764,67 +794,145 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
                                                const float* __restrict__ deltas, TileTable T, Pool P,
                                                const uint32_t* __restrict__ label_lut,
                                                unsigned long long* __restrict__ long_list, Counters* C) {
-  const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  bool head = false, is_long = false;
+  // Phase A — one lane per pair (64 consecutive pairs per wavefront): ray-descriptor gather and
+  //   the voxel-state-independent half of updateTsdfVoxel, all 64 in flight at once.
+  // Phase B — EIGHT LANES COOPERATE PER VOXEL: lane `sub` of a group moves 16 bytes of the
+  //   128-byte record (one coalesced line per voxel); sub 0 walks the TSDF recurrence, subs
+  //   1..6 own four class priors each.  The run's operands come from the phase-A lanes through
+  //   ds_bpermute, so the recurrence has no memory access on its critical path.
+  const uint32_t lane = lane_id();
+  const unsigned long long wbase = ((unsigned long long)blockIdx.x * 4ull + (threadIdx.x >> 6)) * 64ull;
+  const unsigned long long i = wbase + lane;
+  const bool valid = i < n_pairs;
   uint64_t key = 0;
-  uint32_t vox = 0;
-  if (i < n_pairs) {
+  uint32_t vox = 0xffffffffu;
+  bool head = false, is_long = false;
+  UpdateOps u{};
+  if (valid) {
     key = pairs[i];
     vox = (uint32_t)(key >> F.seq_bits);
     head = (i == 0) || ((uint32_t)(pairs[i - 1] >> F.seq_bits) != vox);
     if (head) is_long = (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> F.seq_bits) == vox);
+    u = load_update_ops(F, rays, key, voxel_ref(T, vox));
   }
-  const uint32_t lpos = wave_append(head && is_long, &C->n_long);
-  if (!head) return;
-  if (is_long) {
-    long_list[lpos] = i;
-    return;
-  }
-  const VoxelRef v = voxel_ref(T, vox);
-  float dist = P.dist[v.vbase], weight = P.weight[v.vbase];
-  uint32_t color = P.color[v.vbase];
-  float pri[kNumLabels];
-#pragma unroll
-  for (int l = 0; l < kNumLabels; ++l) pri[l] = P.priors[v.pbase + (size_t)l * kTileVoxels];
+  const uint32_t lpos = block_append(head && is_long, &C->n_long);
+  if (head && is_long) long_list[lpos] = i;
 
-  unsigned long long j = i;
-  uint64_t k = key;
-  do {
-    const uint32_t rp = (uint32_t)k & F.point_mask;
-    const RayDesc d = rays[ray_index(F, rp)];
-    update_tsdf_voxel<COLOR_MODE == KS_COLOR_MODE_COLOR>(F.tsdf, F.T.t, {d.px, d.py, d.pz}, v.vx, v.vy, v.vz, d.color,
-                                                         d.weight, dist, weight, color);
-    const uint32_t kind = (d.info >> 8) & 3u;
-    if (kind == 1u) {
-      const uint32_t lab = d.info & 0xffu;
+  // run boundaries inside the window: every head (short or long) and every invalid lane ends a run
+  const unsigned long long bounds = __ballot(head || !valid);
+  unsigned long long H = __ballot(head && !is_long);
+  const uint32_t grp = lane >> 3, sub = lane & 7u;
+  const uint32_t cbase = (sub - 1u) * 4u;  // first class index of this lane (subs 1..6)
+  while (H) {
+    int my_pos = -1;
 #pragma unroll
-      for (int l = 0; l < kNumLabels; ++l) pri[l] += ((uint32_t)l == lab) ? d.d_match : d.d_non;
-    } else if (kind == 2u) {
-      const float* dl = deltas + (size_t)rp * kNumLabels;
-#pragma unroll
-      for (int l = 0; l < kNumLabels; ++l) pri[l] += dl[l];
+    for (int g = 0; g < 8; ++g) {
+      if (H) {
+        const int p = __ffsll((long long)H) - 1;
+        H &= H - 1ull;
+        if ((int)grp == g) my_pos = p;
+      }
     }
-    ++j;
-    if (j >= n_pairs) break;
-    k = pairs[j];
-  } while ((uint32_t)(k >> F.seq_bits) == vox);
+    const bool active = my_pos >= 0;
+    const uint32_t hp = active ? (uint32_t)my_pos : lane;
+    const uint32_t hvox = perm_u(vox, hp);
+    // length of the run inside this window
+    uint32_t len = 0;
+    if (active) {
+      const unsigned long long above = (hp < 63u) ? (bounds >> (hp + 1u)) : 0ull;
+      len = above ? (uint32_t)__ffsll((long long)above) : (64u - hp);
+    }
+    uint4* rec = P.vox + (size_t)(active ? hvox : 0u) * 8;
+    uint4 q = make_uint4(0u, 0u, 0u, 0u);
+    if (active && sub < 7u) q = rec[sub];
+    float dist = __uint_as_float(q.x), weight = __uint_as_float(q.y);  // meaningful for sub 0
+    uint32_t color = q.z;
+    float p0 = __uint_as_float(q.x), p1 = __uint_as_float(q.y), p2 = __uint_as_float(q.z), p3 = __uint_as_float(q.w);
 
-  // calculateMaximumLikelihoodLabel: first strict maximum [K:src/semantic_integrator_base.cpp:352-367]
-  int best = 0;
-  float m = pri[0];
-#pragma unroll
-  for (int l = 1; l < kNumLabels; ++l)
-    if (pri[l] > m) { m = pri[l]; best = l; }
-  if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = label_lut[best];
-  else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY)
-    color = rainbow_color_map((double)(float)exp((double)m));
+    for (uint32_t s = 0;; ++s) {
+      const bool on = active && s < len;
+      if (__ballot(on) == 0ull) break;
+      const uint32_t src = on ? hp + s : lane;
+      const float sdf_s = perm_f(u.sdf, src), uw_s = perm_f(u.uw, src);
+      const float dm_s = perm_f(u.dm, src), dn_s = perm_f(u.dn, src);
+      const uint32_t info_s = perm_u(u.info, src);
+      uint32_t color_s = 0, rp_s = 0;
+      if (COLOR_MODE == KS_COLOR_MODE_COLOR) color_s = perm_u(u.color, src);
+      if (F.method == KS_METHOD_MERGED) rp_s = perm_u(u.rp, src);
+      if (on) {
+        if (sub == 0u) {
+          tsdf_combine<COLOR_MODE == KS_COLOR_MODE_COLOR>(F.tsdf, sdf_s, uw_s, color_s, dist, weight, color);
+        } else if (sub < 7u) {
+          const uint32_t kind = (info_s >> 8) & 3u;
+          if (kind == 1u) {
+            const uint32_t lab = info_s & 0xffu;
+            p0 += (cbase == lab) ? dm_s : dn_s;
+            p1 += (cbase + 1u == lab) ? dm_s : dn_s;
+            p2 += (cbase + 2u == lab) ? dm_s : dn_s;
+            p3 += (cbase + 3u == lab) ? dm_s : dn_s;
+          } else if (kind == 2u) {
+            const float* dl = deltas + (size_t)rp_s * kNumLabels + cbase;
+            p0 += dl[0];
+            if (sub < 6u) { p1 += dl[1]; p2 += dl[2]; p3 += dl[3]; }
+          }
+        }
+      }
+    }
+    // a run may continue past the 64-pair window: finish it from global memory (rare)
+    if (active && hp + len == 64u) {
+      const VoxelRef v = voxel_ref(T, hvox);
+      for (unsigned long long j = wbase + 64ull; j < n_pairs; ++j) {
+        const uint64_t k = pairs[j];
+        if ((uint32_t)(k >> F.seq_bits) != hvox) break;
+        const UpdateOps t = load_update_ops(F, rays, k, v);
+        if (sub == 0u) {
+          tsdf_combine<COLOR_MODE == KS_COLOR_MODE_COLOR>(F.tsdf, t.sdf, t.uw, t.color, dist, weight, color);
+        } else if (sub < 7u) {
+          const uint32_t kind = (t.info >> 8) & 3u;
+          if (kind == 1u) {
+            const uint32_t lab = t.info & 0xffu;
+            p0 += (cbase == lab) ? t.dm : t.dn;
+            p1 += (cbase + 1u == lab) ? t.dm : t.dn;
+            p2 += (cbase + 2u == lab) ? t.dm : t.dn;
+            p3 += (cbase + 3u == lab) ? t.dm : t.dn;
+          } else if (kind == 2u) {
+            const float* dl = deltas + (size_t)t.rp * kNumLabels + cbase;
+            p0 += dl[0];
+            if (sub < 6u) { p1 += dl[1]; p2 += dl[2]; p3 += dl[3]; }
+          }
+        }
+      }
+    }
 
-  P.dist[v.vbase] = dist;
-  P.weight[v.vbase] = weight;
-  P.color[v.vbase] = color;
-  P.label[v.vbase] = (uint8_t)best;
+    // calculateMaximumLikelihoodLabel: first strict maximum [K:src/semantic_integrator_base.cpp:352-367]
+    float bv = -INFINITY;
+    uint32_t bi = 1000u;
+    if (sub >= 1u && sub < 7u) {
+      bv = p0; bi = cbase;
+      if (sub < 6u) {
+        if (p1 > bv) { bv = p1; bi = cbase + 1u; }
+        if (p2 > bv) { bv = p2; bi = cbase + 2u; }
+        if (p3 > bv) { bv = p3; bi = cbase + 3u; }
+      }
+    }
 #pragma unroll
-  for (int l = 0; l < kNumLabels; ++l) P.priors[v.pbase + (size_t)l * kTileVoxels] = pri[l];
+    for (int o = 1; o < 8; o <<= 1) {
+      const float ov = perm_f(bv, lane ^ (uint32_t)o);
+      const uint32_t oi = perm_u(bi, lane ^ (uint32_t)o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (active) {
+      if (sub == 0u) {
+        if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = label_lut[bi];
+        else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY) color = rainbow_color_map((double)(float)exp((double)bv));
+        rec[0] = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, bi);
+      } else if (sub < 6u) {
+        rec[sub] = make_uint4(__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3));
+      } else if (sub == 6u) {
+        rec[6] = make_uint4(__float_as_uint(p0), 0u, 0u, 0u);
+      }
+    }
+  }
 }
 
 template <int COLOR_MODE>
@@ -845,9 +953,10 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
     const unsigned long long start = long_list[run];
     const uint32_t vox = (uint32_t)(pairs[start] >> F.seq_bits);
     const VoxelRef v = voxel_ref(T, vox);
-    float dist = P.dist[v.vbase], weight = P.weight[v.vbase];
-    uint32_t color = P.color[v.vbase];
-    float pri = (lane < kNumLabels) ? P.priors[v.pbase + (size_t)lane * kTileVoxels] : 0.0f;
+    uint32_t* rec = (uint32_t*)(P.vox + (size_t)vox * 8);
+    float dist = __uint_as_float(rec[0]), weight = __uint_as_float(rec[1]);
+    uint32_t color = rec[2];
+    float pri = (lane < kNumLabels) ? __uint_as_float(rec[4 + lane]) : 0.0f;
     // voxel centre and the origin->centre vector are constant over the run
     const f3 c = {((float)v.vx + 0.5f) * Pm.voxel_size, ((float)v.vy + 0.5f) * Pm.voxel_size,
                   ((float)v.vz + 0.5f) * Pm.voxel_size};
@@ -954,13 +1063,8 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
     if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = label_lut[best];
     else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY)
       color = rainbow_color_map((double)(float)exp((double)m));
-    if (lane < kNumLabels) P.priors[v.pbase + (size_t)lane * kTileVoxels] = pri;
-    if (lane == 0) {
-      P.dist[v.vbase] = dist;
-      P.weight[v.vbase] = weight;
-      P.color[v.vbase] = color;
-      P.label[v.vbase] = (uint8_t)best;
-    }
+    if (lane < kNumLabels) rec[4 + lane] = __float_as_uint(pri);
+    if (lane == 0) *(uint4*)rec = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, (uint32_t)best);
     __builtin_amdgcn_wave_barrier();
   }
 }
@@ -998,14 +1102,22 @@ __global__ void __launch_bounds__(256) k_download(TileTable T, Pool P, const int
   for (int k = 0; k < kNumLabels; ++k) pri[k] = kPriorInit;
   if (slot != 0xffffffffu) {
     const uint32_t local = (uint32_t)(vx & 7) + 8u * ((uint32_t)(vy & 7) + 8u * (uint32_t)(vz & 7));
-    const size_t vbase = (size_t)slot * kTileVoxels + local;
-    dist = P.dist[vbase];
-    weight = P.weight[vbase];
-    color = P.color[vbase];
-    label = P.label[vbase];
-    const size_t pbase = (size_t)slot * kNumLabels * kTileVoxels + local;
+    const uint4* rec = P.vox + ((size_t)slot * kTileVoxels + local) * 8;
+    const uint4 q0 = rec[0];
+    dist = __uint_as_float(q0.x);
+    weight = __uint_as_float(q0.y);
+    color = q0.z;
+    label = q0.w;
 #pragma unroll
-    for (int k = 0; k < kNumLabels; ++k) pri[k] = P.priors[pbase + (size_t)k * kTileVoxels];
+    for (int g = 0; g < 6; ++g) {
+      const uint4 q = rec[1 + g];
+      pri[4 * g] = __uint_as_float(q.x);
+      if (g < 5) {
+        pri[4 * g + 1] = __uint_as_float(q.y);
+        pri[4 * g + 2] = __uint_as_float(q.z);
+        pri[4 * g + 3] = __uint_as_float(q.w);
+      }
+    }
   }
   const size_t o = (size_t)b * nv + l;
   if (tsdf_out) {
@@ -1077,8 +1189,7 @@ struct ks_ctx {
   unsigned long long* d_pair_off = nullptr;
   size_t cap_pairs = 0;
   uint64_t *d_pairs = nullptr, *d_pairs2 = nullptr;
-  void* d_sort_tmp = nullptr;
-  size_t sort_tmp_bytes = 0;
+  ksrs::Workspace sort_ws;
   Counters* d_counters = nullptr;
   Counters* h_counters = nullptr;  // pinned
   int32_t* d_block_idx = nullptr;
@@ -1154,31 +1265,15 @@ int ensure_pairs(ks_ctx* c, size_t n) {
   return KS_OK;
 }
 
-int ensure_sort_tmp(ks_ctx* c, size_t bytes) {
-  if (bytes <= c->sort_tmp_bytes) return KS_OK;
-  if (c->d_sort_tmp) (void)hipFree(c->d_sort_tmp);
-  c->d_sort_tmp = nullptr;
-  HIPCHK(c, hipMalloc(&c->d_sort_tmp, bytes));
-  c->sort_tmp_bytes = bytes;
-  return KS_OK;
-}
-
 template <typename K>
-int sort_keys(ks_ctx* c, K* in, K* out, size_t n, unsigned begin_bit, unsigned end_bit) {
-  size_t bytes = 0;
-  HIPCHK(c, rocprim::radix_sort_keys(nullptr, bytes, in, out, n, begin_bit, end_bit, c->stream));
-  int rc = ensure_sort_tmp(c, bytes);
-  if (rc) return rc;
-  HIPCHK(c, rocprim::radix_sort_keys(c->d_sort_tmp, bytes, in, out, n, begin_bit, end_bit, c->stream));
+int sort_keys(ks_ctx* c, K* a, K* b, size_t n, unsigned end_bit, K** result) {
+  HIPCHK(c, (ksrs::sort<K, false>(c->sort_ws, a, b, nullptr, nullptr, n, end_bit, c->stream, result, nullptr)));
   return KS_OK;
 }
-template <typename K, typename V>
-int sort_pairs(ks_ctx* c, K* kin, K* kout, V* vin, V* vout, size_t n, unsigned begin_bit, unsigned end_bit) {
-  size_t bytes = 0;
-  HIPCHK(c, rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
-  int rc = ensure_sort_tmp(c, bytes);
-  if (rc) return rc;
-  HIPCHK(c, rocprim::radix_sort_pairs(c->d_sort_tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, c->stream));
+template <typename K>
+int sort_pairs(ks_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, size_t n, unsigned end_bit, K** kres,
+               uint32_t** vres) {
+  HIPCHK(c, (ksrs::sort<K, true>(c->sort_ws, ka, kb, va, vb, n, end_bit, c->stream, kres, vres)));
   return KS_OK;
 }
 
@@ -1268,7 +1363,7 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
     F.clear_bit = (cfg.method == KS_METHOD_MERGED) ? (1u << pb) : 0u;
     F.seq_bits = pb + (cfg.method == KS_METHOD_MERGED ? 1u : 0u);
   }
-  F.order = F.sorted_order ? c->d_order : nullptr;
+  F.order = nullptr;  // set below once the sorted order has been computed
   F.inv_order = F.sorted_order ? c->d_inv_order : nullptr;
   std::memcpy(F.dynamic_labels, cfg.dynamic_labels, 32);
   // the early-out can never fire if the threshold exceeds the longest possible ray
@@ -1285,12 +1380,16 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
 
   const uint32_t nb = (uint32_t)((n + 255) / 256);
   const uint32_t nb1k = (uint32_t)((n + 1023) / 1024);
+  const uint32_t* order_ptr = nullptr;
   stage_mark(c, 0);
 
   if (F.sorted_order) {
     hipLaunchKernelGGL(k_sqnorm, dim3(nb), dim3(256), 0, st, (uint32_t)n, d_xyz, c->d_okeys, c->d_ovals);
-    if ((rc = sort_pairs(c, c->d_okeys, c->d_okeys2, c->d_ovals, c->d_order, n, 0, 32))) return rc;
-    hipLaunchKernelGGL(k_invert, dim3(nb), dim3(256), 0, st, (uint32_t)n, c->d_order, c->d_inv_order);
+    uint32_t *ok = nullptr, *ov = nullptr;
+    if ((rc = sort_pairs(c, c->d_okeys, c->d_okeys2, c->d_ovals, c->d_order, n, 32, &ok, &ov))) return rc;
+    order_ptr = ov;  // position -> index
+    hipLaunchKernelGGL(k_invert, dim3(nb), dim3(256), 0, st, (uint32_t)n, order_ptr, c->d_inv_order);
+    F.order = order_ptr;
   }
 
   if (cfg.method == KS_METHOD_FAST) {
@@ -1298,25 +1397,27 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
                        c->d_rays, c->d_hash, c->d_skeys32, c->d_pvals, c->d_counters);
     stage_mark(c, 1);
     // stable sort by slot only: position order inside a slot is preserved
-    if ((rc = sort_pairs(c, c->d_skeys32, c->d_skeys32b, c->d_pvals, c->d_pvals2, n, 0, kSetBits + 1))) return rc;
+    uint32_t *sk = nullptr, *sv = nullptr;
+    if ((rc = sort_pairs(c, c->d_skeys32, c->d_skeys32b, c->d_pvals, c->d_pvals2, n, kSetBits + 1, &sk, &sv))) return rc;
     stage_mark(c, 2);
-    hipLaunchKernelGGL(k_dedup, dim3(nb1k), dim3(1024), 0, st, F, c->d_skeys32b, c->d_pvals2, c->d_hash,
-                       c->d_start_set, c->d_ray_list, c->d_counters);
-    hipLaunchKernelGGL(k_dedup_commit, dim3(nb1k), dim3(1024), 0, st, F, c->d_skeys32b, c->d_pvals2, c->d_hash,
-                       c->d_start_set, c->d_counters);
+    hipLaunchKernelGGL(k_dedup, dim3(nb1k), dim3(1024), 0, st, F, sk, sv, c->d_hash, c->d_start_set, c->d_ray_list,
+                       c->d_counters);
+    hipLaunchKernelGGL(k_dedup_commit, dim3(nb1k), dim3(1024), 0, st, F, sk, sv, c->d_hash, c->d_start_set,
+                       c->d_counters);
   } else {
     hipLaunchKernelGGL(k_points_merged, dim3(nb1k), dim3(1024), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
                        c->d_pkeys, c->d_pvals, c->d_counters);
     stage_mark(c, 1);
-    if ((rc = sort_pairs(c, c->d_pkeys, c->d_pkeys2, c->d_pvals, c->d_pvals2, n, 0, 64))) return rc;
+    uint64_t* sk = nullptr;
+    uint32_t* sv = nullptr;
+    if ((rc = sort_pairs(c, c->d_pkeys, c->d_pkeys2, c->d_pvals, c->d_pvals2, n, 64, &sk, &sv))) return rc;
     stage_mark(c, 2);
     hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       c->d_order, c->d_pkeys2, c->d_pvals2, c->d_gpw, c->d_glc);
-    hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, c->d_pkeys2, c->d_pvals2, c->d_gpw, c->d_glc,
-                       c->d_rays, c->d_deltas, c->d_ray_list, c->d_blong, c->d_counters);
+                       order_ptr, sk, sv, c->d_gpw, c->d_glc);
+    hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, sk, sv, c->d_gpw, c->d_glc, c->d_rays, c->d_deltas,
+                       c->d_ray_list, c->d_blong, c->d_counters);
     hipLaunchKernelGGL(k_bundles_long, dim3((uint32_t)std::min<size_t>(n / kLongRun + 1, 2048)), dim3(64), 0, st, F,
-                       c->d_pkeys2, c->d_pvals2, c->d_gpw, c->d_glc, c->d_rays, c->d_deltas, c->d_ray_list, c->d_blong,
-                       c->d_counters);
+                       sk, sv, c->d_gpw, c->d_glc, c->d_rays, c->d_deltas, c->d_ray_list, c->d_blong, c->d_counters);
   }
   stage_mark(c, 3);
   // march over an upper bound of rays (<= n); the live ray count stays on the device
@@ -1355,14 +1456,15 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
                        c->d_nsteps, c->d_pair_off, c->d_pairs);
     stage_mark(c, 5);
     const unsigned end_bit = F.seq_bits + 9 + bits_for(new_tiles);
-    if ((rc = sort_keys(c, c->d_pairs, c->d_pairs2, n_pairs, 0, std::min(64u, end_bit)))) return rc;
+    uint64_t* sp = nullptr;
+    if ((rc = sort_keys(c, c->d_pairs, c->d_pairs2, n_pairs, std::min(64u, end_bit), &sp))) return rc;
     stage_mark(c, 6);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
 #define KS_LAUNCH_APPLY(MODE)                                                                                        \
-  hipLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, F, n_pairs, c->d_pairs2, c->d_rays, c->d_deltas,      \
+  hipLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, F, n_pairs, sp, c->d_rays, c->d_deltas,               \
                      c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters);                               \
-  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(64), 0, st, F, n_pairs, c->d_pairs2, c->d_rays, c->d_deltas,  \
+  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(64), 0, st, F, n_pairs, sp, c->d_rays, c->d_deltas,           \
                      c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters)
     switch (cfg.color_mode) {
       case KS_COLOR_MODE_COLOR: KS_LAUNCH_APPLY(KS_COLOR_MODE_COLOR); break;
@@ -1523,11 +1625,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipMalloc((void**)&c->table.vals, cap * sizeof(uint32_t)));
   CRCHK(hipMalloc((void**)&c->table.slot_keys, mt * sizeof(uint64_t)));
   CRCHK(hipMemset(c->table.keys, 0xff, cap * sizeof(uint64_t)));
-  CRCHK(hipMalloc((void**)&c->pool.dist, mt * kTileVoxels * sizeof(float)));
-  CRCHK(hipMalloc((void**)&c->pool.weight, mt * kTileVoxels * sizeof(float)));
-  CRCHK(hipMalloc((void**)&c->pool.color, mt * kTileVoxels * sizeof(uint32_t)));
-  CRCHK(hipMalloc((void**)&c->pool.label, mt * kTileVoxels));
-  CRCHK(hipMalloc((void**)&c->pool.priors, mt * kTileVoxels * kNumLabels * sizeof(float)));
+  CRCHK(hipMalloc((void**)&c->pool.vox, mt * kTileVoxels * 8 * sizeof(uint4)));
   CRCHK(hipMalloc((void**)&c->pool.updated, mt));
   CRCHK(hipMemset(c->pool.updated, 0, mt));
   CRCHK(hipMalloc((void**)&c->d_start_set, sizeof(uint64_t) << kSetBits));
@@ -1556,14 +1654,14 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
 void ks_destroy(ks_ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->table.keys, c->table.vals, c->table.slot_keys, c->pool.dist, c->pool.weight, c->pool.color,
-                  c->pool.label, c->pool.priors, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
+  void* ptrs[] = {c->table.keys, c->table.vals, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_rays, c->d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
-                  c->d_ray_list, c->d_nsteps, c->d_pair_off, c->d_pairs, c->d_pairs2, c->d_sort_tmp, c->d_counters,
+                  c->d_ray_list, c->d_nsteps, c->d_pair_off, c->d_pairs, c->d_pairs2, c->d_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  ksrs::release(c->sort_ws);
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
@@ -1673,6 +1771,46 @@ int ks_download_blocks(ks_ctx* c, const int32_t* idx, size_t n, void* tsdf_out, 
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
   return KS_OK;
+}
+
+int ks_debug_radix_sort(ks_ctx* c, void* keys, uint32_t* vals, size_t n, int key_bits, unsigned end_bit) {
+  if (!c || (n && !keys) || (key_bits != 32 && key_bits != 64)) return KS_ERR_INVALID_ARG;
+  if (n == 0) return KS_OK;
+  const size_t kb = key_bits / 8;
+  void *ka = nullptr, *kbuf = nullptr;
+  uint32_t *va = nullptr, *vb = nullptr;
+  HIPCHK(c, hipMalloc(&ka, n * kb));
+  HIPCHK(c, hipMalloc(&kbuf, n * kb));
+  HIPCHK(c, hipMemcpy(ka, keys, n * kb, hipMemcpyHostToDevice));
+  if (vals) {
+    HIPCHK(c, hipMalloc((void**)&va, n * 4));
+    HIPCHK(c, hipMalloc((void**)&vb, n * 4));
+    HIPCHK(c, hipMemcpy(va, vals, n * 4, hipMemcpyHostToDevice));
+  }
+  void* kres = nullptr;
+  uint32_t* vres = nullptr;
+  int rc = KS_OK;
+  if (key_bits == 32) {
+    uint32_t* r = nullptr;
+    rc = vals ? sort_pairs(c, (uint32_t*)ka, (uint32_t*)kbuf, va, vb, n, end_bit, &r, &vres)
+              : sort_keys(c, (uint32_t*)ka, (uint32_t*)kbuf, n, end_bit, &r);
+    kres = r;
+  } else {
+    uint64_t* r = nullptr;
+    rc = vals ? sort_pairs(c, (uint64_t*)ka, (uint64_t*)kbuf, va, vb, n, end_bit, &r, &vres)
+              : sort_keys(c, (uint64_t*)ka, (uint64_t*)kbuf, n, end_bit, &r);
+    kres = r;
+  }
+  if (rc == KS_OK) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(keys, kres, n * kb, hipMemcpyDeviceToHost));
+    if (vals) HIPCHK(c, hipMemcpy(vals, vres, n * 4, hipMemcpyDeviceToHost));
+  }
+  (void)hipFree(ka);
+  (void)hipFree(kbuf);
+  if (va) (void)hipFree(va);
+  if (vb) (void)hipFree(vb);
+  return rc;
 }
 
 int ks_synchronize(ks_ctx* c) {

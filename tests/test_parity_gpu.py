@@ -97,3 +97,25 @@ def test_sorted_integration_order_exact(method):
     sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
     assert (so.n_rays_cast, so.n_voxel_updates) == (sh.n_rays_cast, sh.n_voxel_updates)
     compare_maps(o, h, exact=True)
+
+
+@pytest.mark.parametrize("dtype,n,end_bit", [(np.uint32, 1, 21), (np.uint32, 2047, 21), (np.uint32, 305619, 21),
+                                             (np.uint64, 2049, 64), (np.uint64, 700001, 41), (np.uint64, 3000000, 64),
+                                             (np.uint32, 100000, 32)])
+def test_device_radix_sort_is_correct_and_stable(dtype, n, end_bit):
+    rng = np.random.default_rng(n)
+    h = B.HipIntegrator(B.default_config(max_tiles=64, max_points=1024, **dict(COMMON, method=0)))
+    hi = (1 << end_bit) - 1
+    if n > 4:
+        keys = rng.integers(0, min(hi, 5000), size=n, dtype=np.uint64)      # many duplicates: stability matters
+        keys[: n // 2] = rng.integers(0, hi, size=n // 2, dtype=np.uint64, endpoint=True)
+    else:
+        keys = rng.integers(0, hi, size=n, dtype=np.uint64, endpoint=True)
+    keys = keys.astype(dtype)
+    vals = np.arange(n, dtype=np.uint32)
+    k2, v2 = h.debug_radix_sort(keys, vals, end_bit)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(k2, keys[order])
+    assert np.array_equal(v2, vals[order])
+    k3, _ = h.debug_radix_sort(keys, None, end_bit)
+    assert np.array_equal(k3, keys[order])
