@@ -56,8 +56,14 @@ __global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uin
     const unsigned long long active = __ballot(valid);
     for (int p = 0; p < passes; ++p) {
       const uint32_t d = digit_of(key, p * kRadixBits);
-      const unsigned long long peers = match_digit(d, active);
-      if (valid && (peers & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&s_hist[p][d], (uint32_t)__popcll(peers));
+      // the upper digits of these keys are nearly constant: one add for a wave-uniform digit,
+      // per-lane LDS atomics otherwise
+      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+      if (__ballot(valid && d != d0) == 0ull) {
+        if (lane == (uint32_t)(__ffsll((long long)active) - 1) && active) atomicAdd(&s_hist[p][d0], (uint32_t)__popcll(active));
+      } else if (valid) {
+        atomicAdd(&s_hist[p][d], 1u);
+      }
     }
   }
   __syncthreads();
