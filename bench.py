@@ -127,6 +127,13 @@ def main():
         updates += st.n_voxel_updates
         points += st.n_points
     integ.synchronize()
+    reduce_stats = None
+    if world > 1:
+        # the one exchange step of the frame-sharded path: per-rank partial maps -> owner-sharded
+        # global map (all-to-all of touched tiles over RCCL/xGMI + deterministic owner merge)
+        from kimera_semantics_amd import parallel as PAR
+        reduce_stats = PAR.reduce_maps(PAR.HipTileStore(integ, dev))
+        integ.synchronize()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -173,13 +180,17 @@ def main():
                                    f"'{args.method}' integrator, 5 cm voxels, 5 m rays, trunc 0.2 m, p=0.8",
                        "frames_per_gpu": K, "points_per_frame": int(points_all / max(1, world * K)),
                        "updates_per_frame": int(updates_all / max(1, world * K)),
-                       "parallelism": f"frame-sharded x{world}"},
+                       "parallelism": f"frame-sharded x{world}" + (
+                           " + one all-to-all tile reduce to hash-owners at the end (inside the timed region)"
+                           if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_apply", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(apply_ms, 5),
                          "whole_frame_frac": round(whole_frame_alg / (dt / K) / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms_per_frame": stage_ms,
         }
+        if reduce_stats is not None:
+            out["reduce"] = reduce_stats
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, frames[W:])
         print(json.dumps(out), flush=True)

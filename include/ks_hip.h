@@ -74,7 +74,7 @@ typedef struct ks_config {
   uint8_t label_rgba[256][4];       /* label -> colour (SemanticLabel2Color::semantic_label_to_color_map_) */
   /* ---- device sizing ---- */
   int32_t device_id;                /* HIP device ordinal */
-  uint32_t max_tiles;               /* capacity of the 8^3-voxel tile pool (49.7 KB each) */
+  uint32_t max_tiles;               /* capacity of the 8^3-voxel tile pool (64 KiB each) */
   uint32_t max_points;              /* largest cloud per call (buffers grow on demand if exceeded) */
 } ks_config;
 
@@ -139,6 +139,19 @@ int ks_get_updated_block_indices(ks_ctx* ctx, int32_t* out_xyz, size_t cap, size
  * sem_out:  n * vps^3 * 92 B {u8 label, 3 pad, f32 priors[21], u8 rgba[4]} (semantic_voxel.h:14-27).
  * Either may be NULL.  Absent blocks yield default-constructed voxels. */
 int ks_download_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, void* tsdf_out, void* sem_out);
+
+/* ---- multi-GPU exchange (new functionality: the reference is single-process) ----
+ * The map is a set of 8^3-voxel tiles; a tile travels as its packed 63-bit key plus a raw
+ * 64 KiB record block (512 voxels x 128 B).  ks_get_tile_keys lists the resident tiles in slot
+ * order; ks_export_tiles_device gathers the tiles at the given slots into a DEVICE buffer
+ * (n x 65536 B); ks_merge_tiles_device merges n incoming tiles (HOST keys, DEVICE payload) into
+ * the resident map: weight-averaged distance/colour and summed weight (Voxblox's layer-merge
+ * rule), additive class log-likelihoods, then argmax + colour.  ks_clear empties the map. */
+#define KS_TILE_BYTES 65536
+int ks_get_tile_keys(ks_ctx* ctx, uint64_t* out, size_t cap, size_t* n);
+int ks_export_tiles_device(ks_ctx* ctx, const uint32_t* slots, size_t n, void* d_payload);
+int ks_merge_tiles_device(ks_ctx* ctx, const uint64_t* keys, size_t n, const void* d_payload);
+int ks_clear(ks_ctx* ctx);
 
 /* Diagnostics (used by tests): stable LSD radix sort of n HOST keys (key_bits = 32 or 64, bits
  * [0,end_bit)) and optional u32 payload with the library's own GPU sort. */

@@ -31,7 +31,8 @@ SEM_DTYPE = np.dtype([("label", "u1"), ("pad", "u1", (3,)), ("priors", "<f4", (N
 ABI_SYMBOLS = [
     "ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_set_color_to_label",
     "ks_integrate_points", "ks_integrate_points_device", "ks_num_blocks", "ks_get_block_indices",
-    "ks_get_updated_block_indices", "ks_download_blocks", "ks_debug_radix_sort", "ks_synchronize", "ks_stream",
+    "ks_get_updated_block_indices", "ks_download_blocks", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear",
+    "ks_debug_radix_sort", "ks_synchronize", "ks_stream",
     "ks_profile_enable", "ks_profile_get",
 ]
 
@@ -102,6 +103,10 @@ def lib():
         L.ks_get_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.ks_get_updated_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
         L.ks_download_blocks.argtypes = [vp, vp, C.c_size_t, vp, vp]
+        L.ks_get_tile_keys.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.ks_export_tiles_device.argtypes = [vp, vp, C.c_size_t, vp]
+        L.ks_merge_tiles_device.argtypes = [vp, vp, C.c_size_t, vp]
+        L.ks_clear.argtypes = [vp]
         L.ks_debug_radix_sort.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_uint]
         L.ks_synchronize.argtypes = [vp]
         L.ks_stream.argtypes = [vp]
@@ -219,6 +224,29 @@ class HipIntegrator:
         if len(indices):
             self._chk(lib().ks_download_blocks(self._h, _ptr(indices), len(indices), _ptr(t), _ptr(s)))
         return indices, t, s
+
+    # ---- multi-GPU exchange primitives (used by kimera_semantics_amd.parallel) ----
+    TILE_BYTES = 65536
+
+    def tile_keys(self) -> np.ndarray:
+        n = C.c_size_t()
+        self._chk(lib().ks_get_tile_keys(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint64)
+        if n.value:
+            self._chk(lib().ks_get_tile_keys(self._h, _ptr(out), n.value, C.byref(n)))
+        return out
+
+    def export_tiles(self, slots: np.ndarray, d_payload: int):
+        """Gathers the tiles at `slots` into the device buffer at address d_payload (len(slots) x 64 KiB)."""
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        self._chk(lib().ks_export_tiles_device(self._h, _ptr(s), len(s), d_payload or None))
+
+    def merge_tiles(self, keys: np.ndarray, d_payload: int):
+        k = np.ascontiguousarray(keys, dtype=np.uint64)
+        self._chk(lib().ks_merge_tiles_device(self._h, _ptr(k), len(k), d_payload or None))
+
+    def clear(self):
+        self._chk(lib().ks_clear(self._h))
 
     def debug_radix_sort(self, keys: np.ndarray, vals=None, end_bit=None):
         keys = np.ascontiguousarray(keys).copy()

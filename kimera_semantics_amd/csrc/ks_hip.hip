@@ -1069,6 +1069,91 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Multi-GPU exchange (new functionality): tiles travel as raw 64 KiB records.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) k_export_tiles(Pool P, const uint32_t* __restrict__ slots, uint4* __restrict__ out) {
+  const uint4* src = P.vox + (size_t)slots[blockIdx.x] * kTileVoxels * 8;
+  uint4* dst = out + (size_t)blockIdx.x * kTileVoxels * 8;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) dst[r * 512 + threadIdx.x] = src[r * 512 + threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) k_insert_tiles(TileTable T, Counters* C, const uint64_t* __restrict__ keys, uint32_t n) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tile_insert(T, C, keys[i]);
+}
+
+// Merge one incoming tile per workgroup into the resident map; 8 lanes per voxel.
+//   TSDF: Voxblox's layer-merge rule (mergeVoxelAIntoVoxelB): weight-averaged distance and
+//         colour, summed weight (clamped to max_weight);
+//   semantics: log-likelihoods are additive: priors += (incoming - initial), then argmax/colour
+//         exactly as updateSemanticVoxel ends ([K:src/semantic_integrator_base.cpp:164-191]).
+template <int COLOR_MODE>
+__global__ void __launch_bounds__(512) k_merge_tiles(TileTable T, Pool P, const uint64_t* __restrict__ keys,
+                                                     const uint4* __restrict__ in, float max_weight,
+                                                     const uint32_t* __restrict__ label_lut) {
+  const uint32_t slot = tile_lookup(T, keys[blockIdx.x]);
+  if (slot == 0xffffffffu) return;
+  const uint4* src = in + (size_t)blockIdx.x * kTileVoxels * 8;
+  uint4* dst = P.vox + (size_t)slot * kTileVoxels * 8;
+  const uint32_t lane = lane_id(), sub = lane & 7u;
+  const uint32_t cbase = (sub - 1u) * 4u;
+  for (uint32_t r = 0; r < 8; ++r) {
+    const uint32_t q = r * 512u + threadIdx.x;  // uint4 index in the tile; voxel = q >> 3
+    uint4 a = src[q];
+    uint4 b = dst[q];
+    // every lane of the voxel's group needs A's label (dword 3 of sub 0)
+    const uint32_t a_label = perm_u(a.w, lane & ~7u);
+    const bool touched = a_label != 255u;
+    float bv = -INFINITY;
+    uint32_t bi = 1000u;
+    if (touched) {
+      if (sub == 0u) {
+        const float ad = __uint_as_float(a.x), aw = __uint_as_float(a.y);
+        float bd = __uint_as_float(b.x), bw = __uint_as_float(b.y);
+        const float cw = aw + bw;
+        if (cw > 0.0f) {
+          bd = (ad * aw + bd * bw) / cw;
+          if (COLOR_MODE == KS_COLOR_MODE_COLOR) b.z = blend_two_colors(a.z, aw, b.z, bw);
+          bw = std_min(max_weight, cw);
+        }
+        b.x = __float_as_uint(bd);
+        b.y = __float_as_uint(bw);
+      } else if (sub < 7u) {
+        float p0 = __uint_as_float(b.x) + (__uint_as_float(a.x) - kPriorInit);
+        float p1 = __uint_as_float(b.y), p2 = __uint_as_float(b.z), p3 = __uint_as_float(b.w);
+        bv = p0; bi = cbase;
+        if (sub < 6u) {
+          p1 += __uint_as_float(a.y) - kPriorInit;
+          p2 += __uint_as_float(a.z) - kPriorInit;
+          p3 += __uint_as_float(a.w) - kPriorInit;
+          if (p1 > bv) { bv = p1; bi = cbase + 1u; }
+          if (p2 > bv) { bv = p2; bi = cbase + 2u; }
+          if (p3 > bv) { bv = p3; bi = cbase + 3u; }
+        }
+        b = make_uint4(__float_as_uint(p0), sub < 6u ? __float_as_uint(p1) : 0u, sub < 6u ? __float_as_uint(p2) : 0u,
+                       sub < 6u ? __float_as_uint(p3) : 0u);
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      const float ov = perm_f(bv, lane ^ (uint32_t)o);
+      const uint32_t oi = perm_u(bi, lane ^ (uint32_t)o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (touched && sub < 7u) {
+      if (sub == 0u) {
+        b.w = bi;
+        if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) b.z = label_lut[bi];
+        else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY) b.z = rainbow_color_map((double)(float)exp((double)bv));
+      }
+      dst[q] = b;
+    }
+  }
+}
+
 // sorted integration order: key = bits of squared norm (non-negative float => monotone as u32)
 __global__ void __launch_bounds__(256) k_sqnorm(uint32_t n, const float* __restrict__ xyz, uint32_t* __restrict__ keys,
                                                 uint32_t* __restrict__ vals) {
@@ -1811,6 +1896,90 @@ int ks_debug_radix_sort(ks_ctx* c, void* keys, uint32_t* vals, size_t n, int key
   if (va) (void)hipFree(va);
   if (vb) (void)hipFree(vb);
   return rc;
+}
+
+int ks_get_tile_keys(ks_ctx* c, uint64_t* out, size_t cap, size_t* n) {
+  if (!c || !n) return KS_ERR_INVALID_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *n = c->tiles_initialised;
+  const size_t m = std::min<size_t>(cap, *n);
+  if (out && m) HIPCHK(c, hipMemcpy(out, c->table.slot_keys, m * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return KS_OK;
+}
+
+int ks_export_tiles_device(ks_ctx* c, const uint32_t* slots, size_t n, void* d_payload) {
+  if (!c || (n && (!slots || !d_payload))) return KS_ERR_INVALID_ARG;
+  if (n == 0) return KS_OK;
+  for (size_t i = 0; i < n; ++i)
+    if (slots[i] >= c->tiles_initialised) return KS_ERR_INVALID_ARG;
+  uint32_t* d_slots = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_slots, n * sizeof(uint32_t)));
+  HIPCHK(c, hipMemcpyAsync(d_slots, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_export_tiles, dim3((uint32_t)n), dim3(512), 0, c->stream, c->pool, d_slots, (uint4*)d_payload);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  (void)hipFree(d_slots);
+  return KS_OK;
+}
+
+int ks_merge_tiles_device(ks_ctx* c, const uint64_t* keys, size_t n, const void* d_payload) {
+  if (!c || (n && (!keys || !d_payload))) return KS_ERR_INVALID_ARG;
+  if (n == 0) return KS_OK;
+  if (c->fatal) return KS_ERR_INVALID_ARG;
+  uint64_t* d_keys = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_keys, n * sizeof(uint64_t)));
+  HIPCHK(c, hipMemcpyAsync(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  // allocate tiles this rank has not seen yet
+  const uint32_t old_tiles = c->h_counters->n_tiles;
+  Counters zero{};
+  zero.n_tiles = old_tiles;
+  *c->h_counters = zero;
+  HIPCHK(c, hipMemcpyAsync(c->d_counters, c->h_counters, sizeof(Counters), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_insert_tiles, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->table, c->d_counters,
+                     d_keys, (uint32_t)n);
+  HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->h_counters->err) {
+    c->fatal = true;
+    c->err = "voxel tile pool exhausted while merging: raise ks_config.max_tiles";
+    (void)hipFree(d_keys);
+    return KS_ERR_POOL_FULL;
+  }
+  const uint32_t new_tiles = c->h_counters->n_tiles;
+  if (new_tiles > c->tiles_initialised) {
+    hipLaunchKernelGGL(k_init_tiles, dim3(new_tiles - c->tiles_initialised), dim3(512), 0, c->stream, c->pool,
+                       c->tiles_initialised);
+    c->tiles_initialised = new_tiles;
+  }
+  switch (c->cfg.color_mode) {
+    case KS_COLOR_MODE_COLOR:
+      hipLaunchKernelGGL(k_merge_tiles<KS_COLOR_MODE_COLOR>, dim3((uint32_t)n), dim3(512), 0, c->stream, c->table, c->pool,
+                         d_keys, (const uint4*)d_payload, c->cfg.max_weight, c->d_label_lut);
+      break;
+    case KS_COLOR_MODE_SEMANTIC:
+      hipLaunchKernelGGL(k_merge_tiles<KS_COLOR_MODE_SEMANTIC>, dim3((uint32_t)n), dim3(512), 0, c->stream, c->table,
+                         c->pool, d_keys, (const uint4*)d_payload, c->cfg.max_weight, c->d_label_lut);
+      break;
+    default:
+      hipLaunchKernelGGL(k_merge_tiles<KS_COLOR_MODE_SEMANTIC_PROBABILITY>, dim3((uint32_t)n), dim3(512), 0, c->stream,
+                         c->table, c->pool, d_keys, (const uint4*)d_payload, c->cfg.max_weight, c->d_label_lut);
+      break;
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipGetLastError());
+  (void)hipFree(d_keys);
+  return KS_OK;
+}
+
+int ks_clear(ks_ctx* c) {
+  if (!c) return KS_ERR_INVALID_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemset(c->table.keys, 0xff, ((size_t)c->table.mask + 1) * sizeof(uint64_t)));
+  HIPCHK(c, hipMemset(c->pool.updated, 0, c->cfg.max_tiles));
+  std::memset(c->h_counters, 0, sizeof(Counters));
+  HIPCHK(c, hipMemset(c->d_counters, 0, sizeof(Counters)));
+  c->tiles_initialised = 0;
+  c->fatal = false;
+  return KS_OK;
 }
 
 int ks_synchronize(ks_ctx* c) {

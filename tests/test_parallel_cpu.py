@@ -1,0 +1,114 @@
+"""N>1 path on CPU: two gloo ranks run the exchange protocol of kimera_semantics_amd.parallel
+over numpy tile stores; the result must equal a serial merge in the documented order
+(owner's own state first, then the other ranks ascending)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from kimera_semantics_amd import parallel as PAR
+from kimera_semantics_amd import synth
+from tests import merge_ref as M
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_rank_tiles(rank, n_tiles=12, seed=0):
+    """Random but valid tile records; keys overlap across ranks (same key universe)."""
+    rng = np.random.default_rng(seed * 100 + rank)
+    universe = (np.arange(40, dtype=np.uint64) * np.uint64(7919) + np.uint64(12345)) << np.uint64(3)
+    keys = rng.choice(universe, size=n_tiles, replace=False)
+    tiles = {}
+    for k in keys.tolist():
+        t = M.empty_tile()
+        touched = rng.random(512) < 0.6
+        t[touched, 0] = rng.uniform(-0.2, 0.2, touched.sum()).astype(np.float32).view(np.uint32)
+        t[touched, 1] = rng.uniform(0.01, 30.0, touched.sum()).astype(np.float32).view(np.uint32)
+        pri = (M.PRIOR_INIT + rng.uniform(-20, 0, (touched.sum(), 21))).astype(np.float32)
+        t[touched, 4:25] = pri.view(np.uint32)
+        t[touched, 3] = np.argmax(pri, axis=1).astype(np.uint32)
+        tiles[k] = t
+    return tiles
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lut = synth.default_label_colors()
+    store = M.NumpyTileStore(lut)
+    for k, t in _make_rank_tiles(rank).items():
+        store.add(k, t.copy())
+    stats = PAR.reduce_maps(store)
+    keys = store.tile_keys()
+    mine = PAR.owned_tile_mask(keys, rank, world)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=keys[mine],
+             recs=np.stack([store.tiles[int(k)] for k in keys[mine]]) if mine.any() else np.zeros((0, 512, 32), np.uint32),
+             sent=stats["tiles_sent"], recv=stats["tiles_received"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reduce_maps_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    lut = synth.default_label_colors()
+    per_rank = [_make_rank_tiles(r) for r in range(world)]
+    all_keys = sorted({k for t in per_rank for k in t})
+    owners = PAR.owner_of(np.array(all_keys, dtype=np.uint64), world)
+    got = {}
+    total_sent = total_recv = 0
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        total_sent += int(z["sent"]); total_recv += int(z["recv"])
+        for k, rec in zip(z["keys"].tolist(), z["recs"]):
+            assert k not in got, "a tile must have exactly one owner"
+            got[k] = rec
+    assert total_sent == total_recv
+    assert sorted(got) == all_keys
+    for k, owner in zip(all_keys, owners.tolist()):
+        # documented order: the owner's own state first, then the other ranks ascending
+        exp = per_rank[owner][k].copy() if k in per_rank[owner] else M.empty_tile()
+        for src in range(world):
+            if src != owner and k in per_rank[src]:
+                M.merge_records(exp, per_rank[src][k], 10000.0, 1, lut)
+        assert np.array_equal(got[k], exp), f"tile {k} (owner {owner})"
+
+
+def test_owner_partition_is_total_and_balanced():
+    keys = (np.arange(20000, dtype=np.uint64) * np.uint64(2654435761)) ^ np.uint64(0xABCDEF)
+    for world in (1, 2, 4, 8):
+        own = PAR.owner_of(keys, world)
+        assert own.min() >= 0 and own.max() < world
+        counts = np.bincount(own, minlength=world)
+        assert counts.min() > 0.8 * len(keys) / world
+    assert np.array_equal(PAR.owner_of(keys, 8), PAR.owner_of(keys.copy(), 8))  # deterministic
+
+
+def test_merge_rule_properties():
+    lut = synth.default_label_colors()
+    a, b = M.empty_tile(), M.empty_tile()
+    a[0, 0] = np.float32(0.1).view(np.uint32); a[0, 1] = np.float32(2.0).view(np.uint32); a[0, 3] = 5
+    a[0, 4 + 5] = np.float32(-0.9).view(np.uint32)
+    b[0, 0] = np.float32(-0.1).view(np.uint32); b[0, 1] = np.float32(2.0).view(np.uint32); b[0, 3] = 7
+    b[0, 4 + 7] = np.float32(-0.8).view(np.uint32)
+    out = M.merge_records(b.copy(), a, 10000.0, 1, lut)
+    assert out[0, 0].view(np.float32) == 0.0 and out[0, 1].view(np.float32) == 4.0
+    pri = out[0, 4:25].view(np.float32)
+    assert pri[5] == np.float32(M.PRIOR_INIT + (np.float32(-0.9) - M.PRIOR_INIT))
+    assert out[0, 3] == int(np.argmax(pri))
+    # merging an untouched tile changes nothing
+    assert np.array_equal(M.merge_records(b.copy(), M.empty_tile(), 10000.0, 1, lut), b)
+    # weight clamp
+    big = b.copy(); big[0, 1] = np.float32(9999.5).view(np.uint32)
+    assert M.merge_records(big, a, 10000.0, 1, lut)[0, 1].view(np.float32) == 10000.0

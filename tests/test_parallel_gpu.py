@@ -1,0 +1,100 @@
+"""-m gpu: the device side of the multi-GPU reduce on one GPU.  Several integrators stand in
+for ranks; ks_export_tiles_device / ks_merge_tiles_device must agree bit-for-bit with the
+numpy restatement of the merge rule (tests/merge_ref.py)."""
+import numpy as np
+import pytest
+
+from kimera_semantics_amd import binding as B
+from kimera_semantics_amd import synth
+from oracle import oracle_py as O
+from tests import merge_ref as M
+from tests.util import COMMON, NO_EARLY_OUT
+
+pytestmark = pytest.mark.gpu
+
+
+def _export_all(h):
+    import torch
+    keys = h.tile_keys()
+    buf = torch.empty((len(keys), M.TILE_WORDS), dtype=torch.int32, device="cuda")
+    h.export_tiles(np.arange(len(keys), dtype=np.uint32), buf.data_ptr())
+    torch.cuda.synchronize()
+    return keys, buf
+
+
+@pytest.mark.parametrize("method,color_mode", [(0, 1), (1, 1), (0, 0)])
+def test_merge_kernel_matches_numpy_rule(method, color_mode):
+    import torch
+    sc = synth.make_scene("room")
+    kw = dict(COMMON, method=method, color_mode=color_mode, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    ranks = []
+    for r in range(3):
+        h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 16, **kw))
+        f = synth.render_frame(sc, synth.arc_pose(r, 3), 128, 96, seed=200 + r)
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        ranks.append(h)
+    raw = []
+    for h in ranks:
+        k, buf = _export_all(h)
+        raw.append((k, buf.cpu().numpy().view(np.uint32).reshape(len(k), 512, 32).copy(), buf))
+    # expected: rank 0's map, then ranks 1 and 2 merged into it in order
+    lut = synth.default_label_colors()
+    exp = {int(k): rec.copy() for k, rec in zip(raw[0][0], raw[0][1])}
+    for src in (1, 2):
+        for k, rec in zip(raw[src][0].tolist(), raw[src][1]):
+            if k not in exp:
+                exp[k] = M.empty_tile()
+            M.merge_records(exp[k], rec, 10000.0, color_mode, lut)
+    # device: merge into rank 0
+    for src in (1, 2):
+        ranks[0].merge_tiles(raw[src][0], raw[src][2].data_ptr())
+    k0, buf0 = _export_all(ranks[0])
+    got = buf0.cpu().numpy().view(np.uint32).reshape(len(k0), 512, 32)
+    assert sorted(k0.tolist()) == sorted(exp)
+    overlap = len(set(raw[0][0].tolist()) & set(raw[1][0].tolist()))
+    assert overlap > 10, "poses must overlap for the test to mean anything"
+    for k, rec in zip(k0.tolist(), got):
+        assert np.array_equal(rec[:, :25], exp[k][:, :25]), f"tile {k}"
+
+
+def test_reduced_map_is_close_to_sequential_integration():
+    """Merging per-frame maps is not the same arithmetic as integrating the frames one after the
+    other (the +-truncation clamp and the weight clamp act per update there): labels must agree
+    except near ties, TSDF within a loose tolerance."""
+    sc = synth.make_scene("room")
+    kw = dict(COMMON, method=1)
+    frames = [synth.render_frame(sc, synth.arc_pose(r, 3), 128, 96, seed=300 + r) for r in range(3)]
+    seq = O.Oracle(O.default_config(**kw))
+    for f in frames:
+        seq.integrate(f.T_G_C, f.xyz, None, f.labels)
+    hs = []
+    for f in frames:
+        h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 16, **kw))
+        h.integrate(f.T_G_C, f.xyz, None, f.labels)
+        hs.append(h)
+    for src in (1, 2):
+        k, buf = _export_all(hs[src])
+        hs[0].merge_tiles(k, buf.data_ptr())
+    idx = seq.block_indices()
+    assert np.array_equal(idx, hs[0].block_indices())
+    _, ot, os_ = seq.download(idx)
+    _, ht, hs_ = hs[0].download(idx)
+    touched = ot["weight"] > 0
+    assert np.array_equal(touched, ht["weight"] > 0)
+    agree = (os_["label"] == hs_["label"])[touched].mean()
+    assert agree > 0.99, agree
+    dd = np.abs(ot["distance"] - ht["distance"])[touched]
+    assert np.median(dd) < 1e-4 and (dd > 0.05).mean() < 0.05
+
+
+def test_clear_resets_the_map():
+    sc = synth.make_scene("room")
+    h = B.HipIntegrator(B.default_config(max_tiles=2048, max_points=1 << 16, **dict(COMMON, method=0)))
+    f = synth.render_frame(sc, synth.single_pose(), 96, 72, seed=1)
+    s1 = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    i1, t1, _ = h.download()
+    h.clear()
+    assert len(h.block_indices()) == 0 and len(h.tile_keys()) == 0
+    h2 = B.HipIntegrator(B.default_config(max_tiles=2048, max_points=1 << 16, **dict(COMMON, method=0)))
+    s2 = h2.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    assert s1.n_rays_cast == s2.n_rays_cast
