@@ -130,6 +130,21 @@ int ks_integrate_points(ks_ctx* ctx, const float T_G_C[7], const float* xyz, con
 int ks_integrate_points_device(ks_ctx* ctx, const float T_G_C[7], const float* d_xyz, const uint8_t* d_rgba,
                                const uint8_t* d_labels, size_t n, int freespace, ks_frame_stats* stats);
 
+/* Depth + label image entry: the step BEFORE the hot path fused into the
+ * GPU frontend.  Replaces PointCloudFromDepth::convert
+ * (kimera_semantics_ros/include/kimera_semantics_ros/depth_map_to_pointcloud.h:213-275) plus the
+ * colour->label host loop: back-projects with K = {fx, fy, cx, cy}, drops invalid pixels in image
+ * order, then integrates exactly as ks_integrate_points would on the resulting cloud.
+ * depth_fmt 0 = float32 metres (invalid: non-finite), 1 = uint16 millimetres (invalid: 0).
+ * label_img (u8 per pixel) is preferred; with label_img == NULL the rgba8 segmentation image is
+ * decoded through the colour map.  Host pointers / device pointers respectively. */
+int ks_integrate_depth(ks_ctx* ctx, const float T_G_C[7], const void* depth, int depth_fmt, const uint8_t* label_img,
+                       const uint8_t* rgba_img, int width, int height, const float K[4], int freespace,
+                       ks_frame_stats* stats);
+int ks_integrate_depth_device(ks_ctx* ctx, const float T_G_C[7], const void* d_depth, int depth_fmt,
+                              const uint8_t* d_label_img, const uint8_t* d_rgba_img, int width, int height,
+                              const float K[4], int freespace, ks_frame_stats* stats);
+
 /* Layer views (host Layer<TsdfVoxel> / Layer<SemanticVoxel> contract, block edge = voxels_per_side). */
 int ks_num_blocks(ks_ctx* ctx, size_t* n);
 int ks_get_block_indices(ks_ctx* ctx, int32_t* out_xyz, size_t cap, size_t* n); /* sorted (x,y,z) */

@@ -30,7 +30,7 @@ SEM_DTYPE = np.dtype([("label", "u1"), ("pad", "u1", (3,)), ("priors", "<f4", (N
 # Every symbol include/ks_hip.h declares (checked by tests/test_abi.py).
 ABI_SYMBOLS = [
     "ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_set_color_to_label",
-    "ks_integrate_points", "ks_integrate_points_device", "ks_num_blocks", "ks_get_block_indices",
+    "ks_integrate_points", "ks_integrate_points_device", "ks_integrate_depth", "ks_integrate_depth_device", "ks_num_blocks", "ks_get_block_indices",
     "ks_get_updated_block_indices", "ks_download_blocks", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear",
     "ks_debug_radix_sort", "ks_synchronize", "ks_stream",
     "ks_profile_enable", "ks_profile_get",
@@ -99,6 +99,8 @@ def lib():
         L.ks_set_color_to_label.argtypes = [vp, vp, vp, C.c_size_t]
         L.ks_integrate_points.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(KsFrameStats)]
         L.ks_integrate_points_device.argtypes = [vp, vp, vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(KsFrameStats)]
+        L.ks_integrate_depth.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(KsFrameStats)]
+        L.ks_integrate_depth_device.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.POINTER(KsFrameStats)]
         L.ks_num_blocks.argtypes = [vp, C.POINTER(C.c_size_t)]
         L.ks_get_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.ks_get_updated_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
@@ -189,6 +191,20 @@ class HipIntegrator:
         st = KsFrameStats()
         self._chk(lib().ks_integrate_points(self._h, _ptr(T), _ptr(xyz), _ptr(rgba), _ptr(labels), xyz.shape[0],
                                             int(freespace), C.byref(st)))
+        return st
+
+    def integrate_depth(self, T_G_C, depth, K, label_img=None, rgba_img=None, freespace=False) -> KsFrameStats:
+        """depth: [H,W] float32 metres or uint16 millimetres; K = (fx, fy, cx, cy)."""
+        T = np.ascontiguousarray(T_G_C, dtype=np.float32)
+        depth = np.ascontiguousarray(depth)
+        fmt = 0 if depth.dtype == np.float32 else 1
+        assert depth.dtype in (np.float32, np.uint16)
+        Kc = np.ascontiguousarray(K, dtype=np.float32)
+        lab = None if label_img is None else np.ascontiguousarray(label_img, dtype=np.uint8)
+        col = None if rgba_img is None else np.ascontiguousarray(rgba_img, dtype=np.uint8)
+        st = KsFrameStats()
+        self._chk(lib().ks_integrate_depth(self._h, _ptr(T), _ptr(depth), fmt, _ptr(lab), _ptr(col), depth.shape[1],
+                                           depth.shape[0], _ptr(Kc), int(freespace), C.byref(st)))
         return st
 
     def integrate_device(self, T_G_C, d_xyz: int, d_rgba: int, d_labels: int, n: int, freespace=False) -> KsFrameStats:

@@ -1154,6 +1154,108 @@ __global__ void __launch_bounds__(512) k_merge_tiles(TileTable T, Pool P, const 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// f-1: depth + label image -> camera-frame points on the GPU (replaces the XYZRGB cloud and the
+// colour->label round trip).  Pinhole back-projection exactly as
+// [KR:include/kimera_semantics_ros/depth_map_to_pointcloud.h:256-272]:
+//   x = (u - cx) * depth * (unit/fx);  y = (v - cy) * depth * (unit/fy);  z = toMeters(depth)
+// Invalid pixels (non-finite f32 / zero u16) are DROPPED with a stable compaction, as the
+// Voxblox server drops non-finite points before integratePointCloud, so the
+// point order — and with it the integration order — is that of the reference pipeline.
+// ------------------------------------------------------------------------------------------
+struct DepthParams {
+  const void* depth;
+  const uint8_t* label_img;   // u8 labels (preferred) or nullptr
+  const uint8_t* rgba_img;    // rgba8 segmentation colours (used when label_img == nullptr) or nullptr
+  int fmt;                    // 0 = f32 metres, 1 = u16 millimetres
+  int width, height;
+  float cx, cy, constant_x, constant_y;
+};
+__device__ __forceinline__ bool depth_pixel(const DepthParams& D, uint32_t i, float& x, float& y, float& z) {
+  const int u = (int)(i % (uint32_t)D.width), v = (int)(i / (uint32_t)D.width);
+  if (D.fmt == 0) {
+    const float d = ((const float*)D.depth)[i];
+    if (!isfinite(d)) return false;
+    x = ((float)u - D.cx) * d * D.constant_x;
+    y = ((float)v - D.cy) * d * D.constant_y;
+    z = d;
+  } else {
+    const uint16_t d = ((const uint16_t*)D.depth)[i];
+    if (d == 0) return false;
+    x = ((float)u - D.cx) * (float)d * D.constant_x;
+    y = ((float)v - D.cy) * (float)d * D.constant_y;
+    z = (float)d * 0.001f;
+  }
+  return true;
+}
+__global__ void __launch_bounds__(1024) k_depth_count(DepthParams D, uint32_t n_px, uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  float x, y, z;
+  const bool ok = i < n_px && depth_pixel(D, i, x, y, z);
+  const unsigned long long m = __ballot(ok);
+  if (lane_id() == 0 && m) atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = s_cnt;
+}
+// single workgroup: exclusive scan of the per-block counts (<= 4096 blocks), total in out[nb]
+__global__ void __launch_bounds__(1024) k_depth_scan(uint32_t* __restrict__ counts, uint32_t nb) {
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  for (uint32_t base = 0; base < nb; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nb ? counts[i] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(x, o);
+      if (lane >= (uint32_t)o) x += y;
+    }
+    if (lane == 63) s_wave[wave] = x;
+    __syncthreads();
+    uint32_t add = s_carry;
+    for (uint32_t w = 0; w < wave; ++w) add += s_wave[w];
+    if (i < nb) counts[i] = add + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = add + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) counts[nb] = s_carry;
+}
+__global__ void __launch_bounds__(1024) k_depth_compact(DepthParams D, uint32_t n_px, const uint32_t* __restrict__ block_off,
+                                                        const uint32_t* __restrict__ label_lut, float* __restrict__ xyz,
+                                                        uint8_t* __restrict__ rgba, uint8_t* __restrict__ labels) {
+  __shared__ uint32_t s_wave[16];
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  float x = 0.f, y = 0.f, z = 0.f;
+  const bool ok = i < n_px && depth_pixel(D, i, x, y, z);
+  const unsigned long long m = __ballot(ok);
+  if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t off = block_off[blockIdx.x];
+  for (uint32_t w = 0; w < wave; ++w) off += s_wave[w];
+  if (ok) {
+    const uint32_t o = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    xyz[3 * o] = x;
+    xyz[3 * o + 1] = y;
+    xyz[3 * o + 2] = z;
+    if (D.label_img) {
+      const uint32_t lab = D.label_img[i];
+      labels[o] = (uint8_t)lab;
+      ((uint32_t*)rgba)[o] = (label_lut[lab] & 0x00ffffffu) | 0xff000000u;  // cloud alpha is 255 (:269)
+    } else if (D.rgba_img) {
+      ((uint32_t*)rgba)[o] = (((const uint32_t*)D.rgba_img)[i] & 0x00ffffffu) | 0xff000000u;
+    }
+  }
+}
+
 // sorted integration order: key = bits of squared norm (non-negative float => monotone as u32)
 __global__ void __launch_bounds__(256) k_sqnorm(uint32_t n, const float* __restrict__ xyz, uint32_t* __restrict__ keys,
                                                 uint32_t* __restrict__ vals) {
@@ -1281,6 +1383,12 @@ struct ks_ctx {
   size_t cap_block_idx = 0;
   uint8_t *d_tsdf_out = nullptr, *d_sem_out = nullptr;
   size_t cap_out_blocks = 0;
+
+  uint32_t* d_depth_blocks = nullptr;
+  size_t cap_depth_blocks = 0;
+  uint8_t* d_img_depth = nullptr;
+  uint8_t* d_img_aux = nullptr;
+  size_t cap_img_depth = 0, cap_img_aux = 0;
 
   bool profiling = false;
   ks_profile prof{};
@@ -1743,7 +1851,7 @@ void ks_destroy(ks_ctx* c) {
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_rays, c->d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_ray_list, c->d_nsteps, c->d_pair_off, c->d_pairs, c->d_pairs2, c->d_counters,
-                  c->d_block_idx, c->d_tsdf_out, c->d_sem_out};
+                  c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   ksrs::release(c->sort_ws);
@@ -1797,6 +1905,88 @@ int ks_integrate_points(ks_ctx* c, const float T[7], const float* xyz, const uin
     if (labels) HIPCHK(c, hipMemcpyAsync(c->d_labels, labels, n, hipMemcpyHostToDevice, c->stream));
   }
   return integrate_device(c, T, c->d_xyz, rgba ? c->d_rgba : nullptr, labels ? c->d_labels : nullptr, n, freespace, stats);
+}
+
+static int integrate_depth_impl(ks_ctx* c, const float T[7], DepthParams D, int freespace, ks_frame_stats* stats) {
+  const size_t n_px = (size_t)D.width * D.height;
+  int rc = ensure_points(c, n_px);
+  if (rc) return rc;
+  const uint32_t nb = (uint32_t)((n_px + 1023) / 1024);
+  if (nb + 1 > c->cap_depth_blocks) {
+    if ((rc = dev_alloc(c, &c->d_depth_blocks, (size_t)nb + 1))) return rc;
+    c->cap_depth_blocks = nb + 1;
+  }
+  hipStream_t st = c->stream;
+  hipLaunchKernelGGL(k_depth_count, dim3(nb), dim3(1024), 0, st, D, (uint32_t)n_px, c->d_depth_blocks);
+  hipLaunchKernelGGL(k_depth_scan, dim3(1), dim3(1024), 0, st, c->d_depth_blocks, nb);
+  const bool have_labels = D.label_img != nullptr;
+  hipLaunchKernelGGL(k_depth_compact, dim3(nb), dim3(1024), 0, st, D, (uint32_t)n_px, c->d_depth_blocks, c->d_label_lut,
+                     c->d_xyz, c->d_rgba, c->d_labels);
+  uint32_t n = 0;
+  HIPCHK(c, hipMemcpyAsync(&n, c->d_depth_blocks + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  if (!have_labels && !(D.rgba_img && c->d_color_lut)) {
+    c->err = "ks_integrate_depth: need a label image, or a colour image plus ks_set_color_to_label";
+    return KS_ERR_INVALID_ARG;
+  }
+  return integrate_device(c, T, c->d_xyz, c->d_rgba, have_labels ? c->d_labels : nullptr, n, freespace, stats);
+}
+
+int ks_integrate_depth(ks_ctx* c, const float T[7], const void* depth, int depth_fmt, const uint8_t* label_img,
+                       const uint8_t* rgba_img, int width, int height, const float K[4], int freespace,
+                       ks_frame_stats* stats) {
+  if (!c || !T || !depth || !K || width <= 0 || height <= 0 || (depth_fmt != 0 && depth_fmt != 1)) return KS_ERR_INVALID_ARG;
+  const size_t n_px = (size_t)width * height;
+  const size_t dbytes = n_px * (depth_fmt == 0 ? 4 : 2);
+  if (dbytes > c->cap_img_depth) {
+    int rc = dev_alloc(c, &c->d_img_depth, dbytes);
+    if (rc) return rc;
+    c->cap_img_depth = dbytes;
+  }
+  if (n_px * 4 > c->cap_img_aux) {
+    int rc = dev_alloc(c, &c->d_img_aux, n_px * 4);
+    if (rc) return rc;
+    c->cap_img_aux = n_px * 4;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_img_depth, depth, dbytes, hipMemcpyHostToDevice, c->stream));
+  DepthParams D{};
+  D.depth = c->d_img_depth;
+  if (label_img) {
+    HIPCHK(c, hipMemcpyAsync(c->d_img_aux, label_img, n_px, hipMemcpyHostToDevice, c->stream));
+    D.label_img = c->d_img_aux;
+  } else if (rgba_img) {
+    HIPCHK(c, hipMemcpyAsync(c->d_img_aux, rgba_img, n_px * 4, hipMemcpyHostToDevice, c->stream));
+    D.rgba_img = c->d_img_aux;
+  }
+  D.fmt = depth_fmt;
+  D.width = width;
+  D.height = height;
+  D.cx = K[2];
+  D.cy = K[3];
+  // unit_scaling / fx evaluated in double then narrowed, as depth_map_to_pointcloud.h:227-229
+  const double unit = depth_fmt == 0 ? 1.0 : 0.001;
+  D.constant_x = (float)(unit / (double)K[0]);
+  D.constant_y = (float)(unit / (double)K[1]);
+  return integrate_depth_impl(c, T, D, freespace, stats);
+}
+
+int ks_integrate_depth_device(ks_ctx* c, const float T[7], const void* d_depth, int depth_fmt, const uint8_t* d_label_img,
+                              const uint8_t* d_rgba_img, int width, int height, const float K[4], int freespace,
+                              ks_frame_stats* stats) {
+  if (!c || !T || !d_depth || !K || width <= 0 || height <= 0 || (depth_fmt != 0 && depth_fmt != 1)) return KS_ERR_INVALID_ARG;
+  DepthParams D{};
+  D.depth = d_depth;
+  D.label_img = d_label_img;
+  D.rgba_img = d_label_img ? nullptr : d_rgba_img;
+  D.fmt = depth_fmt;
+  D.width = width;
+  D.height = height;
+  D.cx = K[2];
+  D.cy = K[3];
+  const double unit = depth_fmt == 0 ? 1.0 : 0.001;
+  D.constant_x = (float)(unit / (double)K[0]);
+  D.constant_y = (float)(unit / (double)K[1]);
+  return integrate_depth_impl(c, T, D, freespace, stats);
 }
 
 int ks_num_blocks(ks_ctx* c, size_t* n) {
