@@ -155,6 +155,8 @@ struct FrameParams {
   int carving, allow_clear, freespace, use_const_weight;
   int method, color_mode, early_out, sorted_order;
   int n_dynamic;
+  const uint64_t* grazing_keys;  // merged + anti-grazing: sorted end-voxel keys of this frame (else nullptr)
+  const uint64_t* ray_keys;      // merged + anti-grazing: end-voxel key of each bundle, by first position
   const uint32_t* order;     // sorted mode: position -> index (nullptr in mixed mode)
   const uint32_t* inv_order; // sorted mode: index -> position
   uint32_t seq_bits;         // low bits of a pair key hold the ray sequence
@@ -168,6 +170,26 @@ __device__ __forceinline__ uint32_t point_order(const FrameParams& F, const uint
   if (F.sorted_order) return order[p];
   if (1024u * F.per_group <= p) return p;
   return (p % 1024u) * F.per_group + p / 1024u;
+}
+
+// Anti-grazing (vxb Config::enable_anti_grazing, off by default): a bundle's ray skips voxels that
+// are the END voxel of another non-clearing bundle of this frame
+// [K:src/semantic_tsdf_integrator_merged.cpp:306-313].  Membership = binary search in the sorted
+// point keys (non-clearing keys have bit 63 clear and sort first).
+__device__ __forceinline__ bool grazing_skip(const FrameParams& F, int cx, int cy, int cz, bool clearing, uint64_t own_key) {
+  if (!F.grazing_keys) return false;
+  const int lim = kCoordBias - 1;
+  if (abs(cx) >= lim || abs(cy) >= lim || abs(cz) >= lim) return false;
+  const uint64_t k = ((uint64_t)(uint32_t)(cx + kCoordBias) << 42) | ((uint64_t)(uint32_t)(cy + kCoordBias) << 21) |
+                     (uint64_t)(uint32_t)(cz + kCoordBias);
+  if (!clearing && k == own_key) return false;
+  uint32_t lo = 0, hi = F.n;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (F.grazing_keys[mid] < k) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo < F.n && F.grazing_keys[lo] == k;
 }
 
 // Ray descriptors: fast = one per point, stored at the point's memory index; merged = one
@@ -455,7 +477,8 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
                                                  const uint32_t* __restrict__ svals, const float4* __restrict__ g_pw,
                                                  const uint2* __restrict__ g_lc, RayDesc* __restrict__ rays,
                                                  float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
-                                                 uint32_t* __restrict__ long_list, Counters* C) {
+                                                 uint32_t* __restrict__ long_list, uint64_t* __restrict__ ray_keys,
+                                                 Counters* C) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   bool head = false, is_long = false;
   uint32_t first_p = 0;
@@ -514,6 +537,7 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
       }
     }
     finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p]);
+    if (ray_keys) ray_keys[first_p] = key & ~(1ull << 63);
   }
   const uint32_t pos = block_append(work, &C->n_rays);
   if (work) ray_list[pos] = first_p;
@@ -524,7 +548,8 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
                                                      const float4* __restrict__ g_pw, const uint2* __restrict__ g_lc,
                                                      RayDesc* __restrict__ rays, float* __restrict__ deltas,
                                                      uint32_t* __restrict__ ray_list,
-                                                     const uint32_t* __restrict__ long_list, Counters* C) {
+                                                     const uint32_t* __restrict__ long_list,
+                                                     uint64_t* __restrict__ ray_keys, Counters* C) {
   const uint32_t n_long = C->n_long_bundles;
   const int lane = (int)lane_id();
   for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
@@ -603,6 +628,7 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
     }
     if (lane == 0) {
       finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p]);
+      if (ray_keys) ray_keys[first_p] = key & ~(1ull << 63);
       ray_list[atomicAdd(&C->n_rays, 1u)] = first_p;
     }
   }
@@ -633,6 +659,7 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
     } else {
       uint64_t last_tile = kEmpty64;
       int consecutive = 0;
+      const uint64_t own_key = F.ray_keys ? F.ray_keys[p] : 0ull;
       for (int s = 0; s <= dda.steps; ++s) {
         if (F.early_out) {
           // ApproxHashSet::replaceHash on voxel_observed_approx_set_ — racy by design in the
@@ -643,6 +670,10 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
           if (old == h) ++consecutive;
           else consecutive = 0;
           if (consecutive > F.max_collisions) break;
+        }
+        if (grazing_skip(F, dda.cx, dda.cy, dda.cz, ((d.info >> 10) & 1u) != 0, own_key)) {
+          dda.advance();
+          continue;
         }
         const uint64_t tk = pack_tile(dda.cx >> 3, dda.cy >> 3, dda.cz >> 3);
         if (tk != last_tile) {
@@ -721,7 +752,12 @@ __global__ void __launch_bounds__(256) k_emit(FrameParams F, uint32_t n_rays, co
   uint64_t* out = pairs + pair_off[r];
   uint64_t last_tile = kEmpty64;
   uint32_t slot = 0;
-  for (uint32_t s = 0; s < count; ++s) {
+  const uint64_t own_key = F.ray_keys ? F.ray_keys[p] : 0ull;
+  for (uint32_t s = 0; s < count;) {
+    if (grazing_skip(F, dda.cx, dda.cy, dda.cz, clearing, own_key)) {
+      dda.advance();
+      continue;
+    }
     const uint64_t tk = pack_tile(dda.cx >> 3, dda.cy >> 3, dda.cz >> 3);
     if (tk != last_tile) {
       slot = tile_lookup(T, tk);
@@ -731,6 +767,7 @@ __global__ void __launch_bounds__(256) k_emit(FrameParams F, uint32_t n_rays, co
     const uint32_t local = (uint32_t)(dda.cx & 7) + 8u * ((uint32_t)(dda.cy & 7) + 8u * (uint32_t)(dda.cz & 7));
     out[s] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | seq;
     dda.advance();
+    ++s;
   }
 }
 
@@ -1363,6 +1400,7 @@ struct ks_ctx {
   uint32_t* d_hash = nullptr;
   uint32_t *d_skeys32 = nullptr, *d_skeys32b = nullptr;
   float4* d_gpw = nullptr;
+  uint64_t* d_ray_keys = nullptr;
   uint2* d_glc = nullptr;
   unsigned long long* d_long_list = nullptr;
   uint32_t* d_blong = nullptr;
@@ -1441,6 +1479,7 @@ int ensure_points(ks_ctx* c, size_t n) {
     if ((rc = dev_alloc(c, &c->d_deltas, cap * kNumLabels))) return rc;
     if ((rc = dev_alloc(c, &c->d_gpw, cap))) return rc;
     if ((rc = dev_alloc(c, &c->d_glc, cap))) return rc;
+    if ((rc = dev_alloc(c, &c->d_ray_keys, cap))) return rc;
     if ((rc = dev_alloc(c, &c->d_blong, cap / kLongRun + 64))) return rc;
   }
   c->cap_points = cap;
@@ -1607,10 +1646,16 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
     stage_mark(c, 2);
     hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
                        order_ptr, sk, sv, c->d_gpw, c->d_glc);
+    uint64_t* ray_keys = cfg.enable_anti_grazing ? c->d_ray_keys : nullptr;
     hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, sk, sv, c->d_gpw, c->d_glc, c->d_rays, c->d_deltas,
-                       c->d_ray_list, c->d_blong, c->d_counters);
+                       c->d_ray_list, c->d_blong, ray_keys, c->d_counters);
     hipLaunchKernelGGL(k_bundles_long, dim3((uint32_t)std::min<size_t>(n / kLongRun + 1, 2048)), dim3(64), 0, st, F,
-                       sk, sv, c->d_gpw, c->d_glc, c->d_rays, c->d_deltas, c->d_ray_list, c->d_blong, c->d_counters);
+                       sk, sv, c->d_gpw, c->d_glc, c->d_rays, c->d_deltas, c->d_ray_list, c->d_blong, ray_keys,
+                       c->d_counters);
+    if (cfg.enable_anti_grazing) {
+      F.grazing_keys = sk;
+      F.ray_keys = c->d_ray_keys;
+    }
   }
   stage_mark(c, 3);
   // march over an upper bound of rays (<= n); the live ray count stays on the device
@@ -1766,10 +1811,6 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     g_create_error = "voxels_per_side must be 8, 16, 32 or 64";
     return KS_ERR_INVALID_ARG;
   }
-  if (cfg->enable_anti_grazing) {
-    g_create_error = "enable_anti_grazing is not supported by the HIP integrator yet";
-    return KS_ERR_UNSUPPORTED;
-  }
   if (cfg->n_dynamic_labels < 0 || cfg->n_dynamic_labels > 32 || cfg->max_tiles == 0 || cfg->max_tiles >= (1u << 23)) {
     g_create_error = "bad n_dynamic_labels / max_tiles";
     return KS_ERR_INVALID_ARG;
@@ -1848,7 +1889,7 @@ void ks_destroy(ks_ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->table.keys, c->table.vals, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
-                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_rays, c->d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_long_list, c->d_blong, c->d_pkeys,
+                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_rays, c->d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_ray_list, c->d_nsteps, c->d_pair_off, c->d_pairs, c->d_pairs2, c->d_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};

@@ -162,3 +162,16 @@ def test_depth_image_u16_and_colour_decoding():
     so = o.integrate(f.T_G_C, pts[ok], None, f.label_img.reshape(-1)[ok])
     assert (so.n_rays_cast, so.n_voxel_updates) == (st.n_rays_cast, st.n_voxel_updates)
     compare_maps(o, h, exact=True)
+
+
+def test_merged_anti_grazing_exact():
+    """vxb Config::enable_anti_grazing: rays skip voxels that are another bundle's end voxel."""
+    f = small_frame(seed=13, w=128, h=96)
+    o, h = _pair(1, enable_anti_grazing=1)
+    so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    o2 = O.Oracle(O.default_config(**dict(COMMON, method=1)))
+    s2 = o2.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    assert so.n_voxel_updates < s2.n_voxel_updates  # the flag does something
+    assert (so.n_rays_cast, so.n_voxel_updates) == (sh.n_rays_cast, sh.n_voxel_updates)
+    compare_maps(o, h, exact=True)
