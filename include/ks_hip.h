@@ -94,7 +94,8 @@ enum {
   KS_STAGE_MARCH,        /* DDA count + tile allocation (+ observed-set early-out) */
   KS_STAGE_EMIT,         /* DDA emit of (voxel, ray) pairs */
   KS_STAGE_SORT_PAIRS,   /* group pairs by voxel in ray order */
-  KS_STAGE_APPLY,        /* per-voxel TSDF + semantic log-likelihood update */
+  KS_STAGE_APPLY,        /* k_apply: per-voxel TSDF + semantic log-likelihood update (runs < 32 updates) */
+  KS_STAGE_APPLY_LONG,   /* k_apply_long: one wavefront per voxel with >= 32 updates */
   KS_STAGE_COUNT
 };
 typedef struct ks_profile {

@@ -21,7 +21,7 @@ KS_COLOR_MODE_COLOR, KS_COLOR_MODE_SEMANTIC, KS_COLOR_MODE_SEMANTIC_PROBABILITY 
 KS_ORDER_MIXED, KS_ORDER_SORTED = 0, 1
 KS_ERR_LABEL_RANGE, KS_ERR_PROBABILITY, KS_ERR_POOL_FULL, KS_ERR_NO_DEVICE, KS_ERR_UNSUPPORTED = -2, -3, -5, -7, -8
 
-STAGES = ["points", "sort_points", "rays", "march", "emit", "sort_pairs", "apply"]
+STAGES = ["points", "sort_points", "rays", "march", "emit", "sort_pairs", "apply", "apply_long"]
 
 TSDF_DTYPE = np.dtype([("distance", "<f4"), ("weight", "<f4"), ("color", "u1", (4,))])
 SEM_DTYPE = np.dtype([("label", "u1"), ("pad", "u1", (3,)), ("priors", "<f4", (NUM_LABELS,)),
@@ -62,7 +62,7 @@ class KsFrameStats(C.Structure):
 
 
 class KsProfile(C.Structure):
-    _fields_ = [("ms", C.c_double * 7), ("launches", C.c_uint64 * 7), ("frames", C.c_uint64),
+    _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("frames", C.c_uint64),
                 ("updates", C.c_uint64), ("points", C.c_uint64)]
 
 
@@ -285,5 +285,5 @@ class HipIntegrator:
     def profile(self, reset=False) -> dict:
         p = KsProfile()
         self._chk(lib().ks_profile_get(self._h, C.byref(p), int(reset)))
-        return {"ms": {STAGES[i]: p.ms[i] for i in range(7)}, "launches": {STAGES[i]: p.launches[i] for i in range(7)},
+        return {"ms": {STAGES[i]: p.ms[i] for i in range(8)}, "launches": {STAGES[i]: p.launches[i] for i in range(8)},
                 "frames": p.frames, "updates": p.updates, "points": p.points}

@@ -860,19 +860,38 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
   unsigned long long H = __ballot(head && !is_long);
   const uint32_t grp = lane >> 3, sub = lane & 7u;
   const uint32_t cbase = (sub - 1u) * 4u;  // first class index of this lane (subs 1..6)
-  while (H) {
-    int my_pos = -1;
+  // software pipeline over the groups of 8 heads: the record of the NEXT head is requested
+  // before the recurrence of the current one runs
+  auto next_head = [&](unsigned long long& Hm) {
+    int pos = -1;
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-      if (H) {
-        const int p = __ffsll((long long)H) - 1;
-        H &= H - 1ull;
-        if ((int)grp == g) my_pos = p;
+      if (Hm) {
+        const int p = __ffsll((long long)Hm) - 1;
+        Hm &= Hm - 1ull;
+        if ((int)grp == g) pos = p;
       }
     }
+    return pos;
+  };
+  bool more = H != 0ull;
+  int nxt_pos = more ? next_head(H) : -1;
+  uint32_t nxt_vox = perm_u(vox, nxt_pos >= 0 ? (uint32_t)nxt_pos : lane);
+  uint4 nxt_q = make_uint4(0u, 0u, 0u, 0u);
+  if (nxt_pos >= 0 && sub < 7u) nxt_q = (P.vox + (size_t)nxt_vox * 8)[sub];
+  while (more) {
+    const int my_pos = nxt_pos;
     const bool active = my_pos >= 0;
     const uint32_t hp = active ? (uint32_t)my_pos : lane;
-    const uint32_t hvox = perm_u(vox, hp);
+    const uint32_t hvox = nxt_vox;
+    const uint4 q = nxt_q;
+    more = H != 0ull;
+    if (more) {
+      nxt_pos = next_head(H);
+      nxt_vox = perm_u(vox, nxt_pos >= 0 ? (uint32_t)nxt_pos : lane);
+      nxt_q = make_uint4(0u, 0u, 0u, 0u);
+      if (nxt_pos >= 0 && sub < 7u) nxt_q = (P.vox + (size_t)nxt_vox * 8)[sub];
+    }
     // length of the run inside this window
     uint32_t len = 0;
     if (active) {
@@ -880,8 +899,6 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
       len = above ? (uint32_t)__ffsll((long long)above) : (64u - hp);
     }
     uint4* rec = P.vox + (size_t)(active ? hvox : 0u) * 8;
-    uint4 q = make_uint4(0u, 0u, 0u, 0u);
-    if (active && sub < 7u) q = rec[sub];
     float dist = __uint_as_float(q.x), weight = __uint_as_float(q.y);  // meaningful for sub 0
     uint32_t color = q.z;
     float p0 = __uint_as_float(q.x), p1 = __uint_as_float(q.y), p2 = __uint_as_float(q.z), p3 = __uint_as_float(q.w);
@@ -891,7 +908,10 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
       if (__ballot(on) == 0ull) break;
       const uint32_t src = on ? hp + s : lane;
       const float sdf_s = perm_f(u.sdf, src), uw_s = perm_f(u.uw, src);
-      const float dm_s = perm_f(u.dm, src), dn_s = perm_f(u.dn, src);
+      // fast: every ray carries the same two increments (log p, log(1-p)); merged: per bundle
+      const bool per_ray_inc = F.method == KS_METHOD_MERGED;
+      const float dm_s = per_ray_inc ? perm_f(u.dm, src) : F.log_match;
+      const float dn_s = per_ray_inc ? perm_f(u.dn, src) : F.log_non_match;
       const uint32_t info_s = perm_u(u.info, src);
       uint32_t color_s = 0, rp_s = 0;
       if (COLOR_MODE == KS_COLOR_MODE_COLOR) color_s = perm_u(u.color, src);
@@ -981,7 +1001,6 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
   // One wavefront per block: LDS traffic below is ordered by program order (DS operations of
   // a wave execute in order), no s_barrier needed; wave_barrier() only pins the compiler.
   __shared__ float s_inc[64][kNumLabels];  // class increments of the 64 updates in flight
-  __shared__ float s_uw[64];               // their TSDF weights
   const uint32_t n_long = C->n_long;
   const int lane = (int)lane_id();
   const int cls = lane < kNumLabels ? lane : 0;
@@ -1000,19 +1019,20 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
     const f3 v_voxel_origin = sub3(c, F.T.t);
 
     // software pipeline: rays of batch b+1 and pair keys of batch b+2 are in flight while batch b is applied
+    // All loads of the pipeline are UNCONDITIONAL (indices clamped): a load under a divergent
+    // branch makes the compiler drain vmcnt at the join, which serialises the prefetch.
+    const unsigned long long last = n_pairs - 1ull;
     unsigned long long base = start;
-    uint64_t key_cur = (base + lane < n_pairs) ? pairs[base + lane] : kEmpty64;
-    uint64_t key_nxt = (base + 64 + lane < n_pairs) ? pairs[base + 64 + lane] : kEmpty64;
-    bool in = ((uint32_t)(key_cur >> F.seq_bits) == vox);
-    RayDesc d{};
-    if (in) d = rays[ray_index(F, (uint32_t)key_cur & F.point_mask)];
+    uint64_t key_cur = pairs[min(base + lane, last)];
+    uint64_t key_nxt = pairs[min(base + 64ull + lane, last)];
+    bool in = (base + lane < n_pairs) && ((uint32_t)(key_cur >> F.seq_bits) == vox);
+    RayDesc d = rays[ray_index(F, (uint32_t)key_cur & F.point_mask)];
     for (;;) {
       const int cnt = (int)__popcll(__ballot(in));  // sorted => the in-lanes form a prefix
       if (cnt == 0) break;
-      const bool in_n = ((uint32_t)(key_nxt >> F.seq_bits) == vox);
-      RayDesc d_n{};
-      if (in_n) d_n = rays[ray_index(F, (uint32_t)key_nxt & F.point_mask)];
-      const uint64_t key_nn = (base + 128 + lane < n_pairs) ? pairs[base + 128 + lane] : kEmpty64;
+      const bool in_n = (base + 64ull + lane < n_pairs) && ((uint32_t)(key_nxt >> F.seq_bits) == vox);
+      const RayDesc d_n = rays[ray_index(F, (uint32_t)key_nxt & F.point_mask)];
+      const uint64_t key_nn = pairs[min(base + 128ull + lane, last)];
 
       // ---- per-lane, voxel-state-independent part: computeDistance + weight drop-off ----
       float sdf = 0.f, uw = 0.f;
@@ -1040,17 +1060,23 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
 #pragma unroll
           for (int l = 0; l < kNumLabels; ++l) s_inc[lane][l] = ((uint32_t)l == lab) ? a : b;
         }
-        s_uw[lane] = uw;
       }
       __builtin_amdgcn_wave_barrier();
 
       // ---- pass 1: the weight recurrence (independent of the distance) ----
       // w' = min(max_weight, w + uw) unless w + uw < 1e-6 (then the TSDF update is a no-op).
       float my_w = 0.0f, my_nw = 1.0f;
-      {
+      if (weight == Pm.max_weight && __ballot(in && !(uw >= 0.0f)) == 0ull) {
+        // Weight already clamped at max_weight and every increment is non-negative: each
+        // update sees w = max_weight and leaves min(max_weight, max_weight + uw) = max_weight,
+        // so the recurrence degenerates to 64 independent additions (the steady state of the
+        // voxels next to the sensor, which are the long runs).
+        my_w = weight;
+        my_nw = weight + uw;
+      } else {
         float w_run = weight;
         for (int k = 0; k < cnt; ++k) {
-          const float nw = w_run + s_uw[k];
+          const float nw = w_run + bcast_f(uw, k);  // lane broadcast: an LDS read here costs its full latency per step
           if (lane == k) { my_w = w_run; my_nw = nw; }
           if (!(nw < kEps)) w_run = std_min(Pm.max_weight, nw);
         }
@@ -1702,6 +1728,7 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
 #define KS_LAUNCH_APPLY(MODE)                                                                                        \
   hipLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, F, n_pairs, sp, c->d_rays, c->d_deltas,               \
                      c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters);                               \
+  stage_mark(c, 7);                                                                                                  \
   hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(64), 0, st, F, n_pairs, sp, c->d_rays, c->d_deltas,           \
                      c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters)
     switch (cfg.color_mode) {
@@ -1713,8 +1740,9 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
   } else {
     stage_mark(c, 5);
     stage_mark(c, 6);
+    stage_mark(c, 7);
   }
-  stage_mark(c, 7);
+  stage_mark(c, 8);
   HIPCHK(c, hipGetLastError());
   if (c->profiling) {
     HIPCHK(c, hipEventSynchronize(c->ev[KS_STAGE_COUNT]));

@@ -175,3 +175,20 @@ def test_merged_anti_grazing_exact():
     assert so.n_voxel_updates < s2.n_voxel_updates  # the flag does something
     assert (so.n_rays_cast, so.n_voxel_updates) == (sh.n_rays_cast, sh.n_voxel_updates)
     compare_maps(o, h, exact=True)
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_saturated_weights_exact(method):
+    """Small max_weight: voxel weights clamp within a frame or two, which exercises the
+    saturated-weight shortcut of the wave-per-voxel kernel (and the clamp itself)."""
+    o, h = _pair(method, max_consecutive_ray_collisions=NO_EARLY_OUT, max_weight=3.0)
+    sc = synth.make_scene("room")
+    T = synth.pose_to_T((3.5, 0.3, 1.2), 0.1)
+    for k in range(3):
+        f = synth.render_frame(sc, T, 192, 144, seed=90 + k)
+        so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        assert so.n_voxel_updates == sh.n_voxel_updates
+    rep = compare_maps(o, h, exact=True)
+    _, t, _ = h.download()
+    assert (t["weight"] == np.float32(3.0)).sum() > 1000  # the clamp was hit

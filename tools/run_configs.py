@@ -48,7 +48,7 @@ def run(name, method, n_frames, cpu_frames, max_tiles):
     h.synchronize()
     dt = time.perf_counter() - t0
     prof = h.profile()
-    apply_ms = prof["ms"]["apply"] / max(1, prof["frames"])
+    apply_ms = (prof["ms"]["apply"] + prof["ms"]["apply_long"]) / max(1, prof["frames"])
     res = dict(config=name, method=method, frames=n_frames, points=int(np.mean([len(f.xyz) for f in frames])),
                updates_per_frame=int(upd / n_frames), gpu_ms_per_frame=round(dt / n_frames * 1e3, 3),
                gpu_Mupd_s=round(upd / dt / 1e6, 1), gpu_fps=round(n_frames / dt, 1),
