@@ -52,12 +52,15 @@ def common_cfg(method):
 
 def cpu_baseline(args, frames):
     """Oracle (a restatement of the reference: kind 'port') timed on this host's cores on a
-    bounded sample of the same workload."""
+    bounded sample of the same workload.  The reference defaults to integrator_threads =
+    hardware_concurrency(); on many-core hosts its per-voxel mutexes make that slower than a
+    few threads, so several thread counts are tried and the best one is the reported baseline."""
     from oracle import oracle_py as O
     cores = os.cpu_count() or 1
     n = min(args.cpu_frames, len(frames))
-    out = {}
-    for label, threads, nf in (("mt", cores, n), ("st", 1, max(1, n // 3))):
+    tried = {}
+    for threads in sorted({1, min(8, cores), cores}):
+        nf = n if threads > 1 else max(1, n // 2)
         o = O.Oracle(O.default_config(integrator_threads=threads, **common_cfg(args.method)))
         upd = 0
         t0 = time.perf_counter()
@@ -65,13 +68,15 @@ def cpu_baseline(args, frames):
             st = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
             upd += st.n_voxel_updates
         dt = time.perf_counter() - t0
-        out[label] = (upd / dt / 1e6, nf / dt, nf, upd)
+        tried[threads] = (upd / dt / 1e6, nf / dt, nf)
         o.close()
-    return {"value": round(out["mt"][0], 4), "unit": "Mvoxel-updates/s", "cores": cores, "kind": "port",
-            "frames_per_s": round(out["mt"][1], 3),
-            "single_thread_value": round(out["st"][0], 4),
-            "sample": f"first {out['mt'][2]} frames of the same trajectory, oracle with integrator_threads={cores} "
-                      f"('mixed' order, reference defaults); single-thread value from the first {out['st'][2]} frames"}
+    best = max(tried, key=lambda t: tried[t][0])
+    return {"value": round(tried[best][0], 4), "unit": "Mvoxel-updates/s", "cores": best, "kind": "port",
+            "frames_per_s": round(tried[best][1], 3), "host_cores": cores,
+            "by_threads": {str(t): round(v[0], 4) for t, v in tried.items()},
+            "sample": f"first {tried[best][2]} frames of the same trajectory through the CPU oracle "
+                      f"(restatement, bit-identical to the real reference sources for the Kimera half), "
+                      f"'mixed' order, reference defaults; best of integrator_threads in {sorted(tried)}"}
 
 
 def main():

@@ -192,3 +192,68 @@ def test_saturated_weights_exact(method):
     rep = compare_maps(o, h, exact=True)
     _, t, _ = h.download()
     assert (t["weight"] == np.float32(3.0)).sum() > 1000  # the clamp was hit
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_full_size_640x480_frame_exact(method):
+    """BASELINE.json's frame size (640x480 @ 5 cm, 5 m rays), one frame, bit-exact vs the oracle."""
+    sc = synth.make_scene("room")
+    f = synth.render_frame(sc, synth.trajectory_pose(5), 640, 480, seed=5)  # includes a 4.6k-point bundle
+    o, h = _pair(method, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    assert (so.n_valid_points, so.n_rays_cast, so.n_voxel_updates) == (sh.n_valid_points, sh.n_rays_cast, sh.n_voxel_updates)
+    rep = compare_maps(o, h, exact=True)
+    assert rep["oracle_touched"] > 150000
+
+
+def test_full_size_properties():
+    """Size-independent properties at full frame size: determinism, unknown-label no-op,
+    per-frame update counts add up, untouched voxels keep the initial state."""
+    sc = synth.make_scene("room")
+    f = synth.render_frame(sc, synth.trajectory_pose(9), 640, 480, seed=9)
+    kw = dict(COMMON, method=1)
+    a = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 19, **kw))
+    b = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 19, **kw))
+    sa = a.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    sb = b.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    ia, ta, sea = a.download()
+    ib, tb, seb = b.download()
+    assert sa.n_voxel_updates == sb.n_voxel_updates
+    assert np.array_equal(ia, ib) and ta.tobytes() == tb.tobytes() and sea.tobytes() == seb.tobytes()  # deterministic
+    # a second pass with every label forced to 0 (unknown) must not move any prior or label
+    s2 = a.integrate(f.T_G_C, f.xyz, f.rgba, np.zeros_like(f.labels))
+    assert s2.n_voxel_updates == sa.n_voxel_updates  # same rays, same voxels
+    _, t2, se2 = a.download(ia)
+    assert np.array_equal(se2["priors"].view(np.uint32), sea["priors"].view(np.uint32))
+    assert np.array_equal(se2["label"], sea["label"])
+    touched = ta["weight"] > 0
+    assert np.all(t2["weight"][touched] >= ta["weight"][touched])  # weights only grow
+    untouched = (t2["weight"] == 0) & (se2["label"] == 0)
+    assert np.all(se2["priors"][untouched] == np.float32(-0.60205999132))
+
+
+def test_error_codes_mirror_reference_checks():
+    f = small_frame(seed=1, w=64, h=48)
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 14, **dict(COMMON, method=0)))
+    bad = f.labels.copy()
+    bad[7] = 21  # CHECK_LT(label, 21) in the reference
+    with pytest.raises(B.KsError) as e:
+        h.integrate(f.T_G_C, f.xyz, f.rgba, bad)
+    assert e.value.code == B.KS_ERR_LABEL_RANGE
+    assert len(h.block_indices()) == 0  # nothing was integrated
+    st = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)  # context stays usable
+    assert st.n_voxel_updates > 0
+    # empty cloud is a no-op
+    st = h.integrate(f.T_G_C, np.zeros((0, 3), np.float32), np.zeros((0, 4), np.uint8), np.zeros(0, np.uint8))
+    assert st.n_voxel_updates == 0
+    # invalid probabilities are rejected at construction (CHECKs of setSemanticProbabilities)
+    for p in (0.0, 1.0, 0.4):
+        with pytest.raises(B.KsError) as e:
+            B.HipIntegrator(B.default_config(**dict(COMMON, method=0, semantic_measurement_probability=p)))
+        assert e.value.code == B.KS_ERR_PROBABILITY
+    # tile pool exhaustion is reported, not silently dropped
+    small = B.HipIntegrator(B.default_config(max_tiles=16, max_points=1 << 14, **dict(COMMON, method=1)))
+    with pytest.raises(B.KsError) as e:
+        small.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    assert e.value.code == B.KS_ERR_POOL_FULL
