@@ -10,8 +10,8 @@
 //   points  : one lane per point — validity, T_G_C * p, start-voxel / end-voxel key          (k_points_*)
 //   sort    : radix sort of point keys (start-voxel dedup slots | end-voxel bundles)
 //   rays    : exact sequential-equivalent dedup (fast) or per-bundle merge (merged)           (k_dedup / k_bundles)
-//   march   : one lane per ray — DDA walk, tile allocation in the spatial hash, step count     (k_march)
-//   emit    : one lane per ray — DDA walk again, write (voxel slot, ray seq) pairs             (k_emit)
+//   march   : one lane per ray — ONE DDA walk: tile allocation in the spatial hash, early-out,
+//             (voxel slot, ray seq) pairs staged per wavefront in LDS                          (k_march)
 //   sort    : radix sort of pairs => every voxel's updates contiguous, in reference order
 //   apply   : one lane per voxel run — sequential TSDF + log-likelihood update, one RMW        (k_apply)
 // Ordering contract: per voxel, updates are applied in exactly the order the reference's
@@ -223,6 +223,9 @@ __host__ __device__ __forceinline__ uint32_t mix64(uint64_t k) {
   return (uint32_t)k;
 }
 
+constexpr uint32_t kSlotPending = 0xffffffffu;  // table value before the allocating lane has published the slot
+constexpr uint32_t kSlotBad = 0xfffffffeu;      // pool exhausted
+
 // Allocation of a voxel tile on first touch: CAS on the key claims the table entry, an
 // atomic bump of the pool counter assigns the slot.  Replaces the reference's temp-block map
 // under a global mutex, [K:src/semantic_integrator_base.cpp:205-265].
@@ -234,13 +237,14 @@ __device__ __forceinline__ void tile_insert(const TileTable& T, Counters* C, uin
     if (k == kEmpty64) {
       const uint64_t old = atomicCAS((unsigned long long*)&T.keys[h], (unsigned long long)kEmpty64, (unsigned long long)key);
       if (old == kEmpty64) {
-        const uint32_t slot = atomicAdd(&C->n_tiles, 1u);
+        uint32_t slot = atomicAdd(&C->n_tiles, 1u);
         if (slot < T.max_tiles) {
-          T.vals[h] = slot;
           T.slot_keys[slot] = key;
         } else {
           atomicOr(&C->err, kErrPool);
+          slot = kSlotBad;
         }
+        __hip_atomic_store(&T.vals[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
       if (old == key) return;
@@ -248,6 +252,42 @@ __device__ __forceinline__ void tile_insert(const TileTable& T, Counters* C, uin
     h = (h + 1) & T.mask;
   }
   atomicOr(&C->err, kErrTable);
+}
+
+// get-or-insert WITHOUT waiting: returns the slot, or kSlotPending (with the table position in
+// *hpos) when another lane has claimed the key but not yet published its slot.  Waiting is done
+// by the caller after the wave has reconverged, so a waiting lane can never sit in front of the
+// publishing lane of its own wavefront.
+__device__ __forceinline__ uint32_t tile_slot_nowait(const TileTable& T, Counters* C, uint64_t key, uint32_t* hpos) {
+  uint32_t h = mix64(key) & T.mask;
+  for (uint32_t probes = 0; probes <= T.mask; ++probes) {
+    uint64_t k = T.keys[h];  // plain load first: tiles of earlier frames hit here
+    if (k != key) k = __hip_atomic_load(&T.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k == kEmpty64) {
+      const uint64_t old = atomicCAS((unsigned long long*)&T.keys[h], (unsigned long long)kEmpty64, (unsigned long long)key);
+      if (old == kEmpty64) {
+        uint32_t slot = atomicAdd(&C->n_tiles, 1u);
+        if (slot < T.max_tiles) {
+          T.slot_keys[slot] = key;
+        } else {
+          atomicOr(&C->err, kErrPool);
+          slot = kSlotBad;
+        }
+        __hip_atomic_store(&T.vals[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return slot;
+      }
+      k = old;
+    }
+    if (k == key) {
+      *hpos = h;
+      uint32_t v = T.vals[h];
+      if (v == kSlotPending) v = __hip_atomic_load(&T.vals[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return v;
+    }
+    h = (h + 1) & T.mask;
+  }
+  atomicOr(&C->err, kErrTable);
+  return kSlotBad;
 }
 
 __device__ __forceinline__ uint32_t tile_lookup(const TileTable& T, uint64_t key) {
@@ -635,32 +675,72 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
 }
 
 // ------------------------------------------------------------------------------------------
-// K3a: march — DDA walk per ray, tile allocation, optional observed-set early-out, step count.
-// Launched over an upper bound of rays; the live count is read from device memory so the
-// host does not have to synchronise between the ray stage and the march.
+// K3a/K3b: march + emit — ONE DDA walk per ray: tile allocation in the spatial hash, optional
+// observed-set early-out, and one (voxel slot id, ray sequence) key per update.  Keys are staged
+// in a per-wavefront LDS buffer and flushed with one global atomic per flush (a per-lane or even
+// per-step atomic on the pair counter would serialise at ~88/us).  Launched over an upper bound
+// of rays; the live count is read from device memory, so the host does not synchronise between
+// the ray stage and the march.
 // [K:src/semantic_tsdf_integrator_fast.cpp:94-141], [K:src/semantic_tsdf_integrator_merged.cpp:288-328]
 // ------------------------------------------------------------------------------------------
+constexpr uint32_t kWaveBuf = 512;  // pair keys staged per wavefront (4 KiB)
+
 __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __restrict__ ray_list,
-                                               const RayDesc* __restrict__ rays, TileTable T,
-                                               uint64_t* __restrict__ observed_set, uint32_t* __restrict__ nsteps,
-                                               unsigned long long* __restrict__ pair_off, Counters* C) {
+                                               const RayDesc* __restrict__ rays, TileTable T, Pool P,
+                                               uint64_t* __restrict__ observed_set, uint64_t* __restrict__ pairs,
+                                               unsigned long long pairs_cap, Counters* C) {
+  __shared__ uint64_t s_buf[4][kWaveBuf];
   const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n_rays = C->n_rays;
   if (blockIdx.x * blockDim.x >= n_rays) return;  // whole block idle (uniform)
-  uint32_t count = 0;
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  uint64_t* buf = s_buf[wave];
+
+  bool done = true;
+  Dda dda{};
+  uint32_t seq = 0;
+  bool clearing = false;
+  uint64_t own_key = 0;
   if (r < n_rays && (C->err & (kErrLabel | kErrIndex)) == 0) {
     const uint32_t p = ray_list[r];
     const RayDesc d = rays[ray_index(F, p)];
-    Dda dda;
-    dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv,
-              F.trunc, /*cast_from_origin=*/F.method == KS_METHOD_MERGED);
-    if (!dda.in_range) {
-      atomicOr(&C->err, kErrIndex);
-    } else {
-      uint64_t last_tile = kEmpty64;
-      int consecutive = 0;
-      const uint64_t own_key = F.ray_keys ? F.ray_keys[p] : 0ull;
-      for (int s = 0; s <= dda.steps; ++s) {
+    clearing = ((d.info >> 10) & 1u) != 0;
+    dda.setup(F.T.t, {d.px, d.py, d.pz}, clearing, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
+              /*cast_from_origin=*/F.method == KS_METHOD_MERGED);
+    // merged: normal bundles integrate before clearing bundles ([K:src/semantic_tsdf_integrator_merged.cpp:126-144])
+    seq = (F.method == KS_METHOD_MERGED && clearing) ? (p | F.clear_bit) : p;
+    own_key = F.ray_keys ? F.ray_keys[p] : 0ull;
+    if (!dda.in_range) atomicOr(&C->err, kErrIndex);
+    else done = false;
+  }
+
+  uint32_t wcount = 0;  // keys in this wave's buffer (wave-uniform)
+  auto flush = [&]() {
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd(&C->n_pairs, (unsigned long long)wcount);
+    base = __shfl(base, 0);
+    if (base + wcount <= pairs_cap) {
+      for (uint32_t i = lane; i < wcount; i += 64) pairs[base + i] = buf[i];
+    } else if (lane == 0) {
+      atomicOr(&C->err, kErrTable);
+    }
+    wcount = 0;
+  };
+
+  int s = 0;
+  int consecutive = 0;
+  uint64_t last_tile = kEmpty64;
+  uint32_t slot = 0;
+  while (__ballot(!done) != 0ull) {
+    bool emit = false;
+    uint32_t hpos = 0;
+    uint32_t got = 0;
+    bool need_tile = false;
+    if (!done) {
+      if (s > dda.steps) {
+        done = true;
+      } else {
+        bool stop = false;
         if (F.early_out) {
           // ApproxHashSet::replaceHash on voxel_observed_approx_set_ — racy by design in the
           // multi-threaded reference; here one atomic exchange per step.
@@ -669,48 +749,51 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
               atomicExch((unsigned long long*)&observed_set[(h + F.observed_offset) & kSetMask], (unsigned long long)h);
           if (old == h) ++consecutive;
           else consecutive = 0;
-          if (consecutive > F.max_collisions) break;
+          if (consecutive > F.max_collisions) stop = true;
         }
-        if (grazing_skip(F, dda.cx, dda.cy, dda.cz, ((d.info >> 10) & 1u) != 0, own_key)) {
+        if (stop) {
+          done = true;
+        } else if (grazing_skip(F, dda.cx, dda.cy, dda.cz, clearing, own_key)) {
           dda.advance();
-          continue;
+          ++s;
+        } else {
+          emit = true;
+          const uint64_t tk = pack_tile(dda.cx >> 3, dda.cy >> 3, dda.cz >> 3);
+          if (tk != last_tile) {
+            need_tile = true;
+            last_tile = tk;
+            got = tile_slot_nowait(T, C, tk, &hpos);
+          }
         }
-        const uint64_t tk = pack_tile(dda.cx >> 3, dda.cy >> 3, dda.cz >> 3);
-        if (tk != last_tile) {
-          tile_insert(T, C, tk);
-          last_tile = tk;
-        }
-        ++count;
-        dda.advance();
       }
     }
-  }
-  // exclusive scan of the step counts inside the block, one atomic per workgroup for the base
-  __shared__ uint32_t s_wave[4];
-  __shared__ unsigned long long s_base;
-  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-  uint32_t x = count;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t y = __shfl_up(x, o);
-    if (lane >= (uint32_t)o) x += y;
-  }
-  if (lane == 63) s_wave[wave] = x;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t total = 0;
-    for (int w = 0; w < 4; ++w) {
-      const uint32_t t = s_wave[w];
-      s_wave[w] = total;
-      total += t;
+    // the wave has reconverged: every allocating lane of THIS wave has published its slot
+    if (need_tile) {
+      uint32_t spins = 0;
+      while (got == kSlotPending) {
+        got = __hip_atomic_load(&T.vals[hpos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > (1u << 22)) {
+          atomicOr(&C->err, kErrTable);
+          got = kSlotBad;
+        }
+      }
+      slot = got;
+      if (slot < T.max_tiles) P.updated[slot] = 1;
     }
-    s_base = total ? atomicAdd(&C->n_pairs, (unsigned long long)total) : 0ull;
+    const unsigned long long m = __ballot(emit);
+    if (m) {
+      if (emit) {
+        const uint32_t local = (uint32_t)(dda.cx & 7) + 8u * ((uint32_t)(dda.cy & 7) + 8u * (uint32_t)(dda.cz & 7));
+        const uint32_t pos = wcount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        buf[pos] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | seq;
+        dda.advance();
+        ++s;
+      }
+      wcount += (uint32_t)__popcll(m);
+      if (wcount > kWaveBuf - 64u) flush();
+    }
   }
-  __syncthreads();
-  if (r < n_rays) {
-    nsteps[r] = count;
-    pair_off[r] = s_base + s_wave[wave] + (x - count);
-  }
+  if (wcount) flush();
 }
 
 __global__ void __launch_bounds__(512) k_init_tiles(Pool P, uint32_t first_slot) {
@@ -729,46 +812,6 @@ __global__ void __launch_bounds__(512) k_init_tiles(Pool P, uint32_t first_slot)
     tile[q] = v;
   }
   if (threadIdx.x == 0) P.updated[slot] = 1;
-}
-
-// K3b: emit — same walk, write one (voxel slot id, ray sequence) key per update.
-__global__ void __launch_bounds__(256) k_emit(FrameParams F, uint32_t n_rays, const uint32_t* __restrict__ ray_list,
-                                              const RayDesc* __restrict__ rays, TileTable T, Pool P,
-                                              const uint32_t* __restrict__ nsteps,
-                                              const unsigned long long* __restrict__ pair_off,
-                                              uint64_t* __restrict__ pairs) {
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= n_rays) return;
-  const uint32_t count = nsteps[r];
-  if (count == 0) return;
-  const uint32_t p = ray_list[r];
-  const RayDesc d = rays[ray_index(F, p)];
-  const bool clearing = ((d.info >> 10) & 1u) != 0;
-  Dda dda;
-  dda.setup(F.T.t, {d.px, d.py, d.pz}, clearing, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
-            F.method == KS_METHOD_MERGED);
-  // merged: normal bundles integrate before clearing bundles ([K:src/semantic_tsdf_integrator_merged.cpp:126-144])
-  const uint32_t seq = (F.method == KS_METHOD_MERGED && clearing) ? (p | F.clear_bit) : p;
-  uint64_t* out = pairs + pair_off[r];
-  uint64_t last_tile = kEmpty64;
-  uint32_t slot = 0;
-  const uint64_t own_key = F.ray_keys ? F.ray_keys[p] : 0ull;
-  for (uint32_t s = 0; s < count;) {
-    if (grazing_skip(F, dda.cx, dda.cy, dda.cz, clearing, own_key)) {
-      dda.advance();
-      continue;
-    }
-    const uint64_t tk = pack_tile(dda.cx >> 3, dda.cy >> 3, dda.cz >> 3);
-    if (tk != last_tile) {
-      slot = tile_lookup(T, tk);
-      last_tile = tk;
-      P.updated[slot] = 1;
-    }
-    const uint32_t local = (uint32_t)(dda.cx & 7) + 8u * ((uint32_t)(dda.cy & 7) + 8u * (uint32_t)(dda.cz & 7));
-    out[s] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | seq;
-    dda.advance();
-    ++s;
-  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1436,9 +1479,7 @@ struct ks_ctx {
   uint32_t* d_inv_order = nullptr;
   uint32_t *d_okeys = nullptr, *d_okeys2 = nullptr, *d_ovals = nullptr;
   uint32_t* d_ray_list = nullptr;
-  uint32_t* d_nsteps = nullptr;
-  unsigned long long* d_pair_off = nullptr;
-  size_t cap_pairs = 0;
+  size_t cap_pairs = 0, cap_pairs_in = 0;
   uint64_t *d_pairs = nullptr, *d_pairs2 = nullptr;
   ksrs::Workspace sort_ws;
   Counters* d_counters = nullptr;
@@ -1499,8 +1540,6 @@ int ensure_points(ks_ctx* c, size_t n) {
   if ((rc = dev_alloc(c, &c->d_okeys2, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_ovals, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_ray_list, cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_nsteps, cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_pair_off, cap))) return rc;
   if (c->cfg.method == KS_METHOD_MERGED) {
     if ((rc = dev_alloc(c, &c->d_deltas, cap * kNumLabels))) return rc;
     if ((rc = dev_alloc(c, &c->d_gpw, cap))) return rc;
@@ -1512,11 +1551,20 @@ int ensure_points(ks_ctx* c, size_t n) {
   return KS_OK;
 }
 
-int ensure_pairs(ks_ctx* c, size_t n) {
+// d_pairs is written by k_march before the pair count is known: it is sized for the worst
+// case (every ray at full length); d_pairs2 / the long-run list are sized by the actual count.
+int ensure_pairs_in(ks_ctx* c, size_t bound) {
+  if (bound <= c->cap_pairs_in) return KS_OK;
+  const size_t cap = std::max<size_t>(bound, 1 << 20);
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_pairs, cap))) return rc;
+  c->cap_pairs_in = cap;
+  return KS_OK;
+}
+int ensure_pairs_out(ks_ctx* c, size_t n) {
   if (n <= c->cap_pairs) return KS_OK;
   const size_t cap = std::max<size_t>(n + n / 4, 1 << 20);
   int rc;
-  if ((rc = dev_alloc(c, &c->d_pairs, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_pairs2, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_long_list, cap / kLongRun + 64))) return rc;
   c->cap_pairs = cap;
@@ -1524,8 +1572,8 @@ int ensure_pairs(ks_ctx* c, size_t n) {
 }
 
 template <typename K>
-int sort_keys(ks_ctx* c, K* a, K* b, size_t n, unsigned end_bit, K** result) {
-  HIPCHK(c, (ksrs::sort<K, false>(c->sort_ws, a, b, nullptr, nullptr, n, end_bit, c->stream, result, nullptr)));
+int sort_keys(ks_ctx* c, K* a, K* b, size_t n, unsigned end_bit, K** result, unsigned begin_bit = 0) {
+  HIPCHK(c, (ksrs::sort<K, false>(c->sort_ws, a, b, nullptr, nullptr, n, end_bit, c->stream, result, nullptr, begin_bit)));
   return KS_OK;
 }
 template <typename K>
@@ -1684,9 +1732,15 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
     }
   }
   stage_mark(c, 3);
-  // march over an upper bound of rays (<= n); the live ray count stays on the device
-  hipLaunchKernelGGL(k_march, dim3(nb), dim3(256), 0, st, F, c->d_ray_list, c->d_rays, c->table, c->d_observed_set,
-                     c->d_nsteps, c->d_pair_off, c->d_counters);
+  // march (+emit) over an upper bound of rays (<= n); the live ray count stays on the device.
+  // Worst-case pair count: every point becomes a ray of full length.
+  {
+    const double max_len = (double)cfg.max_ray_length_m + 2.0 * (double)cfg.truncation_distance;
+    const size_t steps_max = (size_t)std::ceil(1.7321 * max_len * (double)c->voxel_size_inv) + 8;
+    if ((rc = ensure_pairs_in(c, n * steps_max))) return rc;
+  }
+  hipLaunchKernelGGL(k_march, dim3(nb), dim3(256), 0, st, F, c->d_ray_list, c->d_rays, c->table, c->pool,
+                     c->d_observed_set, c->d_pairs, (unsigned long long)c->cap_pairs_in, c->d_counters);
   // the only host synchronisation of the frame: pair / tile / ray counts and error flags
   HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
@@ -1714,14 +1768,18 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
     c->tiles_initialised = new_tiles;
   }
   if (n_pairs > 0) {
-    if ((rc = ensure_pairs(c, n_pairs))) return rc;
-    const uint32_t rb = (n_rays + 255) / 256;
-    hipLaunchKernelGGL(k_emit, dim3(rb), dim3(256), 0, st, F, n_rays, c->d_ray_list, c->d_rays, c->table, c->pool,
-                       c->d_nsteps, c->d_pair_off, c->d_pairs);
+    if ((rc = ensure_pairs_out(c, n_pairs))) return rc;
     stage_mark(c, 5);
     const unsigned end_bit = F.seq_bits + 9 + bits_for(new_tiles);
     uint64_t* sp = nullptr;
-    if ((rc = sort_keys(c, c->d_pairs, c->d_pairs2, n_pairs, std::min(64u, end_bit), &sp))) return rc;
+    // Deterministic modes sort by (voxel, ray sequence): every voxel replays its updates in
+    // the reference's single-thread order.  With the racy early-out of `fast` the set of
+    // updates is already schedule dependent (as in the multi-threaded reference, whose per-
+    // voxel order is whatever the mutex grants), so grouping by voxel suffices: the sort
+    // skips the sequence bits (2 fewer passes); the order inside a voxel is then the stable
+    // emission order.
+    const unsigned begin_bit = F.early_out ? F.seq_bits : 0u;
+    if ((rc = sort_keys(c, c->d_pairs, c->d_pairs2, n_pairs, std::min(64u, end_bit), &sp, begin_bit))) return rc;
     stage_mark(c, 6);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
@@ -1887,6 +1945,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipMalloc((void**)&c->table.vals, cap * sizeof(uint32_t)));
   CRCHK(hipMalloc((void**)&c->table.slot_keys, mt * sizeof(uint64_t)));
   CRCHK(hipMemset(c->table.keys, 0xff, cap * sizeof(uint64_t)));
+  CRCHK(hipMemset(c->table.vals, 0xff, cap * sizeof(uint32_t)));  // kSlotPending
   CRCHK(hipMalloc((void**)&c->pool.vox, mt * kTileVoxels * 8 * sizeof(uint4)));
   CRCHK(hipMalloc((void**)&c->pool.updated, mt));
   CRCHK(hipMemset(c->pool.updated, 0, mt));
@@ -1919,7 +1978,7 @@ void ks_destroy(ks_ctx* c) {
   void* ptrs[] = {c->table.keys, c->table.vals, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_rays, c->d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
-                  c->d_ray_list, c->d_nsteps, c->d_pair_off, c->d_pairs, c->d_pairs2, c->d_counters,
+                  c->d_ray_list, c->d_pairs, c->d_pairs2, c->d_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -2233,6 +2292,7 @@ int ks_clear(ks_ctx* c) {
   if (!c) return KS_ERR_INVALID_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemset(c->table.keys, 0xff, ((size_t)c->table.mask + 1) * sizeof(uint64_t)));
+  HIPCHK(c, hipMemset(c->table.vals, 0xff, ((size_t)c->table.mask + 1) * sizeof(uint32_t)));
   HIPCHK(c, hipMemset(c->pool.updated, 0, c->cfg.max_tiles));
   std::memset(c->h_counters, 0, sizeof(Counters));
   HIPCHK(c, hipMemset(c->d_counters, 0, sizeof(Counters)));

@@ -41,7 +41,7 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, unsigned l
 // wave-aggregated (one LDS atomic per distinct digit per wave instruction): the upper digits
 // of these keys are almost constant, a per-lane atomic would serialise 2048-fold.
 template <typename K>
-__global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uint32_t n, int passes,
+__global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uint32_t n, int passes, int begin_bit,
                                                  uint32_t* __restrict__ hist) {
   __shared__ uint32_t s_hist[kMaxPasses][kBins];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uin
     const K key = valid ? keys[idx] : (K)0;
     const unsigned long long active = __ballot(valid);
     for (int p = 0; p < passes; ++p) {
-      const uint32_t d = digit_of(key, p * kRadixBits);
+      const uint32_t d = digit_of(key, begin_bit + p * kRadixBits);
       // the upper digits of these keys are nearly constant: one add for a wave-uniform digit,
       // per-lane LDS atomics otherwise
       const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
@@ -217,13 +217,13 @@ inline void release(Workspace& w) {
 
 template <typename K, bool HAS_VALUES, int THREADS, int ITEMS>
 inline void launch_passes(Workspace& w, K*& kin, K*& kout, uint32_t*& vin, uint32_t*& vout, size_t n, int passes,
-                          uint32_t tiles, hipStream_t stream) {
+                          uint32_t tiles, unsigned begin_bit, hipStream_t stream) {
   uint32_t* hist = w.d_ws;
   uint32_t* tickets = w.d_ws + kMaxPasses * kBins;
   uint32_t* status = w.d_ws + kHeadWords;
   for (int p = 0; p < passes; ++p) {
     hipLaunchKernelGGL((k_rs_pass<K, HAS_VALUES, THREADS, ITEMS>), dim3(tiles), dim3(THREADS), 0, stream, kin, kout, vin,
-                       vout, (uint32_t)n, p * kRadixBits, hist + p * kBins, status + (size_t)p * tiles * kBins,
+                       vout, (uint32_t)n, (int)begin_bit + p * kRadixBits, hist + p * kBins, status + (size_t)p * tiles * kBins,
                        tiles <= 1024u ? (uint32_t*)nullptr : tickets + p);
     K* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
@@ -232,12 +232,13 @@ inline void launch_passes(Workspace& w, K*& kin, K*& kout, uint32_t*& vin, uint3
 
 template <typename K, bool HAS_VALUES>
 inline hipError_t sort(Workspace& w, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b, size_t n,
-                       unsigned end_bit, hipStream_t stream, K** keys_result, uint32_t** vals_result) {
+                       unsigned end_bit, hipStream_t stream, K** keys_result, uint32_t** vals_result,
+                       unsigned begin_bit = 0) {
   *keys_result = keys_a;
   if (vals_result) *vals_result = vals_a;
-  if (n == 0 || end_bit == 0) return hipSuccess;
-  int passes = (int)((end_bit + kRadixBits - 1) / kRadixBits);
-  if (passes > (int)(sizeof(K) * 8 / kRadixBits)) passes = (int)(sizeof(K) * 8 / kRadixBits);
+  if (n == 0 || end_bit <= begin_bit) return hipSuccess;
+  if (end_bit > sizeof(K) * 8) end_bit = (unsigned)(sizeof(K) * 8);
+  const int passes = (int)((end_bit - begin_bit + kRadixBits - 1) / kRadixBits);
   // tile size: keep the number of tiles (look-back chain depth) small for per-frame sizes
   const int tile = (n <= 2048u * 2048u) ? 2048 : (n <= 2048u * 8192u) ? 8192 : 16384;
   const uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
@@ -247,14 +248,14 @@ inline hipError_t sort(Workspace& w, K* keys_a, K* keys_b, uint32_t* vals_a, uin
   e = hipMemsetAsync(w.d_ws, 0, words * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((k_rs_hist<K>), dim3((uint32_t)((n + 2047) / 2048)), dim3(256), 0, stream, keys_a, (uint32_t)n,
-                     passes, w.d_ws);
+                     passes, (int)begin_bit, w.d_ws);
   K* kin = keys_a;
   K* kout = keys_b;
   uint32_t* vin = vals_a;
   uint32_t* vout = vals_b;
-  if (tile == 2048) launch_passes<K, HAS_VALUES, 256, 8>(w, kin, kout, vin, vout, n, passes, tiles, stream);
-  else if (tile == 8192) launch_passes<K, HAS_VALUES, 512, 16>(w, kin, kout, vin, vout, n, passes, tiles, stream);
-  else launch_passes<K, HAS_VALUES, 512, 32>(w, kin, kout, vin, vout, n, passes, tiles, stream);
+  if (tile == 2048) launch_passes<K, HAS_VALUES, 256, 8>(w, kin, kout, vin, vout, n, passes, tiles, begin_bit, stream);
+  else if (tile == 8192) launch_passes<K, HAS_VALUES, 512, 16>(w, kin, kout, vin, vout, n, passes, tiles, begin_bit, stream);
+  else launch_passes<K, HAS_VALUES, 512, 32>(w, kin, kout, vin, vout, n, passes, tiles, begin_bit, stream);
   *keys_result = kin;
   if (vals_result) *vals_result = vin;
   return hipGetLastError();
