@@ -158,7 +158,8 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel (k_apply: the per-voxel TSDF + semantic RMW), from
         # HIP events recorded on the integrator's own stream inside the timed region.
-        apply_ms = prof["ms"]["apply"] / max(1, prof["launches"]["apply"])
+        # k_apply dispatch begin->end (events attached to the dispatch itself, on the integrator's stream)
+        apply_ms = prof["apply_kernel_ms"] / max(1, prof["apply_kernel_launches"])
         upd_per_launch = prof["updates"] / max(1, prof["frames"])
         pts_per_launch = prof["points"] / max(1, prof["frames"])
         alg_bytes = BYTES_PER_UPDATE * upd_per_launch

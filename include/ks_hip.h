@@ -104,6 +104,8 @@ typedef struct ks_profile {
   uint64_t frames;
   uint64_t updates;                /* voxel updates over profiled frames */
   uint64_t points;
+  double apply_kernel_ms;          /* k_apply dispatch begin->end (hipExtLaunchKernel events), summed */
+  uint64_t apply_kernel_launches;
 } ks_profile;
 
 typedef struct ks_ctx ks_ctx;

@@ -63,7 +63,8 @@ class KsFrameStats(C.Structure):
 
 class KsProfile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("frames", C.c_uint64),
-                ("updates", C.c_uint64), ("points", C.c_uint64)]
+                ("updates", C.c_uint64), ("points", C.c_uint64), ("apply_kernel_ms", C.c_double),
+                ("apply_kernel_launches", C.c_uint64)]
 
 
 def build(force: bool = False) -> str:
@@ -286,4 +287,5 @@ class HipIntegrator:
         p = KsProfile()
         self._chk(lib().ks_profile_get(self._h, C.byref(p), int(reset)))
         return {"ms": {STAGES[i]: p.ms[i] for i in range(8)}, "launches": {STAGES[i]: p.launches[i] for i in range(8)},
-                "frames": p.frames, "updates": p.updates, "points": p.points}
+                "frames": p.frames, "updates": p.updates, "points": p.points,
+                "apply_kernel_ms": p.apply_kernel_ms, "apply_kernel_launches": p.apply_kernel_launches}

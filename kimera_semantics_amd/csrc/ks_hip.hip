@@ -25,6 +25,7 @@
 #include <string.h>
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -78,10 +79,6 @@ __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
   if (lane == 0 && m) base = atomicAdd(counter, (uint32_t)__popcll(m));
   base = __shfl(base, 0);
   return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
-__device__ __forceinline__ void wave_count(bool pred, uint32_t* counter) {
-  const unsigned long long m = __ballot(pred);
-  if (lane_id() == 0 && m) atomicAdd(counter, (uint32_t)__popcll(m));
 }
 // Block-level variants: ONE atomic per workgroup (every thread of the block must call).
 __device__ __forceinline__ uint32_t block_append(bool pred, uint32_t* counter) {
@@ -1459,10 +1456,6 @@ __global__ void __launch_bounds__(256) k_download(TileTable T, Pool P, const int
   }
 }
 
-__global__ void k_fill_u64(uint64_t* p, size_t n, uint64_t v) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = v;
-}
 
 std::string g_create_error;
 
@@ -1527,6 +1520,7 @@ struct ks_ctx {
   bool profiling = false;
   ks_profile prof{};
   hipEvent_t ev[KS_STAGE_COUNT + 1]{};
+  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // begin/end of the k_apply dispatch itself
   bool fatal = false;
 };
 
@@ -1813,8 +1807,12 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
 #define KS_LAUNCH_APPLY(MODE)                                                                                        \
-  hipLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, F, n_pairs, sp, c->d_rays, c->d_deltas,               \
-                     c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters);                               \
+  if (c->profiling)                                                                                                  \
+    hipExtLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, c->ev_k0, c->ev_k1, 0, F, n_pairs, sp, c->d_rays, \
+                          c->d_deltas, c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters);             \
+  else                                                                                                               \
+    hipLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, F, n_pairs, sp, c->d_rays, c->d_deltas,             \
+                       c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters);                             \
   stage_mark(c, 7);                                                                                                  \
   hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(64), 0, st, F, n_pairs, sp, c->d_rays, c->d_deltas,           \
                      c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters)
@@ -1838,6 +1836,13 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
       if (hipEventElapsedTime(&ms, c->ev[s], c->ev[s + 1]) == hipSuccess) {
         c->prof.ms[s] += ms;
         c->prof.launches[s] += 1;
+      }
+    }
+    if (n_pairs > 0) {
+      float kms = 0.f;
+      if (hipEventElapsedTime(&kms, c->ev_k0, c->ev_k1) == hipSuccess) {
+        c->prof.apply_kernel_ms += kms;
+        c->prof.apply_kernel_launches += 1;
       }
     }
     c->prof.frames += 1;
@@ -1965,6 +1970,8 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipSetDevice(cfg->device_id));
   CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   for (auto& e : c->ev) CRCHK(hipEventCreate(&e));
+  CRCHK(hipEventCreate(&c->ev_k0));
+  CRCHK(hipEventCreate(&c->ev_k1));
   uint32_t cap = 1024;
   while (cap < 2u * cfg->max_tiles) cap <<= 1;
   c->table.mask = cap - 1;
@@ -2015,6 +2022,8 @@ void ks_destroy(ks_ctx* c) {
   if (c->h_counters) (void)hipHostFree(c->h_counters);
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
+  if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
+  if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
