@@ -61,6 +61,9 @@ class HipTileStore:
 
     def merge(self, keys: np.ndarray, payload):
         if len(keys):
+            # the payload was produced on torch's stream (RCCL); the merge kernel runs on the
+            # integrator's own stream
+            self.torch.cuda.synchronize(self.device)
             self.integ.merge_tiles(keys, payload.data_ptr())
 
 
