@@ -240,7 +240,7 @@ inline hipError_t sort(Workspace& w, K* keys_a, K* keys_b, uint32_t* vals_a, uin
   if (end_bit > sizeof(K) * 8) end_bit = (unsigned)(sizeof(K) * 8);
   const int passes = (int)((end_bit - begin_bit + kRadixBits - 1) / kRadixBits);
   // tile size: keep the number of tiles (look-back chain depth) small for per-frame sizes
-  const int tile = (n <= 2048u * 2048u) ? 2048 : (n <= 2048u * 8192u) ? 8192 : 16384;
+  const int tile = (n <= (1u << 20)) ? 2048 : (n <= (1u << 24)) ? 8192 : 16384;
   const uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
   const size_t words = kHeadWords + (size_t)passes * tiles * kBins;
   hipError_t e = ensure(w, words);
