@@ -120,9 +120,15 @@ struct RayDesc {  // 32 B, indexed by point position p (fast) / bundle first-poi
   uint32_t info;         // [7:0] label, [9:8] kind (0 none, 1 pure, 2 mixed), [10] clearing
 };
 
+struct TileEntry {
+  uint64_t key;
+  uint32_t val;   // pool slot (kSlotPending until published)
+  uint32_t pad;
+};
+
 struct TileTable {
-  uint64_t* keys;      // open addressing, kEmpty64 = free
-  uint32_t* vals;      // pool slot
+  TileEntry* ent;      // open addressing; key == kEmpty64 = free.  Key and slot share one 16-B
+                       // entry so a lookup is ONE memory round trip (it sits on the ray-march chain)
   uint64_t* slot_keys; // slot -> packed tile key
   uint32_t mask;       // capacity - 1
   uint32_t max_tiles;
@@ -229,10 +235,10 @@ constexpr uint32_t kSlotBad = 0xfffffffeu;      // pool exhausted
 __device__ __forceinline__ void tile_insert(const TileTable& T, Counters* C, uint64_t key) {
   uint32_t h = mix64(key) & T.mask;
   for (uint32_t probes = 0; probes <= T.mask; ++probes) {
-    const uint64_t k = __hip_atomic_load(&T.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint64_t k = __hip_atomic_load(&T.ent[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k == key) return;
     if (k == kEmpty64) {
-      const uint64_t old = atomicCAS((unsigned long long*)&T.keys[h], (unsigned long long)kEmpty64, (unsigned long long)key);
+      const uint64_t old = atomicCAS((unsigned long long*)&T.ent[h].key, (unsigned long long)kEmpty64, (unsigned long long)key);
       if (old == kEmpty64) {
         uint32_t slot = atomicAdd(&C->n_tiles, 1u);
         if (slot < T.max_tiles) {
@@ -241,7 +247,7 @@ __device__ __forceinline__ void tile_insert(const TileTable& T, Counters* C, uin
           atomicOr(&C->err, kErrPool);
           slot = kSlotBad;
         }
-        __hip_atomic_store(&T.vals[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&T.ent[h].val, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
       }
       if (old == key) return;
@@ -258,10 +264,16 @@ __device__ __forceinline__ void tile_insert(const TileTable& T, Counters* C, uin
 __device__ __forceinline__ uint32_t tile_slot_nowait(const TileTable& T, Counters* C, uint64_t key, uint32_t* hpos) {
   uint32_t h = mix64(key) & T.mask;
   for (uint32_t probes = 0; probes <= T.mask; ++probes) {
-    uint64_t k = T.keys[h];  // plain load first: tiles of earlier frames hit here
-    if (k != key) k = __hip_atomic_load(&T.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // one 16-B plain load first: tiles of earlier frames hit here with key and slot together
+    const uint4 e = *(const uint4*)&T.ent[h];
+    uint64_t k = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    if (k == key && e.z != kSlotPending) {
+      *hpos = h;
+      return e.z;
+    }
+    if (k != key) k = __hip_atomic_load(&T.ent[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (k == kEmpty64) {
-      const uint64_t old = atomicCAS((unsigned long long*)&T.keys[h], (unsigned long long)kEmpty64, (unsigned long long)key);
+      const uint64_t old = atomicCAS((unsigned long long*)&T.ent[h].key, (unsigned long long)kEmpty64, (unsigned long long)key);
       if (old == kEmpty64) {
         uint32_t slot = atomicAdd(&C->n_tiles, 1u);
         if (slot < T.max_tiles) {
@@ -270,16 +282,14 @@ __device__ __forceinline__ uint32_t tile_slot_nowait(const TileTable& T, Counter
           atomicOr(&C->err, kErrPool);
           slot = kSlotBad;
         }
-        __hip_atomic_store(&T.vals[h], slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&T.ent[h].val, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return slot;
       }
       k = old;
     }
     if (k == key) {
       *hpos = h;
-      uint32_t v = T.vals[h];
-      if (v == kSlotPending) v = __hip_atomic_load(&T.vals[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return v;
+      return __hip_atomic_load(&T.ent[h].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     h = (h + 1) & T.mask;
   }
@@ -290,8 +300,9 @@ __device__ __forceinline__ uint32_t tile_slot_nowait(const TileTable& T, Counter
 __device__ __forceinline__ uint32_t tile_lookup(const TileTable& T, uint64_t key) {
   uint32_t h = mix64(key) & T.mask;
   for (uint32_t probes = 0; probes <= T.mask; ++probes) {
-    const uint64_t k = T.keys[h];
-    if (k == key) return T.vals[h];
+    const uint4 e = *(const uint4*)&T.ent[h];
+    const uint64_t k = (uint64_t)e.x | ((uint64_t)e.y << 32);
+    if (k == key) return e.z;
     if (k == kEmpty64) return 0xffffffffu;
     h = (h + 1) & T.mask;
   }
@@ -800,7 +811,7 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
       if (need_tile) {
         uint32_t spins = 0;
         while (got == kSlotPending) {
-          got = __hip_atomic_load(&T.vals[hpos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          got = __hip_atomic_load(&T.ent[hpos].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (++spins > (1u << 22)) {
             atomicOr(&C->err, kErrTable);
             got = kSlotBad;
@@ -1977,11 +1988,9 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   c->table.mask = cap - 1;
   c->table.max_tiles = cfg->max_tiles;
   const size_t mt = cfg->max_tiles;
-  CRCHK(hipMalloc((void**)&c->table.keys, cap * sizeof(uint64_t)));
-  CRCHK(hipMalloc((void**)&c->table.vals, cap * sizeof(uint32_t)));
+  CRCHK(hipMalloc((void**)&c->table.ent, cap * sizeof(TileEntry)));
   CRCHK(hipMalloc((void**)&c->table.slot_keys, mt * sizeof(uint64_t)));
-  CRCHK(hipMemset(c->table.keys, 0xff, cap * sizeof(uint64_t)));
-  CRCHK(hipMemset(c->table.vals, 0xff, cap * sizeof(uint32_t)));  // kSlotPending
+  CRCHK(hipMemset(c->table.ent, 0xff, cap * sizeof(TileEntry)));  // key = empty, val = kSlotPending
   CRCHK(hipMalloc((void**)&c->pool.vox, mt * kTileVoxels * 8 * sizeof(uint4)));
   CRCHK(hipMalloc((void**)&c->pool.updated, mt));
   CRCHK(hipMemset(c->pool.updated, 0, mt));
@@ -2011,7 +2020,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
 void ks_destroy(ks_ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->table.keys, c->table.vals, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
+  void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_rays, c->d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_ray_list, c->d_pairs, c->d_pairs2, c->d_counters,
@@ -2329,8 +2338,7 @@ int ks_merge_tiles_device(ks_ctx* c, const uint64_t* keys, size_t n, const void*
 int ks_clear(ks_ctx* c) {
   if (!c) return KS_ERR_INVALID_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemset(c->table.keys, 0xff, ((size_t)c->table.mask + 1) * sizeof(uint64_t)));
-  HIPCHK(c, hipMemset(c->table.vals, 0xff, ((size_t)c->table.mask + 1) * sizeof(uint32_t)));
+  HIPCHK(c, hipMemset(c->table.ent, 0xff, ((size_t)c->table.mask + 1) * sizeof(TileEntry)));
   HIPCHK(c, hipMemset(c->pool.updated, 0, c->cfg.max_tiles));
   std::memset(c->h_counters, 0, sizeof(Counters));
   HIPCHK(c, hipMemset(c->d_counters, 0, sizeof(Counters)));
