@@ -604,7 +604,7 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
     const uint32_t start = long_list[run];
     const uint64_t key = skeys[start];
     const bool clearing = (key >> 63) != 0;
-    f3 mp = {0.f, 0.f, 0.f};
+    float mpc = 0.0f;  // lane 0/1/2: x/y/z of the running weighted mean
     float mw = 0.0f;
     uint32_t merged_color = 0;
     float freq = 0.0f;  // lane l < 21 counts label l
@@ -640,13 +640,14 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
       }
       const float my_r = 1.0f / my_den;
       const float ax = q.x * q.w, ay = q.y * q.w, az = q.z * q.w;
-      // pass 2: weighted-mean recurrence, three independent component chains
+      // pass 2: weighted-mean recurrence; lanes 0,1,2 each walk ONE component chain (x, y, z),
+      // so a step is one multiply-add + one reciprocal-based division for the whole wave
       for (unsigned long long m = vmask; m; m &= m - 1ull) {
         const int k = __ffsll((long long)m) - 1;
         const float mw_k = bcast_f(my_mw, k), den_k = bcast_f(my_den, k), r_k = bcast_f(my_r, k);
-        mp.x = div_by_recip(mp.x * mw_k + bcast_f(ax, k), den_k, r_k);
-        mp.y = div_by_recip(mp.y * mw_k + bcast_f(ay, k), den_k, r_k);
-        mp.z = div_by_recip(mp.z * mw_k + bcast_f(az, k), den_k, r_k);
+        const float ax_k = bcast_f(ax, k), ay_k = bcast_f(ay, k), az_k = bcast_f(az, k);
+        const float a_k = (lane == 0) ? ax_k : (lane == 1) ? ay_k : az_k;
+        mpc = div_by_recip(mpc * mw_k + a_k, den_k, r_k);
         if (F.color_mode == KS_COLOR_MODE_COLOR)
           merged_color = blend_two_colors(merged_color, mw_k, bcast_u(lc.y, k), bcast_f(q.w, k));
       }
@@ -662,6 +663,7 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
       lc = lc_n;
       base += 64u;
     }
+    const f3 mp = {bcast_f(mpc, 0), bcast_f(mpc, 1), bcast_f(mpc, 2)};
     const uint32_t first_p = svals[start];
     const unsigned long long present = __ballot(lane >= 1 && lane < kNumLabels && freq > 0.0f);
     const int n_labels = (int)__popcll(present);
