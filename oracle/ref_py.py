@@ -28,7 +28,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.kr_create.restype = C.c_void_p
         L.kr_create.argtypes = [C.c_char_p, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p,
-                                C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p]
+                                C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
         L.kr_destroy.argtypes = [C.c_void_p]
         L.kr_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.kr_num_blocks.argtypes = [C.c_void_p]
@@ -52,12 +52,14 @@ def write_label_csv(path: str, label_rgba: np.ndarray, n_labels: int = 21):
 
 class Reference:
     def __init__(self, method: str, label_csv: str, voxel_size=0.05, vps=16, truncation=0.2, max_ray=5.0, p_match=0.8,
-                 color_mode=1, dynamic_labels=(20,), threads=1, max_consecutive_ray_collisions=2, order_mode="mixed"):
+                 color_mode=1, dynamic_labels=(20,), threads=1, max_consecutive_ray_collisions=2, order_mode="mixed",
+                 **extra):
         self.vps = vps
         dyn = np.array(list(dynamic_labels), dtype=np.uint8)
         self._h = lib().kr_create(method.encode(), voxel_size, vps, truncation, max_ray, p_match, color_mode,
                                   dyn.ctypes.data if len(dyn) else None, len(dyn), threads,
-                                  max_consecutive_ray_collisions, order_mode.encode(), label_csv.encode())
+                                  max_consecutive_ray_collisions, order_mode.encode(), label_csv.encode(),
+                                  ";".join(f"{k}={float(v)}" for k, v in extra.items()).encode())
 
     def close(self):
         if self._h:

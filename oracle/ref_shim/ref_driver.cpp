@@ -26,7 +26,8 @@ extern "C" {
 // label_csv: path of a "name,red,green,blue,alpha,id" file (SemanticLabel2Color input)
 kr_ctx* kr_create(const char* method, float voxel_size, int vps, float truncation, float max_ray, float p_match,
                   int color_mode, const unsigned char* dynamic_labels, int n_dynamic, int threads,
-                  int max_consecutive_ray_collisions, const char* order_mode, const char* label_csv) {
+                  int max_consecutive_ray_collisions, const char* order_mode, const char* label_csv,
+                  const char* extra /* "key=value;key=value" overrides of TsdfIntegratorBase::Config */) {
   auto* c = new kr_ctx();
   c->vps = vps;
   c->merged = std::string(method) == "merged";
@@ -38,6 +39,32 @@ kr_ctx* kr_create(const char* method, float voxel_size, int vps, float truncatio
   cfg.integrator_threads = threads;
   cfg.max_consecutive_ray_collisions = max_consecutive_ray_collisions;
   cfg.integration_order_mode = order_mode;
+  if (extra) {
+    std::string e(extra);
+    size_t pos = 0;
+    while (pos < e.size()) {
+      size_t semi = e.find(';', pos);
+      if (semi == std::string::npos) semi = e.size();
+      const std::string kv = e.substr(pos, semi - pos);
+      pos = semi + 1;
+      const size_t eq = kv.find('=');
+      if (eq == std::string::npos) continue;
+      const std::string k = kv.substr(0, eq);
+      const double v = std::atof(kv.substr(eq + 1).c_str());
+      if (k == "max_weight") cfg.max_weight = v;
+      else if (k == "voxel_carving_enabled") cfg.voxel_carving_enabled = v != 0;
+      else if (k == "min_ray_length_m") cfg.min_ray_length_m = v;
+      else if (k == "use_const_weight") cfg.use_const_weight = v != 0;
+      else if (k == "allow_clear") cfg.allow_clear = v != 0;
+      else if (k == "use_weight_dropoff") cfg.use_weight_dropoff = v != 0;
+      else if (k == "use_sparsity_compensation_factor") cfg.use_sparsity_compensation_factor = v != 0;
+      else if (k == "sparsity_compensation_factor") cfg.sparsity_compensation_factor = v;
+      else if (k == "enable_anti_grazing") cfg.enable_anti_grazing = v != 0;
+      else if (k == "start_voxel_subsampling_factor") cfg.start_voxel_subsampling_factor = v;
+      else if (k == "clear_checks_every_n_frames") cfg.clear_checks_every_n_frames = (int)v;
+      else LOG(FATAL) << "unknown config key " << k;
+    }
+  }
   kimera::SemanticIntegratorBase::SemanticConfig sc;
   sc.semantic_measurement_probability_ = p_match;
   sc.color_mode = static_cast<kimera::ColorMode>(color_mode);

@@ -75,3 +75,37 @@ def test_sorted_order_and_close_up_match_reference(tmp_path):
         o.integrate(f.T_G_C, f.xyz, f.rgba if method == 0 else None, f.labels)
         r.integrate(f.T_G_C, f.xyz, f.rgba)
         _same(o, r)
+
+
+from tests.variants import VARIANTS  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+@pytest.mark.parametrize("method", ["fast", "merged"])
+def test_config_variants_match_reference(tmp_path, name, method):
+    """Every configuration knob the hot path reads, oracle restatement vs the real reference."""
+    csv = _csv(tmp_path)
+    v = dict(VARIANTS[name])
+    okw = dict(COMMON, method=0 if method == "fast" else 1, bundle_order=0)
+    okw.update(v)
+    rkw = dict(v)
+    ref_args = {}
+    if "voxel_size" in rkw:
+        ref_args["voxel_size"] = rkw.pop("voxel_size")
+    if "truncation_distance" in rkw:
+        ref_args["truncation"] = rkw.pop("truncation_distance")
+    if "max_ray_length_m" in rkw:
+        ref_args["max_ray"] = rkw.pop("max_ray_length_m")
+    if "semantic_measurement_probability" in rkw:
+        ref_args["p_match"] = rkw.pop("semantic_measurement_probability")
+    if "dynamic_labels" in rkw:
+        ref_args["dynamic_labels"] = tuple(rkw.pop("dynamic_labels"))
+    o = O.Oracle(O.default_config(**okw))
+    r = R.Reference(method, csv, **ref_args, **rkw)
+    sc = synth.make_scene("room")
+    for k in range(4):
+        f = synth.render_frame(sc, synth.trajectory_pose(7 * k), 80, 60, seed=60 + k)
+        fs = (k == 2)  # one frame flagged as freespace points
+        o.integrate(f.T_G_C, f.xyz, f.rgba if method == "fast" else None, f.labels, freespace=fs)
+        r.integrate(f.T_G_C, f.xyz, f.rgba, freespace=fs)
+    assert _same(o, r) > 300

@@ -257,3 +257,21 @@ def test_error_codes_mirror_reference_checks():
     with pytest.raises(B.KsError) as e:
         small.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
     assert e.value.code == B.KS_ERR_POOL_FULL
+
+
+from tests.variants import VARIANTS  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(VARIANTS))
+@pytest.mark.parametrize("method", [0, 1])
+def test_config_variants_exact(name, method):
+    """Every configuration knob the hot path reads (incl. a freespace frame), HIP vs oracle, bit-exact."""
+    o, h = _pair(method, **dict(dict(max_consecutive_ray_collisions=NO_EARLY_OUT), **VARIANTS[name]))
+    sc = synth.make_scene("room")
+    for k in range(4):
+        f = synth.render_frame(sc, synth.trajectory_pose(7 * k), 80, 60, seed=60 + k)
+        fs = (k == 2)
+        so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels, freespace=fs)
+        sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels, freespace=fs)
+        assert (so.n_valid_points, so.n_rays_cast, so.n_voxel_updates) == (sh.n_valid_points, sh.n_rays_cast, sh.n_voxel_updates), (name, k)
+    compare_maps(o, h, exact=True)

@@ -1,0 +1,18 @@
+"""Configuration variants exercised by both parity tiers (oracle vs real reference on CPU,
+HIP vs oracle on GPU): every TsdfIntegratorBase::Config / SemanticConfig knob the hot path reads."""
+VARIANTS = {
+    "no_carving": dict(voxel_carving_enabled=0),
+    "const_weight": dict(use_const_weight=1),
+    "no_clear": dict(allow_clear=0),
+    "no_dropoff": dict(use_weight_dropoff=0),
+    "sparsity": dict(use_sparsity_compensation_factor=1, sparsity_compensation_factor=2.5),
+    "short_rays": dict(min_ray_length_m=0.5, max_ray_length_m=3.0),
+    "coarse_voxels": dict(voxel_size=0.1, truncation_distance=0.3),
+    "subsample_1": dict(start_voxel_subsampling_factor=1.0),
+    "subsample_4": dict(start_voxel_subsampling_factor=4.0),
+    "clear_every_3": dict(clear_checks_every_n_frames=3),
+    "p_0.9_no_dynamic": dict(semantic_measurement_probability=0.9, dynamic_labels=[]),
+    "many_dynamic": dict(dynamic_labels=[3, 19, 20]),
+    "max_weight_2": dict(max_weight=2.0),
+    "anti_grazing": dict(enable_anti_grazing=1),
+}
