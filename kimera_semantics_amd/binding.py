@@ -208,6 +208,16 @@ class HipIntegrator:
                                            depth.shape[0], _ptr(Kc), int(freespace), C.byref(st)))
         return st
 
+    def integrate_depth_device(self, T_G_C, d_depth: int, fmt: int, d_label_img: int, d_rgba_img: int, width: int,
+                               height: int, K, freespace=False) -> KsFrameStats:
+        """Raw device addresses (e.g. torch.Tensor.data_ptr()); fmt 0 = f32 metres, 1 = u16 mm."""
+        T = np.ascontiguousarray(T_G_C, dtype=np.float32)
+        Kc = np.ascontiguousarray(K, dtype=np.float32)
+        st = KsFrameStats()
+        self._chk(lib().ks_integrate_depth_device(self._h, _ptr(T), d_depth or None, fmt, d_label_img or None,
+                                                  d_rgba_img or None, width, height, _ptr(Kc), int(freespace), C.byref(st)))
+        return st
+
     def integrate_device(self, T_G_C, d_xyz: int, d_rgba: int, d_labels: int, n: int, freespace=False) -> KsFrameStats:
         """d_* are raw device addresses (e.g. torch.Tensor.data_ptr()); 0/None = NULL."""
         T = np.ascontiguousarray(T_G_C, dtype=np.float32)

@@ -275,3 +275,25 @@ def test_config_variants_exact(name, method):
         sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels, freespace=fs)
         assert (so.n_valid_points, so.n_rays_cast, so.n_voxel_updates) == (sh.n_valid_points, sh.n_rays_cast, sh.n_voxel_updates), (name, k)
     compare_maps(o, h, exact=True)
+
+
+def test_device_pointer_entries_equal_host_entries():
+    """ks_integrate_points_device / ks_integrate_depth_device (inputs already in HBM, as bench.py
+    uses them) give the same map as the host-pointer entries."""
+    import torch
+    f = small_frame(seed=21, w=128, h=96)
+    kw = dict(COMMON, method=0, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    a = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 16, **kw))
+    b = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 16, **kw))
+    c = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 16, **kw))
+    a.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    x, col, lab = torch.from_numpy(f.xyz).cuda(), torch.from_numpy(f.rgba).cuda(), torch.from_numpy(f.labels).cuda()
+    torch.cuda.synchronize()
+    b.integrate_device(f.T_G_C, x.data_ptr(), col.data_ptr(), lab.data_ptr(), x.shape[0])
+    d, li = torch.from_numpy(f.depth).cuda(), torch.from_numpy(f.label_img).cuda()
+    torch.cuda.synchronize()
+    c.integrate_depth_device(f.T_G_C, d.data_ptr(), 0, li.data_ptr(), 0, f.depth.shape[1], f.depth.shape[0], f.K)
+    ia, ta, sa = a.download()
+    for other in (b, c):
+        io, to, so = other.download()
+        assert np.array_equal(ia, io) and ta.tobytes() == to.tobytes() and sa.tobytes() == so.tobytes()
