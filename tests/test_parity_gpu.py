@@ -297,3 +297,64 @@ def test_device_pointer_entries_equal_host_entries():
     for other in (b, c):
         io, to, so = other.download()
         assert np.array_equal(ia, io) and ta.tobytes() == to.tobytes() and sa.tobytes() == so.tobytes()
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_long_sequence_exact(method):
+    """12 consecutive trajectory frames at 320x240: tile growth, approximate-set resets across
+    frames, weights accumulating over many frames — still bit-exact at the end."""
+    o, h = _pair(method, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    sc = synth.make_scene("room")
+    for k in range(12):
+        f = synth.render_frame(sc, synth.trajectory_pose(3 * k), 320, 240, seed=500 + k)
+        so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        assert (so.n_rays_cast, so.n_voxel_updates) == (sh.n_rays_cast, sh.n_voxel_updates), k
+    compare_maps(o, h, exact=True)
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_degenerate_inputs_exact(method):
+    """Edge cases the reference code paths contain: zero-weight points (|z| <= 1e-6), duplicate
+    points, points at the min/max ray-length limits, an all-invalid cloud, a one-point cloud, an
+    all-dynamic cloud."""
+    o, h = _pair(method, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    T = synth.pose_to_T((0.3, -0.2, 1.1), 0.4)
+    rng = np.random.default_rng(5)
+    base = rng.uniform(-1.5, 1.5, size=(400, 3)).astype(np.float32)
+    base[:, 2] = np.abs(base[:, 2]) + 0.3
+    pts = np.concatenate([
+        base,
+        base[:50],                                                   # exact duplicates
+        np.array([[0.7, 0.2, 0.0], [0.7, 0.2, 1e-7], [1.2, -0.4, -1e-7]], np.float32),  # zero weight
+        np.array([[0.0, 0.0, 0.1], [0.0, 0.06, 0.08], [0.0, 0.0, 0.0999]], np.float32),  # around min_ray_length
+        np.array([[3.0, 4.0, 0.0], [0.0, 3.0, 4.0], [0.0, 3.0, 4.0001], [30.0, 40.0, 5.0]], np.float32),  # around/beyond max
+    ]).astype(np.float32)
+    labels = rng.integers(0, 21, size=len(pts), dtype=np.uint8)
+    rgba = synth.default_label_colors()[labels]
+    for cloud, lab, col in ((pts, labels, rgba),
+                            (np.full((5, 3), 0.01, np.float32), labels[:5], rgba[:5]),   # all too close: invalid
+                            (pts[:1], labels[:1], rgba[:1]),                               # single point
+                            (pts[:64], np.full(64, 20, np.uint8), synth.default_label_colors()[np.full(64, 20)])):
+        so = o.integrate(T, cloud, col, lab)
+        sh = h.integrate(T, cloud, col, lab)
+        assert (so.n_valid_points, so.n_rays_cast, so.n_voxel_updates) == (sh.n_valid_points, sh.n_rays_cast, sh.n_voxel_updates)
+    rep = compare_maps(o, h, exact=False)
+    # NaN distances (0/0 in computeDistance for a zero-length ray) must be NaN on both sides
+    assert rep["label_mismatches"] == 0 and rep["max_abs_priors_err"] == 0.0
+    idx = o.block_indices()
+    _, ot, _ = o.download(idx)
+    _, ht, _ = h.download(idx)
+    assert np.array_equal(np.isnan(ot["distance"]), np.isnan(ht["distance"]))
+    ok = ~np.isnan(ot["distance"])
+    assert np.array_equal(ot["distance"][ok].view(np.uint32), ht["distance"][ok].view(np.uint32))
+    assert np.array_equal(ot["weight"].view(np.uint32), ht["weight"].view(np.uint32))
+
+
+def test_out_of_range_coordinates_are_reported():
+    h = B.HipIntegrator(B.default_config(max_tiles=1024, max_points=1 << 12, **dict(COMMON, method=1, max_ray_length_m=1e9)))
+    T = np.array([1, 0, 0, 0, 0, 0, 0], np.float32)
+    far = np.array([[1e6, 2e6, 3e6]], np.float32)   # voxel index beyond the packed +-2^20 range
+    with pytest.raises(B.KsError) as e:
+        h.integrate(T, far, None, np.array([1], np.uint8))
+    assert e.value.code == -6  # KS_ERR_INDEX_RANGE
