@@ -157,6 +157,12 @@ int ks_get_updated_block_indices(ks_ctx* ctx, int32_t* out_xyz, size_t cap, size
  * sem_out:  n * vps^3 * 92 B {u8 label, 3 pad, f32 priors[21], u8 rgba[4]} (semantic_voxel.h:14-27).
  * Either may be NULL.  Absent blocks yield default-constructed voxels. */
 int ks_download_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, void* tsdf_out, void* sem_out);
+/* Inverse of ks_download_blocks: seed / overwrite n host-layout blocks in the GPU map (same record
+ * layouts; either array may be NULL to leave that half untouched).  This is how a map the host
+ * already holds — the layers handed to the integrator constructor
+ * (semantic_integrator_base.cpp:92-96, filled e.g. by TsdfServer::loadMap) — reaches the GPU.
+ * Block indices must be distinct.  Errors: KS_ERR_POOL_FULL, KS_ERR_INDEX_RANGE. */
+int ks_upload_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, const void* tsdf_in, const void* sem_in);
 
 /* ---- multi-GPU exchange (new functionality: the reference is single-process) ----
  * The map is a set of 8^3-voxel tiles; a tile travels as its packed 63-bit key plus a raw

@@ -31,7 +31,7 @@ SEM_DTYPE = np.dtype([("label", "u1"), ("pad", "u1", (3,)), ("priors", "<f4", (N
 ABI_SYMBOLS = [
     "ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_set_color_to_label",
     "ks_integrate_points", "ks_integrate_points_device", "ks_integrate_depth", "ks_integrate_depth_device", "ks_num_blocks", "ks_get_block_indices",
-    "ks_get_updated_block_indices", "ks_download_blocks", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear",
+    "ks_get_updated_block_indices", "ks_download_blocks", "ks_upload_blocks", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear",
     "ks_debug_radix_sort", "ks_synchronize", "ks_stream",
     "ks_profile_enable", "ks_profile_get",
 ]
@@ -106,6 +106,7 @@ def lib():
         L.ks_get_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.ks_get_updated_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
         L.ks_download_blocks.argtypes = [vp, vp, C.c_size_t, vp, vp]
+        L.ks_upload_blocks.argtypes = [vp, vp, C.c_size_t, vp, vp]
         L.ks_get_tile_keys.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.ks_export_tiles_device.argtypes = [vp, vp, C.c_size_t, vp]
         L.ks_merge_tiles_device.argtypes = [vp, vp, C.c_size_t, vp]
@@ -251,6 +252,19 @@ class HipIntegrator:
         if len(indices):
             self._chk(lib().ks_download_blocks(self._h, _ptr(indices), len(indices), _ptr(t), _ptr(s)))
         return indices, t, s
+
+    def upload(self, indices, tsdf=None, sem=None):
+        """Seed / overwrite host-layout blocks in the GPU map (inverse of download)."""
+        indices = np.ascontiguousarray(indices, dtype=np.int32).reshape(-1, 3)
+        nv = self.vps ** 3
+        tp = sp = None
+        if tsdf is not None:
+            tsdf = np.ascontiguousarray(tsdf, dtype=TSDF_DTYPE).reshape(len(indices), nv)
+            tp = _ptr(tsdf)
+        if sem is not None:
+            sem = np.ascontiguousarray(sem, dtype=SEM_DTYPE).reshape(len(indices), nv)
+            sp = _ptr(sem)
+        self._chk(lib().ks_upload_blocks(self._h, _ptr(indices), len(indices), tp, sp))
 
     # ---- multi-GPU exchange primitives (used by kimera_semantics_amd.parallel) ----
     TILE_BYTES = 65536

@@ -208,7 +208,7 @@ __device__ __forceinline__ uint32_t point_position(const FrameParams& F, const u
   return (idx % F.per_group) * 1024u + idx / F.per_group;
 }
 
-__device__ __forceinline__ uint64_t pack_tile(int tx, int ty, int tz) {
+__host__ __device__ __forceinline__ uint64_t pack_tile(int tx, int ty, int tz) {
   return ((uint64_t)(uint32_t)(tx + kTileBias) << 36) | ((uint64_t)(uint32_t)(ty + kTileBias) << 18) |
          (uint64_t)(uint32_t)(tz + kTileBias);
 }
@@ -1470,6 +1470,42 @@ __global__ void __launch_bounds__(256) k_download(TileTable T, Pool P, const int
 }
 
 
+// Host-layout import (the inverse of k_download): one lane per voxel of a host block.  A voxel
+// that still looks default-constructed on the semantic side (label 0, Gray, initial priors:
+// [K:include/kimera_semantics/semantic_voxel.h:14-27]) keeps the "never updated" marker.
+__global__ void __launch_bounds__(256) k_upload(TileTable T, Pool P, const int32_t* __restrict__ block_idx, int vps,
+                                                const uint8_t* __restrict__ tsdf_in, const uint8_t* __restrict__ sem_in) {
+  const uint32_t b = blockIdx.y;
+  const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t nv = (uint32_t)(vps * vps * vps);
+  if (l >= nv) return;
+  const int lx = (int)(l % (uint32_t)vps), ly = (int)((l / (uint32_t)vps) % (uint32_t)vps), lz = (int)(l / (uint32_t)(vps * vps));
+  const int vx = block_idx[3 * b] * vps + lx, vy = block_idx[3 * b + 1] * vps + ly, vz = block_idx[3 * b + 2] * vps + lz;
+  const uint32_t slot = tile_lookup(T, pack_tile(vx >> 3, vy >> 3, vz >> 3));
+  if (slot == 0xffffffffu) return;
+  const uint32_t local = (uint32_t)(vx & 7) + 8u * ((uint32_t)(vy & 7) + 8u * (uint32_t)(vz & 7));
+  uint32_t* rec = (uint32_t*)(P.vox + ((size_t)slot * kTileVoxels + local) * 8);
+  const size_t o = (size_t)b * nv + l;
+  if (tsdf_in) {
+    const uint32_t* t = (const uint32_t*)(tsdf_in + o * 12);
+    rec[0] = t[0];
+    rec[1] = t[1];
+    rec[2] = t[2];
+  }
+  if (sem_in) {
+    const uint32_t* s = (const uint32_t*)(sem_in + o * 92);
+    const uint32_t label = s[0] & 0xffu;
+    bool pristine = label == 0u && s[22] == (127u | (127u << 8) | (127u << 16) | (255u << 24));
+    for (int k = 0; k < kNumLabels; ++k) {
+      const uint32_t p = s[1 + k];
+      pristine = pristine && p == __float_as_uint(kPriorInit);
+      rec[4 + k] = p;
+    }
+    rec[3] = pristine ? 255u : label;
+  }
+}
+
+
 std::string g_create_error;
 
 }  // namespace
@@ -1900,6 +1936,31 @@ int collect_block_indices(ks_ctx* c, bool only_updated, bool reset, std::vector<
 
 }  // namespace
 
+// find-or-insert n tile keys (device array) and initialise the newly allocated tiles
+static int insert_tiles(ks_ctx* c, const uint64_t* d_keys, size_t n) {
+  const uint32_t old_tiles = c->h_counters->n_tiles;
+  Counters zero{};
+  zero.n_tiles = old_tiles;
+  *c->h_counters = zero;
+  HIPCHK(c, hipMemcpyAsync(c->d_counters, c->h_counters, sizeof(Counters), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_insert_tiles, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->table, c->d_counters,
+                     d_keys, (uint32_t)n);
+  HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->h_counters->err) {
+    c->fatal = true;
+    c->err = "voxel tile pool exhausted: raise ks_config.max_tiles";
+    return KS_ERR_POOL_FULL;
+  }
+  const uint32_t new_tiles = c->h_counters->n_tiles;
+  if (new_tiles > c->tiles_initialised) {
+    hipLaunchKernelGGL(k_init_tiles, dim3(new_tiles - c->tiles_initialised), dim3(512), 0, c->stream, c->pool,
+                       c->tiles_initialised);
+    c->tiles_initialised = new_tiles;
+  }
+  return KS_OK;
+}
+
 extern "C" {
 
 int ks_default_config(ks_config* c) {
@@ -2225,6 +2286,57 @@ int ks_download_blocks(ks_ctx* c, const int32_t* idx, size_t n, void* tsdf_out, 
   return KS_OK;
 }
 
+int ks_upload_blocks(ks_ctx* c, const int32_t* idx, size_t n, const void* tsdf_in, const void* sem_in) {
+  if (!c || (n && !idx) || (!tsdf_in && !sem_in)) return KS_ERR_INVALID_ARG;
+  if (n == 0) return KS_OK;
+  if (c->fatal) return KS_ERR_INVALID_ARG;
+  const int vps = c->cfg.voxels_per_side;
+  const int tpb = vps / 8;  // tiles per block edge
+  const size_t nv = (size_t)vps * vps * vps;
+  std::vector<uint64_t> keys;
+  keys.reserve(n * tpb * tpb * tpb);
+  const int lim = kTileBias / tpb;
+  for (size_t b = 0; b < n; ++b) {
+    const int bx = idx[3 * b], by = idx[3 * b + 1], bz = idx[3 * b + 2];
+    if (bx < -lim || bx >= lim || by < -lim || by >= lim || bz < -lim || bz >= lim) {
+      c->err = "block index outside the packed tile-key range";
+      return KS_ERR_INDEX_RANGE;
+    }
+    for (int z = 0; z < tpb; ++z)
+      for (int y = 0; y < tpb; ++y)
+        for (int x = 0; x < tpb; ++x) keys.push_back(pack_tile(bx * tpb + x, by * tpb + y, bz * tpb + z));
+  }
+  uint64_t* d_keys = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_keys, keys.size() * sizeof(uint64_t)));
+  HIPCHK(c, hipMemcpyAsync(d_keys, keys.data(), keys.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  int rc = insert_tiles(c, d_keys, keys.size());
+  (void)hipFree(d_keys);
+  if (rc) return rc;
+  // staging buffers shared with ks_download_blocks
+  const size_t chunk = std::max<size_t>(1, (size_t(256) << 20) / (nv * 92));
+  if (c->cap_out_blocks < std::min(chunk, n)) {
+    const size_t cb = std::min(chunk, std::max<size_t>(n, 16));
+    if ((rc = dev_alloc(c, &c->d_tsdf_out, cb * nv * 12))) return rc;
+    if ((rc = dev_alloc(c, &c->d_sem_out, cb * nv * 92))) return rc;
+    if ((rc = dev_alloc(c, &c->d_block_idx, cb * 3))) return rc;
+    c->cap_out_blocks = cb;
+  }
+  for (size_t off = 0; off < n; off += c->cap_out_blocks) {
+    const size_t m = std::min(c->cap_out_blocks, n - off);
+    HIPCHK(c, hipMemcpyAsync(c->d_block_idx, idx + 3 * off, m * 3 * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    if (tsdf_in)
+      HIPCHK(c, hipMemcpyAsync(c->d_tsdf_out, (const uint8_t*)tsdf_in + off * nv * 12, m * nv * 12, hipMemcpyHostToDevice, c->stream));
+    if (sem_in)
+      HIPCHK(c, hipMemcpyAsync(c->d_sem_out, (const uint8_t*)sem_in + off * nv * 92, m * nv * 92, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_upload, dim3((uint32_t)((nv + 255) / 256), (uint32_t)m), dim3(256), 0, c->stream, c->table, c->pool,
+                       c->d_block_idx, vps, tsdf_in ? (const uint8_t*)c->d_tsdf_out : nullptr,
+                       sem_in ? (const uint8_t*)c->d_sem_out : nullptr);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  HIPCHK(c, hipGetLastError());
+  return KS_OK;
+}
+
 int ks_debug_radix_sort(ks_ctx* c, void* keys, uint32_t* vals, size_t n, int key_bits, unsigned end_bit) {
   if (!c || (n && !keys) || (key_bits != 32 && key_bits != 64)) return KS_ERR_INVALID_ARG;
   if (n == 0) return KS_OK;
@@ -2296,26 +2408,9 @@ int ks_merge_tiles_device(ks_ctx* c, const uint64_t* keys, size_t n, const void*
   HIPCHK(c, hipMalloc((void**)&d_keys, n * sizeof(uint64_t)));
   HIPCHK(c, hipMemcpyAsync(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
   // allocate tiles this rank has not seen yet
-  const uint32_t old_tiles = c->h_counters->n_tiles;
-  Counters zero{};
-  zero.n_tiles = old_tiles;
-  *c->h_counters = zero;
-  HIPCHK(c, hipMemcpyAsync(c->d_counters, c->h_counters, sizeof(Counters), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_insert_tiles, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->table, c->d_counters,
-                     d_keys, (uint32_t)n);
-  HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->h_counters->err) {
-    c->fatal = true;
-    c->err = "voxel tile pool exhausted while merging: raise ks_config.max_tiles";
+  if (int rc = insert_tiles(c, d_keys, n)) {
     (void)hipFree(d_keys);
-    return KS_ERR_POOL_FULL;
-  }
-  const uint32_t new_tiles = c->h_counters->n_tiles;
-  if (new_tiles > c->tiles_initialised) {
-    hipLaunchKernelGGL(k_init_tiles, dim3(new_tiles - c->tiles_initialised), dim3(512), 0, c->stream, c->pool,
-                       c->tiles_initialised);
-    c->tiles_initialised = new_tiles;
+    return rc;
   }
   switch (c->cfg.color_mode) {
     case KS_COLOR_MODE_COLOR:

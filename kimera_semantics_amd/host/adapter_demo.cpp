@@ -1,7 +1,9 @@
 // adapter_demo — drives the C++ adapter exactly as SemanticTsdfServer would: build Layers,
 // create the integrator through the factory, feed colour-encoded clouds through the
 // TsdfIntegratorBase virtual, then dump the host Layers.  Used by tests/test_host_adapter_gpu.py.
-//   adapter_demo <method> <labels.csv> <in.bin> <out.bin> [color_mode] [max_consecutive_ray_collisions]
+//   adapter_demo <method> <labels.csv> <in.bin> <out.bin> [color_mode] [max_consecutive_ray_collisions] [restart_after]
+// restart_after = k: after frame k the integrator is destroyed and a new one is created on the
+// same, now non-empty, Layers (the loadMap / re-configure case): it must pick the map up from the host.
 // in.bin : u32 n_frames, then per frame { f32 T[7]; u32 n; f32 xyz[3n]; u8 rgba[4n] }
 // out.bin: u32 n_blocks, u32 vps, then per block { i32 idx[3]; tsdf vps^3*12 B; semantic vps^3*92 B }
 #include <algorithm>
@@ -40,7 +42,12 @@ int main(int argc, char** argv) {
   if (!in) return 3;
   uint32_t n_frames = 0;
   if (std::fread(&n_frames, 4, 1, in) != 1) return 3;
+  const int restart_after = argc > 7 ? std::atoi(argv[7]) : -1;
   for (uint32_t f = 0; f < n_frames; ++f) {
+    if ((int)f == restart_after) {
+      integrator.reset();
+      integrator = kimera::HipSemanticTsdfIntegratorFactory::create(method, cfg, sc, &tsdf_layer, &semantic_layer, opt);
+    }
     float T[7];
     uint32_t n;
     if (std::fread(T, 4, 7, in) != 7 || std::fread(&n, 4, 1, in) != 1) return 3;

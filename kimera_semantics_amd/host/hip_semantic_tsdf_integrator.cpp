@@ -82,6 +82,7 @@ HipSemanticTsdfIntegrator::HipSemanticTsdfIntegrator(Method method, const Config
     labels.push_back(kv.second);
   }
   check(ks_set_color_to_label(ctx_, keys.data(), labels.data(), labels.size()), "ks_set_color_to_label");
+  if (tsdf_layer->getNumberOfAllocatedBlocks() > 0 || semantic_layer->getNumberOfAllocatedBlocks() > 0) uploadLayers();
 }
 
 HipSemanticTsdfIntegrator::~HipSemanticTsdfIntegrator() { ks_destroy(ctx_); }
@@ -172,6 +173,57 @@ void HipSemanticTsdfIntegrator::syncLayers() {
     tb->updated() = true;
     sb->updated() = true;
   }
+}
+
+void HipSemanticTsdfIntegrator::uploadLayers() {
+  vxb::BlockIndexList blocks, sem_only;
+  layer_->getAllAllocatedBlocks(&blocks);
+  semantic_layer_ptr_->getAllAllocatedBlocks(&sem_only);
+  for (const vxb::BlockIndex& idx : sem_only)
+    if (!layer_->hasBlock(idx)) blocks.push_back(idx);
+  const size_t n = blocks.size();
+  if (n == 0) return;
+  const size_t vps = layer_->voxels_per_side();
+  const size_t nv = vps * vps * vps;
+  idx_buf_.resize(3 * n);
+  tsdf_buf_.assign(n * nv * 12, 0);
+  sem_buf_.assign(n * nv * 92, 0);
+  const vxb::TsdfVoxel default_tsdf;
+  const SemanticVoxel default_sem;
+  for (size_t b = 0; b < n; ++b) {
+    const vxb::BlockIndex& idx = blocks[b];
+    idx_buf_[3 * b] = idx.x();
+    idx_buf_[3 * b + 1] = idx.y();
+    idx_buf_[3 * b + 2] = idx.z();
+    const auto tb = layer_->getBlockPtrByIndex(idx);
+    const auto sb = semantic_layer_ptr_->getBlockPtrByIndex(idx);
+    uint8_t* t = tsdf_buf_.data() + b * nv * 12;
+    uint8_t* s = sem_buf_.data() + b * nv * 92;
+    for (size_t i = 0; i < nv; ++i) {
+      const vxb::TsdfVoxel& v = tb ? tb->getVoxelByLinearIndex(i) : default_tsdf;
+      std::memcpy(t + 12 * i, &v.distance, 4);
+      std::memcpy(t + 12 * i + 4, &v.weight, 4);
+      t[12 * i + 8] = v.color.r;
+      t[12 * i + 9] = v.color.g;
+      t[12 * i + 10] = v.color.b;
+      t[12 * i + 11] = v.color.a;
+      const SemanticVoxel& sv = sb ? sb->getVoxelByLinearIndex(i) : default_sem;
+      uint8_t* r = s + 92 * i;
+      r[0] = sv.semantic_label;
+      for (size_t l = 0; l < kTotalNumberOfLabels; ++l) {
+        const float p = sv.semantic_priors[l];
+        std::memcpy(r + 4 + 4 * l, &p, 4);
+      }
+      r[88] = sv.color.r;
+      r[89] = sv.color.g;
+      r[90] = sv.color.b;
+      r[91] = sv.color.a;
+    }
+  }
+  check(ks_upload_blocks(ctx_, idx_buf_.data(), n, tsdf_buf_.data(), sem_buf_.data()), "ks_upload_blocks");
+  // what was just uploaded is not "updated by integration"
+  size_t m = 0;
+  check(ks_get_updated_block_indices(ctx_, nullptr, 0, &m, 1), "ks_get_updated_block_indices");
 }
 
 std::unique_ptr<vxb::TsdfIntegratorBase> HipSemanticTsdfIntegratorFactory::create(

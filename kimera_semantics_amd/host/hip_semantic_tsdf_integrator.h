@@ -56,6 +56,10 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
   /// Copies every block touched since the last call into the host Layers (allocating blocks
   /// as needed) and sets Block::updated(), as semantic_integrator_base.cpp:248 does.
   void syncLayers();
+  /// Host layers -> GPU map (every allocated block).  Called by the constructor when the layers it
+  /// is handed are not empty (a map loaded with TsdfServer::loadMap), so the integrator continues
+  /// from the map the host holds exactly like the CPU integrators do.
+  void uploadLayers();
 
   ks_ctx* context() { return ctx_; }
   const ks_frame_stats& lastFrameStats() const { return last_stats_; }

@@ -358,3 +358,35 @@ def test_out_of_range_coordinates_are_reported():
     with pytest.raises(B.KsError) as e:
         h.integrate(T, far, None, np.array([1], np.uint8))
     assert e.value.code == -6  # KS_ERR_INDEX_RANGE
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_upload_roundtrip_and_resume(method):
+    """ks_upload_blocks is the inverse of ks_download_blocks: a map moved host-side into a fresh
+    context downloads identically, and both contexts then integrate further frames identically."""
+    kw = dict(COMMON, method=method, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    a = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 16, **kw))
+    b = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 16, **kw))
+    sc = synth.make_scene("room")
+    fr = [synth.render_frame(sc, synth.trajectory_pose(4 * k), 160, 120, seed=40 + k) for k in range(4)]
+    for f in fr[:2]:
+        a.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    idx, t, s = a.download()
+    b.upload(idx, t, s)
+    i2, t2, s2 = b.download()
+    assert np.array_equal(idx, i2) and t.tobytes() == t2.tobytes() and s.tobytes() == s2.tobytes()
+    for f in fr[2:]:
+        a.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        b.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    compare_maps(a, b, exact=True)
+    # half uploads leave the other half alone
+    c = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 16, **kw))
+    c.upload(idx, tsdf=t)
+    _, tc, sc_ = c.download(idx)
+    assert tc.tobytes() == t.tobytes()
+    assert np.all(sc_["label"] == 0) and np.all(sc_["color"] == np.array([127, 127, 127, 255], np.uint8))
+    c.upload(idx, sem=s)
+    _, tc, sc_ = c.download(idx)
+    assert tc.tobytes() == t.tobytes() and sc_.tobytes() == s.tobytes()
+    with pytest.raises(B.KsError):
+        c.upload(np.array([[1 << 20, 0, 0]], np.int32), tsdf=t[:1])

@@ -32,7 +32,8 @@ def compare_maps(oracle, hip, exact=True):
     rep["block_jaccard"] = len(so & sh) / max(1, len(so | sh))
     if exact:
         assert so == sh, f"allocated block sets differ: only oracle {sorted(so - sh)[:5]}, only hip {sorted(sh - so)[:5]}"
-        assert {tuple(x) for x in oracle.semantic_block_indices().tolist()} == so
+        if hasattr(oracle, "semantic_block_indices"):
+            assert {tuple(x) for x in oracle.semantic_block_indices().tolist()} == so
     common = np.array(sorted(so & sh), dtype=np.int32).reshape(-1, 3)
     _, ot, osem = oracle.download(common)
     _, ht, hsem = hip.download(common)
