@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=6)
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="ks_config.pipeline_frames=0: every call completes its own frame (host wait not overlapped)")
     return ap.parse_args()
 
 
@@ -108,8 +110,10 @@ def main():
     for f in frames:
         d_frames.append((torch.from_numpy(f.xyz).to(dev), torch.from_numpy(f.rgba).to(dev),
                          torch.from_numpy(f.labels).to(dev)))
+    # bag replay = a stream of frames: frame pipelining on (the host's one wait per frame overlaps
+    # the next frame's GPU work; results are identical, see tests/test_parity_gpu.py)
     cfg = B.default_config(device_id=local_rank, max_tiles=1 << 13, max_points=args.width * args.height,
-                           **common_cfg(args.method))
+                           pipeline_frames=0 if args.no_pipeline else 1, **common_cfg(args.method))
     integ = B.HipIntegrator(cfg)
 
     def step(i):
@@ -118,19 +122,24 @@ def main():
 
     for i in range(W):
         step(i)
-    integ.synchronize()
+    integ.synchronize()       # completes the last warm-up frame: nothing is pending at t0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    integ.profile_enable(True)
+    # level 2: only the k_apply dispatch of every 4th frame carries HIP events (per-stage events
+    # would put ~50 us of stream bubbles into every timed frame)
+    integ.profile_enable(2)
     integ.profile(reset=True)
     t0 = time.perf_counter()
     updates = 0
     points = 0
     for i in range(W, W + K):
-        st = step(i)
+        st = step(i)          # pipelined: statistics of the frame completed by this call
         updates += st.n_voxel_updates
         points += st.n_points
+    st = integ.flush()        # the K-th frame's tail, inside the timed region
+    updates += st.n_voxel_updates
+    points += st.n_points
     integ.synchronize()
     reduce_stats = None
     if world > 1:
@@ -143,7 +152,14 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    prof = integ.profile()
+    prof = integ.profile(reset=True)
+    # per-stage breakdown: separate untimed pass over the last frames with events around every stage
+    integ.profile_enable(1)
+    for i in range(max(W, W + K - 10), W + K):
+        step(i)
+    integ.flush()
+    stage_prof = integ.profile()
+    integ.profile_enable(0)
 
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -160,7 +176,7 @@ def main():
         # HIP events recorded on the integrator's own stream inside the timed region.
         # k_apply dispatch begin->end (events attached to the dispatch itself, on the integrator's stream)
         apply_ms = prof["apply_kernel_ms"] / max(1, prof["apply_kernel_launches"])
-        upd_per_launch = prof["updates"] / max(1, prof["frames"])
+        upd_per_launch = prof["apply_kernel_updates"] / max(1, prof["apply_kernel_launches"])
         pts_per_launch = prof["points"] / max(1, prof["frames"])
         alg_bytes = BYTES_PER_UPDATE * upd_per_launch
         achieved = alg_bytes / (apply_ms * 1e-3) / 1e9 if apply_ms > 0 else 0.0
@@ -171,8 +187,8 @@ def main():
                 traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        stage_ms = {k: round(v / max(1, prof["frames"]), 4) for k, v in prof["ms"].items()}
-        whole_frame_alg = BYTES_PER_UPDATE * upd_per_launch + BYTES_PER_POINT * pts_per_launch
+        stage_ms = {k: round(v / max(1, stage_prof["frames"]), 4) for k, v in stage_prof["ms"].items()}
+        whole_frame_alg = (BYTES_PER_UPDATE * updates + BYTES_PER_POINT * points) / K
         out = {
             "metric": "Mvoxel-updates/s + frames/s, 640x480 @5cm voxels",
             "value": round(updates_all / dt / 1e6, 3),
@@ -184,7 +200,7 @@ def main():
             "frames_per_s": round(world * K / dt, 2),
             "config": {"workload": f"bag-replay stand-in: {args.width}x{args.height} depth+label trajectory, "
                                    f"'{args.method}' integrator, 5 cm voxels, 5 m rays, trunc 0.2 m, p=0.8",
-                       "frames_per_gpu": K, "points_per_frame": int(points_all / max(1, world * K)),
+                       "frames_per_gpu": K, "pipeline_frames": 0 if args.no_pipeline else 1, "points_per_frame": int(points_all / max(1, world * K)),
                        "updates_per_frame": int(updates_all / max(1, world * K)),
                        "parallelism": f"frame-sharded x{world}" + (
                            " + one all-to-all tile reduce to hash-owners at the end (inside the timed region)"
@@ -192,6 +208,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_apply", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(apply_ms, 5),
+                         "timed_launches": prof["apply_kernel_launches"],
                          "whole_frame_frac": round(whole_frame_alg / (dt / K) / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms_per_frame": stage_ms,
         }

@@ -76,6 +76,14 @@ typedef struct ks_config {
   int32_t device_id;                /* HIP device ordinal */
   uint32_t max_tiles;               /* capacity of the 8^3-voxel tile pool (64 KiB each) */
   uint32_t max_points;              /* largest cloud per call (buffers grow on demand if exceeded) */
+  /* 0 (default): an integrate call returns with its frame fully enqueued and its own statistics.
+   * 1: frame pipelining for streams of frames (bag replay): a call enqueues the front half of its
+   *    frame (points .. ray march), then finishes the PREVIOUS frame (pair sort + voxel update), so
+   *    the one host wait of a frame overlaps GPU work of the next; the statistics (and any
+   *    KS_ERR_LABEL_RANGE / pool error) a call returns are those of the previous frame.  Every
+   *    other entry point (queries, download, export, ks_synchronize, ks_flush) completes the
+   *    outstanding frame first, so the map they see is the same as without pipelining. */
+  int32_t pipeline_frames;
 } ks_config;
 
 typedef struct ks_frame_stats {
@@ -105,7 +113,8 @@ typedef struct ks_profile {
   uint64_t updates;                /* voxel updates over profiled frames */
   uint64_t points;
   double apply_kernel_ms;          /* k_apply dispatch begin->end (hipExtLaunchKernel events), summed */
-  uint64_t apply_kernel_launches;
+  uint64_t apply_kernel_launches;  /* ... over this many timed launches */
+  uint64_t apply_kernel_updates;   /* ... which performed this many voxel updates */
 } ks_profile;
 
 typedef struct ks_ctx ks_ctx;
@@ -183,7 +192,12 @@ int ks_debug_radix_sort(ks_ctx* ctx, void* keys, uint32_t* vals, size_t n, int k
 
 int ks_synchronize(ks_ctx* ctx);
 void* ks_stream(ks_ctx* ctx); /* the hipStream_t all kernels are launched on */
-int ks_profile_enable(ks_ctx* ctx, int on);
+/* Finish the frame a pipelined context still holds (no-op otherwise); stats = that frame's. */
+int ks_flush(ks_ctx* ctx, ks_frame_stats* stats);
+/* level 0: off; 1: events around every stage and every k_apply dispatch (costs ~50 us of stream
+ * bubbles per frame); 2: only the k_apply dispatch of every 4th frame is timed (a few us/frame).
+ * Events are resolved lazily, never by a host wait inside a frame. */
+int ks_profile_enable(ks_ctx* ctx, int level);
 int ks_profile_get(ks_ctx* ctx, ks_profile* out, int reset);
 
 #ifdef __cplusplus

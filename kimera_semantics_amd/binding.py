@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_set_color_to_label",
     "ks_integrate_points", "ks_integrate_points_device", "ks_integrate_depth", "ks_integrate_depth_device", "ks_num_blocks", "ks_get_block_indices",
     "ks_get_updated_block_indices", "ks_download_blocks", "ks_upload_blocks", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear",
-    "ks_debug_radix_sort", "ks_synchronize", "ks_stream",
+    "ks_debug_radix_sort", "ks_synchronize", "ks_flush", "ks_stream",
     "ks_profile_enable", "ks_profile_get",
 ]
 
@@ -52,7 +52,7 @@ class KsConfig(C.Structure):
         ("semantic_measurement_probability", C.c_float), ("color_mode", C.c_int32),
         ("n_dynamic_labels", C.c_int32), ("dynamic_labels", C.c_uint8 * 32),
         ("label_rgba", (C.c_uint8 * 4) * 256),
-        ("device_id", C.c_int32), ("max_tiles", C.c_uint32), ("max_points", C.c_uint32),
+        ("device_id", C.c_int32), ("max_tiles", C.c_uint32), ("max_points", C.c_uint32), ("pipeline_frames", C.c_int32),
     ]
 
 
@@ -64,7 +64,7 @@ class KsFrameStats(C.Structure):
 class KsProfile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("frames", C.c_uint64),
                 ("updates", C.c_uint64), ("points", C.c_uint64), ("apply_kernel_ms", C.c_double),
-                ("apply_kernel_launches", C.c_uint64)]
+                ("apply_kernel_launches", C.c_uint64), ("apply_kernel_updates", C.c_uint64)]
 
 
 def build(force: bool = False) -> str:
@@ -113,6 +113,7 @@ def lib():
         L.ks_clear.argtypes = [vp]
         L.ks_debug_radix_sort.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_uint]
         L.ks_synchronize.argtypes = [vp]
+        L.ks_flush.argtypes = [vp, C.POINTER(KsFrameStats)]
         L.ks_stream.argtypes = [vp]
         L.ks_stream.restype = vp
         L.ks_profile_enable.argtypes = [vp, C.c_int]
@@ -304,12 +305,20 @@ class HipIntegrator:
     def stream(self) -> int:
         return lib().ks_stream(self._h) or 0
 
-    def profile_enable(self, on=True):
-        self._chk(lib().ks_profile_enable(self._h, int(on)))
+    def profile_enable(self, level=1):
+        """0 off, 1 all stages, 2 sampled k_apply dispatches only (see ks_hip.h)."""
+        self._chk(lib().ks_profile_enable(self._h, int(level)))
+
+    def flush(self) -> KsFrameStats:
+        """Finish the frame a pipelined context still holds; returns that frame's statistics."""
+        st = KsFrameStats()
+        self._chk(lib().ks_flush(self._h, C.byref(st)))
+        return st
 
     def profile(self, reset=False) -> dict:
         p = KsProfile()
         self._chk(lib().ks_profile_get(self._h, C.byref(p), int(reset)))
         return {"ms": {STAGES[i]: p.ms[i] for i in range(8)}, "launches": {STAGES[i]: p.launches[i] for i in range(8)},
                 "frames": p.frames, "updates": p.updates, "points": p.points,
-                "apply_kernel_ms": p.apply_kernel_ms, "apply_kernel_launches": p.apply_kernel_launches}
+                "apply_kernel_ms": p.apply_kernel_ms, "apply_kernel_launches": p.apply_kernel_launches,
+                "apply_kernel_updates": p.apply_kernel_updates}

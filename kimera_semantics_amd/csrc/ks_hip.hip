@@ -59,7 +59,7 @@ struct Counters {
   unsigned long long n_pairs;
   uint32_t n_valid;
   uint32_t n_rays;
-  uint32_t n_tiles;   // persistent: tiles allocated so far
+  uint32_t pad0;
   uint32_t err;
   uint32_t n_long;    // voxel runs handed to the wave-per-run apply kernel
   uint32_t n_long_bundles;
@@ -130,6 +130,7 @@ struct TileTable {
   TileEntry* ent;      // open addressing; key == kEmpty64 = free.  Key and slot share one 16-B
                        // entry so a lookup is ONE memory round trip (it sits on the ray-march chain)
   uint64_t* slot_keys; // slot -> packed tile key
+  uint32_t* n_tiles;   // persistent: tiles allocated so far (never reset between frames)
   uint32_t mask;       // capacity - 1
   uint32_t max_tiles;
 };
@@ -240,7 +241,7 @@ __device__ __forceinline__ void tile_insert(const TileTable& T, Counters* C, uin
     if (k == kEmpty64) {
       const uint64_t old = atomicCAS((unsigned long long*)&T.ent[h].key, (unsigned long long)kEmpty64, (unsigned long long)key);
       if (old == kEmpty64) {
-        uint32_t slot = atomicAdd(&C->n_tiles, 1u);
+        uint32_t slot = atomicAdd(T.n_tiles, 1u);
         if (slot < T.max_tiles) {
           T.slot_keys[slot] = key;
         } else {
@@ -275,7 +276,7 @@ __device__ __forceinline__ uint32_t tile_slot_nowait(const TileTable& T, Counter
     if (k == kEmpty64) {
       const uint64_t old = atomicCAS((unsigned long long*)&T.ent[h].key, (unsigned long long)kEmpty64, (unsigned long long)key);
       if (old == kEmpty64) {
-        uint32_t slot = atomicAdd(&C->n_tiles, 1u);
+        uint32_t slot = atomicAdd(T.n_tiles, 1u);
         if (slot < T.max_tiles) {
           T.slot_keys[slot] = key;
         } else {
@@ -750,8 +751,13 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
     // speculation; the stop can only fall on the last of them.  On the long rays (the first
     // through their corridor, c stays 0) this cuts the dependent L2 round trips 3-4x.
     int vx[kBatch], vy[kBatch], vz[kBatch];
-    int n_upd = 0;   // steps of this iteration that emit an update
-    int n_adv = 0;   // steps of this iteration the DDA advances over
+    uint64_t tk[kBatch];   // tile key of each step
+    uint4 pre[kBatch];     // its first-probe table entry, loaded TOGETHER with the exchanges below:
+                           // the tile lookup leaves the dependent chain of the ray
+    bool em[kBatch];       // step emits an update
+    int n_adv = 0;         // steps of this iteration the DDA advances over
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) em[j] = false;
     if (!done) {
       const int remaining = dda.steps - s + 1;
       if (remaining <= 0) {
@@ -773,7 +779,14 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
             dda.advance();
           }
         }
-        n_upd = k;
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          if (j < k) {
+            tk[j] = pack_tile(vx[j] >> 3, vy[j] >> 3, vz[j] >> 3);
+            pre[j] = *(const uint4*)&T.ent[mix64(tk[j]) & T.mask];
+          }
+        }
+        int n_upd = k;
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
           if (j < k && !done) {
@@ -785,29 +798,41 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
             }
           }
         }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) em[j] = j < n_upd;
         n_adv = k;
       } else {
-        vx[0] = dda.cx; vy[0] = dda.cy; vz[0] = dda.cz;
-        n_upd = grazing_skip(F, dda.cx, dda.cy, dda.cz, clearing, own_key) ? 0 : 1;
-        n_adv = 1;
-        dda.advance();
+        const int k = remaining < kBatch ? remaining : kBatch;
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          if (j < k) {
+            vx[j] = dda.cx; vy[j] = dda.cy; vz[j] = dda.cz;
+            tk[j] = pack_tile(vx[j] >> 3, vy[j] >> 3, vz[j] >> 3);
+            pre[j] = *(const uint4*)&T.ent[mix64(tk[j]) & T.mask];
+            em[j] = !grazing_skip(F, dda.cx, dda.cy, dda.cz, clearing, own_key);
+            dda.advance();
+          }
+        }
+        n_adv = k;
       }
       s += n_adv;
     }
     // ---- (B) emit the integrated steps (uniform loop over the batch) ----
 #pragma unroll
     for (int j = 0; j < kBatch; ++j) {
-      const bool emit = j < n_upd;
-      if (__ballot(emit) == 0ull) break;
+      const bool emit = em[j];
+      bool any_left = emit;
+#pragma unroll
+      for (int jj = j + 1; jj < kBatch; ++jj) any_left = any_left || em[jj];
+      if (__ballot(any_left) == 0ull) break;
       uint32_t hpos = 0, got = 0;
       bool need_tile = false;
-      if (emit) {
-        const uint64_t tk = pack_tile(vx[j] >> 3, vy[j] >> 3, vz[j] >> 3);
-        if (tk != last_tile) {
-          need_tile = true;
-          last_tile = tk;
-          got = tile_slot_nowait(T, C, tk, &hpos);
-        }
+      if (emit && tk[j] != last_tile) {
+        need_tile = true;
+        last_tile = tk[j];
+        const uint64_t k64 = (uint64_t)pre[j].x | ((uint64_t)pre[j].y << 32);
+        if (k64 == tk[j] && pre[j].z != kSlotPending) got = pre[j].z;   // resident tile: no further memory access
+        else got = tile_slot_nowait(T, C, tk[j], &hpos);
       }
       // the wave has reconverged: every allocating lane of THIS wave has published its slot
       if (need_tile) {
@@ -1513,6 +1538,41 @@ std::string g_create_error;
 // ==========================================================================================
 // Host side of the C ABI
 // ==========================================================================================
+// A frame runs in two halves on the one stream:
+//   front: points -> sort -> dedup / bundles -> march(+emit) -> 40-byte counter snapshot to the host
+//   tail : init new tiles -> sort pairs -> apply           (sized by the snapshot)
+// Everything the tail reads from the front lives in a FrameSlot.  With ks_config.pipeline_frames
+// the tail of frame i is enqueued by the call for frame i+1, AFTER that frame's front, so the
+// host's wait for the snapshot never idles the GPU; two slots alternate.
+constexpr int kSlots = 2;
+struct FrameSlot {
+  int index = 0;
+  RayDesc* d_rays = nullptr;
+  float* d_deltas = nullptr;        // merged: label histograms of mixed bundles
+  uint64_t* d_pairs = nullptr;      // unsorted (voxel, ray) pairs written by k_march
+  size_t cap_pairs_in = 0;
+  Counters* d_counters = nullptr;   // inside ks_ctx::d_state
+  uint8_t* h_snap = nullptr;        // pinned, 64 B: device bytes [32 * index, 32 * index + 64)
+  hipEvent_t ready = nullptr;       // snapshot has landed
+  FrameParams F{};
+  size_t n = 0;
+  int prof_set = -1;
+  bool pending = false;
+  const Counters& counters() const { return *(const Counters*)(h_snap + (index == 0 ? 0 : 32)); }
+  uint32_t n_tiles() const { return *(const uint32_t*)(h_snap + (index == 0 ? 32 : 0)); }
+};
+
+// HIP-event sets for ks_profile: recorded in stream order, resolved lazily (before reuse or in
+// ks_profile_get) so that profiling never adds a host wait to a frame.
+constexpr int kProfSets = 4;
+constexpr int kStageEvents = KS_STAGE_COUNT + 2;  // 0..4 front (4 = snapshot done), 5 = tail start, 6..9
+struct ProfSet {
+  hipEvent_t ev[kStageEvents]{};
+  hipEvent_t k0 = nullptr, k1 = nullptr;  // begin/end of the k_apply dispatch itself
+  bool used = false, complete = false, stages = false, apply = false, applied = false;
+  uint64_t n_pairs = 0, n_points = 0;
+};
+
 struct ks_ctx {
   ks_config cfg{};
   std::string err;
@@ -1535,8 +1595,6 @@ struct ks_ctx {
   float* d_xyz = nullptr;
   uint8_t* d_rgba = nullptr;
   uint8_t* d_labels = nullptr;
-  RayDesc* d_rays = nullptr;
-  float* d_deltas = nullptr;
   uint32_t* d_hash = nullptr;
   uint32_t *d_skeys32 = nullptr, *d_skeys32b = nullptr;
   float4* d_gpw = nullptr;
@@ -1550,11 +1608,17 @@ struct ks_ctx {
   uint32_t* d_inv_order = nullptr;
   uint32_t *d_okeys = nullptr, *d_okeys2 = nullptr, *d_ovals = nullptr;
   uint32_t* d_ray_list = nullptr;
-  size_t cap_pairs = 0, cap_pairs_in = 0;
-  uint64_t *d_pairs = nullptr, *d_pairs2 = nullptr;
+  size_t cap_pairs = 0;
+  uint64_t* d_pairs2 = nullptr;
   ksrs::Workspace sort_ws;
-  Counters* d_counters = nullptr;
-  Counters* h_counters = nullptr;  // pinned
+  // Device words [Counters slot0 (32 B)][n_tiles + pad (32 B)][Counters slot1 (32 B)]: the end-of-
+  // front snapshot of either slot (its counters + the persistent tile count) is ONE 64-byte D2H
+  // copy, and each slot's counters are a 32-byte aligned memset.
+  uint8_t* d_state = nullptr;
+  FrameSlot slot[kSlots];
+  uint64_t frame_no = 0;
+  ks_frame_stats last_stats{};
+  bool stats_undelivered = false;  // a query completed a pipelined frame: its statistics go to the next call
   int32_t* d_block_idx = nullptr;
   size_t cap_block_idx = 0;
   uint8_t *d_tsdf_out = nullptr, *d_sem_out = nullptr;
@@ -1566,10 +1630,9 @@ struct ks_ctx {
   uint8_t* d_img_aux = nullptr;
   size_t cap_img_depth = 0, cap_img_aux = 0;
 
-  bool profiling = false;
+  int profiling = 0;  // 0 off, 1 all stages + every k_apply, 2 every 4th k_apply only
   ks_profile prof{};
-  hipEvent_t ev[KS_STAGE_COUNT + 1]{};
-  hipEvent_t ev_k0 = nullptr, ev_k1 = nullptr;  // begin/end of the k_apply dispatch itself
+  ProfSet pset[kProfSets];
   bool fatal = false;
 };
 
@@ -1598,7 +1661,10 @@ int ensure_points(ks_ctx* c, size_t n) {
   if ((rc = dev_alloc(c, &c->d_xyz, cap * 3))) return rc;
   if ((rc = dev_alloc(c, &c->d_rgba, cap * 4))) return rc;
   if ((rc = dev_alloc(c, &c->d_labels, cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_rays, cap))) return rc;
+  for (int i = 0; i < (c->cfg.pipeline_frames ? kSlots : 1); ++i) {
+    if ((rc = dev_alloc(c, &c->slot[i].d_rays, cap))) return rc;
+    if (c->cfg.method == KS_METHOD_MERGED && (rc = dev_alloc(c, &c->slot[i].d_deltas, cap * kNumLabels))) return rc;
+  }
   if ((rc = dev_alloc(c, &c->d_hash, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_skeys32, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_skeys32b, cap))) return rc;
@@ -1613,7 +1679,6 @@ int ensure_points(ks_ctx* c, size_t n) {
   if ((rc = dev_alloc(c, &c->d_ovals, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_ray_list, cap))) return rc;
   if (c->cfg.method == KS_METHOD_MERGED) {
-    if ((rc = dev_alloc(c, &c->d_deltas, cap * kNumLabels))) return rc;
     if ((rc = dev_alloc(c, &c->d_gpw, cap))) return rc;
     if ((rc = dev_alloc(c, &c->d_glc, cap))) return rc;
     if ((rc = dev_alloc(c, &c->d_ray_keys, cap))) return rc;
@@ -1625,12 +1690,12 @@ int ensure_points(ks_ctx* c, size_t n) {
 
 // d_pairs is written by k_march before the pair count is known: it is sized for the worst
 // case (every ray at full length); d_pairs2 / the long-run list are sized by the actual count.
-int ensure_pairs_in(ks_ctx* c, size_t bound) {
-  if (bound <= c->cap_pairs_in) return KS_OK;
+int ensure_pairs_in(ks_ctx* c, FrameSlot& S, size_t bound) {
+  if (bound <= S.cap_pairs_in) return KS_OK;
   const size_t cap = std::max<size_t>(bound, 1 << 20);
   int rc;
-  if ((rc = dev_alloc(c, &c->d_pairs, cap))) return rc;
-  c->cap_pairs_in = cap;
+  if ((rc = dev_alloc(c, &S.d_pairs, cap))) return rc;
+  S.cap_pairs_in = cap;
   return KS_OK;
 }
 int ensure_pairs_out(ks_ctx* c, size_t n) {
@@ -1673,38 +1738,46 @@ int reset_set(ks_ctx* c, uint64_t* d_set, uint64_t* offset) {
   return KS_OK;
 }
 
-inline void stage_mark(ks_ctx* c, int stage) {
-  if (c->profiling) (void)hipEventRecord(c->ev[stage], c->stream);
+inline void stage_mark(ks_ctx* c, int set, int ev) {
+  if (set >= 0 && c->pset[set].stages) (void)hipEventRecord(c->pset[set].ev[ev], c->stream);
 }
 
-int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba, const uint8_t* d_labels,
-                     size_t n, int freespace, ks_frame_stats* stats) {
-  if (c->fatal) {
-    c->err = "context is in a failed state (earlier pool/index error)";
-    return KS_ERR_INVALID_ARG;
-  }
-  if (n >= (1u << 23)) {
-    c->err = "more than 2^23-1 points per call";
-    return KS_ERR_INVALID_ARG;
-  }
-  const ks_config& cfg = c->cfg;
-  if (stats) std::memset(stats, 0, sizeof(*stats));
-  if (stats) stats->n_points = n;
-
-  // frame-level bookkeeping of the fast integrator [K:src/semantic_tsdf_integrator_fast.cpp:165-170]
-  if (cfg.method == KS_METHOD_FAST) {
-    if ((++c->reset_counter) >= cfg.clear_checks_every_n_frames) {
-      c->reset_counter = 0;
-      int rc;
-      if ((rc = reset_set(c, c->d_start_set, &c->start_offset))) return rc;
-      if ((rc = reset_set(c, c->d_observed_set, &c->observed_offset))) return rc;
+// fold a finished event set into ks_profile
+void resolve_prof(ks_ctx* c, int set) {
+  ProfSet& P = c->pset[set];
+  if (!P.used || !P.complete) return;
+  (void)hipEventSynchronize(P.ev[kStageEvents - 1]);
+  if (P.stages) {
+    for (int s = 0; s < KS_STAGE_COUNT; ++s) {
+      float ms = 0.f;
+      const int a = s < 4 ? s : s + 1;
+      if (hipEventElapsedTime(&ms, P.ev[a], P.ev[a + 1]) == hipSuccess) {
+        c->prof.ms[s] += ms;
+        c->prof.launches[s] += 1;
+      }
     }
   }
-  if (n == 0) return KS_OK;
-  int rc = ensure_points(c, n);
-  if (rc) return rc;
+  if (P.applied) {
+    float kms = 0.f;
+    if (hipEventElapsedTime(&kms, P.k0, P.k1) == hipSuccess) {
+      c->prof.apply_kernel_ms += kms;
+      c->prof.apply_kernel_launches += 1;
+      c->prof.apply_kernel_updates += P.n_pairs;
+    }
+  }
+  c->prof.frames += 1;
+  c->prof.updates += P.n_pairs;
+  c->prof.points += P.n_points;
+  P.used = P.complete = P.applied = false;
+}
 
-  FrameParams F{};
+// ---- front half: everything up to the counter snapshot --------------------------------------
+int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba,
+                const uint8_t* d_labels, size_t n, int freespace) {
+  const ks_config& cfg = c->cfg;
+  int rc;
+  FrameParams& F = S.F;
+  F = FrameParams{};
   F.T.w = Tq[0];
   F.T.v = {Tq[1], Tq[2], Tq[3]};
   F.T.t = {Tq[4], Tq[5], Tq[6]};
@@ -1748,18 +1821,35 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
   const double max_steps = 3.0 * ((double)cfg.max_ray_length_m + 2.0 * cfg.truncation_distance) * c->voxel_size_inv + 8.0;
   F.early_out = (cfg.method == KS_METHOD_FAST) && ((double)cfg.max_consecutive_ray_collisions < max_steps);
 
+  // march (+emit) writes pairs before their count is known: worst case = every point a full-length ray
+  {
+    const double max_len = (double)cfg.max_ray_length_m + 2.0 * (double)cfg.truncation_distance;
+    const size_t steps_max = (size_t)std::ceil(1.7321 * max_len * (double)c->voxel_size_inv) + 8;
+    if ((rc = ensure_pairs_in(c, S, n * steps_max))) return rc;
+  }
+
   hipStream_t st = c->stream;
-  const uint32_t old_tiles = c->h_counters->n_tiles;
-  // reset per-frame counters, keep n_tiles
-  Counters zero{};
-  zero.n_tiles = old_tiles;
-  *c->h_counters = zero;
-  HIPCHK(c, hipMemcpyAsync(c->d_counters, c->h_counters, sizeof(Counters), hipMemcpyHostToDevice, st));
+  S.n = n;
+  S.prof_set = -1;
+  if (c->profiling) {
+    const int set = (int)(c->frame_no % kProfSets);
+    resolve_prof(c, set);
+    ProfSet& P = c->pset[set];
+    P.used = true;
+    P.complete = P.applied = false;
+    P.stages = c->profiling == 1;
+    P.apply = c->profiling == 1 || (c->frame_no % 4) == 0;
+    P.n_points = n;
+    P.n_pairs = 0;
+    S.prof_set = set;
+  }
+  ++c->frame_no;
+  HIPCHK(c, hipMemsetAsync(S.d_counters, 0, sizeof(Counters), st));
 
   const uint32_t nb = (uint32_t)((n + 255) / 256);
   const uint32_t nb1k = (uint32_t)((n + 1023) / 1024);
   const uint32_t* order_ptr = nullptr;
-  stage_mark(c, 0);
+  stage_mark(c, S.prof_set, 0);
 
   if (F.sorted_order) {
     hipLaunchKernelGGL(k_sqnorm, dim3(nb), dim3(256), 0, st, (uint32_t)n, d_xyz, c->d_okeys, c->d_ovals);
@@ -1772,76 +1862,96 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
 
   if (cfg.method == KS_METHOD_FAST) {
     hipLaunchKernelGGL(k_points_fast, dim3(nb1k), dim3(1024), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       c->d_rays, c->d_hash, c->d_skeys32, c->d_pvals, c->d_counters);
-    stage_mark(c, 1);
+                       S.d_rays, c->d_hash, c->d_skeys32, c->d_pvals, S.d_counters);
+    stage_mark(c, S.prof_set, 1);
     // stable sort by slot only: position order inside a slot is preserved
     uint32_t *sk = nullptr, *sv = nullptr;
     if ((rc = sort_pairs(c, c->d_skeys32, c->d_skeys32b, c->d_pvals, c->d_pvals2, n, kSetBits + 1, &sk, &sv))) return rc;
-    stage_mark(c, 2);
+    stage_mark(c, S.prof_set, 2);
     hipLaunchKernelGGL(k_dedup, dim3(nb1k), dim3(1024), 0, st, F, sk, sv, c->d_hash, c->d_start_set, c->d_ray_list,
-                       c->d_counters);
+                       S.d_counters);
     hipLaunchKernelGGL(k_dedup_commit, dim3(nb1k), dim3(1024), 0, st, F, sk, sv, c->d_hash, c->d_start_set,
-                       c->d_counters);
+                       S.d_counters);
   } else {
     hipLaunchKernelGGL(k_points_merged, dim3(nb1k), dim3(1024), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       c->d_pkeys, c->d_pvals, c->d_counters);
-    stage_mark(c, 1);
+                       c->d_pkeys, c->d_pvals, S.d_counters);
+    stage_mark(c, S.prof_set, 1);
     uint64_t* sk = nullptr;
     uint32_t* sv = nullptr;
     if ((rc = sort_pairs(c, c->d_pkeys, c->d_pkeys2, c->d_pvals, c->d_pvals2, n, 64, &sk, &sv))) return rc;
-    stage_mark(c, 2);
+    stage_mark(c, S.prof_set, 2);
     hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
                        order_ptr, sk, sv, c->d_gpw, c->d_glc);
     uint64_t* ray_keys = cfg.enable_anti_grazing ? c->d_ray_keys : nullptr;
-    hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, sk, sv, c->d_gpw, c->d_glc, c->d_rays, c->d_deltas,
-                       c->d_ray_list, c->d_blong, ray_keys, c->d_counters);
+    hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas,
+                       c->d_ray_list, c->d_blong, ray_keys, S.d_counters);
     hipLaunchKernelGGL(k_bundles_long, dim3((uint32_t)std::min<size_t>(n / kLongRun + 1, 2048)), dim3(64), 0, st, F,
-                       sk, sv, c->d_gpw, c->d_glc, c->d_rays, c->d_deltas, c->d_ray_list, c->d_blong, ray_keys,
-                       c->d_counters);
+                       sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas, c->d_ray_list, c->d_blong, ray_keys,
+                       S.d_counters);
     if (cfg.enable_anti_grazing) {
       F.grazing_keys = sk;
       F.ray_keys = c->d_ray_keys;
     }
   }
-  stage_mark(c, 3);
-  // march (+emit) over an upper bound of rays (<= n); the live ray count stays on the device.
-  // Worst-case pair count: every point becomes a ray of full length.
-  {
-    const double max_len = (double)cfg.max_ray_length_m + 2.0 * (double)cfg.truncation_distance;
-    const size_t steps_max = (size_t)std::ceil(1.7321 * max_len * (double)c->voxel_size_inv) + 8;
-    if ((rc = ensure_pairs_in(c, n * steps_max))) return rc;
+  stage_mark(c, S.prof_set, 3);
+  // march (+emit) over an upper bound of rays (<= n); the live ray count stays on the device
+  hipLaunchKernelGGL(k_march, dim3(nb), dim3(256), 0, st, F, c->d_ray_list, S.d_rays, c->table, c->pool,
+                     c->d_observed_set, S.d_pairs, (unsigned long long)S.cap_pairs_in, S.d_counters);
+  // the frame's only device->host traffic: pair / ray / tile counts and error flags
+  HIPCHK(c, hipMemcpyAsync(S.h_snap, c->d_state + 32 * S.index, 64, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipEventRecord(S.ready, st));
+  stage_mark(c, S.prof_set, 4);
+  S.pending = true;
+  return KS_OK;
+}
+
+// ---- tail half: sized by the snapshot --------------------------------------------------------
+int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
+  if (!S.pending) return KS_OK;
+  S.pending = false;
+  hipStream_t st = c->stream;
+  const FrameParams& F = S.F;
+  HIPCHK(c, hipEventSynchronize(S.ready));  // the frame's only host wait
+  const Counters cnt = S.counters();
+  const uint32_t new_tiles = std::min(S.n_tiles(), c->cfg.max_tiles);
+  const uint32_t tiles_before = c->tiles_initialised;
+  const int set = S.prof_set;
+  stage_mark(c, set, 5);
+  // tiles allocated by the front exist in the table whatever happens next: make them valid
+  if (new_tiles > c->tiles_initialised) {
+    hipLaunchKernelGGL(k_init_tiles, dim3(new_tiles - c->tiles_initialised), dim3(512), 0, st, c->pool,
+                       c->tiles_initialised);
+    c->tiles_initialised = new_tiles;
   }
-  hipLaunchKernelGGL(k_march, dim3(nb), dim3(256), 0, st, F, c->d_ray_list, c->d_rays, c->table, c->pool,
-                     c->d_observed_set, c->d_pairs, (unsigned long long)c->cap_pairs_in, c->d_counters);
-  // the only host synchronisation of the frame: pair / tile / ray counts and error flags
-  HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st));
-  if (c->h_counters->err & kErrLabel) {
-    c->h_counters->n_tiles = old_tiles;
+  auto finish_prof = [&](uint64_t n_pairs) {
+    if (set < 0) return;
+    ProfSet& P = c->pset[set];
+    P.n_pairs = n_pairs;
+    (void)hipEventRecord(P.ev[kStageEvents - 1], st);
+    P.complete = true;
+  };
+  if (cnt.err & kErrLabel) {
+    for (int e = 6; e < kStageEvents - 1; ++e) stage_mark(c, set, e);
+    finish_prof(0);
     c->err = "semantic label >= 21 (CHECK_LT in the reference)";
     return KS_ERR_LABEL_RANGE;
   }
-  if (c->h_counters->err) {
+  if (cnt.err) {
+    for (int e = 6; e < kStageEvents - 1; ++e) stage_mark(c, set, e);
+    finish_prof(0);
     c->fatal = true;
-    if (c->h_counters->err & kErrPool) {
+    if (cnt.err & kErrPool) {
       c->err = "voxel tile pool exhausted: raise ks_config.max_tiles";
       return KS_ERR_POOL_FULL;
     }
     c->err = "voxel index out of the packed range / tile table full";
     return KS_ERR_INDEX_RANGE;
   }
-  const uint32_t n_rays = c->h_counters->n_rays;
-  const uint32_t new_tiles = c->h_counters->n_tiles;
-  const unsigned long long n_pairs = c->h_counters->n_pairs;
-  stage_mark(c, 4);
-  if (new_tiles > c->tiles_initialised) {
-    hipLaunchKernelGGL(k_init_tiles, dim3(new_tiles - c->tiles_initialised), dim3(512), 0, st, c->pool,
-                       c->tiles_initialised);
-    c->tiles_initialised = new_tiles;
-  }
+  const unsigned long long n_pairs = cnt.n_pairs;
   if (n_pairs > 0) {
+    int rc;
     if ((rc = ensure_pairs_out(c, n_pairs))) return rc;
-    stage_mark(c, 5);
+    stage_mark(c, set, 6);
     const unsigned end_bit = F.seq_bits + 9 + bits_for(new_tiles);
     uint64_t* sp = nullptr;
     // Deterministic modes sort by (voxel, ray sequence): every voxel replays its updates in
@@ -1851,63 +1961,114 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
     // skips the sequence bits (2 fewer passes); the order inside a voxel is then the stable
     // emission order.
     const unsigned begin_bit = F.early_out ? F.seq_bits : 0u;
-    if ((rc = sort_keys(c, c->d_pairs, c->d_pairs2, n_pairs, std::min(64u, end_bit), &sp, begin_bit))) return rc;
-    stage_mark(c, 6);
+    if ((rc = sort_keys(c, S.d_pairs, c->d_pairs2, n_pairs, std::min(64u, end_bit), &sp, begin_bit))) return rc;
+    stage_mark(c, set, 7);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
+    const bool time_apply = set >= 0 && c->pset[set].apply;
+    if (time_apply) c->pset[set].applied = true;
 #define KS_LAUNCH_APPLY(MODE)                                                                                        \
-  if (c->profiling)                                                                                                  \
-    hipExtLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, c->ev_k0, c->ev_k1, 0, F, n_pairs, sp, c->d_rays, \
-                          c->d_deltas, c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters);             \
+  if (time_apply)                                                                                                    \
+    hipExtLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, c->pset[set].k0, c->pset[set].k1, 0, F, n_pairs, \
+                          sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut, c->d_long_list, S.d_counters); \
   else                                                                                                               \
-    hipLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, F, n_pairs, sp, c->d_rays, c->d_deltas,             \
-                       c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters);                             \
-  stage_mark(c, 7);                                                                                                  \
-  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(64), 0, st, F, n_pairs, sp, c->d_rays, c->d_deltas,           \
-                     c->table, c->pool, c->d_label_lut, c->d_long_list, c->d_counters)
-    switch (cfg.color_mode) {
+    hipLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table,     \
+                       c->pool, c->d_label_lut, c->d_long_list, S.d_counters);                                        \
+  stage_mark(c, set, 8);                                                                                             \
+  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(64), 0, st, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table,   \
+                     c->pool, c->d_label_lut, c->d_long_list, S.d_counters)
+    switch (c->cfg.color_mode) {
       case KS_COLOR_MODE_COLOR: KS_LAUNCH_APPLY(KS_COLOR_MODE_COLOR); break;
       case KS_COLOR_MODE_SEMANTIC: KS_LAUNCH_APPLY(KS_COLOR_MODE_SEMANTIC); break;
       default: KS_LAUNCH_APPLY(KS_COLOR_MODE_SEMANTIC_PROBABILITY); break;
     }
 #undef KS_LAUNCH_APPLY
   } else {
-    stage_mark(c, 5);
-    stage_mark(c, 6);
-    stage_mark(c, 7);
+    stage_mark(c, set, 6);
+    stage_mark(c, set, 7);
+    stage_mark(c, set, 8);
   }
-  stage_mark(c, 8);
+  finish_prof(n_pairs);
   HIPCHK(c, hipGetLastError());
-  if (c->profiling) {
-    HIPCHK(c, hipEventSynchronize(c->ev[KS_STAGE_COUNT]));
-    for (int s = 0; s < KS_STAGE_COUNT; ++s) {
-      float ms = 0.f;
-      if (hipEventElapsedTime(&ms, c->ev[s], c->ev[s + 1]) == hipSuccess) {
-        c->prof.ms[s] += ms;
-        c->prof.launches[s] += 1;
-      }
+  c->last_stats = ks_frame_stats{};
+  c->last_stats.n_points = S.n;
+  c->last_stats.n_valid_points = cnt.n_valid;
+  c->last_stats.n_rays_cast = cnt.n_rays;
+  c->last_stats.n_voxel_updates = n_pairs;
+  c->last_stats.n_blocks_allocated = new_tiles - tiles_before;
+  c->stats_undelivered = stats == nullptr;
+  if (stats) *stats = c->last_stats;
+  return KS_OK;
+}
+
+// run the tail of a frame whose front is still waiting for it (pipelined mode)
+int flush_pending(ks_ctx* c, ks_frame_stats* stats) {
+  // at most one slot is pending between calls; the older frame first in any case
+  for (int k = 0; k < kSlots; ++k) {
+    FrameSlot& S = c->slot[(c->frame_no + k) % kSlots];
+    if (S.pending) {
+      const int rc = frame_tail(c, S, stats);
+      if (rc) return rc;
     }
-    if (n_pairs > 0) {
-      float kms = 0.f;
-      if (hipEventElapsedTime(&kms, c->ev_k0, c->ev_k1) == hipSuccess) {
-        c->prof.apply_kernel_ms += kms;
-        c->prof.apply_kernel_launches += 1;
-      }
-    }
-    c->prof.frames += 1;
-    c->prof.updates += n_pairs;
-    c->prof.points += n;
   }
-  if (stats) {
-    stats->n_valid_points = c->h_counters->n_valid;
-    stats->n_rays_cast = n_rays;
-    stats->n_voxel_updates = n_pairs;
-    stats->n_blocks_allocated = new_tiles - old_tiles;
+  return KS_OK;
+}
+
+int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba, const uint8_t* d_labels,
+                     size_t n, int freespace, ks_frame_stats* stats) {
+  if (c->fatal) {
+    c->err = "context is in a failed state (earlier pool/index error)";
+    return KS_ERR_INVALID_ARG;
+  }
+  if (n >= (1u << 23)) {
+    c->err = "more than 2^23-1 points per call";
+    return KS_ERR_INVALID_ARG;
+  }
+  const ks_config& cfg = c->cfg;
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  // sorted integration order keeps its permutation in single buffers: not pipelined
+  const bool pipelined = cfg.pipeline_frames && cfg.integration_order_mode != KS_ORDER_SORTED;
+  int rc;
+
+  // frame-level bookkeeping of the fast integrator [K:src/semantic_tsdf_integrator_fast.cpp:165-170]
+  if (cfg.method == KS_METHOD_FAST) {
+    if ((++c->reset_counter) >= cfg.clear_checks_every_n_frames) {
+      c->reset_counter = 0;
+      if ((rc = reset_set(c, c->d_start_set, &c->start_offset))) return rc;
+      if ((rc = reset_set(c, c->d_observed_set, &c->observed_offset))) return rc;
+    }
+  }
+  if (n == 0) {
+    if ((rc = flush_pending(c, nullptr))) return rc;
+    if (stats) stats->n_points = 0;
+    return KS_OK;
+  }
+  if (n > c->cap_points) {  // growing frees buffers a pending tail still needs
+    if ((rc = flush_pending(c, nullptr))) return rc;
+    if ((rc = ensure_points(c, n))) return rc;
+  }
+  if (!pipelined) {
+    if ((rc = flush_pending(c, nullptr))) return rc;
+    FrameSlot& S = c->slot[0];
+    if ((rc = frame_front(c, S, Tq, d_xyz, d_rgba, d_labels, n, freespace))) return rc;
+    return frame_tail(c, S, stats);
+  }
+  // pipelined: front of this frame first, then the tail of the previous one; the statistics
+  // returned are those of the frame whose tail ran here (the previous frame)
+  FrameSlot& S = c->slot[c->frame_no % kSlots];
+  FrameSlot& prev = c->slot[(c->frame_no + 1) % kSlots];
+  if (S.pending && (rc = frame_tail(c, S, nullptr))) return rc;  // cannot happen: slots alternate
+  if ((rc = frame_front(c, S, Tq, d_xyz, d_rgba, d_labels, n, freespace))) return rc;
+  if (prev.pending) return frame_tail(c, prev, stats);
+  if (c->stats_undelivered && stats) {
+    *stats = c->last_stats;
+    c->stats_undelivered = false;
   }
   return KS_OK;
 }
 
 int collect_block_indices(ks_ctx* c, bool only_updated, bool reset, std::vector<int32_t>* out) {
+  if (int rc = flush_pending(c, nullptr)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const uint32_t nt = c->tiles_initialised;
   std::vector<uint64_t> keys(nt);
@@ -1938,25 +2099,24 @@ int collect_block_indices(ks_ctx* c, bool only_updated, bool reset, std::vector<
 
 // find-or-insert n tile keys (device array) and initialise the newly allocated tiles
 static int insert_tiles(ks_ctx* c, const uint64_t* d_keys, size_t n) {
-  const uint32_t old_tiles = c->h_counters->n_tiles;
-  Counters zero{};
-  zero.n_tiles = old_tiles;
-  *c->h_counters = zero;
-  HIPCHK(c, hipMemcpyAsync(c->d_counters, c->h_counters, sizeof(Counters), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_insert_tiles, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->table, c->d_counters,
+  int rc;
+  if ((rc = flush_pending(c, nullptr))) return rc;
+  FrameSlot& S = c->slot[0];
+  HIPCHK(c, hipMemsetAsync(S.d_counters, 0, sizeof(Counters), c->stream));
+  hipLaunchKernelGGL(k_insert_tiles, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->table, S.d_counters,
                      d_keys, (uint32_t)n);
-  HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, sizeof(Counters), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(S.h_snap, c->d_state, 64, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->h_counters->err) {
-    c->fatal = true;
-    c->err = "voxel tile pool exhausted: raise ks_config.max_tiles";
-    return KS_ERR_POOL_FULL;
-  }
-  const uint32_t new_tiles = c->h_counters->n_tiles;
+  const uint32_t new_tiles = std::min(S.n_tiles(), c->cfg.max_tiles);
   if (new_tiles > c->tiles_initialised) {
     hipLaunchKernelGGL(k_init_tiles, dim3(new_tiles - c->tiles_initialised), dim3(512), 0, c->stream, c->pool,
                        c->tiles_initialised);
     c->tiles_initialised = new_tiles;
+  }
+  if (S.counters().err) {
+    c->fatal = true;
+    c->err = "voxel tile pool exhausted: raise ks_config.max_tiles";
+    return KS_ERR_POOL_FULL;
   }
   return KS_OK;
 }
@@ -2043,9 +2203,11 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   } while (0)
   CRCHK(hipSetDevice(cfg->device_id));
   CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  for (auto& e : c->ev) CRCHK(hipEventCreate(&e));
-  CRCHK(hipEventCreate(&c->ev_k0));
-  CRCHK(hipEventCreate(&c->ev_k1));
+  for (auto& P : c->pset) {
+    for (auto& e : P.ev) CRCHK(hipEventCreate(&e));
+    CRCHK(hipEventCreate(&P.k0));
+    CRCHK(hipEventCreate(&P.k1));
+  }
   uint32_t cap = 1024;
   while (cap < 2u * cfg->max_tiles) cap <<= 1;
   c->table.mask = cap - 1;
@@ -2066,10 +2228,18 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipMemcpy(c->d_observed_set, &poison, 8, hipMemcpyHostToDevice));
   CRCHK(hipMalloc((void**)&c->d_label_lut, 256 * sizeof(uint32_t)));
   CRCHK(hipMemcpy(c->d_label_lut, cfg->label_rgba, 1024, hipMemcpyHostToDevice));
-  CRCHK(hipMalloc((void**)&c->d_counters, sizeof(Counters)));
-  CRCHK(hipHostMalloc((void**)&c->h_counters, sizeof(Counters)));
-  std::memset(c->h_counters, 0, sizeof(Counters));
-  CRCHK(hipMemset(c->d_counters, 0, sizeof(Counters)));
+  static_assert(sizeof(Counters) == 32, "snapshot layout");
+  CRCHK(hipMalloc((void**)&c->d_state, 96));
+  CRCHK(hipMemset(c->d_state, 0, 96));
+  c->table.n_tiles = (uint32_t*)(c->d_state + 32);
+  for (int i = 0; i < kSlots; ++i) {
+    FrameSlot& S = c->slot[i];
+    S.index = i;
+    S.d_counters = (Counters*)(c->d_state + 64 * i);
+    CRCHK(hipHostMalloc((void**)&S.h_snap, 64));
+    std::memset(S.h_snap, 0, 64);
+    CRCHK(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
+  }
 #undef CRCHK
   if (ensure_points(c, cfg->max_points) != KS_OK) {
     g_create_error = c->err;
@@ -2084,18 +2254,23 @@ void ks_destroy(ks_ctx* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
-                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_rays, c->d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
+                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->slot[0].d_rays, c->slot[1].d_rays, c->slot[0].d_deltas, c->slot[1].d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
-                  c->d_ray_list, c->d_pairs, c->d_pairs2, c->d_counters,
+                  c->d_ray_list, c->slot[0].d_pairs, c->slot[1].d_pairs, c->d_pairs2, c->d_state,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   ksrs::release(c->sort_ws);
-  if (c->h_counters) (void)hipHostFree(c->h_counters);
-  for (auto& e : c->ev)
-    if (e) (void)hipEventDestroy(e);
-  if (c->ev_k0) (void)hipEventDestroy(c->ev_k0);
-  if (c->ev_k1) (void)hipEventDestroy(c->ev_k1);
+  for (auto& S : c->slot) {
+    if (S.h_snap) (void)hipHostFree(S.h_snap);
+    if (S.ready) (void)hipEventDestroy(S.ready);
+  }
+  for (auto& P : c->pset) {
+    for (auto& e : P.ev)
+      if (e) (void)hipEventDestroy(e);
+    if (P.k0) (void)hipEventDestroy(P.k0);
+    if (P.k1) (void)hipEventDestroy(P.k1);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -2259,6 +2434,7 @@ int ks_get_updated_block_indices(ks_ctx* c, int32_t* out, size_t cap, size_t* n,
 int ks_download_blocks(ks_ctx* c, const int32_t* idx, size_t n, void* tsdf_out, void* sem_out) {
   if (!c || (n && !idx)) return KS_ERR_INVALID_ARG;
   if (n == 0) return KS_OK;
+  if (int rc = flush_pending(c, nullptr)) return rc;
   const int vps = c->cfg.voxels_per_side;
   const size_t nv = (size_t)vps * vps * vps;
   // chunk so staging buffers stay bounded (<= ~256 MiB of semantic voxels)
@@ -2379,6 +2555,7 @@ int ks_debug_radix_sort(ks_ctx* c, void* keys, uint32_t* vals, size_t n, int key
 
 int ks_get_tile_keys(ks_ctx* c, uint64_t* out, size_t cap, size_t* n) {
   if (!c || !n) return KS_ERR_INVALID_ARG;
+  if (int rc = flush_pending(c, nullptr)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *n = c->tiles_initialised;
   const size_t m = std::min<size_t>(cap, *n);
@@ -2389,6 +2566,7 @@ int ks_get_tile_keys(ks_ctx* c, uint64_t* out, size_t cap, size_t* n) {
 int ks_export_tiles_device(ks_ctx* c, const uint32_t* slots, size_t n, void* d_payload) {
   if (!c || (n && (!slots || !d_payload))) return KS_ERR_INVALID_ARG;
   if (n == 0) return KS_OK;
+  if (int rc = flush_pending(c, nullptr)) return rc;
   for (size_t i = 0; i < n; ++i)
     if (slots[i] >= c->tiles_initialised) return KS_ERR_INVALID_ARG;
   uint32_t* d_slots = nullptr;
@@ -2434,32 +2612,46 @@ int ks_merge_tiles_device(ks_ctx* c, const uint64_t* keys, size_t n, const void*
 
 int ks_clear(ks_ctx* c) {
   if (!c) return KS_ERR_INVALID_ARG;
+  for (auto& S : c->slot) S.pending = false;  // a frame that was never applied is dropped with the map
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemset(c->table.ent, 0xff, ((size_t)c->table.mask + 1) * sizeof(TileEntry)));
   HIPCHK(c, hipMemset(c->pool.updated, 0, c->cfg.max_tiles));
-  std::memset(c->h_counters, 0, sizeof(Counters));
-  HIPCHK(c, hipMemset(c->d_counters, 0, sizeof(Counters)));
+  HIPCHK(c, hipMemset(c->d_state, 0, 96));
   c->tiles_initialised = 0;
   c->fatal = false;
   return KS_OK;
 }
 
+int ks_flush(ks_ctx* c, ks_frame_stats* stats) {
+  if (!c) return KS_ERR_INVALID_ARG;
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  const bool had = c->slot[0].pending || c->slot[1].pending;
+  const int rc = flush_pending(c, stats);
+  if (rc == KS_OK && !had && c->stats_undelivered && stats) *stats = c->last_stats;
+  if (stats) c->stats_undelivered = false;
+  return rc;
+}
+
 int ks_synchronize(ks_ctx* c) {
   if (!c) return KS_ERR_INVALID_ARG;
+  if (int rc = flush_pending(c, nullptr)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return KS_OK;
 }
 
 void* ks_stream(ks_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
-int ks_profile_enable(ks_ctx* c, int on) {
-  if (!c) return KS_ERR_INVALID_ARG;
-  c->profiling = on != 0;
+int ks_profile_enable(ks_ctx* c, int level) {
+  if (!c || level < 0 || level > 2) return KS_ERR_INVALID_ARG;
+  c->profiling = level;
   return KS_OK;
 }
 
 int ks_profile_get(ks_ctx* c, ks_profile* out, int reset) {
   if (!c || !out) return KS_ERR_INVALID_ARG;
+  if (int rc = flush_pending(c, nullptr)) return rc;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < kProfSets; ++i) resolve_prof(c, i);
   *out = c->prof;
   if (reset) c->prof = ks_profile{};
   return KS_OK;

@@ -47,6 +47,7 @@ ks_config makeConfig(HipSemanticTsdfIntegrator::Method method, const vxb::TsdfIn
   k.device_id = o.device_id;
   k.max_tiles = o.max_tiles;
   k.max_points = o.max_points;
+  k.pipeline_frames = (o.pipeline_frames && o.sync_policy == HipSemanticTsdfIntegrator::SyncPolicy::kOnDemand) ? 1 : 0;
   return k;
 }
 }  // namespace

@@ -34,6 +34,10 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
     uint32_t max_tiles = 1u << 16;   ///< 8^3-voxel tiles (49.7 KB each)
     uint32_t max_points = 1u << 20;
     SyncPolicy sync_policy = SyncPolicy::kEveryFrame;
+    /// ks_config.pipeline_frames: overlap the host wait of frame i with the GPU work of frame i+1.
+    /// Only takes effect with kOnDemand (kEveryFrame reads the map back after every frame, which
+    /// completes the frame first).
+    bool pipeline_frames = false;
   };
 
   HipSemanticTsdfIntegrator(Method method, const Config& config, const SemanticConfig& semantic_config,

@@ -390,3 +390,62 @@ def test_upload_roundtrip_and_resume(method):
     assert tc.tobytes() == t.tobytes() and sc_.tobytes() == s.tobytes()
     with pytest.raises(B.KsError):
         c.upload(np.array([[1 << 20, 0, 0]], np.int32), tsdf=t[:1])
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_pipelined_frames_equal_unpipelined(method):
+    """ks_config.pipeline_frames only moves WHEN a frame's second half is enqueued: the map is
+    bit-identical, the statistics arrive one call later, queries complete the outstanding frame."""
+    kw = dict(COMMON, method=method, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    o = O.Oracle(O.default_config(**kw))
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, pipeline_frames=1, **kw))
+    sc = synth.make_scene("room")
+    # growing clouds force a buffer re-allocation while a frame is outstanding
+    sizes = [(96, 72), (160, 120), (160, 120), (240, 180), (160, 120), (160, 120)]
+    ref_stats, got = [], []
+    for k, (w, hh) in enumerate(sizes):
+        f = synth.render_frame(sc, synth.trajectory_pose(4 * k), w, hh, seed=700 + k)
+        so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        ref_stats.append((so.n_points, so.n_valid_points, so.n_rays_cast, so.n_voxel_updates))
+        sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        got.append((sh.n_points, sh.n_valid_points, sh.n_rays_cast, sh.n_voxel_updates))
+        if k == 2:  # a query in the middle of the stream sees frames 0..2 complete
+            assert len(h.block_indices()) == len(o.block_indices())
+    last = h.flush()
+    got.append((last.n_points, last.n_valid_points, last.n_rays_cast, last.n_voxel_updates))
+    assert h.flush().n_points == 0  # nothing left
+    # call k returns frame k-1 (also when a query or a re-allocation completed that frame early)
+    assert got[0] == (0, 0, 0, 0) and got[1:] == ref_stats, (ref_stats, got)
+    compare_maps(o, h, exact=True)
+
+
+def test_pipelined_label_error_is_reported_by_the_next_call():
+    h = B.HipIntegrator(B.default_config(max_tiles=1024, max_points=1 << 12, pipeline_frames=1, **dict(COMMON, method=0)))
+    T = np.array([1, 0, 0, 0, 0, 0, 0], np.float32)
+    pts = np.array([[0.5, 0.2, 1.0], [0.4, 0.1, 1.2]], np.float32)
+    h.integrate(T, pts, None, np.array([3, 21], np.uint8))      # bad label: found when the frame completes
+    with pytest.raises(B.KsError) as e:
+        h.flush()
+    assert e.value.code == -2  # KS_ERR_LABEL_RANGE
+    h.integrate(T, pts, None, np.array([3, 4], np.uint8))       # context still usable
+    assert h.flush().n_voxel_updates > 0
+
+
+def test_profile_levels():
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, pipeline_frames=1, **dict(COMMON, method=0)))
+    sc = synth.make_scene("room")
+    fr = [synth.render_frame(sc, synth.trajectory_pose(k), 160, 120, seed=k) for k in range(8)]
+    h.profile_enable(1)
+    tot = 0
+    for f in fr:
+        tot += h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
+    tot += h.flush().n_voxel_updates
+    p = h.profile(reset=True)
+    assert p["frames"] == 8 and p["updates"] == tot and p["apply_kernel_launches"] == 8
+    assert all(v >= 0 for v in p["ms"].values()) and p["ms"]["march"] > 0 and p["apply_kernel_ms"] > 0
+    h.profile_enable(2)
+    for f in fr:
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    p = h.profile()
+    assert p["frames"] == 8 and p["apply_kernel_launches"] == 2 and sum(p["ms"].values()) == 0
+    assert 0 < p["apply_kernel_updates"] < p["updates"]
