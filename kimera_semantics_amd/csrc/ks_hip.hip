@@ -1542,8 +1542,11 @@ std::string g_create_error;
 //   front: points -> sort -> dedup / bundles -> march(+emit) -> 40-byte counter snapshot to the host
 //   tail : init new tiles -> sort pairs -> apply           (sized by the snapshot)
 // Everything the tail reads from the front lives in a FrameSlot.  With ks_config.pipeline_frames
-// the tail of frame i is enqueued by the call for frame i+1, AFTER that frame's front, so the
-// host's wait for the snapshot never idles the GPU; two slots alternate.
+// the tail of frame i is enqueued by the call for frame i+1, after that frame's front and on a
+// second stream: the host's wait for the snapshot never idles the GPU, and the tail of frame i
+// (latency-bound sort passes, voxel updates) runs CONCURRENTLY with the front of frame i+1
+// (atomics-bound ray march), which touches no voxel data.  Two slots alternate; a front waits for
+// the tail that last used its slot.
 constexpr int kSlots = 2;
 struct FrameSlot {
   int index = 0;
@@ -1554,6 +1557,8 @@ struct FrameSlot {
   Counters* d_counters = nullptr;   // inside ks_ctx::d_state
   uint8_t* h_snap = nullptr;        // pinned, 64 B: device bytes [32 * index, 32 * index + 64)
   hipEvent_t ready = nullptr;       // snapshot has landed
+  hipEvent_t tail_done = nullptr;   // the tail has consumed this slot's buffers
+  bool tail_recorded = false;
   FrameParams F{};
   size_t n = 0;
   int prof_set = -1;
@@ -1576,7 +1581,8 @@ struct ProfSet {
 struct ks_ctx {
   ks_config cfg{};
   std::string err;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;       // front halves (and everything else)
+  hipStream_t stream_tail = nullptr;  // tail halves; == stream unless ks_config.pipeline_frames
   float voxel_size_inv = 0.f, log_match = 0.f, log_non_match = 0.f;
   int vps_shift = 1;  // log2(vps / 8)
 
@@ -1610,7 +1616,7 @@ struct ks_ctx {
   uint32_t* d_ray_list = nullptr;
   size_t cap_pairs = 0;
   uint64_t* d_pairs2 = nullptr;
-  ksrs::Workspace sort_ws;
+  ksrs::Workspace sort_ws, sort_ws_tail;
   // Device words [Counters slot0 (32 B)][n_tiles + pad (32 B)][Counters slot1 (32 B)]: the end-of-
   // front snapshot of either slot (its counters + the persistent tile count) is ONE 64-byte D2H
   // copy, and each slot's counters are a 32-byte aligned memset.
@@ -1709,8 +1715,9 @@ int ensure_pairs_out(ks_ctx* c, size_t n) {
 }
 
 template <typename K>
-int sort_keys(ks_ctx* c, K* a, K* b, size_t n, unsigned end_bit, K** result, unsigned begin_bit = 0) {
-  HIPCHK(c, (ksrs::sort<K, false>(c->sort_ws, a, b, nullptr, nullptr, n, end_bit, c->stream, result, nullptr, begin_bit)));
+int sort_keys(ks_ctx* c, K* a, K* b, size_t n, unsigned end_bit, K** result, unsigned begin_bit = 0, bool tail = false) {
+  HIPCHK(c, (ksrs::sort<K, false>(tail ? c->sort_ws_tail : c->sort_ws, a, b, nullptr, nullptr, n, end_bit,
+                                  tail ? c->stream_tail : c->stream, result, nullptr, begin_bit)));
   return KS_OK;
 }
 template <typename K>
@@ -1739,7 +1746,8 @@ int reset_set(ks_ctx* c, uint64_t* d_set, uint64_t* offset) {
 }
 
 inline void stage_mark(ks_ctx* c, int set, int ev) {
-  if (set >= 0 && c->pset[set].stages) (void)hipEventRecord(c->pset[set].ev[ev], c->stream);
+  // events 0..4 belong to the front half, 5.. to the tail half
+  if (set >= 0 && c->pset[set].stages) (void)hipEventRecord(c->pset[set].ev[ev], ev <= 4 ? c->stream : c->stream_tail);
 }
 
 // fold a finished event set into ks_profile
@@ -1829,6 +1837,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   }
 
   hipStream_t st = c->stream;
+  if (S.tail_recorded && c->stream_tail != c->stream) HIPCHK(c, hipStreamWaitEvent(st, S.tail_done, 0));
   S.n = n;
   S.prof_set = -1;
   if (c->profiling) {
@@ -1909,7 +1918,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
 int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
   if (!S.pending) return KS_OK;
   S.pending = false;
-  hipStream_t st = c->stream;
+  hipStream_t st = c->stream_tail;  // the host wait below orders the tail after the slot's front
   const FrameParams& F = S.F;
   HIPCHK(c, hipEventSynchronize(S.ready));  // the frame's only host wait
   const Counters cnt = S.counters();
@@ -1961,7 +1970,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
     // skips the sequence bits (2 fewer passes); the order inside a voxel is then the stable
     // emission order.
     const unsigned begin_bit = F.early_out ? F.seq_bits : 0u;
-    if ((rc = sort_keys(c, S.d_pairs, c->d_pairs2, n_pairs, std::min(64u, end_bit), &sp, begin_bit))) return rc;
+    if ((rc = sort_keys(c, S.d_pairs, c->d_pairs2, n_pairs, std::min(64u, end_bit), &sp, begin_bit, /*tail=*/true))) return rc;
     stage_mark(c, set, 7);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
@@ -1989,6 +1998,8 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
     stage_mark(c, set, 8);
   }
   finish_prof(n_pairs);
+  HIPCHK(c, hipEventRecord(S.tail_done, st));
+  S.tail_recorded = true;
   HIPCHK(c, hipGetLastError());
   c->last_stats = ks_frame_stats{};
   c->last_stats.n_points = S.n;
@@ -2012,6 +2023,14 @@ int flush_pending(ks_ctx* c, ks_frame_stats* stats) {
     }
   }
   return KS_OK;
+}
+
+// complete every outstanding frame and drain both streams
+int quiesce(ks_ctx* c) {
+  const int rc = flush_pending(c, nullptr);
+  if (c->stream_tail && c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return rc;
 }
 
 int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba, const uint8_t* d_labels,
@@ -2039,16 +2058,16 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
     }
   }
   if (n == 0) {
-    if ((rc = flush_pending(c, nullptr))) return rc;
+    if ((rc = quiesce(c))) return rc;
     if (stats) stats->n_points = 0;
     return KS_OK;
   }
   if (n > c->cap_points) {  // growing frees buffers a pending tail still needs
-    if ((rc = flush_pending(c, nullptr))) return rc;
+    if ((rc = quiesce(c))) return rc;
     if ((rc = ensure_points(c, n))) return rc;
   }
   if (!pipelined) {
-    if ((rc = flush_pending(c, nullptr))) return rc;
+    if ((rc = quiesce(c))) return rc;
     FrameSlot& S = c->slot[0];
     if ((rc = frame_front(c, S, Tq, d_xyz, d_rgba, d_labels, n, freespace))) return rc;
     return frame_tail(c, S, stats);
@@ -2068,7 +2087,7 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
 }
 
 int collect_block_indices(ks_ctx* c, bool only_updated, bool reset, std::vector<int32_t>* out) {
-  if (int rc = flush_pending(c, nullptr)) return rc;
+  if (int rc = quiesce(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const uint32_t nt = c->tiles_initialised;
   std::vector<uint64_t> keys(nt);
@@ -2100,7 +2119,7 @@ int collect_block_indices(ks_ctx* c, bool only_updated, bool reset, std::vector<
 // find-or-insert n tile keys (device array) and initialise the newly allocated tiles
 static int insert_tiles(ks_ctx* c, const uint64_t* d_keys, size_t n) {
   int rc;
-  if ((rc = flush_pending(c, nullptr))) return rc;
+  if ((rc = quiesce(c))) return rc;
   FrameSlot& S = c->slot[0];
   HIPCHK(c, hipMemsetAsync(S.d_counters, 0, sizeof(Counters), c->stream));
   hipLaunchKernelGGL(k_insert_tiles, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->table, S.d_counters,
@@ -2203,6 +2222,8 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   } while (0)
   CRCHK(hipSetDevice(cfg->device_id));
   CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (cfg->pipeline_frames) CRCHK(hipStreamCreateWithFlags(&c->stream_tail, hipStreamNonBlocking));
+  else c->stream_tail = c->stream;
   for (auto& P : c->pset) {
     for (auto& e : P.ev) CRCHK(hipEventCreate(&e));
     CRCHK(hipEventCreate(&P.k0));
@@ -2239,6 +2260,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     CRCHK(hipHostMalloc((void**)&S.h_snap, 64));
     std::memset(S.h_snap, 0, 64);
     CRCHK(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming));
   }
 #undef CRCHK
   if (ensure_points(c, cfg->max_points) != KS_OK) {
@@ -2252,6 +2274,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
 
 void ks_destroy(ks_ctx* c) {
   if (!c) return;
+  if (c->stream_tail && c->stream_tail != c->stream) (void)hipStreamSynchronize(c->stream_tail);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->slot[0].d_rays, c->slot[1].d_rays, c->slot[0].d_deltas, c->slot[1].d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
@@ -2261,9 +2284,11 @@ void ks_destroy(ks_ctx* c) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   ksrs::release(c->sort_ws);
+  ksrs::release(c->sort_ws_tail);
   for (auto& S : c->slot) {
     if (S.h_snap) (void)hipHostFree(S.h_snap);
     if (S.ready) (void)hipEventDestroy(S.ready);
+    if (S.tail_done) (void)hipEventDestroy(S.tail_done);
   }
   for (auto& P : c->pset) {
     for (auto& e : P.ev)
@@ -2271,6 +2296,7 @@ void ks_destroy(ks_ctx* c) {
     if (P.k0) (void)hipEventDestroy(P.k0);
     if (P.k1) (void)hipEventDestroy(P.k1);
   }
+  if (c->stream_tail && c->stream_tail != c->stream) (void)hipStreamDestroy(c->stream_tail);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -2434,7 +2460,7 @@ int ks_get_updated_block_indices(ks_ctx* c, int32_t* out, size_t cap, size_t* n,
 int ks_download_blocks(ks_ctx* c, const int32_t* idx, size_t n, void* tsdf_out, void* sem_out) {
   if (!c || (n && !idx)) return KS_ERR_INVALID_ARG;
   if (n == 0) return KS_OK;
-  if (int rc = flush_pending(c, nullptr)) return rc;
+  if (int rc = quiesce(c)) return rc;
   const int vps = c->cfg.voxels_per_side;
   const size_t nv = (size_t)vps * vps * vps;
   // chunk so staging buffers stay bounded (<= ~256 MiB of semantic voxels)
@@ -2555,7 +2581,7 @@ int ks_debug_radix_sort(ks_ctx* c, void* keys, uint32_t* vals, size_t n, int key
 
 int ks_get_tile_keys(ks_ctx* c, uint64_t* out, size_t cap, size_t* n) {
   if (!c || !n) return KS_ERR_INVALID_ARG;
-  if (int rc = flush_pending(c, nullptr)) return rc;
+  if (int rc = quiesce(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   *n = c->tiles_initialised;
   const size_t m = std::min<size_t>(cap, *n);
@@ -2566,7 +2592,7 @@ int ks_get_tile_keys(ks_ctx* c, uint64_t* out, size_t cap, size_t* n) {
 int ks_export_tiles_device(ks_ctx* c, const uint32_t* slots, size_t n, void* d_payload) {
   if (!c || (n && (!slots || !d_payload))) return KS_ERR_INVALID_ARG;
   if (n == 0) return KS_OK;
-  if (int rc = flush_pending(c, nullptr)) return rc;
+  if (int rc = quiesce(c)) return rc;
   for (size_t i = 0; i < n; ++i)
     if (slots[i] >= c->tiles_initialised) return KS_ERR_INVALID_ARG;
   uint32_t* d_slots = nullptr;
@@ -2613,6 +2639,7 @@ int ks_merge_tiles_device(ks_ctx* c, const uint64_t* keys, size_t n, const void*
 int ks_clear(ks_ctx* c) {
   if (!c) return KS_ERR_INVALID_ARG;
   for (auto& S : c->slot) S.pending = false;  // a frame that was never applied is dropped with the map
+  if (c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemset(c->table.ent, 0xff, ((size_t)c->table.mask + 1) * sizeof(TileEntry)));
   HIPCHK(c, hipMemset(c->pool.updated, 0, c->cfg.max_tiles));
@@ -2634,7 +2661,7 @@ int ks_flush(ks_ctx* c, ks_frame_stats* stats) {
 
 int ks_synchronize(ks_ctx* c) {
   if (!c) return KS_ERR_INVALID_ARG;
-  if (int rc = flush_pending(c, nullptr)) return rc;
+  if (int rc = quiesce(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return KS_OK;
 }
@@ -2649,7 +2676,7 @@ int ks_profile_enable(ks_ctx* c, int level) {
 
 int ks_profile_get(ks_ctx* c, ks_profile* out, int reset) {
   if (!c || !out) return KS_ERR_INVALID_ARG;
-  if (int rc = flush_pending(c, nullptr)) return rc;
+  if (int rc = quiesce(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   for (int i = 0; i < kProfSets; ++i) resolve_prof(c, i);
   *out = c->prof;
