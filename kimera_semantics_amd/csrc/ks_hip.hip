@@ -860,6 +860,14 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
   if (wcount) flush();
 }
 
+// End of stage B: the frame's counters and the persistent tile count go to pinned host memory.
+__global__ void __launch_bounds__(64) k_publish(const Counters* __restrict__ C, const uint32_t* __restrict__ n_tiles,
+                                                uint32_t* __restrict__ host_snap) {
+  static_assert(sizeof(Counters) == 32, "snapshot layout");
+  if (threadIdx.x < 8) host_snap[threadIdx.x] = ((const uint32_t*)C)[threadIdx.x];
+  if (threadIdx.x == 8) host_snap[8] = *n_tiles;
+}
+
 __global__ void __launch_bounds__(512) k_init_tiles(Pool P, uint32_t first_slot) {
   const size_t slot = (size_t)first_slot + blockIdx.x;
   uint4* tile = P.vox + slot * (size_t)kTileVoxels * 8;
@@ -1541,13 +1549,22 @@ std::string g_create_error;
 // A frame runs in two halves on the one stream:
 //   front: points -> sort -> dedup / bundles -> march(+emit) -> 40-byte counter snapshot to the host
 //   tail : init new tiles -> sort pairs -> apply           (sized by the snapshot)
-// Everything the tail reads from the front lives in a FrameSlot.  With ks_config.pipeline_frames
-// the tail of frame i is enqueued by the call for frame i+1, after that frame's front and on a
-// second stream: the host's wait for the snapshot never idles the GPU, and the tail of frame i
-// (latency-bound sort passes, voxel updates) runs CONCURRENTLY with the front of frame i+1
-// (atomics-bound ray march), which touches no voxel data.  Two slots alternate; a front waits for
-// the tail that last used its slot.
-constexpr int kSlots = 2;
+// Everything a later stage reads from an earlier one lives in a FrameSlot.  With
+// ks_config.pipeline_frames the three stages of a frame run on three streams,
+//   A  points -> sort -> dedup / bundles          (stream)
+//   B  ray march + snapshot                        (stream_march, after A of the same frame)
+//   T  init tiles -> sort pairs -> apply           (stream_tail, enqueued by the NEXT call)
+// so that A(i+1), B(i) and T(i-1) execute concurrently: the march is bound by device-scope atomic
+// throughput, the sorts by dependent-launch latency, the voxel update by memory latency, and
+// neither A nor B touches voxel data.  The host's one wait per frame (for the snapshot that sizes
+// T) never idles the GPU.  Three slots rotate; stage A of a frame waits for the tail that last
+// used its slot.
+constexpr int kSlots = 3;
+struct HostSnap {
+  Counters c;
+  uint32_t n_tiles;
+  uint32_t pad[7];
+};
 struct FrameSlot {
   int index = 0;
   RayDesc* d_rays = nullptr;
@@ -1555,7 +1572,9 @@ struct FrameSlot {
   uint64_t* d_pairs = nullptr;      // unsorted (voxel, ray) pairs written by k_march
   size_t cap_pairs_in = 0;
   Counters* d_counters = nullptr;   // inside ks_ctx::d_state
-  uint8_t* h_snap = nullptr;        // pinned, 64 B: device bytes [32 * index, 32 * index + 64)
+  uint32_t* d_ray_list = nullptr;   // rays to march (written by stage A, read by B)
+  HostSnap* h_snap = nullptr;       // pinned + device-visible: written by k_publish at the end of B
+  hipEvent_t a_done = nullptr;      // stage A complete
   hipEvent_t ready = nullptr;       // snapshot has landed
   hipEvent_t tail_done = nullptr;   // the tail has consumed this slot's buffers
   bool tail_recorded = false;
@@ -1563,14 +1582,14 @@ struct FrameSlot {
   size_t n = 0;
   int prof_set = -1;
   bool pending = false;
-  const Counters& counters() const { return *(const Counters*)(h_snap + (index == 0 ? 0 : 32)); }
-  uint32_t n_tiles() const { return *(const uint32_t*)(h_snap + (index == 0 ? 32 : 0)); }
+  const Counters& counters() const { return h_snap->c; }
+  uint32_t n_tiles() const { return h_snap->n_tiles; }
 };
 
 // HIP-event sets for ks_profile: recorded in stream order, resolved lazily (before reuse or in
 // ks_profile_get) so that profiling never adds a host wait to a frame.
 constexpr int kProfSets = 4;
-constexpr int kStageEvents = KS_STAGE_COUNT + 2;  // 0..4 front (4 = snapshot done), 5 = tail start, 6..9
+constexpr int kStageEvents = KS_STAGE_COUNT + 3;  // 0..3 stage A | 4,5 march begin/end | 6 tail begin, 7..10
 struct ProfSet {
   hipEvent_t ev[kStageEvents]{};
   hipEvent_t k0 = nullptr, k1 = nullptr;  // begin/end of the k_apply dispatch itself
@@ -1581,8 +1600,9 @@ struct ProfSet {
 struct ks_ctx {
   ks_config cfg{};
   std::string err;
-  hipStream_t stream = nullptr;       // front halves (and everything else)
-  hipStream_t stream_tail = nullptr;  // tail halves; == stream unless ks_config.pipeline_frames
+  hipStream_t stream = nullptr;        // stage A (and everything else)
+  hipStream_t stream_march = nullptr;  // stage B; == stream unless pipelined
+  hipStream_t stream_tail = nullptr;   // stage T; == stream unless pipelined
   float voxel_size_inv = 0.f, log_match = 0.f, log_non_match = 0.f;
   int vps_shift = 1;  // log2(vps / 8)
 
@@ -1613,13 +1633,10 @@ struct ks_ctx {
   uint32_t* d_order = nullptr;
   uint32_t* d_inv_order = nullptr;
   uint32_t *d_okeys = nullptr, *d_okeys2 = nullptr, *d_ovals = nullptr;
-  uint32_t* d_ray_list = nullptr;
   size_t cap_pairs = 0;
   uint64_t* d_pairs2 = nullptr;
   ksrs::Workspace sort_ws, sort_ws_tail;
-  // Device words [Counters slot0 (32 B)][n_tiles + pad (32 B)][Counters slot1 (32 B)]: the end-of-
-  // front snapshot of either slot (its counters + the persistent tile count) is ONE 64-byte D2H
-  // copy, and each slot's counters are a 32-byte aligned memset.
+  // Device words: Counters of slot k at 64 * k, the persistent tile count at 64 * kSlots.
   uint8_t* d_state = nullptr;
   FrameSlot slot[kSlots];
   uint64_t frame_no = 0;
@@ -1669,6 +1686,7 @@ int ensure_points(ks_ctx* c, size_t n) {
   if ((rc = dev_alloc(c, &c->d_labels, cap))) return rc;
   for (int i = 0; i < (c->cfg.pipeline_frames ? kSlots : 1); ++i) {
     if ((rc = dev_alloc(c, &c->slot[i].d_rays, cap))) return rc;
+    if ((rc = dev_alloc(c, &c->slot[i].d_ray_list, cap))) return rc;
     if (c->cfg.method == KS_METHOD_MERGED && (rc = dev_alloc(c, &c->slot[i].d_deltas, cap * kNumLabels))) return rc;
   }
   if ((rc = dev_alloc(c, &c->d_hash, cap))) return rc;
@@ -1683,7 +1701,6 @@ int ensure_points(ks_ctx* c, size_t n) {
   if ((rc = dev_alloc(c, &c->d_okeys, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_okeys2, cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_ovals, cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_ray_list, cap))) return rc;
   if (c->cfg.method == KS_METHOD_MERGED) {
     if ((rc = dev_alloc(c, &c->d_gpw, cap))) return rc;
     if ((rc = dev_alloc(c, &c->d_glc, cap))) return rc;
@@ -1736,6 +1753,7 @@ inline unsigned bits_for(uint64_t n) {  // number of bits needed to represent va
 // ApproxHashSet::resetApproxSet
 int reset_set(ks_ctx* c, uint64_t* d_set, uint64_t* offset) {
   if (++(*offset) >= kFullResetThreshold) {
+    if (c->stream_march != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_march));  // the march reads the observed set
     HIPCHK(c, hipMemsetAsync(d_set, 0, sizeof(uint64_t) << kSetBits, c->stream));
     *offset = 0;
     const uint64_t poison = ~0ull;
@@ -1746,8 +1764,8 @@ int reset_set(ks_ctx* c, uint64_t* d_set, uint64_t* offset) {
 }
 
 inline void stage_mark(ks_ctx* c, int set, int ev) {
-  // events 0..4 belong to the front half, 5.. to the tail half
-  if (set >= 0 && c->pset[set].stages) (void)hipEventRecord(c->pset[set].ev[ev], ev <= 4 ? c->stream : c->stream_tail);
+  if (set >= 0 && c->pset[set].stages)
+    (void)hipEventRecord(c->pset[set].ev[ev], ev <= 3 ? c->stream : ev <= 5 ? c->stream_march : c->stream_tail);
 }
 
 // fold a finished event set into ks_profile
@@ -1758,7 +1776,7 @@ void resolve_prof(ks_ctx* c, int set) {
   if (P.stages) {
     for (int s = 0; s < KS_STAGE_COUNT; ++s) {
       float ms = 0.f;
-      const int a = s < 4 ? s : s + 1;
+      const int a = s < 3 ? s : s == 3 ? 4 : s + 2;
       if (hipEventElapsedTime(&ms, P.ev[a], P.ev[a + 1]) == hipSuccess) {
         c->prof.ms[s] += ms;
         c->prof.launches[s] += 1;
@@ -1877,7 +1895,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
     uint32_t *sk = nullptr, *sv = nullptr;
     if ((rc = sort_pairs(c, c->d_skeys32, c->d_skeys32b, c->d_pvals, c->d_pvals2, n, kSetBits + 1, &sk, &sv))) return rc;
     stage_mark(c, S.prof_set, 2);
-    hipLaunchKernelGGL(k_dedup, dim3(nb1k), dim3(1024), 0, st, F, sk, sv, c->d_hash, c->d_start_set, c->d_ray_list,
+    hipLaunchKernelGGL(k_dedup, dim3(nb1k), dim3(1024), 0, st, F, sk, sv, c->d_hash, c->d_start_set, S.d_ray_list,
                        S.d_counters);
     hipLaunchKernelGGL(k_dedup_commit, dim3(nb1k), dim3(1024), 0, st, F, sk, sv, c->d_hash, c->d_start_set,
                        S.d_counters);
@@ -1893,9 +1911,9 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
                        order_ptr, sk, sv, c->d_gpw, c->d_glc);
     uint64_t* ray_keys = cfg.enable_anti_grazing ? c->d_ray_keys : nullptr;
     hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas,
-                       c->d_ray_list, c->d_blong, ray_keys, S.d_counters);
+                       S.d_ray_list, c->d_blong, ray_keys, S.d_counters);
     hipLaunchKernelGGL(k_bundles_long, dim3((uint32_t)std::min<size_t>(n / kLongRun + 1, 2048)), dim3(64), 0, st, F,
-                       sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas, c->d_ray_list, c->d_blong, ray_keys,
+                       sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas, S.d_ray_list, c->d_blong, ray_keys,
                        S.d_counters);
     if (cfg.enable_anti_grazing) {
       F.grazing_keys = sk;
@@ -1903,13 +1921,22 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
     }
   }
   stage_mark(c, S.prof_set, 3);
-  // march (+emit) over an upper bound of rays (<= n); the live ray count stays on the device
-  hipLaunchKernelGGL(k_march, dim3(nb), dim3(256), 0, st, F, c->d_ray_list, S.d_rays, c->table, c->pool,
+  // ---- stage B: march (+emit) over an upper bound of rays (<= n); the live ray count stays on
+  // the device.  Anti-grazing reads stage A's sorted point keys, which the next frame's stage A
+  // overwrites: with it the march stays on stage A's stream.
+  hipStream_t sm = cfg.enable_anti_grazing ? c->stream : c->stream_march;
+  if (sm != st) {
+    HIPCHK(c, hipEventRecord(S.a_done, st));
+    HIPCHK(c, hipStreamWaitEvent(sm, S.a_done, 0));
+  }
+  if (S.prof_set >= 0 && c->pset[S.prof_set].stages) (void)hipEventRecord(c->pset[S.prof_set].ev[4], sm);
+  hipLaunchKernelGGL(k_march, dim3(nb), dim3(256), 0, sm, F, S.d_ray_list, S.d_rays, c->table, c->pool,
                      c->d_observed_set, S.d_pairs, (unsigned long long)S.cap_pairs_in, S.d_counters);
   // the frame's only device->host traffic: pair / ray / tile counts and error flags
-  HIPCHK(c, hipMemcpyAsync(S.h_snap, c->d_state + 32 * S.index, 64, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipEventRecord(S.ready, st));
-  stage_mark(c, S.prof_set, 4);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sm, (const Counters*)S.d_counters, (const uint32_t*)c->table.n_tiles,
+                     (uint32_t*)S.h_snap);
+  HIPCHK(c, hipEventRecord(S.ready, sm));
+  if (S.prof_set >= 0 && c->pset[S.prof_set].stages) (void)hipEventRecord(c->pset[S.prof_set].ev[5], sm);
   S.pending = true;
   return KS_OK;
 }
@@ -1925,7 +1952,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
   const uint32_t new_tiles = std::min(S.n_tiles(), c->cfg.max_tiles);
   const uint32_t tiles_before = c->tiles_initialised;
   const int set = S.prof_set;
-  stage_mark(c, set, 5);
+  stage_mark(c, set, 6);
   // tiles allocated by the front exist in the table whatever happens next: make them valid
   if (new_tiles > c->tiles_initialised) {
     hipLaunchKernelGGL(k_init_tiles, dim3(new_tiles - c->tiles_initialised), dim3(512), 0, st, c->pool,
@@ -1940,13 +1967,13 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
     P.complete = true;
   };
   if (cnt.err & kErrLabel) {
-    for (int e = 6; e < kStageEvents - 1; ++e) stage_mark(c, set, e);
+    for (int e = 7; e < kStageEvents - 1; ++e) stage_mark(c, set, e);
     finish_prof(0);
     c->err = "semantic label >= 21 (CHECK_LT in the reference)";
     return KS_ERR_LABEL_RANGE;
   }
   if (cnt.err) {
-    for (int e = 6; e < kStageEvents - 1; ++e) stage_mark(c, set, e);
+    for (int e = 7; e < kStageEvents - 1; ++e) stage_mark(c, set, e);
     finish_prof(0);
     c->fatal = true;
     if (cnt.err & kErrPool) {
@@ -1960,7 +1987,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
   if (n_pairs > 0) {
     int rc;
     if ((rc = ensure_pairs_out(c, n_pairs))) return rc;
-    stage_mark(c, set, 6);
+    stage_mark(c, set, 7);
     const unsigned end_bit = F.seq_bits + 9 + bits_for(new_tiles);
     uint64_t* sp = nullptr;
     // Deterministic modes sort by (voxel, ray sequence): every voxel replays its updates in
@@ -1971,7 +1998,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
     // emission order.
     const unsigned begin_bit = F.early_out ? F.seq_bits : 0u;
     if ((rc = sort_keys(c, S.d_pairs, c->d_pairs2, n_pairs, std::min(64u, end_bit), &sp, begin_bit, /*tail=*/true))) return rc;
-    stage_mark(c, set, 7);
+    stage_mark(c, set, 8);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
     const bool time_apply = set >= 0 && c->pset[set].apply;
@@ -1983,7 +2010,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
   else                                                                                                               \
     hipLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table,     \
                        c->pool, c->d_label_lut, c->d_long_list, S.d_counters);                                        \
-  stage_mark(c, set, 8);                                                                                             \
+  stage_mark(c, set, 9);                                                                                             \
   hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(64), 0, st, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table,   \
                      c->pool, c->d_label_lut, c->d_long_list, S.d_counters)
     switch (c->cfg.color_mode) {
@@ -1993,9 +2020,9 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
     }
 #undef KS_LAUNCH_APPLY
   } else {
-    stage_mark(c, set, 6);
     stage_mark(c, set, 7);
     stage_mark(c, set, 8);
+    stage_mark(c, set, 9);
   }
   finish_prof(n_pairs);
   HIPCHK(c, hipEventRecord(S.tail_done, st));
@@ -2028,7 +2055,8 @@ int flush_pending(ks_ctx* c, ks_frame_stats* stats) {
 // complete every outstanding frame and drain both streams
 int quiesce(ks_ctx* c) {
   const int rc = flush_pending(c, nullptr);
-  if (c->stream_tail && c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
+  if (c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
+  if (c->stream_march != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_march));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return rc;
 }
@@ -2075,7 +2103,7 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
   // pipelined: front of this frame first, then the tail of the previous one; the statistics
   // returned are those of the frame whose tail ran here (the previous frame)
   FrameSlot& S = c->slot[c->frame_no % kSlots];
-  FrameSlot& prev = c->slot[(c->frame_no + 1) % kSlots];
+  FrameSlot& prev = c->slot[(c->frame_no + kSlots - 1) % kSlots];
   if (S.pending && (rc = frame_tail(c, S, nullptr))) return rc;  // cannot happen: slots alternate
   if ((rc = frame_front(c, S, Tq, d_xyz, d_rgba, d_labels, n, freespace))) return rc;
   if (prev.pending) return frame_tail(c, prev, stats);
@@ -2124,7 +2152,8 @@ static int insert_tiles(ks_ctx* c, const uint64_t* d_keys, size_t n) {
   HIPCHK(c, hipMemsetAsync(S.d_counters, 0, sizeof(Counters), c->stream));
   hipLaunchKernelGGL(k_insert_tiles, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->table, S.d_counters,
                      d_keys, (uint32_t)n);
-  HIPCHK(c, hipMemcpyAsync(S.h_snap, c->d_state, 64, hipMemcpyDeviceToHost, c->stream));
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, (const Counters*)S.d_counters,
+                     (const uint32_t*)c->table.n_tiles, (uint32_t*)S.h_snap);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const uint32_t new_tiles = std::min(S.n_tiles(), c->cfg.max_tiles);
   if (new_tiles > c->tiles_initialised) {
@@ -2222,8 +2251,12 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   } while (0)
   CRCHK(hipSetDevice(cfg->device_id));
   CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  if (cfg->pipeline_frames) CRCHK(hipStreamCreateWithFlags(&c->stream_tail, hipStreamNonBlocking));
-  else c->stream_tail = c->stream;
+  if (cfg->pipeline_frames) {
+    CRCHK(hipStreamCreateWithFlags(&c->stream_march, hipStreamNonBlocking));
+    CRCHK(hipStreamCreateWithFlags(&c->stream_tail, hipStreamNonBlocking));
+  } else {
+    c->stream_march = c->stream_tail = c->stream;
+  }
   for (auto& P : c->pset) {
     for (auto& e : P.ev) CRCHK(hipEventCreate(&e));
     CRCHK(hipEventCreate(&P.k0));
@@ -2250,15 +2283,16 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipMalloc((void**)&c->d_label_lut, 256 * sizeof(uint32_t)));
   CRCHK(hipMemcpy(c->d_label_lut, cfg->label_rgba, 1024, hipMemcpyHostToDevice));
   static_assert(sizeof(Counters) == 32, "snapshot layout");
-  CRCHK(hipMalloc((void**)&c->d_state, 96));
-  CRCHK(hipMemset(c->d_state, 0, 96));
-  c->table.n_tiles = (uint32_t*)(c->d_state + 32);
+  CRCHK(hipMalloc((void**)&c->d_state, 64 * (kSlots + 1)));
+  CRCHK(hipMemset(c->d_state, 0, 64 * (kSlots + 1)));
+  c->table.n_tiles = (uint32_t*)(c->d_state + 64 * kSlots);
   for (int i = 0; i < kSlots; ++i) {
     FrameSlot& S = c->slot[i];
     S.index = i;
     S.d_counters = (Counters*)(c->d_state + 64 * i);
-    CRCHK(hipHostMalloc((void**)&S.h_snap, 64));
-    std::memset(S.h_snap, 0, 64);
+    CRCHK(hipHostMalloc((void**)&S.h_snap, sizeof(HostSnap)));
+    std::memset(S.h_snap, 0, sizeof(HostSnap));
+    CRCHK(hipEventCreateWithFlags(&S.a_done, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming));
   }
@@ -2275,11 +2309,12 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
 void ks_destroy(ks_ctx* c) {
   if (!c) return;
   if (c->stream_tail && c->stream_tail != c->stream) (void)hipStreamSynchronize(c->stream_tail);
+  if (c->stream_march && c->stream_march != c->stream) (void)hipStreamSynchronize(c->stream_march);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
-                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->slot[0].d_rays, c->slot[1].d_rays, c->slot[0].d_deltas, c->slot[1].d_deltas, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
+                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->slot[0].d_rays, c->slot[1].d_rays, c->slot[2].d_rays, c->slot[0].d_deltas, c->slot[1].d_deltas, c->slot[2].d_deltas, c->slot[0].d_ray_list, c->slot[1].d_ray_list, c->slot[2].d_ray_list, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
-                  c->d_ray_list, c->slot[0].d_pairs, c->slot[1].d_pairs, c->d_pairs2, c->d_state,
+                  c->slot[0].d_pairs, c->slot[1].d_pairs, c->slot[2].d_pairs, c->d_pairs2, c->d_state,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -2289,6 +2324,7 @@ void ks_destroy(ks_ctx* c) {
     if (S.h_snap) (void)hipHostFree(S.h_snap);
     if (S.ready) (void)hipEventDestroy(S.ready);
     if (S.tail_done) (void)hipEventDestroy(S.tail_done);
+    if (S.a_done) (void)hipEventDestroy(S.a_done);
   }
   for (auto& P : c->pset) {
     for (auto& e : P.ev)
@@ -2297,6 +2333,7 @@ void ks_destroy(ks_ctx* c) {
     if (P.k1) (void)hipEventDestroy(P.k1);
   }
   if (c->stream_tail && c->stream_tail != c->stream) (void)hipStreamDestroy(c->stream_tail);
+  if (c->stream_march && c->stream_march != c->stream) (void)hipStreamDestroy(c->stream_march);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -2640,10 +2677,11 @@ int ks_clear(ks_ctx* c) {
   if (!c) return KS_ERR_INVALID_ARG;
   for (auto& S : c->slot) S.pending = false;  // a frame that was never applied is dropped with the map
   if (c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
+  if (c->stream_march != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_march));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemset(c->table.ent, 0xff, ((size_t)c->table.mask + 1) * sizeof(TileEntry)));
   HIPCHK(c, hipMemset(c->pool.updated, 0, c->cfg.max_tiles));
-  HIPCHK(c, hipMemset(c->d_state, 0, 96));
+  HIPCHK(c, hipMemset(c->d_state, 0, 64 * (kSlots + 1)));
   c->tiles_initialised = 0;
   c->fatal = false;
   return KS_OK;
