@@ -116,9 +116,12 @@ def main():
                            pipeline_frames=0 if args.no_pipeline else 1, **common_cfg(args.method))
     integ = B.HipIntegrator(cfg)
 
-    def step(i):
+    def step_on(h, i):
         x, c, l = d_frames[i]
-        return integ.integrate_device(frames[i].T_G_C, x.data_ptr(), c.data_ptr(), l.data_ptr(), x.shape[0])
+        return h.integrate_device(frames[i].T_G_C, x.data_ptr(), c.data_ptr(), l.data_ptr(), x.shape[0])
+
+    def step(i):
+        return step_on(integ, i)
 
     for i in range(W):
         step(i)
@@ -160,6 +163,20 @@ def main():
     integ.flush()
     stage_prof = integ.profile()
     integ.profile_enable(0)
+    # k_apply ALONE on the GPU (no other stage overlapping it): a second, unpipelined context over
+    # the same frames; reported next to the timed-region figure as roofline.isolated
+    iso = None
+    if rank == 0 and not args.no_pipeline:
+        cfg0 = B.default_config(device_id=local_rank, max_tiles=1 << 13, max_points=args.width * args.height,
+                                pipeline_frames=0, **common_cfg(args.method))
+        solo = B.HipIntegrator(cfg0)
+        for i in range(min(W + K, 30)):
+            if i == min(W + K, 30) - 10:
+                solo.synchronize()
+                solo.profile_enable(1)
+            step_on(solo, i)
+        iso = solo.profile()
+        solo.close()
 
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -189,6 +206,14 @@ def main():
                 traffic = None
         stage_ms = {k: round(v / max(1, stage_prof["frames"]), 4) for k, v in stage_prof["ms"].items()}
         whole_frame_alg = (BYTES_PER_UPDATE * updates + BYTES_PER_POINT * points) / K
+        isolated = None
+        if iso and iso["apply_kernel_launches"]:
+            i_ms = iso["apply_kernel_ms"] / iso["apply_kernel_launches"]
+            i_bytes = BYTES_PER_UPDATE * iso["apply_kernel_updates"] / iso["apply_kernel_launches"]
+            i_gbs = i_bytes / (i_ms * 1e-3) / 1e9
+            isolated = {"achieved": round(i_gbs, 2), "frac": round(i_gbs / HBM_PEAK_GBS, 5),
+                        "avg_launch_ms": round(i_ms, 5), "launches": iso["apply_kernel_launches"],
+                        "note": "same kernel with nothing else on the GPU (unpipelined context, untimed pass)"}
         out = {
             "metric": "Mvoxel-updates/s + frames/s, 640x480 @5cm voxels",
             "value": round(updates_all / dt / 1e6, 3),
@@ -209,8 +234,11 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(apply_ms, 5),
                          "timed_launches": prof["apply_kernel_launches"],
+                         "overlapped": not args.no_pipeline, "isolated": isolated,
                          "whole_frame_frac": round(whole_frame_alg / (dt / K) / 1e9 / HBM_PEAK_GBS, 5)},
             "stage_ms_per_frame": stage_ms,
+            "host_ms_per_frame": {"in_call": round(prof["host_ms"] / max(1, prof["frames"]), 4),
+                                  "of_which_waiting_for_snapshot": round(prof["host_wait_ms"] / max(1, prof["frames"]), 4)},
         }
         if reduce_stats is not None:
             out["reduce"] = reduce_stats

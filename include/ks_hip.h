@@ -115,6 +115,8 @@ typedef struct ks_profile {
   double apply_kernel_ms;          /* k_apply dispatch begin->end (hipExtLaunchKernel events), summed */
   uint64_t apply_kernel_launches;  /* ... over this many timed launches */
   uint64_t apply_kernel_updates;   /* ... which performed this many voxel updates */
+  double host_ms;                  /* wall time spent inside the integrate calls (enqueue + wait) */
+  double host_wait_ms;             /* ... of which blocked on the per-frame counter snapshot */
 } ks_profile;
 
 typedef struct ks_ctx ks_ctx;

@@ -64,7 +64,8 @@ class KsFrameStats(C.Structure):
 class KsProfile(C.Structure):
     _fields_ = [("ms", C.c_double * 8), ("launches", C.c_uint64 * 8), ("frames", C.c_uint64),
                 ("updates", C.c_uint64), ("points", C.c_uint64), ("apply_kernel_ms", C.c_double),
-                ("apply_kernel_launches", C.c_uint64), ("apply_kernel_updates", C.c_uint64)]
+                ("apply_kernel_launches", C.c_uint64), ("apply_kernel_updates", C.c_uint64),
+                ("host_ms", C.c_double), ("host_wait_ms", C.c_double)]
 
 
 def build(force: bool = False) -> str:
@@ -321,4 +322,4 @@ class HipIntegrator:
         return {"ms": {STAGES[i]: p.ms[i] for i in range(8)}, "launches": {STAGES[i]: p.launches[i] for i in range(8)},
                 "frames": p.frames, "updates": p.updates, "points": p.points,
                 "apply_kernel_ms": p.apply_kernel_ms, "apply_kernel_launches": p.apply_kernel_launches,
-                "apply_kernel_updates": p.apply_kernel_updates}
+                "apply_kernel_updates": p.apply_kernel_updates, "host_ms": p.host_ms, "host_wait_ms": p.host_wait_ms}

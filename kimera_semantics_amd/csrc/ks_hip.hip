@@ -21,6 +21,7 @@
 //   dist f32[512] | weight f32[512] | color u32[512] | label u8[512] | priors f32[21][512]
 // addressed through an open-addressing hash table keyed by the packed tile index.
 
+#include <chrono>
 #include <cstring>
 #include <string.h>
 
@@ -860,11 +861,16 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
   if (wcount) flush();
 }
 
-// End of stage B: the frame's counters and the persistent tile count go to pinned host memory.
-__global__ void __launch_bounds__(64) k_publish(const Counters* __restrict__ C, const uint32_t* __restrict__ n_tiles,
+// End of stage B: the frame's counters and the persistent tile count go to pinned host memory,
+// and the counters are cleared for the slot's next frame (the tail only uses n_long, which it
+// expects to be zero): no memset launch per frame.
+__global__ void __launch_bounds__(64) k_publish(Counters* __restrict__ C, const uint32_t* __restrict__ n_tiles,
                                                 uint32_t* __restrict__ host_snap) {
   static_assert(sizeof(Counters) == 32, "snapshot layout");
-  if (threadIdx.x < 8) host_snap[threadIdx.x] = ((const uint32_t*)C)[threadIdx.x];
+  if (threadIdx.x < 8) {
+    host_snap[threadIdx.x] = ((const uint32_t*)C)[threadIdx.x];
+    ((uint32_t*)C)[threadIdx.x] = 0u;
+  }
   if (threadIdx.x == 8) host_snap[8] = *n_tiles;
 }
 
@@ -1871,7 +1877,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
     S.prof_set = set;
   }
   ++c->frame_no;
-  HIPCHK(c, hipMemsetAsync(S.d_counters, 0, sizeof(Counters), st));
+  // S.d_counters are zero: cleared at create time / by k_publish of the slot's previous frame
 
   const uint32_t nb = (uint32_t)((n + 255) / 256);
   const uint32_t nb1k = (uint32_t)((n + 1023) / 1024);
@@ -1933,7 +1939,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   hipLaunchKernelGGL(k_march, dim3(nb), dim3(256), 0, sm, F, S.d_ray_list, S.d_rays, c->table, c->pool,
                      c->d_observed_set, S.d_pairs, (unsigned long long)S.cap_pairs_in, S.d_counters);
   // the frame's only device->host traffic: pair / ray / tile counts and error flags
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sm, (const Counters*)S.d_counters, (const uint32_t*)c->table.n_tiles,
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sm, S.d_counters, (const uint32_t*)c->table.n_tiles,
                      (uint32_t*)S.h_snap);
   HIPCHK(c, hipEventRecord(S.ready, sm));
   if (S.prof_set >= 0 && c->pset[S.prof_set].stages) (void)hipEventRecord(c->pset[S.prof_set].ev[5], sm);
@@ -1947,7 +1953,11 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
   S.pending = false;
   hipStream_t st = c->stream_tail;  // the host wait below orders the tail after the slot's front
   const FrameParams& F = S.F;
-  HIPCHK(c, hipEventSynchronize(S.ready));  // the frame's only host wait
+  {
+    const auto w0 = std::chrono::steady_clock::now();
+    HIPCHK(c, hipEventSynchronize(S.ready));  // the frame's only host wait
+    if (c->profiling) c->prof.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+  }
   const Counters cnt = S.counters();
   const uint32_t new_tiles = std::min(S.n_tiles(), c->cfg.max_tiles);
   const uint32_t tiles_before = c->tiles_initialised;
@@ -2061,8 +2071,8 @@ int quiesce(ks_ctx* c) {
   return rc;
 }
 
-int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba, const uint8_t* d_labels,
-                     size_t n, int freespace, ks_frame_stats* stats) {
+int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba, const uint8_t* d_labels,
+                          size_t n, int freespace, ks_frame_stats* stats) {
   if (c->fatal) {
     c->err = "context is in a failed state (earlier pool/index error)";
     return KS_ERR_INVALID_ARG;
@@ -2114,6 +2124,15 @@ int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uin
   return KS_OK;
 }
 
+int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba, const uint8_t* d_labels,
+                     size_t n, int freespace, ks_frame_stats* stats) {
+  if (!c->profiling) return integrate_device_impl(c, Tq, d_xyz, d_rgba, d_labels, n, freespace, stats);
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = integrate_device_impl(c, Tq, d_xyz, d_rgba, d_labels, n, freespace, stats);
+  c->prof.host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return rc;
+}
+
 int collect_block_indices(ks_ctx* c, bool only_updated, bool reset, std::vector<int32_t>* out) {
   if (int rc = quiesce(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2152,8 +2171,8 @@ static int insert_tiles(ks_ctx* c, const uint64_t* d_keys, size_t n) {
   HIPCHK(c, hipMemsetAsync(S.d_counters, 0, sizeof(Counters), c->stream));
   hipLaunchKernelGGL(k_insert_tiles, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->table, S.d_counters,
                      d_keys, (uint32_t)n);
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, (const Counters*)S.d_counters,
-                     (const uint32_t*)c->table.n_tiles, (uint32_t*)S.h_snap);
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, S.d_counters, (const uint32_t*)c->table.n_tiles,
+                     (uint32_t*)S.h_snap);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const uint32_t new_tiles = std::min(S.n_tiles(), c->cfg.max_tiles);
   if (new_tiles > c->tiles_initialised) {

@@ -40,12 +40,17 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, unsigned l
 }
 
 // hist[pass][bin] += digit counts of a 2048-key slice, for every pass at once.
+// It also clears the workspace half the PREVIOUS sort used (zero_ptr, zero_words: a multiple of 4),
+// which becomes the next sort's workspace: no memset launch per sort.
 template <typename K, int RB>
 __global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uint32_t n, int passes, int begin_bit,
-                                                 uint32_t* __restrict__ hist) {
+                                                 uint32_t* __restrict__ hist, uint32_t* __restrict__ zero_ptr,
+                                                 uint32_t zero_words) {
   constexpr int kBins = 1 << RB;
   extern __shared__ uint32_t s_hist[];  // [passes][kBins]
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  for (uint32_t i = blockIdx.x * 256u + tid; i < zero_words / 4u; i += gridDim.x * 256u)
+    ((uint4*)zero_ptr)[i] = make_uint4(0u, 0u, 0u, 0u);
   for (int i = tid; i < passes * kBins; i += 256) s_hist[i] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * 2048u;
@@ -198,20 +203,29 @@ __global__ void __launch_bounds__(THREADS) k_rs_pass(const K* __restrict__ keys_
 
 // Host-side workspace + launcher.  Sorts bits [begin_bit, end_bit) of the keys; the result is
 // in (*keys_result, *vals_result), each pointing at one of the two ping-pong buffers.
+// Two halves used alternately: while a sort runs in one half its histogram kernel clears what the
+// previous sort left in the other, so a sort never needs a memset of its own.
 struct Workspace {
-  uint32_t* d_ws = nullptr;  // [kMaxPasses][kMaxBins] histograms | kMaxPasses tickets | status[passes][tiles][bins]
-  size_t words = 0;
+  uint32_t* d_ws = nullptr;  // per half: [kMaxPasses][kMaxBins] histograms | kMaxPasses tickets | status[passes][tiles][bins]
+  size_t words = 0;          // capacity of ONE half (multiple of 4)
+  int cur = 0;               // half used by the last sort
+  size_t dirty[2] = {0, 0};  // words that sort left non-zero in each half
 };
 constexpr size_t kHeadWords = (size_t)kMaxPasses * kMaxBins + kMaxPasses;
 
-inline hipError_t ensure(Workspace& w, size_t words) {
+inline hipError_t ensure(Workspace& w, size_t words, hipStream_t stream) {
   if (words <= w.words) return hipSuccess;
-  if (w.d_ws) (void)hipFree(w.d_ws);
+  if (w.d_ws) (void)hipFree(w.d_ws);  // waits for the device
   w.d_ws = nullptr;
-  const size_t cap = words + words / 4;
-  hipError_t e = hipMalloc((void**)&w.d_ws, cap * sizeof(uint32_t));
+  w.words = 0;
+  const size_t cap = ((words + words / 4) + 3) & ~(size_t)3;
+  hipError_t e = hipMalloc((void**)&w.d_ws, 2 * cap * sizeof(uint32_t));
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(w.d_ws, 0, 2 * cap * sizeof(uint32_t), stream);
   if (e != hipSuccess) return e;
   w.words = cap;
+  w.cur = 0;
+  w.dirty[0] = w.dirty[1] = 0;
   return hipSuccess;
 }
 
@@ -224,9 +238,10 @@ template <typename K, bool HAS_VALUES, int THREADS, int ITEMS, int RB>
 inline void launch_passes(Workspace& w, K*& kin, K*& kout, uint32_t*& vin, uint32_t*& vout, size_t n, int passes,
                           uint32_t tiles, unsigned begin_bit, hipStream_t stream) {
   constexpr int kBins = 1 << RB;
-  uint32_t* hist = w.d_ws;
-  uint32_t* tickets = w.d_ws + (size_t)kMaxPasses * kMaxBins;
-  uint32_t* status = w.d_ws + kHeadWords;
+  uint32_t* base = w.d_ws + (size_t)w.cur * w.words;
+  uint32_t* hist = base;
+  uint32_t* tickets = base + (size_t)kMaxPasses * kMaxBins;
+  uint32_t* status = base + kHeadWords;
   for (int p = 0; p < passes; ++p) {
     hipLaunchKernelGGL((k_rs_pass<K, HAS_VALUES, THREADS, ITEMS, RB>), dim3(tiles), dim3(THREADS), 0, stream, kin, kout,
                        vin, vout, (uint32_t)n, (int)begin_bit + p * RB, hist + (size_t)p * kMaxBins,
@@ -247,12 +262,16 @@ inline hipError_t sort_rb(Workspace& w, K* keys_a, K* keys_b, uint32_t* vals_a, 
   const int tile = (n <= (1u << 20)) ? 2048 : (n <= (1u << 24)) ? 8192 : 16384;
   const uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
   const size_t words = kHeadWords + (size_t)passes * tiles * kBins;
-  hipError_t e = ensure(w, words);
+  hipError_t e = ensure(w, words, stream);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(w.d_ws, 0, words * sizeof(uint32_t), stream);
-  if (e != hipSuccess) return e;
+  const int h = w.cur ^ 1;  // this sort's half is clean; the histogram kernel clears the other one
   hipLaunchKernelGGL((k_rs_hist<K, RB>), dim3((uint32_t)((n + 2047) / 2048)), dim3(256),
-                     (size_t)passes * kBins * sizeof(uint32_t), stream, keys_a, (uint32_t)n, passes, (int)begin_bit, w.d_ws);
+                     (size_t)passes * kBins * sizeof(uint32_t), stream, keys_a, (uint32_t)n, passes, (int)begin_bit,
+                     w.d_ws + (size_t)h * w.words, w.d_ws + (size_t)(h ^ 1) * w.words,
+                     (uint32_t)((w.dirty[h ^ 1] + 3) & ~(size_t)3));
+  w.dirty[h ^ 1] = 0;
+  w.dirty[h] = words;
+  w.cur = h;
   K* kin = keys_a;
   K* kout = keys_b;
   uint32_t* vin = vals_a;

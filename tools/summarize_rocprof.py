@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Turn a rocprofv3 `--kernel-trace --stats` output directory into the text summary kept under
+profiles/: per-kernel calls / total / average, plus (from the trace) how much of the wall-clock
+span had 1, 2, 3... kernels executing at once (the frame pipeline overlaps three streams).
+usage: summarize_rocprof.py <dir with run_kernel_stats.csv, run_kernel_trace.csv> "<command line>" > profiles/xxx.txt
+"""
+import csv
+import sys
+
+
+def main():
+    d, cmd = sys.argv[1], sys.argv[2]
+    rows = list(csv.DictReader(open(f"{d}/run_kernel_stats.csv")))
+    print(f"# rocprofv3 --kernel-trace --stats -- {cmd}  (MI355X)")
+    print(f"{'kernel':100s} {'calls':>8s} {'total_us':>14s} {'avg_us':>12s} {'pct':>8s}")
+    for r in rows:
+        print(f"{r['Name'][:100]:100s} {int(r['Calls']):8d} {int(r['TotalDurationNs']) / 1e3:14.1f} "
+              f"{float(r['AverageNs']) / 1e3:12.2f} {float(r['Percentage']):8.2f}")
+    tr = list(csv.DictReader(open(f"{d}/run_kernel_trace.csv")))
+    ev = []
+    for r in tr:
+        ev.append((int(r["Start_Timestamp"]), 1))
+        ev.append((int(r["End_Timestamp"]), -1))
+    ev.sort()
+    depth, last, hist = 0, ev[0][0], {}
+    for t, dlt in ev:
+        hist[depth] = hist.get(depth, 0) + (t - last)
+        last = t
+        depth += dlt
+    march = sorted(int(r["Start_Timestamp"]) for r in tr if "k_march" in r["Kernel_Name"])
+    # bench.py --steps 20 --warmup 3: the first 23 marches are the pipelined, timed context (the
+    # later ones belong to the per-stage and isolated passes)
+    if len(march) >= 23:
+        per = (march[22] - march[5]) / 17 / 1e3
+        print(f"\n# frame period inside the timed region (k_march start to start, frames 5..22), with tracing on: {per:.1f} us")
+    if len(march) >= 23:
+        lo, hi = march[5], march[22]
+        depth, last, hist = 0, lo, {}
+        for t, dlt in ev:
+            if t > hi:
+                break
+            if t >= lo:
+                hist[depth] = hist.get(depth, 0) + (t - max(last, lo))
+            last = t
+            depth += dlt
+    tot = sum(hist.values())
+    print("# kernels executing concurrently (share of the steady-state span): " +
+          ", ".join(f"{k}: {100.0 * v / tot:.1f}%" for k, v in sorted(hist.items())))
+
+
+if __name__ == "__main__":
+    main()
