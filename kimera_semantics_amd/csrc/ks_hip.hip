@@ -978,25 +978,28 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
 
   // run boundaries inside the window: every head (short or long) and every invalid lane ends a run
   const unsigned long long bounds = __ballot(head || !valid);
-  unsigned long long H = __ballot(head && !is_long);
+  const unsigned long long H = __ballot(head && !is_long);
   const uint32_t grp = lane >> 3, sub = lane & 7u;
   const uint32_t cbase = (sub - 1u) * 4u;  // first class index of this lane (subs 1..6)
+  // The heads are served 8 at a time in lane order: head number r of the window goes to group
+  // r % 8 of iteration r / 8.  One forward permute turns "lane -> is a head" into "r -> lane of
+  // head r" (heads are sent to [0, nh), every other lane to [nh, 64), so it is a permutation).
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t nh = (uint32_t)__popcll(H);
+  const bool is_h = (H >> lane) & 1ull;
+  const uint32_t dst = is_h ? (uint32_t)__popcll(H & below) : nh + (uint32_t)__popcll(~H & below);
+  const uint32_t head_lane = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)lane);
   // software pipeline over the groups of 8 heads: the record of the NEXT head is requested
   // before the recurrence of the current one runs
-  auto next_head = [&](unsigned long long& Hm) {
-    int pos = -1;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (Hm) {
-        const int p = __ffsll((long long)Hm) - 1;
-        Hm &= Hm - 1ull;
-        if ((int)grp == g) pos = p;
-      }
-    }
-    return pos;
+  uint32_t it = 0;
+  auto next_head = [&]() {
+    const uint32_t r = 8u * it + grp;
+    ++it;
+    const uint32_t p = perm_u(head_lane, r & 63u);
+    return r < nh ? (int)p : -1;
   };
-  bool more = H != 0ull;
-  int nxt_pos = more ? next_head(H) : -1;
+  bool more = nh != 0u;
+  int nxt_pos = more ? next_head() : -1;
   uint32_t nxt_vox = perm_u(vox, nxt_pos >= 0 ? (uint32_t)nxt_pos : lane);
   uint4 nxt_q = make_uint4(0u, 0u, 0u, 0u);
   if (nxt_pos >= 0 && sub < 7u) nxt_q = (P.vox + (size_t)nxt_vox * 8)[sub];
@@ -1006,9 +1009,9 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
     const uint32_t hp = active ? (uint32_t)my_pos : lane;
     const uint32_t hvox = nxt_vox;
     const uint4 q = nxt_q;
-    more = H != 0ull;
+    more = 8u * it < nh;
     if (more) {
-      nxt_pos = next_head(H);
+      nxt_pos = next_head();
       nxt_vox = perm_u(vox, nxt_pos >= 0 ? (uint32_t)nxt_pos : lane);
       nxt_q = make_uint4(0u, 0u, 0u, 0u);
       if (nxt_pos >= 0 && sub < 7u) nxt_q = (P.vox + (size_t)nxt_vox * 8)[sub];
@@ -1037,22 +1040,42 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
       uint32_t color_s = 0, rp_s = 0;
       if (COLOR_MODE == KS_COLOR_MODE_COLOR) color_s = perm_u(u.color, src);
       if (F.method == KS_METHOD_MERGED) rp_s = perm_u(u.rp, src);
-      if (on) {
-        if (sub == 0u) {
-          tsdf_combine<COLOR_MODE == KS_COLOR_MODE_COLOR>(F.tsdf, sdf_s, uw_s, color_s, dist, weight, color);
-        } else if (sub < 7u) {
-          const uint32_t kind = (info_s >> 8) & 3u;
-          if (kind == 1u) {
-            const uint32_t lab = info_s & 0xffu;
-            p0 += (cbase == lab) ? dm_s : dn_s;
-            p1 += (cbase + 1u == lab) ? dm_s : dn_s;
-            p2 += (cbase + 2u == lab) ? dm_s : dn_s;
-            p3 += (cbase + 3u == lab) ? dm_s : dn_s;
-          } else if (kind == 2u) {
-            const float* dl = deltas + (size_t)rp_s * kNumLabels + cbase;
-            p0 += dl[0];
-            if (sub < 6u) { p1 += dl[1]; p2 += dl[2]; p3 += dl[3]; }
-          }
+      // The step is straight-line code with selects: k_apply is bound by instruction issue (one
+      // wave per SIMD slot), and the nested divergent branches of the obvious formulation cost
+      // more scalar/branch instructions than the arithmetic they skip.  Every lane evaluates the
+      // TSDF recurrence (only sub 0 keeps it) and its four class sums (only subs 1..6 of a
+      // pure-label update keep them).
+      {
+        // updateTsdfVoxel's state half (tsdf_combine), [K:src/semantic_tsdf_integrator_fast.cpp:128]
+        const float nw = weight + uw_s;
+        const bool upd = on && sub == 0u && !(nw < kEps);
+        const float ns = (sdf_s * uw_s + dist * weight) / nw;
+        const float nd = (ns > 0.0f) ? std_min(F.tsdf.trunc, ns) : std_max(-F.tsdf.trunc, ns);
+        if (COLOR_MODE == KS_COLOR_MODE_COLOR) {
+          if (upd && fabsf(sdf_s) < F.tsdf.trunc) color = blend_two_colors(color, weight, color_s, uw_s);
+        }
+        dist = upd ? nd : dist;
+        weight = upd ? std_min(F.tsdf.max_weight, nw) : weight;
+      }
+      const uint32_t kind = (info_s >> 8) & 3u;
+      const bool sem_lane = on && (sub - 1u) < 6u;
+      {
+        const uint32_t lab = info_s & 0xffu;
+        const bool pure = sem_lane && kind == 1u;
+        const float a0 = p0 + ((cbase == lab) ? dm_s : dn_s);
+        const float a1 = p1 + ((cbase + 1u == lab) ? dm_s : dn_s);
+        const float a2 = p2 + ((cbase + 2u == lab) ? dm_s : dn_s);
+        const float a3 = p3 + ((cbase + 3u == lab) ? dm_s : dn_s);
+        p0 = pure ? a0 : p0;
+        p1 = pure ? a1 : p1;
+        p2 = pure ? a2 : p2;
+        p3 = pure ? a3 : p3;
+      }
+      if (F.method == KS_METHOD_MERGED) {  // mixed-label bundles carry a 21-entry increment vector
+        if (sem_lane && kind == 2u) {
+          const float* dl = deltas + (size_t)rp_s * kNumLabels + cbase;
+          p0 += dl[0];
+          if (sub < 6u) { p1 += dl[1]; p2 += dl[2]; p3 += dl[3]; }
         }
       }
     }

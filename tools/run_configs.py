@@ -37,24 +37,37 @@ def run(name, method, n_frames, cpu_frames, max_tiles):
         T = synth.single_pose() if c["traj"] == "single" else synth.trajectory_pose(k, radius=radius)
         frames.append(synth.render_frame(sc, T, c["w"], c["h"], hfov_deg=c["hfov"], seed=k))
     dev = [(torch.from_numpy(f.xyz).cuda(), torch.from_numpy(f.rgba).cuda(), torch.from_numpy(f.labels).cuda()) for f in frames]
-    h = B.HipIntegrator(B.default_config(max_tiles=max_tiles, max_points=c["w"] * c["h"], **kw))
-    h.profile_enable(True)
+    # timed pass: pipelined frames (a stream of frames), no per-stage events
+    h = B.HipIntegrator(B.default_config(max_tiles=max_tiles, max_points=c["w"] * c["h"], pipeline_frames=1, **kw))
     torch.cuda.synchronize()
     upd = 0
     t0 = time.perf_counter()
     for f, (x, col, lab) in zip(frames, dev):
         st = h.integrate_device(f.T_G_C, x.data_ptr(), col.data_ptr(), lab.data_ptr(), x.shape[0])
         upd += st.n_voxel_updates
+    upd += h.flush().n_voxel_updates
     h.synchronize()
     dt = time.perf_counter() - t0
+    tiles = len(h.tile_keys())
+    h.close()
+    # per-stage pass: unpipelined context, events around every stage (apply figures = kernel alone on the GPU)
+    h = B.HipIntegrator(B.default_config(max_tiles=max_tiles, max_points=c["w"] * c["h"], pipeline_frames=0, **kw))
+    h.profile_enable(1)
+    t1 = time.perf_counter()
+    upd1 = 0
+    for f, (x, col, lab) in zip(frames, dev):
+        upd1 += h.integrate_device(f.T_G_C, x.data_ptr(), col.data_ptr(), lab.data_ptr(), x.shape[0]).n_voxel_updates
+    h.synchronize()
+    dt1 = time.perf_counter() - t1
     prof = h.profile()
     apply_ms = (prof["ms"]["apply"] + prof["ms"]["apply_long"]) / max(1, prof["frames"])
     res = dict(config=name, method=method, frames=n_frames, points=int(np.mean([len(f.xyz) for f in frames])),
                updates_per_frame=int(upd / n_frames), gpu_ms_per_frame=round(dt / n_frames * 1e3, 3),
                gpu_Mupd_s=round(upd / dt / 1e6, 1), gpu_fps=round(n_frames / dt, 1),
+               unpipelined_ms_per_frame_with_stage_events=round(dt1 / n_frames * 1e3, 3),
                apply_ms=round(apply_ms, 4),
-               apply_alg_GBs=round(208 * upd / n_frames / (apply_ms * 1e-3) / 1e9, 1) if apply_ms else 0,
-               tiles=len(h.tile_keys()),
+               apply_alg_GBs=round(208 * upd1 / n_frames / (apply_ms * 1e-3) / 1e9, 1) if apply_ms else 0,
+               tiles=tiles,
                stage_ms={k: round(v / n_frames, 3) for k, v in prof["ms"].items()})
     # CPU oracle on a bounded sample
     cores = os.cpu_count() or 1
