@@ -1249,8 +1249,18 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
         }
       }
       // ---- pass 3: semantic log-likelihood, lane l owns class l; increments stream from LDS ----
+      if (cnt == 64) {
+        // full batch: all 64 increments are requested from LDS before the first dependent add
+        // (this wave is alone on its SIMD: nothing else hides the LDS latency)
+        float x[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) x[k] = s_inc[k][cls];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) pri += x[k];
+      } else {
 #pragma unroll 8
-      for (int k = 0; k < cnt; ++k) pri += s_inc[k][cls];
+        for (int k = 0; k < cnt; ++k) pri += s_inc[k][cls];
+      }
       __builtin_amdgcn_wave_barrier();
       if (cnt < 64) break;
       d = d_n;

@@ -1,7 +1,9 @@
 // adapter_demo — drives the C++ adapter exactly as SemanticTsdfServer would: build Layers,
 // create the integrator through the factory, feed colour-encoded clouds through the
 // TsdfIntegratorBase virtual, then dump the host Layers.  Used by tests/test_host_adapter_gpu.py.
-//   adapter_demo <method> <labels.csv> <in.bin> <out.bin> [color_mode] [max_consecutive_ray_collisions] [restart_after]
+//   adapter_demo <method> <labels.csv> <in.bin> <out.bin> [color_mode] [max_consecutive_ray_collisions] [restart_after] [pipeline]
+// pipeline = 1: SyncPolicy::kOnDemand + DeviceOptions::pipeline_frames (frames overlap on the GPU, the host
+// Layers are filled by one syncLayers() at the end, as a mesh timer would).
 // restart_after = k: after frame k the integrator is destroyed and a new one is created on the
 // same, now non-empty, Layers (the loadMap / re-configure case): it must pick the map up from the host.
 // in.bin : u32 n_frames, then per frame { f32 T[7]; u32 n; f32 xyz[3n]; u8 rgba[4n] }
@@ -35,6 +37,11 @@ int main(int argc, char** argv) {
   kimera::HipSemanticTsdfIntegrator::DeviceOptions opt;
   opt.max_tiles = 4096;
   opt.max_points = 1u << 18;
+  const bool pipeline = argc > 8 && std::atoi(argv[8]) != 0;
+  if (pipeline) {
+    opt.sync_policy = kimera::HipSemanticTsdfIntegrator::SyncPolicy::kOnDemand;
+    opt.pipeline_frames = true;
+  }
   std::unique_ptr<vxb::TsdfIntegratorBase> integrator =
       kimera::HipSemanticTsdfIntegratorFactory::create(method, cfg, sc, &tsdf_layer, &semantic_layer, opt);
 
@@ -63,6 +70,11 @@ int main(int argc, char** argv) {
     integrator->integratePointCloud(vxb::Transformation(T[0], T[1], T[2], T[3], vxb::Point(T[4], T[5], T[6])), pts, cols, false);
   }
   std::fclose(in);
+  if (pipeline) {
+    auto* hip = dynamic_cast<kimera::HipSemanticTsdfIntegrator*>(integrator.get());
+    if (!hip) return 7;
+    hip->syncLayers();
+  }
 
   vxb::BlockIndexList blocks;
   tsdf_layer.getAllAllocatedBlocks(&blocks);

@@ -98,3 +98,29 @@ def test_adapter_resumes_from_host_layers(tmp_path, method):
     assert np.array_equal(t["weight"].view(np.uint32), ot["weight"].view(np.uint32))
     assert np.array_equal(t["color"], ot["color"])
     assert np.array_equal(s["color"], os_["color"])
+
+
+@pytest.mark.parametrize("method", ["fast", "merged"])
+def test_adapter_pipelined_on_demand_sync(tmp_path, method):
+    """DeviceOptions::pipeline_frames + SyncPolicy::kOnDemand: frames overlap on the GPU, one
+    syncLayers() at the end fills the host Layers — same map as frame-by-frame, bit for bit."""
+    sc = synth.make_scene("room")
+    frames = [synth.render_frame(sc, synth.trajectory_pose(5 * k), 128, 96, seed=120 + k) for k in range(5)]
+    csv, fin, fout = str(tmp_path / "labels.csv"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    R.write_label_csv(csv, synth.default_label_colors())
+    _write_in(fin, frames)
+    res = subprocess.run([DEMO, method, csv, fin, fout, "1", str(NO_EARLY_OUT), "-1", "1"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    idx, t, s = _read_out(fout)
+    is_merged = method == "merged"
+    o = O.Oracle(O.default_config(**dict(COMMON, method=1 if is_merged else 0, color_mode=1,
+                                         max_consecutive_ray_collisions=NO_EARLY_OUT)))
+    for f in frames:
+        o.integrate(f.T_G_C, f.xyz, None if is_merged else f.rgba, f.labels)
+    oi, ot, os_ = o.download()
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(s["label"], os_["label"])
+    assert np.array_equal(s["priors"].view(np.uint32), os_["priors"].view(np.uint32))
+    assert np.array_equal(t["distance"].view(np.uint32), ot["distance"].view(np.uint32))
+    assert np.array_equal(t["weight"].view(np.uint32), ot["weight"].view(np.uint32))
+    assert np.array_equal(t["color"], ot["color"])
