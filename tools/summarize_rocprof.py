@@ -43,9 +43,24 @@ def main():
                 hist[depth] = hist.get(depth, 0) + (t - max(last, lo))
             last = t
             depth += dlt
+    ap = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                for r in tr if "k_apply<" in r["Kernel_Name"] and "k_apply_long" not in r["Kernel_Name"])
+    if len(ap) >= 56:
+        timed = [d for _, d in ap[3:23]]
+        solo = [d for _, d in ap[-10:]]
+        print(f"# k_apply average duration: {sum(timed) / len(timed) / 1e3:.2f} us over the 20 timed (pipelined, overlapped) "
+              f"launches; {sum(solo) / len(solo) / 1e3:.2f} us over the last 10 launches of the isolated pass "
+              f"(bench.py's roofline.avg_launch_ms / roofline.isolated.avg_launch_ms of the same run are in the log line below)")
     tot = sum(hist.values())
     print("# kernels executing concurrently (share of the steady-state span): " +
           ", ".join(f"{k}: {100.0 * v / tot:.1f}%" for k, v in sorted(hist.items())))
+    if len(sys.argv) > 3:
+        import json
+        for line in open(sys.argv[3]):
+            if line.startswith("{"):
+                j = json.loads(line)
+                print("# bench.py line of this traced run: value", j["value"], j["unit"], "ms_per_step", j["ms_per_step"],
+                      "roofline", json.dumps(j["roofline"]))
 
 
 if __name__ == "__main__":
