@@ -2403,6 +2403,7 @@ int ks_set_color_to_label(ks_ctx* c, const uint8_t* rgba_keys, const uint8_t* la
     const uint32_t rgb = rgba_keys[4 * i] | (rgba_keys[4 * i + 1] << 8) | (rgba_keys[4 * i + 2] << 16);
     lut[rgb] = labels[i];
   }
+  if (int rc = quiesce(c)) return rc;  // frames in flight still read the old table
   if (!c->d_color_lut) HIPCHK(c, hipMalloc((void**)&c->d_color_lut, 1u << 24));
   HIPCHK(c, hipMemcpy(c->d_color_lut, lut.data(), 1u << 24, hipMemcpyHostToDevice));
   return KS_OK;

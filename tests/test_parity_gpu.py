@@ -449,3 +449,29 @@ def test_profile_levels():
     p = h.profile()
     assert p["frames"] == 8 and p["apply_kernel_launches"] == 2 and sum(p["ms"].values()) == 0
     assert 0 < p["apply_kernel_updates"] < p["updates"]
+
+
+@pytest.mark.parametrize("variant", ["sorted_order", "anti_grazing", "depth_entry", "clearing"])
+def test_pipelined_variants_exact(variant):
+    """Configurations that take special paths under ks_config.pipeline_frames: sorted integration
+    order (falls back to one frame at a time), anti-grazing (the march stays on stage A's stream),
+    the depth-image entry, free-space clouds."""
+    method = 0 if variant in ("sorted_order", "depth_entry") else 1
+    kw = dict(COMMON, method=method, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    if variant == "sorted_order":
+        kw["integration_order_mode"] = 1
+    if variant == "anti_grazing":
+        kw["enable_anti_grazing"] = 1
+    o = O.Oracle(O.default_config(**kw))
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, pipeline_frames=1, **kw))
+    sc = synth.make_scene("room")
+    for k in range(5):
+        f = synth.render_frame(sc, synth.trajectory_pose(3 * k), 160, 120, seed=900 + k)
+        free = 1 if (variant == "clearing" and k % 2 == 1) else 0
+        if variant == "depth_entry":
+            o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)  # f.xyz is the reference-style cloud of f.depth
+            h.integrate_depth(f.T_G_C, f.depth, f.K, label_img=f.label_img)
+        else:
+            o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels, freespace=free)
+            h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels, freespace=free)
+    compare_maps(o, h, exact=True)
