@@ -71,7 +71,8 @@ class KsProfile(C.Structure):
 def build(force: bool = False) -> str:
     """Compile libks_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("ks_hip.hip", "ks_device_math.h", "ks_radix_sort.h")]
+    srcs = [os.path.join(src_dir, f) for f in ("ks_hip.hip", "ks_types.h", "ks_k_rays.h", "ks_k_march.h", "ks_k_apply.h",
+                                                "ks_k_io.h", "ks_device_math.h", "ks_radix_sort.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "ks_hip.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)

@@ -1,0 +1,400 @@
+// ks_k_apply.h — the voxel update: updateTsdfVoxel + updateSemanticVoxel replayed per voxel run.
+#pragma once
+#include "ks_types.h"
+
+namespace ksk {
+// ------------------------------------------------------------------------------------------
+// K3c: apply — the per-voxel update.  Pairs are sorted by (voxel, ray sequence); one voxel's
+// updates form a contiguous run that is replayed in order:
+//   updateTsdfVoxel  (Voxblox; called at [K:fast.cpp:128], [K:merged.cpp:317-319])
+//   updateSemanticVoxel: priors += L*freq, argmax, colour  ([K:src/semantic_integrator_base.cpp:136-194])
+// One read-modify-write of the voxel per frame however many rays crossed it.
+//   k_apply      : one lane per short run (< kLongRun updates); long runs are queued
+//   k_apply_long : one wavefront per long run (voxels near the sensor collect thousands of
+//                  updates): lanes fetch 64 updates at once and pre-compute the voxel-state-
+//                  independent part (sdf, updated weight); the state recurrence is then walked
+//                  in order with lane broadcasts; lanes 0..20 own one class prior each.
+// ------------------------------------------------------------------------------------------
+struct VoxelRef {
+  uint32_t slot, local;
+  int vx, vy, vz;
+};
+__device__ __forceinline__ VoxelRef voxel_ref(const TileTable& T, uint32_t vox) {
+  VoxelRef v;
+  v.slot = vox >> 9;
+  v.local = vox & 511u;
+  int tx, ty, tz;
+  unpack_tile(T.slot_keys[v.slot], tx, ty, tz);
+  v.vx = tx * 8 + (int)(v.local & 7u);
+  v.vy = ty * 8 + (int)((v.local >> 3) & 7u);
+  v.vz = tz * 8 + (int)(v.local >> 6);
+  return v;
+}
+
+// lane permute with every lane of the wave active (ds_bpermute reads 0 from disabled lanes)
+__device__ __forceinline__ uint32_t perm_u(uint32_t x, uint32_t src_lane) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)x);
+}
+__device__ __forceinline__ float perm_f(float x, uint32_t src_lane) { return __uint_as_float(perm_u(__float_as_uint(x), src_lane)); }
+
+// Operands of one (voxel, ray) update that do not depend on the voxel state.
+struct UpdateOps {
+  float sdf, uw, dm, dn;
+  uint32_t info, color, rp;
+};
+__device__ __forceinline__ UpdateOps load_update_ops(const FrameParams& F, const RayDesc* __restrict__ rays, uint64_t key,
+                                                     const VoxelRef& v) {
+  UpdateOps u;
+  u.rp = (uint32_t)key & F.point_mask;
+  const uint4* r4 = (const uint4*)rays + (size_t)ray_index(F, u.rp) * 2;
+  const uint4 d0 = r4[0], d1 = r4[1];
+  tsdf_operands(F.tsdf, F.T.t, {__uint_as_float(d0.x), __uint_as_float(d0.y), __uint_as_float(d0.z)}, v.vx, v.vy, v.vz,
+                __uint_as_float(d0.w), u.sdf, u.uw);
+  u.color = d1.x;
+  u.dm = __uint_as_float(d1.y);
+  u.dn = __uint_as_float(d1.z);
+  u.info = d1.w;
+  return u;
+}
+
+template <int COLOR_MODE>
+__global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long n_pairs,
+                                               const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
+                                               const float* __restrict__ deltas, TileTable T, Pool P,
+                                               const uint32_t* __restrict__ label_lut,
+                                               unsigned long long* __restrict__ long_list, Counters* C) {
+  // Phase A — one lane per pair (64 consecutive pairs per wavefront): ray-descriptor gather and
+  //   the voxel-state-independent half of updateTsdfVoxel, all 64 in flight at once.
+  // Phase B — EIGHT LANES COOPERATE PER VOXEL: lane `sub` of a group moves 16 bytes of the
+  //   128-byte record (one coalesced line per voxel); sub 0 walks the TSDF recurrence, subs
+  //   1..6 own four class priors each.  The run's operands come from the phase-A lanes through
+  //   ds_bpermute, so the recurrence has no memory access on its critical path.
+  const uint32_t lane = lane_id();
+  const unsigned long long wbase = ((unsigned long long)blockIdx.x * 4ull + (threadIdx.x >> 6)) * 64ull;
+  const unsigned long long i = wbase + lane;
+  const bool valid = i < n_pairs;
+  uint64_t key = 0;
+  uint32_t vox = 0xffffffffu;
+  bool head = false, is_long = false;
+  UpdateOps u{};
+  if (valid) {
+    key = pairs[i];
+    vox = (uint32_t)(key >> F.seq_bits);
+    head = (i == 0) || ((uint32_t)(pairs[i - 1] >> F.seq_bits) != vox);
+    if (head) is_long = (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> F.seq_bits) == vox);
+    u = load_update_ops(F, rays, key, voxel_ref(T, vox));
+  }
+  const uint32_t lpos = block_append(head && is_long, &C->n_long);
+  if (head && is_long) long_list[lpos] = i;
+
+  // run boundaries inside the window: every head (short or long) and every invalid lane ends a run
+  const unsigned long long bounds = __ballot(head || !valid);
+  const unsigned long long H = __ballot(head && !is_long);
+  const uint32_t grp = lane >> 3, sub = lane & 7u;
+  const uint32_t cbase = (sub - 1u) * 4u;  // first class index of this lane (subs 1..6)
+  // The heads are served 8 at a time in lane order: head number r of the window goes to group
+  // r % 8 of iteration r / 8.  One forward permute turns "lane -> is a head" into "r -> lane of
+  // head r" (heads are sent to [0, nh), every other lane to [nh, 64), so it is a permutation).
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t nh = (uint32_t)__popcll(H);
+  const bool is_h = (H >> lane) & 1ull;
+  const uint32_t dst = is_h ? (uint32_t)__popcll(H & below) : nh + (uint32_t)__popcll(~H & below);
+  const uint32_t head_lane = (uint32_t)__builtin_amdgcn_ds_permute((int)(dst << 2), (int)lane);
+  // software pipeline over the groups of 8 heads: the record of the NEXT head is requested
+  // before the recurrence of the current one runs
+  uint32_t it = 0;
+  auto next_head = [&]() {
+    const uint32_t r = 8u * it + grp;
+    ++it;
+    const uint32_t p = perm_u(head_lane, r & 63u);
+    return r < nh ? (int)p : -1;
+  };
+  bool more = nh != 0u;
+  int nxt_pos = more ? next_head() : -1;
+  uint32_t nxt_vox = perm_u(vox, nxt_pos >= 0 ? (uint32_t)nxt_pos : lane);
+  uint4 nxt_q = make_uint4(0u, 0u, 0u, 0u);
+  if (nxt_pos >= 0 && sub < 7u) nxt_q = (P.vox + (size_t)nxt_vox * 8)[sub];
+  while (more) {
+    const int my_pos = nxt_pos;
+    const bool active = my_pos >= 0;
+    const uint32_t hp = active ? (uint32_t)my_pos : lane;
+    const uint32_t hvox = nxt_vox;
+    const uint4 q = nxt_q;
+    more = 8u * it < nh;
+    if (more) {
+      nxt_pos = next_head();
+      nxt_vox = perm_u(vox, nxt_pos >= 0 ? (uint32_t)nxt_pos : lane);
+      nxt_q = make_uint4(0u, 0u, 0u, 0u);
+      if (nxt_pos >= 0 && sub < 7u) nxt_q = (P.vox + (size_t)nxt_vox * 8)[sub];
+    }
+    // length of the run inside this window
+    uint32_t len = 0;
+    if (active) {
+      const unsigned long long above = (hp < 63u) ? (bounds >> (hp + 1u)) : 0ull;
+      len = above ? (uint32_t)__ffsll((long long)above) : (64u - hp);
+    }
+    uint4* rec = P.vox + (size_t)(active ? hvox : 0u) * 8;
+    float dist = __uint_as_float(q.x), weight = __uint_as_float(q.y);  // meaningful for sub 0
+    uint32_t color = q.z;
+    float p0 = __uint_as_float(q.x), p1 = __uint_as_float(q.y), p2 = __uint_as_float(q.z), p3 = __uint_as_float(q.w);
+
+    for (uint32_t s = 0;; ++s) {
+      const bool on = active && s < len;
+      if (__ballot(on) == 0ull) break;
+      const uint32_t src = on ? hp + s : lane;
+      const float sdf_s = perm_f(u.sdf, src), uw_s = perm_f(u.uw, src);
+      // fast: every ray carries the same two increments (log p, log(1-p)); merged: per bundle
+      const bool per_ray_inc = F.method == KS_METHOD_MERGED;
+      const float dm_s = per_ray_inc ? perm_f(u.dm, src) : F.log_match;
+      const float dn_s = per_ray_inc ? perm_f(u.dn, src) : F.log_non_match;
+      const uint32_t info_s = perm_u(u.info, src);
+      uint32_t color_s = 0, rp_s = 0;
+      if (COLOR_MODE == KS_COLOR_MODE_COLOR) color_s = perm_u(u.color, src);
+      if (F.method == KS_METHOD_MERGED) rp_s = perm_u(u.rp, src);
+      // The step is straight-line code with selects: k_apply is bound by instruction issue (one
+      // wave per SIMD slot), and the nested divergent branches of the obvious formulation cost
+      // more scalar/branch instructions than the arithmetic they skip.  Every lane evaluates the
+      // TSDF recurrence (only sub 0 keeps it) and its four class sums (only subs 1..6 of a
+      // pure-label update keep them).
+      {
+        // updateTsdfVoxel's state half (tsdf_combine), [K:src/semantic_tsdf_integrator_fast.cpp:128]
+        const float nw = weight + uw_s;
+        const bool upd = on && sub == 0u && !(nw < kEps);
+        const float ns = (sdf_s * uw_s + dist * weight) / nw;
+        const float nd = (ns > 0.0f) ? std_min(F.tsdf.trunc, ns) : std_max(-F.tsdf.trunc, ns);
+        if (COLOR_MODE == KS_COLOR_MODE_COLOR) {
+          if (upd && fabsf(sdf_s) < F.tsdf.trunc) color = blend_two_colors(color, weight, color_s, uw_s);
+        }
+        dist = upd ? nd : dist;
+        weight = upd ? std_min(F.tsdf.max_weight, nw) : weight;
+      }
+      const uint32_t kind = (info_s >> 8) & 3u;
+      const bool sem_lane = on && (sub - 1u) < 6u;
+      {
+        const uint32_t lab = info_s & 0xffu;
+        const bool pure = sem_lane && kind == 1u;
+        const float a0 = p0 + ((cbase == lab) ? dm_s : dn_s);
+        const float a1 = p1 + ((cbase + 1u == lab) ? dm_s : dn_s);
+        const float a2 = p2 + ((cbase + 2u == lab) ? dm_s : dn_s);
+        const float a3 = p3 + ((cbase + 3u == lab) ? dm_s : dn_s);
+        p0 = pure ? a0 : p0;
+        p1 = pure ? a1 : p1;
+        p2 = pure ? a2 : p2;
+        p3 = pure ? a3 : p3;
+      }
+      if (F.method == KS_METHOD_MERGED) {  // mixed-label bundles carry a 21-entry increment vector
+        if (sem_lane && kind == 2u) {
+          const float* dl = deltas + (size_t)rp_s * kNumLabels + cbase;
+          p0 += dl[0];
+          if (sub < 6u) { p1 += dl[1]; p2 += dl[2]; p3 += dl[3]; }
+        }
+      }
+    }
+    // a run may continue past the 64-pair window: finish it from global memory (rare)
+    if (active && hp + len == 64u) {
+      const VoxelRef v = voxel_ref(T, hvox);
+      for (unsigned long long j = wbase + 64ull; j < n_pairs; ++j) {
+        const uint64_t k = pairs[j];
+        if ((uint32_t)(k >> F.seq_bits) != hvox) break;
+        const UpdateOps t = load_update_ops(F, rays, k, v);
+        if (sub == 0u) {
+          tsdf_combine<COLOR_MODE == KS_COLOR_MODE_COLOR>(F.tsdf, t.sdf, t.uw, t.color, dist, weight, color);
+        } else if (sub < 7u) {
+          const uint32_t kind = (t.info >> 8) & 3u;
+          if (kind == 1u) {
+            const uint32_t lab = t.info & 0xffu;
+            p0 += (cbase == lab) ? t.dm : t.dn;
+            p1 += (cbase + 1u == lab) ? t.dm : t.dn;
+            p2 += (cbase + 2u == lab) ? t.dm : t.dn;
+            p3 += (cbase + 3u == lab) ? t.dm : t.dn;
+          } else if (kind == 2u) {
+            const float* dl = deltas + (size_t)t.rp * kNumLabels + cbase;
+            p0 += dl[0];
+            if (sub < 6u) { p1 += dl[1]; p2 += dl[2]; p3 += dl[3]; }
+          }
+        }
+      }
+    }
+
+    // calculateMaximumLikelihoodLabel: first strict maximum [K:src/semantic_integrator_base.cpp:352-367]
+    float bv = -INFINITY;
+    uint32_t bi = 1000u;
+    if (sub >= 1u && sub < 7u) {
+      bv = p0; bi = cbase;
+      if (sub < 6u) {
+        if (p1 > bv) { bv = p1; bi = cbase + 1u; }
+        if (p2 > bv) { bv = p2; bi = cbase + 2u; }
+        if (p3 > bv) { bv = p3; bi = cbase + 3u; }
+      }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      const float ov = perm_f(bv, lane ^ (uint32_t)o);
+      const uint32_t oi = perm_u(bi, lane ^ (uint32_t)o);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (active) {
+      if (sub == 0u) {
+        if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = label_lut[bi];
+        else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY) color = rainbow_color_map((double)(float)exp((double)bv));
+        rec[0] = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, bi);
+      } else if (sub < 6u) {
+        rec[sub] = make_uint4(__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3));
+      } else if (sub == 6u) {
+        rec[6] = make_uint4(__float_as_uint(p0), 0u, 0u, 0u);
+      }
+    }
+  }
+}
+
+template <int COLOR_MODE>
+__global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long long n_pairs,
+                                                   const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
+                                                   const float* __restrict__ deltas, TileTable T, Pool P,
+                                                   const uint32_t* __restrict__ label_lut,
+                                                   const unsigned long long* __restrict__ long_list, const Counters* C) {
+  // One wavefront per block: LDS traffic below is ordered by program order (DS operations of
+  // a wave execute in order), no s_barrier needed; wave_barrier() only pins the compiler.
+  __shared__ float s_inc[64][kNumLabels];  // class increments of the 64 updates in flight
+  const uint32_t n_long = C->n_long;
+  const int lane = (int)lane_id();
+  const int cls = lane < kNumLabels ? lane : 0;
+  const TsdfParams& Pm = F.tsdf;
+  for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
+    const unsigned long long start = long_list[run];
+    const uint32_t vox = (uint32_t)(pairs[start] >> F.seq_bits);
+    const VoxelRef v = voxel_ref(T, vox);
+    uint32_t* rec = (uint32_t*)(P.vox + (size_t)vox * 8);
+    float dist = __uint_as_float(rec[0]), weight = __uint_as_float(rec[1]);
+    uint32_t color = rec[2];
+    float pri = (lane < kNumLabels) ? __uint_as_float(rec[4 + lane]) : 0.0f;
+    // voxel centre and the origin->centre vector are constant over the run
+    const f3 c = {((float)v.vx + 0.5f) * Pm.voxel_size, ((float)v.vy + 0.5f) * Pm.voxel_size,
+                  ((float)v.vz + 0.5f) * Pm.voxel_size};
+    const f3 v_voxel_origin = sub3(c, F.T.t);
+
+    // software pipeline: rays of batch b+1 and pair keys of batch b+2 are in flight while batch b is applied
+    // All loads of the pipeline are UNCONDITIONAL (indices clamped): a load under a divergent
+    // branch makes the compiler drain vmcnt at the join, which serialises the prefetch.
+    const unsigned long long last = n_pairs - 1ull;
+    unsigned long long base = start;
+    uint64_t key_cur = pairs[min(base + lane, last)];
+    uint64_t key_nxt = pairs[min(base + 64ull + lane, last)];
+    bool in = (base + lane < n_pairs) && ((uint32_t)(key_cur >> F.seq_bits) == vox);
+    RayDesc d = rays[ray_index(F, (uint32_t)key_cur & F.point_mask)];
+    for (;;) {
+      const int cnt = (int)__popcll(__ballot(in));  // sorted => the in-lanes form a prefix
+      if (cnt == 0) break;
+      const bool in_n = (base + 64ull + lane < n_pairs) && ((uint32_t)(key_nxt >> F.seq_bits) == vox);
+      const RayDesc d_n = rays[ray_index(F, (uint32_t)key_nxt & F.point_mask)];
+      const uint64_t key_nn = pairs[min(base + 128ull + lane, last)];
+
+      // ---- per-lane, voxel-state-independent part: computeDistance + weight drop-off ----
+      float sdf = 0.f, uw = 0.f;
+      if (in) {
+        const f3 v_point_origin = sub3({d.px, d.py, d.pz}, F.T.t);
+        const float dist_G = norm3(v_point_origin);
+        const float dist_G_V = dot3(v_voxel_origin, v_point_origin) / dist_G;
+        sdf = dist_G - dist_G_V;
+        uw = d.weight;
+        if (Pm.use_dropoff && sdf < -Pm.voxel_size) {
+          uw = d.weight * (Pm.trunc + sdf) / Pm.dropoff_denominator;
+          uw = std_max(uw, 0.0f);
+        }
+        if (Pm.use_sparsity) {
+          if (fabsf(sdf) < Pm.trunc) uw *= Pm.sparsity_factor;
+        }
+        const uint32_t kind = (d.info >> 8) & 3u;
+        const uint32_t lab = d.info & 0xffu;
+        if (kind == 2u) {
+          const float* dl = deltas + (size_t)((uint32_t)key_cur & F.point_mask) * kNumLabels;
+#pragma unroll
+          for (int l = 0; l < kNumLabels; ++l) s_inc[lane][l] = dl[l];
+        } else {
+          const float a = (kind == 1u) ? d.d_match : 0.0f, b = (kind == 1u) ? d.d_non : 0.0f;
+#pragma unroll
+          for (int l = 0; l < kNumLabels; ++l) s_inc[lane][l] = ((uint32_t)l == lab) ? a : b;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+
+      // ---- pass 1: the weight recurrence (independent of the distance) ----
+      // w' = min(max_weight, w + uw) unless w + uw < 1e-6 (then the TSDF update is a no-op).
+      float my_w = 0.0f, my_nw = 1.0f;
+      if (weight == Pm.max_weight && __ballot(in && !(uw >= 0.0f)) == 0ull) {
+        // Weight already clamped at max_weight and every increment is non-negative: each
+        // update sees w = max_weight and leaves min(max_weight, max_weight + uw) = max_weight,
+        // so the recurrence degenerates to 64 independent additions (the steady state of the
+        // voxels next to the sensor, which are the long runs).
+        my_w = weight;
+        my_nw = weight + uw;
+      } else {
+        float w_run = weight;
+        for (int k = 0; k < cnt; ++k) {
+          const float nw = w_run + bcast_f(uw, k);  // lane broadcast: an LDS read here costs its full latency per step
+          if (lane == k) { my_w = w_run; my_nw = nw; }
+          if (!(nw < kEps)) w_run = std_min(Pm.max_weight, nw);
+        }
+        weight = w_run;
+      }
+      const bool my_skip = my_nw < kEps;
+      const float my_r = 1.0f / my_nw;  // correctly rounded reciprocal, off the critical path
+      const float my_p = sdf * uw;      // fl(sdf * uw)
+      // Saturation: with dist == +trunc on entry, an update whose exact weighted mean exceeds
+      // trunc by more than the rounding slack of the f32 operations leaves dist == +trunc (the
+      // clamp).  If that holds for every update of the batch the distance recurrence is skipped.
+      const bool my_sat = my_skip || ((sdf - Pm.trunc) * uw >= 1e-6f * Pm.trunc * my_nw);
+      const bool all_sat = (__ballot(in && !my_sat) == 0ull);
+      if (!(all_sat && dist == Pm.trunc && COLOR_MODE != KS_COLOR_MODE_COLOR)) {
+        // ---- pass 2: the distance recurrence ----
+        for (int k = 0; k < cnt; ++k) {
+          if (bcast_u(my_skip ? 1u : 0u, k)) continue;
+          const float w_k = bcast_f(my_w, k), nw_k = bcast_f(my_nw, k), r_k = bcast_f(my_r, k);
+          const float num = bcast_f(my_p, k) + dist * w_k;
+          const float q = div_by_recip(num, nw_k, r_k);
+          if (COLOR_MODE == KS_COLOR_MODE_COLOR) {
+            if (fabsf(bcast_f(sdf, k)) < Pm.trunc)
+              color = blend_two_colors(color, w_k, bcast_u(d.color, k), bcast_f(uw, k));
+          }
+          dist = (q > 0.0f) ? std_min(Pm.trunc, q) : std_max(-Pm.trunc, q);
+        }
+      }
+      // ---- pass 3: semantic log-likelihood, lane l owns class l; increments stream from LDS ----
+      if (cnt == 64) {
+        // full batch: all 64 increments are requested from LDS before the first dependent add
+        // (this wave is alone on its SIMD: nothing else hides the LDS latency)
+        float x[64];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) x[k] = s_inc[k][cls];
+#pragma unroll
+        for (int k = 0; k < 64; ++k) pri += x[k];
+      } else {
+#pragma unroll 8
+        for (int k = 0; k < cnt; ++k) pri += s_inc[k][cls];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (cnt < 64) break;
+      d = d_n;
+      in = in_n;
+      key_cur = key_nxt;
+      key_nxt = key_nn;
+      base += 64;
+    }
+    // argmax over lanes 0..20, first strict maximum
+    int best = 0;
+    float m = bcast_f(pri, 0);
+#pragma unroll
+    for (int l = 1; l < kNumLabels; ++l) {
+      const float x = bcast_f(pri, l);
+      if (x > m) { m = x; best = l; }
+    }
+    if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = label_lut[best];
+    else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY)
+      color = rainbow_color_map((double)(float)exp((double)m));
+    if (lane < kNumLabels) rec[4 + lane] = __float_as_uint(pri);
+    if (lane == 0) *(uint4*)rec = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, (uint32_t)best);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace ksk

@@ -1,0 +1,363 @@
+// ks_k_rays.h — stage A kernels: per-point work, start-voxel dedup (fast), bundle merge (merged).
+#pragma once
+#include "ks_types.h"
+
+namespace ksk {
+// ------------------------------------------------------------------------------------------
+// K1/K2 (fast): per point — label, validity, dynamic-label filter, point_G, start-voxel slot.
+// [K:src/semantic_tsdf_integrator_fast.cpp:71-92, 150-158]
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_points_fast(FrameParams F, const float* __restrict__ xyz,
+                                                      const uint8_t* __restrict__ rgba,
+                                                      const uint8_t* __restrict__ labels,
+                                                      const uint8_t* __restrict__ color_lut,
+                                                      RayDesc* __restrict__ rays, uint32_t* __restrict__ hash_out,
+                                                      uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                      Counters* C) {
+  // One lane per point in MEMORY order (coalesced reads, coalesced descriptor writes); the
+  // integration position p of the point is arithmetic, only the 4-byte sort key is scattered.
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  bool counted = false;
+  if (idx < F.n) {
+    uint32_t key = kInvalidSlot;
+    const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+    uint32_t color = 0;
+    if (rgba) color = ((const uint32_t*)rgba)[idx];
+    uint32_t label;
+    if (labels) label = labels[idx];
+    else label = color_lut ? color_lut[color & 0xffffffu] : 0u;
+    if (label >= (uint32_t)kNumLabels) {
+      atomicOr(&C->err, kErrLabel);
+    } else {
+      int valid = point_validity(pc, F.min_ray, F.max_ray, F.allow_clear != 0, F.freespace != 0);
+      for (int i = 0; i < F.n_dynamic; ++i)
+        if (F.dynamic_labels[i] == label) valid = 0;
+      if (valid) {
+        const f3 pg = transform_point(F.T, pc);
+        const float gx = grid_coord(pg.x, F.start_inv), gy = grid_coord(pg.y, F.start_inv),
+                    gz = grid_coord(pg.z, F.start_inv);
+        const float lim = 2.0f * (float)kCoordBias;  // finer grid; only the hash of the index is used
+        if (!(fabsf(gx) < lim && fabsf(gy) < lim && fabsf(gz) < lim)) {
+          atomicOr(&C->err, kErrIndex);
+        } else {
+          const uint32_t h = index_hash((int)gx, (int)gy, (int)gz);
+          hash_out[idx] = h;
+          key = (uint32_t)(((uint64_t)h + F.start_offset) & kSetMask);
+          RayDesc d;
+          d.px = pg.x; d.py = pg.y; d.pz = pg.z;
+          d.weight = voxel_weight(pc.z, F.use_const_weight != 0);
+          d.color = color;
+          d.d_match = F.log_match;
+          d.d_non = F.log_non_match;
+          d.info = label | ((label != 0u ? 1u : 0u) << 8) | ((valid == 2 ? 1u : 0u) << 10);
+          rays[idx] = d;
+          counted = true;
+        }
+      }
+    }
+    keys[point_position(F, F.inv_order, idx)] = key;
+    vals[idx] = idx;  // identity: vals[p] = p
+  }
+  block_count(counted, &C->n_valid);
+}
+
+// Start-voxel dedup, exactly as the serial reference.  ApproxHashSet::replaceHash leaves the
+// caller's hash in the slot whether or not it was already there, so a point is kept iff the
+// previous point that mapped to the same slot (in integration order) had a different hash —
+// or, for the first point of a slot this frame, iff the slot's persistent content differs.
+// Input is stably sorted by slot (so position order is preserved inside a slot).
+// [K:src/semantic_tsdf_integrator_fast.cpp:87-92]
+__global__ void __launch_bounds__(1024) k_dedup(FrameParams F, const uint32_t* __restrict__ skeys,
+                                                const uint32_t* __restrict__ svals, const uint32_t* __restrict__ hash,
+                                                uint64_t* __restrict__ start_set, uint32_t* __restrict__ ray_list,
+                                                Counters* C) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = F.n;
+  bool kept = false;
+  uint32_t p = 0;
+  if (i < n && C->err == 0) {
+    const uint32_t slot = skeys[i];
+    if (slot != kInvalidSlot) {
+      p = svals[i];
+      const uint64_t h = hash[point_order(F, F.order, p)];
+      const bool first = (i == 0) || (skeys[i - 1] != slot);
+      uint64_t prev;
+      // the slot's persistent content is only READ here; k_dedup_commit writes it afterwards
+      if (first) prev = start_set[slot];
+      else prev = hash[point_order(F, F.order, svals[i - 1])];
+      kept = prev != h;
+    }
+  }
+  const uint32_t pos = block_append(kept, &C->n_rays);
+  if (kept) ray_list[pos] = p;
+}
+
+// Leaves the last hash of every slot run in the persistent approximate set (what
+// replaceHash would have left behind after the frame).
+__global__ void __launch_bounds__(1024) k_dedup_commit(FrameParams F, const uint32_t* __restrict__ skeys,
+                                                       const uint32_t* __restrict__ svals,
+                                                       const uint32_t* __restrict__ hash, uint64_t* __restrict__ start_set,
+                                                       const Counters* C) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n || C->err != 0) return;
+  const uint32_t slot = skeys[i];
+  if (slot == kInvalidSlot) return;
+  if (i + 1 < F.n && skeys[i + 1] == slot) return;
+  start_set[slot] = (uint64_t)hash[point_order(F, F.order, svals[i])];
+}
+
+// ------------------------------------------------------------------------------------------
+// K4 (merged): per point — validity, point_G, end-voxel key.  vxb::MergedTsdfIntegrator::bundleRays,
+// called at [K:src/semantic_tsdf_integrator_merged.cpp:119-124].
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_points_merged(FrameParams F, const float* __restrict__ xyz,
+                                                        const uint8_t* __restrict__ rgba,
+                                                        const uint8_t* __restrict__ labels,
+                                                        const uint8_t* __restrict__ color_lut,
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                        Counters* C) {
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  bool counted = false;
+  if (idx < F.n) {
+    const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+    uint32_t label;
+    if (labels) label = labels[idx];
+    else label = (color_lut && rgba) ? color_lut[((const uint32_t*)rgba)[idx] & 0xffffffu] : 0u;
+    uint64_t key = kEmpty64;
+    if (label >= (uint32_t)kNumLabels) {
+      atomicOr(&C->err, kErrLabel);
+    } else {
+      const int valid = point_validity(pc, F.min_ray, F.max_ray, F.allow_clear != 0, F.freespace != 0);
+      if (valid) {
+        const f3 pg = transform_point(F.T, pc);
+        const float gx = grid_coord(pg.x, F.voxel_size_inv), gy = grid_coord(pg.y, F.voxel_size_inv),
+                    gz = grid_coord(pg.z, F.voxel_size_inv);
+        const float lim = (float)(kCoordBias - 1);
+        if (!(fabsf(gx) < lim && fabsf(gy) < lim && fabsf(gz) < lim)) {
+          atomicOr(&C->err, kErrIndex);
+        } else {
+          key = ((uint64_t)(valid == 2 ? 1u : 0u) << 63) | ((uint64_t)(uint32_t)((int)gx + kCoordBias) << 42) |
+                ((uint64_t)(uint32_t)((int)gy + kCoordBias) << 21) | (uint64_t)(uint32_t)((int)gz + kCoordBias);
+          counted = true;
+        }
+      }
+    }
+    keys[point_position(F, F.inv_order, idx)] = key;
+    vals[idx] = idx;  // identity: vals[p] = p
+  }
+  block_count(counted, &C->n_valid);
+}
+
+// Gather the per-point operands of the bundle merge into bundle (sorted) order, so that the
+// sequential merge below streams contiguous memory: {x, y, z, weight} and {label, colour}.
+__global__ void __launch_bounds__(256) k_gather_sorted(FrameParams F, const float* __restrict__ xyz,
+                                                       const uint8_t* __restrict__ rgba,
+                                                       const uint8_t* __restrict__ labels,
+                                                       const uint8_t* __restrict__ color_lut,
+                                                       const uint32_t* __restrict__ order,
+                                                       const uint64_t* __restrict__ skeys,
+                                                       const uint32_t* __restrict__ svals, float4* __restrict__ g_pw,
+                                                       uint2* __restrict__ g_lc) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.n) return;
+  if (skeys[i] == kEmpty64) return;
+  const uint32_t idx = point_order(F, order, svals[i]);
+  const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+  const uint32_t color = rgba ? ((const uint32_t*)rgba)[idx] : 0u;
+  uint32_t label;
+  if (labels) label = labels[idx];
+  else label = (color_lut && rgba) ? color_lut[color & 0xffffffu] : 0u;
+  g_pw[i] = make_float4(pc.x, pc.y, pc.z, voxel_weight(pc.z, F.use_const_weight != 0));
+  g_lc[i] = make_uint2(label, color);
+}
+
+// K5 (merged): bundle merge — running weighted mean of point_C, colour blend, label histogram,
+// log-likelihood increment.  [K:src/semantic_tsdf_integrator_merged.cpp:248-287]
+//   k_bundles      : one lane per bundle of < kLongRun points
+//   k_bundles_long : one wavefront per larger bundle (a surface close to the sensor puts
+//                    thousands of pixels into one 5 cm voxel)
+__device__ __forceinline__ void finish_bundle(const FrameParams& F, f3 mp, float mw, uint32_t merged_color,
+                                              bool clearing, int n_labels, int the_label, float c, RayDesc* out) {
+  const f3 pg = transform_point(F.T, mp);
+  RayDesc d;
+  d.px = pg.x; d.py = pg.y; d.pz = pg.z;
+  d.weight = mw;
+  d.color = merged_color;
+  d.d_match = 0.0f;
+  d.d_non = 0.0f;
+  uint32_t kind = 0;
+  if (n_labels == 1) {
+    kind = 1;
+    d.d_match = F.log_match * c;
+    d.d_non = F.log_non_match * c;
+  } else if (n_labels > 1) {
+    kind = 2;
+  }
+  d.info = (uint32_t)the_label | (kind << 8) | ((clearing ? 1u : 0u) << 10);
+  *out = d;
+}
+
+__global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* __restrict__ skeys,
+                                                 const uint32_t* __restrict__ svals, const float4* __restrict__ g_pw,
+                                                 const uint2* __restrict__ g_lc, RayDesc* __restrict__ rays,
+                                                 float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
+                                                 uint32_t* __restrict__ long_list, uint64_t* __restrict__ ray_keys,
+                                                 Counters* C) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool head = false, is_long = false;
+  uint32_t first_p = 0;
+  uint64_t key = 0;
+  if (i < F.n && C->err == 0) {
+    key = skeys[i];
+    head = (key != kEmpty64) && (i == 0 || skeys[i - 1] != key);
+    if (head) is_long = (i + kLongRun < F.n) && (skeys[i + kLongRun] == key);
+  }
+  const uint32_t lpos = block_append(head && is_long, &C->n_long_bundles);
+  if (head && is_long) long_list[lpos] = i;
+  const bool work = head && !is_long;
+  if (work) {
+    const bool clearing = (key >> 63) != 0;
+    uint32_t merged_color = 0;
+    f3 mp = {0.f, 0.f, 0.f};
+    float mw = 0.0f;
+    float freq[kNumLabels];
+#pragma unroll
+    for (int l = 0; l < kNumLabels; ++l) freq[l] = 0.0f;
+    uint32_t j = i;
+    do {
+      const float4 q = g_pw[j];
+      const float pw = q.w;
+      if (!(pw < kEps)) {
+        const uint2 lc = g_lc[j];
+        const float denom = mw + pw;
+        mp.x = (mp.x * mw + q.x * pw) / denom;
+        mp.y = (mp.y * mw + q.y * pw) / denom;
+        mp.z = (mp.z * mw + q.z * pw) / denom;
+        if (F.color_mode == KS_COLOR_MODE_COLOR) merged_color = blend_two_colors(merged_color, mw, lc.y, pw);
+        mw += pw;
+#pragma unroll
+        for (int l = 0; l < kNumLabels; ++l) freq[l] += (lc.x == (uint32_t)l) ? 1.0f : 0.0f;
+        if (clearing) break;
+      }
+      ++j;
+    } while (j < F.n && skeys[j] == key);
+
+    first_p = svals[i];
+    // priors += L * freq with L[i][j] = (j == 0) ? 0 : (i == j ? log p : log(1-p)), j ascending, no FMA
+    // [K:src/semantic_integrator_base.cpp:93-128, 306-307]
+    int n_labels = 0, the_label = 0;
+    float c = 0.0f;
+#pragma unroll
+    for (int l = 1; l < kNumLabels; ++l)
+      if (freq[l] > 0.0f) { ++n_labels; the_label = l; c = freq[l]; }
+    if (n_labels > 1) {
+#pragma unroll
+      for (int r = 0; r < kNumLabels; ++r) {
+        float acc = 0.0f;
+        acc += 0.0f * freq[0];
+#pragma unroll
+        for (int l = 1; l < kNumLabels; ++l) acc += ((r == l) ? F.log_match : F.log_non_match) * freq[l];
+        deltas[(size_t)first_p * kNumLabels + r] = acc;
+      }
+    }
+    finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p]);
+    if (ray_keys) ray_keys[first_p] = key & ~(1ull << 63);
+  }
+  const uint32_t pos = block_append(work, &C->n_rays);
+  if (work) ray_list[pos] = first_p;
+}
+
+__global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64_t* __restrict__ skeys,
+                                                     const uint32_t* __restrict__ svals,
+                                                     const float4* __restrict__ g_pw, const uint2* __restrict__ g_lc,
+                                                     RayDesc* __restrict__ rays, float* __restrict__ deltas,
+                                                     uint32_t* __restrict__ ray_list,
+                                                     const uint32_t* __restrict__ long_list,
+                                                     uint64_t* __restrict__ ray_keys, Counters* C) {
+  const uint32_t n_long = C->n_long_bundles;
+  const int lane = (int)lane_id();
+  for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
+    const uint32_t start = long_list[run];
+    const uint64_t key = skeys[start];
+    const bool clearing = (key >> 63) != 0;
+    float mpc = 0.0f;  // lane 0/1/2: x/y/z of the running weighted mean
+    float mw = 0.0f;
+    uint32_t merged_color = 0;
+    float freq = 0.0f;  // lane l < 21 counts label l
+    bool done = false;
+    uint32_t base = start;
+    // prefetch one batch ahead (contiguous, coalesced)
+    uint32_t j = base + (uint32_t)lane;
+    bool in = (j < F.n) && (skeys[j] == key);
+    float4 q = in ? g_pw[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 lc = in ? g_lc[j] : make_uint2(0u, 0u);
+    while (!done) {
+      const int cnt = (int)__popcll(__ballot(in));
+      if (cnt == 0) break;
+      const uint32_t jn = base + 64u + (uint32_t)lane;
+      const bool in_n = (jn < F.n) && (skeys[jn] == key);
+      const float4 q_n = in_n ? g_pw[jn] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const uint2 lc_n = in_n ? g_lc[jn] : make_uint2(0u, 0u);
+
+      const bool valid = in && !(q.w < kEps);
+      unsigned long long vmask = __ballot(valid);
+      if (clearing && vmask) {  // only the first usable point of a clearing bundle is integrated
+        vmask &= (~vmask + 1ull);
+        done = true;
+      }
+      const bool use = valid && ((vmask >> lane) & 1ull);
+      // pass 1: weight recurrence; lane k keeps (weight before, denominator)
+      float my_mw = 0.0f, my_den = 1.0f;
+      for (unsigned long long m = vmask; m; m &= m - 1ull) {
+        const int k = __ffsll((long long)m) - 1;
+        const float den = mw + bcast_f(q.w, k);
+        if (lane == k) { my_mw = mw; my_den = den; }
+        mw = den;
+      }
+      const float my_r = 1.0f / my_den;
+      const float ax = q.x * q.w, ay = q.y * q.w, az = q.z * q.w;
+      // pass 2: weighted-mean recurrence; lanes 0,1,2 each walk ONE component chain (x, y, z),
+      // so a step is one multiply-add + one reciprocal-based division for the whole wave
+      for (unsigned long long m = vmask; m; m &= m - 1ull) {
+        const int k = __ffsll((long long)m) - 1;
+        const float mw_k = bcast_f(my_mw, k), den_k = bcast_f(my_den, k), r_k = bcast_f(my_r, k);
+        const float ax_k = bcast_f(ax, k), ay_k = bcast_f(ay, k), az_k = bcast_f(az, k);
+        const float a_k = (lane == 0) ? ax_k : (lane == 1) ? ay_k : az_k;
+        mpc = div_by_recip(mpc * mw_k + a_k, den_k, r_k);
+        if (F.color_mode == KS_COLOR_MODE_COLOR)
+          merged_color = blend_two_colors(merged_color, mw_k, bcast_u(lc.y, k), bcast_f(q.w, k));
+      }
+      // label histogram: counts are order independent and exact in f32
+#pragma unroll
+      for (int l = 0; l < kNumLabels; ++l) {
+        const unsigned long long lm = __ballot(use && lc.x == (uint32_t)l);
+        if (lane == l) freq += (float)__popcll(lm);
+      }
+      if (cnt < 64) break;
+      in = in_n;
+      q = q_n;
+      lc = lc_n;
+      base += 64u;
+    }
+    const f3 mp = {bcast_f(mpc, 0), bcast_f(mpc, 1), bcast_f(mpc, 2)};
+    const uint32_t first_p = svals[start];
+    const unsigned long long present = __ballot(lane >= 1 && lane < kNumLabels && freq > 0.0f);
+    const int n_labels = (int)__popcll(present);
+    const int the_label = present ? (63 - __clzll((long long)present)) : 0;
+    const float c = bcast_f(freq, the_label);
+    if (n_labels > 1 && lane < kNumLabels) {
+      float acc = 0.0f;
+      acc += 0.0f * bcast_f(freq, 0);
+#pragma unroll
+      for (int l = 1; l < kNumLabels; ++l) acc += ((lane == l) ? F.log_match : F.log_non_match) * bcast_f(freq, l);
+      deltas[(size_t)first_p * kNumLabels + lane] = acc;
+    }
+    if (lane == 0) {
+      finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p]);
+      if (ray_keys) ray_keys[first_p] = key & ~(1ull << 63);
+      ray_list[atomicAdd(&C->n_rays, 1u)] = first_p;
+    }
+  }
+}
+
+}  // namespace ksk
