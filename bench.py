@@ -128,6 +128,8 @@ def main():
     integ.synchronize()       # completes the last warm-up frame: nothing is pending at t0
     torch.cuda.synchronize()
     if world > 1:
+        from kimera_semantics_amd import parallel as PAR
+        PAR.warm_up(dev)   # RCCL connects peers lazily: not part of the steady state being timed
         dist.barrier()
     # level 2: only the k_apply dispatch of every 4th frame carries HIP events (per-stage events
     # would put ~50 us of stream bubbles into every timed frame)

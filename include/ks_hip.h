@@ -181,7 +181,9 @@ int ks_upload_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, const void* 
  * order; ks_export_tiles_device gathers the tiles at the given slots into a DEVICE buffer
  * (n x 65536 B); ks_merge_tiles_device merges n incoming tiles (HOST keys, DEVICE payload) into
  * the resident map: weight-averaged distance/colour and summed weight (Voxblox's layer-merge
- * rule), additive class log-likelihoods, then argmax + colour.  ks_clear empties the map. */
+ * rule), additive class log-likelihoods, then argmax + colour.  Keys may repeat within one
+ * call (tiles of the same key received from several ranks): they are folded in array order, in
+ * one kernel launch, so the result is deterministic.  ks_clear empties the map. */
 #define KS_TILE_BYTES 65536
 int ks_get_tile_keys(ks_ctx* ctx, uint64_t* out, size_t cap, size_t* n);
 int ks_export_tiles_device(ks_ctx* ctx, const uint32_t* slots, size_t n, void* d_payload);
@@ -193,7 +195,8 @@ int ks_clear(ks_ctx* ctx);
 int ks_debug_radix_sort(ks_ctx* ctx, void* keys, uint32_t* vals, size_t n, int key_bits, unsigned end_bit);
 
 int ks_synchronize(ks_ctx* ctx);
-void* ks_stream(ks_ctx* ctx); /* the hipStream_t all kernels are launched on */
+void* ks_stream(ks_ctx* ctx); /* the hipStream_t that reads the caller's device inputs (stage A; with
+                                * pipeline_frames later stages run on two further internal streams) */
 /* Finish the frame a pipelined context still holds (no-op otherwise); stats = that frame's. */
 int ks_flush(ks_ctx* ctx, ks_frame_stats* stats);
 /* level 0: off; 1: events around every stage and every k_apply dispatch (costs ~50 us of stream

@@ -150,6 +150,10 @@ struct ks_ctx {
   size_t cap_pairs = 0;
   uint64_t* d_pairs2 = nullptr;
   ksrs::Workspace sort_ws, sort_ws_tail;
+  // scratch of the multi-GPU exchange entry points (slots / group offsets + order / distinct keys)
+  uint32_t* d_xchg_u32 = nullptr;
+  uint64_t* d_xchg_u64 = nullptr;
+  size_t cap_xchg = 0;
   // Device words: Counters of slot k at 64 * k, the persistent tile count at 64 * kSlots.
   uint8_t* d_state = nullptr;
   FrameSlot slot[kSlots];
@@ -570,6 +574,16 @@ int flush_pending(ks_ctx* c, ks_frame_stats* stats) {
   return KS_OK;
 }
 
+int ensure_exchange(ks_ctx* c, size_t n) {
+  if (n <= c->cap_xchg) return KS_OK;
+  const size_t cap = std::max<size_t>(n + n / 2, 1024);
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_xchg_u32, 2 * cap + 2))) return rc;
+  if ((rc = dev_alloc(c, &c->d_xchg_u64, cap))) return rc;
+  c->cap_xchg = cap;
+  return KS_OK;
+}
+
 // complete every outstanding frame and drain both streams
 int quiesce(ks_ctx* c) {
   const int rc = flush_pending(c, nullptr);
@@ -841,7 +855,7 @@ void ks_destroy(ks_ctx* c) {
   void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->slot[0].d_rays, c->slot[1].d_rays, c->slot[2].d_rays, c->slot[0].d_deltas, c->slot[1].d_deltas, c->slot[2].d_deltas, c->slot[0].d_ray_list, c->slot[1].d_ray_list, c->slot[2].d_ray_list, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
-                  c->slot[0].d_pairs, c->slot[1].d_pairs, c->slot[2].d_pairs, c->d_pairs2, c->d_state,
+                  c->slot[0].d_pairs, c->slot[1].d_pairs, c->slot[2].d_pairs, c->d_pairs2, c->d_state, c->d_xchg_u32, c->d_xchg_u64,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -1160,12 +1174,10 @@ int ks_export_tiles_device(ks_ctx* c, const uint32_t* slots, size_t n, void* d_p
   if (int rc = quiesce(c)) return rc;
   for (size_t i = 0; i < n; ++i)
     if (slots[i] >= c->tiles_initialised) return KS_ERR_INVALID_ARG;
-  uint32_t* d_slots = nullptr;
-  HIPCHK(c, hipMalloc((void**)&d_slots, n * sizeof(uint32_t)));
-  HIPCHK(c, hipMemcpyAsync(d_slots, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_export_tiles, dim3((uint32_t)n), dim3(512), 0, c->stream, c->pool, d_slots, (uint4*)d_payload);
+  if (int rc = ensure_exchange(c, n)) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_xchg_u32, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_export_tiles, dim3((uint32_t)n), dim3(512), 0, c->stream, c->pool, c->d_xchg_u32, (uint4*)d_payload);
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  (void)hipFree(d_slots);
   return KS_OK;
 }
 
@@ -1173,31 +1185,47 @@ int ks_merge_tiles_device(ks_ctx* c, const uint64_t* keys, size_t n, const void*
   if (!c || (n && (!keys || !d_payload))) return KS_ERR_INVALID_ARG;
   if (n == 0) return KS_OK;
   if (c->fatal) return KS_ERR_INVALID_ARG;
-  uint64_t* d_keys = nullptr;
-  HIPCHK(c, hipMalloc((void**)&d_keys, n * sizeof(uint64_t)));
-  HIPCHK(c, hipMemcpyAsync(d_keys, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-  // allocate tiles this rank has not seen yet
-  if (int rc = insert_tiles(c, d_keys, n)) {
-    (void)hipFree(d_keys);
-    return rc;
+  // group the incoming tiles by key, keeping the caller's order inside a group
+  std::vector<uint32_t> order(n);
+  for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return keys[a] < keys[b]; });
+  std::vector<uint64_t> ukeys;
+  std::vector<uint32_t> offs;
+  for (size_t i = 0; i < n; ++i) {
+    if (i == 0 || keys[order[i]] != keys[order[i - 1]]) {
+      ukeys.push_back(keys[order[i]]);
+      offs.push_back((uint32_t)i);
+    }
   }
+  offs.push_back((uint32_t)n);
+  const size_t nu = ukeys.size();
+  int rc;
+  if ((rc = quiesce(c))) return rc;
+  if ((rc = ensure_exchange(c, n + 1))) return rc;
+  uint32_t* d_offs = c->d_xchg_u32;
+  uint32_t* d_idx = c->d_xchg_u32 + (nu + 1);
+  HIPCHK(c, hipMemcpyAsync(c->d_xchg_u64, ukeys.data(), nu * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_offs, offs.data(), (nu + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(d_idx, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  // allocate tiles this rank has not seen yet
+  if ((rc = insert_tiles(c, c->d_xchg_u64, nu))) return rc;
   switch (c->cfg.color_mode) {
     case KS_COLOR_MODE_COLOR:
-      hipLaunchKernelGGL(k_merge_tiles<KS_COLOR_MODE_COLOR>, dim3((uint32_t)n), dim3(512), 0, c->stream, c->table, c->pool,
-                         d_keys, (const uint4*)d_payload, c->cfg.max_weight, c->d_label_lut);
+      hipLaunchKernelGGL(k_merge_tiles<KS_COLOR_MODE_COLOR>, dim3((uint32_t)nu), dim3(512), 0, c->stream, c->table, c->pool,
+                         c->d_xchg_u64, d_offs, d_idx, (const uint4*)d_payload, c->cfg.max_weight, c->d_label_lut);
       break;
     case KS_COLOR_MODE_SEMANTIC:
-      hipLaunchKernelGGL(k_merge_tiles<KS_COLOR_MODE_SEMANTIC>, dim3((uint32_t)n), dim3(512), 0, c->stream, c->table,
-                         c->pool, d_keys, (const uint4*)d_payload, c->cfg.max_weight, c->d_label_lut);
+      hipLaunchKernelGGL(k_merge_tiles<KS_COLOR_MODE_SEMANTIC>, dim3((uint32_t)nu), dim3(512), 0, c->stream, c->table,
+                         c->pool, c->d_xchg_u64, d_offs, d_idx, (const uint4*)d_payload, c->cfg.max_weight, c->d_label_lut);
       break;
     default:
-      hipLaunchKernelGGL(k_merge_tiles<KS_COLOR_MODE_SEMANTIC_PROBABILITY>, dim3((uint32_t)n), dim3(512), 0, c->stream,
-                         c->table, c->pool, d_keys, (const uint4*)d_payload, c->cfg.max_weight, c->d_label_lut);
+      hipLaunchKernelGGL(k_merge_tiles<KS_COLOR_MODE_SEMANTIC_PROBABILITY>, dim3((uint32_t)nu), dim3(512), 0, c->stream,
+                         c->table, c->pool, c->d_xchg_u64, d_offs, d_idx, (const uint4*)d_payload, c->cfg.max_weight,
+                         c->d_label_lut);
       break;
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipGetLastError());
-  (void)hipFree(d_keys);
   return KS_OK;
 }
 

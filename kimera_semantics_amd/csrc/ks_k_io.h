@@ -19,31 +19,35 @@ __global__ void __launch_bounds__(256) k_insert_tiles(TileTable T, Counters* C, 
   if (i < n) tile_insert(T, C, keys[i]);
 }
 
-// Merge one incoming tile per workgroup into the resident map; 8 lanes per voxel.
+// Merge incoming tiles into the resident map; 8 lanes per voxel.
 //   TSDF: Voxblox's layer-merge rule (mergeVoxelAIntoVoxelB): weight-averaged distance and
 //         colour, summed weight (clamped to max_weight);
 //   semantics: log-likelihoods are additive: priors += (incoming - initial), then argmax/colour
 //         exactly as updateSemanticVoxel ends ([K:src/semantic_integrator_base.cpp:164-191]).
 template <int COLOR_MODE>
-__global__ void __launch_bounds__(512) k_merge_tiles(TileTable T, Pool P, const uint64_t* __restrict__ keys,
+__global__ void __launch_bounds__(512) k_merge_tiles(TileTable T, Pool P, const uint64_t* __restrict__ ukeys,
+                                                     const uint32_t* __restrict__ offs, const uint32_t* __restrict__ idx,
                                                      const uint4* __restrict__ in, float max_weight,
                                                      const uint32_t* __restrict__ label_lut) {
-  const uint32_t slot = tile_lookup(T, keys[blockIdx.x]);
+  // One workgroup per DISTINCT tile key; the incoming tiles of that key (idx[offs[b] .. offs[b+1]),
+  // in the caller's order = ascending source rank) are folded in one after the other, so one
+  // launch merges everything a rank received and the result does not depend on scheduling.
+  const uint32_t slot = tile_lookup(T, ukeys[blockIdx.x]);
   if (slot == 0xffffffffu) return;
-  const uint4* src = in + (size_t)blockIdx.x * kTileVoxels * 8;
+  const uint32_t j0 = offs[blockIdx.x], j1 = offs[blockIdx.x + 1];
   uint4* dst = P.vox + (size_t)slot * kTileVoxels * 8;
   const uint32_t lane = lane_id(), sub = lane & 7u;
   const uint32_t cbase = (sub - 1u) * 4u;
   for (uint32_t r = 0; r < 8; ++r) {
     const uint32_t q = r * 512u + threadIdx.x;  // uint4 index in the tile; voxel = q >> 3
-    uint4 a = src[q];
     uint4 b = dst[q];
-    // every lane of the voxel's group needs A's label (dword 3 of sub 0)
-    const uint32_t a_label = perm_u(a.w, lane & ~7u);
-    const bool touched = a_label != 255u;
-    float bv = -INFINITY;
-    uint32_t bi = 1000u;
-    if (touched) {
+    bool any = false;
+    for (uint32_t j = j0; j < j1; ++j) {
+      const uint4 a = in[(size_t)idx[j] * kTileVoxels * 8 + q];
+      // every lane of the voxel's group needs A's label (dword 3 of sub 0)
+      const uint32_t a_label = perm_u(a.w, lane & ~7u);
+      if (a_label == 255u) continue;  // the sender never updated this voxel
+      any = true;
       if (sub == 0u) {
         const float ad = __uint_as_float(a.x), aw = __uint_as_float(a.y);
         float bd = __uint_as_float(b.x), bw = __uint_as_float(b.y);
@@ -56,19 +60,26 @@ __global__ void __launch_bounds__(512) k_merge_tiles(TileTable T, Pool P, const 
         b.x = __float_as_uint(bd);
         b.y = __float_as_uint(bw);
       } else if (sub < 7u) {
-        float p0 = __uint_as_float(b.x) + (__uint_as_float(a.x) - kPriorInit);
-        float p1 = __uint_as_float(b.y), p2 = __uint_as_float(b.z), p3 = __uint_as_float(b.w);
-        bv = p0; bi = cbase;
+        b.x = __float_as_uint(__uint_as_float(b.x) + (__uint_as_float(a.x) - kPriorInit));
         if (sub < 6u) {
-          p1 += __uint_as_float(a.y) - kPriorInit;
-          p2 += __uint_as_float(a.z) - kPriorInit;
-          p3 += __uint_as_float(a.w) - kPriorInit;
-          if (p1 > bv) { bv = p1; bi = cbase + 1u; }
-          if (p2 > bv) { bv = p2; bi = cbase + 2u; }
-          if (p3 > bv) { bv = p3; bi = cbase + 3u; }
+          b.y = __float_as_uint(__uint_as_float(b.y) + (__uint_as_float(a.y) - kPriorInit));
+          b.z = __float_as_uint(__uint_as_float(b.z) + (__uint_as_float(a.z) - kPriorInit));
+          b.w = __float_as_uint(__uint_as_float(b.w) + (__uint_as_float(a.w) - kPriorInit));
         }
-        b = make_uint4(__float_as_uint(p0), sub < 6u ? __float_as_uint(p1) : 0u, sub < 6u ? __float_as_uint(p2) : 0u,
-                       sub < 6u ? __float_as_uint(p3) : 0u);
+      }
+    }
+    // calculateMaximumLikelihoodLabel on the merged priors: first strict maximum
+    float bv = -INFINITY;
+    uint32_t bi = 1000u;
+    if (any && sub >= 1u && sub < 7u) {
+      bv = __uint_as_float(b.x); bi = cbase;
+      if (sub < 6u) {
+        const float p1 = __uint_as_float(b.y), p2 = __uint_as_float(b.z), p3 = __uint_as_float(b.w);
+        if (p1 > bv) { bv = p1; bi = cbase + 1u; }
+        if (p2 > bv) { bv = p2; bi = cbase + 2u; }
+        if (p3 > bv) { bv = p3; bi = cbase + 3u; }
+      } else {
+        b.y = b.z = b.w = 0u;
       }
     }
 #pragma unroll
@@ -77,7 +88,7 @@ __global__ void __launch_bounds__(512) k_merge_tiles(TileTable T, Pool P, const 
       const uint32_t oi = perm_u(bi, lane ^ (uint32_t)o);
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    if (touched && sub < 7u) {
+    if (any && sub < 7u) {
       if (sub == 0u) {
         b.w = bi;
         if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) b.z = label_lut[bi];

@@ -8,8 +8,9 @@ New functionality: the reference is a single process.  Pro
   2. ranks exchange per-destination tile counts, then keys and raw 64 KiB tile records with a
      single all-to-all each — on a fully connected xGMI node every rank talks to its 7 peers
      at once, which a ring all-reduce (per-link bound) cannot do;
-  3. the owner merges incoming tiles in ascending source-rank order (deterministic) with
-     ks_merge_tiles_device: weight-averaged TSDF (Voxblox's layer-merge rule), additive class
+  3. the owner merges everything it received with ONE ks_merge_tiles_device call; tiles that
+     several ranks sent for the same key are folded in ascending source-rank order
+     (deterministic): weight-averaged TSDF (Voxblox's layer-merge rule), additive class
      log-likelihoods, argmax + colour.
 After the reduce, rank r holds the authoritative state of the tiles it owns.
 
@@ -95,16 +96,29 @@ def reduce_maps(store, group=None) -> dict:
     dist.all_to_all_single(k_recv, k_send, recv_counts, send_counts, group=group)
     p_recv = store.empty(n_recv)
     dist.all_to_all_single(p_recv, payload, recv_counts, send_counts, group=group)
-    # 4) deterministic merge: ascending source rank
+    # 4) deterministic merge: the receive buffer is ordered by source rank, and the store folds
+    #    tiles of the same key in buffer order
     k_host = k_recv.cpu().numpy().view(np.uint64)
-    off = 0
-    for src in range(world):
-        c = recv_counts[src]
-        if c:
-            store.merge(k_host[off:off + c], p_recv[off:off + c])
-        off += c
+    if n_recv:
+        store.merge(k_host, p_recv)
     return {"tiles_sent": int(sum(send_counts)), "tiles_received": n_recv, "tiles_local": int(len(keys)),
             "bytes_sent": int(sum(send_counts)) * TILE_WORDS * 4}
+
+
+def warm_up(device, group=None):
+    """Establishes the point-to-point connections the all-to-alls of reduce_maps use (RCCL sets
+    them up lazily on first use); call once outside any timed region."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    t_send = torch.ones(world, dtype=torch.int64, device=device)
+    t_recv = torch.empty(world, dtype=torch.int64, device=device)
+    dist.all_to_all_single(t_recv, t_send, group=group)
+    counts = [1] * world
+    p_send = torch.zeros((world, TILE_WORDS), dtype=torch.int32, device=device)
+    p_recv = torch.empty((world, TILE_WORDS), dtype=torch.int32, device=device)
+    dist.all_to_all_single(p_recv, p_send, counts, counts, group=group)
+    return int(t_recv.sum().item())
 
 
 def owned_tile_mask(keys: np.ndarray, rank: int, world: int) -> np.ndarray:

@@ -98,3 +98,36 @@ def test_clear_resets_the_map():
     h2 = B.HipIntegrator(B.default_config(max_tiles=2048, max_points=1 << 16, **dict(COMMON, method=0)))
     s2 = h2.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
     assert s1.n_rays_cast == s2.n_rays_cast
+
+
+@pytest.mark.parametrize("color_mode", [1, 0])
+def test_one_merge_call_folds_duplicate_keys_in_order(color_mode):
+    """reduce_maps hands the owner everything it received in ONE ks_merge_tiles_device call, the
+    buffer ordered by source rank: tiles with the same key must be folded in buffer order, i.e.
+    the result equals merging the sources one call after the other (bit for bit)."""
+    import torch
+    sc = synth.make_scene("room")
+    kw = dict(COMMON, method=1, color_mode=color_mode, max_consecutive_ray_collisions=NO_EARLY_OUT)
+
+    def rank(r):
+        h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 16, **kw))
+        f = synth.render_frame(sc, synth.arc_pose(r, 4), 128, 96, seed=400 + r)
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        return h
+
+    srcs = [rank(r) for r in (1, 2, 3)]
+    exported = [_export_all(h) for h in srcs]
+    a, b = rank(0), rank(0)
+    for k, buf in exported:                       # one call per source
+        a.merge_tiles(k, buf.data_ptr())
+    keys = np.concatenate([k for k, _ in exported])
+    payload = torch.cat([buf for _, buf in exported], dim=0).contiguous()
+    assert len(set(keys.tolist())) < len(keys), "sources must share tiles"
+    b.merge_tiles(keys, payload.data_ptr())       # one call for all sources
+    ka, bufa = _export_all(a)
+    kb, bufb = _export_all(b)
+    da = dict(zip(ka.tolist(), bufa.cpu().numpy().view(np.uint32).reshape(len(ka), 512, 32)))
+    db = dict(zip(kb.tolist(), bufb.cpu().numpy().view(np.uint32).reshape(len(kb), 512, 32)))
+    assert sorted(da) == sorted(db)
+    for k in da:
+        assert np.array_equal(da[k][:, :25], db[k][:, :25]), f"tile {k}"
