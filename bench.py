@@ -168,7 +168,7 @@ def main():
     # k_apply ALONE on the GPU (no other stage overlapping it): a second, unpipelined context over
     # the same frames; reported next to the timed-region figure as roofline.isolated
     iso = None
-    if rank == 0 and not args.no_pipeline:
+    if rank == 0 and world == 1 and not args.no_pipeline:
         cfg0 = B.default_config(device_id=local_rank, max_tiles=1 << 13, max_points=args.width * args.height,
                                 pipeline_frames=0, **common_cfg(args.method))
         solo = B.HipIntegrator(cfg0)
@@ -244,7 +244,7 @@ def main():
         }
         if reduce_stats is not None:
             out["reduce"] = reduce_stats
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, frames[W:])
         print(json.dumps(out), flush=True)
     integ.close()
