@@ -475,3 +475,37 @@ def test_pipelined_variants_exact(variant):
             o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels, freespace=free)
             h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels, freespace=free)
     compare_maps(o, h, exact=True)
+
+
+def test_pipelined_soak_equals_unpipelined():
+    """150 frames through the three-stream pipeline with queries sprinkled in: same map as the
+    unpipelined context, bit for bit (deterministic mode), and identical statistics."""
+    kw = dict(COMMON, method=0, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    a = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 15, pipeline_frames=0, **kw))
+    b = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 15, pipeline_frames=1, **kw))
+    sc = synth.make_scene("room")
+    frames = [synth.render_frame(sc, synth.trajectory_pose(k), 128, 96, seed=k) for k in range(30)]
+    sa, sb = [], []
+    for k in range(150):
+        f = frames[k % 30]
+        s = a.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        sa.append((s.n_rays_cast, s.n_voxel_updates, s.n_blocks_allocated))
+        s = b.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        sb.append((s.n_rays_cast, s.n_voxel_updates, s.n_blocks_allocated))
+        if k % 37 == 36:
+            assert len(b.tile_keys()) == len(a.tile_keys())
+    s = b.flush()
+    sb.append((s.n_rays_cast, s.n_voxel_updates, s.n_blocks_allocated))
+    assert sb[1:] == sa
+    compare_maps(a, b, exact=True)
+
+
+def test_pipelined_pool_exhaustion_is_reported():
+    h = B.HipIntegrator(B.default_config(max_tiles=8, max_points=1 << 15, pipeline_frames=1, **dict(COMMON, method=0)))
+    f = small_frame(seed=3, w=128, h=96)
+    h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    with pytest.raises(B.KsError) as e:
+        h.flush()
+    assert e.value.code == B.KS_ERR_POOL_FULL if hasattr(B, "KS_ERR_POOL_FULL") else e.value.code < 0
+    with pytest.raises(B.KsError):          # the context stays in its failed state
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
