@@ -161,7 +161,10 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
         const float nw = weight + uw_s;
         const bool upd = on && sub == 0u && !(nw < kEps);
         const float ns = (sdf_s * uw_s + dist * weight) / nw;
-        const float nd = (ns > 0.0f) ? std_min(F.tsdf.trunc, ns) : std_max(-F.tsdf.trunc, ns);
+        // (ns > 0) ? min(trunc, ns) : max(-trunc, ns) is the median of (-trunc, ns, trunc); v_med3_f32
+        // returns min3 of the non-NaN operands for a NaN input = -trunc, which is what the reference's
+        // std::max(-trunc, NaN) yields too
+        const float nd = __builtin_amdgcn_fmed3f(ns, -F.tsdf.trunc, F.tsdf.trunc);
         if (COLOR_MODE == KS_COLOR_MODE_COLOR) {
           if (upd && fabsf(sdf_s) < F.tsdf.trunc) color = blend_two_colors(color, weight, color_s, uw_s);
         }
