@@ -174,6 +174,11 @@ int ks_download_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, void* tsdf
  * (semantic_integrator_base.cpp:92-96, filled e.g. by TsdfServer::loadMap) — reaches the GPU.
  * Block indices must be distinct.  Errors: KS_ERR_POOL_FULL, KS_ERR_INDEX_RANGE. */
 int ks_upload_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, const void* tsdf_in, const void* sem_in);
+/* Page-locked host memory for the buffers handed to ks_download_blocks / ks_upload_blocks /
+ * ks_integrate_points (transfers from pageable memory go through a staging copy and run at a
+ * fraction of the link rate).  ks_host_alloc returns NULL on failure. */
+void* ks_host_alloc(size_t bytes);
+void ks_host_free(void* p);
 
 /* ---- multi-GPU exchange (new functionality: the reference is single-process) ----
  * The map is a set of 8^3-voxel tiles; a tile travels as its packed 63-bit key plus a raw

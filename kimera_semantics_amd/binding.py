@@ -31,7 +31,7 @@ SEM_DTYPE = np.dtype([("label", "u1"), ("pad", "u1", (3,)), ("priors", "<f4", (N
 ABI_SYMBOLS = [
     "ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_set_color_to_label",
     "ks_integrate_points", "ks_integrate_points_device", "ks_integrate_depth", "ks_integrate_depth_device", "ks_num_blocks", "ks_get_block_indices",
-    "ks_get_updated_block_indices", "ks_download_blocks", "ks_upload_blocks", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear",
+    "ks_get_updated_block_indices", "ks_download_blocks", "ks_upload_blocks", "ks_host_alloc", "ks_host_free", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear",
     "ks_debug_radix_sort", "ks_synchronize", "ks_flush", "ks_stream",
     "ks_profile_enable", "ks_profile_get",
 ]
@@ -109,6 +109,10 @@ def lib():
         L.ks_get_updated_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
         L.ks_download_blocks.argtypes = [vp, vp, C.c_size_t, vp, vp]
         L.ks_upload_blocks.argtypes = [vp, vp, C.c_size_t, vp, vp]
+        L.ks_host_alloc.argtypes = [C.c_size_t]
+        L.ks_host_alloc.restype = C.c_void_p
+        L.ks_host_free.argtypes = [vp]
+        L.ks_host_free.restype = None
         L.ks_get_tile_keys.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.ks_export_tiles_device.argtypes = [vp, vp, C.c_size_t, vp]
         L.ks_merge_tiles_device.argtypes = [vp, vp, C.c_size_t, vp]

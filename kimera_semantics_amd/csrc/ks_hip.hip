@@ -1118,6 +1118,16 @@ int ks_upload_blocks(ks_ctx* c, const int32_t* idx, size_t n, const void* tsdf_i
   return KS_OK;
 }
 
+void* ks_host_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, std::max<size_t>(bytes, 1), hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+
+void ks_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 int ks_debug_radix_sort(ks_ctx* c, void* keys, uint32_t* vals, size_t n, int key_bits, unsigned end_bit) {
   if (!c || (n && !keys) || (key_bits != 32 && key_bits != 64)) return KS_ERR_INVALID_ARG;
   if (n == 0) return KS_OK;

@@ -9,6 +9,7 @@
 // in.bin : u32 n_frames, then per frame { f32 T[7]; u32 n; f32 xyz[3n]; u8 rgba[4n] }
 // out.bin: u32 n_blocks, u32 vps, then per block { i32 idx[3]; tsdf vps^3*12 B; semantic vps^3*92 B }
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -50,6 +51,8 @@ int main(int argc, char** argv) {
   uint32_t n_frames = 0;
   if (std::fread(&n_frames, 4, 1, in) != 1) return 3;
   const int restart_after = argc > 7 ? std::atoi(argv[7]) : -1;
+  double integrate_ms = 0.0, tail_ms = 0.0;
+  uint32_t tail_frames = 0;
   for (uint32_t f = 0; f < n_frames; ++f) {
     if ((int)f == restart_after) {
       integrator.reset();
@@ -67,14 +70,27 @@ int main(int argc, char** argv) {
       pts[i] = vxb::Point(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
       cols[i] = vxb::Color(rgba[4 * i], rgba[4 * i + 1], rgba[4 * i + 2], rgba[4 * i + 3]);
     }
+    const auto t0 = std::chrono::steady_clock::now();
     integrator->integratePointCloud(vxb::Transformation(T[0], T[1], T[2], T[3], vxb::Point(T[4], T[5], T[6])), pts, cols, false);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    integrate_ms += ms;
+    if (3 * f >= 2 * n_frames) {  // steady state: the last third (staging buffers and most blocks exist)
+      tail_ms += ms;
+      ++tail_frames;
+    }
   }
   std::fclose(in);
   if (pipeline) {
     auto* hip = dynamic_cast<kimera::HipSemanticTsdfIntegrator*>(integrator.get());
     if (!hip) return 7;
+    const auto t0 = std::chrono::steady_clock::now();
     hip->syncLayers();
+    std::printf("adapter_demo: final syncLayers %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
+  if (n_frames)
+    std::printf("adapter_demo: integratePointCloud %.3f ms/frame over %u frames, %.3f ms/frame over the last %u (host clouds, %s)\n",
+                integrate_ms / n_frames, n_frames, tail_frames ? tail_ms / tail_frames : 0.0, tail_frames,
+                pipeline ? "kOnDemand + pipeline_frames" : "kEveryFrame layer sync");
 
   vxb::BlockIndexList blocks;
   tsdf_layer.getAllAllocatedBlocks(&blocks);

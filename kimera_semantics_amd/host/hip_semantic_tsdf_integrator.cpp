@@ -1,5 +1,6 @@
 #include "hip_semantic_tsdf_integrator.h"
 
+#include <cstddef>
 #include <cstring>
 
 namespace kimera {
@@ -139,6 +140,27 @@ void HipSemanticTsdfIntegrator::integratePointCloud(const vxb::Transformation& T
   if (options_.sync_policy == SyncPolicy::kEveryFrame) syncLayers();
 }
 
+uint8_t* HipSemanticTsdfIntegrator::Staging::reserve(size_t bytes) {
+  if (bytes > cap) {
+    ks_host_free(p);
+    cap = bytes + bytes / 4;
+    p = static_cast<uint8_t*>(ks_host_alloc(cap));
+    CHECK(p != nullptr) << "ks_host_alloc(" << cap << ") failed";
+  }
+  return p;
+}
+HipSemanticTsdfIntegrator::Staging::~Staging() { ks_host_free(p); }
+
+namespace {
+// The wire records of ks_download_blocks / ks_upload_blocks ARE the host voxel types when those
+// are laid out as upstream's (TsdfVoxel 12 B: distance, weight, rgba; SemanticVoxel 92 B: label,
+// 21 priors, rgba): a block is then one memcpy instead of a per-field loop.
+constexpr bool kTsdfLayoutMatches = sizeof(vxb::TsdfVoxel) == 12 && offsetof(vxb::TsdfVoxel, weight) == 4 &&
+                                    offsetof(vxb::TsdfVoxel, color) == 8 && sizeof(vxb::Color) == 4;
+constexpr bool kSemLayoutMatches = sizeof(SemanticVoxel) == 92 && offsetof(SemanticVoxel, semantic_priors) == 4 &&
+                                   offsetof(SemanticVoxel, color) == 88 && sizeof(HashableColor) == 4;
+}  // namespace
+
 void HipSemanticTsdfIntegrator::syncLayers() {
   size_t n = 0;
   check(ks_get_updated_block_indices(ctx_, nullptr, 0, &n, 0), "ks_get_updated_block_indices");
@@ -147,29 +169,39 @@ void HipSemanticTsdfIntegrator::syncLayers() {
   check(ks_get_updated_block_indices(ctx_, idx_buf_.data(), n, &n, 1), "ks_get_updated_block_indices");
   const size_t vps = layer_->voxels_per_side();
   const size_t nv = vps * vps * vps;
-  tsdf_buf_.resize(n * nv * 12);
-  sem_buf_.resize(n * nv * 92);
-  check(ks_download_blocks(ctx_, idx_buf_.data(), n, tsdf_buf_.data(), sem_buf_.data()), "ks_download_blocks");
+  uint8_t* tsdf = tsdf_buf_.reserve(n * nv * 12);
+  uint8_t* sem = sem_buf_.reserve(n * nv * 92);
+  check(ks_download_blocks(ctx_, idx_buf_.data(), n, tsdf, sem), "ks_download_blocks");
   for (size_t b = 0; b < n; ++b) {
     const vxb::BlockIndex idx(idx_buf_[3 * b], idx_buf_[3 * b + 1], idx_buf_[3 * b + 2]);
     auto tb = layer_->allocateBlockPtrByIndex(idx);
     auto sb = semantic_layer_ptr_->allocateBlockPtrByIndex(idx);
-    const uint8_t* t = tsdf_buf_.data() + b * nv * 12;
-    const uint8_t* s = sem_buf_.data() + b * nv * 92;
-    for (size_t i = 0; i < nv; ++i) {
-      vxb::TsdfVoxel& v = tb->getVoxelByLinearIndex(i);
-      std::memcpy(&v.distance, t + 12 * i, 4);
-      std::memcpy(&v.weight, t + 12 * i + 4, 4);
-      v.color = vxb::Color(t[12 * i + 8], t[12 * i + 9], t[12 * i + 10], t[12 * i + 11]);
-      SemanticVoxel& sv = sb->getVoxelByLinearIndex(i);
-      const uint8_t* r = s + 92 * i;
-      sv.semantic_label = r[0];
-      for (size_t l = 0; l < kTotalNumberOfLabels; ++l) {
-        float p;
-        std::memcpy(&p, r + 4 + 4 * l, 4);
-        sv.semantic_priors[l] = p;
+    const uint8_t* t = tsdf + b * nv * 12;
+    const uint8_t* s = sem + b * nv * 92;
+    if (kTsdfLayoutMatches) {
+      std::memcpy(static_cast<void*>(&tb->getVoxelByLinearIndex(0)), t, nv * 12);
+    } else {
+      for (size_t i = 0; i < nv; ++i) {
+        vxb::TsdfVoxel& v = tb->getVoxelByLinearIndex(i);
+        std::memcpy(&v.distance, t + 12 * i, 4);
+        std::memcpy(&v.weight, t + 12 * i + 4, 4);
+        v.color = vxb::Color(t[12 * i + 8], t[12 * i + 9], t[12 * i + 10], t[12 * i + 11]);
       }
-      sv.color = HashableColor(r[88], r[89], r[90], r[91]);
+    }
+    if (kSemLayoutMatches) {
+      std::memcpy(static_cast<void*>(&sb->getVoxelByLinearIndex(0)), s, nv * 92);
+    } else {
+      for (size_t i = 0; i < nv; ++i) {
+        SemanticVoxel& sv = sb->getVoxelByLinearIndex(i);
+        const uint8_t* r = s + 92 * i;
+        sv.semantic_label = r[0];
+        for (size_t l = 0; l < kTotalNumberOfLabels; ++l) {
+          float p;
+          std::memcpy(&p, r + 4 + 4 * l, 4);
+          sv.semantic_priors[l] = p;
+        }
+        sv.color = HashableColor(r[88], r[89], r[90], r[91]);
+      }
     }
     tb->updated() = true;
     sb->updated() = true;
@@ -187,8 +219,10 @@ void HipSemanticTsdfIntegrator::uploadLayers() {
   const size_t vps = layer_->voxels_per_side();
   const size_t nv = vps * vps * vps;
   idx_buf_.resize(3 * n);
-  tsdf_buf_.assign(n * nv * 12, 0);
-  sem_buf_.assign(n * nv * 92, 0);
+  uint8_t* tsdf_stage = tsdf_buf_.reserve(n * nv * 12);
+  uint8_t* sem_stage = sem_buf_.reserve(n * nv * 92);
+  std::memset(tsdf_stage, 0, n * nv * 12);
+  std::memset(sem_stage, 0, n * nv * 92);
   const vxb::TsdfVoxel default_tsdf;
   const SemanticVoxel default_sem;
   for (size_t b = 0; b < n; ++b) {
@@ -198,8 +232,8 @@ void HipSemanticTsdfIntegrator::uploadLayers() {
     idx_buf_[3 * b + 2] = idx.z();
     const auto tb = layer_->getBlockPtrByIndex(idx);
     const auto sb = semantic_layer_ptr_->getBlockPtrByIndex(idx);
-    uint8_t* t = tsdf_buf_.data() + b * nv * 12;
-    uint8_t* s = sem_buf_.data() + b * nv * 92;
+    uint8_t* t = tsdf_stage + b * nv * 12;
+    uint8_t* s = sem_stage + b * nv * 92;
     for (size_t i = 0; i < nv; ++i) {
       const vxb::TsdfVoxel& v = tb ? tb->getVoxelByLinearIndex(i) : default_tsdf;
       std::memcpy(t + 12 * i, &v.distance, 4);
@@ -221,7 +255,7 @@ void HipSemanticTsdfIntegrator::uploadLayers() {
       r[91] = sv.color.a;
     }
   }
-  check(ks_upload_blocks(ctx_, idx_buf_.data(), n, tsdf_buf_.data(), sem_buf_.data()), "ks_upload_blocks");
+  check(ks_upload_blocks(ctx_, idx_buf_.data(), n, tsdf_stage, sem_stage), "ks_upload_blocks");
   // what was just uploaded is not "updated by integration"
   size_t m = 0;
   check(ks_get_updated_block_indices(ctx_, nullptr, 0, &m, 1), "ks_get_updated_block_indices");

@@ -75,8 +75,15 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
   DeviceOptions options_;
   ks_frame_stats last_stats_{};
   vxb::Layer<SemanticVoxel>* semantic_layer_ptr_;
+  // page-locked staging for layer transfers (ks_host_alloc); grows on demand
+  struct Staging {
+    uint8_t* p = nullptr;
+    size_t cap = 0;
+    uint8_t* reserve(size_t bytes);
+    ~Staging();
+  };
   std::vector<int32_t> idx_buf_;
-  std::vector<uint8_t> tsdf_buf_, sem_buf_;
+  Staging tsdf_buf_, sem_buf_;
 };
 
 /// Same shape as kimera::SemanticTsdfIntegratorFactory
