@@ -525,13 +525,20 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
     const bool time_apply = set >= 0 && c->pset[set].apply;
     if (time_apply) c->pset[set].applied = true;
-#define KS_LAUNCH_APPLY(MODE)                                                                                        \
+#define KS_LAUNCH_APPLY_M(MODE, MERGED)                                                                              \
   if (time_apply)                                                                                                    \
-    hipExtLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, c->pset[set].k0, c->pset[set].k1, 0, F, n_pairs, \
-                          sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut, c->d_long_list, S.d_counters); \
+    hipExtLaunchKernelGGL((k_apply<MODE, MERGED>), dim3(ab), dim3(256), 0, st, c->pset[set].k0, c->pset[set].k1, 0,   \
+                          F, n_pairs, sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut, c->d_long_list,    \
+                          S.d_counters);                                                                              \
   else                                                                                                               \
-    hipLaunchKernelGGL(k_apply<MODE>, dim3(ab), dim3(256), 0, st, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table,     \
-                       c->pool, c->d_label_lut, c->d_long_list, S.d_counters);                                        \
+    hipLaunchKernelGGL((k_apply<MODE, MERGED>), dim3(ab), dim3(256), 0, st, F, n_pairs, sp, S.d_rays, S.d_deltas,     \
+                       c->table, c->pool, c->d_label_lut, c->d_long_list, S.d_counters)
+#define KS_LAUNCH_APPLY(MODE)                                                                                        \
+  if (c->cfg.method == KS_METHOD_MERGED) {                                                                           \
+    KS_LAUNCH_APPLY_M(MODE, true);                                                                                   \
+  } else {                                                                                                           \
+    KS_LAUNCH_APPLY_M(MODE, false);                                                                                  \
+  }                                                                                                                  \
   stage_mark(c, set, 9);                                                                                             \
   hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(64), 0, st, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table,   \
                      c->pool, c->d_label_lut, c->d_long_list, S.d_counters)
@@ -541,6 +548,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
       default: KS_LAUNCH_APPLY(KS_COLOR_MODE_SEMANTIC_PROBABILITY); break;
     }
 #undef KS_LAUNCH_APPLY
+#undef KS_LAUNCH_APPLY_M
   } else {
     stage_mark(c, set, 7);
     stage_mark(c, set, 8);

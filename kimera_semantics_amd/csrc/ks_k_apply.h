@@ -57,7 +57,9 @@ __device__ __forceinline__ UpdateOps load_update_ops(const FrameParams& F, const
   return u;
 }
 
-template <int COLOR_MODE>
+// MERGED is a compile-time copy of F.method == KS_METHOD_MERGED (per-bundle increments, mixed-label
+// increment vectors): the step loop is instruction-issue bound, uniform run-time tests in it are not free.
+template <int COLOR_MODE, bool MERGED>
 __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long n_pairs,
                                                const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
                                                const float* __restrict__ deltas, TileTable T, Pool P,
@@ -144,13 +146,13 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
       const uint32_t src = on ? hp + s : lane;
       const float sdf_s = perm_f(u.sdf, src), uw_s = perm_f(u.uw, src);
       // fast: every ray carries the same two increments (log p, log(1-p)); merged: per bundle
-      const bool per_ray_inc = F.method == KS_METHOD_MERGED;
+      constexpr bool per_ray_inc = MERGED;
       const float dm_s = per_ray_inc ? perm_f(u.dm, src) : F.log_match;
       const float dn_s = per_ray_inc ? perm_f(u.dn, src) : F.log_non_match;
       const uint32_t info_s = perm_u(u.info, src);
       uint32_t color_s = 0, rp_s = 0;
       if (COLOR_MODE == KS_COLOR_MODE_COLOR) color_s = perm_u(u.color, src);
-      if (F.method == KS_METHOD_MERGED) rp_s = perm_u(u.rp, src);
+      if (MERGED) rp_s = perm_u(u.rp, src);
       // The step is straight-line code with selects: k_apply is bound by instruction issue (one
       // wave per SIMD slot), and the nested divergent branches of the obvious formulation cost
       // more scalar/branch instructions than the arithmetic they skip.  Every lane evaluates the
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
         p2 = pure ? a2 : p2;
         p3 = pure ? a3 : p3;
       }
-      if (F.method == KS_METHOD_MERGED) {  // mixed-label bundles carry a 21-entry increment vector
+      if (MERGED) {  // mixed-label bundles carry a 21-entry increment vector
         if (sem_lane && kind == 2u) {
           const float* dl = deltas + (size_t)rp_s * kNumLabels + cbase;
           p0 += dl[0];
