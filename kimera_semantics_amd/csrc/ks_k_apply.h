@@ -58,7 +58,7 @@ __device__ __forceinline__ UpdateOps load_update_ops(const FrameParams& F, const
 }
 
 // MERGED is a compile-time copy of F.method == KS_METHOD_MERGED (per-bundle increments, mixed-label
-// increment vectors): the step loop is instruction-issue bound, uniform run-time tests in it are not free.
+// increment vectors): uniform run-time tests in the step loop are not free.
 template <int COLOR_MODE, bool MERGED>
 __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long n_pairs,
                                                const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
       uint32_t color_s = 0, rp_s = 0;
       if (COLOR_MODE == KS_COLOR_MODE_COLOR) color_s = perm_u(u.color, src);
       if (MERGED) rp_s = perm_u(u.rp, src);
-      // The step is straight-line code with selects: k_apply is bound by instruction issue (one
+      // The step is straight-line code with selects: instruction issue is one of k_apply's limits (one
       // wave per SIMD slot), and the nested divergent branches of the obvious formulation cost
       // more scalar/branch instructions than the arithmetic they skip.  Every lane evaluates the
       // TSDF recurrence (only sub 0 keeps it) and its four class sums (only subs 1..6 of a
