@@ -42,18 +42,31 @@ struct UpdateOps {
   float sdf, uw, dm, dn;
   uint32_t info, color, rp;
 };
+// HOT_ONLY: only the first 16 bytes of the ray descriptor (point_G, weight) are gathered; label /
+// kind / clearing come from the top byte of the pair key, where k_march put them.  That is all the
+// `fast` integrator needs unless colours are blended: one random 16-B gather per update, not two.
+template <bool HOT_ONLY>
 __device__ __forceinline__ UpdateOps load_update_ops(const FrameParams& F, const RayDesc* __restrict__ rays, uint64_t key,
                                                      const VoxelRef& v) {
   UpdateOps u;
   u.rp = (uint32_t)key & F.point_mask;
   const uint4* r4 = (const uint4*)rays + (size_t)ray_index(F, u.rp) * 2;
-  const uint4 d0 = r4[0], d1 = r4[1];
+  const uint4 d0 = r4[0];
   tsdf_operands(F.tsdf, F.T.t, {__uint_as_float(d0.x), __uint_as_float(d0.y), __uint_as_float(d0.z)}, v.vx, v.vy, v.vz,
                 __uint_as_float(d0.w), u.sdf, u.uw);
-  u.color = d1.x;
-  u.dm = __uint_as_float(d1.y);
-  u.dn = __uint_as_float(d1.z);
-  u.info = d1.w;
+  if (HOT_ONLY) {
+    const uint32_t b = (uint32_t)(key >> 56);
+    u.color = 0u;
+    u.dm = F.log_match;
+    u.dn = F.log_non_match;
+    u.info = (b & 0x1fu) | (((b >> 5) & 3u) << 8) | (((b >> 7) & 1u) << 10);
+  } else {
+    const uint4 d1 = r4[1];
+    u.color = d1.x;
+    u.dm = __uint_as_float(d1.y);
+    u.dn = __uint_as_float(d1.z);
+    u.info = d1.w;
+  }
   return u;
 }
 
@@ -84,7 +97,7 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
     vox = (uint32_t)(key >> F.seq_bits);
     head = (i == 0) || ((uint32_t)(pairs[i - 1] >> F.seq_bits) != vox);
     if (head) is_long = (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> F.seq_bits) == vox);
-    u = load_update_ops(F, rays, key, voxel_ref(T, vox));
+    u = load_update_ops<!MERGED && COLOR_MODE != KS_COLOR_MODE_COLOR>(F, rays, key, voxel_ref(T, vox));
   }
   const uint32_t lpos = block_append(head && is_long, &C->n_long);
   if (head && is_long) long_list[lpos] = i;
@@ -201,7 +214,7 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
       for (unsigned long long j = wbase + 64ull; j < n_pairs; ++j) {
         const uint64_t k = pairs[j];
         if ((uint32_t)(k >> F.seq_bits) != hvox) break;
-        const UpdateOps t = load_update_ops(F, rays, k, v);
+        const UpdateOps t = load_update_ops<!MERGED && COLOR_MODE != KS_COLOR_MODE_COLOR>(F, rays, k, v);
         if (sub == 0u) {
           tsdf_combine<COLOR_MODE == KS_COLOR_MODE_COLOR>(F.tsdf, t.sdf, t.uw, t.color, dist, weight, color);
         } else if (sub < 7u) {

@@ -31,10 +31,12 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
   uint32_t seq = 0;
   bool clearing = false;
   uint64_t own_key = 0;
+  uint64_t info_hi = 0;  // label | kind << 5 | clearing << 7 in the key's top byte (rides through the sort)
   if (r < n_rays && (C->err & (kErrLabel | kErrIndex)) == 0) {
     const uint32_t p = ray_list[r];
     const RayDesc d = rays[ray_index(F, p)];
     clearing = ((d.info >> 10) & 1u) != 0;
+    info_hi = (uint64_t)((d.info & 0x1fu) | (((d.info >> 8) & 3u) << 5) | (((d.info >> 10) & 1u) << 7)) << 56;
     dda.setup(F.T.t, {d.px, d.py, d.pz}, clearing, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
               /*cast_from_origin=*/F.method == KS_METHOD_MERGED);
     // merged: normal bundles integrate before clearing bundles ([K:src/semantic_tsdf_integrator_merged.cpp:126-144])
@@ -170,7 +172,7 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
       if (emit) {
         const uint32_t local = (uint32_t)(vx[j] & 7) + 8u * ((uint32_t)(vy[j] & 7) + 8u * (uint32_t)(vz[j] & 7));
         const uint32_t pos = wcount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        buf[pos] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | seq;
+        buf[pos] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | seq | info_hi;
       }
       wcount += (uint32_t)__popcll(m);
       if (wcount > kWaveBuf - 64u) flush();
