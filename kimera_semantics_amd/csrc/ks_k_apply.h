@@ -84,6 +84,10 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
   //   128-byte record (one coalesced line per voxel); sub 0 walks the TSDF recurrence, subs
   //   1..6 own four class priors each.  The run's operands come from the phase-A lanes through
   //   ds_bpermute, so the recurrence has no memory access on its critical path.
+  // label -> colour table in LDS: a global lookup per voxel would sit, with its full latency, between
+  // the recurrence and the record store of every iteration
+  __shared__ uint32_t s_lut[256];
+  s_lut[threadIdx.x] = label_lut[threadIdx.x];  // 256 threads; made visible by block_append's barriers below
   const uint32_t lane = lane_id();
   const unsigned long long wbase = ((unsigned long long)blockIdx.x * 4ull + (threadIdx.x >> 6)) * 64ull;
   const unsigned long long i = wbase + lane;
@@ -124,24 +128,30 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
     const uint32_t p = perm_u(head_lane, r & 63u);
     return r < nh ? (int)p : -1;
   };
-  bool more = nh != 0u;
-  int nxt_pos = more ? next_head() : -1;
-  uint32_t nxt_vox = perm_u(vox, nxt_pos >= 0 ? (uint32_t)nxt_pos : lane);
-  uint4 nxt_q = make_uint4(0u, 0u, 0u, 0u);
-  if (nxt_pos >= 0 && sub < 7u) nxt_q = (P.vox + (size_t)nxt_vox * 8)[sub];
-  while (more) {
+  // the records of the next TWO groups of heads are in flight while the current one is applied
+  auto fetch = [&](int& pos, uint32_t& v, uint4& q) {
+    pos = (8u * it < nh) ? next_head() : (++it, -1);
+    v = perm_u(vox, pos >= 0 ? (uint32_t)pos : lane);
+    // UNCONDITIONAL load (idle groups read record 0, sub 7 reads the spare 16 bytes): a load under a
+    // divergent branch makes the compiler drain vmcnt at the join, which would serialise the prefetch
+    q = (P.vox + (size_t)(pos >= 0 ? v : 0u) * 8)[sub];
+  };
+  const uint32_t n_it = (nh + 7u) >> 3;
+  int nxt_pos, nxt2_pos;
+  uint32_t nxt_vox, nxt2_vox;
+  uint4 nxt_q, nxt2_q;
+  fetch(nxt_pos, nxt_vox, nxt_q);
+  fetch(nxt2_pos, nxt2_vox, nxt2_q);
+  for (uint32_t cur = 0; cur < n_it; ++cur) {
     const int my_pos = nxt_pos;
     const bool active = my_pos >= 0;
     const uint32_t hp = active ? (uint32_t)my_pos : lane;
     const uint32_t hvox = nxt_vox;
     const uint4 q = nxt_q;
-    more = 8u * it < nh;
-    if (more) {
-      nxt_pos = next_head();
-      nxt_vox = perm_u(vox, nxt_pos >= 0 ? (uint32_t)nxt_pos : lane);
-      nxt_q = make_uint4(0u, 0u, 0u, 0u);
-      if (nxt_pos >= 0 && sub < 7u) nxt_q = (P.vox + (size_t)nxt_vox * 8)[sub];
-    }
+    nxt_pos = nxt2_pos;
+    nxt_vox = nxt2_vox;
+    nxt_q = nxt2_q;
+    fetch(nxt2_pos, nxt2_vox, nxt2_q);
     // length of the run inside this window
     uint32_t len = 0;
     if (active) {
@@ -251,17 +261,19 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
       const uint32_t oi = perm_u(bi, lane ^ (uint32_t)o);
       if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
     }
-    if (active) {
-      if (sub == 0u) {
-        if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = label_lut[bi];
-        else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY) color = rainbow_color_map((double)(float)exp((double)bv));
-        rec[0] = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, bi);
-      } else if (sub < 6u) {
-        rec[sub] = make_uint4(__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3));
-      } else if (sub == 6u) {
-        rec[6] = make_uint4(__float_as_uint(p0), 0u, 0u, 0u);
-      }
-    }
+    // ONE unconditional 16-byte store per lane and iteration: idle groups and the spare lane (sub 7)
+    // write zeros into spare dwords (their own record's, or record 0's for an idle group).  With the
+    // stores under divergent branches the compiler cannot count the memory operations in flight and
+    // waits for ALL of them — including the previous iteration's stores — before it touches the
+    // prefetched record.
+    if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = s_lut[bi & 255u];
+    else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY) color = rainbow_color_map((double)(float)exp((double)bv));
+    uint4 outv = make_uint4(0u, 0u, 0u, 0u);
+    if (sub == 0u) outv = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, bi);
+    else if (sub < 6u) outv = make_uint4(__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3));
+    else if (sub == 6u) outv = make_uint4(__float_as_uint(p0), 0u, 0u, 0u);
+    const bool wr = active && sub < 7u;
+    rec[wr ? sub : 7u] = wr ? outv : make_uint4(0u, 0u, 0u, 0u);
   }
 }
 
