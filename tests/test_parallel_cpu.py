@@ -44,6 +44,8 @@ def _worker(rank, world, port, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lut = synth.default_label_colors()
+    import torch
+    assert PAR.warm_up(torch.device("cpu")) == world   # the bench's untimed connection warm-up
     store = M.NumpyTileStore(lut)
     for k, t in _make_rank_tiles(rank).items():
         store.add(k, t.copy())
