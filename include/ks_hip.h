@@ -99,8 +99,10 @@ enum {
   KS_STAGE_POINTS = 0,   /* per-point validity/transform/keys */
   KS_STAGE_SORT_POINTS,  /* dedup / bundling sort */
   KS_STAGE_RAYS,         /* dedup decision or bundle merge */
-  KS_STAGE_MARCH,        /* DDA count + tile allocation (+ observed-set early-out) */
-  KS_STAGE_EMIT,         /* DDA emit of (voxel, ray) pairs */
+  KS_STAGE_MARCH,        /* ONE DDA walk per ray: tile allocation, observed-set early-out, (voxel, ray) pair emission,
+                            counter snapshot (k_march + k_publish) */
+  KS_STAGE_EMIT,         /* start of the tail: initialisation of the tiles the march allocated (the name dates from a
+                            two-pass march; kept for ABI stability) */
   KS_STAGE_SORT_PAIRS,   /* group pairs by voxel in ray order */
   KS_STAGE_APPLY,        /* k_apply: per-voxel TSDF + semantic log-likelihood update (runs < 32 updates) */
   KS_STAGE_APPLY_LONG,   /* k_apply_long: one wavefront per voxel with >= 32 updates */
