@@ -109,3 +109,35 @@ def test_config_variants_match_reference(tmp_path, name, method):
         o.integrate(f.T_G_C, f.xyz, f.rgba if method == "fast" else None, f.labels, freespace=fs)
         r.integrate(f.T_G_C, f.xyz, f.rgba, freespace=fs)
     assert _same(o, r) > 300
+
+
+from tests.variants import random_combo  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("method", ["fast", "merged"])
+def test_random_knob_combinations_match_reference(tmp_path, seed, method):
+    """Seeded random combinations of the configuration knobs (their interactions), several frames
+    incl. a free-space cloud: oracle restatement == real reference sources, bit for bit."""
+    csv = _csv(tmp_path)
+    v = random_combo(seed)
+    okw = dict(COMMON, method=0 if method == "fast" else 1, bundle_order=0)
+    okw.update(v)
+    rkw = dict(v)
+    ref_args = {"color_mode": rkw.pop("color_mode"),
+                "order_mode": "sorted" if rkw.pop("integration_order_mode") == 1 else "mixed"}
+    for src, dst in (("voxel_size", "voxel_size"), ("truncation_distance", "truncation"), ("max_ray_length_m", "max_ray"),
+                     ("semantic_measurement_probability", "p_match")):
+        if src in rkw:
+            ref_args[dst] = rkw.pop(src)
+    if "dynamic_labels" in rkw:
+        ref_args["dynamic_labels"] = tuple(rkw.pop("dynamic_labels"))
+    o = O.Oracle(O.default_config(**okw))
+    r = R.Reference(method, csv, **ref_args, **rkw)
+    sc = synth.make_scene("room")
+    for k in range(3):
+        f = synth.render_frame(sc, synth.trajectory_pose(9 * k + seed), 80, 60, seed=900 + 10 * seed + k)
+        fs = (k == 1)
+        o.integrate(f.T_G_C, f.xyz, f.rgba if method == "fast" else None, f.labels, freespace=fs)
+        r.integrate(f.T_G_C, f.xyz, f.rgba, freespace=fs)
+    assert _same(o, r) > 100, v

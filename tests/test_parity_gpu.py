@@ -509,3 +509,25 @@ def test_pipelined_pool_exhaustion_is_reported():
     assert e.value.code == B.KS_ERR_POOL_FULL if hasattr(B, "KS_ERR_POOL_FULL") else e.value.code < 0
     with pytest.raises(B.KsError):          # the context stays in its failed state
         h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+
+
+from tests.variants import random_combo  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("method", [0, 1])
+def test_random_knob_combinations_exact(seed, method):
+    """Seeded random combinations of the configuration knobs (the same ones the CPU tier checks
+    oracle-vs-reference), alternately unpipelined / pipelined: HIP vs oracle, bit-exact."""
+    v = random_combo(seed)
+    kw = dict(COMMON, method=method, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    kw.update(v)
+    o = O.Oracle(O.default_config(**kw))
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 14, pipeline_frames=seed % 2, **kw))
+    sc = synth.make_scene("room")
+    for k in range(3):
+        f = synth.render_frame(sc, synth.trajectory_pose(9 * k + seed), 80, 60, seed=900 + 10 * seed + k)
+        fs = (k == 1)
+        o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels, freespace=fs)
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels, freespace=fs)
+    compare_maps(o, h, exact=True)

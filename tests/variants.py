@@ -16,3 +16,22 @@ VARIANTS = {
     "max_weight_2": dict(max_weight=2.0),
     "anti_grazing": dict(enable_anti_grazing=1),
 }
+
+
+def random_combo(seed: int) -> dict:
+    """A seeded random COMBINATION of the knobs above (interactions between options: carving x
+    clearing x drop-off x weights x ray limits x set bookkeeping x colour mode)."""
+    import numpy as np
+    rng = np.random.default_rng(1000 + seed)
+    names = sorted(VARIANTS)
+    kw = {}
+    for n in names:
+        if n in ("coarse_voxels",):   # keeps the 5 cm geometry the synthetic frames are made for
+            continue
+        if rng.random() < 0.4:
+            kw.update(VARIANTS[n])
+    if "start_voxel_subsampling_factor" not in kw and rng.random() < 0.3:
+        kw["start_voxel_subsampling_factor"] = float(rng.choice([1.5, 3.0]))
+    kw["color_mode"] = int(rng.integers(0, 3))
+    kw["integration_order_mode"] = int(rng.integers(0, 2))
+    return kw
