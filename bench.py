@@ -159,7 +159,7 @@ def main():
     # bag replay = a stream of frames: frame pipelining on (the host's one wait per frame overlaps
     # the next frame's GPU work; results are identical, see tests/test_parity_gpu.py)
     cfg = B.default_config(device_id=local_rank, max_tiles=1 << 13, max_points=args.width * args.height,
-                           pipeline_frames=0 if args.no_pipeline else 1, **common_cfg(args.method))
+                           pipeline_frames=0 if args.no_pipeline else 2, **common_cfg(args.method))
     integ = B.HipIntegrator(cfg)
 
     def step_on(h, i):
@@ -185,10 +185,10 @@ def main():
     updates = 0
     points = 0
     for i in range(W, W + K):
-        st = step(i)          # pipelined: statistics of the frame completed by this call
+        st = step(i)          # pipelined: statistics of the frame(s) completed by this call
         updates += st.n_voxel_updates
         points += st.n_points
-    st = integ.flush()        # the K-th frame's tail, inside the timed region
+    st = integ.flush()        # the tails of the last two frames, inside the timed region
     updates += st.n_voxel_updates
     points += st.n_points
     integ.synchronize()
@@ -273,7 +273,7 @@ def main():
             "frames_per_s": round(world * K / dt, 2),
             "config": {"workload": f"bag-replay stand-in: {args.width}x{args.height} depth+label trajectory, "
                                    f"'{args.method}' integrator, 5 cm voxels, 5 m rays, trunc 0.2 m, p=0.8",
-                       "frames_per_gpu": K, "pipeline_frames": 0 if args.no_pipeline else 1, "points_per_frame": int(points_all / max(1, world * K)),
+                       "frames_per_gpu": K, "pipeline_frames": 0 if args.no_pipeline else 2, "points_per_frame": int(points_all / max(1, world * K)),
                        "updates_per_frame": int(updates_all / max(1, world * K)),
                        "parallelism": f"frame-sharded x{world}" + (
                            " + one all-to-all tile reduce to hash-owners at the end (inside the timed region)"

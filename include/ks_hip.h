@@ -77,12 +77,16 @@ typedef struct ks_config {
   uint32_t max_tiles;               /* capacity of the 8^3-voxel tile pool (64 KiB each) */
   uint32_t max_points;              /* largest cloud per call (buffers grow on demand if exceeded) */
   /* 0 (default): an integrate call returns with its frame fully enqueued and its own statistics.
-   * 1: frame pipelining for streams of frames (bag replay): a call enqueues the front half of its
-   *    frame (points .. ray march), then finishes the PREVIOUS frame (pair sort + voxel update), so
-   *    the one host wait of a frame overlaps GPU work of the next; the statistics (and any
-   *    KS_ERR_LABEL_RANGE / pool error) a call returns are those of the previous frame.  Every
-   *    other entry point (queries, download, export, ks_synchronize, ks_flush) completes the
-   *    outstanding frame first, so the map they see is the same as without pipelining. */
+   * 1 or 2: frame pipelining for streams of frames (bag replay).  A call enqueues stages A and B of
+   *    its frame (points .. ray march), then finishes the frame 1 or 2 calls back (pair sort + voxel
+   *    update): the one host wait of a frame overlaps GPU work of later frames, and the stages of up
+   *    to three consecutive frames run concurrently on three streams.  With 2 the host never waits
+   *    for a march that is still running (best throughput; one more frame of latency).
+   *    The statistics a call returns are those of the frames completed since statistics were last
+   *    returned (summed if several), i.e. they lag by 1 or 2 calls; so do KS_ERR_LABEL_RANGE / pool
+   *    errors.  Every other entry point (queries, download, export, ks_synchronize, ks_flush)
+   *    completes the outstanding frames first, so the map they see is the same as without
+   *    pipelining. */
   int32_t pipeline_frames;
 } ks_config;
 
@@ -204,7 +208,7 @@ int ks_debug_radix_sort(ks_ctx* ctx, void* keys, uint32_t* vals, size_t n, int k
 int ks_synchronize(ks_ctx* ctx);
 void* ks_stream(ks_ctx* ctx); /* the hipStream_t that reads the caller's device inputs (stage A; with
                                 * pipeline_frames later stages run on two further internal streams) */
-/* Finish the frame a pipelined context still holds (no-op otherwise); stats = that frame's. */
+/* Finish the frames a pipelined context still holds (no-op otherwise); stats = theirs, summed. */
 int ks_flush(ks_ctx* ctx, ks_frame_stats* stats);
 /* level 0: off; 1: events around every stage and every k_apply dispatch (costs ~50 us of stream
  * bubbles per frame); 2: only the k_apply dispatch of every 4th frame is timed (a few us/frame).

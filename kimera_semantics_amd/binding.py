@@ -316,7 +316,7 @@ class HipIntegrator:
         self._chk(lib().ks_profile_enable(self._h, int(level)))
 
     def flush(self) -> KsFrameStats:
-        """Finish the frame a pipelined context still holds; returns that frame's statistics."""
+        """Finish the frames a pipelined context still holds; returns their statistics (summed)."""
         st = KsFrameStats()
         self._chk(lib().ks_flush(self._h, C.byref(st)))
         return st

@@ -73,7 +73,7 @@ std::string g_create_error;
 // neither A nor B touches voxel data.  The host's one wait per frame (for the snapshot that sizes
 // T) never idles the GPU.  Three slots rotate; stage A of a frame waits for the tail that last
 // used its slot.
-constexpr int kSlots = 3;
+constexpr int kSlots = 4;
 struct HostSnap {
   Counters c;
   uint32_t n_tiles;
@@ -102,7 +102,7 @@ struct FrameSlot {
 
 // HIP-event sets for ks_profile: recorded in stream order, resolved lazily (before reuse or in
 // ks_profile_get) so that profiling never adds a host wait to a frame.
-constexpr int kProfSets = 4;
+constexpr int kProfSets = 8;
 constexpr int kStageEvents = KS_STAGE_COUNT + 3;  // 0..3 stage A | 4,5 march begin/end | 6 tail begin, 7..10
 struct ProfSet {
   hipEvent_t ev[kStageEvents]{};
@@ -158,8 +158,7 @@ struct ks_ctx {
   uint8_t* d_state = nullptr;
   FrameSlot slot[kSlots];
   uint64_t frame_no = 0;
-  ks_frame_stats last_stats{};
-  bool stats_undelivered = false;  // a query completed a pipelined frame: its statistics go to the next call
+  ks_frame_stats owed{};  // statistics of frames completed but not yet handed to the caller (summed)
   int32_t* d_block_idx = nullptr;
   size_t cap_block_idx = 0;
   uint8_t *d_tsdf_out = nullptr, *d_sem_out = nullptr;
@@ -460,7 +459,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
 }
 
 // ---- tail half: sized by the snapshot --------------------------------------------------------
-int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
+int frame_tail(ks_ctx* c, FrameSlot& S) {
   if (!S.pending) return KS_OK;
   S.pending = false;
   hipStream_t st = c->stream_tail;  // the host wait below orders the tail after the slot's front
@@ -558,24 +557,27 @@ int frame_tail(ks_ctx* c, FrameSlot& S, ks_frame_stats* stats) {
   HIPCHK(c, hipEventRecord(S.tail_done, st));
   S.tail_recorded = true;
   HIPCHK(c, hipGetLastError());
-  c->last_stats = ks_frame_stats{};
-  c->last_stats.n_points = S.n;
-  c->last_stats.n_valid_points = cnt.n_valid;
-  c->last_stats.n_rays_cast = cnt.n_rays;
-  c->last_stats.n_voxel_updates = n_pairs;
-  c->last_stats.n_blocks_allocated = new_tiles - tiles_before;
-  c->stats_undelivered = stats == nullptr;
-  if (stats) *stats = c->last_stats;
+  c->owed.n_points += S.n;
+  c->owed.n_valid_points += cnt.n_valid;
+  c->owed.n_rays_cast += cnt.n_rays;
+  c->owed.n_voxel_updates += n_pairs;
+  c->owed.n_blocks_allocated += new_tiles - tiles_before;
   return KS_OK;
 }
 
+// hand the statistics of every frame completed since the last hand-over to the caller
+void deliver_stats(ks_ctx* c, ks_frame_stats* stats) {
+  if (stats) *stats = c->owed;
+  c->owed = ks_frame_stats{};
+}
+
 // run the tail of a frame whose front is still waiting for it (pipelined mode)
-int flush_pending(ks_ctx* c, ks_frame_stats* stats) {
-  // at most one slot is pending between calls; the older frame first in any case
+int flush_pending(ks_ctx* c) {
+  // up to two slots are pending between calls; oldest frame first
   for (int k = 0; k < kSlots; ++k) {
     FrameSlot& S = c->slot[(c->frame_no + k) % kSlots];
     if (S.pending) {
-      const int rc = frame_tail(c, S, stats);
+      const int rc = frame_tail(c, S);
       if (rc) return rc;
     }
   }
@@ -594,7 +596,7 @@ int ensure_exchange(ks_ctx* c, size_t n) {
 
 // complete every outstanding frame and drain both streams
 int quiesce(ks_ctx* c) {
-  const int rc = flush_pending(c, nullptr);
+  const int rc = flush_pending(c);
   if (c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
   if (c->stream_march != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_march));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -627,7 +629,7 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
   }
   if (n == 0) {
     if ((rc = quiesce(c))) return rc;
-    if (stats) stats->n_points = 0;
+    deliver_stats(c, stats);
     return KS_OK;
   }
   if (n > c->cap_points) {  // growing frees buffers a pending tail still needs
@@ -638,20 +640,25 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
     if ((rc = quiesce(c))) return rc;
     FrameSlot& S = c->slot[0];
     if ((rc = frame_front(c, S, Tq, d_xyz, d_rgba, d_labels, n, freespace))) return rc;
-    return frame_tail(c, S, stats);
+    rc = frame_tail(c, S);
+    deliver_stats(c, stats);
+    return rc;
   }
-  // pipelined: front of this frame first, then the tail of the previous one; the statistics
-  // returned are those of the frame whose tail ran here (the previous frame)
+  // pipelined: stages A and B of this frame first, then stage T of the frame `lag` calls back
+  // (its snapshot is long there: the host never waits for the march that is still running, and the
+  // next call can enqueue stage A while this frame's march is in flight); the statistics returned
+  // are those of the frames completed here
+  const uint64_t lag = cfg.pipeline_frames >= 2 ? 2u : 1u;
   FrameSlot& S = c->slot[c->frame_no % kSlots];
-  FrameSlot& prev = c->slot[(c->frame_no + kSlots - 1) % kSlots];
-  if (S.pending && (rc = frame_tail(c, S, nullptr))) return rc;  // cannot happen: slots alternate
+  if (S.pending && (rc = frame_tail(c, S))) return rc;  // cannot happen: the slot's frame is 4 calls old
+  const uint64_t this_frame = c->frame_no;
   if ((rc = frame_front(c, S, Tq, d_xyz, d_rgba, d_labels, n, freespace))) return rc;
-  if (prev.pending) return frame_tail(c, prev, stats);
-  if (c->stats_undelivered && stats) {
-    *stats = c->last_stats;
-    c->stats_undelivered = false;
+  if (this_frame >= lag) {
+    FrameSlot& due = c->slot[(this_frame - lag) % kSlots];
+    if (due.pending) rc = frame_tail(c, due);
   }
-  return KS_OK;
+  deliver_stats(c, stats);
+  return rc;
 }
 
 int integrate_device(ks_ctx* c, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba, const uint8_t* d_labels,
@@ -861,12 +868,15 @@ void ks_destroy(ks_ctx* c) {
   if (c->stream_march && c->stream_march != c->stream) (void)hipStreamSynchronize(c->stream_march);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
-                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->slot[0].d_rays, c->slot[1].d_rays, c->slot[2].d_rays, c->slot[0].d_deltas, c->slot[1].d_deltas, c->slot[2].d_deltas, c->slot[0].d_ray_list, c->slot[1].d_ray_list, c->slot[2].d_ray_list, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
+                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
-                  c->slot[0].d_pairs, c->slot[1].d_pairs, c->slot[2].d_pairs, c->d_pairs2, c->d_state, c->d_xchg_u32, c->d_xchg_u64,
+                  c->d_pairs2, c->d_state, c->d_xchg_u32, c->d_xchg_u64,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  for (auto& S : c->slot)
+    for (void* p : {(void*)S.d_rays, (void*)S.d_deltas, (void*)S.d_ray_list, (void*)S.d_pairs})
+      if (p) (void)hipFree(p);
   ksrs::release(c->sort_ws);
   ksrs::release(c->sort_ws_tail);
   for (auto& S : c->slot) {
@@ -1264,10 +1274,8 @@ int ks_clear(ks_ctx* c) {
 int ks_flush(ks_ctx* c, ks_frame_stats* stats) {
   if (!c) return KS_ERR_INVALID_ARG;
   if (stats) std::memset(stats, 0, sizeof(*stats));
-  const bool had = c->slot[0].pending || c->slot[1].pending;
-  const int rc = flush_pending(c, stats);
-  if (rc == KS_OK && !had && c->stats_undelivered && stats) *stats = c->last_stats;
-  if (stats) c->stats_undelivered = false;
+  const int rc = flush_pending(c);
+  deliver_stats(c, stats);
   return rc;
 }
 

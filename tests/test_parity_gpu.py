@@ -531,3 +531,25 @@ def test_random_knob_combinations_exact(seed, method):
         o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels, freespace=fs)
         h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels, freespace=fs)
     compare_maps(o, h, exact=True)
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_pipeline_depth_two(method):
+    """pipeline_frames = 2: the tail of frame i is enqueued by the call for frame i+2.  Same map,
+    statistics lag by two calls, every frame's statistics are handed over exactly once."""
+    kw = dict(COMMON, method=method, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    o = O.Oracle(O.default_config(**kw))
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, pipeline_frames=2, **kw))
+    sc = synth.make_scene("room")
+    ref, got = [], []
+    for k in range(9):
+        f = synth.render_frame(sc, synth.trajectory_pose(3 * k), 128, 96, seed=1300 + k)
+        so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        ref.append((so.n_points, so.n_rays_cast, so.n_voxel_updates))
+        sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        got.append((sh.n_points, sh.n_rays_cast, sh.n_voxel_updates))
+    assert got[0] == (0, 0, 0) and got[1] == (0, 0, 0) and got[2:] == ref[:7], (ref, got)
+    last = h.flush()                       # frames 7 and 8, summed
+    assert (last.n_points, last.n_rays_cast, last.n_voxel_updates) == tuple(a + b for a, b in zip(ref[7], ref[8]))
+    assert h.flush().n_points == 0
+    compare_maps(o, h, exact=True)
