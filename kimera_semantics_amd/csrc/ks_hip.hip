@@ -462,6 +462,9 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
 int frame_tail(ks_ctx* c, FrameSlot& S) {
   if (!S.pending) return KS_OK;
   S.pending = false;
+  // After a pool / index failure the table may hold entries without a tile: frames that were
+  // already in flight are dropped, never applied (the error has been reported for the frame that hit it).
+  if (c->fatal) return KS_OK;
   hipStream_t st = c->stream_tail;  // the host wait below orders the tail after the slot's front
   const FrameParams& F = S.F;
   {
@@ -1260,6 +1263,7 @@ int ks_merge_tiles_device(ks_ctx* c, const uint64_t* keys, size_t n, const void*
 int ks_clear(ks_ctx* c) {
   if (!c) return KS_ERR_INVALID_ARG;
   for (auto& S : c->slot) S.pending = false;  // a frame that was never applied is dropped with the map
+  c->owed = ks_frame_stats{};
   if (c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
   if (c->stream_march != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_march));
   HIPCHK(c, hipStreamSynchronize(c->stream));

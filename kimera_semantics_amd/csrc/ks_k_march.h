@@ -167,6 +167,7 @@ __global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __
         }
         slot = got;
         if (slot < T.max_tiles) P.updated[slot] = 1;
+        else atomicOr(&C->err, kErrPool);  // a tile an earlier frame failed to allocate: this frame must not be applied either
       }
       const unsigned long long m = __ballot(emit);
       if (emit) {

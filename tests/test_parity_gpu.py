@@ -509,6 +509,25 @@ def test_pipelined_pool_exhaustion_is_reported():
     assert e.value.code == B.KS_ERR_POOL_FULL if hasattr(B, "KS_ERR_POOL_FULL") else e.value.code < 0
     with pytest.raises(B.KsError):          # the context stays in its failed state
         h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    assert len(h.tile_keys()) <= 8          # queries still work; frames in flight were dropped, not applied
+    h.clear()                               # and the context is usable again after a clear
+    small = np.array([[0.3, 0.1, 1.0]], np.float32)
+    h.integrate(np.array([1, 0, 0, 0, 0, 0, 0], np.float32), small, None, np.array([2], np.uint8))
+    assert h.flush().n_voxel_updates > 0
+
+
+def test_pool_exhaustion_with_frames_in_flight():
+    """pipeline depth 2: the frame after the one that exhausts the pool is already marching when the
+    failure is noticed; it must be dropped, not applied on tiles that do not exist."""
+    h = B.HipIntegrator(B.default_config(max_tiles=8, max_points=1 << 15, pipeline_frames=2, **dict(COMMON, method=1)))
+    sc = synth.make_scene("room")
+    with pytest.raises(B.KsError):
+        for k in range(4):
+            f = synth.render_frame(sc, synth.trajectory_pose(k), 128, 96, seed=k)
+            h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        h.flush()
+    assert len(h.tile_keys()) <= 8
+    h.synchronize()
 
 
 from tests.variants import random_combo  # noqa: E402
