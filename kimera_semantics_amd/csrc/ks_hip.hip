@@ -67,11 +67,11 @@ std::string g_create_error;
 // ks_config.pipeline_frames the three stages of a frame run on three streams,
 //   A  points -> sort -> dedup / bundles          (stream)
 //   B  ray march + snapshot                        (stream_march, after A of the same frame)
-//   T  init tiles -> sort pairs -> apply           (stream_tail, enqueued by the NEXT call)
+//   T  init tiles -> sort pairs -> apply           (stream_tail, enqueued 1 or 2 calls later)
 // so that A(i+1), B(i) and T(i-1) execute concurrently: the march is bound by device-scope atomic
 // throughput, the sorts by dependent-launch latency, the voxel update by memory latency, and
 // neither A nor B touches voxel data.  The host's one wait per frame (for the snapshot that sizes
-// T) never idles the GPU.  Three slots rotate; stage A of a frame waits for the tail that last
+// T) never idles the GPU.  Four slots rotate; stage A of a frame waits for the tail that last
 // used its slot.
 constexpr int kSlots = 4;
 struct HostSnap {
