@@ -542,7 +542,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     KS_LAUNCH_APPLY_M(MODE, false);                                                                                  \
   }                                                                                                                  \
   stage_mark(c, set, 9);                                                                                             \
-  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(64), 0, st, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table,   \
+  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(128), 0, st, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table,   \
                      c->pool, c->d_label_lut, c->d_long_list, S.d_counters)
     switch (c->cfg.color_mode) {
       case KS_COLOR_MODE_COLOR: KS_LAUNCH_APPLY(KS_COLOR_MODE_COLOR); break;

@@ -278,16 +278,24 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
 }
 
 template <int COLOR_MODE>
-__global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long long n_pairs,
+__global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long long n_pairs,
                                                    const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
                                                    const float* __restrict__ deltas, TileTable T, Pool P,
                                                    const uint32_t* __restrict__ label_lut,
                                                    const unsigned long long* __restrict__ long_list, const Counters* C) {
-  // One wavefront per block: LDS traffic below is ordered by program order (DS operations of
-  // a wave execute in order), no s_barrier needed; wave_barrier() only pins the compiler.
-  __shared__ float s_inc[64][kNumLabels];  // class increments of the 64 updates in flight
+  // TWO wavefronts per run.  A lone wave is bound by instruction issue (one instruction every four
+  // cycles): wave 0 (producer) gathers the rays of a 64-update batch, evaluates the state-
+  // independent half of the update per lane, walks the weight / distance recurrences and writes
+  // the 64 x 21 class increments to LDS; wave 1 (consumer) owns the 21 class sums and folds the
+  // increments of the PREVIOUS batch in, in order, at the same time.  One workgroup barrier per
+  // batch hands a double-buffered increment block over.
+  __shared__ float s_inc[2][64][kNumLabels];  // class increments of the 64 updates of a batch
+  __shared__ int s_cnt[2];                    // updates in the batch (0: the run has ended)
+  __shared__ uint32_t s_best;
+  __shared__ float s_best_val;
   const uint32_t n_long = C->n_long;
   const int lane = (int)lane_id();
+  const bool consumer = (threadIdx.x >> 6) != 0u;
   const int cls = lane < kNumLabels ? lane : 0;
   const TsdfParams& Pm = F.tsdf;
   for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
@@ -297,7 +305,45 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
     uint32_t* rec = (uint32_t*)(P.vox + (size_t)vox * 8);
     float dist = __uint_as_float(rec[0]), weight = __uint_as_float(rec[1]);
     uint32_t color = rec[2];
-    float pri = (lane < kNumLabels) ? __uint_as_float(rec[4 + lane]) : 0.0f;
+    if (consumer) {
+      // ---- wave 1: the semantic log-likelihood sums, lane l owns class l ----
+      float pri = (lane < kNumLabels) ? __uint_as_float(rec[4 + lane]) : 0.0f;
+      for (int buf = 0;; buf ^= 1) {
+        __syncthreads();  // batch `buf` is complete
+        const int cnt = s_cnt[buf];
+        if (cnt == 0) break;
+        if (cnt == 64) {
+          // full batch: all 64 increments are requested from LDS before the first dependent add
+          float x[64];
+#pragma unroll
+          for (int k = 0; k < 64; ++k) x[k] = s_inc[buf][k][cls];
+#pragma unroll
+          for (int k = 0; k < 64; ++k) pri += x[k];
+        } else {
+#pragma unroll 8
+          for (int k = 0; k < cnt; ++k) pri += s_inc[buf][k][cls];
+        }
+        if (cnt < 64) break;
+      }
+      // argmax over lanes 0..20, first strict maximum
+      int best = 0;
+      float m = bcast_f(pri, 0);
+#pragma unroll
+      for (int l = 1; l < kNumLabels; ++l) {
+        const float x = bcast_f(pri, l);
+        if (x > m) { m = x; best = l; }
+      }
+      if (lane < kNumLabels) rec[4 + lane] = __float_as_uint(pri);
+      if (lane == 0) {
+        s_best = (uint32_t)best;
+        s_best_val = m;
+      }
+      __syncthreads();  // label for the producer's record head
+      __syncthreads();  // LDS free for the next run
+      continue;
+    }
+    // ---- wave 0: everything else ----
+    int buf = 0;
     // voxel centre and the origin->centre vector are constant over the run
     const f3 c = {((float)v.vx + 0.5f) * Pm.voxel_size, ((float)v.vy + 0.5f) * Pm.voxel_size,
                   ((float)v.vz + 0.5f) * Pm.voxel_size};
@@ -314,7 +360,11 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
     RayDesc d = rays[ray_index(F, (uint32_t)key_cur & F.point_mask)];
     for (;;) {
       const int cnt = (int)__popcll(__ballot(in));  // sorted => the in-lanes form a prefix
-      if (cnt == 0) break;
+      if (cnt == 0) {
+        if (lane == 0) s_cnt[buf] = 0;
+        __syncthreads();
+        break;
+      }
       const bool in_n = (base + 64ull + lane < n_pairs) && ((uint32_t)(key_nxt >> F.seq_bits) == vox);
       const RayDesc d_n = rays[ray_index(F, (uint32_t)key_nxt & F.point_mask)];
       const uint64_t key_nn = pairs[min(base + 128ull + lane, last)];
@@ -339,11 +389,11 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
         if (kind == 2u) {
           const float* dl = deltas + (size_t)((uint32_t)key_cur & F.point_mask) * kNumLabels;
 #pragma unroll
-          for (int l = 0; l < kNumLabels; ++l) s_inc[lane][l] = dl[l];
+          for (int l = 0; l < kNumLabels; ++l) s_inc[buf][lane][l] = dl[l];
         } else {
           const float a = (kind == 1u) ? d.d_match : 0.0f, b = (kind == 1u) ? d.d_non : 0.0f;
 #pragma unroll
-          for (int l = 0; l < kNumLabels; ++l) s_inc[lane][l] = ((uint32_t)l == lab) ? a : b;
+          for (int l = 0; l < kNumLabels; ++l) s_inc[buf][lane][l] = ((uint32_t)l == lab) ? a : b;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -389,20 +439,10 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
           dist = (q > 0.0f) ? std_min(Pm.trunc, q) : std_max(-Pm.trunc, q);
         }
       }
-      // ---- pass 3: semantic log-likelihood, lane l owns class l; increments stream from LDS ----
-      if (cnt == 64) {
-        // full batch: all 64 increments are requested from LDS before the first dependent add
-        // (this wave is alone on its SIMD: nothing else hides the LDS latency)
-        float x[64];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) x[k] = s_inc[k][cls];
-#pragma unroll
-        for (int k = 0; k < 64; ++k) pri += x[k];
-      } else {
-#pragma unroll 8
-        for (int k = 0; k < cnt; ++k) pri += s_inc[k][cls];
-      }
-      __builtin_amdgcn_wave_barrier();
+      // ---- hand the increments of this batch to the consumer wave ----
+      if (lane == 0) s_cnt[buf] = cnt;
+      __syncthreads();
+      buf ^= 1;
       if (cnt < 64) break;
       d = d_n;
       in = in_n;
@@ -410,20 +450,14 @@ __global__ void __launch_bounds__(64) k_apply_long(FrameParams F, unsigned long 
       key_nxt = key_nn;
       base += 64;
     }
-    // argmax over lanes 0..20, first strict maximum
-    int best = 0;
-    float m = bcast_f(pri, 0);
-#pragma unroll
-    for (int l = 1; l < kNumLabels; ++l) {
-      const float x = bcast_f(pri, l);
-      if (x > m) { m = x; best = l; }
-    }
+    __syncthreads();  // the consumer has the label
+    const uint32_t best = s_best;
+    const float m = s_best_val;
     if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = label_lut[best];
     else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY)
       color = rainbow_color_map((double)(float)exp((double)m));
-    if (lane < kNumLabels) rec[4 + lane] = __float_as_uint(pri);
-    if (lane == 0) *(uint4*)rec = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, (uint32_t)best);
-    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) *(uint4*)rec = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, best);
+    __syncthreads();  // LDS free for the next run
   }
 }
 
