@@ -64,3 +64,25 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_py" not in txt and "ks_oracle" not in txt and "libks_oracle" not in txt, f
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    """sizeof / offsetof of the ABI structs as gcc sees include/ks_hip.h == the ctypes mirrors."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "ks_hip.h"\n'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ks_config), sizeof(ks_frame_stats), sizeof(ks_profile),'
+        ' offsetof(ks_config, label_rgba), offsetof(ks_config, pipeline_frames), offsetof(ks_profile, apply_kernel_ms),'
+        ' offsetof(ks_profile, host_wait_ms)); return 0;}\n')
+    exe = tmp_path / "sz"
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.check_call(["gcc", "-I", inc, "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    want = [ctypes.sizeof(B.KsConfig), ctypes.sizeof(B.KsFrameStats), ctypes.sizeof(B.KsProfile),
+            B.KsConfig.label_rgba.offset, B.KsConfig.pipeline_frames.offset, B.KsProfile.apply_kernel_ms.offset,
+            B.KsProfile.host_wait_ms.offset]
+    assert got == want

@@ -38,7 +38,7 @@ def run(name, method, n_frames, cpu_frames, max_tiles):
         frames.append(synth.render_frame(sc, T, c["w"], c["h"], hfov_deg=c["hfov"], seed=k))
     dev = [(torch.from_numpy(f.xyz).cuda(), torch.from_numpy(f.rgba).cuda(), torch.from_numpy(f.labels).cuda()) for f in frames]
     # timed pass: pipelined frames (a stream of frames), no per-stage events
-    h = B.HipIntegrator(B.default_config(max_tiles=max_tiles, max_points=c["w"] * c["h"], pipeline_frames=1, **kw))
+    h = B.HipIntegrator(B.default_config(max_tiles=max_tiles, max_points=c["w"] * c["h"], pipeline_frames=2, **kw))
     torch.cuda.synchronize()
     upd = 0
     t0 = time.perf_counter()
