@@ -171,7 +171,8 @@ def main():
 
     for i in range(W):
         step(i)
-    integ.synchronize()       # completes the last warm-up frame: nothing is pending at t0
+    integ.flush()             # completes the warm-up frames AND hands their statistics over (discarded):
+    integ.synchronize()       # nothing is pending or owed at t0
     torch.cuda.synchronize()
     if world > 1:
         from kimera_semantics_amd import parallel as PAR

@@ -936,8 +936,9 @@ int ks_integrate_points(ks_ctx* c, const float T[7], const float* xyz, const uin
     c->err = "labels == NULL requires rgba and a colour map (ks_set_color_to_label)";
     return KS_ERR_INVALID_ARG;
   }
-  int rc = ensure_points(c, n);
-  if (rc) return rc;
+  int rc;
+  if (n > c->cap_points && (rc = quiesce(c))) return rc;  // growing frees buffers a pending tail still needs
+  if ((rc = ensure_points(c, n))) return rc;
   if (n) {
     HIPCHK(c, hipMemcpyAsync(c->d_xyz, xyz, n * 12, hipMemcpyHostToDevice, c->stream));
     if (rgba) HIPCHK(c, hipMemcpyAsync(c->d_rgba, rgba, n * 4, hipMemcpyHostToDevice, c->stream));
@@ -948,8 +949,9 @@ int ks_integrate_points(ks_ctx* c, const float T[7], const float* xyz, const uin
 
 static int integrate_depth_impl(ks_ctx* c, const float T[7], DepthParams D, int freespace, ks_frame_stats* stats) {
   const size_t n_px = (size_t)D.width * D.height;
-  int rc = ensure_points(c, n_px);
-  if (rc) return rc;
+  int rc;
+  if (n_px > c->cap_points && (rc = quiesce(c))) return rc;  // growing frees buffers a pending tail still needs
+  if ((rc = ensure_points(c, n_px))) return rc;
   const uint32_t nb = (uint32_t)((n_px + 1023) / 1024);
   if (nb + 1 > c->cap_depth_blocks) {
     if ((rc = dev_alloc(c, &c->d_depth_blocks, (size_t)nb + 1))) return rc;
@@ -1270,6 +1272,14 @@ int ks_clear(ks_ctx* c) {
   HIPCHK(c, hipMemset(c->table.ent, 0xff, ((size_t)c->table.mask + 1) * sizeof(TileEntry)));
   HIPCHK(c, hipMemset(c->pool.updated, 0, c->cfg.max_tiles));
   HIPCHK(c, hipMemset(c->d_state, 0, 64 * (kSlots + 1)));
+  // a cleared context behaves like a fresh one: both approximate sets as their constructor leaves them
+  HIPCHK(c, hipMemset(c->d_start_set, 0, sizeof(uint64_t) << kSetBits));
+  HIPCHK(c, hipMemset(c->d_observed_set, 0, sizeof(uint64_t) << kSetBits));
+  const uint64_t poison = ~0ull;
+  HIPCHK(c, hipMemcpy(c->d_start_set, &poison, 8, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_observed_set, &poison, 8, hipMemcpyHostToDevice));
+  c->start_offset = c->observed_offset = 0;
+  c->reset_counter = 0;
   c->tiles_initialised = 0;
   c->fatal = false;
   return KS_OK;

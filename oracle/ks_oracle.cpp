@@ -847,6 +847,145 @@ int ko_integrate_points(ko_ctx* ctx, const float Tq[7], const float* xyz, const 
   return 0;
 }
 
+
+// Design-study / test diagnostic: the voxels the `fast` integrator UPDATES for one frame on fresh
+// approximate sets (first frame of a context), without touching any voxel state.
+//   n_bounds == 0 : the reference's serial order, [K:semantic_tsdf_integrator_fast.cpp:57-143]
+//   n_bounds  > 0 : the ORDERED-WINDOW schedule of the GPU path: integration positions are cut into
+//                   windows [bounds[i], bounds[i+1]); every ray of a window tests against the
+//                   observed set as it stood when the window began, then the window's marks are
+//                   applied in serial order (last writer of a slot wins).
+// Writes the sorted unique packed voxel keys (21 bits per axis, biased) of the updated voxels to
+// out_keys (up to cap) and returns their number; *n_updates = updates with multiplicity.
+size_t ko_sim_early_out(const ko_config* cfg, const float Tq[7], const float* xyz, const uint8_t* labels, size_t n,
+                        const uint32_t* bounds, size_t n_bounds, uint64_t* out_keys, size_t cap, uint64_t* n_updates) {
+  ko_ctx* c = nullptr;
+  if (ko_create(cfg, &c) != 0) return 0;
+  Transform T;
+  T.w = Tq[0];
+  T.v = {Tq[1], Tq[2], Tq[3]};
+  T.t = {Tq[4], Tq[5], Tq[6]};
+  c->start_voxel_set.reset();
+  c->voxel_observed_set.reset();
+  IndexGetter getter;
+  getter.init(cfg->integration_order_mode, xyz, n);
+  struct Ray { V3 pg; bool clearing; uint32_t pos; };
+  std::vector<Ray> rays;
+  size_t idx;
+  uint32_t pos = 0;
+  while (getter.next(&idx)) {
+    const uint32_t p = pos++;
+    const V3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+    bool clr;
+    if (!c->is_point_valid(pc, false, &clr) || !c->is_semantic_label_valid(labels[idx])) continue;
+    const V3 pg = transform_point(T, pc);
+    const I3 g = grid_index_from_point(pg, cfg->start_voxel_subsampling_factor * c->voxel_size_inv);
+    if (!c->start_voxel_set.replace_hash(LongIndexHash()(g))) continue;
+    rays.push_back({pg, clr, p});
+  }
+  std::vector<uint64_t> keys;
+  uint64_t updates = 0;
+  auto pack = [](const I3& v) {
+    return ((uint64_t)(v.x + (1 << 20)) << 42) | ((uint64_t)(v.y + (1 << 20)) << 21) | (uint64_t)(v.z + (1 << 20));
+  };
+  ApproxHashSet& S = c->voxel_observed_set;
+  const int64_t lim = cfg->max_consecutive_ray_collisions;
+  if (n_bounds == 0) {
+    for (const Ray& r : rays) {
+      RayCaster caster(T.t, r.pg, r.clearing, cfg->voxel_carving_enabled != 0, cfg->max_ray_length_m, c->voxel_size_inv,
+                       cfg->truncation_distance, false);
+      I3 v;
+      int64_t consecutive = 0;
+      while (caster.next(&v)) {
+        if (!S.replace_hash(LongIndexHash()(v))) ++consecutive;
+        else consecutive = 0;
+        if (consecutive > lim) break;
+        keys.push_back(pack(v));
+        ++updates;
+      }
+    }
+  } else if (n_bounds >= 2 && bounds[0] == 0xffffffffu) {
+    // CHAIN schedule: bounds = {0xffffffff, chains, gens_per_phase}.  chain = pos % chains; a phase covers
+    // gens_per_phase generations (pos / chains).  A ray sees the set as of the phase start plus the marks
+    // its OWN chain made earlier in the phase.
+    const uint32_t chains = bounds[1], gpp = bounds[2];
+    // gpp == 0: explicit generation boundaries follow (bounds[3..], ascending, first = 0)
+    auto phase_of = [&](uint32_t pos) -> uint32_t {
+      const uint32_t g = pos / chains;
+      if (gpp) return g / gpp;
+      uint32_t ph = 0;
+      for (size_t i = 3; i < n_bounds; ++i) if (g >= bounds[i]) ph = (uint32_t)(i - 3);
+      return ph;
+    };
+    std::vector<std::pair<size_t, size_t>> marks;
+    std::vector<std::unordered_map<size_t, size_t>> priv(chains);
+    size_t r0 = 0;
+    while (r0 < rays.size()) {
+      const uint32_t phase = phase_of(rays[r0].pos);
+      marks.clear();
+      for (auto& m : priv) m.clear();
+      size_t r1 = r0;
+      for (; r1 < rays.size() && phase_of(rays[r1].pos) == phase; ++r1) {
+        const Ray& r = rays[r1];
+        auto& pm = priv[r.pos % chains];
+        RayCaster caster(T.t, r.pg, r.clearing, cfg->voxel_carving_enabled != 0, cfg->max_ray_length_m, c->voxel_size_inv,
+                         cfg->truncation_distance, false);
+        I3 v;
+        int64_t consecutive = 0;
+        while (caster.next(&v)) {
+          const size_t h = LongIndexHash()(v);
+          const size_t slot = (h + S.offset) & ApproxHashSet::kMask;
+          auto it = pm.find(slot);
+          const size_t content = (it != pm.end()) ? it->second : S.slots[slot].load(std::memory_order_relaxed);
+          if (content == h) ++consecutive;
+          else consecutive = 0;
+          pm[slot] = h;
+          marks.push_back({slot, h});
+          if (consecutive > lim) break;
+          keys.push_back(pack(v));
+          ++updates;
+        }
+      }
+      for (const auto& m : marks) S.slots[m.first].store(m.second, std::memory_order_relaxed);
+      r0 = r1;
+    }
+  } else {
+    size_t r0 = 0;
+    std::vector<std::pair<size_t, size_t>> marks;  // (slot, hash) in serial order
+    for (size_t w = 0; w < n_bounds; ++w) {
+      const uint32_t end = (w + 1 < n_bounds) ? bounds[w + 1] : 0xffffffffu;
+      marks.clear();
+      size_t r1 = r0;
+      for (; r1 < rays.size() && rays[r1].pos < end; ++r1) {
+        const Ray& r = rays[r1];
+        RayCaster caster(T.t, r.pg, r.clearing, cfg->voxel_carving_enabled != 0, cfg->max_ray_length_m, c->voxel_size_inv,
+                         cfg->truncation_distance, false);
+        I3 v;
+        int64_t consecutive = 0;
+        while (caster.next(&v)) {
+          const size_t h = LongIndexHash()(v);
+          const size_t slot = (h + S.offset) & ApproxHashSet::kMask;
+          if (S.slots[slot].load(std::memory_order_relaxed) == h) ++consecutive;
+          else consecutive = 0;
+          marks.push_back({slot, h});
+          if (consecutive > lim) break;
+          keys.push_back(pack(v));
+          ++updates;
+        }
+      }
+      for (const auto& m : marks) S.slots[m.first].store(m.second, std::memory_order_relaxed);
+      r0 = r1;
+    }
+  }
+  std::sort(keys.begin(), keys.end());
+  keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+  if (n_updates) *n_updates = updates;
+  const size_t m = std::min(cap, keys.size());
+  if (out_keys) std::memcpy(out_keys, keys.data(), m * sizeof(uint64_t));
+  ko_destroy(c);
+  return keys.size();
+}
+
 size_t ko_num_blocks(ko_ctx* ctx) { return ctx->tsdf_layer.blocks.size(); }
 size_t ko_num_semantic_blocks(ko_ctx* ctx) { return ctx->semantic_layer.blocks.size(); }
 

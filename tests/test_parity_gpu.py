@@ -572,3 +572,22 @@ def test_pipeline_depth_two(method):
     assert (last.n_points, last.n_rays_cast, last.n_voxel_updates) == tuple(a + b for a, b in zip(ref[7], ref[8]))
     assert h.flush().n_points == 0
     compare_maps(o, h, exact=True)
+
+
+def test_clear_then_integrate_equals_fresh_context():
+    """ks_clear drops the map AND the integrator's approximate sets: with
+    clear_checks_every_n_frames > 1 stale set entries would otherwise suppress rays of the first
+    frames after the clear."""
+    kw = dict(COMMON, method=0, clear_checks_every_n_frames=3)
+    sc = synth.make_scene("room")
+    frames = [synth.render_frame(sc, synth.trajectory_pose(2 * k), 128, 96, seed=40 + k) for k in range(4)]
+    a = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **kw))
+    for f in frames[:2]:
+        a.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    a.clear()
+    b = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **kw))
+    for f in frames[2:]:
+        sa = a.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        sb = b.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        assert (sa.n_valid_points, sa.n_rays_cast, sa.n_voxel_updates) == (sb.n_valid_points, sb.n_rays_cast, sb.n_voxel_updates)
+    compare_maps(b, a, exact=True)
