@@ -8,9 +8,16 @@ parameters (5 cm voxels, 5 m rays, truncation 4 voxels, early-out after 2 consec
 already-observed voxels, p=0.8, dynamic label 20).  One step = one frame integrated into
 the GPU-resident map through the C ABI, inputs already resident in HBM.
 
-Prints ONE JSON line (rank 0).  value = voxel updates/s over the whole job (all ranks),
-where a voxel update is one (ray, voxel) pair for which the reference runs
-updateTsdfVoxel + updateSemanticVoxel (semantic_tsdf_integrator_fast.cpp:128-140).
+Prints ONE JSON line (rank 0).
+  value = voxel updates/s over the whole job, where a voxel update is one (ray, voxel) pair for which
+          the reference runs updateTsdfVoxel + updateSemanticVoxel (semantic_tsdf_integrator_fast.cpp:128-140)
+          and N_updates is the count the SERIAL REFERENCE ORDER (CPU oracle, one thread) gives for the timed
+          frames — the GPU's own count (it runs the deterministic ordered-phase schedule,
+          ~10 % more updates) is reported next to it as gpu_counted_value.
+  roofline = the whole frame against the HBM roofline (lead figure), every stage's share of the frame, and
+          the per-voxel update kernel (k_apply) on its own, all from HIP events of this run.
+  secondary = the same measurement for C3 (`merged`) and C4 (1280x720, 2 cm, 10 m; `fast` and `merged`),
+          so that the driver — not the builder — produces those numbers (N = 1 only).
 """
 from __future__ import annotations
 
@@ -19,8 +26,6 @@ import json
 import os
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -33,6 +38,13 @@ try:
 except Exception:
     METRIC = "Mvoxel-updates/s + frames/s, 640x480 @5cm voxels, 1/2/4/8 MI355X"
 
+WORKLOADS = {
+    "C2": dict(scene="room", w=640, h=480, hfov=90.0, voxel=0.05, max_ray=5.0, radius=1.5, method="fast"),
+    "C3": dict(scene="room", w=640, h=480, hfov=90.0, voxel=0.05, max_ray=5.0, radius=1.5, method="merged"),
+    "C4-fast": dict(scene="hall", w=1280, h=720, hfov=75.0, voxel=0.02, max_ray=10.0, radius=3.0, method="fast"),
+    "C4-merged": dict(scene="hall", w=1280, h=720, hfov=75.0, voxel=0.02, max_ray=10.0, radius=3.0, method="merged"),
+}
+
 
 def parse():
     ap = argparse.ArgumentParser()
@@ -44,19 +56,45 @@ def parse():
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 sub-records")
+    ap.add_argument("--no-oracle-count", action="store_true",
+                    help="value falls back to the GPU's own update count (marked in the output)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="ks_config.pipeline_frames=0: every call completes its own frame (host wait not overlapped)")
     return ap.parse_args()
 
 
-def common_cfg(method):
+def integ_cfg(wl, method=None):
     from kimera_semantics_amd import synth
-    return dict(method=0 if method == "fast" else 1, voxel_size=0.05, voxels_per_side=16,
-                truncation_distance=0.2, max_ray_length_m=5.0, semantic_measurement_probability=0.8,
+    method = method or wl["method"]
+    return dict(method=0 if method == "fast" else 1, voxel_size=wl["voxel"], voxels_per_side=16,
+                truncation_distance=4 * wl["voxel"], max_ray_length_m=wl["max_ray"], semantic_measurement_probability=0.8,
                 dynamic_labels=[20], label_rgba=synth.default_label_colors())
 
 
-def cpu_baseline(args, frames):
+def common_cfg(method):
+    return integ_cfg(WORKLOADS["C2"], method)
+
+
+def make_frames(wl, indices):
+    from kimera_semantics_amd import synth
+    scene = synth.make_scene(wl["scene"])
+    return [synth.render_frame(scene, synth.trajectory_pose(k, radius=wl["radius"]), wl["w"], wl["h"], hfov_deg=wl["hfov"], seed=k)
+            for k in indices]
+
+
+def oracle_counts(wl, frames):
+    """Voxel updates per frame in the SERIAL REFERENCE ORDER (CPU oracle, one thread, reference defaults).
+    Neither integrator's update count depends on the map, and `fast`'s early-out sets are per frame, so the
+    counts of the timed frames do not need the warm-up frames."""
+    from oracle import oracle_py as O
+    o = O.Oracle(O.default_config(integrator_threads=1, **integ_cfg(wl)))
+    out = [int(o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates) for f in frames]
+    o.close()
+    return out
+
+
+def cpu_baseline(args, wl, frames, upd_serial):
     """CPU baseline on this host's cores, on a bounded sample of the same workload.
     kind "reference": oracle/_ref/libks_ref.so = the REAL Kimera-Semantics integrator sources
     compiled (in the build container) against the Voxblox header shims; it has no update counter,
@@ -72,28 +110,16 @@ def cpu_baseline(args, frames):
     cores = os.cpu_count() or 1
     n = min(args.cpu_frames, len(frames))
     thread_counts = sorted({1, min(8, cores), cores})
-    # the port: timing + the update counts
     port = {}
-    upd_serial = None
     for threads in thread_counts:
         nf = n if threads > 1 else max(1, n // 2)
-        o = O.Oracle(O.default_config(integrator_threads=threads, **common_cfg(args.method)))
+        o = O.Oracle(O.default_config(integrator_threads=threads, **integ_cfg(wl)))
         upd = 0
-        per_frame = []
         t0 = time.perf_counter()
         for f in frames[:nf]:
-            st = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
-            upd += st.n_voxel_updates
-            per_frame.append(st.n_voxel_updates)
+            upd += o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
         dt = time.perf_counter() - t0
         port[threads] = (upd / dt / 1e6, nf / dt, nf)
-        if threads == 1:
-            upd_serial = per_frame
-        o.close()
-    if upd_serial is None or len(upd_serial) < n:
-        # single-thread counts for every sampled frame (the reference is credited with these)
-        o = O.Oracle(O.default_config(integrator_threads=1, **common_cfg(args.method)))
-        upd_serial = [o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates for f in frames[:n]]
         o.close()
     kind, tried = "port", port
     if R.available():
@@ -104,8 +130,8 @@ def cpu_baseline(args, frames):
             ref = {}
             for threads in thread_counts:
                 nf = n if threads > 1 else max(1, n // 2)
-                r = R.Reference(args.method, csv, voxel_size=0.05, vps=16, truncation=0.2, max_ray=5.0, p_match=0.8,
-                                color_mode=1, dynamic_labels=(20,), threads=threads)
+                r = R.Reference(wl["method"], csv, voxel_size=wl["voxel"], vps=16, truncation=4 * wl["voxel"],
+                                max_ray=wl["max_ray"], p_match=0.8, color_mode=1, dynamic_labels=(20,), threads=threads)
                 t0 = time.perf_counter()
                 for f in frames[:nf]:
                     r.integrate(f.T_G_C, f.xyz, f.rgba)
@@ -122,9 +148,133 @@ def cpu_baseline(args, frames):
             "frames_per_s": round(tried[best][1], 3), "host_cores": cores,
             "by_threads": {str(t): round(v[0], 4) for t, v in tried.items()},
             "port_by_threads": {str(t): round(v[0], 4) for t, v in port.items()},
-            "sample": f"first {tried[best][2]} frames of the same trajectory through {what}, "
+            "sample": f"first {tried[best][2]} timed frames of the same trajectory through {what}, "
                       f"'mixed' order, reference defaults; best of integrator_threads in {sorted(tried)}"
                       + ("; updates counted by the port in single-thread order" if kind == "reference" else "")}
+
+
+def measure(B, torch, dist, dev, wl, frames, W, K, pipeline, max_tiles, world, reduce_fn=None):
+    """Integrates frames[0 : W + K] as a stream; times the last K of them (barrier + synchronize on both
+    sides).  Returns wall time, the GPU's statistics over EXACTLY the timed frames, and the HIP-event profiles."""
+    cfg = B.default_config(device_id=dev.index or 0, max_tiles=max_tiles, max_points=max(f.xyz.shape[0] for f in frames),
+                           pipeline_frames=pipeline, **integ_cfg(wl))
+    integ = B.HipIntegrator(cfg)
+    d_frames = [(torch.from_numpy(f.xyz).to(dev), torch.from_numpy(f.rgba).to(dev), torch.from_numpy(f.labels).to(dev))
+                for f in frames]
+
+    def step(i):
+        x, c, l = d_frames[i]
+        return integ.integrate_device(frames[i].T_G_C, x.data_ptr(), c.data_ptr(), l.data_ptr(), x.shape[0])
+
+    for i in range(W):
+        step(i)
+    integ.flush()             # completes the warm-up frames AND hands their statistics over (discarded):
+    integ.synchronize()       # nothing is pending or owed at t0
+    # level 2: only the k_apply dispatch of every 4th frame carries HIP events (per-stage events
+    # would put stream bubbles into every timed frame)
+    integ.profile_enable(2)
+    integ.profile(reset=True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    updates = points = rays = 0
+    for i in range(W, W + K):
+        st = step(i)          # pipelined: statistics of the frame(s) completed by this call
+        updates += st.n_voxel_updates
+        points += st.n_points
+        rays += st.n_rays_cast
+    st = integ.flush()        # the tails of the last frames, inside the timed region
+    updates += st.n_voxel_updates
+    points += st.n_points
+    rays += st.n_rays_cast
+    integ.synchronize()
+    reduce_stats = reduce_fn(integ) if reduce_fn else None
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof = integ.profile(reset=True)
+    want_points = sum(int(f.xyz.shape[0]) for f in frames[W:W + K])
+    assert points == want_points, f"statistics cover {points} points, the timed frames hold {want_points}"
+    # per-stage breakdown: separate untimed pass over the last frames with events around every stage
+    integ.profile_enable(1)
+    for i in range(max(W, W + K - 10), W + K):
+        step(i)
+    integ.flush()
+    stage_prof = integ.profile()
+    integ.profile_enable(0)
+    n_tiles = len(integ.tile_keys())
+    integ.close()
+    del d_frames
+    return dict(dt=dt, updates=updates, points=points, rays=rays, prof=prof, stage_prof=stage_prof, reduce=reduce_stats,
+                tiles=n_tiles)
+
+
+def gpu_counts(B, torch, dev, wl, frames, max_tiles):
+    """The GPU's own per-frame update counts for a few frames (unpipelined; for the oracle/GPU ratio)."""
+    cfg = B.default_config(device_id=dev.index or 0, max_tiles=max_tiles, max_points=max(f.xyz.shape[0] for f in frames),
+                           pipeline_frames=0, **integ_cfg(wl))
+    integ = B.HipIntegrator(cfg)
+    out = [int(integ.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates) for f in frames]
+    integ.close()
+    return out
+
+
+def roofline_of(m, K, upd_counted, world=1):
+    """Whole frame + per stage + k_apply, all against the HBM roofline (algorithmic bytes)."""
+    prof, sp = m["prof"], m["stage_prof"]
+    frame_s = m["dt"] / K
+    whole_bytes = (BYTES_PER_UPDATE * upd_counted + BYTES_PER_POINT * m["points"] / world) / K   # per GPU
+    whole_gbs = whole_bytes / frame_s / 1e9
+    nfr = max(1, sp["frames"])
+    stage_ms = {k: v / nfr for k, v in sp["ms"].items()}
+    tot = sum(stage_ms.values()) or 1.0
+    upd_pf, pts_pf = sp["updates"] / nfr, sp["points"] / nfr
+    stage_bytes = {"points": BYTES_PER_POINT * pts_pf, "apply": BYTES_PER_UPDATE * upd_pf}  # the stages that move the algorithmic bytes
+    stages = {}
+    for k, v in stage_ms.items():
+        e = {"ms_per_frame": round(v, 4), "share_of_kernel_time": round(v / tot, 4)}
+        if k in stage_bytes and v > 0:
+            gbs = stage_bytes[k] / (v * 1e-3) / 1e9
+            e.update({"achieved": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 5)})
+        stages[k] = e
+    dominant = max(stage_ms, key=lambda k: stage_ms[k])
+    apply_ms = prof["apply_kernel_ms"] / max(1, prof["apply_kernel_launches"])
+    upd_per_launch = prof["apply_kernel_updates"] / max(1, prof["apply_kernel_launches"])
+    a_gbs = BYTES_PER_UPDATE * upd_per_launch / (apply_ms * 1e-3) / 1e9 if apply_ms > 0 else 0.0
+    return {
+        "bound": "hbm", "kernel": "whole frame (all stages, wall clock of the timed region)",
+        "achieved": round(whole_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole_gbs / HBM_PEAK_GBS, 5),
+        "traffic": None,
+        "traffic_note": "not measured in this run; PMC FETCH/WRITE of named kernels on their own workloads: profiles/*pmc*",
+        "algorithmic_bytes_per_frame": int(whole_bytes),
+        "dominant_stage": dominant,
+        "stages": stages,
+        "stage_note": "HIP events around every stage: separate untimed pass over the last 10 frames (stages of one frame back to "
+                      "back); march = early-out phases + scan + pair emission, sort_* = radix sorts, apply(+_long) = per-voxel update",
+        "k_apply": {"achieved": round(a_gbs, 2), "frac": round(a_gbs / HBM_PEAK_GBS, 5), "avg_launch_ms": round(apply_ms, 5),
+                    "algorithmic_bytes_per_launch": int(BYTES_PER_UPDATE * upd_per_launch),
+                    "timed_launches": prof["apply_kernel_launches"],
+                    "note": "events attached to the k_apply dispatch of every 4th timed frame (GPU's own update count); other "
+                            "stages of neighbouring frames share the GPU (pipelined)"},
+    }
+
+
+def record(name, wl, m, K, counted, how, world=1):
+    """One result record (the primary line's core fields, also used for the secondary configs)."""
+    dt, gpu_upd = m["dt"], m["updates"]
+    return {
+        "config": name,
+        "workload": f"{wl['w']}x{wl['h']} depth+label trajectory ({wl['scene']}), '{wl['method']}' integrator, "
+                    f"{wl['voxel'] * 100:g} cm voxels, {wl['max_ray']:g} m rays, trunc {4 * wl['voxel']:g} m, p=0.8",
+        "value": round(counted / dt / 1e6, 3), "unit": "Mvoxel-updates/s", "updates_counted_by": how,
+        "gpu_counted_value": round(gpu_upd / dt / 1e6, 3),
+        "ms_per_step": round(dt / (K / world) * 1e3, 4), "frames_per_s": round(K / dt, 2), "steps": K // world,
+        "points_per_frame": int(m["points"] / K), "rays_per_frame": int(m["rays"] / K),
+        "updates_per_frame": int(counted / K), "gpu_updates_per_frame": int(gpu_upd / K), "tiles": m["tiles"],
+        "roofline": roofline_of(m, K // world, counted / world, world),
+    }
 
 
 def main():
@@ -132,7 +282,6 @@ def main():
     import torch
     import torch.distributed as dist
     from kimera_semantics_amd import binding as B
-    from kimera_semantics_amd import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -146,155 +295,101 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     K, W = args.steps, args.warmup
+    wl = dict(WORKLOADS["C2"], w=args.width, h=args.height, method=args.method)
     # frame-sharded: rank r integrates trajectory frames r, r+world, ... (weak scaling: K+W frames per GPU)
-    scene = synth.make_scene("room")
-    frames = []
-    for k in range(K + W):
-        gk = rank + world * k
-        frames.append(synth.render_frame(scene, synth.trajectory_pose(gk), args.width, args.height, seed=gk))
-    d_frames = []
-    for f in frames:
-        d_frames.append((torch.from_numpy(f.xyz).to(dev), torch.from_numpy(f.rgba).to(dev),
-                         torch.from_numpy(f.labels).to(dev)))
-    # bag replay = a stream of frames: frame pipelining on (the host's one wait per frame overlaps
-    # the next frame's GPU work; results are identical, see tests/test_parity_gpu.py)
-    cfg = B.default_config(device_id=local_rank, max_tiles=1 << 13, max_points=args.width * args.height,
-                           pipeline_frames=0 if args.no_pipeline else 2, **common_cfg(args.method))
-    integ = B.HipIntegrator(cfg)
+    frames = make_frames(wl, [rank + world * k for k in range(K + W)])
+    pipeline = 0 if args.no_pipeline else 2   # bag replay = a stream of frames: frame pipelining on
 
-    def step_on(h, i):
-        x, c, l = d_frames[i]
-        return h.integrate_device(frames[i].T_G_C, x.data_ptr(), c.data_ptr(), l.data_ptr(), x.shape[0])
-
-    def step(i):
-        return step_on(integ, i)
-
-    for i in range(W):
-        step(i)
-    integ.flush()             # completes the warm-up frames AND hands their statistics over (discarded):
-    integ.synchronize()       # nothing is pending or owed at t0
-    torch.cuda.synchronize()
+    reduce_fn = None
     if world > 1:
         from kimera_semantics_amd import parallel as PAR
         PAR.warm_up(dev)   # RCCL connects peers lazily: not part of the steady state being timed
-        dist.barrier()
-    # level 2: only the k_apply dispatch of every 4th frame carries HIP events (per-stage events
-    # would put ~50 us of stream bubbles into every timed frame)
-    integ.profile_enable(2)
-    integ.profile(reset=True)
-    t0 = time.perf_counter()
-    updates = 0
-    points = 0
-    for i in range(W, W + K):
-        st = step(i)          # pipelined: statistics of the frame(s) completed by this call
-        updates += st.n_voxel_updates
-        points += st.n_points
-    st = integ.flush()        # the tails of the last two frames, inside the timed region
-    updates += st.n_voxel_updates
-    points += st.n_points
-    integ.synchronize()
-    reduce_stats = None
-    if world > 1:
-        # the one exchange step of the frame-sharded path: per-rank partial maps -> owner-sharded
-        # global map (all-to-all of touched tiles over RCCL/xGMI + deterministic owner merge)
-        from kimera_semantics_amd import parallel as PAR
-        reduce_stats = PAR.reduce_maps(PAR.HipTileStore(integ, dev))
-        integ.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    prof = integ.profile(reset=True)
-    # per-stage breakdown: separate untimed pass over the last frames with events around every stage
-    integ.profile_enable(1)
-    for i in range(max(W, W + K - 10), W + K):
-        step(i)
-    integ.flush()
-    stage_prof = integ.profile()
-    integ.profile_enable(0)
-    # k_apply ALONE on the GPU (no other stage overlapping it): a second, unpipelined context over
-    # the same frames; reported next to the timed-region figure as roofline.isolated
-    iso = None
-    if rank == 0 and world == 1 and not args.no_pipeline:
-        cfg0 = B.default_config(device_id=local_rank, max_tiles=1 << 13, max_points=args.width * args.height,
-                                pipeline_frames=0, **common_cfg(args.method))
-        solo = B.HipIntegrator(cfg0)
-        for i in range(min(W + K, 30)):
-            if i == min(W + K, 30) - 10:
-                solo.synchronize()
-                solo.profile_enable(1)
-            step_on(solo, i)
-        iso = solo.profile()
-        solo.close()
+
+        def reduce_fn(integ):
+            # the one exchange step of the frame-sharded path: per-rank partial maps -> owner-sharded
+            # global map (all-to-all of touched tiles over RCCL/xGMI + deterministic owner merge)
+            st = PAR.reduce_maps(PAR.HipTileStore(integ, dev))
+            integ.synchronize()
+            return st
+
+    m = measure(B, torch, dist, dev, wl, frames, W, K, pipeline, 1 << 13, world, reduce_fn=reduce_fn)
+
+    # N_updates in the serial reference order for this rank's timed frames (outside the timed region)
+    upd_serial = None if args.no_oracle_count else oracle_counts(wl, frames[W:W + K])
+    upd_oracle = sum(upd_serial) if upd_serial is not None else None
 
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([m["dt"]], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        u = torch.tensor([updates, points], device=dev, dtype=torch.float64)
+        m["dt"] = float(t.item())
+        u = torch.tensor([m["updates"], m["points"], m["rays"], upd_oracle if upd_oracle is not None else 0], device=dev,
+                         dtype=torch.float64)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
-        updates_all, points_all = int(u[0].item()), int(u[1].item())
-    else:
-        updates_all, points_all = updates, points
+        m["updates"], m["points"], m["rays"] = int(u[0].item()), int(u[1].item()), int(u[2].item())
+        upd_oracle = int(u[3].item()) if upd_oracle is not None else None
 
     if rank == 0:
-        # roofline of the dominant kernel (k_apply: the per-voxel TSDF + semantic RMW), from
-        # HIP events recorded on the integrator's own stream inside the timed region.
-        # k_apply dispatch begin->end (events attached to the dispatch itself, on the integrator's stream)
-        apply_ms = prof["apply_kernel_ms"] / max(1, prof["apply_kernel_launches"])
-        upd_per_launch = prof["apply_kernel_updates"] / max(1, prof["apply_kernel_launches"])
-        pts_per_launch = prof["points"] / max(1, prof["frames"])
-        alg_bytes = BYTES_PER_UPDATE * upd_per_launch
-        achieved = alg_bytes / (apply_ms * 1e-3) / 1e9 if apply_ms > 0 else 0.0
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_apply.json")
-        if os.path.exists(pmc_path):
-            try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        stage_ms = {k: round(v / max(1, stage_prof["frames"]), 4) for k, v in stage_prof["ms"].items()}
-        whole_frame_alg = (BYTES_PER_UPDATE * updates + BYTES_PER_POINT * points) / K
-        isolated = None
-        if iso and iso["apply_kernel_launches"]:
-            i_ms = iso["apply_kernel_ms"] / iso["apply_kernel_launches"]
-            i_bytes = BYTES_PER_UPDATE * iso["apply_kernel_updates"] / iso["apply_kernel_launches"]
-            i_gbs = i_bytes / (i_ms * 1e-3) / 1e9
-            isolated = {"achieved": round(i_gbs, 2), "frac": round(i_gbs / HBM_PEAK_GBS, 5),
-                        "avg_launch_ms": round(i_ms, 5), "launches": iso["apply_kernel_launches"],
-                        "note": "same kernel with nothing else on the GPU (unpipelined context, untimed pass)"}
+        dt = m["dt"]
+        Kall = K * world
+        counted = upd_oracle if upd_oracle is not None else m["updates"]
+        how = ("serial reference order (CPU oracle, 1 thread), every timed frame" if upd_oracle is not None
+               else "GPU's own count (oracle count skipped)")
+        rec = record("C2" if args.method == "fast" else "C3", wl, m, Kall, counted, how, world)
         out = {
             "metric": METRIC,
-            "value": round(updates_all / dt / 1e6, 3),
-            "unit": "Mvoxel-updates/s",
+            "value": rec["value"], "unit": rec["unit"],
             "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "frames_per_s": round(world * K / dt, 2),
-            "config": {"workload": f"bag-replay stand-in: {args.width}x{args.height} depth+label trajectory, "
-                                   f"'{args.method}' integrator, 5 cm voxels, 5 m rays, trunc 0.2 m, p=0.8",
-                       "frames_per_gpu": K, "pipeline_frames": 0 if args.no_pipeline else 2, "points_per_frame": int(points_all / max(1, world * K)),
-                       "updates_per_frame": int(updates_all / max(1, world * K)),
+            "frames_per_s": round(Kall / dt, 2),
+            "gpu_counted_value": rec["gpu_counted_value"],
+            "updates_counted_by": how,
+            "config": {"workload": "bag-replay stand-in: " + rec["workload"],
+                       "frames_per_gpu": K, "pipeline_frames": pipeline,
+                       "points_per_frame": rec["points_per_frame"], "rays_per_frame": rec["rays_per_frame"],
+                       "updates_per_frame": rec["updates_per_frame"], "gpu_updates_per_frame": rec["gpu_updates_per_frame"],
+                       "early_out": ("ordered-phase schedule, doubling phases: deterministic, bit-exact vs its CPU restatement, "
+                                     "touched-set Jaccard 0.976 vs the serial reference order") if args.method == "fast" else "n/a (merged)",
                        "parallelism": f"frame-sharded x{world}" + (
                            " + one all-to-all tile reduce to hash-owners at the end (inside the timed region)"
                            if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": "k_apply", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(apply_ms, 5),
-                         "timed_launches": prof["apply_kernel_launches"],
-                         "overlapped": not args.no_pipeline, "isolated": isolated,
-                         "whole_frame_frac": round(whole_frame_alg / (dt / K) / 1e9 / HBM_PEAK_GBS, 5)},
-            "stage_ms_per_frame": stage_ms,
-            "host_ms_per_frame": {"in_call": round(prof["host_ms"] / max(1, prof["frames"]), 4),
-                                  "of_which_waiting_for_snapshot": round(prof["host_wait_ms"] / max(1, prof["frames"]), 4)},
+            "roofline": rec["roofline"],
+            "host_ms_per_frame": {"in_call": round(m["prof"]["host_ms"] / max(1, m["prof"]["frames"]), 4),
+                                  "of_which_waiting_for_snapshot": round(m["prof"]["host_wait_ms"] / max(1, m["prof"]["frames"]), 4)},
         }
-        if reduce_stats is not None:
-            out["reduce"] = reduce_stats
-        if not args.no_cpu_baseline and world == 1:   # reported on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, frames[W:])
+        if m["reduce"] is not None:
+            out["reduce"] = m["reduce"]
+        if not args.no_cpu_baseline and world == 1 and upd_serial is not None:   # reported on rank 0 at N=1 only
+            out["cpu_baseline"] = cpu_baseline(args, wl, frames[W:], upd_serial)
+        if world == 1 and not args.no_secondary:
+            sec = []
+            for name, steps, warm, tiles, n_oracle in (("C3", 20, 3, 1 << 13, 20), ("C4-fast", 12, 2, 1 << 16, 1),
+                                                       ("C4-merged", 12, 2, 1 << 16, 1)):
+                if name == "C3" and args.method == "merged":
+                    continue
+                try:
+                    swl = WORKLOADS[name]
+                    sfr = make_frames(swl, range(steps + warm))
+                    sm = measure(B, torch, dist, dev, swl, sfr, warm, steps, pipeline, tiles, 1)
+                    counted, how = sm["updates"], "GPU's own count (oracle count skipped)"
+                    if not args.no_oracle_count:
+                        oc = oracle_counts(swl, sfr[warm:warm + n_oracle])
+                        if n_oracle == steps:
+                            counted, how = sum(oc), "serial reference order (CPU oracle, 1 thread), every timed frame"
+                        else:   # the serial oracle needs ~10 s per C4 frame: count a sample, scale the GPU count by its ratio
+                            g = gpu_counts(B, torch, dev, swl, sfr[warm:warm + n_oracle], tiles)
+                            ratio = sum(oc) / max(1, sum(g))
+                            counted = sm["updates"] * ratio
+                            how = (f"GPU count x (serial-oracle / GPU) measured on the first {n_oracle} timed frame(s): "
+                                   f"x{ratio:.4f} (oracle {sum(oc)}, GPU {sum(g)})")
+                    sec.append(record(name, swl, sm, steps, counted, how))
+                    del sfr
+                    torch.cuda.empty_cache()
+                except Exception as e:   # a secondary record must never take the primary line down
+                    sec.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+            out["secondary"] = sec
         print(json.dumps(out), flush=True)
-    integ.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -72,6 +72,14 @@ typedef struct ks_config {
   int32_t n_dynamic_labels;
   uint8_t dynamic_labels[32];
   uint8_t label_rgba[256][4];       /* label -> colour (SemanticLabel2Color::semantic_label_to_color_map_) */
+  /* fast integrator with the early-out enabled (max_consecutive_ray_collisions below the ray length):
+   * the reference's loop (semantic_tsdf_integrator_fast.cpp:110-122) is serial by construction — ray k
+   * stops on the marks rays 1..k-1 left in the approximate set.  The GPU runs the ORDERED-PHASE schedule
+   * (restated for the CPU in oracle/ks_oracle.cpp, against which it is bit-exact):
+   * integration positions are cut into phases whose length grows by this factor (in 1/16ths) — 32 =
+   * doubling (default, also chosen by 0), 16 = one generation of 1024 positions per phase (closest to
+   * the serial order, one pair of kernel launches per generation).  Deterministic for every value. */
+  int32_t early_out_phase_growth;
   /* ---- device sizing ---- */
   int32_t device_id;                /* HIP device ordinal */
   uint32_t max_tiles;               /* capacity of the 8^3-voxel tile pool (64 KiB each) */

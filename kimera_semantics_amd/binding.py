@@ -13,7 +13,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libks_hip.so")
+LIB_PATH = os.environ.get("KS_HIP_LIB") or os.path.join(_HERE, "libks_hip.so")   # KS_HIP_LIB: a diagnostics build
 NUM_LABELS = 21
 
 KS_METHOD_FAST, KS_METHOD_MERGED = 0, 1
@@ -52,6 +52,7 @@ class KsConfig(C.Structure):
         ("semantic_measurement_probability", C.c_float), ("color_mode", C.c_int32),
         ("n_dynamic_labels", C.c_int32), ("dynamic_labels", C.c_uint8 * 32),
         ("label_rgba", (C.c_uint8 * 4) * 256),
+        ("early_out_phase_growth", C.c_int32),
         ("device_id", C.c_int32), ("max_tiles", C.c_uint32), ("max_points", C.c_uint32), ("pipeline_frames", C.c_int32),
     ]
 

@@ -154,15 +154,22 @@ struct Dda {
     else setup_scaled(e, s);
   }
 
-  // advance to the next index (Eigen minCoeff: first strict minimum, NaN never wins)
-  __device__ __forceinline__ void advance() {
-    int k = 0;
-    float m = tx;
-    if (ty < m) { k = 1; m = ty; }
-    if (tz < m) { k = 2; }
-    if (k == 0) { cx += sx; tx += dx; }
-    else if (k == 1) { cy += sy; ty += dy; }
-    else { cz += sz; tz += dz; }
+  // advance to the next index (Eigen minCoeff: first strict minimum, NaN never wins):
+  //   k = 0; m = tx; if (ty < m) { k = 1; m = ty; } if (tz < m) k = 2; cur[k] += sign[k]; t[k] += step[k];
+  // written with selects only (lanes of a group replay different numbers of steps: a branch per step
+  // would serialise the wave); `on` = false leaves the state untouched.
+  __device__ __forceinline__ void advance(bool on = true) {
+    const bool y_lt = ty < tx;
+    const float m = y_lt ? ty : tx;
+    const bool z_lt = tz < m;
+    const bool sel_z = on && z_lt, sel_y = on && y_lt && !z_lt, sel_x = on && !y_lt && !z_lt;
+    const float nx = tx + dx, ny = ty + dy, nz = tz + dz;
+    cx += sel_x ? sx : 0;
+    cy += sel_y ? sy : 0;
+    cz += sel_z ? sz : 0;
+    tx = sel_x ? nx : tx;
+    ty = sel_y ? ny : ty;
+    tz = sel_z ? nz : tz;
   }
 };
 

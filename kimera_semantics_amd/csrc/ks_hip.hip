@@ -83,8 +83,18 @@ struct FrameSlot {
   int index = 0;
   RayDesc* d_rays = nullptr;
   float* d_deltas = nullptr;        // merged: label histograms of mixed bundles
-  uint64_t* d_pairs = nullptr;      // unsorted (voxel, ray) pairs written by k_march
+  uint64_t* d_pairs = nullptr;      // (voxel, ray) pairs in integration order, written by k_emit
   size_t cap_pairs_in = 0;
+  uint32_t* d_cnt = nullptr;        // updates per integration position (merged: 2 n entries)
+  uint32_t* d_lp = nullptr;         // exclusive prefix of d_cnt inside blocks of kScanBlock
+  unsigned long long* d_bt = nullptr;  // block totals of that scan
+  uint8_t* d_live = nullptr;        // fast: position holds a ray that survived start-voxel dedup
+  uint32_t n_scan = 0;
+  bool wide = false;                // stage B uses a whole wavefront per ray (long rays)
+  FrameParams* d_F = nullptr;       // the frame's parameters in device memory (stage B reads them from there)
+  uint64_t *d_gkeys = nullptr, *d_rkeys = nullptr;  // anti-grazing: this frame's sorted end-voxel keys / key per bundle
+  hipGraphExec_t b_graph = nullptr; // stage B of this slot as a captured graph ...
+  uint64_t b_graph_key = 0;         // ... valid for this (point count, buffers) key
   Counters* d_counters = nullptr;   // inside ks_ctx::d_state
   uint32_t* d_ray_list = nullptr;   // rays to march (written by stage A, read by B)
   HostSnap* h_snap = nullptr;       // pinned + device-visible: written by k_publish at the end of B
@@ -115,7 +125,13 @@ struct ks_ctx {
   ks_config cfg{};
   std::string err;
   hipStream_t stream = nullptr;        // stage A (and everything else)
-  hipStream_t stream_march = nullptr;  // stage B; == stream unless pipelined
+  // stage B; == stream unless pipelined.  Pipelined, consecutive frames march on kMarchStreams streams in
+  // turn (stage B of frame i+1 does not depend on stage B of frame i: tile allocation is atomic, and the
+  // early-out set of a frame is private to it when every frame bumps the set offset — then each stream
+  // has its own table)
+  hipStream_t stream_march_[3] = {nullptr, nullptr, nullptr};
+  int n_march = 1;
+  hipStream_t prof_march_stream = nullptr;  // march stream of the frame being enqueued (stage events)
   hipStream_t stream_tail = nullptr;   // stage T; == stream unless pipelined
   float voxel_size_inv = 0.f, log_match = 0.f, log_non_match = 0.f;
   int vps_shift = 1;  // log2(vps / 8)
@@ -123,9 +139,16 @@ struct ks_ctx {
   TileTable table{};
   Pool pool{};
   uint64_t* d_start_set = nullptr;
-  uint64_t* d_observed_set = nullptr;
+  uint64_t* d_observed_[3] = {nullptr, nullptr, nullptr};
+  int n_obs = 1;
   uint64_t start_offset = 0, observed_offset = 0;
   int64_t reset_counter = 0;
+  uint32_t obs_tag = 0, obs_tag_lo = 1;  // frame tag of the observed set's entries (ks_k_march.h)
+  Counters* d_retry_counters = nullptr;  // scratch of the pair-buffer overflow retry
+  size_t pairs_hint = 0;                 // largest pair count of a frame so far
+  bool uses_early_out = false;           // fast integrator whose consecutive-collision limit can fire
+  bool use_graphs = true;                // stage B replayed as a hipGraph (KS_NO_GRAPH=1 or a capture failure: plain launches)
+  uint64_t buffers_epoch = 1;            // bumped whenever a buffer a captured graph points at is re-allocated
   uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
   uint32_t* d_label_lut = nullptr;  // 256 label -> rgba
   uint32_t tiles_initialised = 0;
@@ -187,6 +210,14 @@ struct ks_ctx {
 
 namespace {
 
+inline hipStream_t march_stream(ks_ctx* c, uint64_t frame_no) { return c->stream_march_[frame_no % (uint64_t)c->n_march]; }
+inline uint64_t* observed_table(ks_ctx* c, uint64_t frame_no) { return c->d_observed_[frame_no % (uint64_t)c->n_obs]; }
+int sync_march(ks_ctx* c) {
+  for (int i = 0; i < c->n_march; ++i)
+    if (c->stream_march_[i] != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_march_[i]));
+  return KS_OK;
+}
+
 template <typename T>
 int dev_alloc(ks_ctx* c, T** p, size_t n) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -201,9 +232,19 @@ int ensure_points(ks_ctx* c, size_t n) {
   if ((rc = dev_alloc(c, &c->d_xyz, cap * 3))) return rc;
   if ((rc = dev_alloc(c, &c->d_rgba, cap * 4))) return rc;
   if ((rc = dev_alloc(c, &c->d_labels, cap))) return rc;
+  ++c->buffers_epoch;
+  const size_t scan_cap = (c->cfg.method == KS_METHOD_MERGED ? 2 : 1) * cap;
   for (int i = 0; i < (c->cfg.pipeline_frames ? kSlots : 1); ++i) {
     if ((rc = dev_alloc(c, &c->slot[i].d_rays, cap))) return rc;
     if ((rc = dev_alloc(c, &c->slot[i].d_ray_list, cap))) return rc;
+    if ((rc = dev_alloc(c, &c->slot[i].d_cnt, scan_cap))) return rc;
+    if ((rc = dev_alloc(c, &c->slot[i].d_lp, scan_cap))) return rc;
+    if ((rc = dev_alloc(c, &c->slot[i].d_bt, scan_cap / kScanBlock + 2))) return rc;
+    if (c->cfg.method == KS_METHOD_FAST && (rc = dev_alloc(c, &c->slot[i].d_live, cap))) return rc;
+    if (c->cfg.enable_anti_grazing && c->cfg.method == KS_METHOD_MERGED) {
+      if ((rc = dev_alloc(c, &c->slot[i].d_gkeys, cap))) return rc;
+      if ((rc = dev_alloc(c, &c->slot[i].d_rkeys, cap))) return rc;
+    }
     if (c->cfg.method == KS_METHOD_MERGED && (rc = dev_alloc(c, &c->slot[i].d_deltas, cap * kNumLabels))) return rc;
   }
   if ((rc = dev_alloc(c, &c->d_hash, cap))) return rc;
@@ -228,14 +269,17 @@ int ensure_points(ks_ctx* c, size_t n) {
   return KS_OK;
 }
 
-// d_pairs is written by k_march before the pair count is known: it is sized for the worst
-// case (every ray at full length); d_pairs2 / the long-run list are sized by the actual count.
+// d_pairs is written by k_emit before the host knows the pair count: it is sized from what earlier
+// frames needed (+25 %); a frame that does not fit raises kErrPairs instead of writing, and its tail
+// grows the buffer and repeats the emission (frame_tail).  d_pairs2 / the long-run list are sized by
+// the actual count.
 int ensure_pairs_in(ks_ctx* c, FrameSlot& S, size_t bound) {
   if (bound <= S.cap_pairs_in) return KS_OK;
   const size_t cap = std::max<size_t>(bound, 1 << 20);
   int rc;
   if ((rc = dev_alloc(c, &S.d_pairs, cap))) return rc;
   S.cap_pairs_in = cap;
+  S.b_graph_key = 0;  // the captured stage B points at the old buffer
   return KS_OK;
 }
 int ensure_pairs_out(ks_ctx* c, size_t n) {
@@ -267,22 +311,47 @@ inline unsigned bits_for(uint64_t n) {  // number of bits needed to represent va
   return b;
 }
 
-// ApproxHashSet::resetApproxSet
-int reset_set(ks_ctx* c, uint64_t* d_set, uint64_t* offset) {
-  if (++(*offset) >= kFullResetThreshold) {
-    if (c->stream_march != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_march));  // the march reads the observed set
-    HIPCHK(c, hipMemsetAsync(d_set, 0, sizeof(uint64_t) << kSetBits, c->stream));
-    *offset = 0;
-    const uint64_t poison = ~0ull;
-    HIPCHK(c, hipMemcpyAsync(d_set, &poison, sizeof(poison), hipMemcpyHostToDevice, c->stream));
+// ApproxHashSet::resetApproxSet.  `observed`: the early-out set, whose entries carry a frame tag
+// (ks_k_march.h); its poison value and tag bookkeeping differ from the start-voxel set's raw hashes.
+int reset_set(ks_ctx* c, uint64_t* d_set0, uint64_t* offset, bool observed) {
+  const bool full = ++(*offset) >= kFullResetThreshold;
+  // entries written before this offset bump can never match again; when the 10-bit frame tag is about
+  // to run out they are retired in one pass and the tags start over
+  const bool retag = observed && !full && c->obs_tag + (uint32_t)c->cfg.clear_checks_every_n_frames + 2u >= kObsMaxTag;
+  if (full || retag) {
+    if (int rc = sync_march(c)) return rc;  // stage B reads the observed set
+    if (full) *offset = 0;
+    for (int t = 0; t < (observed ? c->n_obs : 1); ++t) {
+      uint64_t* d_set = observed ? c->d_observed_[t] : d_set0;
+      if (full) {
+        HIPCHK(c, hipMemsetAsync(d_set, 0, sizeof(uint64_t) << kSetBits, c->stream));
+        const uint64_t poison = observed ? kObsPoison : ~0ull;
+        HIPCHK(c, hipMemcpyAsync(d_set, &poison, sizeof(poison), hipMemcpyHostToDevice, c->stream));
+      } else {
+        hipLaunchKernelGGL(k_obs_retag, dim3((1u << kSetBits) / 256), dim3(256), 0, c->stream, d_set);
+      }
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (observed) c->obs_tag = 0;
   }
+  if (observed) c->obs_tag_lo = c->obs_tag + 1;  // the offset generation that starts with the coming frame
   return KS_OK;
+}
+
+// phase boundaries (in generations of 1024 integration positions) of the ordered-phase early-out
+std::vector<uint32_t> phase_bounds(uint32_t n_gen, int growth) {
+  std::vector<uint32_t> b{0};
+  for (;;) {
+    const uint64_t inc = std::max<uint64_t>(1, (uint64_t)b.back() * (uint64_t)(growth - 16) / 16);
+    if (b.back() + inc >= n_gen) break;
+    b.push_back((uint32_t)(b.back() + inc));
+  }
+  return b;
 }
 
 inline void stage_mark(ks_ctx* c, int set, int ev) {
   if (set >= 0 && c->pset[set].stages)
-    (void)hipEventRecord(c->pset[set].ev[ev], ev <= 3 ? c->stream : ev <= 5 ? c->stream_march : c->stream_tail);
+    (void)hipEventRecord(c->pset[set].ev[ev], ev <= 3 ? c->stream : ev <= 5 ? c->prof_march_stream : c->stream_tail);
 }
 
 // fold a finished event set into ks_profile
@@ -314,6 +383,55 @@ void resolve_prof(ks_ctx* c, int set) {
   P.used = P.complete = P.applied = false;
 }
 
+// pair emission over an upper bound of rays (<= n); the live ray count stays on the device
+void launch_emit(ks_ctx* c, FrameSlot& S, hipStream_t st, Counters* counters) {
+  const size_t lds = ((size_t)(S.n_scan + kScanBlock - 1) / kScanBlock) * sizeof(unsigned long long);
+  const size_t n = S.n;
+  if (S.wide)
+    hipLaunchKernelGGL(k_emit<64>, dim3((uint32_t)((n + 3) / 4)), dim3(256), lds, st, (const FrameParams*)S.d_F, S.n_scan,
+                       S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
+                       (unsigned long long)S.cap_pairs_in, counters);
+  else
+    hipLaunchKernelGGL(k_emit<16>, dim3((uint32_t)((n + 15) / 16)), dim3(256), lds, st, (const FrameParams*)S.d_F, S.n_scan,
+                       S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
+                       (unsigned long long)S.cap_pairs_in, counters);
+}
+
+// Stage B of the frame in slot S, as a sequence of launches on stream sm (captured into a graph by the
+// caller, or issued directly).  Everything frame-specific comes from S.d_F.
+void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max) {
+  const ks_config& cfg = c->cfg;
+  const size_t n = S.n;
+  const FrameParams* dF = S.d_F;
+  const uint32_t nb = (uint32_t)((n + 255) / 256);
+  if (c->uses_early_out) {
+    // ordered-phase early-out: per phase, k_test decides how far the phase's rays get against the set as it
+    // stood when the phase began, then k_mark enters their marks (ks_k_march.h)
+    const uint32_t n_gen = (uint32_t)((n + kChains - 1) / kChains);
+    const std::vector<uint32_t> B = phase_bounds(n_gen, cfg.early_out_phase_growth);
+    for (size_t j = 0; j < B.size(); ++j) {
+      const uint32_t g0 = B[j], g1 = (j + 1 < B.size()) ? B[j + 1] : n_gen;
+      const uint32_t p0 = g0 * kChains, p1 = (uint32_t)std::min<uint64_t>((uint64_t)g1 * kChains, n);
+      const uint32_t n_sub = (g1 - g0 + kSubRun - 1) / kSubRun;  // wavefronts per chain
+      const uint32_t steps_cap = (uint32_t)((steps_max + 3) & ~(size_t)3);
+      const size_t lds_wave = (size_t)test_lds_words64(steps_cap) * sizeof(unsigned long long);
+      const uint32_t wpb = lds_wave * 4 <= 60 * 1024 ? 4u : lds_wave * 2 <= 60 * 1024 ? 2u : 1u;  // wavefronts per block
+      hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb), dim3(64 * wpb), lds_wave * wpb, sm, dF, g0, g1, steps_cap, S.d_live,
+                         S.d_rays, S.d_cnt, S.d_counters);
+      hipLaunchKernelGGL(k_mark, dim3(nb), dim3(256), 0, sm, dF, p0, p1, S.d_ray_list, S.d_rays, S.d_cnt, S.d_counters);
+    }
+  }
+  if (cfg.method == KS_METHOD_MERGED && cfg.enable_anti_grazing)
+    hipLaunchKernelGGL(k_count_grazing<16>, dim3((uint32_t)((n + 15) / 16)), dim3(256), 0, sm, dF, S.d_ray_list, S.d_rays,
+                       S.d_cnt, S.d_counters);
+  hipLaunchKernelGGL(k_scan_local, dim3((S.n_scan + kScanBlock - 1) / kScanBlock), dim3(1024), 0, sm, S.n_scan, S.d_cnt,
+                     S.d_lp, S.d_bt);
+  launch_emit(c, S, sm, S.d_counters);
+  // the frame's only device->host traffic: pair / ray / tile counts and error flags
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sm, S.d_counters, (const uint32_t*)c->table.n_tiles,
+                     (uint32_t*)S.h_snap);
+}
+
 // ---- front half: everything up to the counter snapshot --------------------------------------
 int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba,
                 const uint8_t* d_labels, size_t n, int freespace) {
@@ -340,6 +458,8 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   F.tsdf.use_sparsity = cfg.use_sparsity_compensation_factor;
   F.start_offset = c->start_offset;
   F.observed_offset = c->observed_offset;
+  F.obs_tag = c->obs_tag;
+  F.obs_tag_lo = c->obs_tag_lo;
   F.max_collisions = cfg.max_consecutive_ray_collisions;
   F.n = (uint32_t)n;
   F.per_group = (uint32_t)(n / 1024);
@@ -361,15 +481,14 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   F.inv_order = F.sorted_order ? c->d_inv_order : nullptr;
   std::memcpy(F.dynamic_labels, cfg.dynamic_labels, 32);
   // the early-out can never fire if the threshold exceeds the longest possible ray
-  const double max_steps = 3.0 * ((double)cfg.max_ray_length_m + 2.0 * cfg.truncation_distance) * c->voxel_size_inv + 8.0;
-  F.early_out = (cfg.method == KS_METHOD_FAST) && ((double)cfg.max_consecutive_ray_collisions < max_steps);
+  F.early_out = c->uses_early_out;
 
-  // march (+emit) writes pairs before their count is known: worst case = every point a full-length ray
-  {
-    const double max_len = (double)cfg.max_ray_length_m + 2.0 * (double)cfg.truncation_distance;
-    const size_t steps_max = (size_t)std::ceil(1.7321 * max_len * (double)c->voxel_size_inv) + 8;
-    if ((rc = ensure_pairs_in(c, S, n * steps_max))) return rc;
-  }
+  // longest possible ray in steps: long rays get a whole wavefront per ray in stage B, short ones 16 lanes
+  const double max_len = (double)cfg.max_ray_length_m + 2.0 * (double)cfg.truncation_distance;
+  const size_t steps_max = (size_t)std::ceil(1.7321 * max_len * (double)c->voxel_size_inv) + 8;
+  const bool wide = steps_max > 400;
+  S.wide = wide;
+  if ((rc = ensure_pairs_in(c, S, std::max<size_t>(c->pairs_hint + c->pairs_hint / 4, 1 << 20)))) return rc;
 
   hipStream_t st = c->stream;
   if (S.tail_recorded && c->stream_tail != c->stream) HIPCHK(c, hipStreamWaitEvent(st, S.tail_done, 0));
@@ -387,6 +506,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
     P.n_pairs = 0;
     S.prof_set = set;
   }
+  const uint64_t this_frame = c->frame_no;
   ++c->frame_no;
   // S.d_counters are zero: cleared at create time / by k_publish of the slot's previous frame
 
@@ -406,19 +526,19 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
 
   if (cfg.method == KS_METHOD_FAST) {
     hipLaunchKernelGGL(k_points_fast, dim3(nb1k), dim3(1024), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       S.d_rays, c->d_hash, c->d_skeys32, c->d_pvals, S.d_counters);
+                       S.d_rays, c->d_hash, c->d_skeys32, c->d_pvals, S.d_cnt, S.d_live, S.d_counters);
     stage_mark(c, S.prof_set, 1);
     // stable sort by slot only: position order inside a slot is preserved
     uint32_t *sk = nullptr, *sv = nullptr;
     if ((rc = sort_pairs(c, c->d_skeys32, c->d_skeys32b, c->d_pvals, c->d_pvals2, n, kSetBits + 1, &sk, &sv))) return rc;
     stage_mark(c, S.prof_set, 2);
     hipLaunchKernelGGL(k_dedup, dim3(nb1k), dim3(1024), 0, st, F, sk, sv, c->d_hash, c->d_start_set, S.d_ray_list,
-                       S.d_counters);
+                       S.d_rays, S.d_cnt, S.d_live, S.d_counters);
     hipLaunchKernelGGL(k_dedup_commit, dim3(nb1k), dim3(1024), 0, st, F, sk, sv, c->d_hash, c->d_start_set,
                        S.d_counters);
   } else {
     hipLaunchKernelGGL(k_points_merged, dim3(nb1k), dim3(1024), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       c->d_pkeys, c->d_pvals, S.d_counters);
+                       c->d_pkeys, c->d_pvals, S.d_cnt, S.d_counters);
     stage_mark(c, S.prof_set, 1);
     uint64_t* sk = nullptr;
     uint32_t* sv = nullptr;
@@ -426,32 +546,66 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
     stage_mark(c, S.prof_set, 2);
     hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
                        order_ptr, sk, sv, c->d_gpw, c->d_glc);
-    uint64_t* ray_keys = cfg.enable_anti_grazing ? c->d_ray_keys : nullptr;
+    // anti-grazing: the frame keeps its own copy of the keys (the next frame's stage A reuses the sort
+    // buffers while this frame's emission — or its repetition after a pair-buffer overflow — may still run)
+    uint64_t* ray_keys = cfg.enable_anti_grazing ? S.d_rkeys : nullptr;
+    if (cfg.enable_anti_grazing) HIPCHK(c, hipMemcpyAsync(S.d_gkeys, sk, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas,
-                       S.d_ray_list, c->d_blong, ray_keys, S.d_counters);
+                       S.d_ray_list, c->d_blong, ray_keys, S.d_cnt, S.d_counters);
     hipLaunchKernelGGL(k_bundles_long, dim3((uint32_t)std::min<size_t>(n / kLongRun + 1, 2048)), dim3(64), 0, st, F,
-                       sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas, S.d_ray_list, c->d_blong, ray_keys,
+                       sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas, S.d_ray_list, c->d_blong, ray_keys, S.d_cnt,
                        S.d_counters);
     if (cfg.enable_anti_grazing) {
-      F.grazing_keys = sk;
-      F.ray_keys = c->d_ray_keys;
+      F.grazing_keys = S.d_gkeys;
+      F.ray_keys = S.d_rkeys;
     }
   }
   stage_mark(c, S.prof_set, 3);
-  // ---- stage B: march (+emit) over an upper bound of rays (<= n); the live ray count stays on
-  // the device.  Anti-grazing reads stage A's sorted point keys, which the next frame's stage A
-  // overwrites: with it the march stays on stage A's stream.
-  hipStream_t sm = cfg.enable_anti_grazing ? c->stream : c->stream_march;
+  // ---- stage B: early-out phases, scan, pair emission over an upper bound of rays (<= n); the live
+  // ray count stays on the device
+  hipStream_t sm = march_stream(c, this_frame);
+  c->prof_march_stream = sm;
   if (sm != st) {
     HIPCHK(c, hipEventRecord(S.a_done, st));
     HIPCHK(c, hipStreamWaitEvent(sm, S.a_done, 0));
   }
   if (S.prof_set >= 0 && c->pset[S.prof_set].stages) (void)hipEventRecord(c->pset[S.prof_set].ev[4], sm);
-  hipLaunchKernelGGL(k_march, dim3(nb), dim3(256), 0, sm, F, S.d_ray_list, S.d_rays, c->table, c->pool,
-                     c->d_observed_set, S.d_pairs, (unsigned long long)S.cap_pairs_in, S.d_counters);
-  // the frame's only device->host traffic: pair / ray / tile counts and error flags
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sm, S.d_counters, (const uint32_t*)c->table.n_tiles,
-                     (uint32_t*)S.h_snap);
+  // The frame's parameters go to device memory; stage B's kernels take everything else from the slot, so
+  // their launch sequence depends only on the point count: it is captured once per slot and replayed.
+  F.observed = observed_table(c, this_frame);
+  HIPCHK(c, hipMemcpyAsync(S.d_F, &F, sizeof(FrameParams), hipMemcpyHostToDevice, sm));
+  S.n_scan = (uint32_t)((cfg.method == KS_METHOD_MERGED ? 2 : 1) * n);
+  {
+    const uint64_t key = ((uint64_t)n << 24) ^ (c->buffers_epoch << 1) ^ (S.wide ? 1u : 0u);
+    bool replayed = false;
+    if (c->use_graphs) {
+      if (S.b_graph_key != key || !S.b_graph) {
+        if (S.b_graph) (void)hipGraphExecDestroy(S.b_graph);
+        S.b_graph = nullptr;
+        S.b_graph_key = 0;
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamBeginCapture(sm, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+          enqueue_stage_b(c, S, sm, steps_max);
+          ok = hipStreamEndCapture(sm, &g) == hipSuccess && g != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&S.b_graph, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+        if (ok) {
+          S.b_graph_key = key;
+        } else {
+          (void)hipGetLastError();
+          S.b_graph = nullptr;
+          c->use_graphs = false;  // plain launches from now on
+        }
+      }
+      if (S.b_graph) {
+        HIPCHK(c, hipGraphLaunch(S.b_graph, sm));
+        replayed = true;
+      }
+    }
+    if (!replayed) enqueue_stage_b(c, S, sm, steps_max);
+  }
   HIPCHK(c, hipEventRecord(S.ready, sm));
   if (S.prof_set >= 0 && c->pset[S.prof_set].stages) (void)hipEventRecord(c->pset[S.prof_set].ev[5], sm);
   S.pending = true;
@@ -472,11 +626,32 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     HIPCHK(c, hipEventSynchronize(S.ready));  // the frame's only host wait
     if (c->profiling) c->prof.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
   }
-  const Counters cnt = S.counters();
-  const uint32_t new_tiles = std::min(S.n_tiles(), c->cfg.max_tiles);
+  Counters cnt = S.counters();
+  uint32_t new_tiles = std::min(S.n_tiles(), c->cfg.max_tiles);
   const uint32_t tiles_before = c->tiles_initialised;
   const int set = S.prof_set;
   stage_mark(c, set, 6);
+  c->pairs_hint = std::max<size_t>(c->pairs_hint, cnt.n_pairs);
+  if ((cnt.err & kErrPairs) && !(cnt.err & ~kErrPairs)) {
+    // The frame's pairs did not fit the buffer sized from earlier frames: nothing was written and no tile
+    // was allocated.  Grow it and repeat the emission (the scan of the counts is still in the slot).
+    // Later frames may already have allocated tiles; the emission is a get-or-insert, so that is harmless.
+    int rc;
+    if ((rc = sync_march(c))) return rc;
+    HIPCHK(c, hipStreamSynchronize(st));
+    if ((rc = ensure_pairs_in(c, S, (size_t)cnt.n_pairs + (size_t)cnt.n_pairs / 4))) return rc;
+    Counters rcnt{};
+    rcnt.n_rays = cnt.n_rays;
+    HIPCHK(c, hipMemcpyAsync(c->d_retry_counters, &rcnt, sizeof(rcnt), hipMemcpyHostToDevice, st));
+    launch_emit(c, S, st, c->d_retry_counters);
+    HIPCHK(c, hipMemcpyAsync(&rcnt, c->d_retry_counters, sizeof(rcnt), hipMemcpyDeviceToHost, st));
+    uint32_t nt = 0;
+    HIPCHK(c, hipMemcpyAsync(&nt, c->table.n_tiles, sizeof(nt), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    cnt.err = rcnt.err;
+    cnt.n_pairs = rcnt.n_pairs;
+    new_tiles = std::min(nt, c->cfg.max_tiles);
+  }
   // tiles allocated by the front exist in the table whatever happens next: make them valid
   if (new_tiles > c->tiles_initialised) {
     hipLaunchKernelGGL(k_init_tiles, dim3(new_tiles - c->tiles_initialised), dim3(512), 0, st, c->pool,
@@ -514,14 +689,9 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     stage_mark(c, set, 7);
     const unsigned end_bit = F.seq_bits + 9 + bits_for(new_tiles);
     uint64_t* sp = nullptr;
-    // Deterministic modes sort by (voxel, ray sequence): every voxel replays its updates in
-    // the reference's single-thread order.  With the racy early-out of `fast` the set of
-    // updates is already schedule dependent (as in the multi-threaded reference, whose per-
-    // voxel order is whatever the mutex grants), so grouping by voxel suffices: the sort
-    // skips the sequence bits (2 fewer passes); the order inside a voxel is then the stable
-    // emission order.
-    const unsigned begin_bit = F.early_out ? F.seq_bits : 0u;
-    if ((rc = sort_keys(c, S.d_pairs, c->d_pairs2, n_pairs, std::min(64u, end_bit), &sp, begin_bit, /*tail=*/true))) return rc;
+    // k_emit wrote the pairs in integration order; the stable sort only groups them by voxel (it skips
+    // the sequence bits), so every voxel replays its updates in the reference's single-thread order.
+    if ((rc = sort_keys(c, S.d_pairs, c->d_pairs2, n_pairs, std::min(56u, end_bit), &sp, F.seq_bits, /*tail=*/true))) return rc;
     stage_mark(c, set, 8);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
@@ -564,7 +734,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   c->owed.n_valid_points += cnt.n_valid;
   c->owed.n_rays_cast += cnt.n_rays;
   c->owed.n_voxel_updates += n_pairs;
-  c->owed.n_blocks_allocated += new_tiles - tiles_before;
+  c->owed.n_blocks_allocated += new_tiles > tiles_before ? new_tiles - tiles_before : 0u;  // (marches of later frames run ahead)
   return KS_OK;
 }
 
@@ -601,7 +771,7 @@ int ensure_exchange(ks_ctx* c, size_t n) {
 int quiesce(ks_ctx* c) {
   const int rc = flush_pending(c);
   if (c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
-  if (c->stream_march != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_march));
+  if (int rc2 = sync_march(c)) return rc2;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return rc;
 }
@@ -616,6 +786,10 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
     c->err = "more than 2^23-1 points per call";
     return KS_ERR_INVALID_ARG;
   }
+  if (c->uses_early_out && n > kObsMaxPoints) {
+    c->err = "fast integrator with the early-out enabled: at most 2^22-2 points per call";
+    return KS_ERR_UNSUPPORTED;
+  }
   const ks_config& cfg = c->cfg;
   if (stats) std::memset(stats, 0, sizeof(*stats));
   // sorted integration order keeps its permutation in single buffers: not pipelined
@@ -626,9 +800,10 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
   if (cfg.method == KS_METHOD_FAST) {
     if ((++c->reset_counter) >= cfg.clear_checks_every_n_frames) {
       c->reset_counter = 0;
-      if ((rc = reset_set(c, c->d_start_set, &c->start_offset))) return rc;
-      if ((rc = reset_set(c, c->d_observed_set, &c->observed_offset))) return rc;
+      if ((rc = reset_set(c, c->d_start_set, &c->start_offset, false))) return rc;
+      if ((rc = reset_set(c, nullptr, &c->observed_offset, true))) return rc;
     }
+    ++c->obs_tag;  // this frame's marks
   }
   if (n == 0) {
     if ((rc = quiesce(c))) return rc;
@@ -788,6 +963,17 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     g_create_error = "log(p) must exceed log(1-p)";
     return KS_ERR_PROBABILITY;
   }
+  if (cfg->early_out_phase_growth != 0 && (cfg->early_out_phase_growth < 16 || cfg->early_out_phase_growth > 4096)) {
+    g_create_error = "early_out_phase_growth must be 0 (default: 32 = doubling phases) or 16..4096 (in 1/16ths)";
+    return KS_ERR_INVALID_ARG;
+  }
+  // the early-out can never fire if the threshold exceeds the longest possible ray
+  const double max_steps = 3.0 * ((double)cfg->max_ray_length_m + 2.0 * cfg->truncation_distance) / (double)cfg->voxel_size + 8.0;
+  const bool uses_early_out = (cfg->method == KS_METHOD_FAST) && ((double)cfg->max_consecutive_ray_collisions < max_steps);
+  if (uses_early_out && (cfg->clear_checks_every_n_frames > 256)) {
+    g_create_error = "fast integrator with the early-out enabled supports clear_checks_every_n_frames <= 256";
+    return KS_ERR_UNSUPPORTED;
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device_id >= ndev) {
     g_create_error = "no HIP device (the MI355X path has no CPU fallback)";
@@ -795,6 +981,12 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   }
   ks_ctx* c = new ks_ctx();
   c->cfg = *cfg;
+  if (c->cfg.early_out_phase_growth == 0) c->cfg.early_out_phase_growth = 32;
+  c->uses_early_out = uses_early_out;
+  {
+    const char* ng = getenv("KS_NO_GRAPH");
+    c->use_graphs = !(ng && ng[0] == '1');
+  }
   c->log_match = lm;
   c->log_non_match = lnm;
   c->voxel_size_inv = (float)(1.0 / cfg->voxel_size);  // TsdfIntegratorBase::setLayer
@@ -811,10 +1003,11 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipSetDevice(cfg->device_id));
   CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   if (cfg->pipeline_frames) {
-    CRCHK(hipStreamCreateWithFlags(&c->stream_march, hipStreamNonBlocking));
+    c->n_march = 3;
+    for (int i = 0; i < c->n_march; ++i) CRCHK(hipStreamCreateWithFlags(&c->stream_march_[i], hipStreamNonBlocking));
     CRCHK(hipStreamCreateWithFlags(&c->stream_tail, hipStreamNonBlocking));
   } else {
-    c->stream_march = c->stream_tail = c->stream;
+    c->stream_march_[0] = c->stream_tail = c->stream;
   }
   for (auto& P : c->pset) {
     for (auto& e : P.ev) CRCHK(hipEventCreate(&e));
@@ -833,12 +1026,18 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipMalloc((void**)&c->pool.updated, mt));
   CRCHK(hipMemset(c->pool.updated, 0, mt));
   CRCHK(hipMalloc((void**)&c->d_start_set, sizeof(uint64_t) << kSetBits));
-  CRCHK(hipMalloc((void**)&c->d_observed_set, sizeof(uint64_t) << kSetBits));
+  // one early-out table per march stream when a frame's marks can never be seen by the next frame
+  c->n_obs = (c->n_march > 1 && uses_early_out && cfg->clear_checks_every_n_frames <= 1) ? c->n_march : 1;
+  if (uses_early_out && c->n_obs == 1) c->n_march = 1;  // shared table: stage B of consecutive frames stays in order
+  for (int t = 0; t < c->n_obs; ++t) {
+    CRCHK(hipMalloc((void**)&c->d_observed_[t], sizeof(uint64_t) << kSetBits));
+    CRCHK(hipMemset(c->d_observed_[t], 0, sizeof(uint64_t) << kSetBits));
+    CRCHK(hipMemcpy(c->d_observed_[t], &kObsPoison, 8, hipMemcpyHostToDevice));
+  }
   CRCHK(hipMemset(c->d_start_set, 0, sizeof(uint64_t) << kSetBits));
-  CRCHK(hipMemset(c->d_observed_set, 0, sizeof(uint64_t) << kSetBits));
   const uint64_t poison = ~0ull;  // ApproxHashSet ctor: slot[offset_=0] = SIZE_MAX
   CRCHK(hipMemcpy(c->d_start_set, &poison, 8, hipMemcpyHostToDevice));
-  CRCHK(hipMemcpy(c->d_observed_set, &poison, 8, hipMemcpyHostToDevice));
+  CRCHK(hipMalloc((void**)&c->d_retry_counters, sizeof(Counters)));
   CRCHK(hipMalloc((void**)&c->d_label_lut, 256 * sizeof(uint32_t)));
   CRCHK(hipMemcpy(c->d_label_lut, cfg->label_rgba, 1024, hipMemcpyHostToDevice));
   static_assert(sizeof(Counters) == 32, "snapshot layout");
@@ -850,6 +1049,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     S.index = i;
     S.d_counters = (Counters*)(c->d_state + 64 * i);
     CRCHK(hipHostMalloc((void**)&S.h_snap, sizeof(HostSnap)));
+    CRCHK(hipMalloc((void**)&S.d_F, sizeof(FrameParams)));
     std::memset(S.h_snap, 0, sizeof(HostSnap));
     CRCHK(hipEventCreateWithFlags(&S.a_done, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
@@ -868,21 +1068,24 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
 void ks_destroy(ks_ctx* c) {
   if (!c) return;
   if (c->stream_tail && c->stream_tail != c->stream) (void)hipStreamSynchronize(c->stream_tail);
-  if (c->stream_march && c->stream_march != c->stream) (void)hipStreamSynchronize(c->stream_march);
+  for (auto sm : c->stream_march_)
+    if (sm && sm != c->stream) (void)hipStreamSynchronize(sm);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_set, c->d_color_lut,
+  void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_color_lut,
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
-                  c->d_pairs2, c->d_state, c->d_xchg_u32, c->d_xchg_u64,
+                  c->d_pairs2, c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& S : c->slot)
-    for (void* p : {(void*)S.d_rays, (void*)S.d_deltas, (void*)S.d_ray_list, (void*)S.d_pairs})
+    for (void* p : {(void*)S.d_rays, (void*)S.d_deltas, (void*)S.d_ray_list, (void*)S.d_pairs, (void*)S.d_cnt, (void*)S.d_lp,
+                    (void*)S.d_bt, (void*)S.d_live, (void*)S.d_F, (void*)S.d_gkeys, (void*)S.d_rkeys})
       if (p) (void)hipFree(p);
   ksrs::release(c->sort_ws);
   ksrs::release(c->sort_ws_tail);
   for (auto& S : c->slot) {
+    if (S.b_graph) (void)hipGraphExecDestroy(S.b_graph);
     if (S.h_snap) (void)hipHostFree(S.h_snap);
     if (S.ready) (void)hipEventDestroy(S.ready);
     if (S.tail_done) (void)hipEventDestroy(S.tail_done);
@@ -895,7 +1098,8 @@ void ks_destroy(ks_ctx* c) {
     if (P.k1) (void)hipEventDestroy(P.k1);
   }
   if (c->stream_tail && c->stream_tail != c->stream) (void)hipStreamDestroy(c->stream_tail);
-  if (c->stream_march && c->stream_march != c->stream) (void)hipStreamDestroy(c->stream_march);
+  for (auto sm : c->stream_march_)
+    if (sm && sm != c->stream) (void)hipStreamDestroy(sm);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -1267,19 +1471,23 @@ int ks_clear(ks_ctx* c) {
   for (auto& S : c->slot) S.pending = false;  // a frame that was never applied is dropped with the map
   c->owed = ks_frame_stats{};
   if (c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
-  if (c->stream_march != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_march));
+  if (int rc = sync_march(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemset(c->table.ent, 0xff, ((size_t)c->table.mask + 1) * sizeof(TileEntry)));
   HIPCHK(c, hipMemset(c->pool.updated, 0, c->cfg.max_tiles));
   HIPCHK(c, hipMemset(c->d_state, 0, 64 * (kSlots + 1)));
   // a cleared context behaves like a fresh one: both approximate sets as their constructor leaves them
   HIPCHK(c, hipMemset(c->d_start_set, 0, sizeof(uint64_t) << kSetBits));
-  HIPCHK(c, hipMemset(c->d_observed_set, 0, sizeof(uint64_t) << kSetBits));
+  for (int t = 0; t < c->n_obs; ++t) {
+    HIPCHK(c, hipMemset(c->d_observed_[t], 0, sizeof(uint64_t) << kSetBits));
+    HIPCHK(c, hipMemcpy(c->d_observed_[t], &kObsPoison, 8, hipMemcpyHostToDevice));
+  }
   const uint64_t poison = ~0ull;
   HIPCHK(c, hipMemcpy(c->d_start_set, &poison, 8, hipMemcpyHostToDevice));
-  HIPCHK(c, hipMemcpy(c->d_observed_set, &poison, 8, hipMemcpyHostToDevice));
   c->start_offset = c->observed_offset = 0;
   c->reset_counter = 0;
+  c->obs_tag = 0;
+  c->obs_tag_lo = 1;
   c->tiles_initialised = 0;
   c->fatal = false;
   return KS_OK;
@@ -1301,6 +1509,16 @@ int ks_synchronize(ks_ctx* c) {
 }
 
 void* ks_stream(ks_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+#ifdef KS_STATS
+// diagnostics build only: read (and clear) the k_test counters
+int ks_debug_test_stats(unsigned long long* out16) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_test_stats), 16 * sizeof(unsigned long long)) != hipSuccess) return KS_ERR_HIP;
+  unsigned long long z[16] = {0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_test_stats), z, sizeof(z)) != hipSuccess) return KS_ERR_HIP;
+  return KS_OK;
+}
+#endif
 
 int ks_profile_enable(ks_ctx* c, int level) {
   if (!c || level < 0 || level > 2) return KS_ERR_INVALID_ARG;

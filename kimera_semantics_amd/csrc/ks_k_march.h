@@ -1,185 +1,540 @@
-// ks_k_march.h — stage B kernels: the ray march (+ pair emission), the counter snapshot, and
-// the initialisation of freshly allocated tiles.
+// ks_k_march.h — stage B kernels: which voxels each ray updates (ordered-phase early-out), where its
+// updates go in the pair list (scan), the pair emission with tile allocation, the counter snapshot,
+// and the initialisation of freshly allocated tiles.
+//
+// Stage B never walks a ray voxel by voxel with a dependent memory access per step.  A ray (or bundle)
+// is handled by a GROUP OF LANES of one wavefront: every lane runs the ray caster forward to its own
+// step (the DDA state is a handful of registers; its float accumulation is replayed exactly), so one
+// memory round trip serves 16 or 64 consecutive voxels of the ray.
+//   k_test   (fast, early-out on) decides how far every ray gets:  ORDERED-PHASE schedule, below
+//   k_mark   enters a phase's marks into the shared approximate set
+//   k_scan_local + k_emit: exclusive scan of the per-ray update counts in integration order, then
+//            every ray writes its (voxel, ray) keys at its own offset — the pair list comes out in
+//            integration order, so the sort that follows only has to group by voxel (stable)
+// [K:src/semantic_tsdf_integrator_fast.cpp:94-141], [K:src/semantic_tsdf_integrator_merged.cpp:288-328]
 #pragma once
 #include "ks_types.h"
 
 namespace ksk {
-// ------------------------------------------------------------------------------------------
-// K3a/K3b: march + emit — ONE DDA walk per ray: tile allocation in the spatial hash, optional
-// observed-set early-out, and one (voxel slot id, ray sequence) key per update.  Keys are staged
-// in a per-wavefront LDS buffer and flushed with one global atomic per flush (a per-lane or even
-// per-step atomic on the pair counter would serialise at ~88/us).  Launched over an upper bound
-// of rays; the live count is read from device memory, so the host does not synchronise between
-// the ray stage and the march.
-// [K:src/semantic_tsdf_integrator_fast.cpp:94-141], [K:src/semantic_tsdf_integrator_merged.cpp:288-328]
-// ------------------------------------------------------------------------------------------
-constexpr uint32_t kWaveBuf = 512;  // pair keys staged per wavefront (4 KiB)
 
-__global__ void __launch_bounds__(256) k_march(FrameParams F, const uint32_t* __restrict__ ray_list,
-                                               const RayDesc* __restrict__ rays, TileTable T, Pool P,
-                                               uint64_t* __restrict__ observed_set, uint64_t* __restrict__ pairs,
-                                               unsigned long long pairs_cap, Counters* C) {
-  __shared__ uint64_t s_buf[4][kWaveBuf];
-  const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n_rays = C->n_rays;
-  if (blockIdx.x * blockDim.x >= n_rays) return;  // whole block idle (uniform)
+// ------------------------------------------------------------------------------------------
+// Shared approximate set of the fast integrator's early-out (voxel_observed_approx_set_,
+// [K:include/kimera_semantics/semantic_tsdf_integrator_fast.h:102-130]): 2^20 slots, slot =
+// (hash + offset) & mask as in the reference; an entry holds the LAST mark in integration order:
+//   [63:54] frame tag   [53:32] integration position + 1   [31:0] the voxel hash
+// so that marks can be entered with one atomicMax each, in any order, with the reference's
+// "last writer wins" outcome.  Entries of an older offset generation can never match in the
+// reference (the slot depends on the offset); here they are recognised by their tag.
+// 0 = never written since the last full reset; position field 0 with a non-zero hash field = poison /
+// retired entry.  Neither matches anything.  (The reference's zero-initialised slots "contain" hash 0 —
+// the voxel whose hash is 0 looks already observed until something overwrites its slot; the ordered-
+// phase schedule does not reproduce that one-voxel artefact, which lets every frame in flight use a
+// table of its own.)
+// ------------------------------------------------------------------------------------------
+constexpr uint64_t kObsPoison = 0x00000000ffffffffull;   // ApproxHashSet's SIZE_MAX at slot[offset = 0]
+constexpr uint64_t kObsRetired = 0x00000000fffffffeull;  // written by k_obs_retag when the frame tag wraps
+constexpr uint32_t kObsMaxTag = 1023;
+constexpr uint32_t kObsMaxPoints = (1u << 22) - 2;        // position + 1 must fit 22 bits
+
+__device__ __forceinline__ uint64_t obs_entry(uint32_t tag, uint32_t pos, uint32_t hash) {
+  return ((uint64_t)tag << 54) | ((uint64_t)(pos + 1u) << 32) | (uint64_t)hash;
+}
+// does the slot content match hash h?  (tag_lo..tag = the frames of the current offset generation)
+__device__ __forceinline__ bool obs_match(uint64_t e, uint32_t h, uint32_t tag_lo, uint32_t tag) {
+  const uint32_t posf = (uint32_t)(e >> 32) & 0x3fffffu, t = (uint32_t)(e >> 54);
+  return posf != 0u && t >= tag_lo && t <= tag && (uint32_t)e == h;
+}
+
+__global__ void __launch_bounds__(256) k_obs_retag(uint64_t* __restrict__ set) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (1u << kSetBits)) {
+    const uint64_t e = set[i];
+    if (e != 0ull) set[i] = kObsRetired;
+  }
+}
+
+// A group of LPR lanes of one wavefront cooperating on a ray.
+template <int LPR>
+struct LaneGroup {
+  static_assert(LPR == 16 || LPR == 64, "lanes per ray");
+  uint32_t l;      // lane within the group
+  uint32_t shift;  // first wave lane of the group
+  __device__ __forceinline__ LaneGroup() {
+    const uint32_t lane = lane_id();
+    l = lane & (LPR - 1);
+    shift = lane & ~(uint32_t)(LPR - 1);
+  }
+  __device__ __forceinline__ uint64_t bits(unsigned long long ballot) const {
+    return LPR == 64 ? ballot : ((ballot >> shift) & ((1ull << (LPR & 63)) - 1ull));
+  }
+  template <typename T>
+  __device__ __forceinline__ T from(T x, uint32_t src) const { return __shfl(x, (int)(shift + src)); }
+};
+
+// Runs the caster from the round's first step to this lane's step (l advances).  The loop bound is
+// uniform; the float accumulation is exactly the serial caster's.
+template <int LPR>
+__device__ __forceinline__ Dda dda_at_lane(const Dda& round_start, uint32_t l) {
+  Dda d = round_start;
+#pragma unroll 4
+  for (uint32_t i = 0; i + 1 < (uint32_t)LPR; ++i) d.advance(i < l);
+  return d;
+}
+// state of the next round's first step: the last lane's state advanced once more
+template <int LPR>
+__device__ __forceinline__ void dda_next_round(const LaneGroup<LPR>& G, Dda& round_start, Dda mine) {
+  mine.advance();
+  round_start.cx = G.from(mine.cx, LPR - 1);
+  round_start.cy = G.from(mine.cy, LPR - 1);
+  round_start.cz = G.from(mine.cz, LPR - 1);
+  round_start.tx = G.from(mine.tx, LPR - 1);
+  round_start.ty = G.from(mine.ty, LPR - 1);
+  round_start.tz = G.from(mine.tz, LPR - 1);
+}
+
+constexpr uint32_t kChains = 1024;      // = the 1024 groups of the "mixed" integration order
+constexpr uint32_t kPrivSlots = 1024;   // chain-private direct-mapped set (8 KiB of LDS per chain)
+constexpr uint32_t kCntBroke = 1u << 31;  // cnt[] flag: the ray stopped on a voxel it visited but did not update
+
+// ------------------------------------------------------------------------------------------
+// k_test — ORDERED-PHASE early-out (the CPU checker under oracle/ restates it as integrate_fast_phased):
+// integration position s -> chain s % 1024, generation s / 1024; one launch per phase of generations
+// [g0, g1).  Inside a phase a chain's generations are cut into SUB-RUNS of 16; ONE WAVEFRONT owns a
+// (chain, sub-run) and resolves its live rays in generation order.  A ray tests its voxels against (a) the
+// marks previous rays of its sub-run made (8 KiB of LDS, newest (generation, step) wins a slot) and
+// (b) the shared set as it stood when the phase began (read-only during the launch).
+//   A  lanes 0..15, one ray each: descriptor, caster set-up, the first 16 voxels walked serially (no lane
+//      replays another lane's steps); (slot | hash) of every voxel goes to LDS
+//   B  all 64 lanes: the shared-set entries of those <= 256 voxels, four per lane, in flight together
+//   C  the rays one after the other, 16 lanes per ray, LDS only: private-set lookup, the reference's
+//      consecutive-collision rule on the 16-bit hit mask, the ray's marks.  A ray not decided within 16
+//      voxels (the first through its corridor) is walked on by its owner lane 64 voxels at a time and
+//      tested by all 64 lanes.
+// Output: cnt[s] = number of voxels the ray updates (| kCntBroke).
+// The reference's loop: [K:src/semantic_tsdf_integrator_fast.cpp:110-122].
+// ------------------------------------------------------------------------------------------
+constexpr int kTestThreads = 256;    // 4 wavefronts per block
+constexpr uint32_t kSubRun = 16;     // generations per (chain, sub-run) wavefront
+#ifdef KS_STATS
+__device__ unsigned long long g_test_stats[16];  // diagnostics build only (tools/test_stats.py)
+#define KS_STAT_ADD(i, v) do { if (lane_id() == 0) atomicAdd(&g_test_stats[i], (unsigned long long)(v)); } while (0)
+#define KS_STAT_MAX(i, v) do { if (lane_id() == 0) atomicMax(&g_test_stats[i], (unsigned long long)(v)); } while (0)
+#else
+#define KS_STAT_ADD(i, v)
+#define KS_STAT_MAX(i, v)
+#endif
+
+// the reference's consecutive-collision rule over one round: returns the index of the step the ray
+// breaks on (it is visited, not updated) or -1; c = running counter (in/out).  Wave-uniform operands.
+__device__ __forceinline__ int early_out_stop(uint64_t hits, uint64_t valids, int lim, int& c) {
+  // valids is a prefix of ones (steps past the ray's end are invalid); hits is a subset of it
+  const int nv = valids == ~0ull ? 64 : (int)__ffsll((long long)~valids) - 1;
+  if (lim >= 0 && lim <= 6 && c <= lim && nv + c <= 64) {
+    // the ray breaks at the first step that completes a run of lim + 1 hits; the c hits carried in
+    // from the previous round are prepended as ones
+    const uint64_t hh = (c ? ((hits << c) | ((1ull << c) - 1ull)) : hits);
+    uint64_t run = hh;
+    for (int k = 1; k <= lim; ++k) run &= hh >> k;  // bit i set <=> bits i .. i+lim of hh all set
+    if (run != 0ull) {
+      const int stop = (int)__ffsll((long long)run) - 1 + lim - c;
+      if (stop < nv) return stop;  // c is irrelevant after a break
+    }
+    // no break: the new counter is the length of the trailing run of hits among the nv valid steps
+    if (nv == 0) return -1;
+    const uint64_t top = nv + c == 64 ? hh : (hh | (~0ull << (nv + c)));
+    const uint64_t inv = ~top;  // zeros of hh below bit nv + c
+    const int last_zero = inv == 0ull ? -1 : 63 - (int)__clzll((long long)inv);
+    c = nv + c - 1 - last_zero;
+    return -1;
+  }
+  int stop = -1;
+  for (int i = 0; i < nv; ++i) {
+    c = ((hits >> i) & 1ull) ? c + 1 : 0;
+    if (c > lim) {
+      stop = i;
+      break;
+    }
+  }
+  return stop;
+}
+__device__ __forceinline__ unsigned long long priv_key(uint32_t gen, uint32_t s, uint32_t slot, uint32_t h) {
+  return ((unsigned long long)gen << 52) | ((unsigned long long)(s < 1023u ? s : 1023u) << 42) |
+         ((unsigned long long)(slot >> 10) << 32) | (unsigned long long)h;
+}
+// private-set lookup: does an entry for this slot exist, and does it hold hash h?
+__device__ __forceinline__ bool priv_lookup(const unsigned long long* priv, uint32_t slot, uint32_t h, bool& hit) {
+  const unsigned long long pe = priv[slot & (kPrivSlots - 1u)];
+  if (pe != 0ull && (uint32_t)((pe >> 32) & 1023ull) == (slot >> 10)) {
+    hit = (uint32_t)pe == h;
+    return true;
+  }
+  return false;
+}
+
+// LDS per wavefront: private set | keys of the first 16 voxels of 16 rays | keys of one long ray | per-ray words
+__host__ __device__ inline uint32_t test_lds_words64(uint32_t steps_cap) { return kPrivSlots + 256u + steps_cap + 16u; }
+
+__global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __restrict__ Fp, uint32_t g0, uint32_t g1,
+                                                       uint32_t steps_cap, const uint8_t* __restrict__ live,
+                                                       const RayDesc* __restrict__ rays, uint32_t* __restrict__ cnt,
+                                                       const Counters* C) {
+  // stage B kernels read the frame's parameters from device memory: the launch sequence of a frame slot is
+  // then identical from frame to frame and is replayed as a captured graph
+  const FrameParams& F = *Fp;
+  const uint64_t* __restrict__ observed = F.observed;
+  extern __shared__ unsigned long long s_test[];
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
-  uint64_t* buf = s_buf[wave];
+  unsigned long long* priv = s_test + (size_t)wave * test_lds_words64(steps_cap);
+  unsigned long long* keys = priv + kPrivSlots;        // [16 rays][16 steps]  slot << 32 | hash
+  unsigned long long* lkeys = keys + 256;              // [steps_cap]          the long ray's voxels from step 16 on
+  uint32_t* rinfo = (uint32_t*)(lkeys + steps_cap);    // [16] steps of the ray | [16] shared-set hit mask
+  for (uint32_t i = lane; i < kPrivSlots; i += 64) priv[i] = 0ull;  // wave-private: no block barrier needed
+  if (C->err & (kErrLabel | kErrIndex)) return;
+  const uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave;
+  const uint32_t chain = w % kChains, sub = w / kChains;
+  const uint32_t gs = g0 + sub * kSubRun;
+  if (gs >= g1) return;
+  const uint32_t ge = gs + kSubRun < g1 ? gs + kSubRun : g1;
+  const int lim = F.max_collisions;
+#ifdef KS_STATS
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+  uint32_t st_long = 0, st_rounds = 0;
+#endif
 
-  bool done = true;
+  // ---- A: lane l < 16 owns the ray of generation gs + l ----
   Dda dda{};
-  uint32_t seq = 0;
+  int my_steps = -1;
+  {
+    const uint32_t g = gs + lane;
+    const uint64_t p = (uint64_t)g * kChains + chain;
+    const bool is_live = lane < kSubRun && g < ge && p < F.n && live[p] != 0;
+    if (is_live) {
+      const RayDesc d = rays[ray_index(F, (uint32_t)p)];
+      dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
+                /*cast_from_origin=*/false);
+      my_steps = dda.steps;
+    }
+    for (int s = 0; s < 16; ++s) {  // (uniform trip count; lanes without a ray idle through it)
+      if (s <= my_steps) {
+        const uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
+        const uint32_t slot = (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask);
+        keys[lane * 16 + s] = ((unsigned long long)slot << 32) | h;
+      }
+      dda.advance(s < my_steps);  // the state after min(16, steps) advances stays in the owner lane
+    }
+    if (lane < 16) rinfo[lane] = (uint32_t)my_steps;
+  }
+  const uint32_t live_mask = (uint32_t)(__ballot(my_steps >= 0) & 0xffffull);
+  if (live_mask == 0u) return;
+  // ---- B: shared-set entries of the first 16 voxels of every ray: 4 rays per pass, all in flight ----
+  {
+    const uint32_t grp = lane >> 4, l = lane & 15u;
+    bool hit[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const uint32_t r = (uint32_t)b * 4u + grp;
+      hit[b] = false;
+      if (((live_mask >> r) & 1u) && (int)l <= (int)rinfo[r]) {
+        const unsigned long long k = keys[r * 16 + l];
+        hit[b] = obs_match(observed[(uint32_t)(k >> 32)], (uint32_t)k, F.obs_tag_lo, F.obs_tag);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const unsigned long long m = __ballot(hit[b]);
+      if (lane < 4) rinfo[16 + b * 4 + lane] = (uint32_t)((m >> (16 * lane)) & 0xffffull);
+    }
+  }
+  // ---- C: the rays in generation order against the private set ----
+  for (uint32_t todo = live_mask; todo != 0u; todo &= todo - 1u) {
+    const uint32_t j = (uint32_t)__ffs((int)todo) - 1u;
+    const int steps_j = (int)rinfo[j];
+    const uint32_t hs = rinfo[16 + j];
+    const uint32_t gen_j = gs + j, pos_j = gen_j * kChains + chain;
+    const bool valid = lane < 16 && (int)lane <= steps_j;
+    unsigned long long k = 0ull;
+    bool hit = false;
+    if (valid) {
+      k = keys[j * 16 + lane];
+      if (!priv_lookup(priv, (uint32_t)(k >> 32), (uint32_t)k, hit)) hit = (hs >> lane) & 1u;
+    }
+    int c = 0;
+    int stop = early_out_stop(__ballot(valid && hit), __ballot(valid), lim, c);
+    uint32_t updates, visited;
+    if (stop >= 0 || steps_j < 16) {
+      updates = stop >= 0 ? (uint32_t)stop : (uint32_t)steps_j + 1u;
+      visited = stop >= 0 ? updates + 1u : updates;
+    } else {
+      // long ray: its owner lane walks on, 64 voxels at a time; all lanes test them
+#ifdef KS_STATS
+      ++st_long;
+#endif
+      uint32_t s0 = 16;
+      for (;;) {
+#ifdef KS_STATS
+        ++st_rounds;
+#endif
+        const uint32_t n_round = (uint32_t)steps_j + 1u - s0 < 64u ? (uint32_t)steps_j + 1u - s0 : 64u;
+        if (lane == j) {
+          for (uint32_t i = 0; i < n_round; ++i) {
+            const uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
+            const uint32_t slot = (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask);
+            lkeys[s0 - 16u + i] = ((unsigned long long)slot << 32) | h;
+            dda.advance(s0 + i < (uint32_t)steps_j);
+          }
+        }
+        const bool v64 = lane < n_round;
+        bool hit64 = false;
+        if (v64) {
+          const unsigned long long k64 = lkeys[s0 - 16u + lane];
+          if (!priv_lookup(priv, (uint32_t)(k64 >> 32), (uint32_t)k64, hit64))
+            hit64 = obs_match(observed[(uint32_t)(k64 >> 32)], (uint32_t)k64, F.obs_tag_lo, F.obs_tag);
+        }
+        stop = early_out_stop(__ballot(v64 && hit64), __ballot(v64), lim, c);
+        if (stop >= 0) {
+          updates = s0 + (uint32_t)stop;
+          visited = updates + 1u;
+          break;
+        }
+        if (s0 + 64u > (uint32_t)steps_j) {
+          updates = (uint32_t)steps_j + 1u;
+          visited = updates;
+          break;
+        }
+        s0 += 64u;
+      }
+      // marks of the voxels past the first 16 (kept in LDS: no second walk)
+      for (uint32_t m0 = 16; m0 < visited; m0 += 64) {
+        const uint32_t s = m0 + lane;
+        if (s < visited) {
+          const unsigned long long k64 = lkeys[s - 16u];
+          atomicMax(&priv[(uint32_t)(k64 >> 32) & (kPrivSlots - 1u)], priv_key(gen_j, s, (uint32_t)(k64 >> 32), (uint32_t)k64));
+        }
+      }
+    }
+    if (lane == 0) cnt[pos_j] = updates | (stop >= 0 ? kCntBroke : 0u);
+    if (valid && lane < visited)
+      atomicMax(&priv[(uint32_t)(k >> 32) & (kPrivSlots - 1u)], priv_key(gen_j, lane, (uint32_t)(k >> 32), (uint32_t)k));
+  }
+#ifdef KS_STATS
+  {
+    const unsigned long long dt = __builtin_readcyclecounter() - t_begin;
+    KS_STAT_ADD(0, dt);
+    KS_STAT_MAX(1, dt);
+    KS_STAT_ADD(2, 1);
+    KS_STAT_ADD(4, __popc(live_mask));
+    KS_STAT_ADD(5, st_long);
+    KS_STAT_ADD(6, st_rounds);
+    KS_STAT_MAX(7, st_rounds);
+  }
+#endif
+}
+
+// k_mark — the marks of the phase covering positions [pos0, pos1) enter the shared set: every visited
+// voxel of every live ray of the phase, one atomicMax each (the entry with the highest (position, hash)
+// stays = the reference's last writer in serial order).  One lane per ray, walking it serially; the
+// atomics return nothing, so nothing waits for memory.
+__global__ void __launch_bounds__(256) k_mark(const FrameParams* __restrict__ Fp, uint32_t pos0, uint32_t pos1,
+                                              const uint32_t* __restrict__ ray_list, const RayDesc* __restrict__ rays,
+                                              const uint32_t* __restrict__ cnt, const Counters* C) {
+  const FrameParams& F = *Fp;
+  uint64_t* __restrict__ observed = F.observed;
+  if (C->err & (kErrLabel | kErrIndex)) return;
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= C->n_rays) return;
+  const uint32_t pos = ray_list[r];
+  if (pos < pos0 || pos >= pos1) return;
+  const uint32_t cv = cnt[pos];
+  const uint32_t visited = (cv & ~kCntBroke) + ((cv & kCntBroke) ? 1u : 0u);
+  const RayDesc d = rays[ray_index(F, pos)];
+  Dda dda;
+  dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, false);
+  for (uint32_t s = 0; s < visited; ++s) {
+    const uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
+    atomicMax((unsigned long long*)&observed[((uint64_t)h + F.observed_offset) & kSetMask],
+              (unsigned long long)obs_entry(F.obs_tag, pos, h));
+    dda.advance();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Scan of the per-ray update counts in integration order.  cnt[] is indexed by integration position
+// (merged: first-point position of the bundle, clearing bundles offset by n: they integrate after all
+// normal bundles, [K:src/semantic_tsdf_integrator_merged.cpp:126-144]); dead positions hold 0.
+// k_scan_local: 4096 entries per block -> local exclusive prefix + block total; k_emit adds the
+// block offsets (a few hundred values, scanned again by every block in LDS).
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kScanBlock = 4096;
+__global__ void __launch_bounds__(1024) k_scan_local(uint32_t n_scan, const uint32_t* __restrict__ cnt,
+                                                     uint32_t* __restrict__ lp, unsigned long long* __restrict__ bt) {
+  __shared__ uint32_t s_wave[16];
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  const uint32_t i0 = blockIdx.x * kScanBlock + threadIdx.x * 4u;
+  uint32_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n_scan) ? (cnt[i0 + k] & ~kCntBroke) : 0u;
+  const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+  uint32_t x = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o);
+    if (lane >= (uint32_t)o) x += y;
+  }
+  if (lane == 63) s_wave[wave] = x;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (uint32_t w = 0; w < wave; ++w) wbase += s_wave[w];
+  uint32_t run = wbase + x - mine;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (i0 + k < n_scan) lp[i0 + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 1023) bt[blockIdx.x] = (unsigned long long)(wbase + x);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_emit — every live ray writes its (voxel, ray) keys at its offset of the scan; allocates voxel
+// tiles on first touch (CAS + pool bump; waits for a slot another lane is publishing only after the
+// wave has reconverged).  Key = [63:56] label | kind | clearing, [..] voxel id << seq_bits | ray sequence.
+// The list is in integration order; total = Counters::n_pairs.
+// ------------------------------------------------------------------------------------------
+template <int LPR>
+__global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Fp, uint32_t n_scan,
+                                              const uint32_t* __restrict__ ray_list, const RayDesc* __restrict__ rays,
+                                              const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ lp,
+                                              const unsigned long long* __restrict__ bt, TileTable T, Pool P,
+                                              uint64_t* __restrict__ pairs, unsigned long long pairs_cap, Counters* C) {
+  const FrameParams& F = *Fp;
+  // launched over an upper bound of rays: blocks past the live ray count leave at once (block 0 stays:
+  // it publishes the total)
+  if (blockIdx.x != 0 && blockIdx.x * (256u / LPR) >= C->n_rays) return;
+  // exclusive prefix of the block totals (every block redundantly; <= a few thousand values)
+  extern __shared__ unsigned long long s_bt[];
+  __shared__ unsigned long long s_carry;
+  const uint32_t nb = (n_scan + kScanBlock - 1) / kScanBlock;
+  if (threadIdx.x == 0) s_carry = 0ull;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < nb; b0 += 256) {
+    const uint32_t b = b0 + threadIdx.x;
+    const unsigned long long v = b < nb ? bt[b] : 0ull;
+    // block-wide exclusive scan of 256 values
+    __shared__ unsigned long long s_w[4];
+    unsigned long long x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long y = __shfl_up(x, o);
+      if (lane_id() >= (uint32_t)o) x += y;
+    }
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = x;
+    __syncthreads();
+    unsigned long long wb = s_carry;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wb += s_w[w];
+    if (b < nb) s_bt[b] = wb + x - v;
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry = wb + x;
+    __syncthreads();
+  }
+  const unsigned long long total = s_carry;
+  if (blockIdx.x == 0 && threadIdx.x == 0) C->n_pairs = total;
+  if (total > pairs_cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&C->err, kErrPairs);
+    return;
+  }
+  if (C->err & (kErrLabel | kErrIndex)) return;
+  const LaneGroup<LPR> G;
+  const uint32_t n_rays = C->n_rays;
+  const uint32_t r = (blockIdx.x * 256u + threadIdx.x) / LPR;
+  const bool have = r < n_rays;
+  uint32_t p = 0, count = 0;
+  unsigned long long base = 0;
+  uint64_t key_lo = 0;  // info byte | sequence
   bool clearing = false;
   uint64_t own_key = 0;
-  uint64_t info_hi = 0;  // label | kind << 5 | clearing << 7 in the key's top byte (rides through the sort)
-  if (r < n_rays && (C->err & (kErrLabel | kErrIndex)) == 0) {
-    const uint32_t p = ray_list[r];
+  Dda round{};
+  if (have) {
+    p = ray_list[r];
     const RayDesc d = rays[ray_index(F, p)];
     clearing = ((d.info >> 10) & 1u) != 0;
-    info_hi = (uint64_t)((d.info & 0x1fu) | (((d.info >> 8) & 3u) << 5) | (((d.info >> 10) & 1u) << 7)) << 56;
-    dda.setup(F.T.t, {d.px, d.py, d.pz}, clearing, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
-              /*cast_from_origin=*/F.method == KS_METHOD_MERGED);
-    // merged: normal bundles integrate before clearing bundles ([K:src/semantic_tsdf_integrator_merged.cpp:126-144])
-    seq = (F.method == KS_METHOD_MERGED && clearing) ? (p | F.clear_bit) : p;
+    const uint32_t si = p + ((F.method == KS_METHOD_MERGED && clearing) ? F.n : 0u);
+    count = cnt[si] & ~kCntBroke;
+    base = s_bt[si / kScanBlock] + lp[si];
+    key_lo = ((uint64_t)((d.info & 0x1fu) | (((d.info >> 8) & 3u) << 5) | (((d.info >> 10) & 1u) << 7)) << 56) |
+             (uint64_t)((F.method == KS_METHOD_MERGED && clearing) ? (p | F.clear_bit) : p);
     own_key = F.ray_keys ? F.ray_keys[p] : 0ull;
-    if (!dda.in_range) atomicOr(&C->err, kErrIndex);
-    else done = false;
+    round.setup(F.T.t, {d.px, d.py, d.pz}, clearing, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
+                /*cast_from_origin=*/F.method == KS_METHOD_MERGED);
   }
-
-  uint32_t wcount = 0;  // keys in this wave's buffer (wave-uniform)
-  auto flush = [&]() {
-    unsigned long long base = 0;
-    if (lane == 0) base = atomicAdd(&C->n_pairs, (unsigned long long)wcount);
-    base = __shfl(base, 0);
-    if (base + wcount <= pairs_cap) {
-      for (uint32_t i = lane; i < wcount; i += 64) pairs[base + i] = buf[i];
-    } else if (lane == 0) {
-      atomicOr(&C->err, kErrTable);
-    }
-    wcount = 0;
-  };
-
-  int s = 0;
-  int consecutive = 0;
+  // With anti-grazing (merged, off by default) some steps of the walk emit nothing: `count` counts the
+  // emitting steps (k_count_grazing), the walk covers all steps of the ray.
+  const uint32_t walk = have ? (F.grazing_keys ? (uint32_t)round.steps + 1u : count) : 0u;
+  uint32_t emitted = 0;
   uint64_t last_tile = kEmpty64;
   uint32_t slot = 0;
-  constexpr int kBatch = 4;
-  while (__ballot(!done) != 0ull) {
-    // ---- (A) which of the next steps of this ray are integrated ----
-    // Early-out: the ray stops at the first voxel that makes `consecutive` exceed the limit.
-    // With the counter at c, the next (limit + 1 - c) voxels are visited whatever their
-    // state, so that many approximate-set exchanges can be IN FLIGHT TOGETHER without
-    // speculation; the stop can only fall on the last of them.  On the long rays (the first
-    // through their corridor, c stays 0) this cuts the dependent L2 round trips 3-4x.
-    int vx[kBatch], vy[kBatch], vz[kBatch];
-    uint64_t tk[kBatch];   // tile key of each step
-    uint4 pre[kBatch];     // its first-probe table entry, loaded TOGETHER with the exchanges below:
-                           // the tile lookup leaves the dependent chain of the ray
-    bool em[kBatch];       // step emits an update
-    int n_adv = 0;         // steps of this iteration the DDA advances over
-#pragma unroll
-    for (int j = 0; j < kBatch; ++j) em[j] = false;
-    if (!done) {
-      const int remaining = dda.steps - s + 1;
-      if (remaining <= 0) {
-        done = true;
-      } else if (F.early_out) {
-        int k = F.max_collisions + 1 - consecutive;
-        k = k < 1 ? 1 : (k > kBatch ? kBatch : k);
-        k = k > remaining ? remaining : k;
-        uint64_t hh[kBatch], old[kBatch];
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-          if (j < k) {
-            vx[j] = dda.cx; vy[j] = dda.cy; vz[j] = dda.cz;
-            hh[j] = (uint64_t)index_hash(dda.cx, dda.cy, dda.cz);
-            // ApproxHashSet::replaceHash on voxel_observed_approx_set_ — racy by design in the
-            // multi-threaded reference; here one atomic exchange per visited voxel.
-            old[j] = atomicExch((unsigned long long*)&observed_set[(hh[j] + F.observed_offset) & kSetMask],
-                                (unsigned long long)hh[j]);
-            dda.advance();
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-          if (j < k) {
-            tk[j] = pack_tile(vx[j] >> 3, vy[j] >> 3, vz[j] >> 3);
-            pre[j] = *(const uint4*)&T.ent[mix64(tk[j]) & T.mask];
-          }
-        }
-        int n_upd = k;
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-          if (j < k && !done) {
-            if (old[j] == hh[j]) ++consecutive;
-            else consecutive = 0;
-            if (consecutive > F.max_collisions) {
-              done = true;   // break BEFORE updating this voxel
-              n_upd = j;
-            }
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) em[j] = j < n_upd;
-        n_adv = k;
-      } else {
-        const int k = remaining < kBatch ? remaining : kBatch;
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j) {
-          if (j < k) {
-            vx[j] = dda.cx; vy[j] = dda.cy; vz[j] = dda.cz;
-            tk[j] = pack_tile(vx[j] >> 3, vy[j] >> 3, vz[j] >> 3);
-            pre[j] = *(const uint4*)&T.ent[mix64(tk[j]) & T.mask];
-            em[j] = !grazing_skip(F, dda.cx, dda.cy, dda.cz, clearing, own_key);
-            dda.advance();
-          }
-        }
-        n_adv = k;
-      }
-      s += n_adv;
-    }
-    // ---- (B) emit the integrated steps (uniform loop over the batch) ----
-#pragma unroll
-    for (int j = 0; j < kBatch; ++j) {
-      const bool emit = em[j];
-      bool any_left = emit;
-#pragma unroll
-      for (int jj = j + 1; jj < kBatch; ++jj) any_left = any_left || em[jj];
-      if (__ballot(any_left) == 0ull) break;
-      uint32_t hpos = 0, got = 0;
-      bool need_tile = false;
-      if (emit && tk[j] != last_tile) {
+  for (uint32_t s0 = 0; __ballot(s0 < walk) != 0ull; s0 += LPR) {
+    const bool in = s0 < walk;
+    const Dda mine = dda_at_lane<LPR>(round, G.l);
+    const bool step_on = in && (s0 + G.l < walk);
+    const bool emit = step_on && !grazing_skip(F, mine.cx, mine.cy, mine.cz, clearing, own_key);
+    uint32_t hpos = 0, got = 0;
+    bool need_tile = false;
+    if (emit) {
+      const uint64_t tk = pack_tile(mine.cx >> 3, mine.cy >> 3, mine.cz >> 3);
+      if (tk != last_tile) {
         need_tile = true;
-        last_tile = tk[j];
-        const uint64_t k64 = (uint64_t)pre[j].x | ((uint64_t)pre[j].y << 32);
-        if (k64 == tk[j] && pre[j].z != kSlotPending) got = pre[j].z;   // resident tile: no further memory access
-        else got = tile_slot_nowait(T, C, tk[j], &hpos);
+        last_tile = tk;
+        got = tile_slot_nowait(T, C, tk, &hpos);
       }
-      // the wave has reconverged: every allocating lane of THIS wave has published its slot
-      if (need_tile) {
-        uint32_t spins = 0;
-        while (got == kSlotPending) {
-          got = __hip_atomic_load(&T.ent[hpos].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (++spins > (1u << 22)) {
-            atomicOr(&C->err, kErrTable);
-            got = kSlotBad;
-          }
-        }
-        slot = got;
-        if (slot < T.max_tiles) P.updated[slot] = 1;
-        else atomicOr(&C->err, kErrPool);  // a tile an earlier frame failed to allocate: this frame must not be applied either
-      }
-      const unsigned long long m = __ballot(emit);
-      if (emit) {
-        const uint32_t local = (uint32_t)(vx[j] & 7) + 8u * ((uint32_t)(vy[j] & 7) + 8u * (uint32_t)(vz[j] & 7));
-        const uint32_t pos = wcount + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        buf[pos] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | seq | info_hi;
-      }
-      wcount += (uint32_t)__popcll(m);
-      if (wcount > kWaveBuf - 64u) flush();
     }
+    // the wave has reconverged: every allocating lane of THIS wave has published its slot
+    if (need_tile) {
+      uint32_t spins = 0;
+      while (got == kSlotPending) {
+        got = __hip_atomic_load(&T.ent[hpos].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (++spins > (1u << 22)) {
+          atomicOr(&C->err, kErrTable);
+          got = kSlotBad;
+        }
+      }
+      slot = got;
+      if (slot < T.max_tiles) P.updated[slot] = 1;
+      else atomicOr(&C->err, kErrPool);  // pool exhausted (now or in an earlier frame): this frame is not applied
+    }
+    const uint64_t em = G.bits(__ballot(emit));
+    if (emit) {
+      const uint32_t local = (uint32_t)(mine.cx & 7) + 8u * ((uint32_t)(mine.cy & 7) + 8u * (uint32_t)(mine.cz & 7));
+      const uint32_t k = emitted + (uint32_t)__popcll(em & ((1ull << G.l) - 1ull));
+      pairs[base + k] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | key_lo;
+    }
+    emitted += (uint32_t)__popcll(em);
+    if (in && s0 + LPR < walk) dda_next_round<LPR>(G, round, mine);
   }
-  if (wcount) flush();
+}
+
+// merged + anti-grazing: the number of steps of each bundle's ray that emit an update
+template <int LPR>
+__global__ void __launch_bounds__(256) k_count_grazing(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ ray_list,
+                                                       const RayDesc* __restrict__ rays, uint32_t* __restrict__ cnt,
+                                                       const Counters* C) {
+  const FrameParams& F = *Fp;
+  const LaneGroup<LPR> G;
+  const uint32_t r = (blockIdx.x * 256u + threadIdx.x) / LPR;
+  if (r >= C->n_rays) return;
+  const uint32_t p = ray_list[r];
+  const RayDesc d = rays[ray_index(F, p)];
+  const bool clearing = ((d.info >> 10) & 1u) != 0;
+  const uint64_t own_key = F.ray_keys ? F.ray_keys[p] : 0ull;
+  Dda round;
+  round.setup(F.T.t, {d.px, d.py, d.pz}, clearing, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, true);
+  const uint32_t walk = (uint32_t)round.steps + 1u;
+  uint32_t total = 0;
+  for (uint32_t s0 = 0; s0 < walk; s0 += LPR) {
+    const Dda mine = dda_at_lane<LPR>(round, G.l);
+    const bool emit = (s0 + G.l < walk) && !grazing_skip(F, mine.cx, mine.cy, mine.cz, clearing, own_key);
+    total += (uint32_t)__popcll(G.bits(__ballot(emit)));
+    if (s0 + LPR < walk) dda_next_round<LPR>(G, round, mine);
+  }
+  if (G.l == 0) cnt[p + (clearing ? F.n : 0u)] = total;
 }
 
 // End of stage B: the frame's counters and the persistent tile count go to pinned host memory,

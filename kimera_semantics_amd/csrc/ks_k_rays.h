@@ -13,12 +13,15 @@ __global__ void __launch_bounds__(1024) k_points_fast(FrameParams F, const float
                                                       const uint8_t* __restrict__ color_lut,
                                                       RayDesc* __restrict__ rays, uint32_t* __restrict__ hash_out,
                                                       uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                      uint32_t* __restrict__ cnt, uint8_t* __restrict__ live,
                                                       Counters* C) {
   // One lane per point in MEMORY order (coalesced reads, coalesced descriptor writes); the
   // integration position p of the point is arithmetic, only the 4-byte sort key is scattered.
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   bool counted = false;
   if (idx < F.n) {
+    cnt[idx] = 0u;   // per-position update counts / live flags of stage B (set by k_dedup for the kept rays)
+    live[idx] = 0;
     uint32_t key = kInvalidSlot;
     const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
     uint32_t color = 0;
@@ -70,7 +73,8 @@ __global__ void __launch_bounds__(1024) k_points_fast(FrameParams F, const float
 __global__ void __launch_bounds__(1024) k_dedup(FrameParams F, const uint32_t* __restrict__ skeys,
                                                 const uint32_t* __restrict__ svals, const uint32_t* __restrict__ hash,
                                                 uint64_t* __restrict__ start_set, uint32_t* __restrict__ ray_list,
-                                                Counters* C) {
+                                                const RayDesc* __restrict__ rays, uint32_t* __restrict__ cnt,
+                                                uint8_t* __restrict__ live, Counters* C) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t n = F.n;
   bool kept = false;
@@ -79,13 +83,24 @@ __global__ void __launch_bounds__(1024) k_dedup(FrameParams F, const uint32_t* _
     const uint32_t slot = skeys[i];
     if (slot != kInvalidSlot) {
       p = svals[i];
-      const uint64_t h = hash[point_order(F, F.order, p)];
+      const uint32_t idx = point_order(F, F.order, p);
+      const uint64_t h = hash[idx];
       const bool first = (i == 0) || (skeys[i - 1] != slot);
       uint64_t prev;
       // the slot's persistent content is only READ here; k_dedup_commit writes it afterwards
       if (first) prev = start_set[slot];
       else prev = hash[point_order(F, F.order, svals[i - 1])];
       kept = prev != h;
+      if (kept) {
+        // the ray's full length (the early-out of stage B can only shorten it)
+        const RayDesc d = rays[idx];
+        Dda dda;
+        dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv,
+                  F.trunc, /*cast_from_origin=*/false);
+        if (!dda.in_range) atomicOr(&C->err, kErrIndex);
+        cnt[p] = (uint32_t)dda.steps + 1u;
+        live[p] = 1;
+      }
     }
   }
   const uint32_t pos = block_append(kept, &C->n_rays);
@@ -115,10 +130,12 @@ __global__ void __launch_bounds__(1024) k_points_merged(FrameParams F, const flo
                                                         const uint8_t* __restrict__ labels,
                                                         const uint8_t* __restrict__ color_lut,
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        Counters* C) {
+                                                        uint32_t* __restrict__ cnt, Counters* C) {
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   bool counted = false;
   if (idx < F.n) {
+    cnt[idx] = 0u;        // update counts of stage B: normal bundles at their first position,
+    cnt[idx + F.n] = 0u;  // clearing bundles n further on (they integrate after all normal ones)
     const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
     uint32_t label;
     if (labels) label = labels[idx];
@@ -177,8 +194,16 @@ __global__ void __launch_bounds__(256) k_gather_sorted(FrameParams F, const floa
 //   k_bundles_long : one wavefront per larger bundle (a surface close to the sensor puts
 //                    thousands of pixels into one 5 cm voxel)
 __device__ __forceinline__ void finish_bundle(const FrameParams& F, f3 mp, float mw, uint32_t merged_color,
-                                              bool clearing, int n_labels, int the_label, float c, RayDesc* out) {
+                                              bool clearing, int n_labels, int the_label, float c, RayDesc* out,
+                                              uint32_t* cnt_out, Counters* C) {
   const f3 pg = transform_point(F.T, mp);
+  {
+    // length of the bundle's ray (origin -> surface, [K:src/semantic_tsdf_integrator_merged.cpp:288-294])
+    Dda dda;
+    dda.setup(F.T.t, pg, clearing, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, /*cast_from_origin=*/true);
+    if (!dda.in_range) atomicOr(&C->err, kErrIndex);
+    *cnt_out = (uint32_t)dda.steps + 1u;
+  }
   RayDesc d;
   d.px = pg.x; d.py = pg.y; d.pz = pg.z;
   d.weight = mw;
@@ -202,7 +227,7 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
                                                  const uint2* __restrict__ g_lc, RayDesc* __restrict__ rays,
                                                  float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
                                                  uint32_t* __restrict__ long_list, uint64_t* __restrict__ ray_keys,
-                                                 Counters* C) {
+                                                 uint32_t* __restrict__ cnt, Counters* C) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   bool head = false, is_long = false;
   uint32_t first_p = 0;
@@ -260,7 +285,8 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
         deltas[(size_t)first_p * kNumLabels + r] = acc;
       }
     }
-    finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p]);
+    finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p],
+                  &cnt[first_p + (clearing ? F.n : 0u)], C);
     if (ray_keys) ray_keys[first_p] = key & ~(1ull << 63);
   }
   const uint32_t pos = block_append(work, &C->n_rays);
@@ -273,7 +299,8 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
                                                      RayDesc* __restrict__ rays, float* __restrict__ deltas,
                                                      uint32_t* __restrict__ ray_list,
                                                      const uint32_t* __restrict__ long_list,
-                                                     uint64_t* __restrict__ ray_keys, Counters* C) {
+                                                     uint64_t* __restrict__ ray_keys, uint32_t* __restrict__ cnt,
+                                                     Counters* C) {
   const uint32_t n_long = C->n_long_bundles;
   const int lane = (int)lane_id();
   for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
@@ -353,7 +380,8 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
       deltas[(size_t)first_p * kNumLabels + lane] = acc;
     }
     if (lane == 0) {
-      finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p]);
+      finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p],
+                    &cnt[first_p + (clearing ? F.n : 0u)], C);
       if (ray_keys) ray_keys[first_p] = key & ~(1ull << 63);
       ray_list[atomicAdd(&C->n_rays, 1u)] = first_p;
     }

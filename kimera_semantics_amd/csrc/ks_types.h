@@ -20,7 +20,7 @@ constexpr int kCoordBias = 1 << 20;                            // voxel coordina
 constexpr int kTileBias = 1 << 17;                             // tile coordinates packed as 18-bit fields
 
 // error bits raised by kernels
-enum : uint32_t { kErrLabel = 1u, kErrPool = 2u, kErrIndex = 4u, kErrTable = 8u };
+enum : uint32_t { kErrLabel = 1u, kErrPool = 2u, kErrIndex = 4u, kErrTable = 8u, kErrPairs = 16u /* pair buffer too small: the host grows it and repeats the emission */ };
 
 struct Counters {
   unsigned long long n_pairs;
@@ -120,6 +120,8 @@ struct FrameParams {
   float log_match, log_non_match;
   TsdfParams tsdf;
   uint64_t start_offset, observed_offset;
+  uint32_t obs_tag, obs_tag_lo;  // frame tag of this frame's marks; first tag of the current offset generation
+  uint64_t* observed;            // the early-out table this frame uses (one per march stream)
   int32_t max_collisions;
   uint32_t n;                // points this frame
   uint32_t per_group;        // n / 1024 (mixed order)

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <limits>
 #include <list>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -600,6 +601,146 @@ struct ko_ctx {
     n_valid += valid;
   }
 
+  // ---- fast, ORDERED-PHASE schedule (cfg.early_out_phase_growth >= 16) -------------------------
+  // NOT reference code: the restatement of the schedule the HIP kernels run when the early-out of
+  // [K:semantic_tsdf_integrator_fast.cpp:110-122] is enabled, so that the GPU can be checked bit for
+  // bit against a CPU.  The reference's loop is inherently serial (ray k stops on marks rays 1..k-1
+  // left in voxel_observed_approx_set_); the schedule keeps the dependencies that matter and cuts the rest:
+  //   * integration position s -> chain c = s % 1024 (the "mixed" order's group, i.e. a run of
+  //     neighbouring points) and generation g = s / 1024;
+  //   * generations are cut into phases [B_j, B_j+1), B_0 = 0, B_j+1 = B_j + max(1, B_j (growth-16)/16);
+  //   * within a phase the 1024 chains are independent, and a chain's generations are cut into sub-runs
+  //     of 16 (counted from the phase's first generation) that are independent too; a sub-run walks its
+  //     rays in generation order;
+  //   * a ray tests every voxel of its path against: the marks the PREVIOUS rays of its own sub-run made
+  //     (private direct-mapped set of 1024 entries, newest (generation, step) wins an entry), else the
+  //     shared set as it stood when the phase began;
+  //   * when a phase ends its marks enter the shared set: per slot the mark of the highest
+  //     (position, hash) wins (the reference: the last writer in serial order);
+  //   * a slot nothing has been written to never matches (the reference's zero-initialised slots
+  //     "contain" hash 0: that one-voxel artefact is not reproduced; marks are stored with a flag bit).
+  // Start-voxel dedup, the ray caster, the consecutive-collision rule and the per-voxel update order
+  // (integration position) are the reference's.  growth 16 = one generation per phase.
+  static constexpr uint32_t kChains = 1024, kPrivSlots = 1024, kSubRun = 16;
+  static constexpr size_t kMarkFlag = size_t(1) << 40;  // set in every mark the phased schedule stores in the shared set
+  static std::vector<uint32_t> phase_bounds(uint32_t n_gen, int growth) {
+    std::vector<uint32_t> b{0};
+    for (;;) {
+      const uint64_t inc = std::max<uint64_t>(1, (uint64_t)b.back() * (uint64_t)(growth - 16) / 16);
+      if (b.back() + inc >= n_gen) break;
+      b.push_back((uint32_t)(b.back() + inc));
+    }
+    return b;
+  }
+  void integrate_fast_phased(const Transform& T, const float* xyz, const uint8_t* rgba, const uint8_t* labels,
+                             size_t n, bool freespace) {
+    struct Ray { size_t idx; uint32_t pos; V3 pg; bool clearing; uint32_t cnt; };
+    std::vector<Ray> rays;
+    IndexGetter getter;
+    getter.init(cfg.integration_order_mode, xyz, n);
+    size_t point_idx;
+    uint32_t pos = 0;
+    uint64_t valid = 0;
+    while (getter.next(&point_idx)) {
+      const uint32_t p = pos++;
+      const V3 point_C = {xyz[3 * point_idx], xyz[3 * point_idx + 1], xyz[3 * point_idx + 2]};
+      bool is_clearing;
+      if (!is_point_valid(point_C, freespace, &is_clearing) || !is_semantic_label_valid(labels[point_idx])) continue;
+      ++valid;
+      const V3 point_G = transform_point(T, point_C);
+      const I3 g = grid_index_from_point(point_G, cfg.start_voxel_subsampling_factor * voxel_size_inv);
+      if (!start_voxel_set.replace_hash(LongIndexHash()(g))) continue;
+      rays.push_back({point_idx, p, point_G, is_clearing, 0});
+    }
+    const uint32_t n_gen = (uint32_t)((n + kChains - 1) / kChains);
+    const std::vector<uint32_t> B = phase_bounds(n_gen, cfg.early_out_phase_growth);
+    ApproxHashSet& S = voxel_observed_set;
+    const int64_t lim = cfg.max_consecutive_ray_collisions;
+    struct Mark { size_t slot; uint32_t pos; uint32_t hash; };
+    std::vector<Mark> marks;
+    std::vector<uint64_t> priv((size_t)kChains * kPrivSlots);
+    std::vector<uint32_t> priv_sub(kChains);  // sub-run the chain's private set currently belongs to
+    std::vector<std::pair<uint32_t, uint64_t>> own;
+    size_t r0 = 0;
+    for (size_t j = 0; j < B.size() && r0 < rays.size(); ++j) {
+      const uint64_t end_pos = (j + 1 < B.size()) ? (uint64_t)B[j + 1] * kChains : ~0ull;
+      marks.clear();
+      std::fill(priv.begin(), priv.end(), 0ull);
+      std::fill(priv_sub.begin(), priv_sub.end(), 0u);
+      size_t r1 = r0;
+      // rays are in position order = generation-major; a chain's rays therefore appear in generation order
+      for (; r1 < rays.size() && rays[r1].pos < end_pos; ++r1) {
+        Ray& r = rays[r1];
+        const uint32_t chain = r.pos % kChains, gen = r.pos / kChains;
+        uint64_t* pv = &priv[(size_t)chain * kPrivSlots];
+        const uint32_t sub = (gen - B[j]) / kSubRun;
+        if (sub != priv_sub[chain]) {  // a new sub-run starts with an empty private set
+          std::fill(pv, pv + kPrivSlots, 0ull);
+          priv_sub[chain] = sub;
+        }
+        RayCaster caster(T.t, r.pg, r.clearing, cfg.voxel_carving_enabled != 0, cfg.max_ray_length_m, voxel_size_inv,
+                         cfg.truncation_distance, /*cast_from_origin=*/false);
+        I3 v;
+        int64_t consecutive = 0;
+        uint32_t step = 0;
+        own.clear();
+        while (caster.next(&v)) {
+          const uint32_t h = (uint32_t)LongIndexHash()(v);
+          const size_t slot = ((size_t)h + S.offset) & ApproxHashSet::kMask;
+          const uint64_t pe = pv[slot & (kPrivSlots - 1)];
+          size_t content;
+          if (pe != 0 && ((pe >> 32) & 1023u) == (slot >> 10)) content = (size_t)(pe & 0xffffffffull) | kMarkFlag;
+          else content = S.slots[slot].load(std::memory_order_relaxed);
+          if (content == ((size_t)h | kMarkFlag)) ++consecutive;
+          else consecutive = 0;
+          own.push_back({(uint32_t)(slot & (kPrivSlots - 1)),
+                         ((uint64_t)gen << 52) | ((uint64_t)std::min<uint32_t>(step, 1023u) << 42) |
+                             ((uint64_t)(slot >> 10) << 32) | (uint64_t)h});
+          marks.push_back({slot, r.pos, h});
+          ++step;
+          if (consecutive > lim) break;
+          ++r.cnt;
+        }
+        for (const auto& o : own) pv[o.first] = std::max(pv[o.first], o.second);
+      }
+      // the phase's marks enter the shared set: per slot the highest (position, hash)
+      std::sort(marks.begin(), marks.end(), [](const Mark& a, const Mark& b) {
+        if (a.slot != b.slot) return a.slot < b.slot;
+        if (a.pos != b.pos) return a.pos < b.pos;
+        return a.hash < b.hash;
+      });
+      for (size_t i = 0; i < marks.size(); ++i)
+        if (i + 1 == marks.size() || marks[i + 1].slot != marks[i].slot)
+          S.slots[marks[i].slot].store((size_t)marks[i].hash | kMarkFlag, std::memory_order_relaxed);
+      r0 = r1;
+    }
+    // voxel updates: every ray's first cnt voxels, rays in integration order (the order the reference's
+    // single thread applies them in)
+    uint64_t updates = 0;
+    for (const Ray& r : rays) {
+      if (r.cnt == 0) continue;
+      const V3 point_C = {xyz[3 * r.idx], xyz[3 * r.idx + 1], xyz[3 * r.idx + 2]};
+      const Rgba color = rgba ? Rgba{rgba[4 * r.idx], rgba[4 * r.idx + 1], rgba[4 * r.idx + 2], rgba[4 * r.idx + 3]}
+                              : Rgba{0, 0, 0, 0};
+      const uint8_t label = labels[r.idx];
+      RayCaster caster(T.t, r.pg, r.clearing, cfg.voxel_carving_enabled != 0, cfg.max_ray_length_m, voxel_size_inv,
+                       cfg.truncation_distance, false);
+      I3 v;
+      BlockCache bc;
+      const float weight = get_voxel_weight(point_C);
+      float freq[kNumLabels];
+      for (int i = 0; i < kNumLabels; ++i) freq[i] = 0.0f;
+      freq[label] += 1.0f;
+      for (uint32_t s2 = 0; s2 < r.cnt && caster.next(&v); ++s2) {
+        update_voxel(T.t, r.pg, v, color, weight, freq, &bc);
+        ++updates;
+      }
+    }
+    n_updates += updates;
+    n_rays += rays.size();
+    n_valid += valid;
+  }
+
   // [K:semantic_tsdf_integrator_fast.cpp:145-199]
   void integrate_fast(const Transform& T, const float* xyz, const uint8_t* rgba, const uint8_t* labels,
                       size_t n, bool freespace) {
@@ -607,6 +748,10 @@ struct ko_ctx {
       reset_counter = 0;
       start_voxel_set.reset();
       voxel_observed_set.reset();
+    }
+    if (cfg.early_out_phase_growth >= 16) {
+      integrate_fast_phased(T, xyz, rgba, labels, n, freespace);
+      return;
     }
     IndexGetter getter;
     getter.init(cfg.integration_order_mode, xyz, n);
@@ -904,11 +1049,82 @@ size_t ko_sim_early_out(const ko_config* cfg, const float Tq[7], const float* xy
         ++updates;
       }
     }
+  } else if (n_bounds >= 2 && bounds[0] == 0xfffffffeu) {
+    // JACOBI-2 chain schedule (design study): per phase every ray first walks against the phase-start set only
+    // (provisional walk); then every ray is re-tested against the phase-start set plus the provisional marks
+    // of the EARLIER rays of its own chain in the phase (earliest marker of a voxel counts).
+    const uint32_t chains = bounds[1];
+    auto phase_of = [&](uint32_t pos) -> uint32_t {
+      const uint32_t g = pos / chains;
+      uint32_t ph = 0;
+      for (size_t i = 3; i < n_bounds; ++i) if (g >= bounds[i]) ph = (uint32_t)(i - 3);
+      return ph;
+    };
+    const int iters = (int)bounds[2];  // number of refinement passes (1 = the scheme above)
+    std::vector<std::pair<size_t, size_t>> marks;
+    size_t r0 = 0;
+    while (r0 < rays.size()) {
+      const uint32_t phase = phase_of(rays[r0].pos);
+      size_t r1 = r0;
+      while (r1 < rays.size() && phase_of(rays[r1].pos) == phase) ++r1;
+      // paths
+      struct Step { size_t slot, h; I3 v; };
+      std::vector<std::vector<Step>> path(r1 - r0);
+      std::vector<uint32_t> visited(r1 - r0), upd(r1 - r0);
+      for (size_t r = r0; r < r1; ++r) {
+        RayCaster caster(T.t, rays[r].pg, rays[r].clearing, cfg->voxel_carving_enabled != 0, cfg->max_ray_length_m,
+                         c->voxel_size_inv, cfg->truncation_distance, false);
+        I3 v;
+        while (caster.next(&v)) {
+          const size_t h = LongIndexHash()(v);
+          path[r - r0].push_back({(h + S.offset) & ApproxHashSet::kMask, h, v});
+        }
+      }
+      // pass 0: against S only
+      auto walk = [&](size_t i, const std::unordered_map<size_t, std::pair<uint32_t, size_t>>* pm, uint32_t gen) {
+        int64_t consecutive = 0;
+        uint32_t s2 = 0, u = 0;
+        for (const Step& st : path[i]) {
+          bool hit = S.slots[st.slot].load(std::memory_order_relaxed) == st.h;
+          if (pm) {
+            auto it = pm->find(st.slot);
+            if (it != pm->end() && it->second.first < gen) hit = it->second.second == st.h;
+          }
+          consecutive = hit ? consecutive + 1 : 0;
+          ++s2;
+          if (consecutive > lim) break;
+          ++u;
+        }
+        visited[i] = s2;
+        upd[i] = u;
+      };
+      for (size_t i = 0; i < r1 - r0; ++i) walk(i, nullptr, 0);
+      for (int it = 0; it < iters; ++it) {
+        // earliest own-chain marker per slot from the current walks
+        std::vector<std::unordered_map<size_t, std::pair<uint32_t, size_t>>> pm(chains);
+        for (size_t i = 0; i < r1 - r0; ++i) {
+          const uint32_t ch = rays[r0 + i].pos % chains, gen = rays[r0 + i].pos / chains;
+          for (uint32_t s2 = 0; s2 < visited[i]; ++s2) {
+            const Step& st = path[i][s2];
+            auto f = pm[ch].find(st.slot);
+            if (f == pm[ch].end() || gen < f->second.first) pm[ch][st.slot] = {gen, st.h};
+          }
+        }
+        for (size_t i = 0; i < r1 - r0; ++i) walk(i, &pm[rays[r0 + i].pos % chains], rays[r0 + i].pos / chains);
+      }
+      for (size_t i = 0; i < r1 - r0; ++i) {
+        for (uint32_t s2 = 0; s2 < visited[i]; ++s2) S.slots[path[i][s2].slot].store(path[i][s2].h, std::memory_order_relaxed);
+        for (uint32_t s2 = 0; s2 < upd[i]; ++s2) keys.push_back(pack(path[i][s2].v));
+        updates += upd[i];
+      }
+      r0 = r1;
+    }
   } else if (n_bounds >= 2 && bounds[0] == 0xffffffffu) {
     // CHAIN schedule: bounds = {0xffffffff, chains, gens_per_phase}.  chain = pos % chains; a phase covers
     // gens_per_phase generations (pos / chains).  A ray sees the set as of the phase start plus the marks
     // its OWN chain made earlier in the phase.
-    const uint32_t chains = bounds[1], gpp = bounds[2];
+    const uint32_t chains = bounds[1] & 0xffffu, sub_len = bounds[1] >> 16, gpp = bounds[2];
+    // sub_len > 0: inside a phase a chain's generations are cut into sub-runs of sub_len with separate private sets
     // gpp == 0: explicit generation boundaries follow (bounds[3..], ascending, first = 0)
     auto phase_of = [&](uint32_t pos) -> uint32_t {
       const uint32_t g = pos / chains;
@@ -918,28 +1134,43 @@ size_t ko_sim_early_out(const ko_config* cfg, const float Tq[7], const float* xy
       return ph;
     };
     std::vector<std::pair<size_t, size_t>> marks;
-    std::vector<std::unordered_map<size_t, size_t>> priv(chains);
+    std::map<std::pair<uint32_t, uint32_t>, std::unordered_map<size_t, size_t>> priv;
+    // optional: bounds[n_bounds-1] = 0x80000000 | direct-mapped private-set size (power of two)
+    size_t dm = 0;
+    if (n_bounds > 3 && (bounds[n_bounds - 1] & 0x80000000u)) { dm = bounds[n_bounds - 1] & 0x7fffffffu; --n_bounds; }
     size_t r0 = 0;
     while (r0 < rays.size()) {
       const uint32_t phase = phase_of(rays[r0].pos);
       marks.clear();
-      for (auto& m : priv) m.clear();
+      priv.clear();
+      uint32_t g_first = rays[r0].pos / chains;
+      if (gpp) g_first = phase * gpp; else g_first = bounds[3 + phase];
       size_t r1 = r0;
       for (; r1 < rays.size() && phase_of(rays[r1].pos) == phase; ++r1) {
         const Ray& r = rays[r1];
-        auto& pm = priv[r.pos % chains];
+        auto& pm = priv[{r.pos % chains, sub_len ? (r.pos / chains - g_first) / sub_len : 0u}];
         RayCaster caster(T.t, r.pg, r.clearing, cfg->voxel_carving_enabled != 0, cfg->max_ray_length_m, c->voxel_size_inv,
                          cfg->truncation_distance, false);
         I3 v;
         int64_t consecutive = 0;
+        std::vector<std::pair<size_t, size_t>> own;
+        struct Flush { std::unordered_map<size_t, size_t>& m; std::vector<std::pair<size_t, size_t>>& o;
+                       ~Flush() { for (auto& kv : o) m[kv.first] = kv.second; } } flush{pm, own};
         while (caster.next(&v)) {
           const size_t h = LongIndexHash()(v);
           const size_t slot = (h + S.offset) & ApproxHashSet::kMask;
-          auto it = pm.find(slot);
-          const size_t content = (it != pm.end()) ? it->second : S.slots[slot].load(std::memory_order_relaxed);
+          size_t content;
+          if (dm) {
+            auto it = pm.find(slot & (dm - 1));
+            content = (it != pm.end() && (it->second >> 32) == slot) ? (it->second & 0xffffffffu) : S.slots[slot].load(std::memory_order_relaxed);
+            own.push_back({slot & (dm - 1), (slot << 32) | h});
+          } else {
+            auto it = pm.find(slot);
+            content = (it != pm.end()) ? it->second : S.slots[slot].load(std::memory_order_relaxed);
+            own.push_back({slot, h});
+          }
           if (content == h) ++consecutive;
           else consecutive = 0;
-          pm[slot] = h;
           marks.push_back({slot, h});
           if (consecutive > lim) break;
           keys.push_back(pack(v));

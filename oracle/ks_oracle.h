@@ -75,6 +75,12 @@ typedef struct ko_config {
   uint8_t dynamic_labels[32];
   uint8_t label_rgba[256][4];       /* SemanticLabel2Color::semantic_label_to_color_map_ flattened;
                                        absent ids -> (0,0,0,0) (color.cpp:89-92) */
+  /* fast, early-out enabled: 0 = the reference's serial order (one ray after the other,
+   * semantic_tsdf_integrator_fast.cpp:110-122).  >= 16 = the GPU path's ORDERED-PHASE schedule, restated
+   * here so the HIP kernels can be checked bit for bit against it (see integrate_fast_phased in
+   * ks_oracle.cpp for the definition): phase boundaries grow by this factor / 16 (16 = one generation of
+   * 1024 integration positions per phase, 32 = doubling). */
+  int32_t early_out_phase_growth;
 } ko_config;
 
 typedef struct ko_frame_stats {

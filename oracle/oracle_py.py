@@ -35,6 +35,7 @@ class KoConfig(C.Structure):
         ("semantic_measurement_probability", C.c_float), ("color_mode", C.c_int32),
         ("n_dynamic_labels", C.c_int32), ("dynamic_labels", C.c_uint8 * 32),
         ("label_rgba", (C.c_uint8 * 4) * 256),
+        ("early_out_phase_growth", C.c_int32),
     ]
 
 

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_config_struct_layout_and_defaults():
     cfg = B.default_config()
-    assert ctypes.sizeof(B.KsConfig) == 4 * 23 + 32 + 1024 + 16 and cfg.pipeline_frames == 0
+    assert ctypes.sizeof(B.KsConfig) == 4 * 23 + 32 + 1024 + 4 + 16 and cfg.pipeline_frames == 0
     assert abs(cfg.voxel_size - 0.05) < 1e-9 and cfg.voxels_per_side == 16
     assert abs(cfg.truncation_distance - 0.2) < 1e-7 and cfg.max_weight == 10000.0
     assert cfg.max_consecutive_ray_collisions == 2 and abs(cfg.start_voxel_subsampling_factor - 2.0) < 1e-9
