@@ -298,7 +298,7 @@ def main():
     wl = dict(WORKLOADS["C2"], w=args.width, h=args.height, method=args.method)
     # frame-sharded: rank r integrates trajectory frames r, r+world, ... (weak scaling: K+W frames per GPU)
     frames = make_frames(wl, [rank + world * k for k in range(K + W)])
-    pipeline = 0 if args.no_pipeline else 2   # bag replay = a stream of frames: frame pipelining on
+    pipeline = 0 if args.no_pipeline else 4   # bag replay = a stream of frames: frame pipelining on
 
     reduce_fn = None
     if world > 1:

@@ -85,7 +85,9 @@ typedef struct ks_config {
   uint32_t max_tiles;               /* capacity of the 8^3-voxel tile pool (64 KiB each) */
   uint32_t max_points;              /* largest cloud per call (buffers grow on demand if exceeded) */
   /* 0 (default): an integrate call returns with its frame fully enqueued and its own statistics.
-   * 1 or 2: frame pipelining for streams of frames (bag replay).  A call enqueues stages A and B of
+   * 1 .. 4: frame pipelining for streams of frames (bag replay); the value is how many calls the second
+   *    half of a frame lags behind (the text below describes 1 and 2; 3 or 4 keep the host further ahead,
+   *    so that it never waits for a stage B still running — stage B of up to four frames runs concurrently).  A call enqueues stages A and B of
    *    its frame (points .. ray march), then finishes the frame 1 or 2 calls back (pair sort + voxel
    *    update): the one host wait of a frame overlaps GPU work of later frames, and the stages of up
    *    to three consecutive frames run concurrently on three streams.  With 2 the host never waits

@@ -73,7 +73,8 @@ std::string g_create_error;
 // neither A nor B touches voxel data.  The host's one wait per frame (for the snapshot that sizes
 // T) never idles the GPU.  Four slots rotate; stage A of a frame waits for the tail that last
 // used its slot.
-constexpr int kSlots = 4;
+constexpr int kSlots = 6;            // frame slots: the tail may lag up to 4 calls (pipeline_frames)
+constexpr int kMarchStreams = 4;
 struct HostSnap {
   Counters c;
   uint32_t n_tiles;
@@ -101,6 +102,7 @@ struct FrameSlot {
   hipEvent_t a_done = nullptr;      // stage A complete
   hipEvent_t ready = nullptr;       // snapshot has landed
   hipEvent_t tail_done = nullptr;   // the tail has consumed this slot's buffers
+  hipEvent_t fork = nullptr, join = nullptr;  // tail: pairs sorted and long runs listed | long runs applied
   bool tail_recorded = false;
   FrameParams F{};
   size_t n = 0;
@@ -129,17 +131,18 @@ struct ks_ctx {
   // turn (stage B of frame i+1 does not depend on stage B of frame i: tile allocation is atomic, and the
   // early-out set of a frame is private to it when every frame bumps the set offset — then each stream
   // has its own table)
-  hipStream_t stream_march_[3] = {nullptr, nullptr, nullptr};
+  hipStream_t stream_march_[kMarchStreams] = {nullptr, nullptr, nullptr, nullptr};
   int n_march = 1;
   hipStream_t prof_march_stream = nullptr;  // march stream of the frame being enqueued (stage events)
   hipStream_t stream_tail = nullptr;   // stage T; == stream unless pipelined
+  hipStream_t stream_long = nullptr;   // the long-run voxel update, beside k_apply (always its own stream)
   float voxel_size_inv = 0.f, log_match = 0.f, log_non_match = 0.f;
   int vps_shift = 1;  // log2(vps / 8)
 
   TileTable table{};
   Pool pool{};
   uint64_t* d_start_set = nullptr;
-  uint64_t* d_observed_[3] = {nullptr, nullptr, nullptr};
+  uint64_t* d_observed_[kMarchStreams] = {nullptr, nullptr, nullptr, nullptr};
   int n_obs = 1;
   uint64_t start_offset = 0, observed_offset = 0;
   int64_t reset_counter = 0;
@@ -147,6 +150,8 @@ struct ks_ctx {
   Counters* d_retry_counters = nullptr;  // scratch of the pair-buffer overflow retry
   size_t pairs_hint = 0;                 // largest pair count of a frame so far
   bool uses_early_out = false;           // fast integrator whose consecutive-collision limit can fire
+  double hp_a = 0, hp_b = 0, hp_t = 0, hp_sort = 0;   // KS_HOST_PROF=1: host seconds spent enqueueing stage A / B / T, radix sorts (of A+T)
+  bool host_prof = false;
   bool use_graphs = true;                // stage B replayed as a hipGraph (KS_NO_GRAPH=1 or a capture failure: plain launches)
   uint64_t buffers_epoch = 1;            // bumped whenever a buffer a captured graph points at is re-allocated
   uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
@@ -210,6 +215,12 @@ struct ks_ctx {
 
 namespace {
 
+struct HostTimer {
+  double* acc;
+  std::chrono::steady_clock::time_point t0;
+  explicit HostTimer(double* a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+  ~HostTimer() { *acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 inline hipStream_t march_stream(ks_ctx* c, uint64_t frame_no) { return c->stream_march_[frame_no % (uint64_t)c->n_march]; }
 inline uint64_t* observed_table(ks_ctx* c, uint64_t frame_no) { return c->d_observed_[frame_no % (uint64_t)c->n_obs]; }
 int sync_march(ks_ctx* c) {
@@ -294,6 +305,7 @@ int ensure_pairs_out(ks_ctx* c, size_t n) {
 
 template <typename K>
 int sort_keys(ks_ctx* c, K* a, K* b, size_t n, unsigned end_bit, K** result, unsigned begin_bit = 0, bool tail = false) {
+  HostTimer ht(&c->hp_sort);
   HIPCHK(c, (ksrs::sort<K, false>(tail ? c->sort_ws_tail : c->sort_ws, a, b, nullptr, nullptr, n, end_bit,
                                   tail ? c->stream_tail : c->stream, result, nullptr, begin_bit)));
   return KS_OK;
@@ -301,6 +313,7 @@ int sort_keys(ks_ctx* c, K* a, K* b, size_t n, unsigned end_bit, K** result, uns
 template <typename K>
 int sort_pairs(ks_ctx* c, K* ka, K* kb, uint32_t* va, uint32_t* vb, size_t n, unsigned end_bit, K** kres,
                uint32_t** vres) {
+  HostTimer ht(&c->hp_sort);
   HIPCHK(c, (ksrs::sort<K, true>(c->sort_ws, ka, kb, va, vb, n, end_bit, c->stream, kres, vres)));
   return KS_OK;
 }
@@ -387,7 +400,18 @@ void resolve_prof(ks_ctx* c, int set) {
 void launch_emit(ks_ctx* c, FrameSlot& S, hipStream_t st, Counters* counters) {
   const size_t lds = ((size_t)(S.n_scan + kScanBlock - 1) / kScanBlock) * sizeof(unsigned long long);
   const size_t n = S.n;
-  if (S.wide)
+  if (!(c->cfg.method == KS_METHOD_MERGED && c->cfg.enable_anti_grazing)) {
+    // bundles and 2 cm rays are long: 8 rays per wavefront; early-out rays are short: one per lane
+    if (S.wide || c->cfg.method == KS_METHOD_MERGED || !c->uses_early_out)
+      hipLaunchKernelGGL(k_emit_lane<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), lds, st, (const FrameParams*)S.d_F, S.n_scan,
+                         S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
+                         (unsigned long long)S.cap_pairs_in, counters);
+    else
+      hipLaunchKernelGGL(k_emit_lane<64>, dim3((uint32_t)((n + 255) / 256)), dim3(256), lds, st, (const FrameParams*)S.d_F,
+                         S.n_scan, S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
+                         (unsigned long long)S.cap_pairs_in, counters);
+  }
+  else if (S.wide)
     hipLaunchKernelGGL(k_emit<64>, dim3((uint32_t)((n + 3) / 4)), dim3(256), lds, st, (const FrameParams*)S.d_F, S.n_scan,
                        S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
                        (unsigned long long)S.cap_pairs_in, counters);
@@ -418,7 +442,11 @@ void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max) 
       const uint32_t wpb = lds_wave * 4 <= 60 * 1024 ? 4u : lds_wave * 2 <= 60 * 1024 ? 2u : 1u;  // wavefronts per block
       hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb), dim3(64 * wpb), lds_wave * wpb, sm, dF, g0, g1, steps_cap, S.d_live,
                          S.d_rays, S.d_cnt, S.d_counters);
-      hipLaunchKernelGGL(k_mark, dim3(nb), dim3(256), 0, sm, dF, p0, p1, S.d_ray_list, S.d_rays, S.d_cnt, S.d_counters);
+      if (S.wide)
+        hipLaunchKernelGGL(k_mark<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), 0, sm, dF, p0, p1, S.d_ray_list, S.d_rays, S.d_cnt,
+                           S.d_counters);
+      else
+        hipLaunchKernelGGL(k_mark<64>, dim3(nb), dim3(256), 0, sm, dF, p0, p1, S.d_ray_list, S.d_rays, S.d_cnt, S.d_counters);
     }
   }
   if (cfg.method == KS_METHOD_MERGED && cfg.enable_anti_grazing)
@@ -435,6 +463,7 @@ void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max) 
 // ---- front half: everything up to the counter snapshot --------------------------------------
 int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba,
                 const uint8_t* d_labels, size_t n, int freespace) {
+  HostTimer hta(&c->hp_a);
   const ks_config& cfg = c->cfg;
   int rc;
   FrameParams& F = S.F;
@@ -565,6 +594,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   // ray count stays on the device
   hipStream_t sm = march_stream(c, this_frame);
   c->prof_march_stream = sm;
+  HostTimer htb(&c->hp_b);
   if (sm != st) {
     HIPCHK(c, hipEventRecord(S.a_done, st));
     HIPCHK(c, hipStreamWaitEvent(sm, S.a_done, 0));
@@ -573,7 +603,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   // The frame's parameters go to device memory; stage B's kernels take everything else from the slot, so
   // their launch sequence depends only on the point count: it is captured once per slot and replayed.
   F.observed = observed_table(c, this_frame);
-  HIPCHK(c, hipMemcpyAsync(S.d_F, &F, sizeof(FrameParams), hipMemcpyHostToDevice, sm));
+  hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sm, F, S.d_F);
   S.n_scan = (uint32_t)((cfg.method == KS_METHOD_MERGED ? 2 : 1) * n);
   {
     const uint64_t key = ((uint64_t)n << 24) ^ (c->buffers_epoch << 1) ^ (S.wide ? 1u : 0u);
@@ -626,6 +656,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     HIPCHK(c, hipEventSynchronize(S.ready));  // the frame's only host wait
     if (c->profiling) c->prof.host_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
   }
+  HostTimer htt(&c->hp_t);
   Counters cnt = S.counters();
   uint32_t new_tiles = std::min(S.n_tiles(), c->cfg.max_tiles);
   const uint32_t tiles_before = c->tiles_initialised;
@@ -697,6 +728,12 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
     const bool time_apply = set >= 0 && c->pset[set].apply;
     if (time_apply) c->pset[set].applied = true;
+    // long runs (voxels next to the sensor) are listed first; then the two update kernels run side by side:
+    // k_apply on the tail stream, k_apply_long on its own stream (disjoint voxels)
+    hipLaunchKernelGGL(k_find_long, dim3(ab), dim3(256), 0, st, F.seq_bits, n_pairs, (const uint64_t*)sp, c->d_long_list,
+                       S.d_counters);
+    HIPCHK(c, hipEventRecord(S.fork, st));
+    HIPCHK(c, hipStreamWaitEvent(c->stream_long, S.fork, 0));
 #define KS_LAUNCH_APPLY_M(MODE, MERGED)                                                                              \
   if (time_apply)                                                                                                    \
     hipExtLaunchKernelGGL((k_apply<MODE, MERGED>), dim3(ab), dim3(256), 0, st, c->pset[set].k0, c->pset[set].k1, 0,   \
@@ -712,8 +749,8 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     KS_LAUNCH_APPLY_M(MODE, false);                                                                                  \
   }                                                                                                                  \
   stage_mark(c, set, 9);                                                                                             \
-  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(128), 0, st, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table,   \
-                     c->pool, c->d_label_lut, c->d_long_list, S.d_counters)
+  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(128), 0, c->stream_long, F, n_pairs, sp, S.d_rays, S.d_deltas, \
+                     c->table, c->pool, c->d_label_lut, c->d_long_list, S.d_counters)
     switch (c->cfg.color_mode) {
       case KS_COLOR_MODE_COLOR: KS_LAUNCH_APPLY(KS_COLOR_MODE_COLOR); break;
       case KS_COLOR_MODE_SEMANTIC: KS_LAUNCH_APPLY(KS_COLOR_MODE_SEMANTIC); break;
@@ -721,6 +758,8 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     }
 #undef KS_LAUNCH_APPLY
 #undef KS_LAUNCH_APPLY_M
+    HIPCHK(c, hipEventRecord(S.join, c->stream_long));
+    HIPCHK(c, hipStreamWaitEvent(st, S.join, 0));
   } else {
     stage_mark(c, set, 7);
     stage_mark(c, set, 8);
@@ -826,7 +865,7 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
   // (its snapshot is long there: the host never waits for the march that is still running, and the
   // next call can enqueue stage A while this frame's march is in flight); the statistics returned
   // are those of the frames completed here
-  const uint64_t lag = cfg.pipeline_frames >= 2 ? 2u : 1u;
+  const uint64_t lag = (uint64_t)std::min(std::max(cfg.pipeline_frames, 1), 4);
   FrameSlot& S = c->slot[c->frame_no % kSlots];
   if (S.pending && (rc = frame_tail(c, S))) return rc;  // cannot happen: the slot's frame is 4 calls old
   const uint64_t this_frame = c->frame_no;
@@ -984,6 +1023,8 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   if (c->cfg.early_out_phase_growth == 0) c->cfg.early_out_phase_growth = 32;
   c->uses_early_out = uses_early_out;
   {
+    const char* hpf = getenv("KS_HOST_PROF");
+    c->host_prof = hpf && hpf[0] == '1';
     const char* ng = getenv("KS_NO_GRAPH");
     c->use_graphs = !(ng && ng[0] == '1');
   }
@@ -1002,8 +1043,9 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   } while (0)
   CRCHK(hipSetDevice(cfg->device_id));
   CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
   if (cfg->pipeline_frames) {
-    c->n_march = 3;
+    c->n_march = kMarchStreams;
     for (int i = 0; i < c->n_march; ++i) CRCHK(hipStreamCreateWithFlags(&c->stream_march_[i], hipStreamNonBlocking));
     CRCHK(hipStreamCreateWithFlags(&c->stream_tail, hipStreamNonBlocking));
   } else {
@@ -1054,6 +1096,8 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     CRCHK(hipEventCreateWithFlags(&S.a_done, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
   }
 #undef CRCHK
   if (ensure_points(c, cfg->max_points) != KS_OK) {
@@ -1067,11 +1111,16 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
 
 void ks_destroy(ks_ctx* c) {
   if (!c) return;
+  if (c->host_prof && c->frame_no)
+    fprintf(stderr, "[ks host prof] frames %llu: per frame us  A %.1f  B %.1f  T %.1f  (radix sort launches inside A+T: %.1f)\n",
+            (unsigned long long)c->frame_no, 1e6 * (c->hp_a - c->hp_b) / c->frame_no, 1e6 * c->hp_b / c->frame_no,
+            1e6 * c->hp_t / c->frame_no, 1e6 * c->hp_sort / c->frame_no);
   if (c->stream_tail && c->stream_tail != c->stream) (void)hipStreamSynchronize(c->stream_tail);
   for (auto sm : c->stream_march_)
     if (sm && sm != c->stream) (void)hipStreamSynchronize(sm);
+  if (c->stream_long) (void)hipStreamSynchronize(c->stream_long);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_color_lut,
+  void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_observed_[3], c->d_color_lut,
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_pairs2, c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
@@ -1089,6 +1138,8 @@ void ks_destroy(ks_ctx* c) {
     if (S.h_snap) (void)hipHostFree(S.h_snap);
     if (S.ready) (void)hipEventDestroy(S.ready);
     if (S.tail_done) (void)hipEventDestroy(S.tail_done);
+    if (S.fork) (void)hipEventDestroy(S.fork);
+    if (S.join) (void)hipEventDestroy(S.join);
     if (S.a_done) (void)hipEventDestroy(S.a_done);
   }
   for (auto& P : c->pset) {
@@ -1100,6 +1151,7 @@ void ks_destroy(ks_ctx* c) {
   if (c->stream_tail && c->stream_tail != c->stream) (void)hipStreamDestroy(c->stream_tail);
   for (auto sm : c->stream_march_)
     if (sm && sm != c->stream) (void)hipStreamDestroy(sm);
+  if (c->stream_long) (void)hipStreamDestroy(c->stream_long);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

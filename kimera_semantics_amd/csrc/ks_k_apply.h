@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
   // label -> colour table in LDS: a global lookup per voxel would sit, with its full latency, between
   // the recurrence and the record store of every iteration
   __shared__ uint32_t s_lut[256];
-  s_lut[threadIdx.x] = label_lut[threadIdx.x];  // 256 threads; made visible by block_append's barriers below
+  s_lut[threadIdx.x] = label_lut[threadIdx.x];  // 256 threads
   const uint32_t lane = lane_id();
   const unsigned long long wbase = ((unsigned long long)blockIdx.x * 4ull + (threadIdx.x >> 6)) * 64ull;
   const unsigned long long i = wbase + lane;
@@ -103,8 +103,7 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
     if (head) is_long = (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> F.seq_bits) == vox);
     u = load_update_ops<!MERGED && COLOR_MODE != KS_COLOR_MODE_COLOR>(F, rays, key, voxel_ref(T, vox));
   }
-  const uint32_t lpos = block_append(head && is_long, &C->n_long);
-  if (head && is_long) long_list[lpos] = i;
+  __syncthreads();  // s_lut
 
   // run boundaries inside the window: every head (short or long) and every invalid lane ends a run
   const unsigned long long bounds = __ballot(head || !valid);
@@ -275,6 +274,22 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
     const bool wr = active && sub < 7u;
     rec[wr ? sub : 7u] = wr ? outv : make_uint4(0u, 0u, 0u, 0u);
   }
+}
+
+// Heads of runs of >= kLongRun updates, found before either apply kernel runs: k_apply (short runs) and
+// k_apply_long (long runs) touch disjoint voxels and are launched side by side on two streams.
+__global__ void __launch_bounds__(256) k_find_long(uint32_t seq_bits, unsigned long long n_pairs,
+                                                   const uint64_t* __restrict__ pairs,
+                                                   unsigned long long* __restrict__ long_list, Counters* C) {
+  const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
+  bool is_long = false;
+  if (i < n_pairs) {
+    const uint32_t vox = (uint32_t)(pairs[i] >> seq_bits);
+    const bool head = (i == 0) || ((uint32_t)(pairs[i - 1] >> seq_bits) != vox);
+    is_long = head && (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> seq_bits) == vox);
+  }
+  const uint32_t lpos = block_append(is_long, &C->n_long);
+  if (is_long) long_list[lpos] = i;
 }
 
 template <int COLOR_MODE>

@@ -92,6 +92,76 @@ __device__ __forceinline__ void dda_next_round(const LaneGroup<LPR>& G, Dda& rou
   round_start.tz = G.from(mine.tz, LPR - 1);
 }
 
+// ------------------------------------------------------------------------------------------
+// EXACT PARALLEL RAY CASTER: 64 consecutive steps of ONE ray by one wavefront.  The caster's state is three
+// independent float accumulations (t_to_next[a] += t_step[a]); which axis steps next is a 3-way merge of
+// the three increasing sequences of crossing times, ties going to the lower axis (Eigen's minCoeff = first
+// strict minimum).  Lanes 0..2 replay the three accumulations exactly (65 dependent adds instead of 64
+// full caster steps), every lane then ranks crossing number `lane` of each axis in the merged order by
+// binary search (strict / non-strict comparison = the tie rule), and the crossing of rank r yields the voxel
+// of step r.  Valid while every ray component is non-zero and all times are finite (else the three
+// sequences are not increasing: NaN / inf cases of an axis-parallel ray go through the serial caster).
+// Checked against the serial caster on 3.5e5 random rays incl. 1.2e7 exact ties (tools/pdda_model.cpp).
+// ------------------------------------------------------------------------------------------
+constexpr int kES = 66;  // floats per axis of the LDS scratch (65 used)
+__device__ __forceinline__ bool dda_parallel_ok(const Dda& d) {
+  return d.sx != 0 && d.sy != 0 && d.sz != 0 && isfinite(d.tx) && isfinite(d.ty) && isfinite(d.tz) && isfinite(d.dx) &&
+         isfinite(d.dy) && isfinite(d.dz);
+}
+template <bool LE>
+__device__ __forceinline__ int sorted_count(const float* e, float v) {  // #{i < 64 : e[i] < v}  (LE: <=)
+  int base = 0;
+#pragma unroll
+  for (int h = 32; h >= 1; h >>= 1) {
+    const float x = e[base + h - 1];
+    base += (LE ? (x <= v) : (x < v)) ? h : 0;
+  }
+  const float x = e[base];
+  return base + ((LE ? (x <= v) : (x < v)) ? 1 : 0);
+}
+// st: wave-uniform state at the round's first step (advanced by 64 steps on return); E: 3 * kES floats of LDS
+// private to the wavefront; visit(r, vx, vy, vz) is called once for every step r in [0, 64), by the lane
+// that owns the crossing which follows it.
+template <typename Visit>
+__device__ __forceinline__ void dda_round64(Dda& st, float* E, uint32_t lane, Visit&& visit) {
+  if (lane < 3) {
+    float t = lane == 0 ? st.tx : lane == 1 ? st.ty : st.tz;
+    const float d = lane == 0 ? st.dx : lane == 1 ? st.dy : st.dz;
+    float* e = E + lane * kES;
+    for (int i = 0; i < 65; ++i) {
+      e[i] = t;
+      t = t + d;
+    }
+  }
+  const float *Ex = E, *Ey = E + kES, *Ez = E + 2 * kES;
+  const float ex = Ex[lane], ey = Ey[lane], ez = Ez[lane];
+  const int cyx = sorted_count<false>(Ey, ex), czx = sorted_count<false>(Ez, ex);
+  const int cxy = sorted_count<true>(Ex, ey), czy = sorted_count<false>(Ez, ey);
+  const int cxz = sorted_count<true>(Ex, ez), cyz = sorted_count<true>(Ey, ez);
+  const int rx = (int)lane + cyx + czx, ry = (int)lane + cxy + czy, rz = (int)lane + cxz + cyz;
+  if (rx < 64) visit((uint32_t)rx, st.cx + st.sx * (int)lane, st.cy + st.sy * cyx, st.cz + st.sz * czx);
+  if (ry < 64) visit((uint32_t)ry, st.cx + st.sx * cxy, st.cy + st.sy * (int)lane, st.cz + st.sz * czy);
+  if (rz < 64) visit((uint32_t)rz, st.cx + st.sx * cxz, st.cy + st.sy * cyz, st.cz + st.sz * (int)lane);
+  const int nx = (int)__popcll(__ballot(rx < 64)), ny = (int)__popcll(__ballot(ry < 64)), nz = (int)__popcll(__ballot(rz < 64));
+  const float ntx = Ex[nx], nty = Ey[ny], ntz = Ez[nz];
+  st.cx += st.sx * nx;
+  st.cy += st.sy * ny;
+  st.cz += st.sz * nz;
+  st.tx = ntx;
+  st.ty = nty;
+  st.tz = ntz;
+}
+__device__ __forceinline__ Dda dda_bcast(const Dda& d, int src) {
+  Dda r;
+  r.cx = __shfl(d.cx, src); r.cy = __shfl(d.cy, src); r.cz = __shfl(d.cz, src);
+  r.sx = __shfl(d.sx, src); r.sy = __shfl(d.sy, src); r.sz = __shfl(d.sz, src);
+  r.tx = __shfl(d.tx, src); r.ty = __shfl(d.ty, src); r.tz = __shfl(d.tz, src);
+  r.dx = __shfl(d.dx, src); r.dy = __shfl(d.dy, src); r.dz = __shfl(d.dz, src);
+  r.steps = __shfl(d.steps, src);
+  r.in_range = true;
+  return r;
+}
+
 constexpr uint32_t kChains = 1024;      // = the 1024 groups of the "mixed" integration order
 constexpr uint32_t kPrivSlots = 1024;   // chain-private direct-mapped set (8 KiB of LDS per chain)
 constexpr uint32_t kCntBroke = 1u << 31;  // cnt[] flag: the ray stopped on a voxel it visited but did not update
@@ -172,7 +242,7 @@ __device__ __forceinline__ bool priv_lookup(const unsigned long long* priv, uint
 }
 
 // LDS per wavefront: private set | keys of the first 16 voxels of 16 rays | keys of one long ray | per-ray words
-__host__ __device__ inline uint32_t test_lds_words64(uint32_t steps_cap) { return kPrivSlots + 256u + steps_cap + 16u; }
+__host__ __device__ inline uint32_t test_lds_words64(uint32_t steps_cap) { return kPrivSlots + 256u + steps_cap + 16u + (3u * kES + 1u) / 2u; }
 
 __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __restrict__ Fp, uint32_t g0, uint32_t g1,
                                                        uint32_t steps_cap, const uint8_t* __restrict__ live,
@@ -188,6 +258,7 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
   unsigned long long* keys = priv + kPrivSlots;        // [16 rays][16 steps]  slot << 32 | hash
   unsigned long long* lkeys = keys + 256;              // [steps_cap]          the long ray's voxels from step 16 on
   uint32_t* rinfo = (uint32_t*)(lkeys + steps_cap);    // [16] steps of the ray | [16] shared-set hit mask
+  float* escr = (float*)(rinfo + 32);                  // [3 * kES] scratch of the parallel caster
   for (uint32_t i = lane; i < kPrivSlots; i += 64) priv[i] = 0ull;  // wave-private: no block barrier needed
   if (C->err & (kErrLabel | kErrIndex)) return;
   const uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave;
@@ -270,12 +341,22 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
       ++st_long;
 #endif
       uint32_t s0 = 16;
+      Dda ust = dda_bcast(dda, (int)j);          // the ray's state at step 16, wave-uniform
+      const bool par = dda_parallel_ok(ust);
       for (;;) {
 #ifdef KS_STATS
         ++st_rounds;
 #endif
         const uint32_t n_round = (uint32_t)steps_j + 1u - s0 < 64u ? (uint32_t)steps_j + 1u - s0 : 64u;
-        if (lane == j) {
+        if (par) {  // all 64 lanes: the exact parallel caster
+          dda_round64(ust, escr, lane, [&](uint32_t r, int vx, int vy, int vz) {
+            if (r < n_round) {
+              const uint32_t h = index_hash(vx, vy, vz);
+              const uint32_t slot = (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask);
+              lkeys[s0 - 16u + r] = ((unsigned long long)slot << 32) | h;
+            }
+          });
+        } else if (lane == j) {  // axis-parallel ray (NaN / inf crossing times): its owner lane walks it
           for (uint32_t i = 0; i < n_round; ++i) {
             const uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
             const uint32_t slot = (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask);
@@ -332,28 +413,83 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
 
 // k_mark — the marks of the phase covering positions [pos0, pos1) enter the shared set: every visited
 // voxel of every live ray of the phase, one atomicMax each (the entry with the highest (position, hash)
-// stays = the reference's last writer in serial order).  One lane per ray, walking it serially; the
-// atomics return nothing, so nothing waits for memory.
+// stays = the reference's last writer in serial order).  The atomics return nothing, so nothing waits
+// for memory.  One lane per ray walks its first 32 voxels serially; the few rays that go further are then
+// taken one at a time by the whole wavefront (exact parallel caster, 64 voxels per round).
+constexpr uint32_t kLaneWalk = 32;
+// Work split of the kernels that walk whole rays (k_mark, k_emit_lane): RPW rays per wavefront, owned by its
+// first RPW lanes.  RPW = 64 when most rays are a few voxels long (fast with the early-out), 8 when rays are
+// long (merged bundles, 2 cm voxels): the long part of a ray costs whole-wavefront rounds, so fewer rays per
+// wavefront means more wavefronts sharing that work.  Per wavefront, the tail beyond kLaneWalk voxels is
+// either walked by the owner lanes (all at once, as long as the longest) or taken ray by ray with the
+// parallel caster, whichever the step counts say is shorter.
+__device__ __forceinline__ bool tails_by_wavefront(unsigned long long long_mask, uint32_t my_len) {
+  if (long_mask == 0ull) return false;
+  uint32_t rounds = 0, longest = 0;
+  for (unsigned long long m = long_mask; m != 0ull; m &= m - 1ull) {
+    const uint32_t v = __shfl(my_len, __ffsll((long long)m) - 1);
+    rounds += (v - kLaneWalk + 63u) / 64u;
+    longest = v > longest ? v : longest;
+  }
+  return rounds * 8u < longest - kLaneWalk;   // a 64-voxel round ~ 8 owner-lane steps
+}
+template <int RPW>
 __global__ void __launch_bounds__(256) k_mark(const FrameParams* __restrict__ Fp, uint32_t pos0, uint32_t pos1,
                                               const uint32_t* __restrict__ ray_list, const RayDesc* __restrict__ rays,
                                               const uint32_t* __restrict__ cnt, const Counters* C) {
+  __shared__ float s_e[4][3 * kES];
   const FrameParams& F = *Fp;
   uint64_t* __restrict__ observed = F.observed;
   if (C->err & (kErrLabel | kErrIndex)) return;
-  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
-  if (r >= C->n_rays) return;
-  const uint32_t pos = ray_list[r];
-  if (pos < pos0 || pos >= pos1) return;
-  const uint32_t cv = cnt[pos];
-  const uint32_t visited = (cv & ~kCntBroke) + ((cv & kCntBroke) ? 1u : 0u);
-  const RayDesc d = rays[ray_index(F, pos)];
-  Dda dda;
-  dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, false);
-  for (uint32_t s = 0; s < visited; ++s) {
-    const uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
-    atomicMax((unsigned long long*)&observed[((uint64_t)h + F.observed_offset) & kSetMask],
-              (unsigned long long)obs_entry(F.obs_tag, pos, h));
-    dda.advance();
+  const uint32_t lane = lane_id();
+  const uint32_t r0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)RPW;  // first ray of this wavefront
+  const uint32_t r = r0 + lane;
+  if (r0 >= C->n_rays) return;  // whole wavefront idle
+  uint32_t pos = 0, visited = 0;
+  Dda dda{};
+  if (lane < (uint32_t)RPW && r < C->n_rays) {
+    pos = ray_list[r];
+    if (pos >= pos0 && pos < pos1) {
+      const uint32_t cv = cnt[pos];
+      visited = (cv & ~kCntBroke) + ((cv & kCntBroke) ? 1u : 0u);
+      const RayDesc d = rays[ray_index(F, pos)];
+      dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, false);
+    }
+  }
+  const unsigned long long long_mask = __ballot(visited > kLaneWalk);
+  const bool by_wave = tails_by_wavefront(long_mask, visited);
+  const uint32_t own = (by_wave && visited > kLaneWalk) ? kLaneWalk : visited;
+  for (uint32_t s = 0; __ballot(s < own) != 0ull; ++s) {
+    if (s < own) {
+      const uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
+      atomicMax((unsigned long long*)&observed[((uint64_t)h + F.observed_offset) & kSetMask],
+                (unsigned long long)obs_entry(F.obs_tag, pos, h));
+    }
+    dda.advance(s < own);
+  }
+  float* escr = s_e[threadIdx.x >> 6];
+  for (unsigned long long todo = by_wave ? long_mask : 0ull; todo != 0ull; todo &= todo - 1ull) {
+    const int j = __ffsll((long long)todo) - 1;
+    Dda ust = dda_bcast(dda, j);  // state at step kLaneWalk
+    const uint32_t v_j = __shfl(visited, j), pos_j = __shfl(pos, j);
+    if (dda_parallel_ok(ust)) {
+      for (uint32_t s0 = kLaneWalk; s0 < v_j; s0 += 64) {
+        dda_round64(ust, escr, lane, [&](uint32_t rr, int vx, int vy, int vz) {
+          if (s0 + rr < v_j) {
+            const uint32_t h = index_hash(vx, vy, vz);
+            atomicMax((unsigned long long*)&observed[((uint64_t)h + F.observed_offset) & kSetMask],
+                      (unsigned long long)obs_entry(F.obs_tag, pos_j, h));
+          }
+        });
+      }
+    } else if ((int)lane == j) {
+      for (uint32_t s = kLaneWalk; s < visited; ++s) {
+        const uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
+        atomicMax((unsigned long long*)&observed[((uint64_t)h + F.observed_offset) & kSetMask],
+                  (unsigned long long)obs_entry(F.obs_tag, pos, h));
+        dda.advance();
+      }
+    }
   }
 }
 
@@ -511,6 +647,138 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Fp
   }
 }
 
+// k_emit_lane — the same emission without anti-grazing (every step of a ray emits): ONE LANE PER RAY walks the
+// first 32 voxels serially (consecutive voxels share their tile: one table lookup per tile crossing), the few
+// rays that go further are then taken one at a time by the whole wavefront (exact parallel caster).
+template <int RPW>
+__global__ void __launch_bounds__(256) k_emit_lane(const FrameParams* __restrict__ Fp, uint32_t n_scan,
+                                                   const uint32_t* __restrict__ ray_list, const RayDesc* __restrict__ rays,
+                                                   const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ lp,
+                                                   const unsigned long long* __restrict__ bt, TileTable T, Pool P,
+                                                   uint64_t* __restrict__ pairs, unsigned long long pairs_cap, Counters* C) {
+  const FrameParams& F = *Fp;
+  if (blockIdx.x != 0 && blockIdx.x * 4u * (uint32_t)RPW >= C->n_rays) return;
+  extern __shared__ unsigned long long s_bt[];
+  __shared__ unsigned long long s_carry;
+  __shared__ float s_e[4][3 * kES];
+  const uint32_t nb = (n_scan + kScanBlock - 1) / kScanBlock;
+  if (threadIdx.x == 0) s_carry = 0ull;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < nb; b0 += 256) {
+    const uint32_t b = b0 + threadIdx.x;
+    const unsigned long long v = b < nb ? bt[b] : 0ull;
+    __shared__ unsigned long long s_w[4];
+    unsigned long long x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long y = __shfl_up(x, o);
+      if (lane_id() >= (uint32_t)o) x += y;
+    }
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = x;
+    __syncthreads();
+    unsigned long long wb = s_carry;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wb += s_w[w];
+    if (b < nb) s_bt[b] = wb + x - v;
+    __syncthreads();
+    if (threadIdx.x == 255) s_carry = wb + x;
+    __syncthreads();
+  }
+  const unsigned long long total = s_carry;
+  if (blockIdx.x == 0 && threadIdx.x == 0) C->n_pairs = total;
+  if (total > pairs_cap) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&C->err, kErrPairs);
+    return;
+  }
+  if (C->err & (kErrLabel | kErrIndex)) return;
+  const uint32_t lane = lane_id();
+  const uint32_t n_rays = C->n_rays;
+  const uint32_t r = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)RPW + lane;
+  uint32_t count = 0;
+  unsigned long long base = 0;
+  uint64_t key_lo = 0;
+  Dda dda{};
+  if (lane < (uint32_t)RPW && r < n_rays) {
+    const uint32_t p = ray_list[r];
+    const RayDesc d = rays[ray_index(F, p)];
+    const bool clearing = ((d.info >> 10) & 1u) != 0;
+    const uint32_t si = p + ((F.method == KS_METHOD_MERGED && clearing) ? F.n : 0u);
+    count = cnt[si] & ~kCntBroke;
+    base = s_bt[si / kScanBlock] + lp[si];
+    key_lo = ((uint64_t)((d.info & 0x1fu) | (((d.info >> 8) & 3u) << 5) | (((d.info >> 10) & 1u) << 7)) << 56) |
+             (uint64_t)((F.method == KS_METHOD_MERGED && clearing) ? (p | F.clear_bit) : p);
+    dda.setup(F.T.t, {d.px, d.py, d.pz}, clearing, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
+              /*cast_from_origin=*/F.method == KS_METHOD_MERGED);
+  }
+  auto wait_slot = [&](uint32_t got, uint32_t hpos) -> uint32_t {
+    // the allocating lane has stored the slot before it left tile_slot_nowait: this terminates
+    uint32_t spins = 0;
+    while (got == kSlotPending) {
+      got = __hip_atomic_load(&T.ent[hpos].val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (++spins > (1u << 22)) {
+        atomicOr(&C->err, kErrTable);
+        got = kSlotBad;
+      }
+    }
+    if (got < T.max_tiles) P.updated[got] = 1;
+    else atomicOr(&C->err, kErrPool);  // pool exhausted (now or in an earlier frame): this frame is not applied
+    return got;
+  };
+  const unsigned long long long_mask = __ballot(count > kLaneWalk);
+  const bool by_wave = tails_by_wavefront(long_mask, count);
+  const uint32_t own = (by_wave && count > kLaneWalk) ? kLaneWalk : count;
+  uint64_t last_tile = kEmpty64;
+  uint32_t slot = 0;
+  for (uint32_t s = 0; __ballot(s < own) != 0ull; ++s) {
+    const bool on = s < own;
+    uint32_t hpos = 0, got = 0;
+    bool need_tile = false;
+    if (on) {
+      const uint64_t tk = pack_tile(dda.cx >> 3, dda.cy >> 3, dda.cz >> 3);
+      if (tk != last_tile) {
+        need_tile = true;
+        last_tile = tk;
+        got = tile_slot_nowait(T, C, tk, &hpos);
+      }
+    }
+    if (need_tile) slot = wait_slot(got, hpos);  // (the wave has reconverged)
+    if (on) {
+      const uint32_t local = (uint32_t)(dda.cx & 7) + 8u * ((uint32_t)(dda.cy & 7) + 8u * (uint32_t)(dda.cz & 7));
+      pairs[base + s] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | key_lo;
+    }
+    dda.advance(on);
+  }
+  float* escr = s_e[threadIdx.x >> 6];
+  for (unsigned long long todo = by_wave ? long_mask : 0ull; todo != 0ull; todo &= todo - 1ull) {
+    const int j = __ffsll((long long)todo) - 1;
+    Dda ust = dda_bcast(dda, j);  // state at step kLaneWalk
+    const uint32_t c_j = __shfl(count, j);
+    const unsigned long long base_j = __shfl(base, j);
+    const uint64_t key_j = __shfl(key_lo, j);
+    if (dda_parallel_ok(ust)) {
+      for (uint32_t s0 = kLaneWalk; s0 < c_j; s0 += 64) {
+        dda_round64(ust, escr, lane, [&](uint32_t rr, int vx, int vy, int vz) {
+          if (s0 + rr < c_j) {
+            uint32_t hpos = 0;
+            const uint32_t got = tile_slot_nowait(T, C, pack_tile(vx >> 3, vy >> 3, vz >> 3), &hpos);
+            const uint32_t sl = wait_slot(got, hpos);
+            const uint32_t local = (uint32_t)(vx & 7) + 8u * ((uint32_t)(vy & 7) + 8u * (uint32_t)(vz & 7));
+            pairs[base_j + s0 + rr] = ((uint64_t)(sl * (uint32_t)kTileVoxels + local) << F.seq_bits) | key_j;
+          }
+        });
+      }
+    } else if ((int)lane == j) {
+      for (uint32_t s = kLaneWalk; s < count; ++s) {
+        uint32_t hpos = 0;
+        const uint32_t got = tile_slot_nowait(T, C, pack_tile(dda.cx >> 3, dda.cy >> 3, dda.cz >> 3), &hpos);
+        const uint32_t sl = wait_slot(got, hpos);
+        const uint32_t local = (uint32_t)(dda.cx & 7) + 8u * ((uint32_t)(dda.cy & 7) + 8u * (uint32_t)(dda.cz & 7));
+        pairs[base + s] = ((uint64_t)(sl * (uint32_t)kTileVoxels + local) << F.seq_bits) | key_lo;
+        dda.advance();
+      }
+    }
+  }
+}
+
 // merged + anti-grazing: the number of steps of each bundle's ray that emit an update
 template <int LPR>
 __global__ void __launch_bounds__(256) k_count_grazing(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ ray_list,
@@ -535,6 +803,12 @@ __global__ void __launch_bounds__(256) k_count_grazing(const FrameParams* __rest
     if (s0 + LPR < walk) dda_next_round<LPR>(G, round, mine);
   }
   if (G.l == 0) cnt[p + (clearing ? F.n : 0u)] = total;
+}
+
+// The frame's parameters reach device memory through a kernel argument (a pageable-memory memcpy would go
+// through the runtime's staging path and can block the enqueueing thread).
+__global__ void __launch_bounds__(64) k_set_params(FrameParams F, FrameParams* __restrict__ out) {
+  if (threadIdx.x == 0) *out = F;
 }
 
 // End of stage B: the frame's counters and the persistent tile count go to pinned host memory,
