@@ -25,6 +25,9 @@
 // | 21 class priors), addressed through an open-addressing hash table keyed by the packed tile index.
 
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
 #include <cstring>
 #include <string.h>
 
@@ -150,6 +153,16 @@ struct ks_ctx {
   Counters* d_retry_counters = nullptr;  // scratch of the pair-buffer overflow retry
   size_t pairs_hint = 0;                 // largest pair count of a frame so far
   bool uses_early_out = false;           // fast integrator whose consecutive-collision limit can fire
+  // Pipelined contexts enqueue the tail of frame i-lag on a helper thread while the calling thread enqueues
+  // stages A and B of frame i (the host, not the GPU, bounds small frames: ~25 launches of ~8 us each per
+  // frame).  The call still returns only after both are done, so what a call delivers does not change.
+  std::thread tail_thread;
+  std::mutex tail_mu;
+  std::condition_variable tail_cv;
+  FrameSlot* tail_job = nullptr;   // posted by the caller, taken by the helper
+  bool tail_busy = false, tail_quit = false;
+  int tail_rc = KS_OK;
+  bool use_tail_thread = false;
   double hp_a = 0, hp_b = 0, hp_t = 0, hp_sort = 0;   // KS_HOST_PROF=1: host seconds spent enqueueing stage A / B / T, radix sorts (of A+T)
   bool host_prof = false;
   bool use_graphs = true;                // stage B replayed as a hipGraph (KS_NO_GRAPH=1 or a capture failure: plain launches)
@@ -407,7 +420,7 @@ void launch_emit(ks_ctx* c, FrameSlot& S, hipStream_t st, Counters* counters) {
                          S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
                          (unsigned long long)S.cap_pairs_in, counters);
     else
-      hipLaunchKernelGGL(k_emit_lane<64>, dim3((uint32_t)((n + 255) / 256)), dim3(256), lds, st, (const FrameParams*)S.d_F,
+      hipLaunchKernelGGL(k_emit_lane<16>, dim3((uint32_t)((n + 63) / 64)), dim3(256), lds, st, (const FrameParams*)S.d_F,
                          S.n_scan, S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
                          (unsigned long long)S.cap_pairs_in, counters);
   }
@@ -427,7 +440,6 @@ void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max) 
   const ks_config& cfg = c->cfg;
   const size_t n = S.n;
   const FrameParams* dF = S.d_F;
-  const uint32_t nb = (uint32_t)((n + 255) / 256);
   if (c->uses_early_out) {
     // ordered-phase early-out: per phase, k_test decides how far the phase's rays get against the set as it
     // stood when the phase began, then k_mark enters their marks (ks_k_march.h)
@@ -446,7 +458,8 @@ void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max) 
         hipLaunchKernelGGL(k_mark<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), 0, sm, dF, p0, p1, S.d_ray_list, S.d_rays, S.d_cnt,
                            S.d_counters);
       else
-        hipLaunchKernelGGL(k_mark<64>, dim3(nb), dim3(256), 0, sm, dF, p0, p1, S.d_ray_list, S.d_rays, S.d_cnt, S.d_counters);
+        hipLaunchKernelGGL(k_mark<64>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, sm, dF, p0, p1, S.d_ray_list, S.d_rays,
+                           S.d_cnt, S.d_counters);
     }
   }
   if (cfg.method == KS_METHOD_MERGED && cfg.enable_anti_grazing)
@@ -815,6 +828,35 @@ int quiesce(ks_ctx* c) {
   return rc;
 }
 
+void tail_worker(ks_ctx* c) {
+  (void)hipSetDevice(c->cfg.device_id);
+  std::unique_lock<std::mutex> lk(c->tail_mu);
+  for (;;) {
+    c->tail_cv.wait(lk, [&] { return c->tail_job != nullptr || c->tail_quit; });
+    if (c->tail_quit) return;
+    FrameSlot* S = c->tail_job;
+    c->tail_job = nullptr;
+    lk.unlock();
+    const int rc = frame_tail(c, *S);
+    lk.lock();
+    c->tail_rc = rc;
+    c->tail_busy = false;
+    c->tail_cv.notify_all();
+  }
+}
+void tail_post(ks_ctx* c, FrameSlot* S) {
+  std::lock_guard<std::mutex> lk(c->tail_mu);
+  c->tail_job = S;
+  c->tail_busy = true;
+  c->tail_rc = KS_OK;
+  c->tail_cv.notify_all();
+}
+int tail_join(ks_ctx* c) {
+  std::unique_lock<std::mutex> lk(c->tail_mu);
+  c->tail_cv.wait(lk, [&] { return !c->tail_busy; });
+  return c->tail_rc;
+}
+
 int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba, const uint8_t* d_labels,
                           size_t n, int freespace, ks_frame_stats* stats) {
   if (c->fatal) {
@@ -869,10 +911,16 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
   FrameSlot& S = c->slot[c->frame_no % kSlots];
   if (S.pending && (rc = frame_tail(c, S))) return rc;  // cannot happen: the slot's frame is 4 calls old
   const uint64_t this_frame = c->frame_no;
-  if ((rc = frame_front(c, S, Tq, d_xyz, d_rgba, d_labels, n, freespace))) return rc;
-  if (this_frame >= lag) {
-    FrameSlot& due = c->slot[(this_frame - lag) % kSlots];
-    if (due.pending) rc = frame_tail(c, due);
+  FrameSlot* due = (this_frame >= lag) ? &c->slot[(this_frame - lag) % kSlots] : nullptr;
+  if (due && !due->pending) due = nullptr;
+  if (due && c->use_tail_thread) {
+    tail_post(c, due);  // the helper thread enqueues the tail of the frame `lag` calls back ...
+    const int rc_front = frame_front(c, S, Tq, d_xyz, d_rgba, d_labels, n, freespace);  // ... while this one enqueues A and B
+    rc = tail_join(c);
+    if (rc_front) rc = rc_front;
+  } else {
+    if ((rc = frame_front(c, S, Tq, d_xyz, d_rgba, d_labels, n, freespace))) return rc;
+    if (due) rc = frame_tail(c, *due);
   }
   deliver_stats(c, stats);
   return rc;
@@ -1105,12 +1153,25 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     ks_destroy(c);
     return KS_ERR_HIP;
   }
+  {
+    const char* nt = getenv("KS_NO_TAIL_THREAD");
+    c->use_tail_thread = cfg->pipeline_frames > 0 && !(nt && nt[0] == '1');
+    if (c->use_tail_thread) c->tail_thread = std::thread(tail_worker, c);
+  }
   *out = c;
   return KS_OK;
 }
 
 void ks_destroy(ks_ctx* c) {
   if (!c) return;
+  if (c->tail_thread.joinable()) {
+    {
+      std::lock_guard<std::mutex> lk(c->tail_mu);
+      c->tail_quit = true;
+    }
+    c->tail_cv.notify_all();
+    c->tail_thread.join();
+  }
   if (c->host_prof && c->frame_no)
     fprintf(stderr, "[ks host prof] frames %llu: per frame us  A %.1f  B %.1f  T %.1f  (radix sort launches inside A+T: %.1f)\n",
             (unsigned long long)c->frame_no, 1e6 * (c->hp_a - c->hp_b) / c->frame_no, 1e6 * c->hp_b / c->frame_no,
