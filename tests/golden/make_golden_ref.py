@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Golden DIGESTS generated with the REAL reference sources (oracle/_ref/libks_ref.so, built from
+/root/reference/kimera_semantics/src/*.cpp by oracle/ref_shim/build_ref.sh) at BASELINE.json's frame size and
+at C4 geometry.  The inputs are the deterministic synthetic frames (scene / pose / seed below); a fixture
+holds the allocated block set and one SHA-256 per block over (labels, priors, colours, distances, weights),
+so it stays a few KiB.  Run from the repo root in the build container:
+    python tests/golden/make_golden_ref.py
+Checked by tests/test_golden_ref.py: the oracle on the CPU tier, the HIP path on the GPU tier (the cases
+whose per-voxel order the GPU reproduces: `fast` with the early-out disabled)."""
+import hashlib
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from kimera_semantics_amd import synth  # noqa: E402
+from oracle import ref_py as R  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+C2 = dict(voxel_size=0.05, truncation=0.2, max_ray=5.0)
+C4 = dict(voxel_size=0.02, truncation=0.08, max_ray=10.0)
+CASES = {
+    # name: (method, geometry, scene, (w, h), hfov, pose index, seed, reference kwargs)
+    "ref_fast_noearlyout_640x480": ("fast", C2, "room", (640, 480), 90.0, 5, 5, dict(max_consecutive_ray_collisions=1 << 30)),
+    "ref_fast_noearlyout_c4": ("fast", C4, "hall", (320, 180), 75.0, 3, 3, dict(max_consecutive_ray_collisions=1 << 30)),
+    "ref_fast_default_640x480": ("fast", C2, "room", (640, 480), 90.0, 5, 5, dict()),       # serial early-out (oracle only)
+    "ref_merged_640x480": ("merged", C2, "room", (640, 480), 90.0, 5, 5, dict()),          # unordered_map bundle order
+    "ref_merged_c4": ("merged", C4, "hall", (320, 180), 75.0, 3, 3, dict()),
+}
+
+
+def frame_of(case):
+    _, _, scene, size, hfov, pose, seed, _ = CASES[case]
+    radius = 1.5 if scene == "room" else 3.0
+    return synth.render_frame(synth.make_scene(scene), synth.trajectory_pose(pose, radius=radius), size[0], size[1],
+                              hfov_deg=hfov, seed=seed)
+
+
+def block_digests(t, s):
+    out = np.zeros((t.shape[0], 32), dtype=np.uint8)
+    for k in range(t.shape[0]):
+        hsh = hashlib.sha256()
+        for a in (s["label"][k], s["priors"][k], s["color"][k], t["distance"][k], t["weight"][k], t["color"][k]):
+            hsh.update(np.ascontiguousarray(a).tobytes())
+        out[k] = np.frombuffer(hsh.digest(), dtype=np.uint8)
+    return out
+
+
+def main():
+    tmp = tempfile.mkdtemp()
+    csv = os.path.join(tmp, "labels.csv")
+    R.write_label_csv(csv, synth.default_label_colors())
+    for name, (method, geom, *_rest, kw) in CASES.items():
+        f = frame_of(name)
+        r = R.Reference(method, csv, **geom, **kw)
+        r.integrate(f.T_G_C, f.xyz, f.rgba)
+        idx, t, s = r.download()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), block_indices=idx.astype(np.int32), digests=block_digests(t, s),
+                            touched=np.int64((t["weight"] > 0).sum()), n_points=np.int64(f.xyz.shape[0]))
+        print(name, "blocks", len(idx), "touched", int((t["weight"] > 0).sum()))
+
+
+if __name__ == "__main__":
+    main()
