@@ -210,6 +210,23 @@ int ks_get_tile_keys(ks_ctx* ctx, uint64_t* out, size_t cap, size_t* n);
 int ks_export_tiles_device(ks_ctx* ctx, const uint32_t* slots, size_t n, void* d_payload);
 int ks_merge_tiles_device(ks_ctx* ctx, const uint64_t* keys, size_t n, const void* d_payload);
 int ks_clear(ks_ctx* ctx);
+/* Resets the tiles at the given slots to the empty state (a rank that has handed tiles to their owner keeps
+ * them as empty deltas). */
+int ks_reset_tiles(ks_ctx* ctx, const uint32_t* slots, size_t n);
+/* Owner rank of a tile: splitmix64(key) % world. */
+int ks_tile_owner(uint64_t tile_key, int world);
+/* The frame-sharded path's ONE exchange step, for a C/C++ host: every rank of the RCCL
+ * communicator calls it after integrating its share of a batch of frames.  rccl_comm is the caller's
+ * ncclComm_t (one rank per GPU; librccl is loaded on first use, KS_RCCL_LIB overrides its path).  Tiles
+ * touched since the previous reduce travel to their owner rank (all peers at once: one grouped send/recv for
+ * the keys, one for the raw 64 KiB records, over xGMI); the owner folds them into its map in ascending
+ * source-rank order (deterministic; weight-averaged TSDF, additive class log-likelihoods, argmax + colour);
+ * the sender's copies start over as empty deltas, so the call can be repeated batch after batch without
+ * counting anything twice.  Afterwards rank r holds the authoritative state of the tiles it owns. */
+typedef struct ks_reduce_stats {
+  uint64_t tiles_sent, tiles_received, tiles_local, bytes_sent;
+} ks_reduce_stats;
+int ks_reduce(ks_ctx* ctx, void* rccl_comm, int rank, int world, ks_reduce_stats* stats);
 
 /* Diagnostics (used by tests): stable LSD radix sort of n HOST keys (key_bits = 32 or 64, bits
  * [0,end_bit)) and optional u32 payload with the library's own GPU sort. */

@@ -31,7 +31,7 @@ SEM_DTYPE = np.dtype([("label", "u1"), ("pad", "u1", (3,)), ("priors", "<f4", (N
 ABI_SYMBOLS = [
     "ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_set_color_to_label",
     "ks_integrate_points", "ks_integrate_points_device", "ks_integrate_depth", "ks_integrate_depth_device", "ks_num_blocks", "ks_get_block_indices",
-    "ks_get_updated_block_indices", "ks_download_blocks", "ks_upload_blocks", "ks_host_alloc", "ks_host_free", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear",
+    "ks_get_updated_block_indices", "ks_download_blocks", "ks_upload_blocks", "ks_host_alloc", "ks_host_free", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear", "ks_reset_tiles", "ks_tile_owner", "ks_reduce",
     "ks_debug_radix_sort", "ks_synchronize", "ks_flush", "ks_stream",
     "ks_profile_enable", "ks_profile_get",
 ]
@@ -60,6 +60,11 @@ class KsConfig(C.Structure):
 class KsFrameStats(C.Structure):
     _fields_ = [("n_points", C.c_uint64), ("n_valid_points", C.c_uint64), ("n_rays_cast", C.c_uint64),
                 ("n_voxel_updates", C.c_uint64), ("n_blocks_allocated", C.c_uint64)]
+
+
+class KsReduceStats(C.Structure):
+    _fields_ = [("tiles_sent", C.c_uint64), ("tiles_received", C.c_uint64), ("tiles_local", C.c_uint64),
+                ("bytes_sent", C.c_uint64)]
 
 
 class KsProfile(C.Structure):
@@ -118,6 +123,9 @@ def lib():
         L.ks_export_tiles_device.argtypes = [vp, vp, C.c_size_t, vp]
         L.ks_merge_tiles_device.argtypes = [vp, vp, C.c_size_t, vp]
         L.ks_clear.argtypes = [vp]
+        L.ks_reset_tiles.argtypes = [vp, vp, C.c_size_t]
+        L.ks_tile_owner.argtypes = [C.c_uint64, C.c_int]
+        L.ks_reduce.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(KsReduceStats)]
         L.ks_debug_radix_sort.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, C.c_uint]
         L.ks_synchronize.argtypes = [vp]
         L.ks_flush.argtypes = [vp, C.POINTER(KsFrameStats)]
@@ -296,6 +304,17 @@ class HipIntegrator:
 
     def clear(self):
         self._chk(lib().ks_clear(self._h))
+
+    def reset_tiles(self, slots: np.ndarray):
+        s = np.ascontiguousarray(slots, dtype=np.uint32)
+        self._chk(lib().ks_reset_tiles(self._h, _ptr(s), len(s)))
+
+    def reduce(self, rccl_comm, rank: int, world: int) -> dict:
+        """ks_reduce: rccl_comm is an ncclComm_t (int / c_void_p) created with the same librccl."""
+        st = KsReduceStats()
+        self._chk(lib().ks_reduce(self._h, C.c_void_p(rccl_comm) if rccl_comm else None, rank, world, C.byref(st)))
+        return {"tiles_sent": st.tiles_sent, "tiles_received": st.tiles_received, "tiles_local": st.tiles_local,
+                "bytes_sent": st.bytes_sent}
 
     def debug_radix_sort(self, keys: np.ndarray, vals=None, end_bit=None):
         keys = np.ascontiguousarray(keys).copy()

@@ -31,8 +31,10 @@
 #include <cstring>
 #include <string.h>
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1115,6 +1117,8 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipMalloc((void**)&c->pool.vox, mt * kTileVoxels * 8 * sizeof(uint4)));
   CRCHK(hipMalloc((void**)&c->pool.updated, mt));
   CRCHK(hipMemset(c->pool.updated, 0, mt));
+  CRCHK(hipMalloc((void**)&c->pool.dirty, mt));
+  CRCHK(hipMemset(c->pool.dirty, 0, mt));
   CRCHK(hipMalloc((void**)&c->d_start_set, sizeof(uint64_t) << kSetBits));
   // one early-out table per march stream when a frame's marks can never be seen by the next frame
   c->n_obs = (c->n_march > 1 && uses_early_out && cfg->clear_checks_every_n_frames <= 1) ? c->n_march : 1;
@@ -1181,7 +1185,7 @@ void ks_destroy(ks_ctx* c) {
     if (sm && sm != c->stream) (void)hipStreamSynchronize(sm);
   if (c->stream_long) (void)hipStreamSynchronize(c->stream_long);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_observed_[3], c->d_color_lut,
+  void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->pool.dirty, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_observed_[3], c->d_color_lut,
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_pairs2, c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
@@ -1579,6 +1583,188 @@ int ks_merge_tiles_device(ks_ctx* c, const uint64_t* keys, size_t n, const void*
   return KS_OK;
 }
 
+int ks_reset_tiles(ks_ctx* c, const uint32_t* slots, size_t n) {
+  if (!c || (n && !slots)) return KS_ERR_INVALID_ARG;
+  if (n == 0) return KS_OK;
+  if (int rc = quiesce(c)) return rc;
+  for (size_t i = 0; i < n; ++i)
+    if (slots[i] >= c->tiles_initialised) return KS_ERR_INVALID_ARG;
+  if (int rc = ensure_exchange(c, n)) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->d_xchg_u32, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_reset_tiles, dim3((uint32_t)n), dim3(512), 0, c->stream, c->pool, c->d_xchg_u32);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return KS_OK;
+}
+
+// ---- ks_reduce: the frame-sharded path's one exchange step, through RCCL ------------------
+// librccl is loaded on first use (the library itself has no link-time dependency on it); the communicator
+// is the caller's.  KS_RCCL_LIB overrides the path.
+namespace {
+struct RcclApi {
+  void* h = nullptr;
+  decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclSend) send = nullptr;
+  decltype(&ncclRecv) recv = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
+  decltype(&ncclGetErrorString) err_string = nullptr;
+  bool load(std::string* why) {
+    if (h) return true;
+    const char* env = getenv("KS_RCCL_LIB");
+    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* nm : names) {
+      if (!nm) continue;
+      h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
+    if (!h) { *why = "librccl not found (set KS_RCCL_LIB)"; return false; }
+    all_gather = (decltype(all_gather))dlsym(h, "ncclAllGather");
+    send = (decltype(send))dlsym(h, "ncclSend");
+    recv = (decltype(recv))dlsym(h, "ncclRecv");
+    group_start = (decltype(group_start))dlsym(h, "ncclGroupStart");
+    group_end = (decltype(group_end))dlsym(h, "ncclGroupEnd");
+    err_string = (decltype(err_string))dlsym(h, "ncclGetErrorString");
+    if (!all_gather || !send || !recv || !group_start || !group_end) { *why = "librccl lacks a required symbol"; h = nullptr; return false; }
+    return true;
+  }
+};
+RcclApi g_rccl;
+
+inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+}  // namespace
+
+#define NCCLCHK(ctx, expr)                                                                                    \
+  do {                                                                                                        \
+    ncclResult_t r_ = (expr);                                                                                 \
+    if (r_ != ncclSuccess) {                                                                                  \
+      (ctx)->err = std::string(#expr) + ": " + (g_rccl.err_string ? g_rccl.err_string(r_) : "rccl error");    \
+      return KS_ERR_HIP;                                                                                      \
+    }                                                                                                         \
+  } while (0)
+
+int ks_tile_owner(uint64_t tile_key, int world) { return world > 0 ? (int)(splitmix64(tile_key) % (uint64_t)world) : 0; }
+
+int ks_reduce(ks_ctx* c, void* rccl_comm, int rank, int world, ks_reduce_stats* stats) {
+  if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !rccl_comm)) return KS_ERR_INVALID_ARG;
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (c->fatal) return KS_ERR_INVALID_ARG;
+  int rc;
+  if ((rc = quiesce(c))) return rc;
+  const uint32_t nt = c->tiles_initialised;
+  std::vector<uint64_t> keys(nt);
+  std::vector<uint8_t> dirty(nt);
+  if (nt) {
+    HIPCHK(c, hipMemcpy(keys.data(), c->table.slot_keys, nt * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dirty.data(), c->pool.dirty, nt, hipMemcpyDeviceToHost));
+  }
+  if (stats) stats->tiles_local = nt;
+  if (world == 1) {  // everything is owned here: nothing travels
+    if (nt) HIPCHK(c, hipMemset(c->pool.dirty, 0, nt));
+    return KS_OK;
+  }
+  std::string why;
+  if (!g_rccl.load(&why)) {
+    c->err = why;
+    return KS_ERR_UNSUPPORTED;
+  }
+  ncclComm_t comm = (ncclComm_t)rccl_comm;
+  hipStream_t st = c->stream;
+  // 1) what goes where: tiles touched since the last reduce that another rank owns, grouped by owner
+  std::vector<std::vector<uint32_t>> to(world);
+  for (uint32_t s = 0; s < nt; ++s) {
+    if (!dirty[s]) continue;
+    const int o = ks_tile_owner(keys[s], world);
+    if (o != rank) to[o].push_back(s);
+  }
+  std::vector<int32_t> send_counts(world, 0);
+  std::vector<uint32_t> slots_cat;
+  std::vector<uint64_t> keys_cat;
+  for (int d = 0; d < world; ++d) {
+    send_counts[d] = (int32_t)to[d].size();
+    for (uint32_t s : to[d]) {
+      slots_cat.push_back(s);
+      keys_cat.push_back(keys[s]);
+    }
+  }
+  const size_t n_send = slots_cat.size();
+  // 2) every rank learns every rank's send counts (world x world int32)
+  int32_t* d_counts = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_counts, (size_t)(world + 1) * world * sizeof(int32_t)));
+  HIPCHK(c, hipMemcpyAsync(d_counts, send_counts.data(), world * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  NCCLCHK(c, g_rccl.all_gather(d_counts, d_counts + world, (size_t)world, ncclInt32, comm, st));
+  std::vector<int32_t> all_counts((size_t)world * world);
+  HIPCHK(c, hipMemcpyAsync(all_counts.data(), d_counts + world, all_counts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  (void)hipFree(d_counts);
+  std::vector<size_t> recv_counts(world), recv_off(world + 1, 0), send_off(world + 1, 0);
+  for (int src = 0; src < world; ++src) {
+    recv_counts[src] = (size_t)all_counts[(size_t)src * world + rank];
+    recv_off[src + 1] = recv_off[src] + recv_counts[src];
+    send_off[src + 1] = send_off[src] + (size_t)send_counts[src];
+  }
+  const size_t n_recv = recv_off[world];
+  // 3) keys and raw tile records: one grouped exchange each — on a fully connected xGMI node a rank talks
+  //    to all its peers at once (a ring all-reduce would be per-link bound and move every tile through every rank)
+  uint64_t *d_ksend = nullptr, *d_krecv = nullptr;
+  uint8_t *d_psend = nullptr, *d_precv = nullptr;
+  uint32_t* d_slots = nullptr;
+  HIPCHK(c, hipMalloc((void**)&d_ksend, std::max<size_t>(n_send, 1) * 8));
+  HIPCHK(c, hipMalloc((void**)&d_krecv, std::max<size_t>(n_recv, 1) * 8));
+  HIPCHK(c, hipMalloc((void**)&d_psend, std::max<size_t>(n_send, 1) * (size_t)KS_TILE_BYTES));
+  HIPCHK(c, hipMalloc((void**)&d_precv, std::max<size_t>(n_recv, 1) * (size_t)KS_TILE_BYTES));
+  HIPCHK(c, hipMalloc((void**)&d_slots, std::max<size_t>(n_send, 1) * 4));
+  auto free_all = [&]() {
+    (void)hipFree(d_ksend); (void)hipFree(d_krecv); (void)hipFree(d_psend); (void)hipFree(d_precv); (void)hipFree(d_slots);
+  };
+  if (n_send) {
+    HIPCHK(c, hipMemcpyAsync(d_ksend, keys_cat.data(), n_send * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(d_slots, slots_cat.data(), n_send * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_export_tiles, dim3((uint32_t)n_send), dim3(512), 0, st, c->pool, d_slots, (uint4*)d_psend);
+  }
+  NCCLCHK(c, g_rccl.group_start());
+  for (int peer = 0; peer < world; ++peer) {
+    if (peer == rank) continue;
+    if (send_counts[peer]) {
+      NCCLCHK(c, g_rccl.send(d_ksend + send_off[peer], (size_t)send_counts[peer], ncclUint64, peer, comm, st));
+      NCCLCHK(c, g_rccl.send(d_psend + send_off[peer] * (size_t)KS_TILE_BYTES, (size_t)send_counts[peer] * KS_TILE_BYTES, ncclUint8,
+                             peer, comm, st));
+    }
+    if (recv_counts[peer]) {
+      NCCLCHK(c, g_rccl.recv(d_krecv + recv_off[peer], recv_counts[peer], ncclUint64, peer, comm, st));
+      NCCLCHK(c, g_rccl.recv(d_precv + recv_off[peer] * (size_t)KS_TILE_BYTES, recv_counts[peer] * KS_TILE_BYTES, ncclUint8, peer, comm,
+                             st));
+    }
+  }
+  NCCLCHK(c, g_rccl.group_end());
+  std::vector<uint64_t> k_host(n_recv);
+  if (n_recv) HIPCHK(c, hipMemcpyAsync(k_host.data(), d_krecv, n_recv * 8, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  // 4) the owner folds what it received into its map, tiles of one key in ascending source-rank order
+  //    (the receive buffer is ordered by source rank), in one launch
+  if (n_recv && (rc = ks_merge_tiles_device(c, k_host.data(), n_recv, d_precv))) {
+    free_all();
+    return rc;
+  }
+  // 5) what was sent starts over as an empty delta here: a later reduce cannot count it twice
+  if (n_send) {
+    hipLaunchKernelGGL(k_reset_tiles, dim3((uint32_t)n_send), dim3(512), 0, st, c->pool, d_slots);
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
+  HIPCHK(c, hipMemset(c->pool.dirty, 0, c->tiles_initialised));  // owned tiles: authoritative here, nothing pending
+  free_all();
+  if (stats) {
+    stats->tiles_sent = n_send;
+    stats->tiles_received = n_recv;
+    stats->bytes_sent = n_send * (uint64_t)(KS_TILE_BYTES + 8);
+  }
+  return KS_OK;
+}
+
 int ks_clear(ks_ctx* c) {
   if (!c) return KS_ERR_INVALID_ARG;
   for (auto& S : c->slot) S.pending = false;  // a frame that was never applied is dropped with the map
@@ -1588,6 +1774,7 @@ int ks_clear(ks_ctx* c) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemset(c->table.ent, 0xff, ((size_t)c->table.mask + 1) * sizeof(TileEntry)));
   HIPCHK(c, hipMemset(c->pool.updated, 0, c->cfg.max_tiles));
+  HIPCHK(c, hipMemset(c->pool.dirty, 0, c->cfg.max_tiles));
   HIPCHK(c, hipMemset(c->d_state, 0, 64 * (kSlots + 1)));
   // a cleared context behaves like a fresh one: both approximate sets as their constructor leaves them
   HIPCHK(c, hipMemset(c->d_start_set, 0, sizeof(uint64_t) << kSetBits));

@@ -14,6 +14,28 @@ __global__ void __launch_bounds__(512) k_export_tiles(Pool P, const uint32_t* __
   for (int r = 0; r < 8; ++r) dst[r * 512 + threadIdx.x] = src[r * 512 + threadIdx.x];
 }
 
+// tiles handed to their owner rank start over as empty deltas (same content as k_init_tiles writes)
+__global__ void __launch_bounds__(512) k_reset_tiles(Pool P, const uint32_t* __restrict__ slots) {
+  const size_t slot = slots[blockIdx.x];
+  uint4* tile = P.vox + slot * (size_t)kTileVoxels * 8;
+  const uint32_t pi = __float_as_uint(kPriorInit);
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t q = r * 512u + threadIdx.x;
+    const uint32_t sub = q & 7u;
+    uint4 v;
+    if (sub == 0) v = make_uint4(0u, 0u, 0u, 255u);
+    else if (sub < 6) v = make_uint4(pi, pi, pi, pi);
+    else if (sub == 6) v = make_uint4(pi, 0u, 0u, 0u);
+    else v = make_uint4(0u, 0u, 0u, 0u);
+    tile[q] = v;
+  }
+  if (threadIdx.x == 0) {
+    P.updated[slot] = 1;
+    P.dirty[slot] = 0;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_insert_tiles(TileTable T, Counters* C, const uint64_t* __restrict__ keys, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) tile_insert(T, C, keys[i]);

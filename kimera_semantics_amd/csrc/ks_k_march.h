@@ -633,7 +633,7 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Fp
         }
       }
       slot = got;
-      if (slot < T.max_tiles) P.updated[slot] = 1;
+      if (slot < T.max_tiles) { P.updated[slot] = 1; P.dirty[slot] = 1; }
       else atomicOr(&C->err, kErrPool);  // pool exhausted (now or in an earlier frame): this frame is not applied
     }
     const uint64_t em = G.bits(__ballot(emit));
@@ -719,7 +719,7 @@ __global__ void __launch_bounds__(256) k_emit_lane(const FrameParams* __restrict
         got = kSlotBad;
       }
     }
-    if (got < T.max_tiles) P.updated[got] = 1;
+    if (got < T.max_tiles) { P.updated[got] = 1; P.dirty[got] = 1; }
     else atomicOr(&C->err, kErrPool);  // pool exhausted (now or in an earlier frame): this frame is not applied
     return got;
   };

@@ -109,7 +109,8 @@ struct Pool {
   // A record is exactly one 128-B line: the 8 lanes that cooperate on a voxel move it with one
   // coalesced 16-B access each, and a whole tile (512 voxels) is one contiguous 64 KiB range.
   uint4* vox;          // [tile][512][8]
-  uint8_t* updated;    // per tile
+  uint8_t* updated;    // per tile: touched since the host last fetched the updated-block list
+  uint8_t* dirty;      // per tile: touched since the last multi-GPU reduce (ks_reduce)
 };
 
 struct FrameParams {

@@ -12,7 +12,9 @@ New functionality: the reference is a single process.  Pro
      several ranks sent for the same key are folded in ascending source-rank order
      (deterministic): weight-averaged TSDF (Voxblox's layer-merge rule), additive class
      log-likelihoods, argmax + colour.
-After the reduce, rank r holds the authoritative state of the tiles it owns.
+After the reduce, rank r holds the authoritative state of the tiles it owns; its copies of tiles it sent
+away start over as empty deltas, so the reduce can be repeated batch after batch.  (The same exchange
+for a C/C++ host calling RCCL directly: ks_reduce in include/ks_hip.h.)
 
 The exchange logic is backend-agnostic: `store` only needs tile_keys() / export(slots) /
 merge(keys, payload); tests drive it on CPU with a numpy store over gloo.
@@ -67,6 +69,10 @@ class HipTileStore:
             self.torch.cuda.synchronize(self.device)
             self.integ.merge_tiles(keys, payload.data_ptr())
 
+    def reset(self, slots: np.ndarray):
+        if len(slots):
+            self.integ.reset_tiles(slots)
+
 
 def reduce_maps(store, group=None) -> dict:
     """All-to-all reduce of per-rank partial maps to tile owners.  Collective: every rank of
@@ -101,6 +107,9 @@ def reduce_maps(store, group=None) -> dict:
     k_host = k_recv.cpu().numpy().view(np.uint64)
     if n_recv:
         store.merge(k_host, p_recv)
+    # 5) what was sent starts over as an empty delta on the sender: a second reduce counts nothing twice
+    if hasattr(store, "reset"):
+        store.reset(slots_cat)
     return {"tiles_sent": int(sum(send_counts)), "tiles_received": n_recv, "tiles_local": int(len(keys)),
             "bytes_sent": int(sum(send_counts)) * TILE_WORDS * 4}
 

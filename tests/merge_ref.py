@@ -80,6 +80,10 @@ class NumpyTileStore:
         import torch
         return torch.empty((n, TILE_WORDS), dtype=torch.int32)
 
+    def reset(self, slots):
+        for s in slots:
+            self.tiles[self.order[int(s)]] = empty_tile()
+
     def merge(self, keys, payload):
         p = payload.numpy().view(np.uint32).reshape(len(keys), 512, 32)
         for k, rec in zip(keys.tolist(), p):

@@ -50,6 +50,9 @@ def _worker(rank, world, port, out_dir):
     for k, t in _make_rank_tiles(rank).items():
         store.add(k, t.copy())
     stats = PAR.reduce_maps(store)
+    # a second reduce without new integration must not count anything twice: what was sent has
+    # started over as an empty delta on the sender
+    PAR.reduce_maps(store)
     keys = store.tile_keys()
     mine = PAR.owned_tile_mask(keys, rank, world)
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), keys=keys[mine],

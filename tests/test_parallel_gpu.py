@@ -1,6 +1,8 @@
 """-m gpu: the device side of the multi-GPU reduce on one GPU.  Several integrators stand in
 for ranks; ks_export_tiles_device / ks_merge_tiles_device must agree bit-for-bit with the
 numpy restatement of the merge rule (tests/merge_ref.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -131,3 +133,43 @@ def test_one_merge_call_folds_duplicate_keys_in_order(color_mode):
     assert sorted(da) == sorted(db)
     for k in da:
         assert np.array_equal(da[k][:, :25], db[k][:, :25]), f"tile {k}"
+
+
+def _rccl_comm_world1():
+    """An ncclComm_t of one rank, created with the librccl that ks_reduce loads."""
+    import ctypes as C
+    lib = C.CDLL(os.environ.get("KS_RCCL_LIB", "librccl.so.1"))
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert lib.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert lib.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    return lib, comm
+
+
+def test_ks_reduce_c_abi_single_rank_and_repeatable():
+    """ks_reduce through the C ABI with a real RCCL communicator (world size 1 is all one GPU allows here):
+    nothing travels, the map is untouched, the call is repeatable; ks_reset_tiles empties a tile;
+    ks_tile_owner equals the Python protocol's owner function."""
+    from kimera_semantics_amd import parallel as PAR
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **dict(COMMON, method=1)))
+    sc = synth.make_scene("room")
+    f = synth.render_frame(sc, synth.single_pose(), 160, 120, seed=0)
+    h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    idx, t0, s0 = h.download()
+    lib, comm = _rccl_comm_world1()
+    for _ in range(2):
+        st = h.reduce(comm.value, 0, 1)
+        assert st["tiles_sent"] == 0 and st["tiles_received"] == 0 and st["tiles_local"] == len(h.tile_keys())
+    _, t1, s1 = h.download(idx)
+    assert t0.tobytes() == t1.tobytes() and s0.tobytes() == s1.tobytes()
+    keys = h.tile_keys()
+    for w in (2, 3, 8):
+        assert [B.lib().ks_tile_owner(int(k), w) for k in keys[:64]] == PAR.owner_of(keys[:64], w).tolist()
+    h.reset_tiles(np.arange(len(keys), dtype=np.uint32))
+    _, t2, s2 = h.download(idx)
+    assert not (t2["weight"] > 0).any() and (s2["label"] == 0).all()
+    lib.ncclCommDestroy(comm)
