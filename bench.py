@@ -277,6 +277,63 @@ def record(name, wl, m, K, counted, how, world=1):
     }
 
 
+def c5_record(B, torch, dist, dev, rank, world):
+    """BASELINE.json configs[4]: a batch of 8 overlapping 640x480 frames (arc poses looking at the same wall),
+    frame-sharded over the ranks, ONE reduce of the overlapping tiles to their owner ranks inside the timed
+    region; the owner-sharded result is compared with the same frames integrated sequentially on one GPU
+    (merging per-rank maps is not the same arithmetic as sequential integration: SURVEY.md §8e)."""
+    import numpy as np
+    from kimera_semantics_amd import parallel as PAR
+    from kimera_semantics_amd import synth
+    wl = WORKLOADS["C2"]
+    n_frames = 8 if 8 % world == 0 else world
+    scene = synth.make_scene("room")
+    frames = [synth.render_frame(scene, synth.arc_pose(k, n=n_frames), wl["w"], wl["h"], seed=100 + k) for k in range(n_frames)]
+    kw = dict(integ_cfg(wl), voxels_per_side=8)   # host block = device tile: ownership is per block
+    h = B.HipIntegrator(B.default_config(device_id=dev.index or 0, max_tiles=1 << 13, max_points=wl["w"] * wl["h"], **kw))
+    mine = list(range(rank, n_frames, world))
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    upd = sum(int(h.integrate(frames[k].T_G_C, frames[k].xyz, frames[k].rgba, frames[k].labels).n_voxel_updates) for k in mine)
+    h.synchronize()
+    rstats = PAR.reduce_maps(PAR.HipTileStore(h, dev))
+    h.synchronize()
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    # the same batch sequentially on this GPU (untimed), compared on the tiles this rank owns
+    seq = B.HipIntegrator(B.default_config(device_id=dev.index or 0, max_tiles=1 << 13, max_points=wl["w"] * wl["h"], **kw))
+    for f in frames:
+        seq.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    keys = h.tile_keys()
+    own = keys[PAR.owned_tile_mask(keys, rank, world)]
+    bias = 1 << 17
+    idx = np.stack([((own >> np.uint64(36)) & np.uint64(0x3ffff)).astype(np.int64) - bias,
+                    ((own >> np.uint64(18)) & np.uint64(0x3ffff)).astype(np.int64) - bias,
+                    (own & np.uint64(0x3ffff)).astype(np.int64) - bias], axis=1).astype(np.int32) if len(own) else np.zeros((0, 3), np.int32)
+    _, ht, hs = h.download(idx)
+    _, st, ss = seq.download(idx)
+    touched = st["weight"] > 0
+    agg = torch.tensor([float(touched.sum()), float(((hs["label"] == ss["label"]) & touched).sum()),
+                        float(np.abs(ht["distance"] - st["distance"])[touched].sum()), float(upd), dt,
+                        float(rstats["tiles_sent"]), float(rstats["bytes_sent"])], device=dev, dtype=torch.float64)
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    h.close()
+    seq.close()
+    a = agg.tolist()
+    dtm = float(tmax.item())
+    return {"config": "C5", "workload": f"{n_frames} arc-pose 640x480 frames looking at the same wall, frame-sharded x{world}, "
+                                        "one all-to-all tile reduce to hash-owners inside the timed region",
+            "frames": n_frames, "batch_ms": round(dtm * 1e3, 3), "frames_per_s": round(n_frames / dtm, 2),
+            "gpu_counted_value": round(a[3] / dtm / 1e6, 3), "unit": "Mvoxel-updates/s",
+            "reduce": {"tiles_sent": int(a[5]), "bytes_sent": int(a[6])},
+            "vs_sequential_1gpu": {"voxels_compared": int(a[0]), "label_agreement": round(a[1] / max(1.0, a[0]), 6),
+                                   "mean_abs_distance_diff": a[2] / max(1.0, a[0])}}
+
+
 def main():
     args = parse()
     import torch
@@ -328,6 +385,17 @@ def main():
         m["updates"], m["points"], m["rays"] = int(u[0].item()), int(u[1].item()), int(u[2].item())
         upd_oracle = int(u[3].item()) if upd_oracle is not None else None
 
+    c5 = None
+    if world > 1 or os.environ.get("KS_BENCH_C5") == "1":
+        try:
+            if world == 1 and not dist.is_initialized():   # single-GPU self-test of this code path
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29517")
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            c5 = c5_record(B, torch, dist, dev, rank, world)
+        except Exception as e:   # collective calls above are symmetric; a local failure must not take the line down
+            c5 = {"config": "C5", "error": f"{type(e).__name__}: {e}"}
+
     if rank == 0:
         dt = m["dt"]
         Kall = K * world
@@ -360,10 +428,12 @@ def main():
         }
         if m["reduce"] is not None:
             out["reduce"] = m["reduce"]
+        if c5 is not None:
+            out.setdefault("secondary", []).append(c5)
         if not args.no_cpu_baseline and world == 1 and upd_serial is not None:   # reported on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(args, wl, frames[W:], upd_serial)
         if world == 1 and not args.no_secondary:
-            sec = []
+            sec = out.get("secondary", [])
             for name, steps, warm, tiles, n_oracle in (("C3", 20, 3, 1 << 13, 20), ("C4-fast", 12, 2, 1 << 16, 1),
                                                        ("C4-merged", 12, 2, 1 << 16, 1)):
                 if name == "C3" and args.method == "merged":
@@ -390,7 +460,7 @@ def main():
                     sec.append({"config": name, "error": f"{type(e).__name__}: {e}"})
             out["secondary"] = sec
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.destroy_process_group()
 
 
