@@ -27,15 +27,15 @@ def main():
         hist[depth] = hist.get(depth, 0) + (t - last)
         last = t
         depth += dlt
-    march = sorted(int(r["Start_Timestamp"]) for r in tr if "k_march" in r["Kernel_Name"])
-    # bench.py --steps 20 --warmup 3: the first 23 marches are the pipelined, timed context (the
-    # later ones belong to the per-stage and isolated passes)
-    if len(march) >= 23:
-        per = (march[22] - march[5]) / 17 / 1e3
-        print(f"\n# frame period inside the timed region (k_march start to start, frames 5..22), with tracing on: {per:.1f} us")
-    if len(march) >= 23:
-        lo, hi = march[5], march[22]
-        depth, last, hist = 0, lo, {}
+    # frame markers: the first kernel of a frame (k_points_fast / k_points_merged).  bench.py --steps 20 --warmup 3
+    # --no-secondary: the first 23 frames are the pipelined, timed context (later ones belong to the per-stage pass)
+    first = sorted(int(r["Start_Timestamp"]) for r in tr if "k_points_" in r["Kernel_Name"])
+    hist = {}
+    if len(first) >= 23:
+        per = (first[22] - first[5]) / 17 / 1e3
+        print(f"\n# frame period inside the timed region (k_points start to start, frames 5..22), with tracing on: {per:.1f} us")
+        lo, hi = first[5], first[22]
+        depth, last = 0, lo
         for t, dlt in ev:
             if t > hi:
                 break
@@ -45,13 +45,11 @@ def main():
             depth += dlt
     ap = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 for r in tr if "k_apply<" in r["Kernel_Name"] and "k_apply_long" not in r["Kernel_Name"])
-    if len(ap) >= 56:
+    if len(ap) >= 23:
         timed = [d for _, d in ap[3:23]]
-        solo = [d for _, d in ap[-10:]]
-        print(f"# k_apply average duration: {sum(timed) / len(timed) / 1e3:.2f} us over the 20 timed (pipelined, overlapped) "
-              f"launches; {sum(solo) / len(solo) / 1e3:.2f} us over the last 10 launches of the isolated pass "
-              f"(bench.py's roofline.avg_launch_ms / roofline.isolated.avg_launch_ms of the same run are in the log line below)")
-    tot = sum(hist.values())
+        print(f"# k_apply average duration: {sum(timed) / len(timed) / 1e3:.2f} us over the 20 timed (pipelined, overlapped) launches "
+              f"(bench.py's roofline.k_apply.avg_launch_ms of the same run is in the log line below)")
+    tot = sum(hist.values()) or 1
     print("# kernels executing concurrently (share of the steady-state span): " +
           ", ".join(f"{k}: {100.0 * v / tot:.1f}%" for k, v in sorted(hist.items())))
     if len(sys.argv) > 3:
@@ -59,8 +57,9 @@ def main():
         for line in open(sys.argv[3]):
             if line.startswith("{"):
                 j = json.loads(line)
+                rf = j["roofline"]
                 print("# bench.py line of this traced run: value", j["value"], j["unit"], "ms_per_step", j["ms_per_step"],
-                      "roofline", json.dumps(j["roofline"]))
+                      "whole-frame frac", rf["frac"], "k_apply", json.dumps(rf["k_apply"]))
 
 
 if __name__ == "__main__":
