@@ -82,7 +82,10 @@ typedef struct ks_config {
   int32_t early_out_phase_growth;
   /* ---- device sizing ---- */
   int32_t device_id;                /* HIP device ordinal */
-  uint32_t max_tiles;               /* capacity of the 8^3-voxel tile pool (64 KiB each) */
+  uint32_t max_tiles;               /* INITIAL capacity of the 8^3-voxel tile pool (64 KiB each); the pool is doubled
+                                       between frames whenever more than half of it is in use (the reference
+                                       allocates blocks without a cap, semantic_integrator_base.cpp:205-254).
+                                       KS_ERR_POOL_FULL remains for a single frame that needs more than the free half. */
   uint32_t max_points;              /* largest cloud per call (buffers grow on demand if exceeded) */
   /* 0 (default): an integrate call returns with its frame fully enqueued and its own statistics.
    * 1 .. 4: frame pipelining for streams of frames (bag replay); the value is how many calls the second

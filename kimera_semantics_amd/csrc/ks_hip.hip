@@ -859,6 +859,59 @@ int tail_join(ks_ctx* c) {
   return c->tail_rc;
 }
 
+// The reference allocates blocks on demand without a cap [K:src/semantic_integrator_base.cpp:205-254]; the tile
+// pool here is one allocation.  When more than half of it is in use it is doubled between frames (new
+// allocation, device-to-device copy of the tiles in use, table rebuilt with the same slot numbers), so a map
+// only stops growing when HBM is exhausted.  ks_config.max_tiles is the INITIAL capacity.
+int grow_pool(ks_ctx* c) {
+  int rc;
+  if ((rc = quiesce(c))) return rc;
+  const size_t old_max = c->cfg.max_tiles;
+  const size_t new_max = std::min<size_t>(old_max * 2, (1u << 23) - 1);
+  if (new_max <= old_max) return KS_OK;
+  const uint32_t nt = c->tiles_initialised;
+  uint4* vox = nullptr;
+  uint8_t *upd = nullptr, *dirty = nullptr;
+  uint64_t* skeys = nullptr;
+  TileEntry* ent = nullptr;
+  uint32_t cap = 1024;
+  while (cap < 2u * new_max) cap <<= 1;
+  if (hipMalloc((void**)&vox, new_max * kTileVoxels * 8 * sizeof(uint4)) != hipSuccess) {
+    (void)hipGetLastError();
+    return KS_OK;  // no memory for a bigger pool: carry on with the current one (exhaustion is reported when it happens)
+  }
+  HIPCHK(c, hipMalloc((void**)&upd, new_max));
+  HIPCHK(c, hipMalloc((void**)&dirty, new_max));
+  HIPCHK(c, hipMalloc((void**)&skeys, new_max * sizeof(uint64_t)));
+  HIPCHK(c, hipMalloc((void**)&ent, (size_t)cap * sizeof(TileEntry)));
+  HIPCHK(c, hipMemset(upd, 0, new_max));
+  HIPCHK(c, hipMemset(dirty, 0, new_max));
+  HIPCHK(c, hipMemset(ent, 0xff, (size_t)cap * sizeof(TileEntry)));
+  if (nt) {
+    HIPCHK(c, hipMemcpy(vox, c->pool.vox, (size_t)nt * kTileVoxels * 8 * sizeof(uint4), hipMemcpyDeviceToDevice));
+    HIPCHK(c, hipMemcpy(upd, c->pool.updated, nt, hipMemcpyDeviceToDevice));
+    HIPCHK(c, hipMemcpy(dirty, c->pool.dirty, nt, hipMemcpyDeviceToDevice));
+    HIPCHK(c, hipMemcpy(skeys, c->table.slot_keys, (size_t)nt * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+  }
+  (void)hipFree(c->pool.vox);
+  (void)hipFree(c->pool.updated);
+  (void)hipFree(c->pool.dirty);
+  (void)hipFree(c->table.slot_keys);
+  (void)hipFree(c->table.ent);
+  c->pool.vox = vox;
+  c->pool.updated = upd;
+  c->pool.dirty = dirty;
+  c->table.slot_keys = skeys;
+  c->table.ent = ent;
+  c->table.mask = cap - 1;
+  c->table.max_tiles = (uint32_t)new_max;
+  c->cfg.max_tiles = (uint32_t)new_max;
+  if (nt) hipLaunchKernelGGL(k_rehash_tiles, dim3((nt + 255) / 256), dim3(256), 0, c->stream, c->table, (const uint64_t*)skeys, nt);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  ++c->buffers_epoch;  // captured graphs hold the old table / pool
+  return KS_OK;
+}
+
 int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, const uint8_t* d_rgba, const uint8_t* d_labels,
                           size_t n, int freespace, ks_frame_stats* stats) {
   if (c->fatal) {
@@ -893,6 +946,7 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
     deliver_stats(c, stats);
     return KS_OK;
   }
+  if ((size_t)c->tiles_initialised * 2 > (size_t)c->cfg.max_tiles && (rc = grow_pool(c))) return rc;
   if (n > c->cap_points) {  // growing frees buffers a pending tail still needs
     if ((rc = quiesce(c))) return rc;
     if ((rc = ensure_points(c, n))) return rc;

@@ -36,6 +36,22 @@ __global__ void __launch_bounds__(512) k_reset_tiles(Pool P, const uint32_t* __r
   }
 }
 
+// pool growth: the tile table is rebuilt at twice the capacity; slot numbers are kept
+__global__ void __launch_bounds__(256) k_rehash_tiles(TileTable T, const uint64_t* __restrict__ slot_keys, uint32_t n) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n) return;
+  const uint64_t key = slot_keys[slot];
+  uint32_t h = mix64(key) & T.mask;
+  for (uint32_t probes = 0; probes <= T.mask; ++probes) {
+    const uint64_t old = atomicCAS((unsigned long long*)&T.ent[h].key, (unsigned long long)kEmpty64, (unsigned long long)key);
+    if (old == kEmpty64) {
+      T.ent[h].val = slot;
+      return;
+    }
+    h = (h + 1) & T.mask;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_insert_tiles(TileTable T, Counters* C, const uint64_t* __restrict__ keys, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) tile_insert(T, C, keys[i]);

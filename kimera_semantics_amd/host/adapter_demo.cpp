@@ -10,6 +10,7 @@
 // out.bin: u32 n_blocks, u32 vps, then per block { i32 idx[3]; tsdf vps^3*12 B; semantic vps^3*92 B }
 #include <algorithm>
 #include <chrono>
+#include <voxblox/utils/timing.h>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -135,5 +136,7 @@ int main(int argc, char** argv) {
   }
   std::fclose(out);
   std::printf("adapter_demo: %u frames, %u blocks (%zu flagged updated)\n", n_frames, nb, updated);
+  // what SemanticTsdfServer prints when verbose (voxblox::timing::Timing::Print): the integrator's scopes
+  std::printf("timing:\n%s", vxb::timing::Timing::Print().c_str());
   return updated == nb ? 0 : 6;
 }

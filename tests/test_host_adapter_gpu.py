@@ -57,6 +57,11 @@ def test_adapter_matches_oracle(tmp_path, method, color_mode):
     _write_in(fin, frames)
     res = subprocess.run([DEMO, method, csv, fin, fout, str(color_mode), str(NO_EARLY_OUT)], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
+    # the voxblox::timing scopes of the CPU integrators are recorded under the same names
+    # (semantic_tsdf_integrator_fast.cpp:160,195; semantic_tsdf_integrator_merged.cpp:90-91,106,193)
+    want = ("integrate/fast",) if method.startswith("fast") else ("semantic_tsdf/integrate", "integrate/semantic_merged")
+    for name in want + ("inserting_missed_blocks",):
+        assert name in res.stdout, res.stdout
     idx, t, s = _read_out(fout)
     is_merged = method.startswith("merged")
     o = O.Oracle(O.default_config(**dict(COMMON, method=1 if is_merged else 0, color_mode=color_mode,

@@ -685,3 +685,20 @@ def test_clear_then_integrate_equals_fresh_context():
         sb = b.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
         assert (sa.n_valid_points, sa.n_rays_cast, sa.n_voxel_updates) == (sb.n_valid_points, sb.n_rays_cast, sb.n_voxel_updates)
     compare_maps(b, a, exact=True)
+
+
+def test_tile_pool_grows_between_frames():
+    """ks_config.max_tiles is only the initial capacity: the pool doubles between frames when more than
+    half of it is in use (the reference allocates blocks on demand without a cap).  The map stays bit-exact
+    across the re-allocation, in the pipelined mode too."""
+    kw = dict(COMMON, method=0, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    o = O.Oracle(O.default_config(**kw))
+    h = B.HipIntegrator(B.default_config(max_tiles=1024, max_points=1 << 14, pipeline_frames=2, **kw))
+    sc = synth.make_scene("room")
+    for k in range(24):
+        f = synth.render_frame(sc, synth.trajectory_pose(8 * k), 128, 96, seed=500 + k)
+        o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    h.flush()
+    assert len(h.tile_keys()) > 1024, len(h.tile_keys())
+    compare_maps(o, h, exact=True)
