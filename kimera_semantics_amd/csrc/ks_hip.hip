@@ -946,7 +946,13 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
     deliver_stats(c, stats);
     return KS_OK;
   }
-  if ((size_t)c->tiles_initialised * 2 > (size_t)c->cfg.max_tiles && (rc = grow_pool(c))) return rc;
+  {
+    // freshest tile count the host has seen (snapshots of frames whose tail is still to come included)
+    uint32_t known = c->tiles_initialised;
+    for (const FrameSlot& S2 : c->slot)
+      if (S2.h_snap) known = std::max(known, S2.h_snap->n_tiles);
+    if ((size_t)known * 2 > (size_t)c->cfg.max_tiles && (rc = grow_pool(c))) return rc;
+  }
   if (n > c->cap_points) {  // growing frees buffers a pending tail still needs
     if ((rc = quiesce(c))) return rc;
     if ((rc = ensure_points(c, n))) return rc;

@@ -693,12 +693,12 @@ def test_tile_pool_grows_between_frames():
     across the re-allocation, in the pipelined mode too."""
     kw = dict(COMMON, method=0, max_consecutive_ray_collisions=NO_EARLY_OUT)
     o = O.Oracle(O.default_config(**kw))
-    h = B.HipIntegrator(B.default_config(max_tiles=1024, max_points=1 << 14, pipeline_frames=2, **kw))
+    h = B.HipIntegrator(B.default_config(max_tiles=2048, max_points=1 << 14, pipeline_frames=2, **kw))
     sc = synth.make_scene("room")
-    for k in range(24):
+    for k in range(40):
         f = synth.render_frame(sc, synth.trajectory_pose(8 * k), 128, 96, seed=500 + k)
         o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
         h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
     h.flush()
-    assert len(h.tile_keys()) > 1024, len(h.tile_keys())
+    assert len(h.tile_keys()) > 2048, len(h.tile_keys())
     compare_maps(o, h, exact=True)
