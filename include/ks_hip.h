@@ -193,6 +193,17 @@ int ks_download_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, void* tsdf
  * (semantic_integrator_base.cpp:92-96, filled e.g. by TsdfServer::loadMap) — reaches the GPU.
  * Block indices must be distinct.  Errors: KS_ERR_POOL_FULL, KS_ERR_INDEX_RANGE. */
 int ks_upload_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, const void* tsdf_in, const void* sem_in);
+/* Voxel-level sync for the strict drop-in mode (host Layers current after every integratePointCloud, the
+ * contract behind Block::updated(), semantic_integrator_base.cpp:248): only the voxels the integrator has
+ * written since the previous call travel, as KS_VOXEL_RECORD_BYTES-byte records
+ *   { int32 block_x, block_y, block_z; uint32 linear_index (x + vps*(y + vps*z)); TsdfVoxel 12 B; SemanticVoxel 92 B }
+ * with the voxels of one 8^3 device tile contiguous (consecutive records mostly share their block).
+ * ks_count_updated_voxels sizes the buffer; ks_download_updated_voxels fills it (a page-locked buffer from
+ * ks_host_alloc makes the copy run at link rate) and clears the marks.  Voxels changed through
+ * ks_upload_blocks / ks_merge_tiles_device are NOT reported (use ks_download_blocks for those). */
+#define KS_VOXEL_RECORD_BYTES 120
+int ks_count_updated_voxels(ks_ctx* ctx, size_t* n);
+int ks_download_updated_voxels(ks_ctx* ctx, void* out, size_t cap_records, size_t* n);
 /* Page-locked host memory for the buffers handed to ks_download_blocks / ks_upload_blocks /
  * ks_integrate_points (transfers from pageable memory go through a staging copy and run at a
  * fraction of the link rate).  ks_host_alloc returns NULL on failure. */

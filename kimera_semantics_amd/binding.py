@@ -31,7 +31,7 @@ SEM_DTYPE = np.dtype([("label", "u1"), ("pad", "u1", (3,)), ("priors", "<f4", (N
 ABI_SYMBOLS = [
     "ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_set_color_to_label",
     "ks_integrate_points", "ks_integrate_points_device", "ks_integrate_depth", "ks_integrate_depth_device", "ks_num_blocks", "ks_get_block_indices",
-    "ks_get_updated_block_indices", "ks_download_blocks", "ks_upload_blocks", "ks_host_alloc", "ks_host_free", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear", "ks_reset_tiles", "ks_tile_owner", "ks_reduce",
+    "ks_get_updated_block_indices", "ks_count_updated_voxels", "ks_download_updated_voxels", "ks_download_blocks", "ks_upload_blocks", "ks_host_alloc", "ks_host_free", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear", "ks_reset_tiles", "ks_tile_owner", "ks_reduce",
     "ks_debug_radix_sort", "ks_synchronize", "ks_flush", "ks_stream",
     "ks_profile_enable", "ks_profile_get",
 ]
@@ -114,6 +114,8 @@ def lib():
         L.ks_get_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.ks_get_updated_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
         L.ks_download_blocks.argtypes = [vp, vp, C.c_size_t, vp, vp]
+        L.ks_count_updated_voxels.argtypes = [vp, C.POINTER(C.c_size_t)]
+        L.ks_download_updated_voxels.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.ks_upload_blocks.argtypes = [vp, vp, C.c_size_t, vp, vp]
         L.ks_host_alloc.argtypes = [C.c_size_t]
         L.ks_host_alloc.restype = C.c_void_p
@@ -301,6 +303,19 @@ class HipIntegrator:
     def merge_tiles(self, keys: np.ndarray, d_payload: int):
         k = np.ascontiguousarray(keys, dtype=np.uint64)
         self._chk(lib().ks_merge_tiles_device(self._h, _ptr(k), len(k), d_payload or None))
+
+    def download_updated_voxels(self):
+        """Voxels written since the previous call: structured array (block [3] i32, linear u32, tsdf, sem)."""
+        n = C.c_size_t()
+        self._chk(lib().ks_count_updated_voxels(self._h, C.byref(n)))
+        dt = np.dtype([("block", "<i4", (3,)), ("linear", "<u4"), ("tsdf", TSDF_DTYPE), ("sem", SEM_DTYPE)])
+        assert dt.itemsize == 120
+        out = np.zeros(n.value, dtype=dt)
+        if n.value:
+            m = C.c_size_t()
+            self._chk(lib().ks_download_updated_voxels(self._h, _ptr(out), n.value, C.byref(m)))
+            assert m.value == n.value
+        return out
 
     def clear(self):
         self._chk(lib().ks_clear(self._h))

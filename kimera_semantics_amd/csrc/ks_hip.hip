@@ -205,6 +205,8 @@ struct ks_ctx {
   int32_t* d_block_idx = nullptr;
   size_t cap_block_idx = 0;
   uint8_t *d_tsdf_out = nullptr, *d_sem_out = nullptr;
+  uint8_t* d_vox_out = nullptr;     // staging of ks_download_updated_voxels
+  size_t cap_vox_out = 0;
   size_t cap_out_blocks = 0;
 
   uint32_t* d_depth_blocks = nullptr;
@@ -747,8 +749,11 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     // k_apply on the tail stream, k_apply_long on its own stream (disjoint voxels)
     hipLaunchKernelGGL(k_find_long, dim3(ab), dim3(256), 0, st, F.seq_bits, n_pairs, (const uint64_t*)sp, c->d_long_list,
                        S.d_counters);
-    HIPCHK(c, hipEventRecord(S.fork, st));
-    HIPCHK(c, hipStreamWaitEvent(c->stream_long, S.fork, 0));
+    hipStream_t sl = c->stream_long ? c->stream_long : st;
+    if (sl != st) {
+      HIPCHK(c, hipEventRecord(S.fork, st));
+      HIPCHK(c, hipStreamWaitEvent(sl, S.fork, 0));
+    }
 #define KS_LAUNCH_APPLY_M(MODE, MERGED)                                                                              \
   if (time_apply)                                                                                                    \
     hipExtLaunchKernelGGL((k_apply<MODE, MERGED>), dim3(ab), dim3(256), 0, st, c->pset[set].k0, c->pset[set].k1, 0,   \
@@ -764,7 +769,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     KS_LAUNCH_APPLY_M(MODE, false);                                                                                  \
   }                                                                                                                  \
   stage_mark(c, set, 9);                                                                                             \
-  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(128), 0, c->stream_long, F, n_pairs, sp, S.d_rays, S.d_deltas, \
+  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(128), 0, sl, F, n_pairs, sp, S.d_rays, S.d_deltas,             \
                      c->table, c->pool, c->d_label_lut, c->d_long_list, S.d_counters)
     switch (c->cfg.color_mode) {
       case KS_COLOR_MODE_COLOR: KS_LAUNCH_APPLY(KS_COLOR_MODE_COLOR); break;
@@ -773,8 +778,10 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     }
 #undef KS_LAUNCH_APPLY
 #undef KS_LAUNCH_APPLY_M
-    HIPCHK(c, hipEventRecord(S.join, c->stream_long));
-    HIPCHK(c, hipStreamWaitEvent(st, S.join, 0));
+    if (sl != st) {
+      HIPCHK(c, hipEventRecord(S.join, sl));
+      HIPCHK(c, hipStreamWaitEvent(st, S.join, 0));
+    }
   } else {
     stage_mark(c, set, 7);
     stage_mark(c, set, 8);
@@ -1153,7 +1160,11 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   } while (0)
   CRCHK(hipSetDevice(cfg->device_id));
   CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
+  {
+    const char* nl = getenv("KS_NO_LONG_STREAM");   // diagnostics: long runs on the tail stream, after k_apply
+    if (nl && nl[0] == '1') c->stream_long = nullptr;
+    else CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
+  }
   if (cfg->pipeline_frames) {
     c->n_march = kMarchStreams;
     for (int i = 0; i < c->n_march; ++i) CRCHK(hipStreamCreateWithFlags(&c->stream_march_[i], hipStreamNonBlocking));
@@ -1249,7 +1260,7 @@ void ks_destroy(ks_ctx* c) {
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_pairs2, c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
-                  c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};
+                  c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& S : c->slot)
@@ -1520,6 +1531,55 @@ int ks_upload_blocks(ks_ctx* c, const int32_t* idx, size_t n, const void* tsdf_i
   }
   HIPCHK(c, hipGetLastError());
   return KS_OK;
+}
+
+// ---- voxel-level host sync -------------------------------------------------------------------------------
+static int updated_voxels_impl(ks_ctx* c, void* out, size_t cap, size_t* n, bool count_only) {
+  if (!c || !n) return KS_ERR_INVALID_ARG;
+  *n = 0;
+  if (int rc = quiesce(c)) return rc;
+  const uint32_t nt = c->tiles_initialised;
+  if (nt == 0) return KS_OK;
+  int rc;
+  if ((rc = ensure_exchange(c, (size_t)nt + 8))) return rc;
+  uint32_t* d_cnt = c->d_xchg_u32;          // [0] listed tiles, [1] dirty voxels
+  uint32_t* d_list = c->d_xchg_u32 + 8;
+  hipStream_t st = c->stream;
+  HIPCHK(c, hipMemsetAsync(d_cnt, 0, 8 * sizeof(uint32_t), st));
+  hipLaunchKernelGGL(k_list_updated_tiles, dim3((nt + 255) / 256), dim3(256), 0, st, c->pool, nt, d_list, d_cnt);
+  uint32_t h_cnt[2] = {0, 0};
+  HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  const uint32_t n_list = h_cnt[0];
+  if (n_list == 0) return KS_OK;
+  hipLaunchKernelGGL(k_export_dirty, dim3(n_list), dim3(512), 0, st, c->table, c->pool, (const uint32_t*)d_list,
+                     (const uint32_t*)c->d_label_lut, c->vps_shift, 1, d_cnt, (uint8_t*)nullptr);
+  HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  *n = h_cnt[1];
+  if (count_only || h_cnt[1] == 0) return KS_OK;
+  if ((size_t)h_cnt[1] > cap) {
+    c->err = "ks_download_updated_voxels: output buffer too small (call ks_count_updated_voxels first)";
+    return KS_ERR_INVALID_ARG;
+  }
+  const size_t bytes = (size_t)h_cnt[1] * kVoxRecBytes;
+  if (bytes > c->cap_vox_out) {
+    if ((rc = dev_alloc(c, &c->d_vox_out, bytes + bytes / 4))) return rc;
+    c->cap_vox_out = bytes + bytes / 4;
+  }
+  HIPCHK(c, hipMemsetAsync(d_cnt + 1, 0, sizeof(uint32_t), st));
+  hipLaunchKernelGGL(k_export_dirty, dim3(n_list), dim3(512), 0, st, c->table, c->pool, (const uint32_t*)d_list,
+                     (const uint32_t*)c->d_label_lut, c->vps_shift, 0, d_cnt, c->d_vox_out);
+  HIPCHK(c, hipMemcpyAsync(out, c->d_vox_out, bytes, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  HIPCHK(c, hipGetLastError());
+  return KS_OK;
+}
+
+int ks_count_updated_voxels(ks_ctx* c, size_t* n) { return updated_voxels_impl(c, nullptr, 0, n, true); }
+int ks_download_updated_voxels(ks_ctx* c, void* out, size_t cap, size_t* n) {
+  if (!out && cap) return KS_ERR_INVALID_ARG;
+  return updated_voxels_impl(c, out, cap, n, false);
 }
 
 void* ks_host_alloc(size_t bytes) {

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
     uint4 outv = make_uint4(0u, 0u, 0u, 0u);
     if (sub == 0u) outv = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, bi);
     else if (sub < 6u) outv = make_uint4(__float_as_uint(p0), __float_as_uint(p1), __float_as_uint(p2), __float_as_uint(p3));
-    else if (sub == 6u) outv = make_uint4(__float_as_uint(p0), 0u, 0u, 0u);
+    else if (sub == 6u) outv = make_uint4(__float_as_uint(p0), 1u, 0u, 0u);  // dword 25 = 1: updated since the last voxel-level host sync
     const bool wr = active && sub < 7u;
     rec[wr ? sub : 7u] = wr ? outv : make_uint4(0u, 0u, 0u, 0u);
   }
@@ -471,7 +471,10 @@ __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long
     if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = label_lut[best];
     else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY)
       color = rainbow_color_map((double)(float)exp((double)m));
-    if (lane == 0) *(uint4*)rec = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, best);
+    if (lane == 0) {
+      *(uint4*)rec = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, best);
+      rec[25] = 1u;  // updated since the last voxel-level host sync
+    }
     __syncthreads();  // LDS free for the next run
   }
 }

@@ -308,6 +308,52 @@ __global__ void __launch_bounds__(256) k_download(TileTable T, Pool P, const int
 }
 
 
+// Voxel-level host sync (strict drop-in: the host Layers are brought up to date after every frame).  Only the
+// voxels the update kernels wrote since the last sync travel: record dword 25 is their dirty mark.
+//   k_list_updated_tiles : slots of tiles flagged `updated` -> compact list
+//   k_export_dirty       : one workgroup per listed tile, one lane per voxel; dirty voxels are packed as 120-byte
+//                          host records {int32 block x, y, z; uint32 linear index in the block; TsdfVoxel 12 B;
+//                          SemanticVoxel 92 B}, a tile's voxels contiguous; count_only: just the total.
+__global__ void __launch_bounds__(256) k_list_updated_tiles(Pool P, uint32_t n_tiles, uint32_t* __restrict__ list,
+                                                            uint32_t* __restrict__ counters) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = s < n_tiles && P.updated[s] != 0;
+  const uint32_t pos = block_append(on, &counters[0]);
+  if (on) list[pos] = s;
+}
+constexpr uint32_t kVoxRecBytes = 120;
+__global__ void __launch_bounds__(512) k_export_dirty(TileTable T, Pool P, const uint32_t* __restrict__ list,
+                                                      const uint32_t* __restrict__ label_lut, int vps_shift, int count_only,
+                                                      uint32_t* __restrict__ counters, uint8_t* __restrict__ out) {
+  const uint32_t slot = list[blockIdx.x];
+  const uint32_t local = threadIdx.x;
+  uint32_t* rec = (uint32_t*)(P.vox + ((size_t)slot * kTileVoxels + local) * 8);
+  const bool dirty = rec[25] != 0u;
+  const uint32_t pos = block_append(dirty, &counters[1]);
+  if (count_only) return;
+  if (threadIdx.x == 0) P.updated[slot] = 0;
+  if (!dirty) return;
+  rec[25] = 0u;
+  int tx, ty, tz;
+  unpack_tile(T.slot_keys[slot], tx, ty, tz);
+  const int vps = 8 << vps_shift;
+  const int vx = tx * 8 + (int)(local & 7u), vy = ty * 8 + (int)((local >> 3) & 7u), vz = tz * 8 + (int)(local >> 6);
+  uint32_t* o = (uint32_t*)(out + (size_t)pos * kVoxRecBytes);
+  o[0] = (uint32_t)(vx >> (3 + vps_shift));
+  o[1] = (uint32_t)(vy >> (3 + vps_shift));
+  o[2] = (uint32_t)(vz >> (3 + vps_shift));
+  o[3] = (uint32_t)((vx & (vps - 1)) + vps * ((vy & (vps - 1)) + vps * (vz & (vps - 1))));
+  const uint32_t label = rec[3];
+  const bool touched = label != 255u;
+  o[4] = rec[0];
+  o[5] = rec[1];
+  o[6] = rec[2];
+  o[7] = touched ? label : 0u;
+#pragma unroll
+  for (int k = 0; k < kNumLabels; ++k) o[8 + k] = rec[4 + k];
+  o[29] = touched ? label_lut[label] : (127u | (127u << 8) | (127u << 16) | (255u << 24));
+}
+
 // Host-layout import (the inverse of k_download): one lane per voxel of a host block.  A voxel
 // that still looks default-constructed on the semantic side (label 0, Gray, initial priors:
 // [K:include/kimera_semantics/semantic_voxel.h:14-27]) keeps the "never updated" marker.

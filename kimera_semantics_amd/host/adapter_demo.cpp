@@ -12,6 +12,7 @@
 #include <chrono>
 #include <voxblox/utils/timing.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -75,6 +76,7 @@ int main(int argc, char** argv) {
     integrator->integratePointCloud(vxb::Transformation(T[0], T[1], T[2], T[3], vxb::Point(T[4], T[5], T[6])), pts, cols, false);
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     integrate_ms += ms;
+    if (std::getenv("KS_DEMO_TRACE")) std::fprintf(stderr, "frame %u done (%.3f ms, %zu blocks)\n", f, ms, tsdf_layer.getNumberOfAllocatedBlocks());
     if (3 * f >= 2 * n_frames) {  // steady state: the last third (staging buffers and most blocks exist)
       tail_ms += ms;
       ++tail_frames;

@@ -1,6 +1,7 @@
 #include "hip_semantic_tsdf_integrator.h"
 
 #include <cstddef>
+#include <cstdint>
 #include <cstring>
 
 #include <voxblox/utils/timing.h>
@@ -179,6 +180,60 @@ constexpr bool kSemLayoutMatches = sizeof(SemanticVoxel) == 92 && offsetof(Seman
 }  // namespace
 
 void HipSemanticTsdfIntegrator::syncLayers() {
+  if (!options_.voxel_sync) {
+    syncLayersByBlock();
+    return;
+  }
+  // Only the voxels the integrator wrote since the last sync travel (a frame touches ~1.7e5 voxels of ~150
+  // blocks: 20 MB instead of 60-85 MB of whole blocks); a tile's voxels are contiguous in the buffer, so the
+  // block lookup happens once per tile, not once per voxel.
+  size_t n = 0;
+  check(ks_count_updated_voxels(ctx_, &n), "ks_count_updated_voxels");
+  if (n == 0) return;
+  const uint8_t* buf = vox_buf_.reserve(n * KS_VOXEL_RECORD_BYTES);
+  check(ks_download_updated_voxels(ctx_, vox_buf_.p, n, &n), "ks_download_updated_voxels");
+  int32_t last[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+  vxb::Block<vxb::TsdfVoxel>::Ptr tb;
+  vxb::Block<SemanticVoxel>::Ptr sb;
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t* r = buf + i * KS_VOXEL_RECORD_BYTES;
+    int32_t h[4];
+    std::memcpy(h, r, 16);
+    if (h[0] != last[0] || h[1] != last[1] || h[2] != last[2]) {
+      const vxb::BlockIndex idx(h[0], h[1], h[2]);
+      tb = layer_->allocateBlockPtrByIndex(idx);
+      sb = semantic_layer_ptr_->allocateBlockPtrByIndex(idx);
+      tb->updated() = true;
+      sb->updated() = true;
+      last[0] = h[0]; last[1] = h[1]; last[2] = h[2];
+    }
+    const size_t lin = static_cast<uint32_t>(h[3]);
+    const uint8_t* t = r + 16;
+    const uint8_t* sv_in = r + 28;
+    vxb::TsdfVoxel& v = tb->getVoxelByLinearIndex(lin);
+    if (kTsdfLayoutMatches) {
+      std::memcpy(static_cast<void*>(&v), t, 12);
+    } else {
+      std::memcpy(&v.distance, t, 4);
+      std::memcpy(&v.weight, t + 4, 4);
+      v.color = vxb::Color(t[8], t[9], t[10], t[11]);
+    }
+    SemanticVoxel& sv = sb->getVoxelByLinearIndex(lin);
+    if (kSemLayoutMatches) {
+      std::memcpy(static_cast<void*>(&sv), sv_in, 92);
+    } else {
+      sv.semantic_label = sv_in[0];
+      for (size_t l = 0; l < kTotalNumberOfLabels; ++l) {
+        float p;
+        std::memcpy(&p, sv_in + 4 + 4 * l, 4);
+        sv.semantic_priors[l] = p;
+      }
+      sv.color = HashableColor(sv_in[88], sv_in[89], sv_in[90], sv_in[91]);
+    }
+  }
+}
+
+void HipSemanticTsdfIntegrator::syncLayersByBlock() {
   size_t n = 0;
   check(ks_get_updated_block_indices(ctx_, nullptr, 0, &n, 0), "ks_get_updated_block_indices");
   if (n == 0) return;

@@ -38,6 +38,9 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
     /// Only takes effect with kOnDemand (kEveryFrame reads the map back after every frame, which
     /// completes the frame first).
     bool pipeline_frames = false;
+    /// syncLayers() moves only the VOXELS written since the previous sync (ks_download_updated_voxels: 120-byte
+    /// records scattered into the host blocks) instead of whole updated blocks (ks_download_blocks).
+    bool voxel_sync = true;
   };
 
   HipSemanticTsdfIntegrator(Method method, const Config& config, const SemanticConfig& semantic_config,
@@ -60,6 +63,7 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
   /// Copies every block touched since the last call into the host Layers (allocating blocks
   /// as needed) and sets Block::updated(), as semantic_integrator_base.cpp:248 does.
   void syncLayers();
+  void syncLayersByBlock();  ///< the whole-block variant (DeviceOptions::voxel_sync = false)
   /// Host layers -> GPU map (every allocated block).  Called by the constructor when the layers it
   /// is handed are not empty (a map loaded with TsdfServer::loadMap), so the integrator continues
   /// from the map the host holds exactly like the CPU integrators do.
@@ -83,7 +87,7 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
     ~Staging();
   };
   std::vector<int32_t> idx_buf_;
-  Staging tsdf_buf_, sem_buf_;
+  Staging tsdf_buf_, sem_buf_, vox_buf_;
 };
 
 /// Same shape as kimera::SemanticTsdfIntegratorFactory

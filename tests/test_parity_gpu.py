@@ -702,3 +702,39 @@ def test_tile_pool_grows_between_frames():
     h.flush()
     assert len(h.tile_keys()) > 2048, len(h.tile_keys())
     compare_maps(o, h, exact=True)
+
+
+@pytest.mark.parametrize("method,vps", [(0, 16), (1, 32), (0, 8)])
+def test_voxel_level_sync_rebuilds_the_map(method, vps):
+    """ks_download_updated_voxels (the strict drop-in's per-frame sync): replaying its records frame after frame
+    into an empty host map gives exactly the map ks_download_blocks reports, and a second call returns nothing."""
+    kw = dict(COMMON, method=method, voxels_per_side=vps, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **kw))
+    sc = synth.make_scene("room")
+    nv = vps ** 3
+    host = {}
+    total = 0
+    for k in range(3):
+        f = synth.render_frame(sc, synth.trajectory_pose(4 * k), 128, 96, seed=70 + k)
+        st = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        rec = h.download_updated_voxels()
+        assert 0 < len(rec) <= st.n_voxel_updates
+        total += len(rec)
+        for r in rec:
+            key = tuple(int(x) for x in r["block"])
+            if key not in host:
+                t = np.zeros(nv, dtype=B.TSDF_DTYPE)
+                s = np.zeros(nv, dtype=B.SEM_DTYPE)
+                s["priors"] = np.float32(-0.60205999132)
+                s["color"] = (127, 127, 127, 255)
+                host[key] = (t, s)
+            host[key][0][r["linear"]] = r["tsdf"]
+            host[key][1][r["linear"]] = r["sem"]
+        assert len(h.download_updated_voxels()) == 0
+    idx, t, s = h.download()
+    assert {tuple(x) for x in idx.tolist()} >= set(host)
+    for b, key in enumerate(tuple(x) for x in idx.tolist()):
+        if key in host:
+            assert host[key][0].tobytes() == t[b].tobytes() and host[key][1].tobytes() == s[b].tobytes(), key
+        else:  # a block whose tiles were allocated but never updated
+            assert not (t[b]["weight"] > 0).any()

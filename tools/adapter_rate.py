@@ -30,4 +30,4 @@ with open(fin, "wb") as fh:
 for method in ("fast", "merged"):
     for pipe in ("0", "1"):
         res = subprocess.run([DEMO, method, csv, fin, fout, "1", "2", "-1", pipe], capture_output=True, text=True)
-        print(method, "pipeline" if pipe == "1" else "strict  ", "|", " | ".join(l for l in res.stdout.splitlines()), res.stderr[-200:])
+        print(method, "pipeline" if pipe == "1" else "strict  ", "|", " | ".join(l for l in res.stdout.splitlines()), res.stderr[-600:])
