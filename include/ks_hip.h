@@ -202,8 +202,16 @@ int ks_upload_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, const void* 
  * ks_host_alloc makes the copy run at link rate) and clears the marks.  Voxels changed through
  * ks_upload_blocks / ks_merge_tiles_device are NOT reported (use ks_download_blocks for those). */
 #define KS_VOXEL_RECORD_BYTES 120
-int ks_count_updated_voxels(ks_ctx* ctx, size_t* n);
-int ks_download_updated_voxels(ks_ctx* ctx, void* out, size_t cap_records, size_t* n);
+/* The records of one device tile form a run that lies inside ONE host block: with the run list the host
+ * finds its blocks without reading the records (runs may be NULL). */
+typedef struct ks_voxel_run {
+  int32_t block[3];
+  uint32_t first; /* index of the run's first record */
+  uint32_t count;
+} ks_voxel_run;
+int ks_count_updated_voxels(ks_ctx* ctx, size_t* n_records, size_t* n_runs /* may be NULL */);
+int ks_download_updated_voxels(ks_ctx* ctx, void* out, size_t cap_records, size_t* n_records, ks_voxel_run* runs,
+                               size_t cap_runs, size_t* n_runs);
 /* Page-locked host memory for the buffers handed to ks_download_blocks / ks_upload_blocks /
  * ks_integrate_points (transfers from pageable memory go through a staging copy and run at a
  * fraction of the link rate).  ks_host_alloc returns NULL on failure. */

@@ -114,8 +114,8 @@ def lib():
         L.ks_get_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.ks_get_updated_block_indices.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), C.c_int]
         L.ks_download_blocks.argtypes = [vp, vp, C.c_size_t, vp, vp]
-        L.ks_count_updated_voxels.argtypes = [vp, C.POINTER(C.c_size_t)]
-        L.ks_download_updated_voxels.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.ks_count_updated_voxels.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.ks_download_updated_voxels.argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t), vp, C.c_size_t, C.POINTER(C.c_size_t)]
         L.ks_upload_blocks.argtypes = [vp, vp, C.c_size_t, vp, vp]
         L.ks_host_alloc.argtypes = [C.c_size_t]
         L.ks_host_alloc.restype = C.c_void_p
@@ -306,15 +306,22 @@ class HipIntegrator:
 
     def download_updated_voxels(self):
         """Voxels written since the previous call: structured array (block [3] i32, linear u32, tsdf, sem)."""
-        n = C.c_size_t()
-        self._chk(lib().ks_count_updated_voxels(self._h, C.byref(n)))
+        n, nr = C.c_size_t(), C.c_size_t()
+        self._chk(lib().ks_count_updated_voxels(self._h, C.byref(n), C.byref(nr)))
         dt = np.dtype([("block", "<i4", (3,)), ("linear", "<u4"), ("tsdf", TSDF_DTYPE), ("sem", SEM_DTYPE)])
-        assert dt.itemsize == 120
+        rdt = np.dtype([("block", "<i4", (3,)), ("first", "<u4"), ("count", "<u4")])
+        assert dt.itemsize == 120 and rdt.itemsize == 20
         out = np.zeros(n.value, dtype=dt)
+        runs = np.zeros(nr.value, dtype=rdt)
         if n.value:
-            m = C.c_size_t()
-            self._chk(lib().ks_download_updated_voxels(self._h, _ptr(out), n.value, C.byref(m)))
-            assert m.value == n.value
+            m, mr = C.c_size_t(), C.c_size_t()
+            self._chk(lib().ks_download_updated_voxels(self._h, _ptr(out), n.value, C.byref(m), _ptr(runs), nr.value, C.byref(mr)))
+            assert m.value == n.value and mr.value == nr.value
+            # every record belongs to exactly one run, and carries its run's block index
+            assert int(runs["count"].sum()) == n.value
+            for r in runs[:: max(1, len(runs) // 16)]:
+                if r["count"]:
+                    assert (out["block"][r["first"]:r["first"] + r["count"]] == r["block"]).all()
         return out
 
     def clear(self):

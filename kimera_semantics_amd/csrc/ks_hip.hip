@@ -167,6 +167,7 @@ struct ks_ctx {
   bool use_tail_thread = false;
   double hp_a = 0, hp_b = 0, hp_t = 0, hp_sort = 0;   // KS_HOST_PROF=1: host seconds spent enqueueing stage A / B / T, radix sorts (of A+T)
   bool host_prof = false;
+  bool export_staged = false;             // KS_EXPORT_STAGED=1: voxel export via a device buffer + copy even for pinned targets
   bool use_graphs = true;                // stage B replayed as a hipGraph (KS_NO_GRAPH=1 or a capture failure: plain launches)
   uint64_t buffers_epoch = 1;            // bumped whenever a buffer a captured graph points at is re-allocated
   uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
@@ -1144,6 +1145,8 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     c->host_prof = hpf && hpf[0] == '1';
     const char* ng = getenv("KS_NO_GRAPH");
     c->use_graphs = !(ng && ng[0] == '1');
+    const char* es = getenv("KS_EXPORT_STAGED");
+    c->export_staged = es && es[0] == '1';
   }
   c->log_match = lm;
   c->log_non_match = lnm;
@@ -1534,9 +1537,21 @@ int ks_upload_blocks(ks_ctx* c, const int32_t* idx, size_t n, const void* tsdf_i
 }
 
 // ---- voxel-level host sync -------------------------------------------------------------------------------
-static int updated_voxels_impl(ks_ctx* c, void* out, size_t cap, size_t* n, bool count_only) {
+// Device-side address of a host allocation the GPU can write (hipHostMalloc'ed: ks_host_alloc), else nullptr.
+static void* device_view_of_pinned(void* p) {
+  hipPointerAttribute_t a;
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return a.type == hipMemoryTypeHost ? a.devicePointer : nullptr;
+}
+
+static int updated_voxels_impl(ks_ctx* c, void* out, size_t cap, size_t* n, bool count_only, ks_voxel_run* runs, size_t cap_runs,
+                               size_t* n_runs) {
   if (!c || !n) return KS_ERR_INVALID_ARG;
   *n = 0;
+  if (n_runs) *n_runs = 0;
   if (int rc = quiesce(c)) return rc;
   const uint32_t nt = c->tiles_initialised;
   if (nt == 0) return KS_OK;
@@ -1552,8 +1567,9 @@ static int updated_voxels_impl(ks_ctx* c, void* out, size_t cap, size_t* n, bool
   HIPCHK(c, hipStreamSynchronize(st));
   const uint32_t n_list = h_cnt[0];
   if (n_list == 0) return KS_OK;
+  if (n_runs) *n_runs = n_list;
   hipLaunchKernelGGL(k_export_dirty, dim3(n_list), dim3(512), 0, st, c->table, c->pool, (const uint32_t*)d_list,
-                     (const uint32_t*)c->d_label_lut, c->vps_shift, 1, d_cnt, (uint8_t*)nullptr);
+                     (const uint32_t*)c->d_label_lut, c->vps_shift, 1, d_cnt, (uint8_t*)nullptr, (uint32_t*)nullptr);
   HIPCHK(c, hipMemcpyAsync(h_cnt, d_cnt, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   *n = h_cnt[1];
@@ -1562,24 +1578,40 @@ static int updated_voxels_impl(ks_ctx* c, void* out, size_t cap, size_t* n, bool
     c->err = "ks_download_updated_voxels: output buffer too small (call ks_count_updated_voxels first)";
     return KS_ERR_INVALID_ARG;
   }
-  const size_t bytes = (size_t)h_cnt[1] * kVoxRecBytes;
-  if (bytes > c->cap_vox_out) {
-    if ((rc = dev_alloc(c, &c->d_vox_out, bytes + bytes / 4))) return rc;
-    c->cap_vox_out = bytes + bytes / 4;
+  if (runs && (size_t)n_list > cap_runs) {
+    c->err = "ks_download_updated_voxels: run buffer too small";
+    return KS_ERR_INVALID_ARG;
   }
+  // pinned host targets (ks_host_alloc) are written by the kernel itself: no staging copy
+  uint8_t* rec_direct = (uint8_t*)device_view_of_pinned(out);
+  uint32_t* run_direct = runs ? (uint32_t*)device_view_of_pinned(runs) : nullptr;
+  if (c->export_staged) rec_direct = nullptr, run_direct = nullptr;
+  const size_t bytes = (size_t)h_cnt[1] * kVoxRecBytes;
+  const size_t run_bytes = (size_t)n_list * sizeof(ks_voxel_run);
+  const size_t need = (rec_direct ? 0 : bytes + bytes / 4) + (run_direct ? 0 : 2 * run_bytes) + 64;
+  if ((!rec_direct || (runs && !run_direct)) && need > c->cap_vox_out) {
+    if ((rc = dev_alloc(c, &c->d_vox_out, need))) return rc;
+    c->cap_vox_out = need;
+  }
+  uint8_t* d_rec = rec_direct ? rec_direct : c->d_vox_out;
+  uint32_t* d_runs = run_direct ? run_direct : (uint32_t*)(c->d_vox_out + (rec_direct ? 0 : ((bytes + 15) & ~(size_t)15)));
   HIPCHK(c, hipMemsetAsync(d_cnt + 1, 0, sizeof(uint32_t), st));
   hipLaunchKernelGGL(k_export_dirty, dim3(n_list), dim3(512), 0, st, c->table, c->pool, (const uint32_t*)d_list,
-                     (const uint32_t*)c->d_label_lut, c->vps_shift, 0, d_cnt, c->d_vox_out);
-  HIPCHK(c, hipMemcpyAsync(out, c->d_vox_out, bytes, hipMemcpyDeviceToHost, st));
+                     (const uint32_t*)c->d_label_lut, c->vps_shift, 0, d_cnt, d_rec, runs ? d_runs : (uint32_t*)nullptr);
+  if (!rec_direct) HIPCHK(c, hipMemcpyAsync(out, c->d_vox_out, bytes, hipMemcpyDeviceToHost, st));
+  if (runs && !run_direct) HIPCHK(c, hipMemcpyAsync(runs, d_runs, run_bytes, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   HIPCHK(c, hipGetLastError());
   return KS_OK;
 }
 
-int ks_count_updated_voxels(ks_ctx* c, size_t* n) { return updated_voxels_impl(c, nullptr, 0, n, true); }
-int ks_download_updated_voxels(ks_ctx* c, void* out, size_t cap, size_t* n) {
+int ks_count_updated_voxels(ks_ctx* c, size_t* n, size_t* n_runs) {
+  return updated_voxels_impl(c, nullptr, 0, n, true, nullptr, 0, n_runs);
+}
+int ks_download_updated_voxels(ks_ctx* c, void* out, size_t cap, size_t* n, ks_voxel_run* runs, size_t cap_runs, size_t* n_runs) {
   if (!out && cap) return KS_ERR_INVALID_ARG;
-  return updated_voxels_impl(c, out, cap, n, false);
+  static_assert(sizeof(ks_voxel_run) == 20, "run record layout");
+  return updated_voxels_impl(c, out, cap, n, false, runs, cap_runs, n_runs);
 }
 
 void* ks_host_alloc(size_t bytes) {

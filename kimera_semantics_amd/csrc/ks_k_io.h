@@ -324,34 +324,72 @@ __global__ void __launch_bounds__(256) k_list_updated_tiles(Pool P, uint32_t n_t
 constexpr uint32_t kVoxRecBytes = 120;
 __global__ void __launch_bounds__(512) k_export_dirty(TileTable T, Pool P, const uint32_t* __restrict__ list,
                                                       const uint32_t* __restrict__ label_lut, int vps_shift, int count_only,
-                                                      uint32_t* __restrict__ counters, uint8_t* __restrict__ out) {
+                                                      uint32_t* __restrict__ counters, uint8_t* __restrict__ out,
+                                                      uint32_t* __restrict__ runs) {
+  __shared__ uint32_t s_wave[8];
+  __shared__ uint32_t s_base, s_total;
+  __shared__ __attribute__((aligned(16))) uint32_t s_rec[kTileVoxels * (kVoxRecBytes / 4)];
   const uint32_t slot = list[blockIdx.x];
   const uint32_t local = threadIdx.x;
   uint32_t* rec = (uint32_t*)(P.vox + ((size_t)slot * kTileVoxels + local) * 8);
   const bool dirty = rec[25] != 0u;
-  const uint32_t pos = block_append(dirty, &counters[1]);
+  // the tile's dirty voxels get one contiguous range of records (one atomic per workgroup)
+  const unsigned long long m = __ballot(dirty);
+  const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
+  if (lane == 0) s_wave[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (uint32_t w = 0; w < 8; ++w) {
+      const uint32_t t = s_wave[w];
+      s_wave[w] = total;
+      total += t;
+    }
+    s_total = total;
+    s_base = total ? atomicAdd(&counters[1], total) : 0u;
+  }
+  __syncthreads();
+  const uint32_t pos = s_base + s_wave[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
   if (count_only) return;
-  if (threadIdx.x == 0) P.updated[slot] = 0;
-  if (!dirty) return;
-  rec[25] = 0u;
   int tx, ty, tz;
   unpack_tile(T.slot_keys[slot], tx, ty, tz);
-  const int vps = 8 << vps_shift;
-  const int vx = tx * 8 + (int)(local & 7u), vy = ty * 8 + (int)((local >> 3) & 7u), vz = tz * 8 + (int)(local >> 6);
-  uint32_t* o = (uint32_t*)(out + (size_t)pos * kVoxRecBytes);
-  o[0] = (uint32_t)(vx >> (3 + vps_shift));
-  o[1] = (uint32_t)(vy >> (3 + vps_shift));
-  o[2] = (uint32_t)(vz >> (3 + vps_shift));
-  o[3] = (uint32_t)((vx & (vps - 1)) + vps * ((vy & (vps - 1)) + vps * (vz & (vps - 1))));
-  const uint32_t label = rec[3];
-  const bool touched = label != 255u;
-  o[4] = rec[0];
-  o[5] = rec[1];
-  o[6] = rec[2];
-  o[7] = touched ? label : 0u;
+  if (threadIdx.x == 0) {
+    P.updated[slot] = 0;
+    if (runs) {  // {block x, y, z, first record, records}: a device tile lies inside one host block
+      uint32_t* r = runs + (size_t)blockIdx.x * 5;
+      r[0] = (uint32_t)(tx >> vps_shift);
+      r[1] = (uint32_t)(ty >> vps_shift);
+      r[2] = (uint32_t)(tz >> vps_shift);
+      r[3] = s_base;
+      r[4] = s_total;
+    }
+  }
+  // records are assembled in LDS in the tile's record order, then leave as one contiguous, coalesced range
+  // (the target may be pinned host memory: scattered dword stores would crawl over PCIe)
+  if (dirty) {
+    rec[25] = 0u;
+    const int vps = 8 << vps_shift;
+    const int vx = tx * 8 + (int)(local & 7u), vy = ty * 8 + (int)((local >> 3) & 7u), vz = tz * 8 + (int)(local >> 6);
+    uint32_t* o = s_rec + (size_t)(pos - s_base) * (kVoxRecBytes / 4);
+    o[0] = (uint32_t)(vx >> (3 + vps_shift));
+    o[1] = (uint32_t)(vy >> (3 + vps_shift));
+    o[2] = (uint32_t)(vz >> (3 + vps_shift));
+    o[3] = (uint32_t)((vx & (vps - 1)) + vps * ((vy & (vps - 1)) + vps * (vz & (vps - 1))));
+    const uint32_t label = rec[3];
+    const bool touched = label != 255u;
+    o[4] = rec[0];
+    o[5] = rec[1];
+    o[6] = rec[2];
+    o[7] = touched ? label : 0u;
 #pragma unroll
-  for (int k = 0; k < kNumLabels; ++k) o[8 + k] = rec[4 + k];
-  o[29] = touched ? label_lut[label] : (127u | (127u << 8) | (127u << 16) | (255u << 24));
+    for (int k = 0; k < kNumLabels; ++k) o[8 + k] = rec[4 + k];
+    o[29] = touched ? label_lut[label] : (127u | (127u << 8) | (127u << 16) | (255u << 24));
+  }
+  __syncthreads();
+  const uint32_t n2 = s_total * (kVoxRecBytes / 8);  // 120-byte records: the range starts 8-byte aligned
+  uint2* dst = (uint2*)(out + (size_t)s_base * kVoxRecBytes);
+  const uint2* src = (const uint2*)s_rec;
+  for (uint32_t i = threadIdx.x; i < n2; i += 512) dst[i] = src[i];
 }
 
 // Host-layout import (the inverse of k_download): one lane per voxel of a host block.  A voxel

@@ -2,7 +2,11 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
+#include <algorithm>
 
 #include <voxblox/utils/timing.h>
 
@@ -158,6 +162,66 @@ void HipSemanticTsdfIntegrator::integratePointCloud(const vxb::Transformation& T
   }
 }
 
+HipSemanticTsdfIntegrator::Workers::~Workers() {
+  {
+    std::lock_guard<std::mutex> lk(mu_);
+    stop_ = true;
+  }
+  cv_work_.notify_all();
+  for (auto& t : threads_) t.join();
+}
+
+void HipSemanticTsdfIntegrator::Workers::loop(size_t) {
+  std::unique_lock<std::mutex> lk(mu_);
+  uint64_t seen = 0;
+  for (;;) {
+    cv_work_.wait(lk, [&] { return stop_ || (epoch_ != seen && next_ < parts_); });
+    if (stop_) return;
+    while (next_ < parts_) {
+      const size_t part = next_++;
+      const size_t chunk = (n_ + parts_ - 1) / parts_;
+      const size_t b = std::min(n_, part * chunk), e = std::min(n_, (part + 1) * chunk);
+      const auto* fn = fn_;
+      lk.unlock();
+      (*fn)(b, e);
+      lk.lock();
+      if (--pending_ == 0) cv_done_.notify_all();
+    }
+    seen = epoch_;
+  }
+}
+
+void HipSemanticTsdfIntegrator::Workers::run(size_t n, size_t parts, const std::function<void(size_t, size_t)>& fn) {
+  if (parts <= 1) {
+    fn(0, n);
+    return;
+  }
+  std::unique_lock<std::mutex> lk(mu_);
+  while (threads_.size() + 1 < parts) {
+    const size_t id = threads_.size();
+    threads_.emplace_back([this, id] { loop(id); });
+  }
+  fn_ = &fn;
+  n_ = n;
+  parts_ = parts;
+  next_ = 0;
+  pending_ = parts;
+  ++epoch_;
+  cv_work_.notify_all();
+  // the caller works too
+  while (next_ < parts_) {
+    const size_t part = next_++;
+    const size_t chunk = (n_ + parts_ - 1) / parts_;
+    const size_t b = std::min(n_, part * chunk), e = std::min(n_, (part + 1) * chunk);
+    lk.unlock();
+    fn(b, e);
+    lk.lock();
+    --pending_;
+  }
+  cv_done_.wait(lk, [&] { return pending_ == 0; });
+  fn_ = nullptr;
+}
+
 uint8_t* HipSemanticTsdfIntegrator::Staging::reserve(size_t bytes) {
   if (bytes > cap) {
     ks_host_free(p);
@@ -187,50 +251,76 @@ void HipSemanticTsdfIntegrator::syncLayers() {
   // Only the voxels the integrator wrote since the last sync travel (a frame touches ~1.7e5 voxels of ~150
   // blocks: 20 MB instead of 60-85 MB of whole blocks); a tile's voxels are contiguous in the buffer, so the
   // block lookup happens once per tile, not once per voxel.
-  size_t n = 0;
-  check(ks_count_updated_voxels(ctx_, &n), "ks_count_updated_voxels");
-  if (n == 0) return;
-  const uint8_t* buf = vox_buf_.reserve(n * KS_VOXEL_RECORD_BYTES);
-  check(ks_download_updated_voxels(ctx_, vox_buf_.p, n, &n), "ks_download_updated_voxels");
-  int32_t last[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
-  vxb::Block<vxb::TsdfVoxel>::Ptr tb;
-  vxb::Block<SemanticVoxel>::Ptr sb;
-  for (size_t i = 0; i < n; ++i) {
-    const uint8_t* r = buf + i * KS_VOXEL_RECORD_BYTES;
-    int32_t h[4];
-    std::memcpy(h, r, 16);
-    if (h[0] != last[0] || h[1] != last[1] || h[2] != last[2]) {
-      const vxb::BlockIndex idx(h[0], h[1], h[2]);
-      tb = layer_->allocateBlockPtrByIndex(idx);
-      sb = semantic_layer_ptr_->allocateBlockPtrByIndex(idx);
-      tb->updated() = true;
-      sb->updated() = true;
-      last[0] = h[0]; last[1] = h[1]; last[2] = h[2];
-    }
-    const size_t lin = static_cast<uint32_t>(h[3]);
-    const uint8_t* t = r + 16;
-    const uint8_t* sv_in = r + 28;
-    vxb::TsdfVoxel& v = tb->getVoxelByLinearIndex(lin);
-    if (kTsdfLayoutMatches) {
-      std::memcpy(static_cast<void*>(&v), t, 12);
-    } else {
-      std::memcpy(&v.distance, t, 4);
-      std::memcpy(&v.weight, t + 4, 4);
-      v.color = vxb::Color(t[8], t[9], t[10], t[11]);
-    }
-    SemanticVoxel& sv = sb->getVoxelByLinearIndex(lin);
-    if (kSemLayoutMatches) {
-      std::memcpy(static_cast<void*>(&sv), sv_in, 92);
-    } else {
-      sv.semantic_label = sv_in[0];
-      for (size_t l = 0; l < kTotalNumberOfLabels; ++l) {
-        float p;
-        std::memcpy(&p, sv_in + 4 + 4 * l, 4);
-        sv.semantic_priors[l] = p;
-      }
-      sv.color = HashableColor(sv_in[88], sv_in[89], sv_in[90], sv_in[91]);
-    }
+  // The staging buffers keep the size of the largest sync so far: the download is tried with what is there,
+  // and only a sync that outgrows it pays for a second attempt (the call reports the sizes it needs).
+  size_t n = 0, n_runs = 0;
+  vxb::timing::Timer t_dl("sync/download");
+  int rc = ks_download_updated_voxels(ctx_, vox_buf_.p, vox_buf_.cap / KS_VOXEL_RECORD_BYTES, &n,
+                                      reinterpret_cast<ks_voxel_run*>(run_buf_.p), run_buf_.cap / sizeof(ks_voxel_run), &n_runs);
+  if (rc == KS_ERR_INVALID_ARG && (n * KS_VOXEL_RECORD_BYTES > vox_buf_.cap || n_runs * sizeof(ks_voxel_run) > run_buf_.cap)) {
+    vox_buf_.reserve((n + n / 4) * KS_VOXEL_RECORD_BYTES);
+    run_buf_.reserve((n_runs + n_runs / 4) * sizeof(ks_voxel_run));
+    rc = ks_download_updated_voxels(ctx_, vox_buf_.p, vox_buf_.cap / KS_VOXEL_RECORD_BYTES, &n,
+                                    reinterpret_cast<ks_voxel_run*>(run_buf_.p), run_buf_.cap / sizeof(ks_voxel_run), &n_runs);
   }
+  check(rc, "ks_download_updated_voxels");
+  if (n == 0) return;
+  const uint8_t* buf = vox_buf_.p;
+  const ks_voxel_run* runs = reinterpret_cast<const ks_voxel_run*>(run_buf_.p);
+  t_dl.Stop();
+  vxb::timing::Timer t_scatter("sync/scatter");
+  // pass 1 (serial, one step per device tile): make sure the host blocks exist and are flagged
+  for (size_t r = 0; r < n_runs; ++r) {
+    if (runs[r].count == 0) continue;
+    const vxb::BlockIndex idx(runs[r].block[0], runs[r].block[1], runs[r].block[2]);
+    layer_->allocateBlockPtrByIndex(idx)->updated() = true;
+    semantic_layer_ptr_->allocateBlockPtrByIndex(idx)->updated() = true;
+  }
+  // pass 2 (parallel over record ranges; distinct records are distinct voxels, block lookups are read-only)
+  auto scatter = [this, buf](size_t begin, size_t end) {
+    int32_t last[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    vxb::Block<vxb::TsdfVoxel>::Ptr tb;
+    vxb::Block<SemanticVoxel>::Ptr sb;
+    for (size_t i = begin; i < end; ++i) {
+      const uint8_t* r = buf + i * KS_VOXEL_RECORD_BYTES;
+      int32_t h[4];
+      std::memcpy(h, r, 16);
+      if (h[0] != last[0] || h[1] != last[1] || h[2] != last[2]) {
+        const vxb::BlockIndex idx(h[0], h[1], h[2]);
+        tb = layer_->getBlockPtrByIndex(idx);
+        sb = semantic_layer_ptr_->getBlockPtrByIndex(idx);
+        last[0] = h[0]; last[1] = h[1]; last[2] = h[2];
+      }
+      const size_t lin = static_cast<uint32_t>(h[3]);
+      const uint8_t* t = r + 16;
+      const uint8_t* sv_in = r + 28;
+      vxb::TsdfVoxel& v = tb->getVoxelByLinearIndex(lin);
+      if (kTsdfLayoutMatches) {
+        std::memcpy(static_cast<void*>(&v), t, 12);
+      } else {
+        std::memcpy(&v.distance, t, 4);
+        std::memcpy(&v.weight, t + 4, 4);
+        v.color = vxb::Color(t[8], t[9], t[10], t[11]);
+      }
+      SemanticVoxel& sv = sb->getVoxelByLinearIndex(lin);
+      if (kSemLayoutMatches) {
+        std::memcpy(static_cast<void*>(&sv), sv_in, 92);
+      } else {
+        sv.semantic_label = sv_in[0];
+        for (size_t l = 0; l < kTotalNumberOfLabels; ++l) {
+          float p;
+          std::memcpy(&p, sv_in + 4 + 4 * l, 4);
+          sv.semantic_priors[l] = p;
+        }
+        sv.color = HashableColor(sv_in[88], sv_in[89], sv_in[90], sv_in[91]);
+      }
+    }
+  };
+  static const size_t kThreadsEnv = std::getenv("KS_SYNC_THREADS") ? std::strtoul(std::getenv("KS_SYNC_THREADS"), nullptr, 10) : 0;
+  const size_t n_threads = kThreadsEnv ? kThreadsEnv
+                                       : (n < 20000 ? 1 : std::min<size_t>(16, std::max<size_t>(1, std::thread::hardware_concurrency())));
+  workers_.run(n, n_threads, scatter);
+  t_scatter.Stop();
 }
 
 void HipSemanticTsdfIntegrator::syncLayersByBlock() {

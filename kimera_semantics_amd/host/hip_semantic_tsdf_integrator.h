@@ -7,8 +7,12 @@
 // libks_hip.so (include/ks_hip.h); this class only marshals arguments and keeps the host
 // Layers consistent.
 #pragma once
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <voxblox/integrator/tsdf_integrator.h>
@@ -87,7 +91,27 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
     ~Staging();
   };
   std::vector<int32_t> idx_buf_;
-  Staging tsdf_buf_, sem_buf_, vox_buf_;
+  Staging tsdf_buf_, sem_buf_, vox_buf_, run_buf_;
+
+  /// Persistent workers for the scatter of downloaded voxels into the host layers (thread start-up per frame
+  /// costs as much as the scatter itself).
+  class Workers {
+   public:
+    ~Workers();
+    /// fn(begin, end) over [0, n) cut into `parts` ranges; returns when all ranges are done.
+    void run(size_t n, size_t parts, const std::function<void(size_t, size_t)>& fn);
+
+   private:
+    void loop(size_t id);
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(size_t, size_t)>* fn_ = nullptr;
+    size_t n_ = 0, parts_ = 0, next_ = 0, pending_ = 0;
+    uint64_t epoch_ = 0;
+    bool stop_ = false;
+  };
+  Workers workers_;
 };
 
 /// Same shape as kimera::SemanticTsdfIntegratorFactory
