@@ -69,7 +69,9 @@ def integ_cfg(wl, method=None):
     method = method or wl["method"]
     return dict(method=0 if method == "fast" else 1, voxel_size=wl["voxel"], voxels_per_side=16,
                 truncation_distance=4 * wl["voxel"], max_ray_length_m=wl["max_ray"], semantic_measurement_probability=0.8,
-                dynamic_labels=[20], label_rgba=synth.default_label_colors())
+                dynamic_labels=[20], label_rgba=synth.default_label_colors(),
+                # experiments only (the default, 0, is the library's default schedule)
+                early_out_phase_growth=int(os.environ.get("KS_BENCH_GROWTH", "0")))
 
 
 def common_cfg(method):

@@ -95,7 +95,6 @@ struct FrameSlot {
   uint32_t* d_lp = nullptr;         // exclusive prefix of d_cnt inside blocks of kScanBlock
   unsigned long long* d_bt = nullptr;  // block totals of that scan
   uint8_t* d_live = nullptr;        // fast: position holds a ray that survived start-voxel dedup
-  uint32_t n_scan = 0;
   bool wide = false;                // stage B uses a whole wavefront per ray (long rays)
   FrameParams* d_F = nullptr;       // the frame's parameters in device memory (stage B reads them from there)
   uint64_t *d_gkeys = nullptr, *d_rkeys = nullptr;  // anti-grazing: this frame's sorted end-voxel keys / key per bundle
@@ -416,25 +415,27 @@ void resolve_prof(ks_ctx* c, int set) {
 
 // pair emission over an upper bound of rays (<= n); the live ray count stays on the device
 void launch_emit(ks_ctx* c, FrameSlot& S, hipStream_t st, Counters* counters) {
-  const size_t lds = ((size_t)(S.n_scan + kScanBlock - 1) / kScanBlock) * sizeof(unsigned long long);
-  const size_t n = S.n;
+  // grids and LDS are sized by the slot's capacity (the kernels take the frame's own counts from S.d_F and the
+  // counters): the launch sequence is the same for every frame and can be replayed
+  const size_t n = c->cap_points;
+  const size_t lds = ((2 * n + kScanBlock - 1) / kScanBlock) * sizeof(unsigned long long);
   if (!(c->cfg.method == KS_METHOD_MERGED && c->cfg.enable_anti_grazing)) {
     // bundles and 2 cm rays are long: 8 rays per wavefront; early-out rays are short: one per lane
     if (S.wide || c->cfg.method == KS_METHOD_MERGED || !c->uses_early_out)
-      hipLaunchKernelGGL(k_emit_lane<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), lds, st, (const FrameParams*)S.d_F, S.n_scan,
+      hipLaunchKernelGGL(k_emit_lane<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), lds, st, (const FrameParams*)S.d_F,
                          S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
                          (unsigned long long)S.cap_pairs_in, counters);
     else
       hipLaunchKernelGGL(k_emit_lane<16>, dim3((uint32_t)((n + 63) / 64)), dim3(256), lds, st, (const FrameParams*)S.d_F,
-                         S.n_scan, S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
+                         S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
                          (unsigned long long)S.cap_pairs_in, counters);
   }
   else if (S.wide)
-    hipLaunchKernelGGL(k_emit<64>, dim3((uint32_t)((n + 3) / 4)), dim3(256), lds, st, (const FrameParams*)S.d_F, S.n_scan,
+    hipLaunchKernelGGL(k_emit<64>, dim3((uint32_t)((n + 3) / 4)), dim3(256), lds, st, (const FrameParams*)S.d_F,
                        S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
                        (unsigned long long)S.cap_pairs_in, counters);
   else
-    hipLaunchKernelGGL(k_emit<16>, dim3((uint32_t)((n + 15) / 16)), dim3(256), lds, st, (const FrameParams*)S.d_F, S.n_scan,
+    hipLaunchKernelGGL(k_emit<16>, dim3((uint32_t)((n + 15) / 16)), dim3(256), lds, st, (const FrameParams*)S.d_F,
                        S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
                        (unsigned long long)S.cap_pairs_in, counters);
 }
@@ -443,7 +444,7 @@ void launch_emit(ks_ctx* c, FrameSlot& S, hipStream_t st, Counters* counters) {
 // caller, or issued directly).  Everything frame-specific comes from S.d_F.
 void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max) {
   const ks_config& cfg = c->cfg;
-  const size_t n = S.n;
+  const size_t n = c->cap_points;  // NOT the frame's point count: see launch_emit
   const FrameParams* dF = S.d_F;
   if (c->uses_early_out) {
     // ordered-phase early-out: per phase, k_test decides how far the phase's rays get against the set as it
@@ -451,8 +452,8 @@ void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max) 
     const uint32_t n_gen = (uint32_t)((n + kChains - 1) / kChains);
     const std::vector<uint32_t> B = phase_bounds(n_gen, cfg.early_out_phase_growth);
     for (size_t j = 0; j < B.size(); ++j) {
-      const uint32_t g0 = B[j], g1 = (j + 1 < B.size()) ? B[j + 1] : n_gen;
-      const uint32_t p0 = g0 * kChains, p1 = (uint32_t)std::min<uint64_t>((uint64_t)g1 * kChains, n);
+      const uint32_t g0 = B[j], g1 = (j + 1 < B.size()) ? B[j + 1] : n_gen;  // k_test ends the frame's last phase at ITS n
+      const uint32_t p0 = g0 * kChains, p1 = (uint32_t)std::min<uint64_t>((uint64_t)g1 * kChains, UINT32_MAX);
       const uint32_t n_sub = (g1 - g0 + kSubRun - 1) / kSubRun;  // wavefronts per chain
       const uint32_t steps_cap = (uint32_t)((steps_max + 3) & ~(size_t)3);
       const size_t lds_wave = (size_t)test_lds_words64(steps_cap) * sizeof(unsigned long long);
@@ -470,8 +471,8 @@ void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max) 
   if (cfg.method == KS_METHOD_MERGED && cfg.enable_anti_grazing)
     hipLaunchKernelGGL(k_count_grazing<16>, dim3((uint32_t)((n + 15) / 16)), dim3(256), 0, sm, dF, S.d_ray_list, S.d_rays,
                        S.d_cnt, S.d_counters);
-  hipLaunchKernelGGL(k_scan_local, dim3((S.n_scan + kScanBlock - 1) / kScanBlock), dim3(1024), 0, sm, S.n_scan, S.d_cnt,
-                     S.d_lp, S.d_bt);
+  hipLaunchKernelGGL(k_scan_local, dim3((uint32_t)(((cfg.method == KS_METHOD_MERGED ? 2 : 1) * n + kScanBlock - 1) / kScanBlock)),
+                     dim3(1024), 0, sm, dF, S.d_cnt, S.d_lp, S.d_bt);
   launch_emit(c, S, sm, S.d_counters);
   // the frame's only device->host traffic: pair / ray / tile counts and error flags
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sm, S.d_counters, (const uint32_t*)c->table.n_tiles,
@@ -622,9 +623,8 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   // their launch sequence depends only on the point count: it is captured once per slot and replayed.
   F.observed = observed_table(c, this_frame);
   hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sm, F, S.d_F);
-  S.n_scan = (uint32_t)((cfg.method == KS_METHOD_MERGED ? 2 : 1) * n);
   {
-    const uint64_t key = ((uint64_t)n << 24) ^ (c->buffers_epoch << 1) ^ (S.wide ? 1u : 0u);
+    const uint64_t key = ((uint64_t)c->cap_points << 24) ^ (c->buffers_epoch << 1) ^ (S.wide ? 1u : 0u);
     bool replayed = false;
     if (c->use_graphs) {
       if (S.b_graph_key != key || !S.b_graph) {
@@ -1170,6 +1170,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   }
   if (cfg->pipeline_frames) {
     c->n_march = kMarchStreams;
+    if (const char* ms = getenv("KS_MARCH_STREAMS")) c->n_march = std::min(kMarchStreams, std::max(1, atoi(ms)));  // diagnostics
     for (int i = 0; i < c->n_march; ++i) CRCHK(hipStreamCreateWithFlags(&c->stream_march_[i], hipStreamNonBlocking));
     CRCHK(hipStreamCreateWithFlags(&c->stream_tail, hipStreamNonBlocking));
   } else {

@@ -264,6 +264,10 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
   const uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave;
   const uint32_t chain = w % kChains, sub = w / kChains;
   const uint32_t gs = g0 + sub * kSubRun;
+  {  // the launch covers the slot's capacity: the frame's last generation ends the last phase
+    const uint32_t n_gen = (F.n + kChains - 1u) / kChains;
+    if (g1 > n_gen) g1 = n_gen;
+  }
   if (gs >= g1) return;
   const uint32_t ge = gs + kSubRun < g1 ? gs + kSubRun : g1;
   const int lim = F.max_collisions;
@@ -493,6 +497,9 @@ __global__ void __launch_bounds__(256) k_mark(const FrameParams* __restrict__ Fp
   }
 }
 
+// entries of the per-position update counts: merged keeps the clearing bundles' counts at +n
+__device__ __forceinline__ uint32_t scan_length(const FrameParams& F) { return (F.method == KS_METHOD_MERGED ? 2u : 1u) * F.n; }
+
 // ------------------------------------------------------------------------------------------
 // Scan of the per-ray update counts in integration order.  cnt[] is indexed by integration position
 // (merged: first-point position of the bundle, clearing bundles offset by n: they integrate after all
@@ -501,9 +508,10 @@ __global__ void __launch_bounds__(256) k_mark(const FrameParams* __restrict__ Fp
 // block offsets (a few hundred values, scanned again by every block in LDS).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kScanBlock = 4096;
-__global__ void __launch_bounds__(1024) k_scan_local(uint32_t n_scan, const uint32_t* __restrict__ cnt,
+__global__ void __launch_bounds__(1024) k_scan_local(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ cnt,
                                                      uint32_t* __restrict__ lp, unsigned long long* __restrict__ bt) {
   __shared__ uint32_t s_wave[16];
+  const uint32_t n_scan = scan_length(*Fp);  // the grid covers the slot's capacity
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
   const uint32_t i0 = blockIdx.x * kScanBlock + threadIdx.x * 4u;
   uint32_t v[4];
@@ -536,7 +544,7 @@ __global__ void __launch_bounds__(1024) k_scan_local(uint32_t n_scan, const uint
 // The list is in integration order; total = Counters::n_pairs.
 // ------------------------------------------------------------------------------------------
 template <int LPR>
-__global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Fp, uint32_t n_scan,
+__global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Fp,
                                               const uint32_t* __restrict__ ray_list, const RayDesc* __restrict__ rays,
                                               const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ lp,
                                               const unsigned long long* __restrict__ bt, TileTable T, Pool P,
@@ -548,7 +556,7 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Fp
   // exclusive prefix of the block totals (every block redundantly; <= a few thousand values)
   extern __shared__ unsigned long long s_bt[];
   __shared__ unsigned long long s_carry;
-  const uint32_t nb = (n_scan + kScanBlock - 1) / kScanBlock;
+  const uint32_t nb = (scan_length(F) + kScanBlock - 1) / kScanBlock;
   if (threadIdx.x == 0) s_carry = 0ull;
   __syncthreads();
   for (uint32_t b0 = 0; b0 < nb; b0 += 256) {
@@ -651,7 +659,7 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Fp
 // first 32 voxels serially (consecutive voxels share their tile: one table lookup per tile crossing), the few
 // rays that go further are then taken one at a time by the whole wavefront (exact parallel caster).
 template <int RPW>
-__global__ void __launch_bounds__(256) k_emit_lane(const FrameParams* __restrict__ Fp, uint32_t n_scan,
+__global__ void __launch_bounds__(256) k_emit_lane(const FrameParams* __restrict__ Fp,
                                                    const uint32_t* __restrict__ ray_list, const RayDesc* __restrict__ rays,
                                                    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ lp,
                                                    const unsigned long long* __restrict__ bt, TileTable T, Pool P,
@@ -661,7 +669,7 @@ __global__ void __launch_bounds__(256) k_emit_lane(const FrameParams* __restrict
   extern __shared__ unsigned long long s_bt[];
   __shared__ unsigned long long s_carry;
   __shared__ float s_e[4][3 * kES];
-  const uint32_t nb = (n_scan + kScanBlock - 1) / kScanBlock;
+  const uint32_t nb = (scan_length(F) + kScanBlock - 1) / kScanBlock;
   if (threadIdx.x == 0) s_carry = 0ull;
   __syncthreads();
   for (uint32_t b0 = 0; b0 < nb; b0 += 256) {
