@@ -1171,8 +1171,22 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   if (cfg->pipeline_frames) {
     c->n_march = kMarchStreams;
     if (const char* ms = getenv("KS_MARCH_STREAMS")) c->n_march = std::min(kMarchStreams, std::max(1, atoi(ms)));  // diagnostics
-    for (int i = 0; i < c->n_march; ++i) CRCHK(hipStreamCreateWithFlags(&c->stream_march_[i], hipStreamNonBlocking));
-    CRCHK(hipStreamCreateWithFlags(&c->stream_tail, hipStreamNonBlocking));
+    {
+      // KS_STREAM_PRIORITY (diagnostics): m = march streams at the highest priority, t = tail, l = long at the lowest
+      const char* sp = getenv("KS_STREAM_PRIORITY");
+      int lo = 0, hi = 0;
+      CRCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      auto mk = [&](hipStream_t* st, char tag) {
+        if (sp && strchr(sp, tag)) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, tag == 'l' ? lo : hi);
+        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+      };
+      for (int i = 0; i < c->n_march; ++i) CRCHK(mk(&c->stream_march_[i], 'm'));
+      CRCHK(mk(&c->stream_tail, 't'));
+      if (sp && strchr(sp, 'l') && c->stream_long) {
+        (void)hipStreamDestroy(c->stream_long);
+        CRCHK(mk(&c->stream_long, 'l'));
+      }
+    }
   } else {
     c->stream_march_[0] = c->stream_tail = c->stream;
   }
