@@ -255,7 +255,9 @@ int dev_alloc(ks_ctx* c, T** p, size_t n) {
 
 int ensure_points(ks_ctx* c, size_t n) {
   if (n <= c->cap_points) return KS_OK;
-  const size_t cap = std::max<size_t>(n, 1024);
+  // the create-time size is exact; a cloud that outgrows it gets head-room (growing completes the frames in
+  // flight and re-captures stage B)
+  const size_t cap = std::max<size_t>(c->cap_points ? n + n / 8 : n, 1024);
   int rc;
   if ((rc = dev_alloc(c, &c->d_xyz, cap * 3))) return rc;
   if ((rc = dev_alloc(c, &c->d_rgba, cap * 4))) return rc;

@@ -738,3 +738,25 @@ def test_voxel_level_sync_rebuilds_the_map(method, vps):
             assert host[key][0].tobytes() == t[b].tobytes() and host[key][1].tobytes() == s[b].tobytes(), key
         else:  # a block whose tiles were allocated but never updated
             assert not (t[b]["weight"] > 0).any()
+
+
+@pytest.mark.parametrize("method,early_out", [(0, False), (0, True), (1, False)])
+def test_cloud_outgrows_max_points_with_frames_in_flight(method, early_out):
+    """A later frame is larger than ks_config.max_points while earlier frames still wait for their tails
+    (pipelined): the point buffers are re-allocated only after those frames have completed, and
+    stage B's replayed launch sequence is re-captured for the new capacity."""
+    kw = dict(COMMON, method=method)
+    if early_out:
+        kw["early_out_phase_growth"] = 32
+    else:
+        kw["max_consecutive_ray_collisions"] = NO_EARLY_OUT
+    o = O.Oracle(O.default_config(**kw))
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=80 * 60, pipeline_frames=3, **kw))
+    sc = synth.make_scene("room")
+    sizes = [(80, 60)] * 4 + [(160, 120)] * 3 + [(96, 72)] * 2 + [(200, 150)] * 2
+    for k, (w, hh) in enumerate(sizes):
+        f = synth.render_frame(sc, synth.trajectory_pose(4 * k), w, hh, seed=2100 + k)
+        o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    h.flush()
+    compare_maps(o, h, exact=True)
