@@ -108,6 +108,8 @@ struct FrameSlot {
   hipEvent_t tail_done = nullptr;   // the tail has consumed this slot's buffers
   hipEvent_t fork = nullptr, join = nullptr;  // tail: pairs sorted and long runs listed | long runs applied
   bool tail_recorded = false;
+  bool join_recorded = false;
+  uint64_t frame_no = 0;      // the frame the slot holds
   FrameParams F{};
   size_t n = 0;
   int prof_set = -1;
@@ -183,7 +185,9 @@ struct ks_ctx {
   float4* d_gpw = nullptr;
   uint64_t* d_ray_keys = nullptr;
   uint2* d_glc = nullptr;
-  unsigned long long* d_long_list = nullptr;
+  // stage T's shared buffers exist twice (frame parity): the long runs of frame f may still be applied from
+  // set f & 1 while frame f+1 sorts its pairs and lists its long runs into the other set (deferred join)
+  unsigned long long* d_long_list_[2] = {nullptr, nullptr};
   uint32_t* d_blong = nullptr;
   uint64_t *d_pkeys = nullptr, *d_pkeys2 = nullptr;
   uint32_t *d_pvals = nullptr, *d_pvals2 = nullptr;
@@ -191,7 +195,9 @@ struct ks_ctx {
   uint32_t* d_inv_order = nullptr;
   uint32_t *d_okeys = nullptr, *d_okeys2 = nullptr, *d_ovals = nullptr;
   size_t cap_pairs = 0;
-  uint64_t* d_pairs2 = nullptr;
+  uint64_t* d_pairs2_[2] = {nullptr, nullptr};
+  bool defer_join = false;               // k_apply_long of frame f overlaps the pair sort of frame f+1 (KS_NO_DEFER_JOIN=1: off)
+  hipEvent_t pending_join = nullptr;     // recorded on stream_long; the next k_apply / k_apply_long wait for it
   ksrs::Workspace sort_ws, sort_ws_tail;
   // scratch of the multi-GPU exchange entry points (slots / group offsets + order / distinct keys)
   uint32_t* d_xchg_u32 = nullptr;
@@ -316,8 +322,12 @@ int ensure_pairs_out(ks_ctx* c, size_t n) {
   if (n <= c->cap_pairs) return KS_OK;
   const size_t cap = std::max<size_t>(n + n / 4, 1 << 20);
   int rc;
-  if ((rc = dev_alloc(c, &c->d_pairs2, cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_long_list, cap / kLongRun + 64))) return rc;
+  if (c->stream_long) HIPCHK(c, hipStreamSynchronize(c->stream_long));  // long runs of the previous frame may still read them
+  if (c->stream_tail) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
+  for (int b = 0; b < 2; ++b) {
+    if ((rc = dev_alloc(c, &c->d_pairs2_[b], cap))) return rc;
+    if ((rc = dev_alloc(c, &c->d_long_list_[b], cap / kLongRun + 64))) return rc;
+  }
   c->cap_pairs = cap;
   return KS_OK;
 }
@@ -542,6 +552,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
 
   hipStream_t st = c->stream;
   if (S.tail_recorded && c->stream_tail != c->stream) HIPCHK(c, hipStreamWaitEvent(st, S.tail_done, 0));
+  if (S.join_recorded) HIPCHK(c, hipStreamWaitEvent(st, S.join, 0));  // (its long runs may have ended after its tail_done)
   S.n = n;
   S.prof_set = -1;
   if (c->profiling) {
@@ -557,6 +568,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
     S.prof_set = set;
   }
   const uint64_t this_frame = c->frame_no;
+  S.frame_no = this_frame;
   ++c->frame_no;
   // S.d_counters are zero: cleared at create time / by k_publish of the slot's previous frame
 
@@ -742,7 +754,10 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     uint64_t* sp = nullptr;
     // k_emit wrote the pairs in integration order; the stable sort only groups them by voxel (it skips
     // the sequence bits), so every voxel replays its updates in the reference's single-thread order.
-    if ((rc = sort_keys(c, S.d_pairs, c->d_pairs2, n_pairs, std::min(56u, end_bit), &sp, F.seq_bits, /*tail=*/true))) return rc;
+    const int par = (int)(S.frame_no & 1u);
+    uint64_t* const d_pairs2 = c->d_pairs2_[par];
+    unsigned long long* const d_long_list = c->d_long_list_[par];
+    if ((rc = sort_keys(c, S.d_pairs, d_pairs2, n_pairs, std::min(56u, end_bit), &sp, F.seq_bits, /*tail=*/true))) return rc;
     stage_mark(c, set, 8);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
@@ -750,21 +765,24 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     if (time_apply) c->pset[set].applied = true;
     // long runs (voxels next to the sensor) are listed first; then the two update kernels run side by side:
     // k_apply on the tail stream, k_apply_long on its own stream (disjoint voxels)
-    hipLaunchKernelGGL(k_find_long, dim3(ab), dim3(256), 0, st, F.seq_bits, n_pairs, (const uint64_t*)sp, c->d_long_list,
+    hipLaunchKernelGGL(k_find_long, dim3(ab), dim3(256), 0, st, F.seq_bits, n_pairs, (const uint64_t*)sp, d_long_list,
                        S.d_counters);
     hipStream_t sl = c->stream_long ? c->stream_long : st;
     if (sl != st) {
+      // the previous frame's long runs end before any voxel of this frame is touched
+      if (c->pending_join) HIPCHK(c, hipStreamWaitEvent(st, c->pending_join, 0));
+      c->pending_join = nullptr;
       HIPCHK(c, hipEventRecord(S.fork, st));
       HIPCHK(c, hipStreamWaitEvent(sl, S.fork, 0));
     }
 #define KS_LAUNCH_APPLY_M(MODE, MERGED)                                                                              \
   if (time_apply)                                                                                                    \
     hipExtLaunchKernelGGL((k_apply<MODE, MERGED>), dim3(ab), dim3(256), 0, st, c->pset[set].k0, c->pset[set].k1, 0,   \
-                          F, n_pairs, sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut, c->d_long_list,    \
+                          F, n_pairs, sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut, d_long_list,       \
                           S.d_counters);                                                                              \
   else                                                                                                               \
     hipLaunchKernelGGL((k_apply<MODE, MERGED>), dim3(ab), dim3(256), 0, st, F, n_pairs, sp, S.d_rays, S.d_deltas,     \
-                       c->table, c->pool, c->d_label_lut, c->d_long_list, S.d_counters)
+                       c->table, c->pool, c->d_label_lut, d_long_list, S.d_counters)
 #define KS_LAUNCH_APPLY(MODE)                                                                                        \
   if (c->cfg.method == KS_METHOD_MERGED) {                                                                           \
     KS_LAUNCH_APPLY_M(MODE, true);                                                                                   \
@@ -773,7 +791,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   }                                                                                                                  \
   stage_mark(c, set, 9);                                                                                             \
   hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(128), 0, sl, F, n_pairs, sp, S.d_rays, S.d_deltas,             \
-                     c->table, c->pool, c->d_label_lut, c->d_long_list, S.d_counters)
+                     c->table, c->pool, c->d_label_lut, d_long_list, S.d_counters)
     switch (c->cfg.color_mode) {
       case KS_COLOR_MODE_COLOR: KS_LAUNCH_APPLY(KS_COLOR_MODE_COLOR); break;
       case KS_COLOR_MODE_SEMANTIC: KS_LAUNCH_APPLY(KS_COLOR_MODE_SEMANTIC); break;
@@ -783,7 +801,11 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
 #undef KS_LAUNCH_APPLY_M
     if (sl != st) {
       HIPCHK(c, hipEventRecord(S.join, sl));
-      HIPCHK(c, hipStreamWaitEvent(st, S.join, 0));
+      S.join_recorded = true;
+      // deferred: the tail stream goes on with the next frame's tile initialisation, pair sort and long-run
+      // listing (none of which touches voxels or this frame's buffer set) and waits before its k_apply
+      if (c->defer_join && !(set >= 0 && c->pset[set].stages)) c->pending_join = S.join;
+      else HIPCHK(c, hipStreamWaitEvent(st, S.join, 0));
     }
   } else {
     stage_mark(c, set, 7);
@@ -835,6 +857,8 @@ int ensure_exchange(ks_ctx* c, size_t n) {
 int quiesce(ks_ctx* c) {
   const int rc = flush_pending(c);
   if (c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
+  if (c->stream_long) HIPCHK(c, hipStreamSynchronize(c->stream_long));
+  c->pending_join = nullptr;
   if (int rc2 = sync_march(c)) return rc2;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return rc;
@@ -1147,6 +1171,8 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     c->host_prof = hpf && hpf[0] == '1';
     const char* ng = getenv("KS_NO_GRAPH");
     c->use_graphs = !(ng && ng[0] == '1');
+    const char* dj = getenv("KS_NO_DEFER_JOIN");
+    c->defer_join = !(dj && dj[0] == '1');
     const char* es = getenv("KS_EXPORT_STAGED");
     c->export_staged = es && es[0] == '1';
   }
@@ -1277,9 +1303,9 @@ void ks_destroy(ks_ctx* c) {
   if (c->stream_long) (void)hipStreamSynchronize(c->stream_long);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->pool.dirty, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_observed_[3], c->d_color_lut,
-                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list, c->d_blong, c->d_pkeys,
+                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list_[0], c->d_long_list_[1], c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
-                  c->d_pairs2, c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
+                  c->d_pairs2_[0], c->d_pairs2_[1], c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
