@@ -765,7 +765,8 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     if (time_apply) c->pset[set].applied = true;
     // long runs (voxels next to the sensor) are listed first; then the two update kernels run side by side:
     // k_apply on the tail stream, k_apply_long on its own stream (disjoint voxels)
-    hipLaunchKernelGGL(k_find_long, dim3(ab), dim3(256), 0, st, F.seq_bits, n_pairs, (const uint64_t*)sp, d_long_list,
+    hipLaunchKernelGGL(k_find_long, dim3((uint32_t)((n_pairs + 256 * kFindLongItems - 1) / (256 * kFindLongItems))), dim3(256), 0, st,
+                       F.seq_bits, n_pairs, (const uint64_t*)sp, d_long_list,
                        S.d_counters);
     hipStream_t sl = c->stream_long ? c->stream_long : st;
     if (sl != st) {

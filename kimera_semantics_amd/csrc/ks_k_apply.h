@@ -278,18 +278,33 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
 
 // Heads of runs of >= kLongRun updates, found before either apply kernel runs: k_apply (short runs) and
 // k_apply_long (long runs) touch disjoint voxels and are launched side by side on two streams.
+constexpr uint32_t kFindLongItems = 8;  // pairs per thread
 __global__ void __launch_bounds__(256) k_find_long(uint32_t seq_bits, unsigned long long n_pairs,
                                                    const uint64_t* __restrict__ pairs,
                                                    unsigned long long* __restrict__ long_list, Counters* C) {
-  const unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
-  bool is_long = false;
-  if (i < n_pairs) {
-    const uint32_t vox = (uint32_t)(pairs[i] >> seq_bits);
-    const bool head = (i == 0) || ((uint32_t)(pairs[i - 1] >> seq_bits) != vox);
-    is_long = head && (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> seq_bits) == vox);
+  // heads of long runs are more than kLongRun apart: at most 2048 / 33 + 1 of them per workgroup
+  __shared__ unsigned long long s_list[2048 / kLongRun + 2];
+  __shared__ uint32_t s_n, s_base;
+  static_assert(kLongRun >= 32, "s_list size");
+  if (threadIdx.x == 0) s_n = 0u;
+  __syncthreads();
+  const unsigned long long base = (unsigned long long)blockIdx.x * (256ull * kFindLongItems);
+#pragma unroll
+  for (uint32_t k = 0; k < kFindLongItems; ++k) {
+    const unsigned long long i = base + k * 256ull + threadIdx.x;
+    if (i < n_pairs) {
+      const uint32_t vox = (uint32_t)(pairs[i] >> seq_bits);
+      const bool head = (i == 0) || ((uint32_t)(pairs[i - 1] >> seq_bits) != vox);
+      if (head && (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> seq_bits) == vox))
+        s_list[atomicAdd(&s_n, 1u)] = i;
+    }
   }
-  const uint32_t lpos = block_append(is_long, &C->n_long);
-  if (is_long) long_list[lpos] = i;
+  __syncthreads();
+  const uint32_t n_l = s_n;
+  if (n_l == 0u) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&C->n_long, n_l);
+  __syncthreads();
+  if (threadIdx.x < n_l) long_list[s_base + threadIdx.x] = s_list[threadIdx.x];
 }
 
 template <int COLOR_MODE>

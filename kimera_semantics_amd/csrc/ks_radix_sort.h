@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace ksrs {
 
@@ -80,8 +81,10 @@ __global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uin
   }
 }
 
-// One pass.  THREADS x ITEMS keys per tile.
-template <typename K, bool HAS_VALUES, int THREADS, int ITEMS, int RB>
+// One pass.  THREADS x ITEMS keys per tile.  REORDER (keys only, large inputs): the tile's keys are first put in
+// digit order in LDS and leave from there, so that neighbouring lanes write neighbouring addresses (runs of
+// ~tile/256 keys per digit) instead of 8-byte scatters — the direct scatter wrote 2.6x its bytes at 3e7 keys.
+template <typename K, bool HAS_VALUES, int THREADS, int ITEMS, int RB, bool REORDER = false>
 __global__ void __launch_bounds__(THREADS) k_rs_pass(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                                      const uint32_t* __restrict__ vals_in,
                                                      uint32_t* __restrict__ vals_out, uint32_t n, int shift,
@@ -95,6 +98,9 @@ __global__ void __launch_bounds__(THREADS) k_rs_pass(const K* __restrict__ keys_
   __shared__ uint32_t s_off[kBins];          // global offset of this tile's first key of each digit
   __shared__ uint32_t s_chunk[kChunks];      // sums of 64-bin chunks of the pass histogram
   __shared__ uint32_t s_tile;
+  __shared__ K s_keys[REORDER ? kTile : 1];
+  __shared__ uint32_t s_loc[REORDER ? kBins : 1];   // tile-local exclusive prefix of the digit totals
+  static_assert(!REORDER || (!HAS_VALUES && kBins <= THREADS), "reorder variant: keys only");
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   // Tickets order the tiles by arrival so a predecessor is always resident (forward progress of the
   // look-back does not depend on the dispatch order or on what else shares the CUs); the same-address
@@ -136,6 +142,7 @@ __global__ void __launch_bounds__(THREADS) k_rs_pass(const K* __restrict__ keys_
       s_cnt[w][d] = total;
       total += c;
     }
+    if (REORDER) s_loc[d] = total;
     // decoupled look-back over the tiles with smaller index; kWindow predecessor loads are
     // kept in flight.  Tile "-1" reads as an inclusive prefix of zero.
     uint32_t* st = status + d;
@@ -189,6 +196,45 @@ __global__ void __launch_bounds__(THREADS) k_rs_pass(const K* __restrict__ keys_
   }
   __syncthreads();
 
+  if (REORDER) {
+    // exclusive scan of the tile's digit totals (s_loc holds the totals): 64-bin chunks by one wave each
+    __shared__ uint32_t s_lchunk[kChunks];
+    for (int c = wave; c < kChunks; c += kWaves) {
+      const uint32_t tv = s_loc[c * 64 + lane];
+      uint32_t x = tv;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o);
+        if (lane >= (uint32_t)o) x += y;
+      }
+      if (lane == 63) s_lchunk[c] = x;
+      s_loc[c * 64 + lane] = x - tv;
+    }
+    __syncthreads();
+    for (int d = tid; d < kBins; d += THREADS) {
+      uint32_t add = 0;
+      for (int cc = 0; cc < d / 64; ++cc) add += s_lchunk[cc];
+      s_loc[d] += add;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const uint32_t idx = wbase + i * 64 + lane;
+      if (idx < n) {
+        const uint32_t d = rd[i] >> 20;
+        s_keys[s_loc[d] + s_cnt[wave][d] + (rd[i] & 0xfffffu)] = key[i];
+      }
+    }
+    __syncthreads();
+    const uint32_t t0 = tile * (uint32_t)kTile;
+    const uint32_t count = (n - t0 < (uint32_t)kTile) ? n - t0 : (uint32_t)kTile;
+    for (uint32_t j = tid; j < count; j += THREADS) {
+      const K k = s_keys[j];
+      const uint32_t d = digit_of<RB>(k, shift);
+      keys_out[s_off[d] + (j - s_loc[d])] = k;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const uint32_t idx = wbase + i * 64 + lane;
@@ -234,7 +280,7 @@ inline void release(Workspace& w) {
   w = Workspace{};
 }
 
-template <typename K, bool HAS_VALUES, int THREADS, int ITEMS, int RB>
+template <typename K, bool HAS_VALUES, int THREADS, int ITEMS, int RB, bool REORDER = false>
 inline void launch_passes(Workspace& w, K*& kin, K*& kout, uint32_t*& vin, uint32_t*& vout, size_t n, int passes,
                           uint32_t tiles, unsigned begin_bit, hipStream_t stream) {
   constexpr int kBins = 1 << RB;
@@ -243,7 +289,7 @@ inline void launch_passes(Workspace& w, K*& kin, K*& kout, uint32_t*& vin, uint3
   uint32_t* tickets = base + (size_t)kMaxPasses * kMaxBins;
   uint32_t* status = base + kHeadWords;
   for (int p = 0; p < passes; ++p) {
-    hipLaunchKernelGGL((k_rs_pass<K, HAS_VALUES, THREADS, ITEMS, RB>), dim3(tiles), dim3(THREADS), 0, stream, kin, kout,
+    hipLaunchKernelGGL((k_rs_pass<K, HAS_VALUES, THREADS, ITEMS, RB, REORDER>), dim3(tiles), dim3(THREADS), 0, stream, kin, kout,
                        vin, vout, (uint32_t)n, (int)begin_bit + p * RB, hist + (size_t)p * kMaxBins,
                        status + (size_t)p * tiles * kBins, tickets + p);
     K* tk = kin; kin = kout; kout = tk;
@@ -259,7 +305,10 @@ inline hipError_t sort_rb(Workspace& w, K* keys_a, K* keys_b, uint32_t* vals_a, 
   const int passes = (int)((end_bit - begin_bit + RB - 1) / RB);
   // tile size: 2048 keys keeps per-tile latency low for per-frame sizes; larger tiles shorten
   // the look-back chain for million-scale inputs
-  const int tile = (n <= (1u << 20)) ? 2048 : (n <= (1u << 24)) ? 8192 : 16384;
+  // keys-only sorts of more than 2^20 keys (the pair sort of large frames) take the LDS-reordering variant
+  static const bool no_reorder = getenv("KS_RS_NO_REORDER") != nullptr;  // diagnostics
+  const bool reorder = !HAS_VALUES && n > (1u << 20) && !no_reorder;
+  const int tile = (n <= (1u << 20)) ? 2048 : (reorder || n <= (1u << 24)) ? 8192 : 16384;
   const uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
   const size_t words = kHeadWords + (size_t)passes * tiles * kBins;
   hipError_t e = ensure(w, words, stream);
@@ -277,7 +326,9 @@ inline hipError_t sort_rb(Workspace& w, K* keys_a, K* keys_b, uint32_t* vals_a, 
   uint32_t* vin = vals_a;
   uint32_t* vout = vals_b;
   if (tile == 2048) launch_passes<K, HAS_VALUES, 256, 8, RB>(w, kin, kout, vin, vout, n, passes, tiles, begin_bit, stream);
-  else if (tile == 8192) launch_passes<K, HAS_VALUES, 512, 16, RB>(w, kin, kout, vin, vout, n, passes, tiles, begin_bit, stream);
+  else if (tile == 8192 && reorder) {
+    if constexpr (!HAS_VALUES) launch_passes<K, false, 512, 16, RB, true>(w, kin, kout, vin, vout, n, passes, tiles, begin_bit, stream);
+  } else if (tile == 8192) launch_passes<K, HAS_VALUES, 512, 16, RB>(w, kin, kout, vin, vout, n, passes, tiles, begin_bit, stream);
   else launch_passes<K, HAS_VALUES, 512, 32, RB>(w, kin, kout, vin, vout, n, passes, tiles, begin_bit, stream);
   *keys_result = kin;
   if (vals_result) *vals_result = vin;

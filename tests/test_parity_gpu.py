@@ -195,7 +195,8 @@ def test_sorted_integration_order_exact(method):
 
 @pytest.mark.parametrize("dtype,n,end_bit", [(np.uint32, 1, 21), (np.uint32, 2047, 21), (np.uint32, 305619, 21),
                                              (np.uint64, 2049, 64), (np.uint64, 700001, 41), (np.uint64, 3000000, 64),
-                                             (np.uint32, 100000, 32)])
+                                             (np.uint32, 100000, 32), (np.uint64, 1 << 20, 40), (np.uint64, (1 << 20) + 1, 40),
+                                             (np.uint64, 17000001, 33)])
 def test_device_radix_sort_is_correct_and_stable(dtype, n, end_bit):
     rng = np.random.default_rng(n)
     h = B.HipIntegrator(B.default_config(max_tiles=64, max_points=1024, **dict(COMMON, method=0)))
