@@ -75,14 +75,16 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "ks_hip.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(ks_config), sizeof(ks_frame_stats), sizeof(ks_profile),'
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %d\\n", sizeof(ks_config), sizeof(ks_frame_stats), sizeof(ks_profile),'
         ' offsetof(ks_config, label_rgba), offsetof(ks_config, pipeline_frames), offsetof(ks_profile, apply_kernel_ms),'
-        ' offsetof(ks_profile, host_wait_ms)); return 0;}\n')
+        ' offsetof(ks_profile, host_wait_ms), offsetof(ks_config, early_out_phase_growth), sizeof(ks_reduce_stats),'
+        ' sizeof(ks_voxel_run), offsetof(ks_voxel_run, first), KS_VOXEL_RECORD_BYTES); return 0;}\n')
     exe = tmp_path / "sz"
     inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
     subprocess.check_call(["gcc", "-I", inc, "-o", str(exe), str(src)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     want = [ctypes.sizeof(B.KsConfig), ctypes.sizeof(B.KsFrameStats), ctypes.sizeof(B.KsProfile),
             B.KsConfig.label_rgba.offset, B.KsConfig.pipeline_frames.offset, B.KsProfile.apply_kernel_ms.offset,
-            B.KsProfile.host_wait_ms.offset]
+            B.KsProfile.host_wait_ms.offset, B.KsConfig.early_out_phase_growth.offset, ctypes.sizeof(B.KsReduceStats),
+            20, 12, 120]  # ks_voxel_run {int32 block[3]; uint32 first, count}; 16 B header + 12 B TsdfVoxel + 92 B SemanticVoxel
     assert got == want
