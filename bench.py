@@ -338,6 +338,11 @@ def c5_record(B, torch, dist, dev, rank, world):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON record: libraries that print to the C stdout (RCCL's version
+    # banner, flushed at exit) are sent to stderr for the rest of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from kimera_semantics_amd import binding as B
@@ -461,7 +466,7 @@ def main():
                 except Exception as e:   # a secondary record must never take the primary line down
                     sec.append({"config": name, "error": f"{type(e).__name__}: {e}"})
             out["secondary"] = sec
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.destroy_process_group()
 
