@@ -96,7 +96,7 @@ def test_fast_early_out_ordered_phases_variants_exact(variant):
 
 def test_fast_early_out_fidelity_vs_serial_reference():
     """Distance of the ordered-phase schedule from the SERIAL reference order (oracle, one thread).
-    Measured on the CPU restatement (tools/early_out_fidelity.py): touched-set Jaccard 0.976 with doubling
+    Measured on the CPU restatement (tests/early_out_fidelity.py): touched-set Jaccard 0.976 with doubling
     phases (default), 0.987 with growth 1.5, 0.995 with one generation per phase; the reference's own
     1-thread vs 8-thread spread is 0.998."""
     sc = synth.make_scene("room")

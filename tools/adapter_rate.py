@@ -11,14 +11,16 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from kimera_semantics_amd import synth  # noqa: E402
-from oracle import ref_py as R  # noqa: E402  (only its CSV writer)
 
 DEMO = os.path.join(ROOT, "kimera_semantics_amd", "host", "adapter_demo")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 sc = synth.make_scene("room")
 tmp = tempfile.mkdtemp(prefix="ks_adapter_")
 fin, fout, csv = (os.path.join(tmp, x) for x in ("in.bin", "out.bin", "labels.csv"))
-R.write_label_csv(csv, synth.default_label_colors())
+with open(csv, "w") as fh:   # the reference's label CSV format (name,red,green,blue,alpha,id)
+    fh.write("name,red,green,blue,alpha,id\n")
+    for i, (r, g, b, a) in enumerate(synth.default_label_colors()[:21]):
+        fh.write(f"label{i},{int(r)},{int(g)},{int(b)},{int(a)},{i}\n")
 with open(fin, "wb") as fh:
     fh.write(struct.pack("<I", n))
     for k in range(n):
