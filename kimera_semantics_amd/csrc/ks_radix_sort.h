@@ -14,12 +14,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <stdlib.h>
 
 namespace ksrs {
 
 constexpr int kMaxPasses = 8;
 constexpr int kMaxBins = 2048;
+constexpr size_t kHistBlocks = 2048;   // workgroups of the histogram kernel at most
 constexpr uint32_t kFlagLocal = 1u << 30, kFlagPrefix = 2u << 30, kCountMask = (1u << 30) - 1u;
 
 template <int RB, typename K>
@@ -54,7 +56,11 @@ __global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uin
     ((uint4*)zero_ptr)[i] = make_uint4(0u, 0u, 0u, 0u);
   for (int i = tid; i < passes * kBins; i += 256) s_hist[i] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * 2048u;
+  // a workgroup walks several 2048-key slices (grid <= kHistBlocks): the flush below is up to passes x 256
+  // same-address global atomics per workgroup, which at 2e4 workgroups cost more than the pass itself
+  const uint32_t n_slices = (n + 2047u) / 2048u;
+  for (uint32_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
+  const uint32_t base = slice * 2048u;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const uint32_t idx = base + i * 256 + tid;
@@ -73,6 +79,7 @@ __global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uin
         atomicAdd(&s_hist[p * kBins + d], 1u);
       }
     }
+  }
   }
   __syncthreads();
   for (int i = tid; i < passes * kBins; i += 256) {
@@ -314,7 +321,7 @@ inline hipError_t sort_rb(Workspace& w, K* keys_a, K* keys_b, uint32_t* vals_a, 
   hipError_t e = ensure(w, words, stream);
   if (e != hipSuccess) return e;
   const int h = w.cur ^ 1;  // this sort's half is clean; the histogram kernel clears the other one
-  hipLaunchKernelGGL((k_rs_hist<K, RB>), dim3((uint32_t)((n + 2047) / 2048)), dim3(256),
+  hipLaunchKernelGGL((k_rs_hist<K, RB>), dim3((uint32_t)std::min<size_t>((n + 2047) / 2048, kHistBlocks)), dim3(256),
                      (size_t)passes * kBins * sizeof(uint32_t), stream, keys_a, (uint32_t)n, passes, (int)begin_bit,
                      w.d_ws + (size_t)h * w.words, w.d_ws + (size_t)(h ^ 1) * w.words,
                      (uint32_t)((w.dirty[h ^ 1] + 3) & ~(size_t)3));
