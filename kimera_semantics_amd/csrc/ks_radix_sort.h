@@ -60,26 +60,26 @@ __global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uin
   // same-address global atomics per workgroup, which at 2e4 workgroups cost more than the pass itself
   const uint32_t n_slices = (n + 2047u) / 2048u;
   for (uint32_t slice = blockIdx.x; slice < n_slices; slice += gridDim.x) {
-  const uint32_t base = slice * 2048u;
+    const uint32_t base = slice * 2048u;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint32_t idx = base + i * 256 + tid;
-    const bool valid = idx < n;
-    const K key = valid ? keys[idx] : (K)0;
-    const unsigned long long active = __ballot(valid);
-    for (int p = 0; p < passes; ++p) {
-      const uint32_t d = digit_of<RB>(key, begin_bit + p * RB);
-      // the upper digits of these keys are nearly constant: one add for a wave-uniform digit,
-      // per-lane LDS atomics otherwise
-      const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
-      if (__ballot(valid && d != d0) == 0ull) {
-        if (active && lane == (uint32_t)(__ffsll((long long)active) - 1))
-          atomicAdd(&s_hist[p * kBins + d0], (uint32_t)__popcll(active));
-      } else if (valid) {
-        atomicAdd(&s_hist[p * kBins + d], 1u);
+    for (int i = 0; i < 8; ++i) {
+      const uint32_t idx = base + i * 256 + tid;
+      const bool valid = idx < n;
+      const K key = valid ? keys[idx] : (K)0;
+      const unsigned long long active = __ballot(valid);
+      for (int p = 0; p < passes; ++p) {
+        const uint32_t d = digit_of<RB>(key, begin_bit + p * RB);
+        // the upper digits of these keys are nearly constant: one add for a wave-uniform digit,
+        // per-lane LDS atomics otherwise
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+        if (__ballot(valid && d != d0) == 0ull) {
+          if (active && lane == (uint32_t)(__ffsll((long long)active) - 1))
+            atomicAdd(&s_hist[p * kBins + d0], (uint32_t)__popcll(active));
+        } else if (valid) {
+          atomicAdd(&s_hist[p * kBins + d], 1u);
+        }
       }
     }
-  }
   }
   __syncthreads();
   for (int i = tid; i < passes * kBins; i += 256) {
