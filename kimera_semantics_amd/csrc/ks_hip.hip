@@ -1966,6 +1966,8 @@ int ks_clear(ks_ctx* c) {
   for (auto& S : c->slot) S.pending = false;  // a frame that was never applied is dropped with the map
   c->owed = ks_frame_stats{};
   if (c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
+  if (c->stream_long) HIPCHK(c, hipStreamSynchronize(c->stream_long));  // (long runs of the last frame: deferred join)
+  c->pending_join = nullptr;
   if (int rc = sync_march(c)) return rc;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemset(c->table.ent, 0xff, ((size_t)c->table.mask + 1) * sizeof(TileEntry)));
