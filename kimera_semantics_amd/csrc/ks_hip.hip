@@ -10,12 +10,15 @@
 //   stage A  points  : one lane per point — validity, T_G_C * p, start-voxel / end-voxel key  (k_points_*)
 //            sort    : radix sort of point keys (start-voxel dedup slots | end-voxel bundles)   (ks_radix_sort.h)
 //            rays    : exact sequential-equivalent dedup (fast) or per-bundle merge (merged)   (k_dedup / k_bundles)
-//   stage B  march   : one lane per ray — ONE DDA walk: tile allocation in the spatial hash,
-//                      early-out, (voxel, ray seq) pairs staged per wavefront in LDS           (k_march)
+//   stage B  early-out: (fast) ordered phases of k_test + k_mark decide how far every ray gets        (ks_k_march.h)
+//            emit    : scan of the per-position update counts, then every ray writes its (voxel, position)
+//                      pairs at its own offset, allocating tiles in the spatial hash              (k_scan_local, k_emit_lane)
 //            publish : pair / ray / tile counts -> pinned host memory                           (k_publish)
-//   stage T  sort    : radix sort of pairs => every voxel's updates contiguous, in reference order
+//   stage T  sort    : stable radix sort of the pairs on the voxel bits => every voxel's updates contiguous,
+//                      in reference order (the pair list is emitted in integration order)
 //            apply   : 8 lanes per voxel run — sequential TSDF + log-likelihood update, one
-//                      128-byte record read and written once                                    (k_apply, k_apply_long)
+//                      128-byte record read and written once; runs of >= 32 updates get a workgroup each
+//                      on a second stream                                                        (k_find_long, k_apply, k_apply_long)
 // Kernels live in ks_k_rays.h / ks_k_march.h / ks_k_apply.h / ks_k_io.h (types: ks_types.h); this
 // file is the host side: context, frame slots, the three-stream frame pipeline, the C ABI.
 // Ordering contract: per voxel, updates are applied in exactly the order the reference's
@@ -69,15 +72,16 @@ std::string g_create_error;
 // Host side of the C ABI
 // ==========================================================================================
 // Everything a later stage reads from an earlier one lives in a FrameSlot.  With
-// ks_config.pipeline_frames the three stages of a frame run on three streams,
-//   A  points -> sort -> dedup / bundles          (stream)
-//   B  ray march + snapshot                        (stream_march, after A of the same frame)
-//   T  init tiles -> sort pairs -> apply           (stream_tail, enqueued 1 or 2 calls later)
-// so that A(i+1), B(i) and T(i-1) execute concurrently: the march is bound by device-scope atomic
-// throughput, the sorts by dependent-launch latency, the voxel update by memory latency, and
-// neither A nor B touches voxel data.  The host's one wait per frame (for the snapshot that sizes
-// T) never idles the GPU.  Four slots rotate; stage A of a frame waits for the tail that last
-// used its slot.
+// ks_config.pipeline_frames the stages of a frame run on separate streams,
+//   A  points -> sort -> dedup / bundles                  (stream)
+//   B  early-out phases, scan, emission, snapshot          (one of kMarchStreams march streams: frame % 4)
+//   T  init tiles -> sort pairs -> find_long -> apply       (stream_tail; k_apply_long beside it on stream_long),
+//      enqueued by a helper thread 1..4 calls later
+// so that A, B and T of neighbouring frames execute concurrently: B is a chain of small dependent launches
+// (replayed as a graph captured once per slot), the sorts are bound by dependent-launch latency, the voxel
+// update by memory latency, and neither A nor B touches voxel data.  The host's one wait per frame (for the
+// snapshot that sizes T) never idles the GPU.  Six slots rotate; stage A of a frame waits for the tail (and
+// the long runs) that last used its slot.
 constexpr int kSlots = 6;            // frame slots: the tail may lag up to 4 calls (pipeline_frames)
 constexpr int kMarchStreams = 4;
 struct HostSnap {
