@@ -88,16 +88,15 @@ typedef struct ks_config {
                                        KS_ERR_POOL_FULL remains for a single frame that needs more than the free half. */
   uint32_t max_points;              /* largest cloud per call (buffers grow on demand if exceeded) */
   /* 0 (default): an integrate call returns with its frame fully enqueued and its own statistics.
-   * 1 .. 4: frame pipelining for streams of frames (bag replay); the value is how many calls the second
-   *    half of a frame lags behind (the text below describes 1 and 2; 3 or 4 keep the host further ahead,
-   *    so that it never waits for a stage B still running — stage B of up to four frames runs concurrently).  A call enqueues stages A and B of
-   *    its frame (points .. ray march), then finishes the frame 1 or 2 calls back (pair sort + voxel
-   *    update): the one host wait of a frame overlaps GPU work of later frames, and the stages of up
-   *    to three consecutive frames run concurrently on three streams.  With 2 the host never waits
-   *    for a march that is still running (best throughput; one more frame of latency).
+   * 1 .. 4: frame pipelining for streams of frames (bag replay): the value is how many calls the second
+   *    half of a frame (pair sort + voxel update) lags behind.  A call enqueues stages A and B of its frame
+   *    (points .. early-out phases and pair emission) and finishes the frame `pipeline_frames` calls back; the
+   *    one host wait of a frame then overlaps GPU work of later frames, and stage B of up to four
+   *    consecutive frames runs concurrently (one stream each).  Larger values keep the host further ahead
+   *    (best throughput at 4) at the price of that many frames of latency.
    *    The statistics a call returns are those of the frames completed since statistics were last
-   *    returned (summed if several), i.e. they lag by 1 or 2 calls; so do KS_ERR_LABEL_RANGE / pool
-   *    errors.  Every other entry point (queries, download, export, ks_synchronize, ks_flush)
+   *    returned (summed if several), i.e. they lag by `pipeline_frames` calls; so do KS_ERR_LABEL_RANGE /
+   *    pool errors.  Every other entry point (queries, download, export, ks_synchronize, ks_flush)
    *    completes the outstanding frames first, so the map they see is the same as without
    *    pipelining. */
   int32_t pipeline_frames;
@@ -256,7 +255,7 @@ int ks_debug_radix_sort(ks_ctx* ctx, void* keys, uint32_t* vals, size_t n, int k
 
 int ks_synchronize(ks_ctx* ctx);
 void* ks_stream(ks_ctx* ctx); /* the hipStream_t that reads the caller's device inputs (stage A; with
-                                * pipeline_frames later stages run on two further internal streams) */
+                                * pipeline_frames the later stages run on further internal streams) */
 /* Finish the frames a pipelined context still holds (no-op otherwise); stats = theirs, summed. */
 int ks_flush(ks_ctx* ctx, ks_frame_stats* stats);
 /* level 0: off; 1: events around every stage and every k_apply dispatch (costs ~50 us of stream
