@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <list>
@@ -625,8 +626,10 @@ struct ko_ctx {
   static constexpr size_t kMarkFlag = size_t(1) << 40;  // set in every mark the phased schedule stores in the shared set
   static std::vector<uint32_t> phase_bounds(uint32_t n_gen, int growth) {
     std::vector<uint32_t> b{0};
+    // schedule research only (tests/early_out_fidelity.py): KO_EXP_FIRST_PHASE = generations in the first phase
+    static const uint64_t first = getenv("KO_EXP_FIRST_PHASE") ? strtoull(getenv("KO_EXP_FIRST_PHASE"), nullptr, 10) : 1;
     for (;;) {
-      const uint64_t inc = std::max<uint64_t>(1, (uint64_t)b.back() * (uint64_t)(growth - 16) / 16);
+      const uint64_t inc = std::max<uint64_t>(b.back() == 0 ? first : 1, (uint64_t)b.back() * (uint64_t)(growth - 16) / 16);
       if (b.back() + inc >= n_gen) break;
       b.push_back((uint32_t)(b.back() + inc));
     }
