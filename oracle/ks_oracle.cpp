@@ -676,7 +676,9 @@ struct ko_ctx {
         Ray& r = rays[r1];
         const uint32_t chain = r.pos % kChains, gen = r.pos / kChains;
         uint64_t* pv = &priv[(size_t)chain * kPrivSlots];
-        const uint32_t sub = (gen - B[j]) / kSubRun;
+        // (KO_EXP_SUB_RUN: schedule research only — the GPU's sub-runs are kSubRun generations long)
+        static const uint32_t sub_run = getenv("KO_EXP_SUB_RUN") ? (uint32_t)strtoul(getenv("KO_EXP_SUB_RUN"), nullptr, 10) : kSubRun;
+        const uint32_t sub = (gen - B[j]) / sub_run;
         if (sub != priv_sub[chain]) {  // a new sub-run starts with an empty private set
           std::fill(pv, pv + kPrivSlots, 0ull);
           priv_sub[chain] = sub;
