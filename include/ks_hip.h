@@ -41,6 +41,13 @@ enum {
 enum { KS_METHOD_FAST = 0, KS_METHOD_MERGED = 1 };          /* factory names "fast"/"merged", semantic_tsdf_integrator_factory.h:49-54 */
 enum { KS_COLOR_MODE_COLOR = 0, KS_COLOR_MODE_SEMANTIC = 1, KS_COLOR_MODE_SEMANTIC_PROBABILITY = 2 }; /* ColorMode, semantic_integrator_base.h:54-58 */
 enum { KS_ORDER_MIXED = 0, KS_ORDER_SORTED = 1 };           /* voxblox integration_order_mode */
+/* merged: the order the ray bundles are integrated in.
+ * REFERENCE (default): the iteration order of the libstdc++ std::unordered_map the reference keeps them in
+ *   (semantic_tsdf_integrator_merged.cpp:108-124, 200-232; VoxelMap, common.h:37) — what the reference does at
+ *   integrator_threads = 1, reproduced on the GPU from the keys' insertion order, hash codes and the container's
+ *   rehash schedule (csrc/ks_k_bundle_order.h): results are bit-identical to the reference's.
+ * CANONICAL: first-insertion order (a container-independent order; a few launches cheaper per frame). */
+enum { KS_BUNDLE_ORDER_REFERENCE = 0, KS_BUNDLE_ORDER_CANONICAL = 1 };
 
 /* voxblox::TsdfIntegratorBase::Config + kimera SemanticIntegratorBase::SemanticConfig
  * (semantic_integrator_base.h:68-87) + layer geometry + device sizing, as one POD.
@@ -66,7 +73,7 @@ typedef struct ks_config {
   int32_t integration_order_mode;
   int32_t integrator_threads;       /* ignored on the GPU (kept for config compatibility) */
   int32_t method;
-  int32_t bundle_order;             /* ignored: the GPU always integrates bundles in first-insertion order */
+  int32_t bundle_order;             /* KS_BUNDLE_ORDER_* (merged only) */
   float semantic_measurement_probability;
   int32_t color_mode;
   int32_t n_dynamic_labels;

@@ -19,6 +19,7 @@ NUM_LABELS = 21
 KS_METHOD_FAST, KS_METHOD_MERGED = 0, 1
 KS_COLOR_MODE_COLOR, KS_COLOR_MODE_SEMANTIC, KS_COLOR_MODE_SEMANTIC_PROBABILITY = 0, 1, 2
 KS_ORDER_MIXED, KS_ORDER_SORTED = 0, 1
+KS_BUNDLE_ORDER_REFERENCE, KS_BUNDLE_ORDER_CANONICAL = 0, 1
 KS_ERR_LABEL_RANGE, KS_ERR_PROBABILITY, KS_ERR_POOL_FULL, KS_ERR_NO_DEVICE, KS_ERR_UNSUPPORTED = -2, -3, -5, -7, -8
 
 STAGES = ["points", "sort_points", "rays", "march", "emit", "sort_pairs", "apply", "apply_long"]
@@ -77,7 +78,7 @@ class KsProfile(C.Structure):
 def build(force: bool = False) -> str:
     """Compile libks_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("ks_hip.hip", "ks_types.h", "ks_k_rays.h", "ks_k_march.h", "ks_k_apply.h",
+    srcs = [os.path.join(src_dir, f) for f in ("ks_hip.hip", "ks_types.h", "ks_k_rays.h", "ks_k_bundle_order.h", "ks_k_march.h", "ks_k_apply.h",
                                                 "ks_k_io.h", "ks_device_math.h", "ks_radix_sort.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "ks_hip.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(

@@ -46,6 +46,7 @@
 #include <set>
 #include <string>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/ks_hip.h"
@@ -55,6 +56,7 @@
 using namespace ksd;
 
 #include "ks_types.h"
+#include "ks_k_bundle_order.h"
 #include "ks_k_rays.h"
 #include "ks_k_march.h"
 #include "ks_k_apply.h"
@@ -203,6 +205,12 @@ struct ks_ctx {
   bool defer_join = false;               // k_apply_long of frame f overlaps the pair sort of frame f+1 (KS_NO_DEFER_JOIN=1: off)
   hipEvent_t pending_join = nullptr;     // recorded on stream_long; the next k_apply / k_apply_long wait for it
   ksrs::Workspace sort_ws, sort_ws_tail;
+  // merged in the reference's bundle order (ks_k_bundle_order.h): scratch of the rank computation, one slab
+  bool use_bundle_rank = false;
+  BoCtx bo{};
+  BoSchedule bo_sched{};
+  uint8_t* d_bo_slab = nullptr;
+  int bo_epochs = 0;                     // epochs launched per frame (those a cloud of cap_points could reach)
   // scratch of the multi-GPU exchange entry points (slots / group offsets + order / distinct keys)
   uint32_t* d_xchg_u32 = nullptr;
   uint64_t* d_xchg_u64 = nullptr;
@@ -263,6 +271,79 @@ int dev_alloc(ks_ctx* c, T** p, size_t n) {
   return KS_OK;
 }
 
+// Rehash schedule of the host's libstdc++ unordered_map (the container the reference keeps its bundles in,
+// [K:include/kimera_semantics/common.h:37]): probed from a real container, once, up to the element count needed.
+void probe_rehash_schedule(size_t n_max, BoSchedule* out) {
+  static std::mutex mu;
+  static std::vector<uint32_t> t, b;
+  static size_t probed = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  if (probed < n_max) {
+    t.clear();
+    b.clear();
+    std::unordered_map<uint32_t, char> m;
+    size_t bc = m.bucket_count();
+    for (uint32_t i = 0; i < n_max; ++i) {
+      m.emplace(i, 0);
+      if (m.bucket_count() != bc) {  // inserting element i took over a new bucket array
+        bc = m.bucket_count();
+        t.push_back(i);
+        b.push_back((uint32_t)bc);
+      }
+    }
+    probed = n_max;
+  }
+  *out = BoSchedule{};
+  uint32_t off = 0;
+  int e = 0;
+  for (; e < (int)t.size() && e < kBoMaxEpochs && t[e] < n_max; ++e) {
+    out->t[e] = t[e];
+    out->b[e] = b[e];
+    out->head_off[e] = off;
+    off += b[e];
+  }
+  out->n_epochs = (uint32_t)e;
+  out->t[e] = UINT32_MAX;
+}
+
+int ensure_bundle_order(ks_ctx* c, size_t cap) {
+  probe_rehash_schedule(cap, &c->bo_sched);
+  const BoSchedule& S = c->bo_sched;
+  c->bo_epochs = (int)S.n_epochs;
+  size_t heads = 0;
+  for (uint32_t e = 0; e < S.n_epochs; ++e) heads += S.b[e];
+  const size_t nbt = cap / kBoBlock + 2, nfbt = 2 * cap / kBoBlock + 2;
+  auto al = [](size_t words) { return (words * 4 + 255) & ~(size_t)255; };
+  const size_t per_map = 11 * al(cap) + al(nbt) + al(heads);
+  const size_t total = 2 * per_map + al(2) + al((sizeof(BoSchedule) + 3) / 4) + 2 * al(2 * cap) + al(nfbt) + al(cap);
+  if (c->d_bo_slab) (void)hipFree(c->d_bo_slab);
+  c->d_bo_slab = nullptr;
+  HIPCHK(c, hipMalloc((void**)&c->d_bo_slab, total));
+  uint8_t* p = c->d_bo_slab;
+  auto take = [&](size_t words) { uint32_t* r = (uint32_t*)p; p += al(words); return r; };
+  for (int m = 0; m < 2; ++m) {
+    BoMap& M = c->bo.m[m];
+    M.H = take(cap); M.rank = take(cap);
+    M.next[0] = take(cap); M.next[1] = take(cap);
+    M.idj[0] = take(cap); M.idj[1] = take(cap);
+    M.kj[0] = take(cap); M.kj[1] = take(cap);
+    M.lp = take(cap); M.gm = take(cap); M.cj = take(cap);
+    M.bt = take(nbt);
+    M.head = take(heads);
+    HIPCHK(c, hipMemsetAsync(M.head, 0xff, heads * 4, c->stream));  // chains are empty between frames
+  }
+  c->bo.B = take(2);
+  BoSchedule* d_sched = (BoSchedule*)take((sizeof(BoSchedule) + 3) / 4);
+  c->bo.sched = d_sched;
+  c->bo.flag = take(2 * cap);
+  c->bo.flag_lp = take(2 * cap);
+  c->bo.flag_bt = take(nfbt);
+  c->bo.t_of_head = take(cap);
+  HIPCHK(c, hipMemcpyAsync(d_sched, &c->bo_sched, sizeof(BoSchedule), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return KS_OK;
+}
+
 int ensure_points(ks_ctx* c, size_t n) {
   if (n <= c->cap_points) return KS_OK;
   // the create-time size is exact; a cloud that outgrows it gets head-room (growing completes the frames in
@@ -305,6 +386,7 @@ int ensure_points(ks_ctx* c, size_t n) {
     if ((rc = dev_alloc(c, &c->d_ray_keys, cap))) return rc;
     if ((rc = dev_alloc(c, &c->d_blong, cap / kLongRun + 64))) return rc;
   }
+  if (c->use_bundle_rank && (rc = ensure_bundle_order(c, cap))) return rc;
   c->cap_points = cap;
   return KS_OK;
 }
@@ -604,23 +686,39 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
                        S.d_counters);
   } else {
     hipLaunchKernelGGL(k_points_merged, dim3(nb1k), dim3(1024), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       c->d_pkeys, c->d_pvals, S.d_cnt, S.d_counters);
+                       c->d_pkeys, c->d_pvals, S.d_cnt, c->use_bundle_rank ? c->bo.flag : nullptr, S.d_counters);
     stage_mark(c, S.prof_set, 1);
     uint64_t* sk = nullptr;
     uint32_t* sv = nullptr;
     if ((rc = sort_pairs(c, c->d_pkeys, c->d_pkeys2, c->d_pvals, c->d_pvals2, n, 64, &sk, &sv))) return rc;
     stage_mark(c, S.prof_set, 2);
     hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       order_ptr, sk, sv, c->d_gpw, c->d_glc);
+                       order_ptr, sk, sv, c->d_gpw, c->d_glc, c->use_bundle_rank ? c->bo.flag : nullptr);
+    if (c->use_bundle_rank) {
+      // the bundles' ranks in the iteration order of the reference's unordered_map (ks_k_bundle_order.h):
+      // insertion indices, then one walk + link launch per rehash epoch the slot capacity can reach
+      const uint32_t capb = (uint32_t)((c->cap_points + kBoBlock - 1) / kBoBlock);
+      const size_t lds_f = (2 * c->cap_points / kBoBlock + 3) * sizeof(uint32_t), lds_e = ((size_t)capb + 2) * sizeof(uint32_t);
+      hipLaunchKernelGGL(k_bo_scan_flags, dim3((uint32_t)((2 * n + kBoBlock - 1) / kBoBlock)), dim3(kBoBlock), 0, st, (uint32_t)n, c->bo);
+      hipLaunchKernelGGL(k_bo_init, dim3((uint32_t)((n + kBoBlock - 1) / kBoBlock)), dim3(kBoBlock), lds_f, st, (uint32_t)n,
+                         (const uint64_t*)sk, (const uint32_t*)sv, c->bo);
+      const uint32_t nbb = (uint32_t)((n + kBoBlock - 1) / kBoBlock);  // a frame of n points has at most n bundles
+      for (int e = 0; e <= c->bo_epochs; ++e) {
+        if (e > 0 && c->bo_sched.t[e - 1] >= n) break;  // no map of this frame reaches epoch e - 1
+        hipLaunchKernelGGL(k_bo_link, dim3(nbb, 2), dim3(kBoBlock), lds_e, st, c->bo, e);
+        if (e < c->bo_epochs && c->bo_sched.t[e] < n)
+          hipLaunchKernelGGL(k_bo_walk, dim3(nbb, 2), dim3(kBoBlock), 0, st, c->bo, e);
+      }
+    }
     // anti-grazing: the frame keeps its own copy of the keys (the next frame's stage A reuses the sort
     // buffers while this frame's emission — or its repetition after a pair-buffer overflow — may still run)
     uint64_t* ray_keys = cfg.enable_anti_grazing ? S.d_rkeys : nullptr;
     if (cfg.enable_anti_grazing) HIPCHK(c, hipMemcpyAsync(S.d_gkeys, sk, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas,
-                       S.d_ray_list, c->d_blong, ray_keys, S.d_cnt, S.d_counters);
+                       S.d_ray_list, c->d_blong, ray_keys, S.d_cnt, c->bo, c->use_bundle_rank, S.d_counters);
     hipLaunchKernelGGL(k_bundles_long, dim3((uint32_t)std::min<size_t>(n / kLongRun + 1, 2048)), dim3(64), 0, st, F,
                        sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas, S.d_ray_list, c->d_blong, ray_keys, S.d_cnt,
-                       S.d_counters);
+                       c->bo, c->use_bundle_rank, S.d_counters);
     if (cfg.enable_anti_grazing) {
       F.grazing_keys = S.d_gkeys;
       F.ray_keys = S.d_rkeys;
@@ -1115,7 +1213,7 @@ int ks_default_config(ks_config* c) {
   c->integration_order_mode = KS_ORDER_MIXED;
   c->integrator_threads = 1;
   c->method = KS_METHOD_FAST;
-  c->bundle_order = 1;
+  c->bundle_order = KS_BUNDLE_ORDER_REFERENCE;
   c->semantic_measurement_probability = 0.9f;
   c->color_mode = KS_COLOR_MODE_SEMANTIC;
   c->n_dynamic_labels = 0;
@@ -1171,6 +1269,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   c->cfg = *cfg;
   if (c->cfg.early_out_phase_growth == 0) c->cfg.early_out_phase_growth = 32;
   c->uses_early_out = uses_early_out;
+  c->use_bundle_rank = cfg->method == KS_METHOD_MERGED && cfg->bundle_order == KS_BUNDLE_ORDER_REFERENCE;
   {
     const char* hpf = getenv("KS_HOST_PROF");
     c->host_prof = hpf && hpf[0] == '1';
@@ -1311,7 +1410,7 @@ void ks_destroy(ks_ctx* c) {
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list_[0], c->d_long_list_[1], c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_pairs2_[0], c->d_pairs2_[1], c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
-                  c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux};
+                  c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux, c->d_bo_slab};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& S : c->slot)

@@ -1,6 +1,7 @@
 // ks_k_rays.h — stage A kernels: per-point work, start-voxel dedup (fast), bundle merge (merged).
 #pragma once
 #include "ks_types.h"
+#include "ks_k_bundle_order.h"
 
 namespace ksk {
 // ------------------------------------------------------------------------------------------
@@ -130,12 +131,17 @@ __global__ void __launch_bounds__(1024) k_points_merged(FrameParams F, const flo
                                                         const uint8_t* __restrict__ labels,
                                                         const uint8_t* __restrict__ color_lut,
                                                         uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint32_t* __restrict__ cnt, Counters* C) {
+                                                        uint32_t* __restrict__ cnt, uint32_t* __restrict__ bo_flag,
+                                                        Counters* C) {
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   bool counted = false;
   if (idx < F.n) {
-    cnt[idx] = 0u;        // update counts of stage B: normal bundles at their first position,
+    cnt[idx] = 0u;        // update counts of stage B: normal bundles at their integration id,
     cnt[idx + F.n] = 0u;  // clearing bundles n further on (they integrate after all normal ones)
+    if (bo_flag) {        // reference bundle order: first-point marks of this frame's bundles (ks_k_bundle_order.h)
+      bo_flag[idx] = 0u;
+      bo_flag[idx + F.n] = 0u;
+    }
     const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
     uint32_t label;
     if (labels) label = labels[idx];
@@ -174,10 +180,12 @@ __global__ void __launch_bounds__(256) k_gather_sorted(FrameParams F, const floa
                                                        const uint32_t* __restrict__ order,
                                                        const uint64_t* __restrict__ skeys,
                                                        const uint32_t* __restrict__ svals, float4* __restrict__ g_pw,
-                                                       uint2* __restrict__ g_lc) {
+                                                       uint2* __restrict__ g_lc, uint32_t* __restrict__ bo_flag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= F.n) return;
   if (skeys[i] == kEmpty64) return;
+  if (bo_flag && (i == 0 || skeys[i - 1] != skeys[i]))  // a bundle's first point in integration order: its insertion
+    bo_flag[svals[i] + (uint32_t)(skeys[i] >> 63) * F.n] = 1u;
   const uint32_t idx = point_order(F, order, svals[i]);
   const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
   const uint32_t color = rgba ? ((const uint32_t*)rgba)[idx] : 0u;
@@ -227,7 +235,7 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
                                                  const uint2* __restrict__ g_lc, RayDesc* __restrict__ rays,
                                                  float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
                                                  uint32_t* __restrict__ long_list, uint64_t* __restrict__ ray_keys,
-                                                 uint32_t* __restrict__ cnt, Counters* C) {
+                                                 uint32_t* __restrict__ cnt, BoCtx X, bool use_rank, Counters* C) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   bool head = false, is_long = false;
   uint32_t first_p = 0;
@@ -267,7 +275,7 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
       ++j;
     } while (j < F.n && skeys[j] == key);
 
-    first_p = svals[i];
+    first_p = bundle_id(X, use_rank, svals, i, clearing);  // the bundle's integration id
     // priors += L * freq with L[i][j] = (j == 0) ? 0 : (i == j ? log p : log(1-p)), j ascending, no FMA
     // [K:src/semantic_integrator_base.cpp:93-128, 306-307]
     int n_labels = 0, the_label = 0;
@@ -300,7 +308,7 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
                                                      uint32_t* __restrict__ ray_list,
                                                      const uint32_t* __restrict__ long_list,
                                                      uint64_t* __restrict__ ray_keys, uint32_t* __restrict__ cnt,
-                                                     Counters* C) {
+                                                     BoCtx X, bool use_rank, Counters* C) {
   const uint32_t n_long = C->n_long_bundles;
   const int lane = (int)lane_id();
   for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
@@ -367,7 +375,7 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
       base += 64u;
     }
     const f3 mp = {bcast_f(mpc, 0), bcast_f(mpc, 1), bcast_f(mpc, 2)};
-    const uint32_t first_p = svals[start];
+    const uint32_t first_p = bundle_id(X, use_rank, svals, start, clearing);
     const unsigned long long present = __ballot(lane >= 1 && lane < kNumLabels && freq > 0.0f);
     const int n_labels = (int)__popcll(present);
     const int the_label = present ? (63 - __clzll((long long)present)) : 0;

@@ -933,7 +933,7 @@ void ko_default_config(ko_config* c) {
   c->integration_order_mode = KO_ORDER_MIXED;
   c->integrator_threads = 1;
   c->method = KO_METHOD_FAST;
-  c->bundle_order = KO_BUNDLE_ORDER_CANONICAL;
+  c->bundle_order = KO_BUNDLE_ORDER_REFERENCE;
   c->semantic_measurement_probability = 0.9f;  // [K:semantic_integrator_base.h:77]
   c->color_mode = KO_COLOR_MODE_SEMANTIC;      // [K:semantic_integrator_base.h:80]
   c->n_dynamic_labels = 0;

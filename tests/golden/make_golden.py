@@ -22,8 +22,8 @@ CASES = {
     # name: (method, extra config)
     "fast_noearlyout": (0, dict(max_consecutive_ray_collisions=1 << 30)),
     "fast_default": (0, dict()),
-    "merged": (1, dict()),
-    "merged_color_mode": (1, dict(color_mode=0)),
+    "merged": (1, dict(bundle_order=1)),                    # first-insertion bundle order (the container-independent one)
+    "merged_color_mode": (1, dict(color_mode=0, bundle_order=1)),
 }
 GEOM = dict(voxel_size=0.2, voxels_per_side=16, truncation_distance=0.8, max_ray_length_m=5.0,
             semantic_measurement_probability=0.8, dynamic_labels=[20])

@@ -1,7 +1,8 @@
 """Golden digests generated with the REAL reference sources (tests/golden/make_golden_ref.py: oracle/_ref at
 640x480 / 5 cm and at C4 geometry).  CPU tier: the oracle restatement reproduces every one of them bit for
 bit (merged: in the reference's unordered_map bundle order).  GPU tier: the HIP path reproduces the cases
-whose per-voxel update order it replays exactly (`fast` with the early-out disabled)."""
+whose per-voxel update order it replays exactly (`fast` with the early-out disabled; `merged`, whose bundle
+ranks in the container's order are computed on the device)."""
 import os
 
 import numpy as np
@@ -40,7 +41,7 @@ def test_oracle_reproduces_reference_golden(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(n for n in CASES if "noearlyout" in n))
+@pytest.mark.parametrize("name", sorted(n for n in CASES if "noearlyout" in n or "merged" in n))
 def test_hip_reproduces_reference_golden(name):
     from kimera_semantics_amd import binding as B
     _check(B.HipIntegrator(B.default_config(max_tiles=1 << 15, max_points=1 << 19, **_cfg(name))), name)

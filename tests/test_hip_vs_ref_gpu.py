@@ -4,13 +4,11 @@ travels to the GPU box).  No oracle restatement in between.
 
   * fast, early-out disabled, 640x480 and C4 geometry: bit-exact (the per-voxel update order is the
     reference's single-thread order).
-  * merged: the reference integrates bundles in std::unordered_map iteration order
-    (semantic_tsdf_integrator_merged.cpp:200-232), the GPU in first-insertion order.  Voxels crossed by
-    several bundles then accumulate their f32 sums in a different order.  This test MEASURES the gap and
-    asserts the tolerance that actually holds: same blocks, same touched voxels, identical
-    weights (sums of per-bundle constants commute only approximately: rel <= 1e-5), labels identical except
-    on near-ties (<= 1 % of voxels), |delta distance| <= 1e-5 on >= 97 % of voxels and <= 2 * truncation
-    everywhere (a clamp taken in a different order)."""
+  * merged, 640x480 and C4 geometry, several frames: bit-exact.  The reference integrates bundles in
+    std::unordered_map iteration order (semantic_tsdf_integrator_merged.cpp:200-232); the GPU computes every
+    bundle's rank in that order (csrc/ks_k_bundle_order.h) and replays the per-voxel updates in it.
+  * merged in first-insertion order (KS_BUNDLE_ORDER_CANONICAL) against the reference: the gap that the
+    container's order makes is measured and bounded (it is why the reference order is the default)."""
 import numpy as np
 import pytest
 
@@ -63,28 +61,63 @@ def test_fast_no_early_out_bit_exact_vs_real_reference(tmp_path, geom, size):
     assert np.array_equal(rt["color"], ht["color"]) and np.array_equal(rs["color"], hs["color"])
 
 
+def _assert_identical(rt, rs, ht, hs):
+    assert np.array_equal(rs["label"], hs["label"])
+    assert np.array_equal(rs["priors"].view(np.uint32), hs["priors"].view(np.uint32))
+    assert np.array_equal(rt["distance"].view(np.uint32), ht["distance"].view(np.uint32))
+    assert np.array_equal(rt["weight"].view(np.uint32), ht["weight"].view(np.uint32))
+    assert np.array_equal(rt["color"], ht["color"]) and np.array_equal(rs["color"], hs["color"])
+
+
+@pytest.mark.parametrize("geom,size,frames", [(C2, (640, 480), 3), (C4, (320, 180), 2), (C2, (97, 61), 4)])
+def test_merged_bit_exact_vs_real_reference(tmp_path, geom, size, frames):
+    """merged, default configuration: every voxel identical to the real reference sources' result."""
+    r, h = _pair(tmp_path, 1, geom)
+    sc = synth.make_scene("room" if geom is C2 else "hall")
+    for k in range(frames):
+        if geom is C2:
+            f = synth.render_frame(sc, synth.trajectory_pose(5 + 2 * k), size[0], size[1], seed=5 + k)
+        else:
+            f = synth.render_frame(sc, synth.trajectory_pose(3 + k, radius=3.0), size[0], size[1], hfov_deg=75.0, seed=3 + k)
+        r.integrate(f.T_G_C, f.xyz, f.rgba)
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    rt, rs, ht, hs = _maps(r, h)
+    assert int((rt["weight"] > 0).sum()) > (100000 if size[0] > 100 else 1000)
+    _assert_identical(rt, rs, ht, hs)
+
+
+@pytest.mark.parametrize("color_mode", [0, 2])
+def test_merged_colour_modes_bit_exact_vs_real_reference(tmp_path, color_mode):
+    f = _frame(C2, (320, 240))
+    r, h = _pair(tmp_path, 1, C2, color_mode=color_mode)
+    r.integrate(f.T_G_C, f.xyz, f.rgba)
+    # the reference's colour overload never fills hash_colors (semantic_tsdf_integrator_merged.cpp:70,92-93): what it
+    # blends is (0,0,0,0) — the C ABI's rgba == NULL (the adapter passes exactly that)
+    h.integrate(f.T_G_C, f.xyz, None, f.labels)
+    rt, rs, ht, hs = _maps(r, h)
+    if color_mode == 2:  # colours through exp(): a colour LSB may differ on <= 1e-3 of the voxels (DESIGN.md)
+        assert (rt["color"] != ht["color"]).any(axis=-1).mean() <= 1e-3
+        ht["color"] = rt["color"]
+    _assert_identical(rt, rs, ht, hs)
+
+
 @pytest.mark.parametrize("geom,size", [(C2, (640, 480)), (C4, (320, 180))])
-def test_merged_vs_real_reference_order_measured(tmp_path, geom, size, record_property):
+def test_merged_canonical_order_gap_measured(tmp_path, geom, size, record_property):
+    """first-insertion bundle order (opt-in) vs the reference: same voxels, f32 sums in another order."""
     f = _frame(geom, size)
     r, h = _pair(tmp_path, 1, geom)
+    h.close()
+    h = B.HipIntegrator(B.default_config(max_tiles=1 << 15, max_points=1 << 19,
+                                         **dict(COMMON, method=1, bundle_order=B.KS_BUNDLE_ORDER_CANONICAL, **geom)))
     r.integrate(f.T_G_C, f.xyz, f.rgba)
     h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
     rt, rs, ht, hs = _maps(r, h)
     touched_r, touched_h = rt["weight"] > 0, ht["weight"] > 0
     assert np.array_equal(touched_r, touched_h), "touched voxel sets differ"
     n = int(touched_r.sum())
-    assert n > 100000
     dd = np.abs(rt["distance"] - ht["distance"])[touched_r]
-    wrel = (np.abs(rt["weight"] - ht["weight"]) / np.maximum(rt["weight"], 1e-12))[touched_r]
     flips = int((rs["label"] != hs["label"])[touched_r].sum())
-    dpri = np.abs(rs["priors"] - hs["priors"])[touched_r].max()
-    rep = dict(voxels=n, label_flips=flips, label_flip_frac=flips / n, frac_dd_le_1e5=float((dd <= 1e-5).mean()),
-               dd_p999=float(np.quantile(dd, 0.999)), dd_max=float(dd.max()), weight_rel_max=float(wrel.max()),
-               priors_abs_max=float(dpri))
-    record_property("merged_vs_reference_order", rep)
-    print("merged vs real reference (unordered_map order):", rep)
-    assert rep["label_flip_frac"] <= 0.01, rep
-    assert rep["frac_dd_le_1e5"] >= 0.97, rep
-    assert rep["dd_max"] <= 2.0 * geom["truncation_distance"] + 1e-6, rep
-    assert rep["weight_rel_max"] <= 1e-5, rep
-    assert rep["priors_abs_max"] <= 1e-3 * max(1.0, float(np.abs(rs["priors"]).max())), rep
+    rep = dict(voxels=n, label_flips=flips, label_flip_frac=flips / n, frac_dd_le_1e5=float((dd <= 1e-5).mean()), dd_max=float(dd.max()))
+    record_property("merged_canonical_vs_reference_order", rep)
+    print("merged, first-insertion order vs real reference:", rep)
+    assert rep["label_flip_frac"] <= 0.01 and rep["frac_dd_le_1e5"] >= 0.97, rep
