@@ -48,6 +48,7 @@ enum { KS_ORDER_MIXED = 0, KS_ORDER_SORTED = 1 };           /* voxblox integrati
  *   rehash schedule (csrc/ks_k_bundle_order.h): results are bit-identical to the reference's.
  * CANONICAL: first-insertion order (a container-independent order; a few launches cheaper per frame). */
 enum { KS_BUNDLE_ORDER_REFERENCE = 0, KS_BUNDLE_ORDER_CANONICAL = 1 };
+enum { KS_EARLY_OUT_EXACT = 1 };                             /* value of ks_config.early_out_phase_growth, see there */
 
 /* voxblox::TsdfIntegratorBase::Config + kimera SemanticIntegratorBase::SemanticConfig
  * (semantic_integrator_base.h:68-87) + layer geometry + device sizing, as one POD.
@@ -85,7 +86,12 @@ typedef struct ks_config {
    * (restated for the CPU in oracle/ks_oracle.cpp, against which it is bit-exact):
    * integration positions are cut into phases whose length grows by this factor (in 1/16ths) — 32 =
    * doubling (default, also chosen by 0), 16 = one generation of 1024 positions per phase (closest to
-   * the serial order, one pair of kernel launches per generation).  Deterministic for every value. */
+   * the serial order, one pair of kernel launches per generation).  Deterministic for every value.
+   * KS_EARLY_OUT_EXACT: the reference's SERIAL result itself (what integrator_threads = 1 produces, bit for bit,
+   * including the ApproxHashSet's zero-initialised slots that "contain" hash 0): the ordered-phase result is only
+   * the seed of a fix-point iteration over the rays' visited lengths (csrc/ks_k_exact.h; ~10 iterations of
+   * emit marks / sort / re-test per 640x480 frame).  The iteration count is data dependent and read back by the
+   * host, so pipeline_frames is ignored (treated as 0) in this mode. */
   int32_t early_out_phase_growth;
   /* ---- device sizing ---- */
   int32_t device_id;                /* HIP device ordinal */
@@ -269,6 +275,8 @@ int ks_flush(ks_ctx* ctx, ks_frame_stats* stats);
  * bubbles per frame); 2: only the k_apply dispatch of every 4th frame is timed (a few us/frame).
  * Events are resolved lazily, never by a host wait inside a frame. */
 int ks_profile_enable(ks_ctx* ctx, int level);
+/* KS_EARLY_OUT_EXACT contexts: frames integrated and fix-point iterations run so far (either may be NULL). */
+int ks_early_out_iterations(ks_ctx* ctx, uint64_t* frames, uint64_t* iterations);
 int ks_profile_get(ks_ctx* ctx, ks_profile* out, int reset);
 
 #ifdef __cplusplus

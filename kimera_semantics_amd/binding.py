@@ -20,6 +20,7 @@ KS_METHOD_FAST, KS_METHOD_MERGED = 0, 1
 KS_COLOR_MODE_COLOR, KS_COLOR_MODE_SEMANTIC, KS_COLOR_MODE_SEMANTIC_PROBABILITY = 0, 1, 2
 KS_ORDER_MIXED, KS_ORDER_SORTED = 0, 1
 KS_BUNDLE_ORDER_REFERENCE, KS_BUNDLE_ORDER_CANONICAL = 0, 1
+KS_EARLY_OUT_EXACT = 1   # value of KsConfig.early_out_phase_growth: the reference's serial early-out result
 KS_ERR_LABEL_RANGE, KS_ERR_PROBABILITY, KS_ERR_POOL_FULL, KS_ERR_NO_DEVICE, KS_ERR_UNSUPPORTED = -2, -3, -5, -7, -8
 
 STAGES = ["points", "sort_points", "rays", "march", "emit", "sort_pairs", "apply", "apply_long"]
@@ -34,7 +35,7 @@ ABI_SYMBOLS = [
     "ks_integrate_points", "ks_integrate_points_device", "ks_integrate_depth", "ks_integrate_depth_device", "ks_num_blocks", "ks_get_block_indices",
     "ks_get_updated_block_indices", "ks_count_updated_voxels", "ks_download_updated_voxels", "ks_download_blocks", "ks_upload_blocks", "ks_host_alloc", "ks_host_free", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear", "ks_reset_tiles", "ks_tile_owner", "ks_reduce",
     "ks_debug_radix_sort", "ks_synchronize", "ks_flush", "ks_stream",
-    "ks_profile_enable", "ks_profile_get",
+    "ks_profile_enable", "ks_profile_get", "ks_early_out_iterations",
 ]
 
 
@@ -78,7 +79,7 @@ class KsProfile(C.Structure):
 def build(force: bool = False) -> str:
     """Compile libks_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     src_dir = os.path.join(_HERE, "csrc")
-    srcs = [os.path.join(src_dir, f) for f in ("ks_hip.hip", "ks_types.h", "ks_k_rays.h", "ks_k_bundle_order.h", "ks_k_march.h", "ks_k_apply.h",
+    srcs = [os.path.join(src_dir, f) for f in ("ks_hip.hip", "ks_types.h", "ks_k_rays.h", "ks_k_bundle_order.h", "ks_k_march.h", "ks_k_exact.h", "ks_k_apply.h",
                                                 "ks_k_io.h", "ks_device_math.h", "ks_radix_sort.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "ks_hip.h"))
     stale = (not os.path.exists(LIB_PATH)) or any(
@@ -136,6 +137,7 @@ def lib():
         L.ks_stream.restype = vp
         L.ks_profile_enable.argtypes = [vp, C.c_int]
         L.ks_profile_get.argtypes = [vp, C.POINTER(KsProfile), C.c_int]
+        L.ks_early_out_iterations.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -357,6 +359,12 @@ class HipIntegrator:
     def profile_enable(self, level=1):
         """0 off, 1 all stages, 2 sampled k_apply dispatches only (see ks_hip.h)."""
         self._chk(lib().ks_profile_enable(self._h, int(level)))
+
+    def early_out_iterations(self):
+        """(frames, fix-point iterations) of a KS_EARLY_OUT_EXACT context."""
+        f, it = C.c_uint64(), C.c_uint64()
+        self._chk(lib().ks_early_out_iterations(self._h, C.byref(f), C.byref(it)))
+        return f.value, it.value
 
     def flush(self) -> KsFrameStats:
         """Finish the frames a pipelined context still holds; returns their statistics (summed)."""

@@ -59,6 +59,7 @@ using namespace ksd;
 #include "ks_k_bundle_order.h"
 #include "ks_k_rays.h"
 #include "ks_k_march.h"
+#include "ks_k_exact.h"
 #include "ks_k_apply.h"
 #include "ks_k_io.h"
 
@@ -205,6 +206,19 @@ struct ks_ctx {
   bool defer_join = false;               // k_apply_long of frame f overlaps the pair sort of frame f+1 (KS_NO_DEFER_JOIN=1: off)
   hipEvent_t pending_join = nullptr;     // recorded on stream_long; the next k_apply / k_apply_long wait for it
   ksrs::Workspace sort_ws, sort_ws_tail;
+  // fast, early-out in the reference's serial order (ks_k_exact.h): marks (two sets for the sort), slot ranges,
+  // the reference's table content, the scan of the visited lengths, the iteration's counters
+  bool exact_early_out = false;
+  uint64_t* d_eo_keys[2] = {nullptr, nullptr};
+  uint32_t* d_eo_vals[2] = {nullptr, nullptr};
+  size_t cap_marks = 0;
+  uint2* d_eo_range = nullptr;
+  uint64_t* d_eo_plain = nullptr;
+  uint32_t* d_eo_lp = nullptr;
+  unsigned long long* d_eo_bt = nullptr;
+  EoState* d_eo_state = nullptr;
+  EoState* h_eo_state = nullptr;         // pinned
+  uint64_t eo_iterations = 0, eo_frames = 0;  // statistics (ks_exact_early_out_stats)
   // merged in the reference's bundle order (ks_k_bundle_order.h): scratch of the rank computation, one slab
   bool use_bundle_rank = false;
   BoCtx bo{};
@@ -387,6 +401,10 @@ int ensure_points(ks_ctx* c, size_t n) {
     if ((rc = dev_alloc(c, &c->d_blong, cap / kLongRun + 64))) return rc;
   }
   if (c->use_bundle_rank && (rc = ensure_bundle_order(c, cap))) return rc;
+  if (c->exact_early_out) {
+    if ((rc = dev_alloc(c, &c->d_eo_lp, cap))) return rc;
+    if ((rc = dev_alloc(c, &c->d_eo_bt, cap / kScanBlock + 2))) return rc;
+  }
   c->cap_points = cap;
   return KS_OK;
 }
@@ -458,6 +476,11 @@ int reset_set(ks_ctx* c, uint64_t* d_set0, uint64_t* offset, bool observed) {
       } else {
         hipLaunchKernelGGL(k_obs_retag, dim3((1u << kSetBits) / 256), dim3(256), 0, c->stream, d_set);
       }
+    }
+    if (observed && full && c->d_eo_plain) {  // resetApproxSet's full reset of the table the exact mode keeps verbatim
+      HIPCHK(c, hipMemsetAsync(c->d_eo_plain, 0, sizeof(uint64_t) << kSetBits, c->stream));
+      const uint64_t poison = ~0ull;
+      HIPCHK(c, hipMemcpyAsync(c->d_eo_plain, &poison, sizeof(poison), hipMemcpyHostToDevice, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (observed) c->obs_tag = 0;
@@ -540,11 +563,13 @@ void launch_emit(ks_ctx* c, FrameSlot& S, hipStream_t st, Counters* counters) {
 
 // Stage B of the frame in slot S, as a sequence of launches on stream sm (captured into a graph by the
 // caller, or issued directly).  Everything frame-specific comes from S.d_F.
-void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max) {
+// part: 0 = all of it; 1 = the early-out phases only; 2 = everything after them (the exact early-out mode runs its
+// fix-point iteration, with host waits, in between)
+void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max, int part = 0) {
   const ks_config& cfg = c->cfg;
   const size_t n = c->cap_points;  // NOT the frame's point count: see launch_emit
   const FrameParams* dF = S.d_F;
-  if (c->uses_early_out) {
+  if (c->uses_early_out && part != 2) {
     // ordered-phase early-out: per phase, k_test decides how far the phase's rays get against the set as it
     // stood when the phase began, then k_mark enters their marks (ks_k_march.h)
     const uint32_t n_gen = (uint32_t)((n + kChains - 1) / kChains);
@@ -566,6 +591,7 @@ void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max) 
                            S.d_cnt, S.d_counters);
     }
   }
+  if (part == 1) return;
   if (cfg.method == KS_METHOD_MERGED && cfg.enable_anti_grazing)
     hipLaunchKernelGGL(k_count_grazing<16>, dim3((uint32_t)((n + 15) / 16)), dim3(256), 0, sm, dF, S.d_ray_list, S.d_rays,
                        S.d_cnt, S.d_counters);
@@ -575,6 +601,82 @@ void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max) 
   // the frame's only device->host traffic: pair / ray / tile counts and error flags
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sm, S.d_counters, (const uint32_t*)c->table.n_tiles,
                      (uint32_t*)S.h_snap);
+}
+
+// fast, early-out in the reference's serial order: fix-point iteration over the rays' visited lengths, seeded by
+// the ordered-phase result already in S.d_cnt (ks_k_exact.h).  Host waits inside: unpipelined contexts only.
+int ensure_marks(ks_ctx* c, size_t n) {
+  if (n <= c->cap_marks) return KS_OK;
+  const size_t cap = std::max<size_t>(n + n / 4, 1 << 20);
+  int rc;
+  for (int b = 0; b < 2; ++b) {
+    if ((rc = dev_alloc(c, &c->d_eo_keys[b], cap))) return rc;
+    if ((rc = dev_alloc(c, &c->d_eo_vals[b], cap))) return rc;
+  }
+  c->cap_marks = cap;
+  return KS_OK;
+}
+constexpr int kEoMaxIterations = 4096;
+int exact_early_out(ks_ctx* c, FrameSlot& S, hipStream_t st) {
+  const size_t n = S.n;
+  const FrameParams* dF = S.d_F;
+  EoState* hs = c->h_eo_state;
+  HIPCHK(c, hipMemsetAsync(c->d_eo_state, 0, sizeof(EoState), st));
+  hipLaunchKernelGGL(k_eo_total, dim3((uint32_t)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, st, dF,
+                     (const uint32_t*)S.d_cnt, c->d_eo_state);
+  HIPCHK(c, hipMemcpyAsync(hs, c->d_eo_state, sizeof(EoState), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  const uint32_t nb4k = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
+  const size_t lds = (size_t)nb4k * sizeof(unsigned long long);
+  uint64_t* kres = nullptr;
+  uint32_t* vres = nullptr;
+  unsigned long long n_marks = hs->n_marks_next;
+  bool converged = n_marks == 0;
+  int it = 0;
+  for (; !converged && it < kEoMaxIterations; ++it) {
+    int rc;
+    if ((rc = ensure_marks(c, n_marks))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->d_eo_range, 0, sizeof(uint2) << kSetBits, st));
+    hipLaunchKernelGGL(k_eo_scan, dim3(nb4k), dim3(1024), 0, st, dF, (const uint32_t*)S.d_cnt, c->d_eo_lp, c->d_eo_bt, c->d_eo_state);
+    if (S.wide)
+      hipLaunchKernelGGL(k_eo_emit<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), lds, st, dF, S.d_ray_list, S.d_rays, S.d_cnt,
+                         c->d_eo_lp, c->d_eo_bt, c->d_eo_keys[0], c->d_eo_vals[0], (unsigned long long)c->cap_marks, S.d_counters,
+                         c->d_eo_state);
+    else
+      hipLaunchKernelGGL(k_eo_emit<64>, dim3((uint32_t)((n + 255) / 256)), dim3(256), lds, st, dF, S.d_ray_list, S.d_rays, S.d_cnt,
+                         c->d_eo_lp, c->d_eo_bt, c->d_eo_keys[0], c->d_eo_vals[0], (unsigned long long)c->cap_marks, S.d_counters,
+                         c->d_eo_state);
+    // stable sort on the slot bits only: a slot's marks stay in (position, step) order
+    HIPCHK(c, (ksrs::sort<uint64_t, true>(c->sort_ws, c->d_eo_keys[0], c->d_eo_keys[1], c->d_eo_vals[0], c->d_eo_vals[1],
+                                          (size_t)n_marks, 64, st, &kres, &vres, 44)));
+    hipLaunchKernelGGL(k_eo_index, dim3((uint32_t)((n_marks + 255) / 256)), dim3(256), 0, st, n_marks, (const uint64_t*)kres,
+                       c->d_eo_range);
+    EoBuf E{kres, vres, c->d_eo_range, c->d_eo_plain};
+    if (S.wide)
+      hipLaunchKernelGGL(k_eo_eval<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), 0, st, dF, S.d_ray_list, S.d_rays, S.d_cnt, E,
+                         S.d_counters, c->d_eo_state);
+    else
+      hipLaunchKernelGGL(k_eo_eval<16>, dim3((uint32_t)((n + 63) / 64)), dim3(256), 0, st, dF, S.d_ray_list, S.d_rays, S.d_cnt, E,
+                         S.d_counters, c->d_eo_state);
+    HIPCHK(c, hipMemcpyAsync(hs, c->d_eo_state, sizeof(EoState), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (hs->n_marks != n_marks) {
+      c->err = "exact early-out: mark count mismatch";
+      return KS_ERR_HIP;
+    }
+    if (hs->changed == 0) converged = true;  // the marks just sorted are the frame's marks
+    else n_marks = hs->n_marks_next;
+  }
+  if (!converged) {
+    c->err = "exact early-out: no fixed point within the iteration limit";
+    return KS_ERR_UNSUPPORTED;
+  }
+  c->eo_iterations += (uint64_t)it;
+  c->eo_frames += 1;
+  if (n_marks)
+    hipLaunchKernelGGL(k_eo_commit, dim3((uint32_t)((n_marks + 255) / 256)), dim3(256), 0, st, n_marks, (const uint64_t*)kres,
+                       (const uint32_t*)vres, c->d_eo_plain);
+  return KS_OK;
 }
 
 // ---- front half: everything up to the counter snapshot --------------------------------------
@@ -742,7 +844,13 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   {
     const uint64_t key = ((uint64_t)c->cap_points << 24) ^ (c->buffers_epoch << 1) ^ (S.wide ? 1u : 0u);
     bool replayed = false;
-    if (c->use_graphs) {
+    if (c->exact_early_out) {
+      // the ordered phases give the seed; the fix-point iteration (host waits inside) makes it the serial result
+      enqueue_stage_b(c, S, sm, steps_max, 1);
+      if ((rc = exact_early_out(c, S, sm))) return rc;
+      enqueue_stage_b(c, S, sm, steps_max, 2);
+      replayed = true;
+    } else if (c->use_graphs) {
       if (S.b_graph_key != key || !S.b_graph) {
         if (S.b_graph) (void)hipGraphExecDestroy(S.b_graph);
         S.b_graph = nullptr;
@@ -801,8 +909,10 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     // The frame's pairs did not fit the buffer sized from earlier frames: nothing was written and no tile
     // was allocated.  Grow it and repeat the emission (the scan of the counts is still in the slot).
     // Later frames may already have allocated tiles; the emission is a get-or-insert, so that is harmless.
+    // (This runs on the helper thread while the caller may be capturing stage B of another slot on a march
+    // stream: nothing here may touch a march stream.  None has to: S.ready has ordered this slot's stage B, the
+    // tail stream is this thread's own, and no other frame reads this slot's pair buffer.)
     int rc;
-    if ((rc = sync_march(c))) return rc;
     HIPCHK(c, hipStreamSynchronize(st));
     if ((rc = ensure_pairs_in(c, S, (size_t)cnt.n_pairs + (size_t)cnt.n_pairs / 4))) return rc;
     Counters rcnt{};
@@ -848,6 +958,12 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     return KS_ERR_INDEX_RANGE;
   }
   const unsigned long long n_pairs = cnt.n_pairs;
+  if (n_pairs == 0 && c->pending_join) {
+    // a frame without updates still separates the frame before it from the one after it, which share a parity
+    // buffer set: the long runs of the previous frame end before anything later is enqueued on the tail stream
+    HIPCHK(c, hipStreamWaitEvent(st, c->pending_join, 0));
+    c->pending_join = nullptr;
+  }
   if (n_pairs > 0) {
     int rc;
     if ((rc = ensure_pairs_out(c, n_pairs))) return rc;
@@ -1249,8 +1365,9 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     g_create_error = "log(p) must exceed log(1-p)";
     return KS_ERR_PROBABILITY;
   }
-  if (cfg->early_out_phase_growth != 0 && (cfg->early_out_phase_growth < 16 || cfg->early_out_phase_growth > 4096)) {
-    g_create_error = "early_out_phase_growth must be 0 (default: 32 = doubling phases) or 16..4096 (in 1/16ths)";
+  if (cfg->early_out_phase_growth != 0 && cfg->early_out_phase_growth != KS_EARLY_OUT_EXACT &&
+      (cfg->early_out_phase_growth < 16 || cfg->early_out_phase_growth > 4096)) {
+    g_create_error = "early_out_phase_growth must be 0 (default: 32 = doubling phases), KS_EARLY_OUT_EXACT, or 16..4096 (in 1/16ths)";
     return KS_ERR_INVALID_ARG;
   }
   // the early-out can never fire if the threshold exceeds the longest possible ray
@@ -1267,7 +1384,9 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   }
   ks_ctx* c = new ks_ctx();
   c->cfg = *cfg;
-  if (c->cfg.early_out_phase_growth == 0) c->cfg.early_out_phase_growth = 32;
+  c->exact_early_out = uses_early_out && cfg->early_out_phase_growth == KS_EARLY_OUT_EXACT;
+  if (c->cfg.early_out_phase_growth == 0 || c->exact_early_out) c->cfg.early_out_phase_growth = 32;  // (exact: the seed's schedule)
+  if (c->exact_early_out) c->cfg.pipeline_frames = 0;  // the fix-point iteration waits for the device: one frame at a time
   c->uses_early_out = uses_early_out;
   c->use_bundle_rank = cfg->method == KS_METHOD_MERGED && cfg->bundle_order == KS_BUNDLE_ORDER_REFERENCE;
   {
@@ -1300,7 +1419,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     if (nl && nl[0] == '1') c->stream_long = nullptr;
     else CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
   }
-  if (cfg->pipeline_frames) {
+  if (c->cfg.pipeline_frames) {
     c->n_march = kMarchStreams;
     if (const char* ms = getenv("KS_MARCH_STREAMS")) c->n_march = std::min(kMarchStreams, std::max(1, atoi(ms)));  // diagnostics
     {
@@ -1353,6 +1472,14 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   const uint64_t poison = ~0ull;  // ApproxHashSet ctor: slot[offset_=0] = SIZE_MAX
   CRCHK(hipMemcpy(c->d_start_set, &poison, 8, hipMemcpyHostToDevice));
   CRCHK(hipMalloc((void**)&c->d_retry_counters, sizeof(Counters)));
+  if (c->exact_early_out) {
+    CRCHK(hipMalloc((void**)&c->d_eo_range, sizeof(uint2) << kSetBits));
+    CRCHK(hipMalloc((void**)&c->d_eo_plain, sizeof(uint64_t) << kSetBits));
+    CRCHK(hipMemset(c->d_eo_plain, 0, sizeof(uint64_t) << kSetBits));
+    CRCHK(hipMemcpy(c->d_eo_plain, &poison, 8, hipMemcpyHostToDevice));  // ApproxHashSet ctor: slot[0] = SIZE_MAX
+    CRCHK(hipMalloc((void**)&c->d_eo_state, sizeof(EoState)));
+    CRCHK(hipHostMalloc((void**)&c->h_eo_state, sizeof(EoState)));
+  }
   CRCHK(hipMalloc((void**)&c->d_label_lut, 256 * sizeof(uint32_t)));
   CRCHK(hipMemcpy(c->d_label_lut, cfg->label_rgba, 1024, hipMemcpyHostToDevice));
   static_assert(sizeof(Counters) == 32, "snapshot layout");
@@ -1373,6 +1500,9 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     CRCHK(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
   }
 #undef CRCHK
+  // pair buffers start at 4 updates per point of the largest cloud (a frame that needs more grows its buffer and
+  // repeats the emission once)
+  c->pairs_hint = (size_t)cfg->max_points * 4;
   if (ensure_points(c, cfg->max_points) != KS_OK) {
     g_create_error = c->err;
     ks_destroy(c);
@@ -1380,7 +1510,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   }
   {
     const char* nt = getenv("KS_NO_TAIL_THREAD");
-    c->use_tail_thread = cfg->pipeline_frames > 0 && !(nt && nt[0] == '1');
+    c->use_tail_thread = c->cfg.pipeline_frames > 0 && !(nt && nt[0] == '1');
     if (c->use_tail_thread) c->tail_thread = std::thread(tail_worker, c);
   }
   *out = c;
@@ -1410,13 +1540,16 @@ void ks_destroy(ks_ctx* c) {
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list_[0], c->d_long_list_[1], c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_pairs2_[0], c->d_pairs2_[1], c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
-                  c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux, c->d_bo_slab};
+                  c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux, c->d_bo_slab,
+                  c->d_eo_keys[0], c->d_eo_keys[1], c->d_eo_vals[0], c->d_eo_vals[1], c->d_eo_range, c->d_eo_plain, c->d_eo_lp, c->d_eo_bt,
+                  c->d_eo_state};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& S : c->slot)
     for (void* p : {(void*)S.d_rays, (void*)S.d_deltas, (void*)S.d_ray_list, (void*)S.d_pairs, (void*)S.d_cnt, (void*)S.d_lp,
                     (void*)S.d_bt, (void*)S.d_live, (void*)S.d_F, (void*)S.d_gkeys, (void*)S.d_rkeys})
       if (p) (void)hipFree(p);
+  if (c->h_eo_state) (void)hipHostFree(c->h_eo_state);
   ksrs::release(c->sort_ws);
   ksrs::release(c->sort_ws_tail);
   for (auto& S : c->slot) {
@@ -2085,11 +2218,17 @@ int ks_clear(ks_ctx* c) {
   }
   const uint64_t poison = ~0ull;
   HIPCHK(c, hipMemcpy(c->d_start_set, &poison, 8, hipMemcpyHostToDevice));
+  if (c->d_eo_plain) {
+    HIPCHK(c, hipMemset(c->d_eo_plain, 0, sizeof(uint64_t) << kSetBits));
+    HIPCHK(c, hipMemcpy(c->d_eo_plain, &poison, 8, hipMemcpyHostToDevice));
+  }
   c->start_offset = c->observed_offset = 0;
   c->reset_counter = 0;
   c->obs_tag = 0;
   c->obs_tag_lo = 1;
   c->tiles_initialised = 0;
+  for (auto& S : c->slot)
+    if (S.h_snap) std::memset(S.h_snap, 0, sizeof(HostSnap));  // (the pool-growth trigger reads the snapshots' tile counts)
   c->fatal = false;
   return KS_OK;
 }
@@ -2120,6 +2259,13 @@ int ks_debug_test_stats(unsigned long long* out16) {
   return KS_OK;
 }
 #endif
+
+int ks_early_out_iterations(ks_ctx* c, uint64_t* frames, uint64_t* iterations) {
+  if (!c) return KS_ERR_INVALID_ARG;
+  if (frames) *frames = c->eo_frames;
+  if (iterations) *iterations = c->eo_iterations;
+  return KS_OK;
+}
 
 int ks_profile_enable(ks_ctx* c, int level) {
   if (!c || level < 0 || level > 2) return KS_ERR_INVALID_ARG;
