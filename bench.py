@@ -8,22 +8,32 @@ parameters (5 cm voxels, 5 m rays, truncation 4 voxels, early-out after 2 consec
 already-observed voxels, p=0.8, dynamic label 20).  One step = one frame integrated into
 the GPU-resident map through the C ABI, inputs already resident in HBM.
 
+Timing.  Every context first integrates PRIME untimed frames (one per frame slot and pipeline stage: per-slot
+graph capture and buffer growth happen there), then the W warm-up steps, then R >= 5 timed regions of EXACTLY K
+steps each, every region bracketed by barrier + synchronize; the line reports the MEDIAN region (value,
+ms_per_step) and the spread over the regions.
+
 Prints ONE JSON line (rank 0).
   value = voxel updates/s over the whole job, where a voxel update is one (ray, voxel) pair for which
           the reference runs updateTsdfVoxel + updateSemanticVoxel (semantic_tsdf_integrator_fast.cpp:128-140)
           and N_updates is the count the SERIAL REFERENCE ORDER (CPU oracle, one thread) gives for the timed
-          frames — the GPU's own count (it runs the deterministic ordered-phase schedule,
-          ~10 % more updates) is reported next to it as gpu_counted_value.
+          frames; whenever the GPU performs FEWER updates than that, the GPU's own count is
+          credited instead (no credit for skipped work).  gpu_counted_value is always the GPU's own count.
   roofline = the whole frame against the HBM roofline (lead figure), every stage's share of the frame, and
-          the per-voxel update kernel (k_apply) on its own, all from HIP events of this run.
-  secondary = the same measurement for C3 (`merged`) and C4 (1280x720, 2 cm, 10 m; `fast` and `merged`),
-          so that the driver — not the builder — produces those numbers (N = 1 only).
+          the per-voxel update kernel (k_apply) on its own, all from HIP events of this run; traffic = HBM
+          bytes per k_apply launch from the committed PMC pass of this same command (profiles/), or null.
+  early_out_fidelity = touched-voxel Jaccard / label agreement of the benched schedule against the serial
+          reference order, MEASURED in this run on the first timed frames (outside the timed regions).
+  secondary = the same measurement for the exact-serial early-out mode (C2-exact), C3 (`merged`, reference
+          bundle order), C4 (1280x720, 2 cm, 10 m; `fast` and `merged`), the host-pointer entry (H2D inside the
+          call: SURVEY.md §8d's frames/s) and the unmodified-server adapter path (N = 1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,6 +43,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_UPDATE = 208         # R+W of TsdfVoxel (12 B) + SemanticVoxel (92 B), SURVEY.md §8d
 BYTES_PER_POINT = 17           # xyz 12 B + rgba 4 B + label 1 B
+PRIME = 10                     # untimed frames per context before the warm-up: kSlots (6) + pipeline_frames (4)
+MIN_REPEATS = 5
+MIN_TIMED_FRAMES = 100
+MAX_DISTINCT_FRAMES = 96       # the trajectory is replayed cyclically beyond this many frames
 try:
     METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
 except Exception:
@@ -49,14 +63,15 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--method", default="fast", choices=["fast", "merged"])
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=12)
-    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 sub-records")
+    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--no-secondary", action="store_true", help="skip the sub-records")
+    ap.add_argument("--only-secondary", default="", help="comma list of sub-records to run (default: all)")
     ap.add_argument("--no-oracle-count", action="store_true",
                     help="value falls back to the GPU's own update count (marked in the output)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -64,18 +79,16 @@ def parse():
     return ap.parse_args()
 
 
-def integ_cfg(wl, method=None):
+def integ_cfg(wl, method=None, **extra):
     from kimera_semantics_amd import synth
     method = method or wl["method"]
-    return dict(method=0 if method == "fast" else 1, voxel_size=wl["voxel"], voxels_per_side=16,
-                truncation_distance=4 * wl["voxel"], max_ray_length_m=wl["max_ray"], semantic_measurement_probability=0.8,
-                dynamic_labels=[20], label_rgba=synth.default_label_colors(),
-                # experiments only (the default, 0, is the library's default schedule)
-                early_out_phase_growth=int(os.environ.get("KS_BENCH_GROWTH", "0")))
-
-
-def common_cfg(method):
-    return integ_cfg(WORKLOADS["C2"], method)
+    kw = dict(method=0 if method == "fast" else 1, voxel_size=wl["voxel"], voxels_per_side=16,
+              truncation_distance=4 * wl["voxel"], max_ray_length_m=wl["max_ray"], semantic_measurement_probability=0.8,
+              dynamic_labels=[20], label_rgba=synth.default_label_colors(),
+              # experiments only (the default, 0, is the library's default schedule)
+              early_out_phase_growth=int(os.environ.get("KS_BENCH_GROWTH", "0")))
+    kw.update(extra)
+    return kw
 
 
 def make_frames(wl, indices):
@@ -88,146 +101,246 @@ def make_frames(wl, indices):
 def oracle_counts(wl, frames):
     """Voxel updates per frame in the SERIAL REFERENCE ORDER (CPU oracle, one thread, reference defaults).
     Neither integrator's update count depends on the map, and `fast`'s early-out sets are per frame, so the
-    counts of the timed frames do not need the warm-up frames."""
+    counts of the timed frames do not need the frames before them."""
     from oracle import oracle_py as O
-    o = O.Oracle(O.default_config(integrator_threads=1, **integ_cfg(wl)))
+    o = O.Oracle(O.default_config(integrator_threads=1, **integ_cfg(wl, early_out_phase_growth=0)))
     out = [int(o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates) for f in frames]
     o.close()
     return out
 
 
+def median_spread(xs):
+    med = statistics.median(xs)
+    return med, (max(xs) - min(xs)) / med if med else 0.0
+
+
 def cpu_baseline(args, wl, frames, upd_serial):
-    """CPU baseline on this host's cores, on a bounded sample of the same workload.
-    kind "reference": oracle/_ref/libks_ref.so = the REAL Kimera-Semantics integrator sources
-    compiled (in the build container) against the Voxblox header shims; it has no update counter,
-    so its voxel-update count is the one the bit-identical port (oracle/) reports for the same
-    frames in single-thread order.  kind "port" (the oracle itself) when the prebuilt library is
-    not there.  The reference defaults to integrator_threads = hardware_concurrency(); on many-core
-    hosts its per-voxel mutexes make that slower than a few threads, so several thread counts are
-    tried and the best one is the reported baseline."""
+    """CPU baseline on this host's cores, on a bounded sample of the same workload: for every thread count one
+    warm-up pass and 5 timed passes over the sample (a fresh integrator each), median reported.
+    kind "reference": oracle/_ref/libks_ref.so = the REAL Kimera-Semantics integrator sources compiled (in the
+    build container) against the Voxblox header shims; it has no update counter, so its voxel-update count is the
+    one the bit-identical port (oracle/) reports for the same frames in single-thread order.  kind "port" (the
+    oracle itself) when the prebuilt library is not there.  The reference defaults to integrator_threads =
+    hardware_concurrency(); on many-core hosts its per-voxel mutexes make that slower than a few threads, so
+    several thread counts are tried and the best one is the reported baseline."""
     import tempfile
     from oracle import oracle_py as O
     from oracle import ref_py as R
     from kimera_semantics_amd import synth
     cores = os.cpu_count() or 1
     n = min(args.cpu_frames, len(frames))
+    sample, upd = frames[:n], sum(upd_serial[:n])
     thread_counts = sorted({1, min(8, cores), cores})
-    port = {}
-    for threads in thread_counts:
-        nf = n if threads > 1 else max(1, n // 2)
-        o = O.Oracle(O.default_config(integrator_threads=threads, **integ_cfg(wl)))
-        upd = 0
-        t0 = time.perf_counter()
-        for f in frames[:nf]:
-            upd += o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
-        dt = time.perf_counter() - t0
-        port[threads] = (upd / dt / 1e6, nf / dt, nf)
-        o.close()
-    kind, tried = "port", port
+    passes = 1 + 5
+
+    def timed(make, run):
+        ts = []
+        for p in range(passes):
+            inst = make()
+            t0 = time.perf_counter()
+            for f in sample:
+                run(inst, f)
+            ts.append(time.perf_counter() - t0)
+            inst.close()
+        return statistics.median(ts[1:]), (max(ts[1:]) - min(ts[1:])) / statistics.median(ts[1:])
+
+    kind, tried = "port", {}
     if R.available():
         try:
             tmp = tempfile.mkdtemp(prefix="ks_bench_")
             csv = os.path.join(tmp, "labels.csv")
             R.write_label_csv(csv, synth.default_label_colors())
-            ref = {}
             for threads in thread_counts:
-                nf = n if threads > 1 else max(1, n // 2)
-                r = R.Reference(wl["method"], csv, voxel_size=wl["voxel"], vps=16, truncation=4 * wl["voxel"],
-                                max_ray=wl["max_ray"], p_match=0.8, color_mode=1, dynamic_labels=(20,), threads=threads)
-                t0 = time.perf_counter()
-                for f in frames[:nf]:
-                    r.integrate(f.T_G_C, f.xyz, f.rgba)
-                dt = time.perf_counter() - t0
-                ref[threads] = (sum(upd_serial[:nf]) / dt / 1e6, nf / dt, nf)
-                r.close()
-            kind, tried = "reference", ref
+                dt, spread = timed(lambda: R.Reference(wl["method"], csv, voxel_size=wl["voxel"], vps=16, truncation=4 * wl["voxel"],
+                                                       max_ray=wl["max_ray"], p_match=0.8, color_mode=1, dynamic_labels=(20,), threads=threads),
+                                   lambda r, f: r.integrate(f.T_G_C, f.xyz, f.rgba))
+                tried[threads] = (upd / dt / 1e6, n / dt, spread)
+            kind = "reference"
         except Exception as e:  # a stale or missing prebuilt library must not take the bench down
             sys.stderr.write(f"cpu_baseline: reference library unusable ({e}); using the port\n")
+            tried = {}
+    if not tried:
+        for threads in thread_counts:
+            dt, spread = timed(lambda: O.Oracle(O.default_config(integrator_threads=threads, **integ_cfg(wl, early_out_phase_growth=0))),
+                               lambda o, f: o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels))
+            tried[threads] = (upd / dt / 1e6, n / dt, spread)
     best = max(tried, key=lambda t: tried[t][0])
     what = ("the real Kimera-Semantics integrator sources (oracle/_ref, Voxblox half restated)" if kind == "reference"
             else "the CPU oracle (restatement, bit-identical to the real reference sources for the Kimera half)")
     return {"value": round(tried[best][0], 4), "unit": "Mvoxel-updates/s", "cores": best, "kind": kind,
-            "frames_per_s": round(tried[best][1], 3), "host_cores": cores,
+            "frames_per_s": round(tried[best][1], 3), "host_cores": cores, "spread": round(tried[best][2], 4),
             "by_threads": {str(t): round(v[0], 4) for t, v in tried.items()},
-            "port_by_threads": {str(t): round(v[0], 4) for t, v in port.items()},
-            "sample": f"first {tried[best][2]} timed frames of the same trajectory through {what}, "
-                      f"'mixed' order, reference defaults; best of integrator_threads in {sorted(tried)}"
+            "sample": f"first {n} timed frames of the same trajectory through {what}, 'mixed' order, reference defaults; "
+                      f"per thread count 1 warm-up + 5 timed passes (fresh integrator each), median; best of "
+                      f"integrator_threads in {sorted(tried)}"
                       + ("; updates counted by the port in single-thread order" if kind == "reference" else "")}
 
 
-def measure(B, torch, dist, dev, wl, frames, W, K, pipeline, max_tiles, world, reduce_fn=None):
-    """Integrates frames[0 : W + K] as a stream; times the last K of them (barrier + synchronize on both
-    sides).  Returns wall time, the GPU's statistics over EXACTLY the timed frames, and the HIP-event profiles."""
-    cfg = B.default_config(device_id=dev.index or 0, max_tiles=max_tiles, max_points=max(f.xyz.shape[0] for f in frames),
-                           pipeline_frames=pipeline, **integ_cfg(wl))
+class FrameRing:
+    """frames[i] for any i: the distinct frames replayed cyclically (device copies made once)."""
+
+    def __init__(self, frames, torch=None, dev=None):
+        self.frames = frames
+        self.dev_frames = None
+        if torch is not None:
+            self.dev_frames = [(torch.from_numpy(f.xyz).to(dev), torch.from_numpy(f.rgba).to(dev), torch.from_numpy(f.labels).to(dev))
+                               for f in frames]
+
+    def __len__(self):
+        return len(self.frames)
+
+    def host(self, i):
+        return self.frames[i % len(self.frames)]
+
+    def dev(self, i):
+        return self.dev_frames[i % len(self.frames)]
+
+
+def measure(B, torch, dist, dev, wl, ring, W, K, R, pipeline, max_tiles, world, reduce_fn=None, entry="device", **cfg_extra):
+    """Integrates the ring as a stream: PRIME + W untimed frames, then R regions of K timed frames.  Returns the
+    regions' wall times, the GPU's statistics per region (checked to cover EXACTLY its frames), HIP-event profiles."""
+    cfg = B.default_config(device_id=dev.index or 0, max_tiles=max_tiles, max_points=max(f.xyz.shape[0] for f in ring.frames),
+                           pipeline_frames=pipeline, **integ_cfg(wl, **cfg_extra))
     integ = B.HipIntegrator(cfg)
-    d_frames = [(torch.from_numpy(f.xyz).to(dev), torch.from_numpy(f.rgba).to(dev), torch.from_numpy(f.labels).to(dev))
-                for f in frames]
+    pinned = None
+    if entry == "host":
+        # page-locked host buffers (ks_host_alloc), one set per distinct frame: the call itself moves them (H2D inside)
+        import ctypes
+        import numpy as np
+        pinned = []
+        for f in ring.frames:
+            n = f.xyz.shape[0]
+            bufs = []
+            for arr in (f.xyz, f.rgba, f.labels):
+                p = B.lib().ks_host_alloc(arr.nbytes)
+                v = np.frombuffer((ctypes.c_uint8 * arr.nbytes).from_address(p), dtype=arr.dtype).reshape(arr.shape)
+                v[...] = arr
+                bufs.append((p, v))
+            pinned.append((n, bufs))
 
     def step(i):
-        x, c, l = d_frames[i]
-        return integ.integrate_device(frames[i].T_G_C, x.data_ptr(), c.data_ptr(), l.data_ptr(), x.shape[0])
+        if entry == "host":
+            f = ring.host(i)
+            n, bufs = pinned[i % len(ring)]
+            return integ.integrate(f.T_G_C, bufs[0][1], bufs[1][1], bufs[2][1])
+        x, c, l = ring.dev(i)
+        return integ.integrate_device(ring.host(i).T_G_C, x.data_ptr(), c.data_ptr(), l.data_ptr(), x.shape[0])
 
-    for i in range(W):
+    for i in range(PRIME + W):
         step(i)
-    integ.flush()             # completes the warm-up frames AND hands their statistics over (discarded):
+    integ.flush()             # completes the untimed frames AND hands their statistics over (discarded):
     integ.synchronize()       # nothing is pending or owed at t0
     # level 2: only the k_apply dispatch of every 4th frame carries HIP events (per-stage events
     # would put stream bubbles into every timed frame)
     integ.profile_enable(2)
     integ.profile(reset=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    updates = points = rays = 0
-    for i in range(W, W + K):
-        st = step(i)          # pipelined: statistics of the frame(s) completed by this call
+    regions = []
+    base = PRIME + W
+    for r in range(R):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        updates = points = rays = 0
+        for i in range(base + r * K, base + (r + 1) * K):
+            st = step(i)          # pipelined: statistics of the frame(s) completed by this call
+            updates += st.n_voxel_updates
+            points += st.n_points
+            rays += st.n_rays_cast
+        st = integ.flush()        # the tails of the last frames, inside the timed region
         updates += st.n_voxel_updates
         points += st.n_points
         rays += st.n_rays_cast
-    st = integ.flush()        # the tails of the last frames, inside the timed region
-    updates += st.n_voxel_updates
-    points += st.n_points
-    rays += st.n_rays_cast
-    integ.synchronize()
-    reduce_stats = reduce_fn(integ) if reduce_fn else None
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+        integ.synchronize()
+        reduce_stats = reduce_fn(integ) if reduce_fn else None
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        want_points = sum(int(ring.host(i).xyz.shape[0]) for i in range(base + r * K, base + (r + 1) * K))
+        assert points == want_points, f"statistics cover {points} points, the timed frames hold {want_points}"
+        regions.append(dict(dt=dt, updates=updates, points=points, rays=rays, reduce=reduce_stats,
+                            frames=list(range(base + r * K, base + (r + 1) * K))))
     prof = integ.profile(reset=True)
-    want_points = sum(int(f.xyz.shape[0]) for f in frames[W:W + K])
-    assert points == want_points, f"statistics cover {points} points, the timed frames hold {want_points}"
-    # per-stage breakdown: separate untimed pass over the last frames with events around every stage
+    # per-stage breakdown: separate untimed pass over a few frames with events around every stage
     integ.profile_enable(1)
-    for i in range(max(W, W + K - 10), W + K):
+    for i in range(base, base + min(10, K)):
         step(i)
     integ.flush()
     stage_prof = integ.profile()
     integ.profile_enable(0)
     n_tiles = len(integ.tile_keys())
+    eo = integ.early_out_iterations()
     integ.close()
-    del d_frames
-    return dict(dt=dt, updates=updates, points=points, rays=rays, prof=prof, stage_prof=stage_prof, reduce=reduce_stats,
-                tiles=n_tiles)
+    if pinned:
+        for _, bufs in pinned:
+            for p, v in bufs:
+                del v
+                B.lib().ks_host_free(p)
+    return dict(regions=regions, prof=prof, stage_prof=stage_prof, tiles=n_tiles, early_out_iterations=eo)
 
 
-def gpu_counts(B, torch, dev, wl, frames, max_tiles):
+def gpu_counts(B, dev, wl, frames, max_tiles, **cfg_extra):
     """The GPU's own per-frame update counts for a few frames (unpipelined; for the oracle/GPU ratio)."""
     cfg = B.default_config(device_id=dev.index or 0, max_tiles=max_tiles, max_points=max(f.xyz.shape[0] for f in frames),
-                           pipeline_frames=0, **integ_cfg(wl))
+                           pipeline_frames=0, **integ_cfg(wl, **cfg_extra))
     integ = B.HipIntegrator(cfg)
     out = [int(integ.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates) for f in frames]
     integ.close()
     return out
 
 
-def roofline_of(m, K, upd_counted, world=1):
+def early_out_fidelity(B, dev, wl, frames, max_tiles):
+    """The benched `fast` schedule against the SERIAL reference order, measured here and now: both integrate the
+    same frames into fresh maps; touched-voxel Jaccard, label agreement on the common voxels, update ratio."""
+    import numpy as np
+    from oracle import oracle_py as O
+    o = O.Oracle(O.default_config(integrator_threads=1, **integ_cfg(wl, early_out_phase_growth=0)))
+    h = B.HipIntegrator(B.default_config(device_id=dev.index or 0, max_tiles=max_tiles, max_points=max(f.xyz.shape[0] for f in frames),
+                                         pipeline_frames=0, **integ_cfg(wl)))
+    uo = uh = 0
+    for f in frames:
+        uo += int(o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates)
+        uh += int(h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates)
+    so = {tuple(x) for x in o.block_indices().tolist()}
+    sh = {tuple(x) for x in h.block_indices().tolist()}
+    common = np.array(sorted(so & sh), dtype=np.int32).reshape(-1, 3)
+    _, ot, osem = o.download(common)
+    _, ht, hsem = h.download(common)
+    to, th = ot["weight"] > 0, ht["weight"] > 0
+    both = to & th
+    # voxels of blocks only one side allocated count against the union
+    extra = 0
+    for only, integ in ((so - sh, o), (sh - so, h)):
+        if only:
+            _, t, _ = integ.download(np.array(sorted(only), dtype=np.int32).reshape(-1, 3))
+            extra += int((t["weight"] > 0).sum())
+    o.close()
+    h.close()
+    union = int((to | th).sum()) + extra
+    return {"frames": len(frames), "touched_jaccard": round(float(both.sum()) / max(1, union), 5),
+            "block_jaccard": round(len(so & sh) / max(1, len(so | sh)), 5),
+            "label_agreement_common_voxels": round(float((osem["label"] == hsem["label"])[both].mean()) if both.any() else 1.0, 5),
+            "updates_gpu_over_serial": round(uh / max(1, uo), 4),
+            "how": "this run: the benched schedule (HIP) vs the serial reference order (CPU oracle, 1 thread), same frames, fresh maps"}
+
+
+def pmc_traffic(name):
+    """HBM bytes per k_apply launch from the committed PMC pass of this command (profiles/r03_pmc_<name>.json,
+    written by tools/pmc_bench.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 unit correction applied)."""
+    p = os.path.join(ROOT, "profiles", f"r03_pmc_{name}.json")
+    try:
+        d = json.load(open(p))
+        return d
+    except Exception:
+        return None
+
+
+def roofline_of(m, region, K, upd_counted, world=1, pmc_name=None):
     """Whole frame + per stage + k_apply, all against the HBM roofline (algorithmic bytes)."""
     prof, sp = m["prof"], m["stage_prof"]
-    frame_s = m["dt"] / K
-    whole_bytes = (BYTES_PER_UPDATE * upd_counted + BYTES_PER_POINT * m["points"] / world) / K   # per GPU
+    frame_s = region["dt"] / K
+    whole_bytes = (BYTES_PER_UPDATE * upd_counted + BYTES_PER_POINT * region["points"] / world) / K   # per GPU
     whole_gbs = whole_bytes / frame_s / 1e9
     nfr = max(1, sp["frames"])
     stage_ms = {k: v / nfr for k, v in sp["ms"].items()}
@@ -245,15 +358,19 @@ def roofline_of(m, K, upd_counted, world=1):
     apply_ms = prof["apply_kernel_ms"] / max(1, prof["apply_kernel_launches"])
     upd_per_launch = prof["apply_kernel_updates"] / max(1, prof["apply_kernel_launches"])
     a_gbs = BYTES_PER_UPDATE * upd_per_launch / (apply_ms * 1e-3) / 1e9 if apply_ms > 0 else 0.0
+    pmc = pmc_traffic(pmc_name) if pmc_name else None
+    traffic = pmc.get("k_apply_hbm_bytes_per_launch") if pmc else None
     return {
-        "bound": "hbm", "kernel": "whole frame (all stages, wall clock of the timed region)",
+        "bound": "hbm", "kernel": "whole frame (all stages, wall clock of the median timed region)",
         "achieved": round(whole_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole_gbs / HBM_PEAK_GBS, 5),
-        "traffic": None,
-        "traffic_note": "not measured in this run; PMC FETCH/WRITE of named kernels on their own workloads: profiles/*pmc*",
+        "traffic": traffic,
+        "traffic_note": (f"k_apply, HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command, "
+                         f"gfx950 correction applied): {pmc.get('source', 'profiles/')}" if pmc else
+                         "no committed PMC pass for this workload (profiles/r03_pmc_*.json)"),
         "algorithmic_bytes_per_frame": int(whole_bytes),
         "dominant_stage": dominant,
         "stages": stages,
-        "stage_note": "HIP events around every stage: separate untimed pass over the last 10 frames (stages of one frame back to "
+        "stage_note": "HIP events around every stage: separate untimed pass over 10 frames (stages of one frame back to "
                       "back); march = early-out phases + scan + pair emission, sort_* = radix sorts, apply(+_long) = per-voxel update",
         "k_apply": {"achieved": round(a_gbs, 2), "frac": round(a_gbs / HBM_PEAK_GBS, 5), "avg_launch_ms": round(apply_ms, 5),
                     "algorithmic_bytes_per_launch": int(BYTES_PER_UPDATE * upd_per_launch),
@@ -263,25 +380,89 @@ def roofline_of(m, K, upd_counted, world=1):
     }
 
 
-def record(name, wl, m, K, counted, how, world=1):
-    """One result record (the primary line's core fields, also used for the secondary configs)."""
-    dt, gpu_upd = m["dt"], m["updates"]
-    return {
+def record(name, wl, m, K, count_of_frame, how, world=1, pmc_name=None, note=None, credit_scale=1.0):
+    """One result record from the MEDIAN timed region (the primary line's core fields; also the secondary configs).
+    count_of_frame(i) = reference-order update count of frame i, or None: the GPU's own count (x credit_scale <= 1)."""
+    rates, per_region = [], []
+    for reg in m["regions"]:
+        gpu_upd = reg["updates"]
+        counted = gpu_upd * min(1.0, credit_scale)
+        if count_of_frame is not None:
+            oc = sum(count_of_frame(i) for i in reg["frames"])
+            counted = min(oc, gpu_upd)     # never credit updates the GPU skipped
+        rates.append(counted / reg["dt"])
+        per_region.append((reg, counted))
+    order = sorted(range(len(rates)), key=lambda i: rates[i])
+    mid = order[len(order) // 2]
+    reg, counted = per_region[mid]
+    dt, gpu_upd = reg["dt"], reg["updates"]
+    _, spread = median_spread(rates)
+    credit = how
+    if count_of_frame is not None and sum(count_of_frame(i) for i in reg["frames"]) > gpu_upd:
+        credit = how + "; the GPU performed fewer updates than that, so its own count is credited"
+    out = {
         "config": name,
         "workload": f"{wl['w']}x{wl['h']} depth+label trajectory ({wl['scene']}), '{wl['method']}' integrator, "
                     f"{wl['voxel'] * 100:g} cm voxels, {wl['max_ray']:g} m rays, trunc {4 * wl['voxel']:g} m, p=0.8",
-        "value": round(counted / dt / 1e6, 3), "unit": "Mvoxel-updates/s", "updates_counted_by": how,
+        "value": round(counted / dt / 1e6, 3), "unit": "Mvoxel-updates/s", "updates_counted_by": credit,
         "gpu_counted_value": round(gpu_upd / dt / 1e6, 3),
         "ms_per_step": round(dt / (K / world) * 1e3, 4), "frames_per_s": round(K / dt, 2), "steps": K // world,
-        "points_per_frame": int(m["points"] / K), "rays_per_frame": int(m["rays"] / K),
+        "repeats": len(rates), "spread": round(spread, 4),
+        "ms_per_step_all_regions": [round(r["dt"] / (K / world) * 1e3, 4) for r in m["regions"]],
+        "points_per_frame": int(reg["points"] / K), "rays_per_frame": int(reg["rays"] / K),
         "updates_per_frame": int(counted / K), "gpu_updates_per_frame": int(gpu_upd / K), "tiles": m["tiles"],
-        "roofline": roofline_of(m, K // world, counted / world, world),
+        "roofline": roofline_of(m, reg, K // world, counted / world, world, pmc_name),
     }
+    if note:
+        out["note"] = note
+    return out, reg
 
 
-def c5_record(B, torch, dist, dev, rank, world):
+def adapter_record(wl_frames):
+    """The C++ drop-in adapter behind the reference's virtual, as an UNMODIFIED SemanticTsdfServer would drive it:
+    host clouds in, host Layers current after every integratePointCloud (SyncPolicy::kEveryFrame), and the
+    on-demand policy with pipelined frames beside it (kimera_semantics_amd/host/adapter_demo)."""
+    import re
+    import struct
+    import subprocess
+    import tempfile
+    from kimera_semantics_amd import synth
+    demo = os.path.join(ROOT, "kimera_semantics_amd", "host", "adapter_demo")
+    if not os.path.exists(demo):
+        return {"config": "adapter", "error": "adapter_demo not built"}
+    tmp = tempfile.mkdtemp(prefix="ks_adapter_")
+    fin, fout, csv = (os.path.join(tmp, x) for x in ("in.bin", "out.bin", "labels.csv"))
+    with open(csv, "w") as fh:
+        fh.write("name,red,green,blue,alpha,id\n")
+        for i, (r, g, b, a) in enumerate(synth.default_label_colors()[:21]):
+            fh.write(f"label{i},{int(r)},{int(g)},{int(b)},{int(a)},{i}\n")
+    with open(fin, "wb") as fh:
+        fh.write(struct.pack("<I", len(wl_frames)))
+        for f in wl_frames:
+            fh.write(f.T_G_C.astype("<f4").tobytes())
+            fh.write(struct.pack("<I", len(f.xyz)))
+            fh.write(f.xyz.astype("<f4").tobytes())
+            fh.write(f.rgba.tobytes())
+    out = {"config": "adapter", "workload": f"{len(wl_frames)} 640x480 host clouds through kimera::HipSemanticTsdfIntegrator "
+                                            "(TsdfIntegratorBase virtual), steady state = last third of the frames"}
+    for method in ("fast", "merged"):
+        for pipe, key in (("0", "every_frame_sync"), ("1", "on_demand_sync_pipelined")):
+            res = subprocess.run([demo, method, csv, fin, fout, "1", "2", "-1", pipe], capture_output=True, text=True, timeout=600)
+            mm = re.search(r"integratePointCloud ([0-9.]+) ms/frame over (\d+) frames, ([0-9.]+) ms/frame over the last (\d+)", res.stdout)
+            out[f"{method}_{key}_ms_per_frame"] = float(mm.group(3)) if mm else None
+            if not mm:
+                out[f"{method}_{key}_error"] = (res.stdout + res.stderr)[-300:]
+    for p in (fin, fout):
+        try:
+            os.remove(p)
+        except OSError:
+            pass
+    return out
+
+
+def c5_record(B, torch, dist, dev, rank, world, comm):
     """BASELINE.json configs[4]: a batch of 8 overlapping 640x480 frames (arc poses looking at the same wall),
-    frame-sharded over the ranks, ONE reduce of the overlapping tiles to their owner ranks inside the timed
+    frame-sharded over the ranks, ONE ks_reduce of the dirty tiles to their owner ranks inside the timed
     region; the owner-sharded result is compared with the same frames integrated sequentially on one GPU
     (merging per-rank maps is not the same arithmetic as sequential integration: SURVEY.md §8e)."""
     import numpy as np
@@ -299,7 +480,7 @@ def c5_record(B, torch, dist, dev, rank, world):
     t0 = time.perf_counter()
     upd = sum(int(h.integrate(frames[k].T_G_C, frames[k].xyz, frames[k].rgba, frames[k].labels).n_voxel_updates) for k in mine)
     h.synchronize()
-    rstats = PAR.reduce_maps(PAR.HipTileStore(h, dev))
+    rstats = h.reduce(comm, rank, world)
     h.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
@@ -328,7 +509,7 @@ def c5_record(B, torch, dist, dev, rank, world):
     a = agg.tolist()
     dtm = float(tmax.item())
     return {"config": "C5", "workload": f"{n_frames} arc-pose 640x480 frames looking at the same wall, frame-sharded x{world}, "
-                                        "one all-to-all tile reduce to hash-owners inside the timed region",
+                                        "one ks_reduce (RCCL all-to-all of the dirty tiles to their hash-owners) inside the timed region",
             "frames": n_frames, "batch_ms": round(dtm * 1e3, 3), "frames_per_s": round(n_frames / dtm, 2),
             "gpu_counted_value": round(a[3] / dtm / 1e6, 3), "unit": "Mvoxel-updates/s",
             "reduce": {"tiles_sent": int(a[5]), "bytes_sent": int(a[6])},
@@ -359,112 +540,186 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     K, W = args.steps, args.warmup
+    R = max(MIN_REPEATS, -(-MIN_TIMED_FRAMES // max(1, K)))
     wl = dict(WORKLOADS["C2"], w=args.width, h=args.height, method=args.method)
-    # frame-sharded: rank r integrates trajectory frames r, r+world, ... (weak scaling: K+W frames per GPU)
-    frames = make_frames(wl, [rank + world * k for k in range(K + W)])
+    # frame-sharded: rank r integrates trajectory frames r, r+world, ... (weak scaling: the same number of frames per GPU)
+    n_distinct = min(PRIME + W + R * K, MAX_DISTINCT_FRAMES)
+    frames = make_frames(wl, [rank + world * k for k in range(n_distinct)])
+    ring = FrameRing(frames, torch, dev)
     pipeline = 0 if args.no_pipeline else 4   # bag replay = a stream of frames: frame pipelining on
 
     reduce_fn = None
-    if world > 1:
+    comm = None
+    if world > 1 or os.environ.get("KS_BENCH_C5") == "1":
         from kimera_semantics_amd import parallel as PAR
-        PAR.warm_up(dev)   # RCCL connects peers lazily: not part of the steady state being timed
-
+        if world == 1 and not dist.is_initialized():   # single-GPU self-test of this code path
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        comm = PAR.rccl_comm(rank, world, dev)   # an ncclComm_t of the librccl ks_reduce loads (id broadcast over torch.distributed)
+    if world > 1:
         def reduce_fn(integ):
-            # the one exchange step of the frame-sharded path: per-rank partial maps -> owner-sharded
-            # global map (all-to-all of touched tiles over RCCL/xGMI + deterministic owner merge)
-            st = PAR.reduce_maps(PAR.HipTileStore(integ, dev))
+            # the one exchange step of the frame-sharded path (C ABI): dirty tiles -> their owner ranks, all peers at
+            # once over RCCL/xGMI, deterministic owner merge
+            st = integ.reduce(comm, rank, world)
             integ.synchronize()
             return st
 
-    m = measure(B, torch, dist, dev, wl, frames, W, K, pipeline, 1 << 13, world, reduce_fn=reduce_fn)
+    m = measure(B, torch, dist, dev, wl, ring, W, K, R, pipeline, 1 << 13, world, reduce_fn=reduce_fn)
 
-    # N_updates in the serial reference order for this rank's timed frames (outside the timed region)
-    upd_serial = None if args.no_oracle_count else oracle_counts(wl, frames[W:W + K])
-    upd_oracle = sum(upd_serial) if upd_serial is not None else None
+    # N_updates in the serial reference order for this rank's frames (outside the timed regions)
+    upd_serial = None if args.no_oracle_count else oracle_counts(wl, frames)
+    count_of_frame = (lambda i: upd_serial[i % n_distinct]) if upd_serial is not None else None
+    how = ("serial reference order (CPU oracle, 1 thread), every timed frame" if upd_serial is not None
+           else "GPU's own count (oracle count skipped)")
 
     if world > 1:
-        t = torch.tensor([m["dt"]], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        m["dt"] = float(t.item())
-        u = torch.tensor([m["updates"], m["points"], m["rays"], upd_oracle if upd_oracle is not None else 0], device=dev,
-                         dtype=torch.float64)
-        dist.all_reduce(u, op=dist.ReduceOp.SUM)
-        m["updates"], m["points"], m["rays"] = int(u[0].item()), int(u[1].item()), int(u[2].item())
-        upd_oracle = int(u[3].item()) if upd_oracle is not None else None
+        # whole-job regions: MAX of the ranks' wall times, SUM of their work
+        for r, reg in enumerate(m["regions"]):
+            t = torch.tensor([reg["dt"]], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            oc = sum(count_of_frame(i) for i in reg["frames"]) if count_of_frame else 0
+            u = torch.tensor([reg["updates"], reg["points"], reg["rays"], oc], device=dev, dtype=torch.float64)
+            dist.all_reduce(u, op=dist.ReduceOp.SUM)
+            reg["dt"] = float(t.item())
+            reg["updates"], reg["points"], reg["rays"] = int(u[0].item()), int(u[1].item()), int(u[2].item())
+            reg["oracle_sum"] = int(u[3].item())
+        if count_of_frame is not None:
+            sums = {tuple(reg["frames"]): reg["oracle_sum"] for reg in m["regions"]}
+            per_frame = {}
+            for fr, s in sums.items():
+                for i in fr:
+                    per_frame[i] = s / len(fr)
+            count_of_frame = lambda i: per_frame[i]   # noqa: E731  (only sums over whole regions are used)
 
     c5 = None
-    if world > 1 or os.environ.get("KS_BENCH_C5") == "1":
+    if comm is not None:
         try:
-            if world == 1 and not dist.is_initialized():   # single-GPU self-test of this code path
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29517")
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-            c5 = c5_record(B, torch, dist, dev, rank, world)
+            c5 = c5_record(B, torch, dist, dev, rank, world, comm)
         except Exception as e:   # collective calls above are symmetric; a local failure must not take the line down
             c5 = {"config": "C5", "error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
-        dt = m["dt"]
         Kall = K * world
-        counted = upd_oracle if upd_oracle is not None else m["updates"]
-        how = ("serial reference order (CPU oracle, 1 thread), every timed frame" if upd_oracle is not None
-               else "GPU's own count (oracle count skipped)")
-        rec = record("C2" if args.method == "fast" else "C3", wl, m, Kall, counted, how, world)
+        rec, reg = record("C2" if args.method == "fast" else "C3", wl, m, Kall, count_of_frame, how, world,
+                          pmc_name="c2" if args.method == "fast" else "c3")
         out = {
             "metric": METRIC,
             "value": rec["value"], "unit": rec["unit"],
             "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": round(dt / K * 1e3, 4),
+            "ms_per_step": rec["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "frames_per_s": round(Kall / dt, 2),
+            "frames_per_s": rec["frames_per_s"],
             "gpu_counted_value": rec["gpu_counted_value"],
-            "updates_counted_by": how,
+            "updates_counted_by": rec["updates_counted_by"],
+            "timing": {"untimed_frames_before_t0": PRIME + W, "timed_regions": R, "steps_per_region": K,
+                       "reported": "median region", "spread_max_minus_min_over_median": rec["spread"],
+                       "ms_per_step_all_regions": rec["ms_per_step_all_regions"]},
             "config": {"workload": "bag-replay stand-in: " + rec["workload"],
-                       "frames_per_gpu": K, "pipeline_frames": pipeline,
+                       "frames_per_gpu": K, "pipeline_frames": pipeline, "distinct_frames_replayed_cyclically": n_distinct,
                        "points_per_frame": rec["points_per_frame"], "rays_per_frame": rec["rays_per_frame"],
                        "updates_per_frame": rec["updates_per_frame"], "gpu_updates_per_frame": rec["gpu_updates_per_frame"],
-                       "early_out": ("ordered-phase schedule, doubling phases: deterministic, bit-exact vs its CPU restatement, "
-                                     "touched-set Jaccard 0.976 vs the serial reference order") if args.method == "fast" else "n/a (merged)",
+                       "early_out": ("ordered-phase schedule, doubling phases (the throughput default): deterministic, bit-exact vs its "
+                                     "CPU restatement; distance from the serial reference order: early_out_fidelity (measured in this "
+                                     "run); the serial result itself: secondary C2-exact") if args.method == "fast" else "n/a (merged)",
+                       "bundle_order": "reference (std::unordered_map iteration order, computed on the GPU)" if args.method == "merged" else "n/a (fast)",
                        "parallelism": f"frame-sharded x{world}" + (
-                           " + one all-to-all tile reduce to hash-owners at the end (inside the timed region)"
+                           " + one ks_reduce (RCCL all-to-all of the dirty tiles to hash-owners) at the end of every timed region"
                            if world > 1 else "")},
             "roofline": rec["roofline"],
             "host_ms_per_frame": {"in_call": round(m["prof"]["host_ms"] / max(1, m["prof"]["frames"]), 4),
                                   "of_which_waiting_for_snapshot": round(m["prof"]["host_wait_ms"] / max(1, m["prof"]["frames"]), 4)},
         }
-        if m["reduce"] is not None:
-            out["reduce"] = m["reduce"]
+        if reg["reduce"] is not None:
+            out["reduce"] = reg["reduce"]
         if c5 is not None:
             out.setdefault("secondary", []).append(c5)
+        if world == 1 and args.method == "fast" and upd_serial is not None:
+            try:
+                out["early_out_fidelity"] = early_out_fidelity(B, dev, wl, [ring.host(PRIME + W + i) for i in range(2)], 1 << 13)
+            except Exception as e:
+                out["early_out_fidelity"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1 and upd_serial is not None:   # reported on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(args, wl, frames[W:], upd_serial)
+            first = [(PRIME + W + i) % n_distinct for i in range(args.cpu_frames)]
+            out["cpu_baseline"] = cpu_baseline(args, wl, [frames[i] for i in first], [upd_serial[i] for i in first])
         if world == 1 and not args.no_secondary:
             sec = out.get("secondary", [])
-            for name, steps, warm, tiles, n_oracle in (("C3", 20, 3, 1 << 13, 20), ("C4-fast", 12, 2, 1 << 16, 1),
-                                                       ("C4-merged", 12, 2, 1 << 16, 1)):
-                if name == "C3" and args.method == "merged":
+            only = set(filter(None, args.only_secondary.split(",")))
+
+            def want(name):
+                return not only or name in only
+
+            # ---- the exact serial early-out mode, the merged integrator, the host-pointer entry (640x480) ----
+            n_sub = min(24, n_distinct)     # these records replay the first n_sub frames cyclically
+            sub_ring = FrameRing(frames[:n_sub], torch, dev)
+            for name, swl, kw in (("C2-exact", WORKLOADS["C2"], dict(cfg=dict(early_out_phase_growth=B.KS_EARLY_OUT_EXACT), pipe=0)),
+                                  ("C3", WORKLOADS["C3"], dict(cfg={}, pipe=pipeline)),
+                                  ("C2-host-inputs", WORKLOADS["C2"], dict(cfg={}, pipe=pipeline, entry="host"))):
+                if not want(name) or args.method != "fast" or (args.width, args.height) != (640, 480):
+                    continue
+                try:
+                    sK, sR = 20, MIN_REPEATS
+                    sm = measure(B, torch, dist, dev, swl, sub_ring, 2, sK, sR, kw["pipe"], 1 << 13, 1,
+                                 entry=kw.get("entry", "device"), **kw["cfg"])
+                    cof, show = None, "GPU's own count (oracle count skipped)"
+                    if not args.no_oracle_count:
+                        oc = upd_serial[:n_sub] if swl["method"] == "fast" else oracle_counts(swl, sub_ring.frames)
+                        cof = lambda i, oc=oc: oc[i % len(oc)]   # noqa: E731
+                        show = "serial reference order (CPU oracle, 1 thread), every timed frame"
+                    note = None
+                    if name == "C2-exact":
+                        nf, it = sm["early_out_iterations"]
+                        note = (f"KS_EARLY_OUT_EXACT: the reference's serial early-out result (bit-exact: tests/test_exact_early_out_gpu.py); "
+                                f"{it / max(1, nf):.1f} fix-point iterations per frame; unpipelined (the host reads a counter per iteration)")
+                    elif name == "C2-host-inputs":
+                        note = ("ks_integrate_points on page-locked HOST buffers: the H2D copy of every frame is inside the call "
+                                "(SURVEY.md §8d's frames/s definition); never the headline value")
+                    elif name == "C3":
+                        note = "bundles integrated in the reference's std::unordered_map iteration order (bit-exact vs the real sources)"
+                    srec, _ = record(name, swl, sm, sK, cof, show, note=note, pmc_name="c3" if name == "C3" else None)
+                    if name == "C2-exact" and cof is not None:
+                        srec["gpu_count_equals_serial_reference_count"] = all(
+                            r["updates"] == sum(cof(i) for i in r["frames"]) for r in sm["regions"])
+                    sec.append(srec)
+                except Exception as e:   # a secondary record must never take the primary line down
+                    sec.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+            del sub_ring
+            # ---- C4: 1280x720, 2 cm voxels, 10 m rays (both integrators on the same frames) ----
+            c4_ring = None
+            for name, steps, tiles in (("C4-fast", 6, 1 << 16), ("C4-merged", 6, 1 << 16)):
+                if not want(name):
                     continue
                 try:
                     swl = WORKLOADS[name]
-                    sfr = make_frames(swl, range(steps + warm))
-                    sm = measure(B, torch, dist, dev, swl, sfr, warm, steps, pipeline, tiles, 1)
-                    counted, how = sm["updates"], "GPU's own count (oracle count skipped)"
+                    if c4_ring is None:
+                        c4_ring = FrameRing(make_frames(swl, range(PRIME + 2 + steps)), torch, dev)
+                    sm = measure(B, torch, dist, dev, swl, c4_ring, 2, steps, MIN_REPEATS, pipeline, tiles, 1)
+                    scale, show = 1.0, "GPU's own count (oracle count skipped)"
                     if not args.no_oracle_count:
-                        oc = oracle_counts(swl, sfr[warm:warm + n_oracle])
-                        if n_oracle == steps:
-                            counted, how = sum(oc), "serial reference order (CPU oracle, 1 thread), every timed frame"
-                        else:   # the serial oracle needs ~10 s per C4 frame: count a sample, scale the GPU count by its ratio
-                            g = gpu_counts(B, torch, dev, swl, sfr[warm:warm + n_oracle], tiles)
-                            ratio = sum(oc) / max(1, sum(g))
-                            counted = sm["updates"] * ratio
-                            how = (f"GPU count x (serial-oracle / GPU) measured on the first {n_oracle} timed frame(s): "
-                                   f"x{ratio:.4f} (oracle {sum(oc)}, GPU {sum(g)})")
-                    sec.append(record(name, swl, sm, steps, counted, how))
-                    del sfr
+                        # the serial oracle needs ~10 s per C4 frame: count ONE timed frame, compare with the GPU's count of it
+                        i0 = PRIME + 2
+                        oc = oracle_counts(swl, [c4_ring.host(i0)])[0]
+                        g = gpu_counts(B, dev, swl, [c4_ring.host(i0)], tiles)[0]
+                        ratio = oc / max(1, g)
+                        if ratio >= 1.0:
+                            show = (f"GPU's own count: on the first timed frame the serial reference order performs x{ratio:.4f} the GPU's "
+                                    f"updates (oracle {oc}, GPU {g}); work the GPU skipped is not credited")
+                        else:
+                            scale = ratio
+                            show = (f"GPU count x (serial-oracle / GPU) measured on the first timed frame: x{ratio:.4f} "
+                                    f"(oracle {oc}, GPU {g})")
+                    srec, _ = record(name, swl, sm, steps, None, show, credit_scale=scale)
+                    sec.append(srec)
                     torch.cuda.empty_cache()
-                except Exception as e:   # a secondary record must never take the primary line down
+                except Exception as e:
                     sec.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+            del c4_ring
+            if want("adapter") and args.method == "fast":
+                try:
+                    sec.append(adapter_record([ring.host(PRIME + i) for i in range(12)]))
+                except Exception as e:
+                    sec.append({"config": "adapter", "error": f"{type(e).__name__}: {e}"})
             out["secondary"] = sec
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or (dist.is_available() and dist.is_initialized()):

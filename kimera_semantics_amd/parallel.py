@@ -132,3 +132,40 @@ def warm_up(device, group=None):
 
 def owned_tile_mask(keys: np.ndarray, rank: int, world: int) -> np.ndarray:
     return owner_of(keys, world) == rank
+
+
+def rccl_comm(rank: int, world: int, device):
+    """An ncclComm_t (as an int) over the ranks of the default process group, created with the SAME librccl that
+    ks_reduce loads (KS_RCCL_LIB is pointed at torch's copy so the process holds one RCCL): rank 0 draws the
+    unique id, torch.distributed broadcasts its 128 bytes, every rank calls ncclCommInitRank.  One rank per GPU."""
+    import ctypes as C
+    import os
+
+    import torch
+    import torch.distributed as dist
+    path = os.environ.get("KS_RCCL_LIB")
+    if not path:
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = cand if os.path.exists(cand) else "librccl.so.1"
+        os.environ["KS_RCCL_LIB"] = path
+    lib = C.CDLL(path)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_byte * 128)]
+    uid = UniqueId()
+    if rank == 0:
+        rc = lib.ncclGetUniqueId(C.byref(uid))
+        if rc != 0:
+            raise RuntimeError(f"ncclGetUniqueId: {rc}")
+    t = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).to(device)
+    if world > 1:
+        dist.broadcast(t, src=0)
+    raw = bytes(t.cpu().numpy().tobytes())
+    C.memmove(C.byref(uid), raw, 128)
+    comm = C.c_void_p()
+    lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(device)
+    rc = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    if rc != 0:
+        raise RuntimeError(f"ncclCommInitRank: {rc}")
+    return comm.value

@@ -121,3 +121,21 @@ def test_merged_canonical_order_gap_measured(tmp_path, geom, size, record_proper
     record_property("merged_canonical_vs_reference_order", rep)
     print("merged, first-insertion order vs real reference:", rep)
     assert rep["label_flip_frac"] <= 0.01 and rep["frac_dd_le_1e5"] >= 0.97, rep
+
+
+@pytest.mark.parametrize("method", [1, 0])
+def test_full_size_c4_frame_bit_exact_vs_real_reference(tmp_path, method):
+    """One FULL-SIZE C4 frame (1280x720, 2 cm voxels, 10 m rays, 75 deg) — the size bench.py's C4 records run —
+    merged (reference bundle order) and fast with the early-out out of reach: HIP == the real reference sources."""
+    kw = dict(max_consecutive_ray_collisions=NO_EARLY_OUT) if method == 0 else {}
+    csv = str(tmp_path / "labels.csv")
+    R.write_label_csv(csv, synth.default_label_colors())
+    r = R.Reference("fast" if method == 0 else "merged", csv, voxel_size=C4["voxel_size"], truncation=C4["truncation_distance"],
+                    max_ray=C4["max_ray_length_m"], **kw)
+    h = B.HipIntegrator(B.default_config(max_tiles=1 << 16, max_points=1280 * 720, **dict(COMMON, method=method, **C4, **kw)))
+    f = synth.render_frame(synth.make_scene("hall"), synth.trajectory_pose(3, radius=3.0), 1280, 720, hfov_deg=75.0, seed=3)
+    r.integrate(f.T_G_C, f.xyz, f.rgba)
+    st = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    assert st.n_voxel_updates > 3e7
+    rt, rs, ht, hs = _maps(r, h)
+    _assert_identical(rt, rs, ht, hs)

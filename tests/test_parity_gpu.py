@@ -761,3 +761,30 @@ def test_cloud_outgrows_max_points_with_frames_in_flight(method, early_out):
         h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
     h.flush()
     compare_maps(o, h, exact=True)
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_benched_configuration_map_is_exact(method):
+    """EXACTLY what bench.py times: pipeline_frames = 4, 640x480, reference defaults (fast: early-out on, the
+    ordered-phase schedule; merged: reference bundle order), device-pointer entry, 18 trajectory frames so that
+    every frame slot, march stream and captured stage-B graph is reused — final map bit-for-bit against the oracle
+    (fast: the restatement of the schedule, early_out_phase_growth = 32; merged: unordered_map order)."""
+    import torch
+    kw = dict(COMMON, method=method, voxel_size=0.05, voxels_per_side=16, truncation_distance=0.2, max_ray_length_m=5.0)
+    o = O.Oracle(O.default_config(early_out_phase_growth=32 if method == 0 else 0, **kw))
+    h = B.HipIntegrator(B.default_config(max_tiles=1 << 13, max_points=640 * 480, pipeline_frames=4, **kw))
+    sc = synth.make_scene("room")
+    n_frames = 18 if method == 0 else 8
+    upd_o = upd_h = 0
+    keep = []
+    for k in range(n_frames):
+        f = synth.render_frame(sc, synth.trajectory_pose(k), 640, 480, seed=k)
+        upd_o += o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
+        d = (torch.from_numpy(f.xyz).cuda(), torch.from_numpy(f.rgba).cuda(), torch.from_numpy(f.labels).cuda())
+        keep.append(d)   # inputs stay resident until their (pipelined) frame has been integrated
+        torch.cuda.synchronize()
+        upd_h += h.integrate_device(f.T_G_C, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[0].shape[0]).n_voxel_updates
+    upd_h += h.flush().n_voxel_updates
+    assert upd_o == upd_h
+    rep = compare_maps(o, h, exact=True)
+    assert rep["oracle_touched"] > 200000
