@@ -17,6 +17,9 @@
 #include <vector>
 
 #include "hip_semantic_tsdf_integrator.h"
+#ifdef KS_DEMO_REAL_FACTORY
+#include <kimera_semantics/semantic_tsdf_integrator_factory.h>
+#endif
 
 namespace vxb = voxblox;
 
@@ -29,6 +32,7 @@ int main(int argc, char** argv) {
   vxb::TsdfIntegratorBase::Config cfg;
   cfg.default_truncation_distance = 0.2f;  // voxblox_ros: 4 x voxel size
   cfg.max_ray_length_m = 5.0f;
+  cfg.integrator_threads = 1;  // (only the reference's CPU integrators read it: one thread = their deterministic order)
   if (argc > 6) cfg.max_consecutive_ray_collisions = std::atoi(argv[6]);
   kimera::SemanticIntegratorBase::SemanticConfig sc;
   sc.semantic_measurement_probability_ = 0.8f;
@@ -45,8 +49,24 @@ int main(int argc, char** argv) {
     opt.sync_policy = kimera::HipSemanticTsdfIntegrator::SyncPolicy::kOnDemand;
     opt.pipeline_frames = true;
   }
-  std::unique_ptr<vxb::TsdfIntegratorBase> integrator =
-      kimera::HipSemanticTsdfIntegratorFactory::create(method, cfg, sc, &tsdf_layer, &semantic_layer, opt);
+#ifdef KS_DEMO_REAL_FACTORY
+  // integration/build_real_kimera.sh: the REAL kimera::SemanticTsdfIntegratorFactory (reference source +
+  // integration/factory.patch) hands the integrator out, as SemanticTsdfServer's constructor gets it
+  // (kimera_semantics_ros/src/semantic_tsdf_server.cpp:71-78); "enum:<n>" goes through the enum overload.
+  auto make = [&]() -> std::unique_ptr<vxb::TsdfIntegratorBase> {
+    if (method.rfind("enum:", 0) == 0)
+      return kimera::SemanticTsdfIntegratorFactory::create(static_cast<kimera::SemanticTsdfIntegratorType>(std::atoi(method.c_str() + 5)),
+                                                          cfg, sc, &tsdf_layer, &semantic_layer);
+    return kimera::SemanticTsdfIntegratorFactory::create(method, cfg, sc, &tsdf_layer, &semantic_layer);
+  };
+#else
+  auto make = [&]() -> std::unique_ptr<vxb::TsdfIntegratorBase> {
+    if (method.rfind("enum:", 0) == 0)
+      return kimera::HipSemanticTsdfIntegratorFactory::create(std::atoi(method.c_str() + 5), cfg, sc, &tsdf_layer, &semantic_layer, opt);
+    return kimera::HipSemanticTsdfIntegratorFactory::create(method, cfg, sc, &tsdf_layer, &semantic_layer, opt);
+  };
+#endif
+  std::unique_ptr<vxb::TsdfIntegratorBase> integrator = make();
 
   FILE* in = std::fopen(argv[3], "rb");
   if (!in) return 3;
@@ -58,7 +78,7 @@ int main(int argc, char** argv) {
   for (uint32_t f = 0; f < n_frames; ++f) {
     if ((int)f == restart_after) {
       integrator.reset();
-      integrator = kimera::HipSemanticTsdfIntegratorFactory::create(method, cfg, sc, &tsdf_layer, &semantic_layer, opt);
+      integrator = make();
     }
     float T[7];
     uint32_t n;

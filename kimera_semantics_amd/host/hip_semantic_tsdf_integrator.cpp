@@ -441,4 +441,23 @@ std::unique_ptr<vxb::TsdfIntegratorBase> HipSemanticTsdfIntegratorFactory::creat
   return nullptr;
 }
 
+std::unique_ptr<vxb::TsdfIntegratorBase> HipSemanticTsdfIntegratorFactory::create(
+    int integrator_type, const vxb::TsdfIntegratorBase::Config& config,
+    const SemanticIntegratorBase::SemanticConfig& semantic_config, vxb::Layer<vxb::TsdfVoxel>* tsdf_layer,
+    vxb::Layer<SemanticVoxel>* semantic_layer, const HipSemanticTsdfIntegrator::DeviceOptions& options) {
+  CHECK_NOTNULL(tsdf_layer);
+  switch (integrator_type) {
+    case 1:  // SemanticTsdfIntegratorType::kFast
+    case 3:  // kFastHip (integration/factory.patch)
+      return create("fast", config, semantic_config, tsdf_layer, semantic_layer, options);
+    case 0:  // kMerged
+    case 2:  // kMergedHip
+      return create("merged", config, semantic_config, tsdf_layer, semantic_layer, options);
+    default:
+      LOG(FATAL) << "Unknown Semantic/TSDF integrator type: " << integrator_type;
+      break;
+  }
+  return nullptr;
+}
+
 }  // namespace kimera

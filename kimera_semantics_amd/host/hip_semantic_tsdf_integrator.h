@@ -13,6 +13,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include <voxblox/integrator/tsdf_integrator.h>
@@ -125,6 +126,24 @@ class HipSemanticTsdfIntegratorFactory {
       const SemanticIntegratorBase::SemanticConfig& semantic_config, vxb::Layer<vxb::TsdfVoxel>* tsdf_layer,
       vxb::Layer<SemanticVoxel>* semantic_layer,
       const HipSemanticTsdfIntegrator::DeviceOptions& options = HipSemanticTsdfIntegrator::DeviceOptions());
+
+  /// The enum overload of the reference factory (semantic_tsdf_integrator_factory.h:84-93): kMerged = 0, kFast = 1,
+  /// plus the values integration/factory.patch adds for the explicit names, kMergedHip = 2, kFastHip = 3.  Taken
+  /// as the enum's underlying int so that this header does not depend on the (patched) factory header;
+  /// anything else is LOG(FATAL), like the reference's default branch (semantic_tsdf_integrator_factory.cpp:82-86).
+  static std::unique_ptr<vxb::TsdfIntegratorBase> create(
+      int integrator_type, const vxb::TsdfIntegratorBase::Config& config,
+      const SemanticIntegratorBase::SemanticConfig& semantic_config, vxb::Layer<vxb::TsdfVoxel>* tsdf_layer,
+      vxb::Layer<SemanticVoxel>* semantic_layer,
+      const HipSemanticTsdfIntegrator::DeviceOptions& options = HipSemanticTsdfIntegrator::DeviceOptions());
+  template <typename Enum, typename = typename std::enable_if<std::is_enum<Enum>::value>::type>
+  static std::unique_ptr<vxb::TsdfIntegratorBase> create(
+      const Enum& integrator_type, const vxb::TsdfIntegratorBase::Config& config,
+      const SemanticIntegratorBase::SemanticConfig& semantic_config, vxb::Layer<vxb::TsdfVoxel>* tsdf_layer,
+      vxb::Layer<SemanticVoxel>* semantic_layer,
+      const HipSemanticTsdfIntegrator::DeviceOptions& options = HipSemanticTsdfIntegrator::DeviceOptions()) {
+    return create(static_cast<int>(integrator_type), config, semantic_config, tsdf_layer, semantic_layer, options);
+  }
 
  private:
   HipSemanticTsdfIntegratorFactory() = default;

@@ -129,3 +129,35 @@ def test_adapter_pipelined_on_demand_sync(tmp_path, method):
     assert np.array_equal(t["distance"].view(np.uint32), ot["distance"].view(np.uint32))
     assert np.array_equal(t["weight"].view(np.uint32), ot["weight"].view(np.uint32))
     assert np.array_equal(t["color"], ot["color"])
+
+
+REAL_DEMO = os.path.join(ROOT, "integration", "_build", "adapter_demo_real")
+
+
+@pytest.mark.skipif(not os.path.exists(REAL_DEMO), reason="integration/_build not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("method", ["fast_hip", "merged_hip", "enum:3", "enum:2", "fast", "merged"])
+def test_adapter_through_the_real_kimera_factory(tmp_path, method):
+    """the adapter compiled with -DKS_USE_REAL_KIMERA against the reference's own headers, handed
+    out by the reference's own SemanticTsdfIntegratorFactory (its source + integration/factory.patch), driven through
+    the TsdfIntegratorBase virtual.  "fast_hip" / "merged_hip" / the enum values run on the GPU; "fast" / "merged"
+    through the same binary are the reference's CPU integrators — both must give the oracle's map."""
+    frames = _frames()
+    csv, fin, fout = str(tmp_path / "labels.csv"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    R.write_label_csv(csv, synth.default_label_colors())
+    _write_in(fin, frames)
+    res = subprocess.run([REAL_DEMO, method, csv, fin, fout, "1", str(NO_EARLY_OUT)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    idx, t, s = _read_out(fout)
+    is_merged = method in ("merged_hip", "enum:2", "merged")
+    o = O.Oracle(O.default_config(**dict(COMMON, method=1 if is_merged else 0, color_mode=1,
+                                         max_consecutive_ray_collisions=NO_EARLY_OUT)))
+    for f in frames:
+        o.integrate(f.T_G_C, f.xyz, None if is_merged else f.rgba, f.labels)
+    oi, ot, os_ = o.download()
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(s["label"], os_["label"])
+    assert np.array_equal(s["priors"].view(np.uint32), os_["priors"].view(np.uint32))
+    assert np.array_equal(t["distance"].view(np.uint32), ot["distance"].view(np.uint32))
+    assert np.array_equal(t["weight"].view(np.uint32), ot["weight"].view(np.uint32))
+    assert np.array_equal(t["color"], ot["color"])
+    assert np.array_equal(s["color"], os_["color"])
