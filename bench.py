@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_UPDATE = 208         # R+W of TsdfVoxel (12 B) + SemanticVoxel (92 B), SURVEY.md §8d
 BYTES_PER_POINT = 17           # xyz 12 B + rgba 4 B + label 1 B
-PRIME = 10                     # untimed frames per context before the warm-up: kSlots (6) + pipeline_frames (4)
+PRIME = 20                     # untimed frames per context before the warm-up: >= frame slots (12) + pipeline_frames (<= 8)
 MIN_REPEATS = 5
 MIN_TIMED_FRAMES = 100
 MAX_DISTINCT_FRAMES = 96       # the trajectory is replayed cyclically beyond this many frames
@@ -546,7 +546,7 @@ def main():
     n_distinct = min(PRIME + W + R * K, MAX_DISTINCT_FRAMES)
     frames = make_frames(wl, [rank + world * k for k in range(n_distinct)])
     ring = FrameRing(frames, torch, dev)
-    pipeline = 0 if args.no_pipeline else 4   # bag replay = a stream of frames: frame pipelining on
+    pipeline = 0 if args.no_pipeline else int(os.environ.get("KS_BENCH_PIPE", "4"))   # bag replay = a stream of frames: frame pipelining on
 
     reduce_fn = None
     comm = None

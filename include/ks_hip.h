@@ -101,12 +101,12 @@ typedef struct ks_config {
                                        KS_ERR_POOL_FULL remains for a single frame that needs more than the free half. */
   uint32_t max_points;              /* largest cloud per call (buffers grow on demand if exceeded) */
   /* 0 (default): an integrate call returns with its frame fully enqueued and its own statistics.
-   * 1 .. 4: frame pipelining for streams of frames (bag replay): the value is how many calls the second
+   * 1 .. 8: frame pipelining for streams of frames (bag replay): the value is how many calls the second
    *    half of a frame (pair sort + voxel update) lags behind.  A call enqueues stages A and B of its frame
    *    (points .. early-out phases and pair emission) and finishes the frame `pipeline_frames` calls back; the
-   *    one host wait of a frame then overlaps GPU work of later frames, and stage B of up to four
+   *    one host wait of a frame then overlaps GPU work of later frames, and stage B of up to max(4, value)
    *    consecutive frames runs concurrently (one stream each).  Larger values keep the host further ahead
-   *    (best throughput at 4) at the price of that many frames of latency.
+   *    at the price of that many frames of latency.
    *    The statistics a call returns are those of the frames completed since statistics were last
    *    returned (summed if several), i.e. they lag by `pipeline_frames` calls; so do KS_ERR_LABEL_RANGE /
    *    pool errors.  Every other entry point (queries, download, export, ks_synchronize, ks_flush)
@@ -211,8 +211,10 @@ int ks_upload_blocks(ks_ctx* ctx, const int32_t* idx_xyz, size_t n, const void* 
  *   { int32 block_x, block_y, block_z; uint32 linear_index (x + vps*(y + vps*z)); TsdfVoxel 12 B; SemanticVoxel 92 B }
  * with the voxels of one 8^3 device tile contiguous (consecutive records mostly share their block).
  * ks_count_updated_voxels sizes the buffer; ks_download_updated_voxels fills it (a page-locked buffer from
- * ks_host_alloc makes the copy run at link rate) and clears the marks.  Voxels changed through
- * ks_upload_blocks / ks_merge_tiles_device are NOT reported (use ks_download_blocks for those). */
+ * ks_host_alloc makes the copy run at link rate) and clears the marks.  Voxels merged in by ks_merge_tiles_device /
+ * ks_reduce are reported too; voxels written by ks_upload_blocks are not (the host has them).
+ * The voxel-level sync and the block-level sync (ks_get_updated_block_indices) share the per-tile "updated" flag:
+ * a host uses ONE of the two (either call consumes the flag the other one reads). */
 #define KS_VOXEL_RECORD_BYTES 120
 /* The records of one device tile form a run that lies inside ONE host block: with the run list the host
  * finds its blocks without reading the records (runs may be NULL). */
@@ -256,7 +258,10 @@ int ks_tile_owner(uint64_t tile_key, int world);
  * the keys, one for the raw 64 KiB records, over xGMI); the owner folds them into its map in ascending
  * source-rank order (deterministic; weight-averaged TSDF, additive class log-likelihoods, argmax + colour);
  * the sender's copies start over as empty deltas, so the call can be repeated batch after batch without
- * counting anything twice.  Afterwards rank r holds the authoritative state of the tiles it owns. */
+ * counting anything twice.  Afterwards rank r holds the authoritative state of the tiles it owns.
+ * COLLECTIVE: every rank calls it (a rank that returns early on a local error leaves its peers waiting, as with any
+ * RCCL collective).  Steady state: the dirty-tile lists are built on the device, the exchange buffers are kept and
+ * only grow; the host reads the world x world count matrix and the received keys (8 bytes per tile). */
 typedef struct ks_reduce_stats {
   uint64_t tiles_sent, tiles_received, tiles_local, bytes_sent;
 } ks_reduce_stats;

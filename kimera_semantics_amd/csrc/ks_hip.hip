@@ -77,7 +77,7 @@ std::string g_create_error;
 // Everything a later stage reads from an earlier one lives in a FrameSlot.  With
 // ks_config.pipeline_frames the stages of a frame run on separate streams,
 //   A  points -> sort -> dedup / bundles                  (stream)
-//   B  early-out phases, scan, emission, snapshot          (one of kMarchStreams march streams: frame % 4)
+//   B  early-out phases, scan, emission, snapshot          (one of the march streams: frame % n_march)
 //   T  init tiles -> sort pairs -> find_long -> apply       (stream_tail; k_apply_long beside it on stream_long),
 //      enqueued by a helper thread 1..4 calls later
 // so that A, B and T of neighbouring frames execute concurrently: B is a chain of small dependent launches
@@ -85,8 +85,9 @@ std::string g_create_error;
 // update by memory latency, and neither A nor B touches voxel data.  The host's one wait per frame (for the
 // snapshot that sizes T) never idles the GPU.  Six slots rotate; stage A of a frame waits for the tail (and
 // the long runs) that last used its slot.
-constexpr int kSlots = 6;            // frame slots: the tail may lag up to 4 calls (pipeline_frames)
-constexpr int kMarchStreams = 4;
+constexpr int kMaxLag = 8;           // largest ks_config.pipeline_frames
+constexpr int kSlots = kMaxLag + 4;  // frame slots: the tail may lag up to kMaxLag calls
+constexpr int kMarchStreams = 8;
 struct HostSnap {
   Counters c;
   uint32_t n_tiles;
@@ -127,7 +128,7 @@ struct FrameSlot {
 
 // HIP-event sets for ks_profile: recorded in stream order, resolved lazily (before reuse or in
 // ks_profile_get) so that profiling never adds a host wait to a frame.
-constexpr int kProfSets = 8;
+constexpr int kProfSets = 16;
 constexpr int kStageEvents = KS_STAGE_COUNT + 3;  // 0..3 stage A | 4,5 march begin/end | 6 tail begin, 7..10
 struct ProfSet {
   hipEvent_t ev[kStageEvents]{};
@@ -144,7 +145,7 @@ struct ks_ctx {
   // turn (stage B of frame i+1 does not depend on stage B of frame i: tile allocation is atomic, and the
   // early-out set of a frame is private to it when every frame bumps the set offset — then each stream
   // has its own table)
-  hipStream_t stream_march_[kMarchStreams] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream_march_[kMarchStreams] = {};
   int n_march = 1;
   hipStream_t prof_march_stream = nullptr;  // march stream of the frame being enqueued (stage events)
   hipStream_t stream_tail = nullptr;   // stage T; == stream unless pipelined
@@ -155,7 +156,7 @@ struct ks_ctx {
   TileTable table{};
   Pool pool{};
   uint64_t* d_start_set = nullptr;
-  uint64_t* d_observed_[kMarchStreams] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t* d_observed_[kMarchStreams] = {};
   int n_obs = 1;
   uint64_t start_offset = 0, observed_offset = 0;
   int64_t reset_counter = 0;
@@ -225,6 +226,13 @@ struct ks_ctx {
   BoSchedule bo_sched{};
   uint8_t* d_bo_slab = nullptr;
   int bo_epochs = 0;                     // epochs launched per frame (those a cloud of cap_points could reach)
+  // ks_reduce: grow-only exchange scratch (send / receive keys and raw tile records, per-owner counts)
+  int32_t* d_rx_counts = nullptr;
+  size_t rx_world = 0;
+  uint64_t *d_tx_keys = nullptr, *d_rx_keys = nullptr;
+  uint32_t* d_tx_slots = nullptr;
+  uint8_t *d_tx_payload = nullptr, *d_rx_payload = nullptr;
+  size_t cap_tx = 0, cap_rx = 0;
   // scratch of the multi-GPU exchange entry points (slots / group offsets + order / distinct keys)
   uint32_t* d_xchg_u32 = nullptr;
   uint64_t* d_xchg_u64 = nullptr;
@@ -1133,18 +1141,29 @@ int grow_pool(ks_ctx* c) {
     (void)hipGetLastError();
     return KS_OK;  // no memory for a bigger pool: carry on with the current one (exhaustion is reported when it happens)
   }
-  HIPCHK(c, hipMalloc((void**)&upd, new_max));
-  HIPCHK(c, hipMalloc((void**)&dirty, new_max));
-  HIPCHK(c, hipMalloc((void**)&skeys, new_max * sizeof(uint64_t)));
-  HIPCHK(c, hipMalloc((void**)&ent, (size_t)cap * sizeof(TileEntry)));
-  HIPCHK(c, hipMemset(upd, 0, new_max));
-  HIPCHK(c, hipMemset(dirty, 0, new_max));
-  HIPCHK(c, hipMemset(ent, 0xff, (size_t)cap * sizeof(TileEntry)));
-  if (nt) {
-    HIPCHK(c, hipMemcpy(vox, c->pool.vox, (size_t)nt * kTileVoxels * 8 * sizeof(uint4), hipMemcpyDeviceToDevice));
-    HIPCHK(c, hipMemcpy(upd, c->pool.updated, nt, hipMemcpyDeviceToDevice));
-    HIPCHK(c, hipMemcpy(dirty, c->pool.dirty, nt, hipMemcpyDeviceToDevice));
-    HIPCHK(c, hipMemcpy(skeys, c->table.slot_keys, (size_t)nt * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+  // (a failure part-way leaves the old pool in place and frees what was allocated for the new one)
+  auto fill = [&]() -> hipError_t {
+    hipError_t e;
+    if ((e = hipMalloc((void**)&upd, new_max)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&dirty, new_max)) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&skeys, new_max * sizeof(uint64_t))) != hipSuccess) return e;
+    if ((e = hipMalloc((void**)&ent, (size_t)cap * sizeof(TileEntry))) != hipSuccess) return e;
+    if ((e = hipMemset(upd, 0, new_max)) != hipSuccess) return e;
+    if ((e = hipMemset(dirty, 0, new_max)) != hipSuccess) return e;
+    if ((e = hipMemset(ent, 0xff, (size_t)cap * sizeof(TileEntry))) != hipSuccess) return e;
+    if (nt) {
+      if ((e = hipMemcpy(vox, c->pool.vox, (size_t)nt * kTileVoxels * 8 * sizeof(uint4), hipMemcpyDeviceToDevice)) != hipSuccess) return e;
+      if ((e = hipMemcpy(upd, c->pool.updated, nt, hipMemcpyDeviceToDevice)) != hipSuccess) return e;
+      if ((e = hipMemcpy(dirty, c->pool.dirty, nt, hipMemcpyDeviceToDevice)) != hipSuccess) return e;
+      if ((e = hipMemcpy(skeys, c->table.slot_keys, (size_t)nt * sizeof(uint64_t), hipMemcpyDeviceToDevice)) != hipSuccess) return e;
+    }
+    return hipSuccess;
+  };
+  if (const hipError_t e = fill(); e != hipSuccess) {
+    for (void* q : {(void*)vox, (void*)upd, (void*)dirty, (void*)skeys, (void*)ent})
+      if (q) (void)hipFree(q);
+    c->err = std::string("grow_pool: ") + hipGetErrorString(e);
+    return KS_ERR_HIP;
   }
   (void)hipFree(c->pool.vox);
   (void)hipFree(c->pool.updated);
@@ -1222,7 +1241,7 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
   // (its snapshot is long there: the host never waits for the march that is still running, and the
   // next call can enqueue stage A while this frame's march is in flight); the statistics returned
   // are those of the frames completed here
-  const uint64_t lag = (uint64_t)std::min(std::max(cfg.pipeline_frames, 1), 4);
+  const uint64_t lag = (uint64_t)std::min(std::max(cfg.pipeline_frames, 1), kMaxLag);
   FrameSlot& S = c->slot[c->frame_no % kSlots];
   if (S.pending && (rc = frame_tail(c, S))) return rc;  // cannot happen: the slot's frame is 4 calls old
   const uint64_t this_frame = c->frame_no;
@@ -1284,6 +1303,12 @@ int collect_block_indices(ks_ctx* c, bool only_updated, bool reset, std::vector<
 static int insert_tiles(ks_ctx* c, const uint64_t* d_keys, size_t n) {
   int rc;
   if ((rc = quiesce(c))) return rc;
+  // as for frames: keep at least half of the pool free for what is coming (all n keys may be new tiles)
+  while ((size_t)c->tiles_initialised + n > (size_t)c->cfg.max_tiles / 2) {
+    const uint32_t before = c->cfg.max_tiles;
+    if ((rc = grow_pool(c))) return rc;
+    if (c->cfg.max_tiles == before) break;  // at the limit, or no memory: exhaustion is reported if it happens
+  }
   FrameSlot& S = c->slot[0];
   HIPCHK(c, hipMemsetAsync(S.d_counters, 0, sizeof(Counters), c->stream));
   hipLaunchKernelGGL(k_insert_tiles, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->table, S.d_counters,
@@ -1420,7 +1445,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     else CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
   }
   if (c->cfg.pipeline_frames) {
-    c->n_march = kMarchStreams;
+    c->n_march = std::min(kMarchStreams, std::max(4, c->cfg.pipeline_frames));  // stage B of that many consecutive frames can overlap
     if (const char* ms = getenv("KS_MARCH_STREAMS")) c->n_march = std::min(kMarchStreams, std::max(1, atoi(ms)));  // diagnostics
     {
       // KS_STREAM_PRIORITY (diagnostics): m = march streams at the highest priority, t = tail, l = long at the lowest
@@ -1536,13 +1561,13 @@ void ks_destroy(ks_ctx* c) {
     if (sm && sm != c->stream) (void)hipStreamSynchronize(sm);
   if (c->stream_long) (void)hipStreamSynchronize(c->stream_long);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->pool.dirty, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_observed_[3], c->d_color_lut,
+  void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->pool.dirty, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_observed_[3], c->d_observed_[4], c->d_observed_[5], c->d_observed_[6], c->d_observed_[7], c->d_color_lut,
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list_[0], c->d_long_list_[1], c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_pairs2_[0], c->d_pairs2_[1], c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux, c->d_bo_slab,
                   c->d_eo_keys[0], c->d_eo_keys[1], c->d_eo_vals[0], c->d_eo_vals[1], c->d_eo_range, c->d_eo_plain, c->d_eo_lp, c->d_eo_bt,
-                  c->d_eo_state};
+                  c->d_eo_state, c->d_rx_counts, c->d_tx_keys, c->d_rx_keys, c->d_tx_slots, c->d_tx_payload, c->d_rx_payload};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& S : c->slot)
@@ -2081,6 +2106,31 @@ inline uint64_t splitmix64(uint64_t x) {
 
 int ks_tile_owner(uint64_t tile_key, int world) { return world > 0 ? (int)(splitmix64(tile_key) % (uint64_t)world) : 0; }
 
+// grow-only scratch of ks_reduce (no allocation in the steady state)
+static int ensure_reduce_scratch(ks_ctx* c, size_t n_send, size_t n_recv, int world) {
+  int rc;
+  if ((size_t)world > c->rx_world) {
+    if ((rc = dev_alloc(c, &c->d_rx_counts, (size_t)(world + 3) * world))) return rc;  // [world] own | [world x world] all | [world] offsets | [world] cursors
+    c->rx_world = (size_t)world;
+  }
+  if (n_send > c->cap_tx) {
+    const size_t cap = std::max<size_t>(n_send + n_send / 2, 64);
+    if ((rc = dev_alloc(c, &c->d_tx_keys, cap))) return rc;
+    if ((rc = dev_alloc(c, &c->d_tx_slots, cap))) return rc;
+    if ((rc = dev_alloc(c, &c->d_tx_payload, cap * (size_t)KS_TILE_BYTES))) return rc;
+    c->cap_tx = cap;
+  }
+  if (n_recv > c->cap_rx) {
+    const size_t cap = std::max<size_t>(n_recv + n_recv / 2, 64);
+    if ((rc = dev_alloc(c, &c->d_rx_keys, cap))) return rc;
+    if ((rc = dev_alloc(c, &c->d_rx_payload, cap * (size_t)KS_TILE_BYTES))) return rc;
+    c->cap_rx = cap;
+  }
+  return KS_OK;
+}
+
+// COLLECTIVE: every rank of the communicator must call it (a rank that returns early on a local error leaves its
+// peers waiting in the exchange, as with any RCCL collective).
 int ks_reduce(ks_ctx* c, void* rccl_comm, int rank, int world, ks_reduce_stats* stats) {
   if (!c || world < 1 || rank < 0 || rank >= world || (world > 1 && !rccl_comm)) return KS_ERR_INVALID_ARG;
   if (stats) std::memset(stats, 0, sizeof(*stats));
@@ -2088,15 +2138,11 @@ int ks_reduce(ks_ctx* c, void* rccl_comm, int rank, int world, ks_reduce_stats* 
   int rc;
   if ((rc = quiesce(c))) return rc;
   const uint32_t nt = c->tiles_initialised;
-  std::vector<uint64_t> keys(nt);
-  std::vector<uint8_t> dirty(nt);
-  if (nt) {
-    HIPCHK(c, hipMemcpy(keys.data(), c->table.slot_keys, nt * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(dirty.data(), c->pool.dirty, nt, hipMemcpyDeviceToHost));
-  }
   if (stats) stats->tiles_local = nt;
+  hipStream_t st = c->stream;
   if (world == 1) {  // everything is owned here: nothing travels
-    if (nt) HIPCHK(c, hipMemset(c->pool.dirty, 0, nt));
+    if (nt) HIPCHK(c, hipMemsetAsync(c->pool.dirty, 0, nt, st));
+    HIPCHK(c, hipStreamSynchronize(st));
     return KS_OK;
   }
   std::string why;
@@ -2105,90 +2151,69 @@ int ks_reduce(ks_ctx* c, void* rccl_comm, int rank, int world, ks_reduce_stats* 
     return KS_ERR_UNSUPPORTED;
   }
   ncclComm_t comm = (ncclComm_t)rccl_comm;
-  hipStream_t st = c->stream;
-  // 1) what goes where: tiles touched since the last reduce that another rank owns, grouped by owner
-  std::vector<std::vector<uint32_t>> to(world);
-  for (uint32_t s = 0; s < nt; ++s) {
-    if (!dirty[s]) continue;
-    const int o = ks_tile_owner(keys[s], world);
-    if (o != rank) to[o].push_back(s);
-  }
-  std::vector<int32_t> send_counts(world, 0);
-  std::vector<uint32_t> slots_cat;
-  std::vector<uint64_t> keys_cat;
-  for (int d = 0; d < world; ++d) {
-    send_counts[d] = (int32_t)to[d].size();
-    for (uint32_t s : to[d]) {
-      slots_cat.push_back(s);
-      keys_cat.push_back(keys[s]);
-    }
-  }
-  const size_t n_send = slots_cat.size();
-  // 2) every rank learns every rank's send counts (world x world int32)
-  int32_t* d_counts = nullptr;
-  HIPCHK(c, hipMalloc((void**)&d_counts, (size_t)(world + 1) * world * sizeof(int32_t)));
-  HIPCHK(c, hipMemcpyAsync(d_counts, send_counts.data(), world * sizeof(int32_t), hipMemcpyHostToDevice, st));
-  NCCLCHK(c, g_rccl.all_gather(d_counts, d_counts + world, (size_t)world, ncclInt32, comm, st));
+  if ((rc = ensure_reduce_scratch(c, 0, 0, world))) return rc;
+  // 1) what goes where, counted on the device: tiles touched since the last reduce that another rank owns;
+  //    every rank learns every rank's counts (world x world int32) in the same breath
+  int32_t* d_own = c->d_rx_counts;
+  int32_t* d_all = d_own + world;
+  uint32_t* d_offs = (uint32_t*)(d_all + (size_t)world * world);
+  uint32_t* d_cursor = d_offs + world;
+  HIPCHK(c, hipMemsetAsync(d_own, 0, (size_t)(world + 3) * world * sizeof(int32_t), st));
+  const uint32_t nb = (nt + 255) / 256;
+  if (nt)
+    hipLaunchKernelGGL(k_dirty_by_owner, dim3(nb), dim3(256), 0, st, c->pool, (const uint64_t*)c->table.slot_keys, nt, (uint32_t)rank,
+                       (uint32_t)world, 0, d_own, (const uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint64_t*)nullptr);
+  NCCLCHK(c, g_rccl.all_gather(d_own, d_all, (size_t)world, ncclInt32, comm, st));
   std::vector<int32_t> all_counts((size_t)world * world);
-  HIPCHK(c, hipMemcpyAsync(all_counts.data(), d_counts + world, all_counts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(all_counts.data(), d_all, all_counts.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
-  (void)hipFree(d_counts);
-  std::vector<size_t> recv_counts(world), recv_off(world + 1, 0), send_off(world + 1, 0);
-  for (int src = 0; src < world; ++src) {
-    recv_counts[src] = (size_t)all_counts[(size_t)src * world + rank];
-    recv_off[src + 1] = recv_off[src] + recv_counts[src];
-    send_off[src + 1] = send_off[src] + (size_t)send_counts[src];
+  std::vector<size_t> send_counts(world), recv_counts(world), recv_off(world + 1, 0), send_off(world + 1, 0);
+  for (int p = 0; p < world; ++p) {
+    send_counts[p] = (size_t)all_counts[(size_t)rank * world + p];
+    recv_counts[p] = (size_t)all_counts[(size_t)p * world + rank];
+    send_off[p + 1] = send_off[p] + send_counts[p];
+    recv_off[p + 1] = recv_off[p] + recv_counts[p];
   }
-  const size_t n_recv = recv_off[world];
-  // 3) keys and raw tile records: one grouped exchange each — on a fully connected xGMI node a rank talks
-  //    to all its peers at once (a ring all-reduce would be per-link bound and move every tile through every rank)
-  uint64_t *d_ksend = nullptr, *d_krecv = nullptr;
-  uint8_t *d_psend = nullptr, *d_precv = nullptr;
-  uint32_t* d_slots = nullptr;
-  HIPCHK(c, hipMalloc((void**)&d_ksend, std::max<size_t>(n_send, 1) * 8));
-  HIPCHK(c, hipMalloc((void**)&d_krecv, std::max<size_t>(n_recv, 1) * 8));
-  HIPCHK(c, hipMalloc((void**)&d_psend, std::max<size_t>(n_send, 1) * (size_t)KS_TILE_BYTES));
-  HIPCHK(c, hipMalloc((void**)&d_precv, std::max<size_t>(n_recv, 1) * (size_t)KS_TILE_BYTES));
-  HIPCHK(c, hipMalloc((void**)&d_slots, std::max<size_t>(n_send, 1) * 4));
-  auto free_all = [&]() {
-    (void)hipFree(d_ksend); (void)hipFree(d_krecv); (void)hipFree(d_psend); (void)hipFree(d_precv); (void)hipFree(d_slots);
-  };
+  const size_t n_send = send_off[world], n_recv = recv_off[world];
+  if ((rc = ensure_reduce_scratch(c, n_send, n_recv, world))) return rc;
+  // 2) the send list (slots + keys grouped by owner) and the raw tile records, all on the device
   if (n_send) {
-    HIPCHK(c, hipMemcpyAsync(d_ksend, keys_cat.data(), n_send * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(c, hipMemcpyAsync(d_slots, slots_cat.data(), n_send * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_export_tiles, dim3((uint32_t)n_send), dim3(512), 0, st, c->pool, d_slots, (uint4*)d_psend);
+    std::vector<uint32_t> offs32(world);
+    for (int p = 0; p < world; ++p) offs32[p] = (uint32_t)send_off[p];
+    HIPCHK(c, hipMemcpyAsync(d_offs, offs32.data(), world * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_dirty_by_owner, dim3(nb), dim3(256), 0, st, c->pool, (const uint64_t*)c->table.slot_keys, nt, (uint32_t)rank,
+                       (uint32_t)world, 1, d_own, (const uint32_t*)d_offs, d_cursor, c->d_tx_slots, c->d_tx_keys);
+    hipLaunchKernelGGL(k_export_tiles, dim3((uint32_t)n_send), dim3(512), 0, st, c->pool, (const uint32_t*)c->d_tx_slots,
+                       (uint4*)c->d_tx_payload);
+    HIPCHK(c, hipStreamSynchronize(st));  // (offs32 is a stack-side buffer)
   }
+  // 3) keys and raw tile records: one grouped exchange — on a fully connected xGMI node a rank talks to all its
+  //    peers at once (a ring all-reduce would be per-link bound and move every tile through every rank)
   NCCLCHK(c, g_rccl.group_start());
   for (int peer = 0; peer < world; ++peer) {
     if (peer == rank) continue;
     if (send_counts[peer]) {
-      NCCLCHK(c, g_rccl.send(d_ksend + send_off[peer], (size_t)send_counts[peer], ncclUint64, peer, comm, st));
-      NCCLCHK(c, g_rccl.send(d_psend + send_off[peer] * (size_t)KS_TILE_BYTES, (size_t)send_counts[peer] * KS_TILE_BYTES, ncclUint8,
-                             peer, comm, st));
+      NCCLCHK(c, g_rccl.send(c->d_tx_keys + send_off[peer], send_counts[peer], ncclUint64, peer, comm, st));
+      NCCLCHK(c, g_rccl.send(c->d_tx_payload + send_off[peer] * (size_t)KS_TILE_BYTES, send_counts[peer] * (size_t)KS_TILE_BYTES,
+                             ncclUint8, peer, comm, st));
     }
     if (recv_counts[peer]) {
-      NCCLCHK(c, g_rccl.recv(d_krecv + recv_off[peer], recv_counts[peer], ncclUint64, peer, comm, st));
-      NCCLCHK(c, g_rccl.recv(d_precv + recv_off[peer] * (size_t)KS_TILE_BYTES, recv_counts[peer] * KS_TILE_BYTES, ncclUint8, peer, comm,
-                             st));
+      NCCLCHK(c, g_rccl.recv(c->d_rx_keys + recv_off[peer], recv_counts[peer], ncclUint64, peer, comm, st));
+      NCCLCHK(c, g_rccl.recv(c->d_rx_payload + recv_off[peer] * (size_t)KS_TILE_BYTES, recv_counts[peer] * (size_t)KS_TILE_BYTES,
+                             ncclUint8, peer, comm, st));
     }
   }
   NCCLCHK(c, g_rccl.group_end());
   std::vector<uint64_t> k_host(n_recv);
-  if (n_recv) HIPCHK(c, hipMemcpyAsync(k_host.data(), d_krecv, n_recv * 8, hipMemcpyDeviceToHost, st));
+  if (n_recv) HIPCHK(c, hipMemcpyAsync(k_host.data(), c->d_rx_keys, n_recv * 8, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipStreamSynchronize(st));
   // 4) the owner folds what it received into its map, tiles of one key in ascending source-rank order
   //    (the receive buffer is ordered by source rank), in one launch
-  if (n_recv && (rc = ks_merge_tiles_device(c, k_host.data(), n_recv, d_precv))) {
-    free_all();
-    return rc;
-  }
+  if (n_recv && (rc = ks_merge_tiles_device(c, k_host.data(), n_recv, c->d_rx_payload))) return rc;
   // 5) what was sent starts over as an empty delta here: a later reduce cannot count it twice
-  if (n_send) {
-    hipLaunchKernelGGL(k_reset_tiles, dim3((uint32_t)n_send), dim3(512), 0, st, c->pool, d_slots);
-    HIPCHK(c, hipStreamSynchronize(st));
-  }
-  HIPCHK(c, hipMemset(c->pool.dirty, 0, c->tiles_initialised));  // owned tiles: authoritative here, nothing pending
-  free_all();
+  if (n_send) hipLaunchKernelGGL(k_reset_tiles, dim3((uint32_t)n_send), dim3(512), 0, st, c->pool, (const uint32_t*)c->d_tx_slots);
+  HIPCHK(c, hipMemsetAsync(c->pool.dirty, 0, c->tiles_initialised, st));  // owned tiles: authoritative here, nothing pending
+  HIPCHK(c, hipStreamSynchronize(st));
   if (stats) {
     stats->tiles_sent = n_send;
     stats->tiles_received = n_recv;

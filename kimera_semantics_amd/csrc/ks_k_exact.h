@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256) k_eo_emit(const FrameParams* __restrict__
                                                  unsigned long long cap, const Counters* C, EoState* __restrict__ st) {
   extern __shared__ unsigned long long s_bt[];
   __shared__ float s_e[4][3 * kES];
-  const FrameParams& F = *Fp;
+  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   if (blockIdx.x != 0 && blockIdx.x * 4u * (uint32_t)RPW >= C->n_rays) return;
   const unsigned long long total = eo_fold_totals(bt, (F.n + kScanBlock - 1u) / kScanBlock, s_bt);
   if (blockIdx.x == 0 && threadIdx.x == 0) st->n_marks = total;
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) k_eo_eval(const FrameParams* __restrict__
                                                  const Counters* C, EoState* __restrict__ st) {
   __shared__ float s_e[4][3 * kES];
   __shared__ unsigned long long s_keys[4][64];
-  const FrameParams& F = *Fp;
+  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
   const uint32_t r0 = (blockIdx.x * 4u + wave) * (uint32_t)RPW;
   if (r0 >= C->n_rays) return;

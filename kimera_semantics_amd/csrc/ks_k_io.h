@@ -52,6 +52,33 @@ __global__ void __launch_bounds__(256) k_rehash_tiles(TileTable T, const uint64_
   }
 }
 
+// ks_reduce: the tiles touched since the last reduce that ANOTHER rank owns, grouped by owner.  Owner of a tile =
+// splitmix64(key) % world (ks_tile_owner).  Pass 0 counts per owner; pass 1 (offsets known) writes slots and keys.
+__device__ __forceinline__ uint32_t tile_owner_dev(uint64_t x, uint32_t world) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x % (uint64_t)world);
+}
+__global__ void __launch_bounds__(256) k_dirty_by_owner(Pool P, const uint64_t* __restrict__ slot_keys, uint32_t nt, uint32_t rank,
+                                                        uint32_t world, int pass, int32_t* __restrict__ counts,
+                                                        const uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor,
+                                                        uint32_t* __restrict__ out_slots, uint64_t* __restrict__ out_keys) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nt || !P.dirty[s]) return;
+  const uint64_t key = slot_keys[s];
+  const uint32_t o = tile_owner_dev(key, world);
+  if (o == rank) return;
+  if (pass == 0) {
+    atomicAdd(&counts[o], 1);
+  } else {
+    const uint32_t at = offs[o] + atomicAdd(&cursor[o], 1u);
+    out_slots[at] = s;
+    out_keys[at] = key;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_insert_tiles(TileTable T, Counters* C, const uint64_t* __restrict__ keys, uint32_t n) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) tile_insert(T, C, keys[i]);
@@ -117,7 +144,8 @@ __global__ void __launch_bounds__(512) k_merge_tiles(TileTable T, Pool P, const 
         if (p2 > bv) { bv = p2; bi = cbase + 2u; }
         if (p3 > bv) { bv = p3; bi = cbase + 3u; }
       } else {
-        b.y = b.z = b.w = 0u;
+        b.y = 1u;  // dword 25: written since the last voxel-level host sync (merged voxels are reported by it too)
+        b.z = b.w = 0u;
       }
     }
 #pragma unroll

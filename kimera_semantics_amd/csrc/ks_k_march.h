@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
                                                        const Counters* C) {
   // stage B kernels read the frame's parameters from device memory: the launch sequence of a frame slot is
   // then identical from frame to frame and is replayed as a captured graph
-  const FrameParams& F = *Fp;
+  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   const uint64_t* __restrict__ observed = F.observed;
   extern __shared__ unsigned long long s_test[];
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(256) k_mark(const FrameParams* __restrict__ Fp
                                               const uint32_t* __restrict__ ray_list, const RayDesc* __restrict__ rays,
                                               const uint32_t* __restrict__ cnt, const Counters* C) {
   __shared__ float s_e[4][3 * kES];
-  const FrameParams& F = *Fp;
+  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   uint64_t* __restrict__ observed = F.observed;
   if (C->err & (kErrLabel | kErrIndex)) return;
   const uint32_t lane = lane_id();
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Fp
                                               const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ lp,
                                               const unsigned long long* __restrict__ bt, TileTable T, Pool P,
                                               uint64_t* __restrict__ pairs, unsigned long long pairs_cap, Counters* C) {
-  const FrameParams& F = *Fp;
+  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   // launched over an upper bound of rays: blocks past the live ray count leave at once (block 0 stays:
   // it publishes the total)
   if (blockIdx.x != 0 && blockIdx.x * (256u / LPR) >= C->n_rays) return;
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(256) k_emit_lane(const FrameParams* __restrict
                                                    const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ lp,
                                                    const unsigned long long* __restrict__ bt, TileTable T, Pool P,
                                                    uint64_t* __restrict__ pairs, unsigned long long pairs_cap, Counters* C) {
-  const FrameParams& F = *Fp;
+  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   if (blockIdx.x != 0 && blockIdx.x * 4u * (uint32_t)RPW >= C->n_rays) return;
   extern __shared__ unsigned long long s_bt[];
   __shared__ unsigned long long s_carry;
@@ -792,7 +792,7 @@ template <int LPR>
 __global__ void __launch_bounds__(256) k_count_grazing(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ ray_list,
                                                        const RayDesc* __restrict__ rays, uint32_t* __restrict__ cnt,
                                                        const Counters* C) {
-  const FrameParams& F = *Fp;
+  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   const LaneGroup<LPR> G;
   const uint32_t r = (blockIdx.x * 256u + threadIdx.x) / LPR;
   if (r >= C->n_rays) return;

@@ -1,0 +1,105 @@
+"""-m gpu: the MULTI-RANK path of ks_reduce (include/ks_hip.h) — count exchange, per-peer offsets, grouped
+send / receive of keys and raw tile records, owner merge in ascending source-rank order, sender reset, repeated
+reduce — with 2 and 3 ranks.  A development box has one GPU and RCCL refuses two ranks on one device, so the ranks
+are PROCESSES SHARING THE GPU and the communicator is the test double tests/mock_rccl (same seven entry points,
+messages through /dev/shm); the real RCCL path is exercised with one rank in test_parallel_gpu.py and with N ranks
+by the driver's multi-GPU bench.  Expected result: the same exchange emulated inside one process with the
+tile primitives (ks_export_tiles_device / ks_merge_tiles_device / ks_reset_tiles), bit for bit."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from kimera_semantics_amd import binding as B
+from kimera_semantics_amd import parallel as PAR
+from tests.reduce_worker import config_kw, export_all, frames_of
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MOCK = os.path.join(ROOT, "tests", "mock_rccl", "libmock_rccl.so")
+
+
+def _emulate(world):
+    """The protocol with in-process 'ranks': owner r receives, in ascending source-rank order, every tile another
+    rank holds that r owns (untouched tiles are empty deltas: merging them is a no-op); the senders reset them."""
+    import torch
+    hs = [B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **config_kw())) for _ in range(world)]
+    for batch in range(2):
+        for r in range(world):
+            for f in frames_of(r, world, batch):
+                hs[r].integrate(f.T_G_C, f.xyz, None, f.labels)
+        exported = []
+        for r in range(world):
+            keys = hs[r].tile_keys()
+            buf = torch.empty((len(keys), 16384), dtype=torch.int32, device="cuda")
+            hs[r].export_tiles(np.arange(len(keys), dtype=np.uint32), buf.data_ptr())
+            exported.append((keys, buf, PAR.owner_of(keys, world)))
+        torch.cuda.synchronize()
+        for dst in range(world):
+            ks, bufs = [], []
+            for src in range(world):
+                if src == dst:
+                    continue
+                keys, buf, own = exported[src]
+                sel = np.nonzero(own == dst)[0]
+                ks.append(keys[sel])
+                bufs.append(buf[torch.from_numpy(sel.astype(np.int64)).cuda()])
+            k = np.concatenate(ks)
+            if len(k):
+                hs[dst].merge_tiles(k, torch.cat(bufs, dim=0).contiguous().data_ptr())
+        for src in range(world):
+            keys, _, own = exported[src]
+            hs[src].reset_tiles(np.nonzero(own != src)[0].astype(np.uint32))
+    out = []
+    for r in range(world):
+        keys, rec = export_all(hs[r], torch)
+        out.append(dict(zip(keys.tolist(), rec[:, :, :25])))
+        hs[r].close()
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ks_reduce_multi_rank_equals_emulation(tmp_path, world):
+    if not os.path.exists(MOCK):
+        pytest.fail("tests/mock_rccl/libmock_rccl.so not built: run __graft_entry__.build()")
+    lib = C.CDLL(MOCK)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_byte * 128)]
+    uid = UniqueId()
+    assert lib.ncclGetUniqueId(C.byref(uid)) == 0
+    env = dict(os.environ, KS_RCCL_LIB=MOCK)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "reduce_worker.py"), str(r), str(world), bytes(uid).hex(), str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung")
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    want = _emulate(world)
+    total_sent = total_recv = 0
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        total_sent += int(got["sent"].sum())
+        total_recv += int(got["received"].sum())
+        assert int(got["sent"][0]) > 0 and int(got["sent"][1]) > 0, "both reduces must move tiles"
+        gk = got["keys"].tolist()
+        own = PAR.owner_of(got["keys"], world)
+        owned = {k: got["rec"][i] for i, k in enumerate(gk) if own[i] == r}
+        want_owned = {k: v for k, v in want[r].items() if PAR.owner_of(np.array([k], dtype=np.uint64), world)[0] == r}
+        assert sorted(owned) == sorted(want_owned)
+        for k in owned:
+            assert np.array_equal(owned[k], want_owned[k]), f"rank {r} tile {k}"
+        # what a rank sent away is an empty delta again
+        for i, k in enumerate(gk):
+            if own[i] != r:
+                assert (got["rec"][i][:, 3] == 255).all(), f"rank {r} kept content of tile {k} it does not own"
+    assert total_sent == total_recv
