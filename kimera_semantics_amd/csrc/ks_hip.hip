@@ -10,7 +10,7 @@
 //   stage A  points  : one lane per point — validity, T_G_C * p, start-voxel / end-voxel key  (k_points_*)
 //            sort    : radix sort of point keys (start-voxel dedup slots | end-voxel bundles)   (ks_radix_sort.h)
 //            rays    : exact sequential-equivalent dedup (fast) or per-bundle merge (merged)   (k_dedup / k_bundles)
-//   stage B  early-out: (fast) ordered phases of k_test + k_mark decide how far every ray gets        (ks_k_march.h)
+//   stage B  early-out: (fast) ordered phases of k_test decide how far every ray gets (and enter its marks)        (ks_k_march.h)
 //            emit    : scan of the per-position update counts, then every ray writes its (voxel, position)
 //                      pairs at its own offset, allocating tiles in the spatial hash              (k_scan_local, k_emit_lane)
 //            publish : pair / ray / tile counts -> pinned host memory                           (k_publish)
@@ -478,11 +478,11 @@ int reset_set(ks_ctx* c, uint64_t* d_set0, uint64_t* offset, bool observed) {
     for (int t = 0; t < (observed ? c->n_obs : 1); ++t) {
       uint64_t* d_set = observed ? c->d_observed_[t] : d_set0;
       if (full) {
-        HIPCHK(c, hipMemsetAsync(d_set, 0, sizeof(uint64_t) << kSetBits, c->stream));
+        HIPCHK(c, hipMemsetAsync(d_set, 0, (observed ? 2 : 1) * (sizeof(uint64_t) << kSetBits), c->stream));
         const uint64_t poison = observed ? kObsPoison : ~0ull;
         HIPCHK(c, hipMemcpyAsync(d_set, &poison, sizeof(poison), hipMemcpyHostToDevice, c->stream));
       } else {
-        hipLaunchKernelGGL(k_obs_retag, dim3((1u << kSetBits) / 256), dim3(256), 0, c->stream, d_set);
+        hipLaunchKernelGGL(k_obs_retag, dim3((2u << kSetBits) / 256), dim3(256), 0, c->stream, d_set);
       }
     }
     if (observed && full && c->d_eo_plain) {  // resetApproxSet's full reset of the table the exact mode keeps verbatim
@@ -579,7 +579,7 @@ void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max, 
   const FrameParams* dF = S.d_F;
   if (c->uses_early_out && part != 2) {
     // ordered-phase early-out: per phase, k_test decides how far the phase's rays get against the set as it
-    // stood when the phase began, then k_mark enters their marks (ks_k_march.h)
+    // stood when the phase began and enters their marks (ks_k_march.h)
     const uint32_t n_gen = (uint32_t)((n + kChains - 1) / kChains);
     const std::vector<uint32_t> B = phase_bounds(n_gen, cfg.early_out_phase_growth);
     for (size_t j = 0; j < B.size(); ++j) {
@@ -591,12 +591,6 @@ void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max, 
       const uint32_t wpb = lds_wave * 4 <= 60 * 1024 ? 4u : lds_wave * 2 <= 60 * 1024 ? 2u : 1u;  // wavefronts per block
       hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb), dim3(64 * wpb), lds_wave * wpb, sm, dF, g0, g1, steps_cap, S.d_live,
                          S.d_rays, S.d_cnt, S.d_counters);
-      if (S.wide)
-        hipLaunchKernelGGL(k_mark<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), 0, sm, dF, p0, p1, S.d_ray_list, S.d_rays, S.d_cnt,
-                           S.d_counters);
-      else
-        hipLaunchKernelGGL(k_mark<64>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, sm, dF, p0, p1, S.d_ray_list, S.d_rays,
-                           S.d_cnt, S.d_counters);
     }
   }
   if (part == 1) return;
@@ -1489,8 +1483,8 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   c->n_obs = (c->n_march > 1 && uses_early_out && cfg->clear_checks_every_n_frames <= 1) ? c->n_march : 1;
   if (uses_early_out && c->n_obs == 1) c->n_march = 1;  // shared table: stage B of consecutive frames stays in order
   for (int t = 0; t < c->n_obs; ++t) {
-    CRCHK(hipMalloc((void**)&c->d_observed_[t], sizeof(uint64_t) << kSetBits));
-    CRCHK(hipMemset(c->d_observed_[t], 0, sizeof(uint64_t) << kSetBits));
+    CRCHK(hipMalloc((void**)&c->d_observed_[t], 2 * (sizeof(uint64_t) << kSetBits)));   // {newest, older} per slot
+    CRCHK(hipMemset(c->d_observed_[t], 0, 2 * (sizeof(uint64_t) << kSetBits)));
     CRCHK(hipMemcpy(c->d_observed_[t], &kObsPoison, 8, hipMemcpyHostToDevice));
   }
   CRCHK(hipMemset(c->d_start_set, 0, sizeof(uint64_t) << kSetBits));
@@ -2238,7 +2232,7 @@ int ks_clear(ks_ctx* c) {
   // a cleared context behaves like a fresh one: both approximate sets as their constructor leaves them
   HIPCHK(c, hipMemset(c->d_start_set, 0, sizeof(uint64_t) << kSetBits));
   for (int t = 0; t < c->n_obs; ++t) {
-    HIPCHK(c, hipMemset(c->d_observed_[t], 0, sizeof(uint64_t) << kSetBits));
+    HIPCHK(c, hipMemset(c->d_observed_[t], 0, 2 * (sizeof(uint64_t) << kSetBits)));
     HIPCHK(c, hipMemcpy(c->d_observed_[t], &kObsPoison, 8, hipMemcpyHostToDevice));
   }
   const uint64_t poison = ~0ull;

@@ -6,8 +6,7 @@
 // is handled by a GROUP OF LANES of one wavefront: every lane runs the ray caster forward to its own
 // step (the DDA state is a handful of registers; its float accumulation is replayed exactly), so one
 // memory round trip serves 16 or 64 consecutive voxels of the ray.
-//   k_test   (fast, early-out on) decides how far every ray gets:  ORDERED-PHASE schedule, below
-//   k_mark   enters a phase's marks into the shared approximate set
+//   k_test   (fast, early-out on) decides how far every ray gets and enters its marks:  ORDERED-PHASE schedule, below
 //   k_scan_local + k_emit: exclusive scan of the per-ray update counts in integration order, then
 //            every ray writes its (voxel, ray) keys at its own offset — the pair list comes out in
 //            integration order, so the sort that follows only has to group by voxel (stable)
@@ -26,7 +25,13 @@ namespace ksk {
 // "last writer wins" outcome.  Entries of an older offset generation can never match in the
 // reference (the slot depends on the offset); here they are recognised by their tag.
 // 0 = never written since the last full reset; position field 0 with a non-zero hash field = poison /
-// retired entry.  Neither matches anything.  (The reference's zero-initialised slots "contain" hash 0 —
+// retired entry.  Neither matches anything.
+// A slot is TWO such entries, 16 bytes: {newest, older}.  k_test enters a ray's marks itself, with atomicMax on
+// `newest`, while other wavefronts of the same launch are still testing — and a test must see the set AS IT STOOD
+// WHEN THE PHASE BEGAN.  So a test that finds a current-phase mark in `newest` (same frame tag, position inside the
+// phase) reads `older` instead, which holds the newest mark from BEFORE the phase: every test that loads an older-
+// phase `newest` saves it there first (atomicMax; idempotent), and a wavefront waits for its saves to complete
+// (s_waitcnt vmcnt(0)) before it enters marks of its own.  Both entries share one 16-byte line: one load per test.  (The reference's zero-initialised slots "contain" hash 0 —
 // the voxel whose hash is 0 looks already observed until something overwrites its slot; the ordered-
 // phase schedule does not reproduce that one-voxel artefact, which lets every frame in flight use a
 // table of its own.)
@@ -47,7 +52,7 @@ __device__ __forceinline__ bool obs_match(uint64_t e, uint32_t h, uint32_t tag_l
 
 __global__ void __launch_bounds__(256) k_obs_retag(uint64_t* __restrict__ set) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (1u << kSetBits)) {
+  if (i < (2u << kSetBits)) {  // both entries of every slot
     const uint64_t e = set[i];
     if (e != 0ull) set[i] = kObsRetired;
   }
@@ -180,6 +185,9 @@ constexpr uint32_t kCntBroke = 1u << 31;  // cnt[] flag: the ray stopped on a vo
 //      consecutive-collision rule on the 16-bit hit mask, the ray's marks.  A ray not decided within 16
 //      voxels (the first through its corridor) is walked on by its owner lane 64 voxels at a time and
 //      tested by all 64 lanes.
+//   Every ray's marks (all visited voxels: the highest (position, hash) stays in a slot = the reference's last writer
+//   in serial order) enter the shared set as soon as the ray is decided, by the same wavefront, from the keys it holds
+//   in LDS — there is no second walk and no second launch per phase.
 // Output: cnt[s] = number of voxels the ray updates (| kCntBroke).
 // The reference's loop: [K:src/semantic_tsdf_integrator_fast.cpp:110-122].
 // ------------------------------------------------------------------------------------------
@@ -251,7 +259,17 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
   // stage B kernels read the frame's parameters from device memory: the launch sequence of a frame slot is
   // then identical from frame to frame and is replayed as a captured graph
   const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
-  const uint64_t* __restrict__ observed = F.observed;
+  unsigned long long* observed = (unsigned long long*)F.observed;   // [slot] = {newest, older}
+  const uint32_t phase_pos0 = g0 * kChains;  // marks at positions >= this one belong to the phase being run
+  // slot content as it stood when the phase began (see the set's description above)
+  auto snapshot_decide = [&](const ulonglong2 e, uint32_t slot, uint32_t h) -> bool {
+    unsigned long long content = e.x;
+    const bool current = (uint32_t)(e.x >> 54) == F.obs_tag && ((uint32_t)(e.x >> 32) & 0x3fffffu) > phase_pos0;
+    if (current) content = e.y;
+    else if (e.x != 0ull && e.x != e.y) atomicMax(&observed[2u * slot + 1u], e.x);
+    return obs_match(content, h, F.obs_tag_lo, F.obs_tag);
+  };
+  auto snapshot_hit = [&](uint32_t slot, uint32_t h) -> bool { return snapshot_decide(((const ulonglong2*)observed)[slot], slot, h); };
   extern __shared__ unsigned long long s_test[];
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
   unsigned long long* priv = s_test + (size_t)wave * test_lds_words64(steps_cap);
@@ -305,15 +323,17 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
   {
     const uint32_t grp = lane >> 4, l = lane & 15u;
     bool hit[4];
+    unsigned long long kk[4];
+    ulonglong2 ee[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < 4; ++b) {  // the four loads first (the saves below may not be reordered with loads of the set)
       const uint32_t r = (uint32_t)b * 4u + grp;
-      hit[b] = false;
-      if (((live_mask >> r) & 1u) && (int)l <= (int)rinfo[r]) {
-        const unsigned long long k = keys[r * 16 + l];
-        hit[b] = obs_match(observed[(uint32_t)(k >> 32)], (uint32_t)k, F.obs_tag_lo, F.obs_tag);
-      }
+      const bool on = ((live_mask >> r) & 1u) && (int)l <= (int)rinfo[r];
+      kk[b] = on ? keys[r * 16 + l] : ~0ull;
+      ee[b] = on ? ((const ulonglong2*)observed)[(uint32_t)(kk[b] >> 32)] : make_ulonglong2(0ull, 0ull);
     }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) hit[b] = kk[b] != ~0ull && snapshot_decide(ee[b], (uint32_t)(kk[b] >> 32), (uint32_t)kk[b]);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const unsigned long long m = __ballot(hit[b]);
@@ -372,8 +392,7 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
         bool hit64 = false;
         if (v64) {
           const unsigned long long k64 = lkeys[s0 - 16u + lane];
-          if (!priv_lookup(priv, (uint32_t)(k64 >> 32), (uint32_t)k64, hit64))
-            hit64 = obs_match(observed[(uint32_t)(k64 >> 32)], (uint32_t)k64, F.obs_tag_lo, F.obs_tag);
+          if (!priv_lookup(priv, (uint32_t)(k64 >> 32), (uint32_t)k64, hit64)) hit64 = snapshot_hit((uint32_t)(k64 >> 32), (uint32_t)k64);
         }
         stop = early_out_stop(__ballot(v64 && hit64), __ballot(v64), lim, c);
         if (stop >= 0) {
@@ -388,18 +407,23 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
         }
         s0 += 64u;
       }
-      // marks of the voxels past the first 16 (kept in LDS: no second walk)
-      for (uint32_t m0 = 16; m0 < visited; m0 += 64) {
-        const uint32_t s = m0 + lane;
-        if (s < visited) {
-          const unsigned long long k64 = lkeys[s - 16u];
-          atomicMax(&priv[(uint32_t)(k64 >> 32) & (kPrivSlots - 1u)], priv_key(gen_j, s, (uint32_t)(k64 >> 32), (uint32_t)k64));
-        }
+    }
+    // the older-phase marks this wavefront's tests saved have been performed before any mark of its own goes out
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // marks of the voxels past the first 16 (kept in LDS: no second walk): the chain's private set, and the shared set
+    for (uint32_t m0 = 16; m0 < visited; m0 += 64) {
+      const uint32_t s = m0 + lane;
+      if (s < visited) {
+        const unsigned long long k64 = lkeys[s - 16u];
+        atomicMax(&priv[(uint32_t)(k64 >> 32) & (kPrivSlots - 1u)], priv_key(gen_j, s, (uint32_t)(k64 >> 32), (uint32_t)k64));
+        atomicMax(&observed[2u * (uint32_t)(k64 >> 32)], (unsigned long long)obs_entry(F.obs_tag, pos_j, (uint32_t)k64));
       }
     }
     if (lane == 0) cnt[pos_j] = updates | (stop >= 0 ? kCntBroke : 0u);
-    if (valid && lane < visited)
+    if (valid && lane < visited) {
       atomicMax(&priv[(uint32_t)(k >> 32) & (kPrivSlots - 1u)], priv_key(gen_j, lane, (uint32_t)(k >> 32), (uint32_t)k));
+      atomicMax(&observed[2u * (uint32_t)(k >> 32)], (unsigned long long)obs_entry(F.obs_tag, pos_j, (uint32_t)k));
+    }
   }
 #ifdef KS_STATS
   {
@@ -415,13 +439,8 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
 #endif
 }
 
-// k_mark — the marks of the phase covering positions [pos0, pos1) enter the shared set: every visited
-// voxel of every live ray of the phase, one atomicMax each (the entry with the highest (position, hash)
-// stays = the reference's last writer in serial order).  The atomics return nothing, so nothing waits
-// for memory.  One lane per ray walks its first 32 voxels serially; the few rays that go further are then
-// taken one at a time by the whole wavefront (exact parallel caster, 64 voxels per round).
 constexpr uint32_t kLaneWalk = 32;
-// Work split of the kernels that walk whole rays (k_mark, k_emit_lane): RPW rays per wavefront, owned by its
+// Work split of the kernels that walk whole rays (k_emit_lane, k_eo_emit): RPW rays per wavefront, owned by its
 // first RPW lanes.  RPW = 64 when most rays are a few voxels long (fast with the early-out), 8 when rays are
 // long (merged bundles, 2 cm voxels): the long part of a ray costs whole-wavefront rounds, so fewer rays per
 // wavefront means more wavefronts sharing that work.  Per wavefront, the tail beyond kLaneWalk voxels is
@@ -437,66 +456,6 @@ __device__ __forceinline__ bool tails_by_wavefront(unsigned long long long_mask,
   }
   return rounds * 8u < longest - kLaneWalk;   // a 64-voxel round ~ 8 owner-lane steps
 }
-template <int RPW>
-__global__ void __launch_bounds__(256) k_mark(const FrameParams* __restrict__ Fp, uint32_t pos0, uint32_t pos1,
-                                              const uint32_t* __restrict__ ray_list, const RayDesc* __restrict__ rays,
-                                              const uint32_t* __restrict__ cnt, const Counters* C) {
-  __shared__ float s_e[4][3 * kES];
-  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
-  uint64_t* __restrict__ observed = F.observed;
-  if (C->err & (kErrLabel | kErrIndex)) return;
-  const uint32_t lane = lane_id();
-  const uint32_t r0 = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)RPW;  // first ray of this wavefront
-  const uint32_t r = r0 + lane;
-  if (r0 >= C->n_rays) return;  // whole wavefront idle
-  uint32_t pos = 0, visited = 0;
-  Dda dda{};
-  if (lane < (uint32_t)RPW && r < C->n_rays) {
-    pos = ray_list[r];
-    if (pos >= pos0 && pos < pos1) {
-      const uint32_t cv = cnt[pos];
-      visited = (cv & ~kCntBroke) + ((cv & kCntBroke) ? 1u : 0u);
-      const RayDesc d = rays[ray_index(F, pos)];
-      dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, false);
-    }
-  }
-  const unsigned long long long_mask = __ballot(visited > kLaneWalk);
-  const bool by_wave = tails_by_wavefront(long_mask, visited);
-  const uint32_t own = (by_wave && visited > kLaneWalk) ? kLaneWalk : visited;
-  for (uint32_t s = 0; __ballot(s < own) != 0ull; ++s) {
-    if (s < own) {
-      const uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
-      atomicMax((unsigned long long*)&observed[((uint64_t)h + F.observed_offset) & kSetMask],
-                (unsigned long long)obs_entry(F.obs_tag, pos, h));
-    }
-    dda.advance(s < own);
-  }
-  float* escr = s_e[threadIdx.x >> 6];
-  for (unsigned long long todo = by_wave ? long_mask : 0ull; todo != 0ull; todo &= todo - 1ull) {
-    const int j = __ffsll((long long)todo) - 1;
-    Dda ust = dda_bcast(dda, j);  // state at step kLaneWalk
-    const uint32_t v_j = __shfl(visited, j), pos_j = __shfl(pos, j);
-    if (dda_parallel_ok(ust)) {
-      for (uint32_t s0 = kLaneWalk; s0 < v_j; s0 += 64) {
-        dda_round64(ust, escr, lane, [&](uint32_t rr, int vx, int vy, int vz) {
-          if (s0 + rr < v_j) {
-            const uint32_t h = index_hash(vx, vy, vz);
-            atomicMax((unsigned long long*)&observed[((uint64_t)h + F.observed_offset) & kSetMask],
-                      (unsigned long long)obs_entry(F.obs_tag, pos_j, h));
-          }
-        });
-      }
-    } else if ((int)lane == j) {
-      for (uint32_t s = kLaneWalk; s < visited; ++s) {
-        const uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
-        atomicMax((unsigned long long*)&observed[((uint64_t)h + F.observed_offset) & kSetMask],
-                  (unsigned long long)obs_entry(F.obs_tag, pos, h));
-        dda.advance();
-      }
-    }
-  }
-}
-
 // entries of the per-position update counts: merged keeps the clearing bundles' counts at +n
 __device__ __forceinline__ uint32_t scan_length(const FrameParams& F) { return (F.method == KS_METHOD_MERGED ? 2u : 1u) * F.n; }
 
