@@ -262,11 +262,15 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
   unsigned long long* observed = (unsigned long long*)F.observed;   // [slot] = {newest, older}
   const uint32_t phase_pos0 = g0 * kChains;  // marks at positions >= this one belong to the phase being run
   // slot content as it stood when the phase began (see the set's description above)
+  bool my_save = false;  // this lane has issued a save since the wavefront last waited for its saves
   auto snapshot_decide = [&](const ulonglong2 e, uint32_t slot, uint32_t h) -> bool {
     unsigned long long content = e.x;
     const bool current = (uint32_t)(e.x >> 54) == F.obs_tag && ((uint32_t)(e.x >> 32) & 0x3fffffu) > phase_pos0;
     if (current) content = e.y;
-    else if (e.x != 0ull && e.x != e.y) atomicMax(&observed[2u * slot + 1u], e.x);
+    else if (e.x != 0ull && e.x != e.y) {
+      atomicMax(&observed[2u * slot + 1u], e.x);
+      my_save = true;
+    }
     return obs_match(content, h, F.obs_tag_lo, F.obs_tag);
   };
   auto snapshot_hit = [&](uint32_t slot, uint32_t h) -> bool { return snapshot_decide(((const ulonglong2*)observed)[slot], slot, h); };
@@ -409,7 +413,10 @@ __global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __rest
       }
     }
     // the older-phase marks this wavefront's tests saved have been performed before any mark of its own goes out
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (__ballot(my_save) != 0ull) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      my_save = false;
+    }
     // marks of the voxels past the first 16 (kept in LDS: no second walk): the chain's private set, and the shared set
     for (uint32_t m0 = 16; m0 < visited; m0 += 64) {
       const uint32_t s = m0 + lane;

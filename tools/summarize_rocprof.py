@@ -27,14 +27,14 @@ def main():
         hist[depth] = hist.get(depth, 0) + (t - last)
         last = t
         depth += dlt
-    # frame markers: the first kernel of a frame (k_points_fast / k_points_merged).  bench.py --steps 20 --warmup 3
-    # --no-secondary: the first 23 frames are the pipelined, timed context (later ones belong to the per-stage pass)
+    # frame markers: the first kernel of a frame (k_points_fast / k_points_merged).  bench.py --steps 20 --warmup 2:
+    # frames [22, 122) of the first context are the five timed regions (PRIME = 20 untimed frames + 2 warm-up steps)
     first = sorted(int(r["Start_Timestamp"]) for r in tr if "k_points_" in r["Kernel_Name"])
     hist = {}
-    if len(first) >= 23:
-        per = (first[22] - first[5]) / 17 / 1e3
-        print(f"\n# frame period inside the timed region (k_points start to start, frames 5..22), with tracing on: {per:.1f} us")
-        lo, hi = first[5], first[22]
+    if len(first) >= 122:
+        per = (first[121] - first[22]) / 99 / 1e3
+        print(f"\n# frame period inside the timed regions (k_points start to start, frames 22..121), with tracing on: {per:.1f} us")
+        lo, hi = first[22], first[121]
         depth, last = 0, lo
         for t, dlt in ev:
             if t > hi:
@@ -45,9 +45,9 @@ def main():
             depth += dlt
     ap = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 for r in tr if "k_apply<" in r["Kernel_Name"] and "k_apply_long" not in r["Kernel_Name"])
-    if len(ap) >= 23:
-        timed = [d for _, d in ap[3:23]]
-        print(f"# k_apply average duration: {sum(timed) / len(timed) / 1e3:.2f} us over the 20 timed (pipelined, overlapped) launches "
+    if len(ap) >= 122:
+        timed = [d for _, d in ap[22:122]]
+        print(f"# k_apply average duration: {sum(timed) / len(timed) / 1e3:.2f} us over the 100 timed (pipelined, overlapped) launches "
               f"(bench.py's roofline.k_apply.avg_launch_ms of the same run is in the log line below)")
     tot = sum(hist.values()) or 1
     print("# kernels executing concurrently (share of the steady-state span): " +
