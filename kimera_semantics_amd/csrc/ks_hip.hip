@@ -117,6 +117,8 @@ struct FrameSlot {
   hipEvent_t fork = nullptr, join = nullptr;  // tail: pairs sorted and long runs listed | long runs applied
   bool tail_recorded = false;
   bool join_recorded = false;
+  bool b_launched = false;    // stage B of the frame has been enqueued (with its batch)
+  size_t steps_max = 0;       // longest possible ray of the frame, in voxels
   uint64_t frame_no = 0;      // the frame the slot holds
   FrameParams F{};
   size_t n = 0;
@@ -147,6 +149,8 @@ struct ks_ctx {
   // has its own table)
   hipStream_t stream_march_[kMarchStreams] = {};
   int n_march = 1;
+  int batch = 1;                        // frames whose stage B is launched together (ks_k_march.h: BatchView)
+  std::vector<FrameSlot*> batch_slots;  // frames whose stage A is enqueued and whose stage B waits for the batch to fill
   hipStream_t prof_march_stream = nullptr;  // march stream of the frame being enqueued (stage events)
   hipStream_t stream_tail = nullptr;   // stage T; == stream unless pipelined
   hipStream_t stream_long = nullptr;   // the long-run voxel update, beside k_apply (always its own stream)
@@ -427,7 +431,7 @@ int ensure_pairs_in(ks_ctx* c, FrameSlot& S, size_t bound) {
   int rc;
   if ((rc = dev_alloc(c, &S.d_pairs, cap))) return rc;
   S.cap_pairs_in = cap;
-  S.b_graph_key = 0;  // the captured stage B points at the old buffer
+  ++c->buffers_epoch;  // captured stage-B graphs point at the old buffer
   return KS_OK;
 }
 int ensure_pairs_out(ks_ctx* c, size_t n) {
@@ -542,41 +546,50 @@ void resolve_prof(ks_ctx* c, int set) {
   P.used = P.complete = P.applied = false;
 }
 
+// what stage B's kernels see of a frame slot (ks_k_march.h)
+SlotView slot_view(const FrameSlot& S, Counters* counters = nullptr) {
+  SlotView v{};
+  v.F = S.d_F;
+  v.live = S.d_live;
+  v.rays = S.d_rays;
+  v.cnt = S.d_cnt;
+  v.lp = S.d_lp;
+  v.bt = S.d_bt;
+  v.ray_list = S.d_ray_list;
+  v.pairs = S.d_pairs;
+  v.pairs_cap = (unsigned long long)S.cap_pairs_in;
+  v.C = counters ? counters : S.d_counters;
+  v.host_snap = (uint32_t*)S.h_snap;
+  return v;
+}
+
 // pair emission over an upper bound of rays (<= n); the live ray count stays on the device
-void launch_emit(ks_ctx* c, FrameSlot& S, hipStream_t st, Counters* counters) {
-  // grids and LDS are sized by the slot's capacity (the kernels take the frame's own counts from S.d_F and the
+void launch_emit(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipStream_t st) {
+  // grids and LDS are sized by the slot's capacity (the kernels take the frame's own counts from its d_F and its
   // counters): the launch sequence is the same for every frame and can be replayed
   const size_t n = c->cap_points;
   const size_t lds = ((2 * n + kScanBlock - 1) / kScanBlock) * sizeof(unsigned long long);
   if (!(c->cfg.method == KS_METHOD_MERGED && c->cfg.enable_anti_grazing)) {
     // bundles and 2 cm rays are long: 8 rays per wavefront; early-out rays are short: one per lane
-    if (S.wide || c->cfg.method == KS_METHOD_MERGED || !c->uses_early_out)
-      hipLaunchKernelGGL(k_emit_lane<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), lds, st, (const FrameParams*)S.d_F,
-                         S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
-                         (unsigned long long)S.cap_pairs_in, counters);
+    if (wide || c->cfg.method == KS_METHOD_MERGED || !c->uses_early_out)
+      hipLaunchKernelGGL(k_emit_lane<8>, dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, V, c->table, c->pool);
     else
-      hipLaunchKernelGGL(k_emit_lane<16>, dim3((uint32_t)((n + 63) / 64)), dim3(256), lds, st, (const FrameParams*)S.d_F,
-                         S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
-                         (unsigned long long)S.cap_pairs_in, counters);
+      hipLaunchKernelGGL(k_emit_lane<16>, dim3((uint32_t)((n + 63) / 64), nb), dim3(256), lds, st, V, c->table, c->pool);
+  } else if (wide) {
+    hipLaunchKernelGGL(k_emit<64>, dim3((uint32_t)((n + 3) / 4), nb), dim3(256), lds, st, V, c->table, c->pool);
+  } else {
+    hipLaunchKernelGGL(k_emit<16>, dim3((uint32_t)((n + 15) / 16), nb), dim3(256), lds, st, V, c->table, c->pool);
   }
-  else if (S.wide)
-    hipLaunchKernelGGL(k_emit<64>, dim3((uint32_t)((n + 3) / 4)), dim3(256), lds, st, (const FrameParams*)S.d_F,
-                       S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
-                       (unsigned long long)S.cap_pairs_in, counters);
-  else
-    hipLaunchKernelGGL(k_emit<16>, dim3((uint32_t)((n + 15) / 16)), dim3(256), lds, st, (const FrameParams*)S.d_F,
-                       S.d_ray_list, S.d_rays, S.d_cnt, S.d_lp, S.d_bt, c->table, c->pool, S.d_pairs,
-                       (unsigned long long)S.cap_pairs_in, counters);
 }
 
-// Stage B of the frame in slot S, as a sequence of launches on stream sm (captured into a graph by the
-// caller, or issued directly).  Everything frame-specific comes from S.d_F.
+// Stage B of the nb frames of a batch, as a sequence of launches on stream sm (captured into a graph by the caller,
+// or issued directly): every kernel covers the whole batch (blockIdx.y = frame).  Everything frame-specific comes
+// from the slots' d_F.
 // part: 0 = all of it; 1 = the early-out phases only; 2 = everything after them (the exact early-out mode runs its
 // fix-point iteration, with host waits, in between)
-void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max, int part = 0) {
+void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipStream_t sm, size_t steps_max, int part = 0) {
   const ks_config& cfg = c->cfg;
   const size_t n = c->cap_points;  // NOT the frame's point count: see launch_emit
-  const FrameParams* dF = S.d_F;
   if (c->uses_early_out && part != 2) {
     // ordered-phase early-out: per phase, k_test decides how far the phase's rays get against the set as it
     // stood when the phase began and enters their marks (ks_k_march.h)
@@ -584,25 +597,21 @@ void enqueue_stage_b(ks_ctx* c, FrameSlot& S, hipStream_t sm, size_t steps_max, 
     const std::vector<uint32_t> B = phase_bounds(n_gen, cfg.early_out_phase_growth);
     for (size_t j = 0; j < B.size(); ++j) {
       const uint32_t g0 = B[j], g1 = (j + 1 < B.size()) ? B[j + 1] : n_gen;  // k_test ends the frame's last phase at ITS n
-      const uint32_t p0 = g0 * kChains, p1 = (uint32_t)std::min<uint64_t>((uint64_t)g1 * kChains, UINT32_MAX);
       const uint32_t n_sub = (g1 - g0 + kSubRun - 1) / kSubRun;  // wavefronts per chain
       const uint32_t steps_cap = (uint32_t)((steps_max + 3) & ~(size_t)3);
       const size_t lds_wave = (size_t)test_lds_words64(steps_cap) * sizeof(unsigned long long);
       const uint32_t wpb = lds_wave * 4 <= 60 * 1024 ? 4u : lds_wave * 2 <= 60 * 1024 ? 2u : 1u;  // wavefronts per block
-      hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb), dim3(64 * wpb), lds_wave * wpb, sm, dF, g0, g1, steps_cap, S.d_live,
-                         S.d_rays, S.d_cnt, S.d_counters);
+      hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb, nb), dim3(64 * wpb), lds_wave * wpb, sm, V, g0, g1, steps_cap);
     }
   }
   if (part == 1) return;
   if (cfg.method == KS_METHOD_MERGED && cfg.enable_anti_grazing)
-    hipLaunchKernelGGL(k_count_grazing<16>, dim3((uint32_t)((n + 15) / 16)), dim3(256), 0, sm, dF, S.d_ray_list, S.d_rays,
-                       S.d_cnt, S.d_counters);
-  hipLaunchKernelGGL(k_scan_local, dim3((uint32_t)(((cfg.method == KS_METHOD_MERGED ? 2 : 1) * n + kScanBlock - 1) / kScanBlock)),
-                     dim3(1024), 0, sm, dF, S.d_cnt, S.d_lp, S.d_bt);
-  launch_emit(c, S, sm, S.d_counters);
-  // the frame's only device->host traffic: pair / ray / tile counts and error flags
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, sm, S.d_counters, (const uint32_t*)c->table.n_tiles,
-                     (uint32_t*)S.h_snap);
+    hipLaunchKernelGGL(k_count_grazing<16>, dim3((uint32_t)((n + 15) / 16), nb), dim3(256), 0, sm, V);
+  hipLaunchKernelGGL(k_scan_local, dim3((uint32_t)(((cfg.method == KS_METHOD_MERGED ? 2 : 1) * n + kScanBlock - 1) / kScanBlock), nb),
+                     dim3(1024), 0, sm, V);
+  launch_emit(c, V, nb, wide, sm);
+  // the frames' only device->host traffic: pair / ray / tile counts and error flags
+  hipLaunchKernelGGL(k_publish, dim3(nb), dim3(64), 0, sm, V, (const uint32_t*)c->table.n_tiles);
 }
 
 // fast, early-out in the reference's serial order: fix-point iteration over the rays' visited lengths, seeded by
@@ -678,6 +687,77 @@ int exact_early_out(ks_ctx* c, FrameSlot& S, hipStream_t st) {
   if (n_marks)
     hipLaunchKernelGGL(k_eo_commit, dim3((uint32_t)((n_marks + 255) / 256)), dim3(256), 0, st, n_marks, (const uint64_t*)kres,
                        (const uint32_t*)vres, c->d_eo_plain);
+  return KS_OK;
+}
+
+// Stage B of the frames whose stage A has been enqueued (consecutive frames, at most kBatchMax): ONE sequence of
+// launches for all of them, captured once per (first slot, size) and replayed.  Called by the thread that enqueues
+// stage A (graph capture and the helper thread's tail never meet on a stream).
+int launch_batch(ks_ctx* c) {
+  if (c->batch_slots.empty()) return KS_OK;
+  HostTimer htb(&c->hp_b);
+  std::vector<FrameSlot*> slots;
+  slots.swap(c->batch_slots);
+  const uint32_t nb = (uint32_t)slots.size();
+  FrameSlot& S0 = *slots[0];
+  hipStream_t st = c->stream;
+  hipStream_t sm = c->batch > 1 ? c->stream_march_[0] : march_stream(c, S0.frame_no);
+  c->prof_march_stream = sm;
+  if (sm != st) HIPCHK(c, hipStreamWaitEvent(sm, slots[nb - 1]->a_done, 0));  // stage A is one in-order stream: the last frame's event covers all
+  const bool stage_events = nb == 1 && S0.prof_set >= 0 && c->pset[S0.prof_set].stages;
+  if (stage_events) (void)hipEventRecord(c->pset[S0.prof_set].ev[4], sm);
+  // The frames' parameters go to device memory; stage B's kernels take everything else from the slots, so
+  // their launch sequence depends only on the capacity: it is captured once per group of slots and replayed.
+  BatchView V{};
+  size_t steps_max = 0;
+  for (uint32_t k = 0; k < nb; ++k) {
+    FrameSlot& S = *slots[k];
+    S.F.observed = observed_table(c, S.frame_no);
+    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sm, S.F, S.d_F);
+    V.s[k] = slot_view(S);
+    steps_max = std::max(steps_max, S.steps_max);
+  }
+  const uint64_t key = ((uint64_t)c->cap_points << 24) ^ (c->buffers_epoch << 4) ^ (S0.wide ? 1u : 0u) ^ ((uint64_t)nb << 1);
+  bool replayed = false;
+  int rc;
+  if (c->exact_early_out) {
+    // (batches of one) the ordered phases give the seed; the fix-point iteration (host waits inside) makes it the serial result
+    enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
+    if ((rc = exact_early_out(c, S0, sm))) return rc;
+    enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 2);
+    replayed = true;
+  } else if (c->use_graphs) {
+    if (S0.b_graph_key != key || !S0.b_graph) {
+      if (S0.b_graph) (void)hipGraphExecDestroy(S0.b_graph);
+      S0.b_graph = nullptr;
+      S0.b_graph_key = 0;
+      hipGraph_t g = nullptr;
+      bool ok = hipStreamBeginCapture(sm, hipStreamCaptureModeRelaxed) == hipSuccess;
+      if (ok) {
+        enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max);
+        ok = hipStreamEndCapture(sm, &g) == hipSuccess && g != nullptr;
+      }
+      if (ok) ok = hipGraphInstantiate(&S0.b_graph, g, nullptr, nullptr, 0) == hipSuccess;
+      if (g) (void)hipGraphDestroy(g);
+      if (ok) {
+        S0.b_graph_key = key;
+      } else {
+        (void)hipGetLastError();
+        S0.b_graph = nullptr;
+        c->use_graphs = false;  // plain launches from now on
+      }
+    }
+    if (S0.b_graph) {
+      HIPCHK(c, hipGraphLaunch(S0.b_graph, sm));
+      replayed = true;
+    }
+  }
+  if (!replayed) enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max);
+  for (uint32_t k = 0; k < nb; ++k) {
+    HIPCHK(c, hipEventRecord(slots[k]->ready, sm));
+    slots[k]->b_launched = true;
+  }
+  if (stage_events) (void)hipEventRecord(c->pset[S0.prof_set].ev[5], sm);
   return KS_OK;
 }
 
@@ -829,60 +909,13 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
     }
   }
   stage_mark(c, S.prof_set, 3);
-  // ---- stage B: early-out phases, scan, pair emission over an upper bound of rays (<= n); the live
-  // ray count stays on the device
-  hipStream_t sm = march_stream(c, this_frame);
-  c->prof_march_stream = sm;
-  HostTimer htb(&c->hp_b);
-  if (sm != st) {
-    HIPCHK(c, hipEventRecord(S.a_done, st));
-    HIPCHK(c, hipStreamWaitEvent(sm, S.a_done, 0));
-  }
-  if (S.prof_set >= 0 && c->pset[S.prof_set].stages) (void)hipEventRecord(c->pset[S.prof_set].ev[4], sm);
-  // The frame's parameters go to device memory; stage B's kernels take everything else from the slot, so
-  // their launch sequence depends only on the point count: it is captured once per slot and replayed.
-  F.observed = observed_table(c, this_frame);
-  hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sm, F, S.d_F);
-  {
-    const uint64_t key = ((uint64_t)c->cap_points << 24) ^ (c->buffers_epoch << 1) ^ (S.wide ? 1u : 0u);
-    bool replayed = false;
-    if (c->exact_early_out) {
-      // the ordered phases give the seed; the fix-point iteration (host waits inside) makes it the serial result
-      enqueue_stage_b(c, S, sm, steps_max, 1);
-      if ((rc = exact_early_out(c, S, sm))) return rc;
-      enqueue_stage_b(c, S, sm, steps_max, 2);
-      replayed = true;
-    } else if (c->use_graphs) {
-      if (S.b_graph_key != key || !S.b_graph) {
-        if (S.b_graph) (void)hipGraphExecDestroy(S.b_graph);
-        S.b_graph = nullptr;
-        S.b_graph_key = 0;
-        hipGraph_t g = nullptr;
-        bool ok = hipStreamBeginCapture(sm, hipStreamCaptureModeRelaxed) == hipSuccess;
-        if (ok) {
-          enqueue_stage_b(c, S, sm, steps_max);
-          ok = hipStreamEndCapture(sm, &g) == hipSuccess && g != nullptr;
-        }
-        if (ok) ok = hipGraphInstantiate(&S.b_graph, g, nullptr, nullptr, 0) == hipSuccess;
-        if (g) (void)hipGraphDestroy(g);
-        if (ok) {
-          S.b_graph_key = key;
-        } else {
-          (void)hipGetLastError();
-          S.b_graph = nullptr;
-          c->use_graphs = false;  // plain launches from now on
-        }
-      }
-      if (S.b_graph) {
-        HIPCHK(c, hipGraphLaunch(S.b_graph, sm));
-        replayed = true;
-      }
-    }
-    if (!replayed) enqueue_stage_b(c, S, sm, steps_max);
-  }
-  HIPCHK(c, hipEventRecord(S.ready, sm));
-  if (S.prof_set >= 0 && c->pset[S.prof_set].stages) (void)hipEventRecord(c->pset[S.prof_set].ev[5], sm);
+  // ---- stage B (early-out phases, scan, pair emission) is enqueued per BATCH of frames: launch_batch
+  if (c->stream_march_[0] != st) HIPCHK(c, hipEventRecord(S.a_done, st));
+  S.steps_max = steps_max;
+  S.b_launched = false;
   S.pending = true;
+  c->batch_slots.push_back(&S);
+  if ((int)c->batch_slots.size() >= c->batch || c->profiling == 1) return launch_batch(c);
   return KS_OK;
 }
 
@@ -893,6 +926,9 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   // After a pool / index failure the table may hold entries without a tile: frames that were
   // already in flight are dropped, never applied (the error has been reported for the frame that hit it).
   if (c->fatal) return KS_OK;
+  if (!S.b_launched) {  // the frame's batch has not filled up (flush, or a lag shorter than the batch): it goes out as it is
+    if (int rc = launch_batch(c)) return rc;
+  }
   hipStream_t st = c->stream_tail;  // the host wait below orders the tail after the slot's front
   const FrameParams& F = S.F;
   {
@@ -920,7 +956,11 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     Counters rcnt{};
     rcnt.n_rays = cnt.n_rays;
     HIPCHK(c, hipMemcpyAsync(c->d_retry_counters, &rcnt, sizeof(rcnt), hipMemcpyHostToDevice, st));
-    launch_emit(c, S, st, c->d_retry_counters);
+    {
+      BatchView V{};
+      V.s[0] = slot_view(S, c->d_retry_counters);
+      launch_emit(c, V, 1, S.wide, st);
+    }
     HIPCHK(c, hipMemcpyAsync(&rcnt, c->d_retry_counters, sizeof(rcnt), hipMemcpyDeviceToHost, st));
     uint32_t nt = 0;
     HIPCHK(c, hipMemcpyAsync(&nt, c->table.n_tiles, sizeof(nt), hipMemcpyDeviceToHost, st));
@@ -1241,6 +1281,7 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
   const uint64_t this_frame = c->frame_no;
   FrameSlot* due = (this_frame >= lag) ? &c->slot[(this_frame - lag) % kSlots] : nullptr;
   if (due && !due->pending) due = nullptr;
+  if (due && !due->b_launched && (rc = launch_batch(c))) return rc;  // (only with a lag shorter than the batch)
   if (due && c->use_tail_thread) {
     tail_post(c, due);  // the helper thread enqueues the tail of the frame `lag` calls back ...
     const int rc_front = frame_front(c, S, Tq, d_xyz, d_rgba, d_labels, n, freespace);  // ... while this one enqueues A and B
@@ -1307,8 +1348,11 @@ static int insert_tiles(ks_ctx* c, const uint64_t* d_keys, size_t n) {
   HIPCHK(c, hipMemsetAsync(S.d_counters, 0, sizeof(Counters), c->stream));
   hipLaunchKernelGGL(k_insert_tiles, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, c->stream, c->table, S.d_counters,
                      d_keys, (uint32_t)n);
-  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, S.d_counters, (const uint32_t*)c->table.n_tiles,
-                     (uint32_t*)S.h_snap);
+  {
+    BatchView V{};
+    V.s[0] = slot_view(S);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, V, (const uint32_t*)c->table.n_tiles);
+  }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   const uint32_t new_tiles = std::min(S.n_tiles(), c->cfg.max_tiles);
   if (new_tiles > c->tiles_initialised) {
@@ -1433,13 +1477,22 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   } while (0)
   CRCHK(hipSetDevice(cfg->device_id));
   CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  {
-    const char* nl = getenv("KS_NO_LONG_STREAM");   // diagnostics: long runs on the tail stream, after k_apply
-    if (nl && nl[0] == '1') c->stream_long = nullptr;
-    else CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
+  // Frames in flight share nothing in stage B when a frame's early-out marks can never be seen by the next frame
+  // (every frame bumps the set offset).  Then either (pipeline_frames < 8) every frame's stage B is its own launch
+  // sequence and up to four of them run side by side on four streams, or (pipeline_frames = 8) stage B of four
+  // consecutive frames is launched as ONE batch on one stream; each frame in flight has an early-out table of its
+  // own.  Otherwise stage B stays strictly in frame order.
+  const bool frames_independent = !uses_early_out || c->cfg.clear_checks_every_n_frames <= 1;
+  c->batch = 1;
+  if (c->cfg.pipeline_frames >= 2 && frames_independent && !c->exact_early_out && c->cfg.integration_order_mode != KS_ORDER_SORTED) {
+    // (measured, 640x480: a batch of 4 behind 8 frames of lag ~ four single-frame sequences on four streams behind 4
+    // frames of lag; batches of 2 or 3 lose to both: DESIGN.md)
+    c->batch = c->cfg.pipeline_frames >= 8 ? kBatchMax : 1;
+    if (const char* bs = getenv("KS_BATCH")) c->batch = std::min(kBatchMax, std::max(1, atoi(bs)));  // diagnostics
   }
   if (c->cfg.pipeline_frames) {
-    c->n_march = std::min(kMarchStreams, std::max(4, c->cfg.pipeline_frames));  // stage B of that many consecutive frames can overlap
+    // (shared early-out table: stage B of consecutive frames stays in order on one stream)
+    c->n_march = (!frames_independent || c->batch > 1) ? 1 : std::min(kMarchStreams, std::max(4, c->cfg.pipeline_frames));
     if (const char* ms = getenv("KS_MARCH_STREAMS")) c->n_march = std::min(kMarchStreams, std::max(1, atoi(ms)));  // diagnostics
     {
       // KS_STREAM_PRIORITY (diagnostics): m = march streams at the highest priority, t = tail, l = long at the lowest
@@ -1451,14 +1504,23 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
         return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
       };
       for (int i = 0; i < c->n_march; ++i) CRCHK(mk(&c->stream_march_[i], 'm'));
-      CRCHK(mk(&c->stream_tail, 't'));
-      if (sp && strchr(sp, 'l') && c->stream_long) {
-        (void)hipStreamDestroy(c->stream_long);
-        CRCHK(mk(&c->stream_long, 'l'));
+      {
+        const char* tm = getenv("KS_TAIL_ON_MAIN");  // experiments: stage T shares stage A's stream
+        if (tm && tm[0] == '1') c->stream_tail = c->stream;
+        else CRCHK(mk(&c->stream_tail, 't'));
       }
     }
   } else {
     c->stream_march_[0] = c->stream_tail = c->stream;
+  }
+  {
+    // Created LAST.  The runtime spreads streams over its hardware queues in creation order, and kernels of streams that
+    // share a hardware queue run one after the other: the heavy chains (stage B, stage T) must not share one.  With
+    // the default of four hardware queues — one of which other streams of the process use — stage A and the long
+    // runs (the two lightest: ~90 + ~65 us per 640x480 frame) are the pair that shares.  KS_STREAM_ORDER: experiments.
+    const char* nl = getenv("KS_NO_LONG_STREAM");   // diagnostics: long runs on the tail stream, after k_apply
+    if (nl && nl[0] == '1') c->stream_long = nullptr;
+    else CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
   }
   for (auto& P : c->pset) {
     for (auto& e : P.ev) CRCHK(hipEventCreate(&e));
@@ -1479,9 +1541,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipMalloc((void**)&c->pool.dirty, mt));
   CRCHK(hipMemset(c->pool.dirty, 0, mt));
   CRCHK(hipMalloc((void**)&c->d_start_set, sizeof(uint64_t) << kSetBits));
-  // one early-out table per march stream when a frame's marks can never be seen by the next frame
-  c->n_obs = (c->n_march > 1 && uses_early_out && cfg->clear_checks_every_n_frames <= 1) ? c->n_march : 1;
-  if (uses_early_out && c->n_obs == 1) c->n_march = 1;  // shared table: stage B of consecutive frames stays in order
+  c->n_obs = (uses_early_out && frames_independent) ? std::max(c->n_march, c->batch) : 1;
   for (int t = 0; t < c->n_obs; ++t) {
     CRCHK(hipMalloc((void**)&c->d_observed_[t], 2 * (sizeof(uint64_t) << kSetBits)));   // {newest, older} per slot
     CRCHK(hipMemset(c->d_observed_[t], 0, 2 * (sizeof(uint64_t) << kSetBits)));
@@ -2219,6 +2279,7 @@ int ks_reduce(ks_ctx* c, void* rccl_comm, int rank, int world, ks_reduce_stats* 
 int ks_clear(ks_ctx* c) {
   if (!c) return KS_ERR_INVALID_ARG;
   for (auto& S : c->slot) S.pending = false;  // a frame that was never applied is dropped with the map
+  c->batch_slots.clear();
   c->owed = ks_frame_stats{};
   if (c->stream_tail != c->stream) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
   if (c->stream_long) HIPCHK(c, hipStreamSynchronize(c->stream_long));  // (long runs of the last frame: deferred join)

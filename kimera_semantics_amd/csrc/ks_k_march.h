@@ -167,6 +167,28 @@ __device__ __forceinline__ Dda dda_bcast(const Dda& d, int src) {
   return r;
 }
 
+// What stage B reads and writes of ONE frame (slot), and a batch of up to kBatchMax frames: every stage-B kernel is
+// launched once for the whole batch (blockIdx.y = frame of the batch).  The chains of small dependent launches that
+// decide the early-out are latency bound — a launch costs the same for one frame or four — and the hardware runs at
+// most a couple of such chains side by side when they sit on different streams.
+constexpr int kBatchMax = 4;
+struct SlotView {
+  const FrameParams* F;          // the frame's parameters in device memory
+  const uint8_t* live;           // fast: position holds a ray that survived the start-voxel dedup
+  const RayDesc* rays;
+  uint32_t* cnt;                 // updates per integration position (| kCntBroke)
+  uint32_t* lp;                  // block-local exclusive prefix of cnt
+  unsigned long long* bt;        // block totals of that scan
+  const uint32_t* ray_list;
+  uint64_t* pairs;               // (voxel, position) keys, integration order
+  unsigned long long pairs_cap;
+  Counters* C;
+  uint32_t* host_snap;           // pinned snapshot (k_publish)
+};
+struct BatchView {
+  SlotView s[kBatchMax];
+};
+
 constexpr uint32_t kChains = 1024;      // = the 1024 groups of the "mixed" integration order
 constexpr uint32_t kPrivSlots = 1024;   // chain-private direct-mapped set (8 KiB of LDS per chain)
 constexpr uint32_t kCntBroke = 1u << 31;  // cnt[] flag: the ray stopped on a voxel it visited but did not update
@@ -252,13 +274,15 @@ __device__ __forceinline__ bool priv_lookup(const unsigned long long* priv, uint
 // LDS per wavefront: private set | keys of the first 16 voxels of 16 rays | keys of one long ray | per-ray words
 __host__ __device__ inline uint32_t test_lds_words64(uint32_t steps_cap) { return kPrivSlots + 256u + steps_cap + 16u + (3u * kES + 1u) / 2u; }
 
-__global__ void __launch_bounds__(kTestThreads) k_test(const FrameParams* __restrict__ Fp, uint32_t g0, uint32_t g1,
-                                                       uint32_t steps_cap, const uint8_t* __restrict__ live,
-                                                       const RayDesc* __restrict__ rays, uint32_t* __restrict__ cnt,
-                                                       const Counters* C) {
+__global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0, uint32_t g1, uint32_t steps_cap) {
   // stage B kernels read the frame's parameters from device memory: the launch sequence of a frame slot is
   // then identical from frame to frame and is replayed as a captured graph
-  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
+  const SlotView& sv = V.s[blockIdx.y];
+  const uint8_t* __restrict__ live = sv.live;
+  const RayDesc* __restrict__ rays = sv.rays;
+  uint32_t* __restrict__ cnt = sv.cnt;
+  const Counters* C = sv.C;
+  const FrameParams F = *sv.F;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   unsigned long long* observed = (unsigned long long*)F.observed;   // [slot] = {newest, older}
   const uint32_t phase_pos0 = g0 * kChains;  // marks at positions >= this one belong to the phase being run
   // slot content as it stood when the phase began (see the set's description above)
@@ -474,10 +498,13 @@ __device__ __forceinline__ uint32_t scan_length(const FrameParams& F) { return (
 // block offsets (a few hundred values, scanned again by every block in LDS).
 // ------------------------------------------------------------------------------------------
 constexpr uint32_t kScanBlock = 4096;
-__global__ void __launch_bounds__(1024) k_scan_local(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ cnt,
-                                                     uint32_t* __restrict__ lp, unsigned long long* __restrict__ bt) {
+__global__ void __launch_bounds__(1024) k_scan_local(BatchView V) {
   __shared__ uint32_t s_wave[16];
-  const uint32_t n_scan = scan_length(*Fp);  // the grid covers the slot's capacity
+  const SlotView& sv = V.s[blockIdx.y];
+  const uint32_t* __restrict__ cnt = sv.cnt;
+  uint32_t* __restrict__ lp = sv.lp;
+  unsigned long long* __restrict__ bt = sv.bt;
+  const uint32_t n_scan = scan_length(*sv.F);  // the grid covers the slot's capacity
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
   const uint32_t i0 = blockIdx.x * kScanBlock + threadIdx.x * 4u;
   uint32_t v[4];
@@ -509,13 +536,21 @@ __global__ void __launch_bounds__(1024) k_scan_local(const FrameParams* __restri
 // wave has reconverged).  Key = [63:56] label | kind | clearing, [..] voxel id << seq_bits | ray sequence.
 // The list is in integration order; total = Counters::n_pairs.
 // ------------------------------------------------------------------------------------------
+#define KS_SLOT_ARGS(V)                                       \
+  const SlotView& sv = (V).s[blockIdx.y];                     \
+  const uint32_t* __restrict__ ray_list = sv.ray_list;        \
+  const RayDesc* __restrict__ rays = sv.rays;                 \
+  const uint32_t* __restrict__ cnt = sv.cnt;                  \
+  const uint32_t* __restrict__ lp = sv.lp;                    \
+  const unsigned long long* __restrict__ bt = sv.bt;          \
+  uint64_t* __restrict__ pairs = sv.pairs;                    \
+  const unsigned long long pairs_cap = sv.pairs_cap;          \
+  Counters* C = sv.C;                                         \
+  const FrameParams F = *sv.F; /* a COPY: through the pointer every loop iteration would re-load the fields it uses */
+
 template <int LPR>
-__global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Fp,
-                                              const uint32_t* __restrict__ ray_list, const RayDesc* __restrict__ rays,
-                                              const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ lp,
-                                              const unsigned long long* __restrict__ bt, TileTable T, Pool P,
-                                              uint64_t* __restrict__ pairs, unsigned long long pairs_cap, Counters* C) {
-  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
+__global__ void __launch_bounds__(256) k_emit(BatchView V, TileTable T, Pool P) {
+  KS_SLOT_ARGS(V)
   // launched over an upper bound of rays: blocks past the live ray count leave at once (block 0 stays:
   // it publishes the total)
   if (blockIdx.x != 0 && blockIdx.x * (256u / LPR) >= C->n_rays) return;
@@ -625,12 +660,8 @@ __global__ void __launch_bounds__(256) k_emit(const FrameParams* __restrict__ Fp
 // first 32 voxels serially (consecutive voxels share their tile: one table lookup per tile crossing), the few
 // rays that go further are then taken one at a time by the whole wavefront (exact parallel caster).
 template <int RPW>
-__global__ void __launch_bounds__(256) k_emit_lane(const FrameParams* __restrict__ Fp,
-                                                   const uint32_t* __restrict__ ray_list, const RayDesc* __restrict__ rays,
-                                                   const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ lp,
-                                                   const unsigned long long* __restrict__ bt, TileTable T, Pool P,
-                                                   uint64_t* __restrict__ pairs, unsigned long long pairs_cap, Counters* C) {
-  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
+__global__ void __launch_bounds__(256) k_emit_lane(BatchView V, TileTable T, Pool P) {
+  KS_SLOT_ARGS(V)
   if (blockIdx.x != 0 && blockIdx.x * 4u * (uint32_t)RPW >= C->n_rays) return;
   extern __shared__ unsigned long long s_bt[];
   __shared__ unsigned long long s_carry;
@@ -755,10 +786,13 @@ __global__ void __launch_bounds__(256) k_emit_lane(const FrameParams* __restrict
 
 // merged + anti-grazing: the number of steps of each bundle's ray that emit an update
 template <int LPR>
-__global__ void __launch_bounds__(256) k_count_grazing(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ ray_list,
-                                                       const RayDesc* __restrict__ rays, uint32_t* __restrict__ cnt,
-                                                       const Counters* C) {
-  const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
+__global__ void __launch_bounds__(256) k_count_grazing(BatchView V) {
+  const SlotView& sv = V.s[blockIdx.y];
+  const uint32_t* __restrict__ ray_list = sv.ray_list;
+  const RayDesc* __restrict__ rays = sv.rays;
+  uint32_t* __restrict__ cnt = sv.cnt;
+  const Counters* C = sv.C;
+  const FrameParams F = *sv.F;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   const LaneGroup<LPR> G;
   const uint32_t r = (blockIdx.x * 256u + threadIdx.x) / LPR;
   if (r >= C->n_rays) return;
@@ -788,9 +822,10 @@ __global__ void __launch_bounds__(64) k_set_params(FrameParams F, FrameParams* _
 // End of stage B: the frame's counters and the persistent tile count go to pinned host memory,
 // and the counters are cleared for the slot's next frame (the tail only uses n_long, which it
 // expects to be zero): no memset launch per frame.
-__global__ void __launch_bounds__(64) k_publish(Counters* __restrict__ C, const uint32_t* __restrict__ n_tiles,
-                                                uint32_t* __restrict__ host_snap) {
+__global__ void __launch_bounds__(64) k_publish(BatchView V, const uint32_t* __restrict__ n_tiles) {
   static_assert(sizeof(Counters) == 32, "snapshot layout");
+  Counters* __restrict__ C = V.s[blockIdx.x].C;      // one workgroup per frame of the batch
+  uint32_t* __restrict__ host_snap = V.s[blockIdx.x].host_snap;
   if (threadIdx.x < 8) {
     host_snap[threadIdx.x] = ((const uint32_t*)C)[threadIdx.x];
     ((uint32_t*)C)[threadIdx.x] = 0u;

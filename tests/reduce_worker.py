@@ -28,18 +28,24 @@ def config_kw():
                 method=1, voxels_per_side=8)
 
 
-def export_all(h, torch):
+def export_all(h, torch=None):
+    """Every resident tile as (keys, [n, 512, 32] u32 records).  Device staging through the HIP runtime directly
+    (ctypes), so that a worker process does not have to import torch."""
     keys = h.tile_keys()
-    buf = torch.empty((len(keys), 16384), dtype=torch.int32, device="cuda")
-    if len(keys):
-        h.export_tiles(np.arange(len(keys), dtype=np.uint32), buf.data_ptr())
-    torch.cuda.synchronize()
-    return keys, buf.cpu().numpy().view(np.uint32).reshape(len(keys), 512, 32)
+    n = len(keys)
+    rec = np.zeros((n, 512, 32), dtype=np.uint32)
+    if n:
+        hip = C.CDLL("libamdhip64.so")
+        d = C.c_void_p()
+        assert hip.hipMalloc(C.byref(d), C.c_size_t(n * 65536)) == 0
+        h.export_tiles(np.arange(n, dtype=np.uint32), d.value)
+        assert hip.hipMemcpy(C.c_void_p(rec.ctypes.data), d, C.c_size_t(n * 65536), C.c_int(2)) == 0   # hipMemcpyDeviceToHost
+        hip.hipFree(d)
+    return keys, rec
 
 
 def main():
     rank, world, uid_hex, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
-    import torch
     from kimera_semantics_amd import binding as B
     lib = C.CDLL(os.environ["KS_RCCL_LIB"])
 
@@ -56,7 +62,7 @@ def main():
         for f in frames_of(rank, world, batch):
             h.integrate(f.T_G_C, f.xyz, None, f.labels)
         stats.append(h.reduce(comm.value, rank, world))
-    keys, rec = export_all(h, torch)
+    keys, rec = export_all(h)
     np.savez(os.path.join(out, f"rank{rank}.npz"), keys=keys, rec=rec[:, :, :25],
              sent=np.array([s["tiles_sent"] for s in stats]), received=np.array([s["tiles_received"] for s in stats]))
     h.close()

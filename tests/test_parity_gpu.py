@@ -788,3 +788,24 @@ def test_benched_configuration_map_is_exact(method):
     assert upd_o == upd_h
     rep = compare_maps(o, h, exact=True)
     assert rep["oracle_touched"] > 200000
+
+
+@pytest.mark.parametrize("method", [0, 1])
+def test_batched_stage_b_equals_unpipelined(method):
+    """pipeline_frames = 8: stage B of four consecutive frames is ONE batched launch sequence (blockIdx.y = frame).
+    22 frames (full batches, a partial one at the flush, a query in between that forces a partial batch): same map
+    and statistics as the unpipelined context; fast runs the default early-out schedule."""
+    kw = dict(COMMON, method=method)
+    a = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 15, pipeline_frames=0, **kw))
+    b = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 15, pipeline_frames=8, **kw))
+    sc = synth.make_scene("room")
+    ua = ub = 0
+    for k in range(22):
+        f = synth.render_frame(sc, synth.trajectory_pose(k), 128, 96, seed=k)
+        ua += a.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
+        ub += b.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
+        if k == 13:
+            assert len(b.tile_keys()) == len(a.tile_keys())   # completes the frames in flight (a partial batch)
+    ub += b.flush().n_voxel_updates
+    assert ua == ub
+    compare_maps(a, b, exact=True)

@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/pipe_trace
 rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O -o run -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-secondary --no-oracle-count > $O/log.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O -o run -- env KS_BENCH_PIPE=${KS_BENCH_PIPE:-4} python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-secondary --no-oracle-count > $O/log.txt 2>&1
 tail -c 600 $O/log.txt
 cd $R
 python - <<'PY'
