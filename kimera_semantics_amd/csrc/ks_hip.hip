@@ -173,6 +173,8 @@ struct ks_ctx {
   // frame).  The call still returns only after both are done, so what a call delivers does not change.
   std::thread tail_thread;
   std::mutex tail_mu;
+  std::mutex capture_mu;           // a stream capture (caller) never overlaps a tail being enqueued (helper): the tail may
+                                   // allocate, free or synchronise, which a capture in progress on another thread does not survive reliably
   std::condition_variable tail_cv;
   FrameSlot* tail_job = nullptr;   // posted by the caller, taken by the helper
   bool tail_busy = false, tail_quit = false;
@@ -728,6 +730,7 @@ int launch_batch(ks_ctx* c) {
     replayed = true;
   } else if (c->use_graphs) {
     if (S0.b_graph_key != key || !S0.b_graph) {
+      std::lock_guard<std::mutex> cap(c->capture_mu);  // (rare: once per group of slots)
       if (S0.b_graph) (void)hipGraphExecDestroy(S0.b_graph);
       S0.b_graph = nullptr;
       S0.b_graph_key = 0;
@@ -1134,7 +1137,11 @@ void tail_worker(ks_ctx* c) {
     FrameSlot* S = c->tail_job;
     c->tail_job = nullptr;
     lk.unlock();
-    const int rc = frame_tail(c, *S);
+    int rc;
+    {
+      std::lock_guard<std::mutex> cap(c->capture_mu);
+      rc = frame_tail(c, *S);
+    }
     lk.lock();
     c->tail_rc = rc;
     c->tail_busy = false;
@@ -1503,7 +1510,15 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
         if (sp && strchr(sp, tag)) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, tag == 'l' ? lo : hi);
         return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
       };
-      for (int i = 0; i < c->n_march; ++i) CRCHK(mk(&c->stream_march_[i], 'm'));
+      // without an early-out stage B is short (scan + emission): it follows stage A on the same stream, and the three
+      // streams that remain (A+B, T, long runs) map onto hardware queues of their own
+      static const bool merged_own_march = getenv("KS_MERGED_OWN_MARCH") != nullptr;  // experiments
+      if (!uses_early_out && !merged_own_march) {
+        c->n_march = 1;
+        c->stream_march_[0] = c->stream;
+      } else {
+        for (int i = 0; i < c->n_march; ++i) CRCHK(mk(&c->stream_march_[i], 'm'));
+      }
       {
         const char* tm = getenv("KS_TAIL_ON_MAIN");  // experiments: stage T shares stage A's stream
         if (tm && tm[0] == '1') c->stream_tail = c->stream;

@@ -379,25 +379,32 @@ __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long
                   ((float)v.vz + 0.5f) * Pm.voxel_size};
     const f3 v_voxel_origin = sub3(c, F.T.t);
 
-    // software pipeline: rays of batch b+1 and pair keys of batch b+2 are in flight while batch b is applied
-    // All loads of the pipeline are UNCONDITIONAL (indices clamped): a load under a divergent
-    // branch makes the compiler drain vmcnt at the join, which serialises the prefetch.
+    // software pipeline: the ray descriptors of the next kPf batches and the pair keys of the one after them are in
+    // flight while batch b is applied (a batch is applied in well under the latency of its random 32-byte gathers:
+    // with one batch of look-ahead the voxel next to the sensor — one run of ~1e4 .. 1e5 updates — ran at memory
+    // latency per 64 updates).  All loads of the pipeline are UNCONDITIONAL (indices clamped): a load under a
+    // divergent branch makes the compiler drain vmcnt at the join, which serialises the prefetch.
+    constexpr int kPf = 4;
     const unsigned long long last = n_pairs - 1ull;
     unsigned long long base = start;
-    uint64_t key_cur = pairs[min(base + lane, last)];
-    uint64_t key_nxt = pairs[min(base + 64ull + lane, last)];
-    bool in = (base + lane < n_pairs) && ((uint32_t)(key_cur >> F.seq_bits) == vox);
-    RayDesc d = rays[ray_index(F, (uint32_t)key_cur & F.point_mask)];
+    uint64_t key_q[kPf + 1];  // key_q[i]: batch b + i
+    RayDesc d_q[kPf];
+#pragma unroll
+    for (int i = 0; i <= kPf; ++i) key_q[i] = pairs[min(base + 64ull * i + lane, last)];
+#pragma unroll
+    for (int i = 0; i < kPf; ++i) d_q[i] = rays[ray_index(F, (uint32_t)key_q[i] & F.point_mask)];
     for (;;) {
+      const uint64_t key_cur = key_q[0];
+      const RayDesc d = d_q[0];
+      const bool in = (base + lane < n_pairs) && ((uint32_t)(key_cur >> F.seq_bits) == vox);
       const int cnt = (int)__popcll(__ballot(in));  // sorted => the in-lanes form a prefix
       if (cnt == 0) {
         if (lane == 0) s_cnt[buf] = 0;
         __syncthreads();
         break;
       }
-      const bool in_n = (base + 64ull + lane < n_pairs) && ((uint32_t)(key_nxt >> F.seq_bits) == vox);
-      const RayDesc d_n = rays[ray_index(F, (uint32_t)key_nxt & F.point_mask)];
-      const uint64_t key_nn = pairs[min(base + 128ull + lane, last)];
+      const RayDesc d_new = rays[ray_index(F, (uint32_t)key_q[kPf] & F.point_mask)];     // batch b + kPf
+      const uint64_t key_new = pairs[min(base + 64ull * (kPf + 1) + lane, last)];      // batch b + kPf + 1
 
       // ---- per-lane, voxel-state-independent part: computeDistance + weight drop-off ----
       float sdf = 0.f, uw = 0.f;
@@ -474,10 +481,12 @@ __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long
       __syncthreads();
       buf ^= 1;
       if (cnt < 64) break;
-      d = d_n;
-      in = in_n;
-      key_cur = key_nxt;
-      key_nxt = key_nn;
+#pragma unroll
+      for (int i = 0; i + 1 < kPf; ++i) d_q[i] = d_q[i + 1];
+      d_q[kPf - 1] = d_new;
+#pragma unroll
+      for (int i = 0; i < kPf; ++i) key_q[i] = key_q[i + 1];
+      key_q[kPf] = key_new;
       base += 64;
     }
     __syncthreads();  // the consumer has the label
