@@ -890,9 +890,15 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
       hipLaunchKernelGGL(k_bo_init, dim3((uint32_t)((n + kBoBlock - 1) / kBoBlock)), dim3(kBoBlock), lds_f, st, (uint32_t)n,
                          (const uint64_t*)sk, (const uint32_t*)sv, c->bo);
       const uint32_t nbb = (uint32_t)((n + kBoBlock - 1) / kBoBlock);  // a frame of n points has at most n bundles
-      for (int e = 0; e <= c->bo_epochs; ++e) {
+      // epochs whose bucket count fits one workgroup's LDS: one launch for all of them (both maps)
+      int e_small = 0;
+      while (e_small < c->bo_epochs && c->bo_sched.b[e_small] <= kBoSmallBuckets) ++e_small;
+      static const bool no_small = getenv("KS_BO_NO_SMALL") != nullptr;  // diagnostics: every epoch through the global kernels
+      if (no_small) e_small = 0;
+      if (e_small > 0) hipLaunchKernelGGL(k_bo_small, dim3(2), dim3(kBoBlock), 0, st, c->bo, e_small);
+      for (int e = e_small; e <= c->bo_epochs; ++e) {
         if (e > 0 && c->bo_sched.t[e - 1] >= n) break;  // no map of this frame reaches epoch e - 1
-        hipLaunchKernelGGL(k_bo_link, dim3(nbb, 2), dim3(kBoBlock), lds_e, st, c->bo, e);
+        hipLaunchKernelGGL(k_bo_link, dim3(nbb, 2), dim3(kBoBlock), lds_e, st, c->bo, e, (e == e_small && e_small > 0) ? 1 : 0);
         if (e < c->bo_epochs && c->bo_sched.t[e] < n)
           hipLaunchKernelGGL(k_bo_walk, dim3(nbb, 2), dim3(kBoBlock), 0, st, c->bo, e);
       }

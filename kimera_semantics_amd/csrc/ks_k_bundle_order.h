@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(kBoBlock) k_bo_init(uint32_t n, const uint64_t
 }
 
 // one epoch transition: ranks of epoch e-1 (-> final result, or positions of epoch e) and the chains of epoch e
-__global__ void __launch_bounds__(kBoBlock) k_bo_link(BoCtx X, int e) {
+// prev_small: epochs [0, e) were evaluated by k_bo_small, which left every element's rank in M.rank
+__global__ void __launch_bounds__(kBoBlock) k_bo_link(BoCtx X, int e, int prev_small) {
   extern __shared__ uint32_t s_tot[];
   const BoSchedule& S = *X.sched;
   const BoMap& M = X.m[blockIdx.y];
@@ -157,6 +158,7 @@ __global__ void __launch_bounds__(kBoBlock) k_bo_link(BoCtx X, int e) {
   const bool prev_active = e >= 1 && Bm > S.t[e - 1];
   const bool cur_active = e < (int)S.n_epochs && Bm > S.t[e];
   if (!prev_active && !cur_active) return;
+  if (prev_small && !cur_active) return;  // the ranks k_bo_small left are this map's final ranks
   const uint32_t prev_total = prev_active ? (S.t[e] < Bm ? S.t[e] : Bm) : 0u;
   const uint32_t cur_total = cur_active ? (S.t[e + 1] < Bm ? S.t[e + 1] : Bm) : 0u;
   const uint32_t i0 = blockIdx.x * kBoBlock;
@@ -172,7 +174,9 @@ __global__ void __launch_bounds__(kBoBlock) k_bo_link(BoCtx X, int e) {
     M.idj[cur][j] = id;
     M.kj[cur][j] = k;
   };
-  if (prev_active) {
+  if (prev_active && prev_small) {
+    if (i < prev_total) insert(i, M.rank[i]);
+  } else if (prev_active) {
     bo_prefix_totals(M.bt, (prev_total + kBoBlock - 1u) / kBoBlock, s_tot);
     if (i < prev_total) {
       const uint32_t g = M.gm[i];
@@ -212,6 +216,82 @@ __global__ void __launch_bounds__(kBoBlock) k_bo_walk(BoCtx X, int e) {
   const uint32_t ex = bo_block_scan(w, &tot);
   if (j < total) M.lp[j] = ex;
   if (threadIdx.x == 0) M.bt[blockIdx.x] = tot;
+}
+
+// The epochs that fit one workgroup's LDS — bucket counts up to kBoSmallBuckets, i.e. the first kBoSmallBuckets
+// elements — in ONE launch (a 640x480 / 5 cm frame has ~1e4 bundles: two launch pairs remain of fifteen).  Same
+// recurrence as k_bo_link / k_bo_walk, the chains, the scan and the ranks in LDS; one workgroup per map.
+constexpr uint32_t kBoSmallBuckets = 5087;   // libstdc++'s 10th bucket count (13, 29, ..., 2357, 5087)
+constexpr uint32_t kBoSmallItems = (kBoSmallBuckets + kBoBlock - 1) / kBoBlock;  // elements per thread
+__global__ void __launch_bounds__(kBoBlock) k_bo_small(BoCtx X, int e_end) {
+  __shared__ uint32_t s_head[kBoSmallBuckets];  // chain heads (reverse positions)
+  __shared__ uint16_t s_next[kBoSmallBuckets], s_idj[kBoSmallBuckets], s_gm[kBoSmallBuckets], s_rank[kBoSmallBuckets];
+  __shared__ uint16_t s_w[kBoSmallBuckets], s_cj[kBoSmallBuckets];
+  __shared__ uint32_t s_H[kBoSmallBuckets];     // hash codes of the elements the small epochs cover
+  const BoSchedule& S = *X.sched;
+  const BoMap& M = X.m[blockIdx.x];
+  const uint32_t Bm = X.B[blockIdx.x];
+  const uint32_t tid = threadIdx.x;
+  constexpr uint16_t kNil = 0xffffu;
+  {
+    const uint32_t cover = S.t[e_end] < Bm ? S.t[e_end] : Bm;
+    for (uint32_t id = tid; id < cover; id += kBoBlock) s_H[id] = M.H[id];
+  }
+  __syncthreads();
+  for (int e = 0; e < e_end; ++e) {
+    if (!(Bm > S.t[e])) break;  // uniform
+    const uint32_t total = S.t[e + 1] < Bm ? S.t[e + 1] : Bm;
+    const uint32_t b = S.b[e], t_e = S.t[e];
+    for (uint32_t k = tid; k < b; k += kBoBlock) s_head[k] = kBoEmpty;
+    __syncthreads();
+    // link: reverse position j = total - 1 - position
+    for (uint32_t id = tid; id < total; id += kBoBlock) {
+      const uint32_t pos = id < t_e ? (uint32_t)s_rank[id] : id;
+      const uint32_t j = total - 1u - pos;
+      const uint32_t nx = atomicExch(&s_head[s_H[id] % b], j);
+      s_next[j] = nx == kBoEmpty ? kNil : (uint16_t)nx;
+      s_idj[j] = (uint16_t)id;
+    }
+    __syncthreads();
+    // walk: the bucket's largest j, its size, the smaller j's in it; the largest j carries the size into the scan
+    for (uint32_t j = tid; j < total; j += kBoBlock) {
+      uint32_t cnt = 0, mx = 0, smaller = 0;
+      uint32_t x = s_head[s_H[s_idj[j]] % b];
+      while (x != kBoEmpty) {
+        ++cnt;
+        mx = x > mx ? x : mx;
+        smaller += x < j ? 1u : 0u;
+        const uint16_t n = s_next[x];
+        x = n == kNil ? kBoEmpty : (uint32_t)n;
+      }
+      s_gm[j] = (uint16_t)mx;
+      s_cj[j] = (uint16_t)smaller;
+      s_w[j] = (uint16_t)(mx == j ? cnt : 0u);
+    }
+    __syncthreads();
+    // exclusive scan of s_w over j: thread t owns j in [t * kBoSmallItems, (t + 1) * kBoSmallItems)
+    {
+      uint32_t mine = 0;
+      const uint32_t j0 = tid * kBoSmallItems;
+      for (uint32_t q = 0; q < kBoSmallItems; ++q)
+        if (j0 + q < total) mine += s_w[j0 + q];
+      uint32_t tot;
+      uint32_t run = bo_block_scan(mine, &tot);
+      (void)tot;
+      for (uint32_t q = 0; q < kBoSmallItems; ++q)
+        if (j0 + q < total) {
+          const uint32_t v = s_w[j0 + q];
+          s_w[j0 + q] = (uint16_t)run;   // exclusive prefix
+          run += v;
+        }
+    }
+    __syncthreads();
+    for (uint32_t j = tid; j < total; j += kBoBlock) s_rank[s_idj[j]] = (uint16_t)((uint32_t)s_w[s_gm[j]] + (uint32_t)s_cj[j]);
+    __syncthreads();
+  }
+  // ranks of the elements the small epochs covered: final if the map ended there, positions of the next epoch otherwise
+  const uint32_t done = S.t[e_end] < Bm ? S.t[e_end] : Bm;
+  for (uint32_t id = tid; id < done; id += kBoBlock) M.rank[id] = s_rank[id];
 }
 
 // integration id q of the bundle whose head sits at sorted index i: canonical order = the position of its

@@ -11,14 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def frames_of(rank, world, batch, n_per_rank=2):
+def frames_of(rank, world, batch, n_per_rank=1):
     from kimera_semantics_amd import synth
     sc = synth.make_scene("room")
     n = world * n_per_rank
     out = []
     for j in range(n_per_rank):
         k = rank + world * j
-        out.append(synth.render_frame(sc, synth.arc_pose(k, n, spacing=0.3 + 0.1 * batch), 160, 120, seed=500 + 10 * batch + k))
+        out.append(synth.render_frame(sc, synth.arc_pose(k, n, spacing=0.3 + 0.1 * batch), 96, 72, seed=500 + 10 * batch + k))
     return out
 
 
