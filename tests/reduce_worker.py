@@ -11,14 +11,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def frames_of(rank, world, batch, n_per_rank=1):
+def frames_of(rank, world, batch, n_per_rank=2):
     from kimera_semantics_amd import synth
     sc = synth.make_scene("room")
     n = world * n_per_rank
     out = []
     for j in range(n_per_rank):
         k = rank + world * j
-        out.append(synth.render_frame(sc, synth.arc_pose(k, n, spacing=0.3 + 0.1 * batch), 96, 72, seed=500 + 10 * batch + k))
+        out.append(synth.render_frame(sc, synth.arc_pose(k, n, spacing=0.3 + 0.1 * batch), 160, 120, seed=500 + 10 * batch + k))
     return out
 
 
@@ -45,6 +45,8 @@ def export_all(h, torch=None):
 
 
 def main():
+    import time
+    t0 = time.time()
     rank, world, uid_hex, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     from kimera_semantics_amd import binding as B
     lib = C.CDLL(os.environ["KS_RCCL_LIB"])
@@ -56,17 +58,26 @@ def main():
     comm = C.c_void_p()
     lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     assert lib.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+    t1 = time.time()
     h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **config_kw()))   # small pool: it has to grow (frames and received tiles)
-    stats = []
+    t2 = time.time()
+    stats, times = [], []
     for batch in range(2):
-        for f in frames_of(rank, world, batch):
+        ta = time.time()
+        fr = frames_of(rank, world, batch)
+        tb = time.time()
+        for f in fr:
             h.integrate(f.T_G_C, f.xyz, None, f.labels)
+        h.synchronize()
+        tc = time.time()
         stats.append(h.reduce(comm.value, rank, world))
+        times.append((round(tb - ta, 2), round(tc - tb, 2), round(time.time() - tc, 2)))
     keys, rec = export_all(h)
     np.savez(os.path.join(out, f"rank{rank}.npz"), keys=keys, rec=rec[:, :, :25],
              sent=np.array([s["tiles_sent"] for s in stats]), received=np.array([s["tiles_received"] for s in stats]))
     h.close()
-    print("worker", rank, "ok", stats)
+    print("worker", rank, "ok", stats, "seconds: imports", round(t1 - t0, 2), "create", round(t2 - t1, 2),
+          "per batch (render, integrate, reduce)", times, "total", round(time.time() - t0, 2))
 
 
 if __name__ == "__main__":

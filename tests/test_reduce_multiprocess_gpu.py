@@ -1,6 +1,6 @@
 """-m gpu: the MULTI-RANK path of ks_reduce (include/ks_hip.h) — count exchange, per-peer offsets, grouped
 send / receive of keys and raw tile records, owner merge in ascending source-rank order, sender reset, repeated
-reduce — with 3 ranks (every rank both sends to and receives from two peers).  A development box has one GPU and RCCL refuses two ranks on one device, so the ranks
+reduce — with 2 and 3 ranks.  A development box has one GPU and RCCL refuses two ranks on one device, so the ranks
 are PROCESSES SHARING THE GPU and the communicator is the test double tests/mock_rccl (same seven entry points,
 messages through /dev/shm); the real RCCL path is exercised with one rank in test_parallel_gpu.py and with N ranks
 by the driver's multi-GPU bench.  Expected result: the same exchange emulated inside one process with the
@@ -61,7 +61,7 @@ def _emulate(world):
     return out
 
 
-@pytest.mark.parametrize("world", [3])
+@pytest.mark.parametrize("world", [2, 3])
 def test_ks_reduce_multi_rank_equals_emulation(tmp_path, world):
     if not os.path.exists(MOCK):
         pytest.fail("tests/mock_rccl/libmock_rccl.so not built: run __graft_entry__.build()")
@@ -84,10 +84,15 @@ def test_ks_reduce_multi_rank_equals_emulation(tmp_path, world):
             pytest.fail("a rank hung")
         outs.append(o)
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    print("\n".join(o.strip().splitlines()[-1] for o in outs))
+    import time
+    t_em = time.time()
     want = _emulate(world)
+    print("emulation seconds", round(time.time() - t_em, 2))
     total_sent = total_recv = 0
     for r in range(world):
-        got = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        with np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) as npz:
+            got = {k: npz[k] for k in npz.files}   # (an NpzFile re-reads the array on every access)
         total_sent += int(got["sent"].sum())
         total_recv += int(got["received"].sum())
         assert int(got["sent"][0]) > 0 and int(got["sent"][1]) > 0, "both reduces must move tiles"
