@@ -480,7 +480,7 @@ def c5_record(B, torch, dist, dev, rank, world, comm):
     t0 = time.perf_counter()
     upd = sum(int(h.integrate(frames[k].T_G_C, frames[k].xyz, frames[k].rgba, frames[k].labels).n_voxel_updates) for k in mine)
     h.synchronize()
-    rstats = h.reduce(comm, rank, world)
+    rstats = h.reduce(comm, rank, world) if comm is not None else PAR.reduce_maps(PAR.HipTileStore(h, dev))
     h.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
@@ -556,12 +556,27 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-        comm = PAR.rccl_comm(rank, world, dev)   # an ncclComm_t of the librccl ks_reduce loads (id broadcast over torch.distributed)
+        try:
+            comm = PAR.rccl_comm(rank, world, dev)   # an ncclComm_t of the librccl ks_reduce loads (id broadcast over torch.distributed)
+        except Exception as e:   # (never take the line down: the same protocol also runs over torch.distributed)
+            sys.stderr.write(f"bench: ctypes RCCL communicator unavailable ({type(e).__name__}: {e}); exchange through torch.distributed\n")
+            comm = None
+        if world > 1:
+            # every rank must take the same path
+            ok = torch.tensor([1 if comm is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                comm = None
+    exchange = "ks_reduce (C ABI, RCCL all-to-all of the dirty tiles to hash-owners)" if comm is not None else \
+        "parallel.reduce_maps (the same protocol over torch.distributed)"
     if world > 1:
+        if comm is None:
+            PAR.warm_up(dev)
+
         def reduce_fn(integ):
-            # the one exchange step of the frame-sharded path (C ABI): dirty tiles -> their owner ranks, all peers at
-            # once over RCCL/xGMI, deterministic owner merge
-            st = integ.reduce(comm, rank, world)
+            # the one exchange step of the frame-sharded path: dirty tiles -> their owner ranks, all peers at once over
+            # RCCL/xGMI, deterministic owner merge
+            st = integ.reduce(comm, rank, world) if comm is not None else PAR.reduce_maps(PAR.HipTileStore(integ, dev))
             integ.synchronize()
             return st
 
@@ -593,7 +608,7 @@ def main():
             count_of_frame = lambda i: per_frame[i]   # noqa: E731  (only sums over whole regions are used)
 
     c5 = None
-    if comm is not None:
+    if world > 1 or os.environ.get("KS_BENCH_C5") == "1":
         try:
             c5 = c5_record(B, torch, dist, dev, rank, world, comm)
         except Exception as e:   # collective calls above are symmetric; a local failure must not take the line down
@@ -625,7 +640,7 @@ def main():
                                      "run); the serial result itself: secondary C2-exact") if args.method == "fast" else "n/a (merged)",
                        "bundle_order": "reference (std::unordered_map iteration order, computed on the GPU)" if args.method == "merged" else "n/a (fast)",
                        "parallelism": f"frame-sharded x{world}" + (
-                           " + one ks_reduce (RCCL all-to-all of the dirty tiles to hash-owners) at the end of every timed region"
+                           f" + one exchange at the end of every timed region: {exchange}"
                            if world > 1 else "")},
             "roofline": rec["roofline"],
             "host_ms_per_frame": {"in_call": round(m["prof"]["host_ms"] / max(1, m["prof"]["frames"]), 4),
