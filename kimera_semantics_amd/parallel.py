@@ -134,7 +134,7 @@ def owned_tile_mask(keys: np.ndarray, rank: int, world: int) -> np.ndarray:
     return owner_of(keys, world) == rank
 
 
-def rccl_comm(rank: int, world: int, device):
+def rccl_comm(rank: int, world: int, device, timeout: float = 120.0):
     """An ncclComm_t (as an int) over the ranks of the default process group, created with the SAME librccl that
     ks_reduce loads (KS_RCCL_LIB is pointed at torch's copy so the process holds one RCCL): rank 0 draws the
     unique id, torch.distributed broadcasts its 128 bytes, every rank calls ncclCommInitRank.  One rank per GPU."""
@@ -165,7 +165,19 @@ def rccl_comm(rank: int, world: int, device):
     comm = C.c_void_p()
     lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     torch.cuda.set_device(device)
-    rc = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
-    if rc != 0:
-        raise RuntimeError(f"ncclCommInitRank: {rc}")
+    # the collective initialisation runs on a helper thread with a deadline: a caller (bench.py) can fall back to the
+    # torch.distributed exchange instead of hanging if the bootstrap of a second communicator does not complete
+    import threading
+    box = {}
+
+    def init():
+        torch.cuda.set_device(device)
+        box["rc"] = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
+    th = threading.Thread(target=init, daemon=True)
+    th.start()
+    th.join(timeout)
+    if th.is_alive():
+        raise TimeoutError(f"ncclCommInitRank did not return within {timeout} s")
+    if box.get("rc", -1) != 0:
+        raise RuntimeError(f"ncclCommInitRank: {box.get('rc')}")
     return comm.value
