@@ -184,6 +184,7 @@ struct ks_ctx {
   bool host_prof = false;
   bool export_staged = false;             // KS_EXPORT_STAGED=1: voxel export via a device buffer + copy even for pinned targets
   bool use_graphs = true;                // stage B replayed as a hipGraph (KS_NO_GRAPH=1 or a capture failure: plain launches)
+  bool test_pre = false;                 // early phases through k_test_pre (KS_TEST_PRE=0/1)
   uint64_t buffers_epoch = 1;            // bumped whenever a buffer a captured graph points at is re-allocated
   uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
   uint32_t* d_label_lut = nullptr;  // 256 label -> rgba
@@ -603,7 +604,14 @@ void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipS
       const uint32_t steps_cap = (uint32_t)((steps_max + 3) & ~(size_t)3);
       const size_t lds_wave = (size_t)test_lds_words64(steps_cap) * sizeof(unsigned long long);
       const uint32_t wpb = lds_wave * 4 <= 60 * 1024 ? 4u : lds_wave * 2 <= 60 * 1024 ? 2u : 1u;  // wavefronts per block
-      hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb, nb), dim3(64 * wpb), lds_wave * wpb, sm, V, g0, g1, steps_cap);
+      // early phases of 2 .. 16 generations (one sub-run per chain, nearly every ray walked to its end): the variant that
+      // walks and looks up all rays of the sub-run side by side, when their keys fit the LDS of a wavefront
+      const uint32_t cap_pre = test_pre_cap(steps_cap);
+      const size_t lds_pre = test_pre_lds_bytes(cap_pre);
+      if (c->test_pre && n_sub == 1 && g1 - g0 >= 2 && lds_pre <= 64 * 1024)
+        hipLaunchKernelGGL(k_test_pre, dim3(kChains, nb), dim3(64), lds_pre, sm, V, g0, g1, cap_pre);
+      else
+        hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb, nb), dim3(64 * wpb), lds_wave * wpb, sm, V, g0, g1, steps_cap);
     }
   }
   if (part == 1) return;
@@ -1497,6 +1505,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   // own.  Otherwise stage B stays strictly in frame order.
   const bool frames_independent = !uses_early_out || c->cfg.clear_checks_every_n_frames <= 1;
   c->batch = 1;
+  if (const char* tp = getenv("KS_TEST_PRE")) c->test_pre = atoi(tp) != 0;
   if (c->cfg.pipeline_frames >= 2 && frames_independent && !c->exact_early_out && c->cfg.integration_order_mode != KS_ORDER_SORTED) {
     // (measured, 640x480: a batch of 4 behind 8 frames of lag ~ four single-frame sequences on four streams behind 4
     // frames of lag; batches of 2 or 3 lose to both: DESIGN.md)

@@ -138,6 +138,7 @@ __device__ __forceinline__ void dda_round64(Dda& st, float* E, uint32_t lane, Vi
       t = t + d;
     }
   }
+  KS_WAVE_LDS_ORDER();
   const float *Ex = E, *Ey = E + kES, *Ez = E + 2 * kES;
   const float ex = Ex[lane], ey = Ey[lane], ez = Ez[lane];
   const int cyx = sorted_count<false>(Ey, ex), czx = sorted_count<false>(Ez, ex);
@@ -370,6 +371,7 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
   }
   // ---- C: the rays in generation order against the private set ----
   for (uint32_t todo = live_mask; todo != 0u; todo &= todo - 1u) {
+    KS_WAVE_LDS_ORDER();   // B's hit masks / the previous ray's marks in the private set
     const uint32_t j = (uint32_t)__ffs((int)todo) - 1u;
     const int steps_j = (int)rinfo[j];
     const uint32_t hs = rinfo[16 + j];
@@ -416,6 +418,7 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
             dda.advance(s0 + i < (uint32_t)steps_j);
           }
         }
+        KS_WAVE_LDS_ORDER();
         const bool v64 = lane < n_round;
         bool hit64 = false;
         if (v64) {
@@ -438,7 +441,7 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
     }
     // the older-phase marks this wavefront's tests saved have been performed before any mark of its own goes out
     if (__ballot(my_save) != 0ull) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      KS_WAIT_VMEM();
       my_save = false;
     }
     // marks of the voxels past the first 16 (kept in LDS: no second walk): the chain's private set, and the shared set
@@ -468,6 +471,178 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
     KS_STAT_MAX(7, st_rounds);
   }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------
+// k_test_pre — the same phase, same schedule, same result as k_test, for a phase of at most ONE sub-run per chain
+// (the early phases: 2 .. 16 generations).  There hardly any mark exists yet, nearly every ray is walked to its end,
+// and k_test spends the phase on one ray after the other: caster rounds, then a round trip to the shared set, per 64
+// voxels, 16 rays in sequence, on a chip that holds exactly one such wavefront per SIMD.  Nothing of that depends on
+// the previous rays of the chain except the private-set lookup.  So:
+//   A  lanes 0..15, one ray each: ALL voxels of the ray walked by its owner lane (16 rays side by side); the voxel
+//      hashes go to LDS (the slot follows from the hash)
+//   B  all 64 lanes: the shared-set entries of all those voxels, 16 loads per lane in flight; the snapshot verdict
+//      goes to a bitmap in LDS; older-phase entries are saved exactly as in k_test; ONE wait for the saves
+//   C  the rays in generation order, LDS only: private set, else the stored verdict; collision rule; marks
+// LDS per wavefront: private set (8 KiB) + 16 x cap hashes (cap = longest possible ray + 1, padded to 1 mod 32 so that
+// the 16 owner lanes write to different banks) + 16 x cap verdict bits.  One wavefront per block.
+// Checked against k_test and a serial restatement of the schedule without a GPU: tools/emu/test_k_test_pre.cpp.
+// ------------------------------------------------------------------------------------------
+typedef unsigned long long obs_u64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) unsigned long long obs_global_u64;
+typedef __attribute__((address_space(1))) obs_u64x2 obs_global_u64x2;
+__device__ __forceinline__ void obs_atomic_max(obs_global_u64* p, unsigned long long v) {   // = atomicMax, result unused
+  (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr uint32_t kPreInFlight = 16;
+__host__ __device__ inline uint32_t test_pre_cap(uint32_t steps_cap) { return ((steps_cap + 1u + 31u) & ~31u) + 1u; }
+__host__ __device__ inline uint32_t test_pre_bit_words(uint32_t cap) { return (cap + 31u) / 32u; }
+__host__ __device__ inline uint32_t test_pre_lds_bytes(uint32_t cap) {
+  return kPrivSlots * 8u + 16u * cap * 4u + 16u * test_pre_bit_words(cap) * 4u + 64u;
+}
+
+__global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint32_t g1, uint32_t cap) {
+  const SlotView& sv = V.s[blockIdx.y];
+  const uint8_t* __restrict__ live = sv.live;
+  const RayDesc* __restrict__ rays = sv.rays;
+  uint32_t* __restrict__ cnt = sv.cnt;
+  const Counters* C = sv.C;
+  const FrameParams F = *sv.F;
+  // [slot] = {newest, older}.  The table pointer comes out of a struct in memory, i.e. as a generic pointer; accesses
+  // through it would be FLAT operations, which the compiler must order conservatively against LDS traffic (a full
+  // s_waitcnt after every save).  It is device memory: say so.
+  obs_global_u64* observed = (obs_global_u64*)(unsigned long long*)F.observed;
+  const uint32_t phase_pos0 = g0 * kChains;
+  extern __shared__ unsigned long long s_test[];
+  const uint32_t lane = lane_id();
+  const uint32_t hw = test_pre_bit_words(cap);
+  unsigned long long* priv = s_test;
+  uint32_t* ahash = (uint32_t*)(priv + kPrivSlots);     // [16 rays][cap]  voxel hashes
+  uint32_t* hbits = ahash + 16u * cap;                  // [16 rays][hw]   bit s: the shared set (phase start) holds voxel s
+  int* rsteps = (int*)(hbits + 16u * hw);               // [16] steps of the ray, -1 = no ray
+  for (uint32_t i = lane; i < kPrivSlots; i += 64) priv[i] = 0ull;
+  for (uint32_t i = lane; i < 16u * hw; i += 64) hbits[i] = 0u;
+  if (C->err & (kErrLabel | kErrIndex)) return;
+  const uint32_t chain = blockIdx.x;   // the phase is one sub-run: one wavefront per chain
+  const uint32_t gs = g0;
+  {
+    const uint32_t n_gen = (F.n + kChains - 1u) / kChains;
+    if (g1 > n_gen) g1 = n_gen;
+  }
+  if (gs >= g1) return;
+  const uint32_t ge = gs + kSubRun < g1 ? gs + kSubRun : g1;
+  const int lim = F.max_collisions;
+  auto slot_of = [&](uint32_t h) -> uint32_t { return (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask); };
+
+  {
+    // ---- A: lane l < 16 walks the whole ray of generation gs + l ----
+    int my_steps = -1;
+    Dda dda{};
+    const uint32_t g = gs + lane;
+    const uint64_t p = (uint64_t)g * kChains + chain;
+    const bool is_live = lane < kSubRun && g < ge && p < F.n && live[p] != 0;
+    if (is_live) {
+      const RayDesc d = rays[ray_index(F, (uint32_t)p)];
+      dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
+                /*cast_from_origin=*/false);
+      my_steps = dda.steps < (int)cap ? dda.steps : (int)cap - 1;   // (cap covers the longest possible ray)
+    }
+    int max_steps = my_steps;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const int other = __shfl_xor(max_steps, o);
+      max_steps = other > max_steps ? other : max_steps;
+    }
+    if (lane < 16) rsteps[lane] = my_steps;
+    if (max_steps < 0) return;   // no live ray in this sub-run (wave-uniform)
+    uint32_t* mine = ahash + (size_t)(lane & 15u) * cap;
+    for (int s = 0; s <= my_steps; ++s) {   // (no collective inside: every lane runs its own trip count)
+      mine[s] = index_hash(dda.cx, dda.cy, dda.cz);
+      if (s < my_steps) dda.advance();
+    }
+    __syncthreads();   // (one wavefront: orders the LDS writes above against the reads below)
+    // ---- B: the shared set as it stood when the phase began, for every voxel of every ray ----
+    const uint32_t cpr = ((uint32_t)max_steps + 64u) >> 6;   // 64-voxel chunks per ray
+    const uint32_t n_chunks = 16u * cpr;
+    for (uint32_t q0 = 0; q0 < n_chunks; q0 += kPreInFlight) {
+      uint32_t hh[kPreInFlight];
+      uint32_t on_m = 0u;
+      obs_u64x2 ee[kPreInFlight];
+#pragma unroll
+      for (uint32_t b = 0; b < kPreInFlight; ++b) {   // the loads first, all in flight
+        const uint32_t q = q0 + b, r = (q / cpr) & 15u, s = (q % cpr) * 64u + lane;
+        const bool on = q < n_chunks && (int)s <= rsteps[r];
+        hh[b] = on ? ahash[r * cap + s] : 0u;
+        on_m |= on ? (1u << b) : 0u;
+        ee[b] = on ? ((const obs_global_u64x2*)observed)[slot_of(hh[b])] : obs_u64x2{0ull, 0ull};
+      }
+      // verdicts first, without a branch around a use of the loaded data (the compiler then waits for exactly the load
+      // a verdict needs; behind a branch it would wait for everything in flight, saves included, verdict after verdict)
+      uint32_t save_m = 0u, hit_m = 0u;
+#pragma unroll
+      for (uint32_t b = 0; b < kPreInFlight; ++b) {
+        const obs_u64x2 e = ee[b];
+        const bool valid = ((on_m >> b) & 1u) != 0u;
+        const bool current = (uint32_t)(e.x >> 54) == F.obs_tag && ((uint32_t)(e.x >> 32) & 0x3fffffu) > phase_pos0;
+        const unsigned long long content = current ? e.y : e.x;
+        save_m |= (valid && !current && e.x != 0ull && e.x != e.y) ? (1u << b) : 0u;
+        hit_m |= (valid && obs_match(content, hh[b], F.obs_tag_lo, F.obs_tag)) ? (1u << b) : 0u;
+      }
+#pragma unroll
+      for (uint32_t b = 0; b < kPreInFlight; ++b) {
+        if ((save_m >> b) & 1u) obs_atomic_max(&observed[2u * slot_of(hh[b]) + 1u], ee[b].x);   // save the older-phase mark
+        if ((hit_m >> b) & 1u) {
+          const uint32_t q = q0 + b, r = (q / cpr) & 15u, s = (q % cpr) * 64u + lane;
+          atomicOr(&hbits[r * hw + (s >> 5)], 1u << (s & 31u));
+        }
+      }
+    }
+    // every save of this wavefront has been performed before any of its marks goes out
+    KS_WAIT_VMEM();
+    __syncthreads();
+  }
+  // ---- C: the rays in generation order ----
+  for (uint32_t j = 0; j < kSubRun; ++j) {
+    const int steps_j = rsteps[j];
+    if (steps_j < 0) continue;   // (wave-uniform)
+    KS_WAVE_LDS_ORDER();         // the previous ray's marks in the private set
+    const uint32_t gen_j = gs + j, pos_j = gen_j * kChains + chain;
+    const uint32_t* hj = ahash + (size_t)j * cap;
+    const uint32_t* bj = hbits + (size_t)j * hw;
+    int c = 0, stop = -1;
+    uint32_t updates = 0, visited = 0;
+    for (uint32_t s0 = 0;; s0 += 64u) {
+      const uint32_t left = (uint32_t)steps_j + 1u - s0;
+      const uint32_t n_round = left < 64u ? left : 64u;
+      const bool v = lane < n_round;
+      bool hit = false;
+      if (v) {
+        const uint32_t s = s0 + lane, h = hj[s];
+        if (!priv_lookup(priv, slot_of(h), h, hit)) hit = ((bj[s >> 5] >> (s & 31u)) & 1u) != 0u;
+      }
+      stop = early_out_stop(__ballot(v && hit), __ballot(v), lim, c);
+      if (stop >= 0) {
+        updates = s0 + (uint32_t)stop;
+        visited = updates + 1u;
+        break;
+      }
+      if (s0 + 64u > (uint32_t)steps_j) {
+        updates = (uint32_t)steps_j + 1u;
+        visited = updates;
+        break;
+      }
+    }
+    // the ray's marks (all visited voxels): the chain's private set and the shared set
+    for (uint32_t m0 = 0; m0 < visited; m0 += 64u) {
+      const uint32_t s = m0 + lane;
+      if (s < visited) {
+        const uint32_t h = hj[s], slot = slot_of(h);
+        atomicMax(&priv[slot & (kPrivSlots - 1u)], priv_key(gen_j, s, slot, h));
+        obs_atomic_max(&observed[2u * slot], (unsigned long long)obs_entry(F.obs_tag, pos_j, h));
+      }
+    }
+    if (lane == 0) cnt[pos_j] = updates | (stop >= 0 ? kCntBroke : 0u);
+  }
 }
 
 constexpr uint32_t kLaneWalk = 32;

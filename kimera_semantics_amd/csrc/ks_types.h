@@ -37,6 +37,17 @@ constexpr uint32_t kInvalidSlot = 1u << kSetBits;  // sort key of dropped points
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
+// Two facts about a wavefront that kernels rely on and a host-side functional model (tools/emu) has to be told:
+//  * its LDS operations run in program order, so a lane may read what ANOTHER lane of the same wavefront wrote earlier in
+//    the program without any barrier in between — marked KS_WAVE_LDS_ORDER() (nothing on the GPU, a wave barrier in the model);
+//  * KS_WAIT_VMEM(): the wavefront's outstanding global-memory operations (atomics without return included) have been performed.
+#ifndef KS_WAVE_LDS_ORDER
+#define KS_WAVE_LDS_ORDER()
+#endif
+#ifndef KS_WAIT_VMEM
+#define KS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
+
 // Compaction slot for lanes with pred == true: one atomic per wavefront (a same-address
 // returning atomic per lane saturates at ~88/us on MI355X).  Must be called converged.
 __device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
