@@ -171,6 +171,22 @@ struct Dda {
     ty = sel_y ? ny : ty;
     tz = sel_z ? nz : tz;
   }
+  // advance(), carrying index_hash(cx, cy, cz) along: the hash is linear in the coordinates (mod 2^32), so a step along
+  // an axis adds that axis' increment (hx = sx, hy = 17191 sy, hz = 17191^2 sz as uint32) — no multiplies per step
+  __device__ __forceinline__ void advance_hashed(uint32_t& h, uint32_t hx, uint32_t hy, uint32_t hz) {
+    const bool y_lt = ty < tx;
+    const float m = y_lt ? ty : tx;
+    const bool z_lt = tz < m;
+    const bool sel_z = z_lt, sel_y = y_lt && !z_lt, sel_x = !y_lt && !z_lt;
+    const float nx = tx + dx, ny = ty + dy, nz = tz + dz;
+    cx += sel_x ? sx : 0;
+    cy += sel_y ? sy : 0;
+    cz += sel_z ? sz : 0;
+    h += sel_z ? hz : sel_y ? hy : hx;
+    tx = sel_x ? nx : tx;
+    ty = sel_y ? ny : ty;
+    tz = sel_z ? nz : tz;
+  }
 };
 
 // vxb::Color::blendTwoColors — [K:src/semantic_tsdf_integrator_merged.cpp:273-274] and inside updateTsdfVoxel

@@ -103,6 +103,8 @@ struct FrameSlot {
   uint32_t* d_lp = nullptr;         // exclusive prefix of d_cnt inside blocks of kScanBlock
   unsigned long long* d_bt = nullptr;  // block totals of that scan
   uint8_t* d_live = nullptr;        // fast: position holds a ray that survived start-voxel dedup
+  uint32_t* d_pre_hash = nullptr;   // k_prewalk -> k_test_pre (ks_k_march.h); allocated when the context uses them
+  int* d_pre_steps = nullptr;
   bool wide = false;                // stage B uses a whole wavefront per ray (long rays)
   FrameParams* d_F = nullptr;       // the frame's parameters in device memory (stage B reads them from there)
   uint64_t *d_gkeys = nullptr, *d_rkeys = nullptr;  // anti-grazing: this frame's sorted end-voxel keys / key per bundle
@@ -373,6 +375,50 @@ int ensure_bundle_order(ks_ctx* c, size_t cap) {
   return KS_OK;
 }
 
+// phase boundaries (in generations of 1024 integration positions) of the ordered-phase early-out
+std::vector<uint32_t> phase_bounds(uint32_t n_gen, int growth) {
+  std::vector<uint32_t> b{0};
+  for (;;) {
+    const uint64_t inc = std::max<uint64_t>(1, (uint64_t)b.back() * (uint64_t)(growth - 16) / 16);
+    if (b.back() + inc >= n_gen) break;
+    b.push_back((uint32_t)(b.back() + inc));
+  }
+  return b;
+}
+
+// longest possible ray of a frame of this context, in voxels
+size_t steps_max_of(const ks_config& cfg, float voxel_size_inv) {
+  const double max_len = (double)cfg.max_ray_length_m + 2.0 * (double)cfg.truncation_distance;
+  return (size_t)std::ceil(1.7321 * max_len * (double)voxel_size_inv) + 8;
+}
+// The leading early-out phases of one sub-run per chain go through k_prewalk + k_test_pre when the context asks for it
+// and a wavefront's LDS holds the rays of a sub-run: generations [0, G), rows of `cap` hashes, Gpad generations per chain.
+struct PrePlan {
+  bool on = false;
+  uint32_t G = 0, Gpad = 0, cap = 0;
+};
+PrePlan pre_plan(const ks_ctx* c, size_t cap_points) {
+  PrePlan P;
+  if (!c->test_pre || !c->uses_early_out || cap_points == 0) return P;
+  const uint32_t steps_cap = (uint32_t)((steps_max_of(c->cfg, c->voxel_size_inv) + 3) & ~(size_t)3);
+  const uint32_t cap = test_pre_cap(steps_cap);
+  if (test_pre_lds_bytes(cap) > 64 * 1024 || (cap + 63) / 64 * 16 > kPreMaxChunks) return P;
+  const uint32_t n_gen = (uint32_t)((cap_points + kChains - 1) / kChains);
+  const std::vector<uint32_t> B = phase_bounds(n_gen, c->cfg.early_out_phase_growth);
+  uint32_t G = 0;
+  for (size_t j = 0; j < B.size(); ++j) {
+    const uint32_t g0 = B[j], g1 = (j + 1 < B.size()) ? B[j + 1] : n_gen;
+    if (g1 - g0 > kSubRun) break;
+    G = g1;
+  }
+  if (G == 0) return P;
+  P.on = true;
+  P.G = G;
+  P.Gpad = (G + kSubRun - 1) / kSubRun * kSubRun;
+  P.cap = cap;
+  return P;
+}
+
 int ensure_points(ks_ctx* c, size_t n) {
   if (n <= c->cap_points) return KS_OK;
   // the create-time size is exact; a cloud that outgrows it gets head-room (growing completes the frames in
@@ -391,6 +437,13 @@ int ensure_points(ks_ctx* c, size_t n) {
     if ((rc = dev_alloc(c, &c->slot[i].d_lp, scan_cap))) return rc;
     if ((rc = dev_alloc(c, &c->slot[i].d_bt, scan_cap / kScanBlock + 2))) return rc;
     if (c->cfg.method == KS_METHOD_FAST && (rc = dev_alloc(c, &c->slot[i].d_live, cap))) return rc;
+    {
+      const PrePlan P = pre_plan(c, cap);
+      if (P.on) {
+        if ((rc = dev_alloc(c, &c->slot[i].d_pre_hash, (size_t)kChains * P.Gpad * P.cap))) return rc;
+        if ((rc = dev_alloc(c, &c->slot[i].d_pre_steps, (size_t)kChains * P.Gpad))) return rc;
+      }
+    }
     if (c->cfg.enable_anti_grazing && c->cfg.method == KS_METHOD_MERGED) {
       if ((rc = dev_alloc(c, &c->slot[i].d_gkeys, cap))) return rc;
       if ((rc = dev_alloc(c, &c->slot[i].d_rkeys, cap))) return rc;
@@ -504,17 +557,6 @@ int reset_set(ks_ctx* c, uint64_t* d_set0, uint64_t* offset, bool observed) {
   return KS_OK;
 }
 
-// phase boundaries (in generations of 1024 integration positions) of the ordered-phase early-out
-std::vector<uint32_t> phase_bounds(uint32_t n_gen, int growth) {
-  std::vector<uint32_t> b{0};
-  for (;;) {
-    const uint64_t inc = std::max<uint64_t>(1, (uint64_t)b.back() * (uint64_t)(growth - 16) / 16);
-    if (b.back() + inc >= n_gen) break;
-    b.push_back((uint32_t)(b.back() + inc));
-  }
-  return b;
-}
-
 inline void stage_mark(ks_ctx* c, int set, int ev) {
   if (set >= 0 && c->pset[set].stages)
     (void)hipEventRecord(c->pset[set].ev[ev], ev <= 3 ? c->stream : ev <= 5 ? c->prof_march_stream : c->stream_tail);
@@ -563,6 +605,8 @@ SlotView slot_view(const FrameSlot& S, Counters* counters = nullptr) {
   v.pairs_cap = (unsigned long long)S.cap_pairs_in;
   v.C = counters ? counters : S.d_counters;
   v.host_snap = (uint32_t*)S.h_snap;
+  v.pre_hash = S.d_pre_hash;
+  v.pre_steps = S.d_pre_steps;
   return v;
 }
 
@@ -598,18 +642,18 @@ void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipS
     // stood when the phase began and enters their marks (ks_k_march.h)
     const uint32_t n_gen = (uint32_t)((n + kChains - 1) / kChains);
     const std::vector<uint32_t> B = phase_bounds(n_gen, cfg.early_out_phase_growth);
+    // the leading phases of one sub-run per chain: all their rays walked once, up front (ks_k_march.h)
+    const PrePlan P = pre_plan(c, n);
+    if (P.on)
+      hipLaunchKernelGGL(k_prewalk, dim3(kChains * (P.Gpad / kSubRun), nb), dim3(64), prewalk_lds_bytes(P.cap), sm, V, P.G, P.Gpad, P.cap);
     for (size_t j = 0; j < B.size(); ++j) {
       const uint32_t g0 = B[j], g1 = (j + 1 < B.size()) ? B[j + 1] : n_gen;  // k_test ends the frame's last phase at ITS n
       const uint32_t n_sub = (g1 - g0 + kSubRun - 1) / kSubRun;  // wavefronts per chain
       const uint32_t steps_cap = (uint32_t)((steps_max + 3) & ~(size_t)3);
       const size_t lds_wave = (size_t)test_lds_words64(steps_cap) * sizeof(unsigned long long);
       const uint32_t wpb = lds_wave * 4 <= 60 * 1024 ? 4u : lds_wave * 2 <= 60 * 1024 ? 2u : 1u;  // wavefronts per block
-      // early phases of 2 .. 16 generations (one sub-run per chain, nearly every ray walked to its end): the variant that
-      // walks and looks up all rays of the sub-run side by side, when their keys fit the LDS of a wavefront
-      const uint32_t cap_pre = test_pre_cap(steps_cap);
-      const size_t lds_pre = test_pre_lds_bytes(cap_pre);
-      if (c->test_pre && n_sub == 1 && g1 - g0 >= 2 && lds_pre <= 64 * 1024)
-        hipLaunchKernelGGL(k_test_pre, dim3(kChains, nb), dim3(64), lds_pre, sm, V, g0, g1, cap_pre);
+      if (P.on && g1 <= P.G)
+        hipLaunchKernelGGL(k_test_pre, dim3(kChains, nb), dim3(64), test_pre_lds_bytes(P.cap), sm, V, g0, g1, P.Gpad, P.cap);
       else
         hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb, nb), dim3(64 * wpb), lds_wave * wpb, sm, V, g0, g1, steps_cap);
     }
@@ -825,8 +869,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   F.early_out = c->uses_early_out;
 
   // longest possible ray in steps: long rays get a whole wavefront per ray in stage B, short ones 16 lanes
-  const double max_len = (double)cfg.max_ray_length_m + 2.0 * (double)cfg.truncation_distance;
-  const size_t steps_max = (size_t)std::ceil(1.7321 * max_len * (double)c->voxel_size_inv) + 8;
+  const size_t steps_max = steps_max_of(cfg, c->voxel_size_inv);
   const bool wide = steps_max > 400;
   S.wide = wide;
   if ((rc = ensure_pairs_in(c, S, std::max<size_t>(c->pairs_hint + c->pairs_hint / 4, 1 << 20)))) return rc;
@@ -1656,7 +1699,7 @@ void ks_destroy(ks_ctx* c) {
     if (p) (void)hipFree(p);
   for (auto& S : c->slot)
     for (void* p : {(void*)S.d_rays, (void*)S.d_deltas, (void*)S.d_ray_list, (void*)S.d_pairs, (void*)S.d_cnt, (void*)S.d_lp,
-                    (void*)S.d_bt, (void*)S.d_live, (void*)S.d_F, (void*)S.d_gkeys, (void*)S.d_rkeys})
+                    (void*)S.d_bt, (void*)S.d_live, (void*)S.d_F, (void*)S.d_gkeys, (void*)S.d_rkeys, (void*)S.d_pre_hash, (void*)S.d_pre_steps})
       if (p) (void)hipFree(p);
   if (c->h_eo_state) (void)hipHostFree(c->h_eo_state);
   ksrs::release(c->sort_ws);

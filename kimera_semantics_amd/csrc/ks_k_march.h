@@ -185,6 +185,8 @@ struct SlotView {
   unsigned long long pairs_cap;
   Counters* C;
   uint32_t* host_snap;           // pinned snapshot (k_publish)
+  uint32_t* pre_hash;            // k_prewalk -> k_test_pre: voxel hashes of the rays of the first generations, [chain][generation][cap]
+  int* pre_steps;                //   and their step counts (-1 = no ray), [chain][generation]
 };
 struct BatchView {
   SlotView s[kBatchMax];
@@ -474,18 +476,24 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
 }
 
 // ------------------------------------------------------------------------------------------
-// k_test_pre — the same phase, same schedule, same result as k_test, for a phase of at most ONE sub-run per chain
-// (the early phases: 2 .. 16 generations).  There hardly any mark exists yet, nearly every ray is walked to its end,
-// and k_test spends the phase on one ray after the other: caster rounds, then a round trip to the shared set, per 64
-// voxels, 16 rays in sequence, on a chip that holds exactly one such wavefront per SIMD.  Nothing of that depends on
-// the previous rays of the chain except the private-set lookup.  So:
-//   A  lanes 0..15, one ray each: ALL voxels of the ray walked by its owner lane (16 rays side by side); the voxel
-//      hashes go to LDS (the slot follows from the hash)
-//   B  all 64 lanes: the shared-set entries of all those voxels, 16 loads per lane in flight; the snapshot verdict
-//      goes to a bitmap in LDS; older-phase entries are saved exactly as in k_test; ONE wait for the saves
-//   C  the rays in generation order, LDS only: private set, else the stored verdict; collision rule; marks
-// LDS per wavefront: private set (8 KiB) + 16 x cap hashes (cap = longest possible ray + 1, padded to 1 mod 32 so that
-// the 16 owner lanes write to different banks) + 16 x cap verdict bits.  One wavefront per block.
+// k_prewalk + k_test_pre — the same phases, same schedule, same result as k_test, for the LEADING phases of at most
+// one sub-run per chain (generations [0, G), G = 32 with the default growth).  There hardly any mark exists yet, nearly
+// every ray is walked to its end, and k_test spends such a phase on one ray after the other: caster rounds, then a
+// round trip to the shared set, per 64 voxels, up to 16 rays in sequence, on a chip that holds exactly one such
+// wavefront per SIMD (measured: 16 / 22 / 44 / 54 us for phases of 2 / 4 / 8 / 16 generations at 640x480).  Nothing of
+// that depends on the previous rays of the chain except the private-set lookup, and the walk does not depend on the
+// set at all.  So:
+//   k_prewalk (once per frame): the voxel hashes of ALL steps of every ray of generations [0, G), one ray per lane of
+//      the first 16 lanes, 16 generations of a chain per wavefront; staged in LDS, written out as rows
+//      pre_hash[(chain * Gpad + generation) * cap + step] (a chain's generations are adjacent: what a phase reads
+//      is one contiguous range), pre_steps[chain * Gpad + generation] = steps of the ray, -1 = no ray
+//   k_test_pre (per phase), one wavefront per chain:
+//      B  all 64 lanes: the rays' hashes (global -> registers, and LDS for C) and the shared-set entries of all
+//         their voxels, 32 of each per lane in flight; the snapshot verdict goes to a bitmap in LDS; older-phase entries
+//         are saved exactly as in k_test; ONE wait for the saves
+//      C  the rays in generation order, LDS only: private set, else the stored verdict; collision rule; marks
+// LDS per k_test_pre wavefront: private set (8 KiB) + 16 x cap hashes + 16 x cap verdict bits (cap = longest possible
+// ray + 1, padded to 1 mod 32: the 16 owner lanes of k_prewalk write to different banks).  One wavefront per block.
 // Checked against k_test and a serial restatement of the schedule without a GPU: tools/emu/test_k_test_pre.cpp.
 // ------------------------------------------------------------------------------------------
 typedef unsigned long long obs_u64x2 __attribute__((ext_vector_type(2)));
@@ -494,17 +502,55 @@ typedef __attribute__((address_space(1))) obs_u64x2 obs_global_u64x2;
 __device__ __forceinline__ void obs_atomic_max(obs_global_u64* p, unsigned long long v) {   // = atomicMax, result unused
   (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-constexpr uint32_t kPreInFlight = 16;
+constexpr uint32_t kPreInFlight = 32;
+constexpr uint32_t kPreMaxChunks = 128;   // 16 rays x ceil(cap / 64), cap <= 512
 __host__ __device__ inline uint32_t test_pre_cap(uint32_t steps_cap) { return ((steps_cap + 1u + 31u) & ~31u) + 1u; }
 __host__ __device__ inline uint32_t test_pre_bit_words(uint32_t cap) { return (cap + 31u) / 32u; }
 __host__ __device__ inline uint32_t test_pre_lds_bytes(uint32_t cap) {
-  return kPrivSlots * 8u + 16u * cap * 4u + 16u * test_pre_bit_words(cap) * 4u + 64u;
+  return kPrivSlots * 8u + 16u * cap * 4u + 16u * test_pre_bit_words(cap) * 4u + 64u + kPreMaxChunks * 4u;
 }
+__host__ __device__ inline uint32_t prewalk_lds_bytes(uint32_t cap) { return 16u * cap * 4u; }
 
-__global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint32_t g1, uint32_t cap) {
+__global__ void __launch_bounds__(64) k_prewalk(BatchView V, uint32_t G, uint32_t Gpad, uint32_t cap) {
   const SlotView& sv = V.s[blockIdx.y];
   const uint8_t* __restrict__ live = sv.live;
   const RayDesc* __restrict__ rays = sv.rays;
+  const FrameParams F = *sv.F;
+  extern __shared__ unsigned long long s_test[];
+  uint32_t* rows = (uint32_t*)s_test;   // [16 rays][cap]
+  if (sv.C->err & (kErrLabel | kErrIndex)) return;
+  const uint32_t lane = lane_id();
+  const uint32_t chain = blockIdx.x % kChains, gs = (blockIdx.x / kChains) * kSubRun;
+  int my_steps = -1;
+  if (lane < kSubRun) {
+    const uint32_t g = gs + lane;
+    const uint64_t p = (uint64_t)g * kChains + chain;
+    if (g < G && p < F.n && live[p] != 0) {
+      const RayDesc d = rays[ray_index(F, (uint32_t)p)];
+      Dda dda{};
+      dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
+                /*cast_from_origin=*/false);
+      my_steps = dda.steps < (int)cap ? dda.steps : (int)cap - 1;   // (cap covers the longest possible ray)
+      uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
+      const uint32_t hx = (uint32_t)dda.sx, hy = (uint32_t)dda.sy * 17191u, hz = (uint32_t)dda.sz * 295530481u;
+      uint32_t* mine = rows + (size_t)lane * cap;
+      for (int s = 0; s <= my_steps; ++s) {   // (no collective inside: every lane runs its own trip count; the state
+        mine[s] = h;                          //  after the last voxel is not used)
+        dda.advance_hashed(h, hx, hy, hz);
+      }
+    }
+    sv.pre_steps[(size_t)chain * Gpad + g] = my_steps;
+  }
+  __syncthreads();   // (one wavefront: orders the LDS writes above against the reads below)
+  uint32_t* __restrict__ out = sv.pre_hash + ((size_t)chain * Gpad + gs) * cap;
+  for (uint32_t r = 0; r < kSubRun; ++r) {
+    const int steps_r = __shfl(my_steps, (int)r);
+    for (int i = (int)lane; i <= steps_r; i += 64) out[r * cap + (uint32_t)i] = rows[r * cap + (uint32_t)i];
+  }
+}
+
+__global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint32_t g1, uint32_t Gpad, uint32_t cap) {
+  const SlotView& sv = V.s[blockIdx.y];
   uint32_t* __restrict__ cnt = sv.cnt;
   const Counters* C = sv.C;
   const FrameParams F = *sv.F;
@@ -520,6 +566,7 @@ __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint3
   uint32_t* ahash = (uint32_t*)(priv + kPrivSlots);     // [16 rays][cap]  voxel hashes
   uint32_t* hbits = ahash + 16u * cap;                  // [16 rays][hw]   bit s: the shared set (phase start) holds voxel s
   int* rsteps = (int*)(hbits + 16u * hw);               // [16] steps of the ray, -1 = no ray
+  uint32_t* clist = (uint32_t*)(rsteps + 16);           // [<= kPreMaxChunks] ray << 8 | 64-voxel chunk of the ray
   for (uint32_t i = lane; i < kPrivSlots; i += 64) priv[i] = 0ull;
   for (uint32_t i = lane; i < 16u * hw; i += 64) hbits[i] = 0u;
   if (C->err & (kErrLabel | kErrIndex)) return;
@@ -533,47 +580,61 @@ __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint3
   const uint32_t ge = gs + kSubRun < g1 ? gs + kSubRun : g1;
   const int lim = F.max_collisions;
   auto slot_of = [&](uint32_t h) -> uint32_t { return (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask); };
-
+#ifdef KS_STATS
+  const unsigned long long tp0 = __builtin_readcyclecounter(), tw0 = wall_clock64();
+  unsigned long long tp1 = 0, tp2 = 0;
+  uint32_t st_steps = 0, st_chunks = 0;
+#endif
   {
-    // ---- A: lane l < 16 walks the whole ray of generation gs + l ----
+    // ---- the rays of the sub-run: lane l < 16 holds the one of generation gs + l ----
     int my_steps = -1;
-    Dda dda{};
-    const uint32_t g = gs + lane;
-    const uint64_t p = (uint64_t)g * kChains + chain;
-    const bool is_live = lane < kSubRun && g < ge && p < F.n && live[p] != 0;
-    if (is_live) {
-      const RayDesc d = rays[ray_index(F, (uint32_t)p)];
-      dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
-                /*cast_from_origin=*/false);
-      my_steps = dda.steps < (int)cap ? dda.steps : (int)cap - 1;   // (cap covers the longest possible ray)
-    }
+    if (lane < kSubRun && gs + lane < ge) my_steps = sv.pre_steps[(size_t)chain * Gpad + gs + lane];
+    if (lane < 16) rsteps[lane] = my_steps;
+    // 64-voxel chunks of the live rays, ray after ray (no collective: lane 0 alone; <= 128 entries)
     int max_steps = my_steps;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
       const int other = __shfl_xor(max_steps, o);
       max_steps = other > max_steps ? other : max_steps;
     }
-    if (lane < 16) rsteps[lane] = my_steps;
     if (max_steps < 0) return;   // no live ray in this sub-run (wave-uniform)
-    uint32_t* mine = ahash + (size_t)(lane & 15u) * cap;
-    for (int s = 0; s <= my_steps; ++s) {   // (no collective inside: every lane runs its own trip count)
-      mine[s] = index_hash(dda.cx, dda.cy, dda.cz);
-      if (s < my_steps) dda.advance();
+    uint32_t n_chunks = 0;
+    for (uint32_t r = 0; r < kSubRun; ++r) {
+      const int steps_r = __shfl(my_steps, (int)r);
+      if (steps_r < 0) continue;   // (wave-uniform)
+      const uint32_t nc = ((uint32_t)steps_r + 64u) >> 6;
+      if (lane < nc && n_chunks + lane < kPreMaxChunks) clist[n_chunks + lane] = (r << 8) | lane;
+      n_chunks += nc;
     }
+    if (n_chunks > kPreMaxChunks) n_chunks = kPreMaxChunks;   // (cannot happen: cap <= 512)
     __syncthreads();   // (one wavefront: orders the LDS writes above against the reads below)
-    // ---- B: the shared set as it stood when the phase began, for every voxel of every ray ----
-    const uint32_t cpr = ((uint32_t)max_steps + 64u) >> 6;   // 64-voxel chunks per ray
-    const uint32_t n_chunks = 16u * cpr;
+#ifdef KS_STATS
+    tp1 = __builtin_readcyclecounter();
+    st_steps = (uint32_t)max_steps + 1u;
+    st_chunks = n_chunks;
+#endif
+    // ---- B: hashes, and the shared set as it stood when the phase began, for every voxel of every ray ----
+    const uint32_t* __restrict__ gh = sv.pre_hash + ((size_t)chain * Gpad + gs) * cap;
     for (uint32_t q0 = 0; q0 < n_chunks; q0 += kPreInFlight) {
       uint32_t hh[kPreInFlight];
       uint32_t on_m = 0u;
       obs_u64x2 ee[kPreInFlight];
 #pragma unroll
-      for (uint32_t b = 0; b < kPreInFlight; ++b) {   // the loads first, all in flight
-        const uint32_t q = q0 + b, r = (q / cpr) & 15u, s = (q % cpr) * 64u + lane;
+      for (uint32_t b = 0; b < kPreInFlight; ++b) {   // the hashes first, all in flight
+        const uint32_t q = q0 + b;
+        const uint32_t e = q < n_chunks ? clist[q] : 0u;
+        const uint32_t r = e >> 8, s = (e & 255u) * 64u + lane;
         const bool on = q < n_chunks && (int)s <= rsteps[r];
-        hh[b] = on ? ahash[r * cap + s] : 0u;
         on_m |= on ? (1u << b) : 0u;
+        hh[b] = on ? gh[r * cap + s] : 0u;
+      }
+#pragma unroll
+      for (uint32_t b = 0; b < kPreInFlight; ++b) {   // then the set entries, all in flight; the hashes to LDS for C
+        const bool on = ((on_m >> b) & 1u) != 0u;
+        if (on) {
+          const uint32_t e = clist[q0 + b];
+          ahash[(e >> 8) * cap + (e & 255u) * 64u + lane] = hh[b];
+        }
         ee[b] = on ? ((const obs_global_u64x2*)observed)[slot_of(hh[b])] : obs_u64x2{0ull, 0ull};
       }
       // verdicts first, without a branch around a use of the loaded data (the compiler then waits for exactly the load
@@ -592,7 +653,8 @@ __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint3
       for (uint32_t b = 0; b < kPreInFlight; ++b) {
         if ((save_m >> b) & 1u) obs_atomic_max(&observed[2u * slot_of(hh[b]) + 1u], ee[b].x);   // save the older-phase mark
         if ((hit_m >> b) & 1u) {
-          const uint32_t q = q0 + b, r = (q / cpr) & 15u, s = (q % cpr) * 64u + lane;
+          const uint32_t e = clist[q0 + b];
+          const uint32_t r = e >> 8, s = (e & 255u) * 64u + lane;
           atomicOr(&hbits[r * hw + (s >> 5)], 1u << (s & 31u));
         }
       }
@@ -600,6 +662,9 @@ __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint3
     // every save of this wavefront has been performed before any of its marks goes out
     KS_WAIT_VMEM();
     __syncthreads();
+#ifdef KS_STATS
+    tp2 = __builtin_readcyclecounter();
+#endif
   }
   // ---- C: the rays in generation order ----
   for (uint32_t j = 0; j < kSubRun; ++j) {
@@ -643,6 +708,19 @@ __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint3
     }
     if (lane == 0) cnt[pos_j] = updates | (stop >= 0 ? kCntBroke : 0u);
   }
+#ifdef KS_STATS
+  {
+    const unsigned long long tp3 = __builtin_readcyclecounter(), tw3 = wall_clock64();
+    KS_STAT_ADD(8, tp1 - tp0);
+    KS_STAT_ADD(9, tp2 - tp1);
+    KS_STAT_ADD(10, tp3 - tp2);
+    KS_STAT_ADD(11, 1);
+    KS_STAT_ADD(12, tw3 - tw0);
+    KS_STAT_ADD(13, st_steps);
+    KS_STAT_ADD(14, st_chunks);
+    KS_STAT_MAX(15, tw3 - tw0);
+  }
+#endif
 }
 
 constexpr uint32_t kLaneWalk = 32;

@@ -3,7 +3,8 @@
 // stand-in <hip/hip_runtime.h> of this directory) over a synthetic frame, phase by phase, and compares three things
 // after every phase — the per-ray update counts and the newest entry of every slot of the shared early-out set:
 //   (1) every phase through k_test                       (the kernel the GPU tests pin against the oracle)
-//   (2) the phases of 2..16 generations through k_test_pre, the others through k_test   (what ks_hip.hip launches)
+//   (2) k_prewalk, then the leading phases of one sub-run per chain through k_test_pre, the others through k_test
+//       (what ks_hip.hip launches with KS_TEST_PRE=1)
 //   (3) a plain serial restatement of the ordered-phase schedule written here
 // Usage: test_k_test_pre [n_points] [max_collisions] [seed] [voxel_size_m]
 #include <algorithm>
@@ -95,11 +96,13 @@ static Frame make_frame(uint32_t n, int lim, uint32_t seed, uint32_t tag, uint32
 struct State {
   std::vector<unsigned long long> observed;   // [2^20][2]
   std::vector<uint32_t> cnt;
+  std::vector<uint32_t> pre_hash;
+  std::vector<int> pre_steps;
   Counters C{};
   FrameParams F;
 };
 
-static void run_phase_kernel(const Frame& fr, State& st, uint32_t g0, uint32_t g1, bool pre) {
+static BatchView view_of(const Frame& fr, State& st) {
   st.F = fr.F;
   st.F.observed = (uint64_t*)st.observed.data();
   BatchView V{};
@@ -109,11 +112,23 @@ static void run_phase_kernel(const Frame& fr, State& st, uint32_t g0, uint32_t g
   sv.rays = fr.rays.data();
   sv.cnt = st.cnt.data();
   sv.C = &st.C;
+  sv.pre_hash = st.pre_hash.data();
+  sv.pre_steps = st.pre_steps.data();
+  return V;
+}
+
+static void run_prewalk(const Frame& fr, State& st, uint32_t G, uint32_t Gpad, uint32_t cap) {
+  st.pre_hash.assign((size_t)kChains * Gpad * cap, 0xdeadbeefu);
+  st.pre_steps.assign((size_t)kChains * Gpad, -7);
+  BatchView V = view_of(fr, st);
+  emu::launch(dim3(kChains * (Gpad / kSubRun), 1), dim3(64), [&] { k_prewalk(V, G, Gpad, cap); });
+}
+
+static void run_phase_kernel(const Frame& fr, State& st, uint32_t g0, uint32_t g1, bool pre, uint32_t Gpad, uint32_t cap) {
+  BatchView V = view_of(fr, st);
   const uint32_t n_sub = (g1 - g0 + kSubRun - 1) / kSubRun;
   if (pre) {
-    const uint32_t cap = test_pre_cap(fr.steps_cap);
-    if (test_pre_lds_bytes(cap) > 64 * 1024) { fprintf(stderr, "LDS\n"); exit(2); }
-    emu::launch(dim3(kChains, 1), dim3(64), [&] { k_test_pre(V, g0, g1, cap); });
+    emu::launch(dim3(kChains, 1), dim3(64), [&] { k_test_pre(V, g0, g1, Gpad, cap); });
   } else {
     // one wavefront per block (the kernel derives its (chain, sub-run) from blockIdx and blockDim)
     emu::launch(dim3(kChains * n_sub, 1), dim3(64), [&] { k_test(V, g0, g1, fr.steps_cap); });
@@ -198,16 +213,26 @@ int main(int argc, char** argv) {
   for (uint32_t frame = 0; frame < 2 && ok; ++frame) {
     const Frame fr = make_frame(n, lim, seed + 17u * frame, 5u + frame, 5u, 0x9e3779b97f4a7c15ull, voxel);
     if (frame == 0) printf("n %u, voxel %.3f m, steps_cap %u, k_test_pre cap %u, LDS %u B\n", n, voxel, fr.steps_cap, test_pre_cap(fr.steps_cap), test_pre_lds_bytes(test_pre_cap(fr.steps_cap)));
+    A.pre_hash.assign(4, 0u); A.pre_steps.assign(4, 0);
     for (State* s : {&A, &B, &S}) std::fill(s->cnt.begin(), s->cnt.end(), 0u);
     const uint32_t n_gen = (n + kChains - 1) / kChains;
     const std::vector<uint32_t> PB = phase_bounds(n_gen, 32);
+    // = pre_plan() of ks_hip.hip: the leading phases of at most one sub-run per chain
+    uint32_t G = 0;
+    for (size_t j = 0; j < PB.size(); ++j) {
+      const uint32_t g0 = PB[j], g1 = j + 1 < PB.size() ? PB[j + 1] : n_gen;
+      if (g1 - g0 > kSubRun) break;
+      G = g1;
+    }
+    const uint32_t Gpad = (G + kSubRun - 1) / kSubRun * kSubRun, cap = test_pre_cap(fr.steps_cap);
+    if (test_pre_lds_bytes(cap) > 64 * 1024 || (cap + 63) / 64 * 16 > kPreMaxChunks) { fprintf(stderr, "k_test_pre does not apply (LDS)\n"); return 2; }
+    run_prewalk(fr, B, G, Gpad, cap);
     unsigned long long updates = 0, broke = 0, rays = 0;
     for (size_t j = 0; j < PB.size() && ok; ++j) {
       const uint32_t g0 = PB[j], g1 = j + 1 < PB.size() ? PB[j + 1] : n_gen;
-      const uint32_t n_sub = (g1 - g0 + kSubRun - 1) / kSubRun;
-      const bool pre = n_sub == 1 && g1 - g0 >= 2;
-      run_phase_kernel(fr, A, g0, g1, false);
-      run_phase_kernel(fr, B, g0, g1, pre);
+      const bool pre = g1 <= G;
+      run_phase_kernel(fr, A, g0, g1, false, Gpad, cap);
+      run_phase_kernel(fr, B, g0, g1, pre, Gpad, cap);
       run_phase_serial(fr, S, g0, g1);
       const bool ok1 = same(A, S, "k_test vs serial restatement", g0, g1);
       const bool ok2 = same(B, S, pre ? "k_test_pre vs serial restatement" : "k_test (after k_test_pre phases) vs serial restatement", g0, g1);
