@@ -652,9 +652,15 @@ void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipS
       const uint32_t steps_cap = (uint32_t)((steps_max + 3) & ~(size_t)3);
       const size_t lds_wave = (size_t)test_lds_words64(steps_cap) * sizeof(unsigned long long);
       const uint32_t wpb = lds_wave * 4 <= 60 * 1024 ? 4u : lds_wave * 2 <= 60 * 1024 ? 2u : 1u;  // wavefronts per block
-      if (P.on && g1 <= P.G)
-        hipLaunchKernelGGL(k_test_pre, dim3(kChains, nb), dim3(64), test_pre_lds_bytes(P.cap), sm, V, g0, g1, P.Gpad, P.cap);
-      else
+      if (P.on && g1 <= P.G) {
+        // (with one wavefront per SIMD every instruction of the unrolled look-up batch is paid for, used or not: the
+        // batch is sized to the work of the phase — about 2.3 chunks of 64 voxels per ray)
+        const dim3 grid(kChains, nb), block(64);
+        const size_t lds = test_pre_lds_bytes(P.cap);
+        if (g1 - g0 <= 4) hipLaunchKernelGGL(k_test_pre<8>, grid, block, lds, sm, V, g0, g1, P.Gpad, P.cap);
+        else if (g1 - g0 <= 8) hipLaunchKernelGGL(k_test_pre<16>, grid, block, lds, sm, V, g0, g1, P.Gpad, P.cap);
+        else hipLaunchKernelGGL(k_test_pre<32>, grid, block, lds, sm, V, g0, g1, P.Gpad, P.cap);
+      } else
         hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb, nb), dim3(64 * wpb), lds_wave * wpb, sm, V, g0, g1, steps_cap);
     }
   }

@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
 //      is one contiguous range), pre_steps[chain * Gpad + generation] = steps of the ray, -1 = no ray
 //   k_test_pre (per phase), one wavefront per chain:
 //      B  all 64 lanes: the rays' hashes (global -> registers, and LDS for C) and the shared-set entries of all
-//         their voxels, 32 of each per lane in flight; the snapshot verdict goes to a bitmap in LDS; older-phase entries
+//         their voxels, W (8 / 16 / 32) of each per lane in flight; the snapshot verdict goes to a bitmap in LDS; older-phase entries
 //         are saved exactly as in k_test; ONE wait for the saves
 //      C  the rays in generation order, LDS only: private set, else the stored verdict; collision rule; marks
 // LDS per k_test_pre wavefront: private set (8 KiB) + 16 x cap hashes + 16 x cap verdict bits (cap = longest possible
@@ -502,7 +502,6 @@ typedef __attribute__((address_space(1))) obs_u64x2 obs_global_u64x2;
 __device__ __forceinline__ void obs_atomic_max(obs_global_u64* p, unsigned long long v) {   // = atomicMax, result unused
   (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-constexpr uint32_t kPreInFlight = 32;
 constexpr uint32_t kPreMaxChunks = 128;   // 16 rays x ceil(cap / 64), cap <= 512
 __host__ __device__ inline uint32_t test_pre_cap(uint32_t steps_cap) { return ((steps_cap + 1u + 31u) & ~31u) + 1u; }
 __host__ __device__ inline uint32_t test_pre_bit_words(uint32_t cap) { return (cap + 31u) / 32u; }
@@ -549,6 +548,7 @@ __global__ void __launch_bounds__(64) k_prewalk(BatchView V, uint32_t G, uint32_
   }
 }
 
+template <uint32_t W>   // look-ups per lane in flight (a batch runs all W slots, used or not: sized to the phase by the host)
 __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint32_t g1, uint32_t Gpad, uint32_t cap) {
   const SlotView& sv = V.s[blockIdx.y];
   uint32_t* __restrict__ cnt = sv.cnt;
@@ -615,12 +615,12 @@ __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint3
 #endif
     // ---- B: hashes, and the shared set as it stood when the phase began, for every voxel of every ray ----
     const uint32_t* __restrict__ gh = sv.pre_hash + ((size_t)chain * Gpad + gs) * cap;
-    for (uint32_t q0 = 0; q0 < n_chunks; q0 += kPreInFlight) {
-      uint32_t hh[kPreInFlight];
+    for (uint32_t q0 = 0; q0 < n_chunks; q0 += W) {
+      uint32_t hh[W];
       uint32_t on_m = 0u;
-      obs_u64x2 ee[kPreInFlight];
+      obs_u64x2 ee[W];
 #pragma unroll
-      for (uint32_t b = 0; b < kPreInFlight; ++b) {   // the hashes first, all in flight
+      for (uint32_t b = 0; b < W; ++b) {   // the hashes first, all in flight
         const uint32_t q = q0 + b;
         const uint32_t e = q < n_chunks ? clist[q] : 0u;
         const uint32_t r = e >> 8, s = (e & 255u) * 64u + lane;
@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint3
         hh[b] = on ? gh[r * cap + s] : 0u;
       }
 #pragma unroll
-      for (uint32_t b = 0; b < kPreInFlight; ++b) {   // then the set entries, all in flight; the hashes to LDS for C
+      for (uint32_t b = 0; b < W; ++b) {   // then the set entries, all in flight; the hashes to LDS for C
         const bool on = ((on_m >> b) & 1u) != 0u;
         if (on) {
           const uint32_t e = clist[q0 + b];
@@ -641,7 +641,7 @@ __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint3
       // a verdict needs; behind a branch it would wait for everything in flight, saves included, verdict after verdict)
       uint32_t save_m = 0u, hit_m = 0u;
 #pragma unroll
-      for (uint32_t b = 0; b < kPreInFlight; ++b) {
+      for (uint32_t b = 0; b < W; ++b) {
         const obs_u64x2 e = ee[b];
         const bool valid = ((on_m >> b) & 1u) != 0u;
         const bool current = (uint32_t)(e.x >> 54) == F.obs_tag && ((uint32_t)(e.x >> 32) & 0x3fffffu) > phase_pos0;
@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint3
         hit_m |= (valid && obs_match(content, hh[b], F.obs_tag_lo, F.obs_tag)) ? (1u << b) : 0u;
       }
 #pragma unroll
-      for (uint32_t b = 0; b < kPreInFlight; ++b) {
+      for (uint32_t b = 0; b < W; ++b) {
         if ((save_m >> b) & 1u) obs_atomic_max(&observed[2u * slot_of(hh[b]) + 1u], ee[b].x);   // save the older-phase mark
         if ((hit_m >> b) & 1u) {
           const uint32_t e = clist[q0 + b];

@@ -128,7 +128,10 @@ static void run_phase_kernel(const Frame& fr, State& st, uint32_t g0, uint32_t g
   BatchView V = view_of(fr, st);
   const uint32_t n_sub = (g1 - g0 + kSubRun - 1) / kSubRun;
   if (pre) {
-    emu::launch(dim3(kChains, 1), dim3(64), [&] { k_test_pre(V, g0, g1, Gpad, cap); });
+    // = the choice of ks_hip.hip
+    if (g1 - g0 <= 4) emu::launch(dim3(kChains, 1), dim3(64), [&] { k_test_pre<8>(V, g0, g1, Gpad, cap); });
+    else if (g1 - g0 <= 8) emu::launch(dim3(kChains, 1), dim3(64), [&] { k_test_pre<16>(V, g0, g1, Gpad, cap); });
+    else emu::launch(dim3(kChains, 1), dim3(64), [&] { k_test_pre<32>(V, g0, g1, Gpad, cap); });
   } else {
     // one wavefront per block (the kernel derives its (chain, sub-run) from blockIdx and blockDim)
     emu::launch(dim3(kChains * n_sub, 1), dim3(64), [&] { k_test(V, g0, g1, fr.steps_cap); });
