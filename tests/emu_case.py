@@ -1,0 +1,46 @@
+"""One parity case through the HOST FUNCTIONAL MODEL of the library (tools/emu: ks_hip.hip and every kernel header
+compiled for the CPU, work-items as fibers), run as a subprocess by tests/test_emu_parity.py:
+    KS_HIP_LIB=tools/emu/_build/libks_hip_emu.so python -m tests.emu_case '<json spec>'
+The checker is the oracle, exactly as in the GPU tier (tests/util.compare_maps, bit-exact)."""
+import json
+import os
+import sys
+
+
+def main():
+    spec = json.loads(sys.argv[1])
+    assert os.environ.get("KS_HIP_LIB", "").endswith("libks_hip_emu.so"), "this script drives the functional model only"
+    from kimera_semantics_amd import binding as B
+    from kimera_semantics_amd import synth
+    from oracle import oracle_py as O
+    from tests.util import COMMON, NO_EARLY_OUT, compare_maps
+    from tests.variants import random_combo
+    cfg = dict(COMMON, method=spec["method"])
+    if spec.get("random_combo") is not None:
+        cfg.update(random_combo(spec["random_combo"]))
+    cfg.update(spec.get("cfg", {}))
+    if spec.get("no_early_out"):
+        cfg["max_consecutive_ray_collisions"] = NO_EARLY_OUT
+    ocfg, hcfg = dict(cfg), dict(cfg)
+    if spec.get("exact"):
+        hcfg["early_out_phase_growth"] = B.KS_EARLY_OUT_EXACT   # oracle: growth 0 = the reference's serial loop
+    w, h = spec["size"]
+    o = O.Oracle(O.default_config(integrator_threads=1, **ocfg))
+    g = B.HipIntegrator(B.default_config(max_tiles=spec.get("max_tiles", 2048), max_points=w * h, pipeline_frames=spec.get("pipeline", 0), **hcfg))
+    sc = synth.make_scene("room")
+    tot_o = tot_g = 0
+    for k in range(spec.get("frames", 1)):
+        f = synth.render_frame(sc, synth.trajectory_pose(5 * k), w, h, seed=40 + k)
+        so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        sg = g.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        tot_o += so.n_voxel_updates
+        tot_g += sg.n_voxel_updates
+    tot_g += g.flush().n_voxel_updates
+    assert tot_o == tot_g, (tot_o, tot_g)
+    rep = compare_maps(o, g, exact=True)
+    assert rep["oracle_touched"] > 500, rep
+    print("EMU_CASE_OK", json.dumps({"updates": tot_g, "voxels": rep["oracle_touched"]}))
+
+
+if __name__ == "__main__":
+    main()

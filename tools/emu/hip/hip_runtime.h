@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <ucontext.h>
 
 #include <functional>
@@ -25,7 +26,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__
+#define __shared__ thread_local   // (all fibers of a block run on the launching OS thread: one instance, like LDS)
 #define __launch_bounds__(...)
 #ifndef __HIP_MEMORY_SCOPE_AGENT
 #define __HIP_MEMORY_SCOPE_AGENT 4
@@ -39,75 +40,140 @@ struct uint4 { unsigned x, y, z, w; };
 inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
 struct ulonglong2 { unsigned long long x, y; };
 inline ulonglong2 make_ulonglong2(unsigned long long x, unsigned long long y) { return ulonglong2{x, y}; }
+struct float4 { float x, y, z, w; };
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct float2 { float x, y; };
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+struct float3 { float x, y, z; };
+inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+struct uint3 { unsigned x, y, z; };
+struct int4 { int x, y, z, w; };
+inline int4 make_int4(int x, int y, int z, int w) { return int4{x, y, z, w}; }
 struct uint2 { unsigned x, y; };
 inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
 
-namespace emu {
-inline dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;
+// A fiber switch without the two sigprocmask system calls of swapcontext (a collective costs one switch per lane):
+// callee-saved registers + stack pointer, x86-64 System V.
+#if defined(__x86_64__)
+asm(R"(
+.text
+.weak emu_ctx_switch
+.type emu_ctx_switch,@function
+emu_ctx_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq %rsi, %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size emu_ctx_switch,.-emu_ctx_switch
+)");
+extern "C" void emu_ctx_switch(void** save_sp, void* new_sp);
+#define EMU_FAST_SWITCH 1
+#else
+#define EMU_FAST_SWITCH 0
+#endif
 
-struct Wave {
-  int alive = 0, arrived = 0, line = 0;
+namespace emu {
+inline thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;   // per launching OS thread
+
+// One collective site (source location) of a wavefront: what the arriving lanes contribute, and the last completed
+// exchange.  Lanes of one wavefront may wait at DIFFERENT sites at the same time (divergent branches, e.g. the four
+// 16-lane groups of a wavefront taking different paths): an exchange completes when every live lane of the wavefront
+// is waiting somewhere, and the lanes of a site see only each other — the exec mask of that instruction.
+struct Xchg {
+  long site = 0;
   unsigned gen = 0;
-  uint64_t slot[2][64];
-  uint64_t contrib[2] = {0, 0};
+  uint64_t in_mask = 0, res_mask = 0;
+  uint64_t in[64], res[64];
+};
+constexpr int kSites = 96;
+struct Wave {
+  int alive = 0, blocked = 0, at_barrier = 0, n_sites = 0;
+  Xchg x[kSites];
 };
 struct Block {
   std::vector<ucontext_t> ctx;
+  std::vector<void*> sp;   // fast switch: saved stack pointers of the fibers
+  void* sched_sp = nullptr;
   std::vector<char*> stacks;
   std::vector<char> done;
   std::vector<Wave> waves;
-  int alive = 0, arrived = 0, line = 0;
+  int alive = 0, arrived = 0;
   unsigned gen = 0;
   ucontext_t sched;
   int cur = 0;
   std::function<void()> body;
   unsigned long long switches = 0;
 };
-inline Block* B = nullptr;
+inline thread_local Block* B = nullptr;
 constexpr size_t kStack = 256 * 1024;
 
 inline void yield() {
   Block* b = B;
   const int me = b->cur;
   ++b->switches;
+#if EMU_FAST_SWITCH
+  emu_ctx_switch(&b->sp[me], b->sched_sp);
+#else
   swapcontext(&b->ctx[me], &b->sched);
+#endif
 }
 inline void fail(const char* what, int line) {
   fprintf(stderr, "emu: %s (source line %d, block %u,%u thread %u)\n", what, line, g_blockIdx.x, g_blockIdx.y, g_threadIdx.x);
   abort();
 }
-// every live lane of the calling wavefront contributes v; returns the parity of the exchange buffer to read
-inline int wave_exchange(uint64_t v, int line) {
+inline void release_wave(Wave& w) {
+  for (int i = 0; i < w.n_sites; ++i) {
+    Xchg& x = w.x[i];
+    if (!x.in_mask) continue;
+    for (int l = 0; l < 64; ++l)
+      if ((x.in_mask >> l) & 1ull) x.res[l] = x.in[l];
+    x.res_mask = x.in_mask;
+    x.in_mask = 0;
+    ++x.gen;
+  }
+  w.blocked = 0;
+}
+// the calling lane contributes v at `site`; returns the completed exchange (valid until the lane's next collective)
+inline const Xchg& wave_exchange(uint64_t v, long site) {
   Block* b = B;
   Wave& w = b->waves[b->cur >> 6];
   const int lane = b->cur & 63;
-  const unsigned g = w.gen;
-  const int par = (int)(g & 1u);
-  if (w.arrived == 0) {
-    w.line = line;
-    w.contrib[par] = 0;
-  } else if (w.line != line) {
-    fail("wave collective reached from different source lines (divergent control flow)", line);
+  Xchg* x = nullptr;
+  for (int i = 0; i < w.n_sites; ++i)
+    if (w.x[i].site == site) { x = &w.x[i]; break; }
+  if (!x) {
+    if (w.n_sites == kSites) fail("too many collective sites in one kernel", (int)site);
+    x = &w.x[w.n_sites++];
+    x->site = site;
+    x->gen = 0;
+    x->in_mask = x->res_mask = 0;
   }
-  w.slot[par][lane] = v;
-  w.contrib[par] |= 1ull << lane;
-  ++w.arrived;
-  while (w.gen == g) {
-    if (w.arrived == w.alive) {
-      ++w.gen;
-      w.arrived = 0;
-      break;
-    }
-    yield();
+  x->in[lane] = v;
+  x->in_mask |= 1ull << lane;
+  ++w.blocked;
+  const unsigned g = x->gen;
+  while (x->gen == g) {
+    if (w.blocked + w.at_barrier >= w.alive) release_wave(w);   // every live lane of the wavefront waits somewhere
+    else yield();
   }
-  return par;
+  return *x;
 }
-inline unsigned long long ballot(bool p, int line) {
-  const int par = wave_exchange(p ? 1u : 0u, line);
-  const Wave& w = B->waves[B->cur >> 6];
+inline unsigned long long ballot(bool p, long site) {
+  const Xchg& x = wave_exchange(p ? 1u : 0u, site);
   unsigned long long m = 0;
   for (int l = 0; l < 64; ++l)
-    if (((w.contrib[par] >> l) & 1ull) && (w.slot[par][l] & 1ull)) m |= 1ull << l;
+    if (((x.res_mask >> l) & 1ull) && (x.res[l] & 1ull)) m |= 1ull << l;
   return m;
 }
 template <typename T>
@@ -124,26 +190,41 @@ inline T from_bits(uint64_t u) {
   return x;
 }
 template <typename T>
-inline T shfl_from(T x, int src, int line) {   // src = absolute lane; out of range / not participating: own value
-  const int par = wave_exchange(to_bits(x), line);
-  const Wave& w = B->waves[B->cur >> 6];
-  if (src < 0 || src > 63 || !((w.contrib[par] >> src) & 1ull)) return x;
-  return from_bits<T>(w.slot[par][src]);
+inline T shfl_from(T v, int src, long site) {   // src = absolute lane; out of range / not participating: own value
+  const Xchg& x = wave_exchange(to_bits(v), site);
+  if (src < 0 || src > 63 || !((x.res_mask >> src) & 1ull)) return v;
+  return from_bits<T>(x.res[src]);
 }
+template <typename T>
+inline T first_lane(T v, long site) {   // value of the lowest participating lane
+  const Xchg& x = wave_exchange(to_bits(v), site);
+  return from_bits<T>(x.res[__builtin_ctzll(x.res_mask)]);
+}
+inline int permute_fwd(int dst, int v, long site) {   // ds_permute_b32: lane i sends v to lane dst_i; untargeted lanes read 0
+  const Xchg& x = wave_exchange(((uint64_t)(uint32_t)v << 8) | (uint64_t)(uint32_t)dst, site);
+  const int me = B->cur & 63;
+  int out = 0;
+  for (int l = 0; l < 64; ++l)
+    if (((x.res_mask >> l) & 1ull) && (int)(x.res[l] & 255u) == me) out = (int)(uint32_t)(x.res[l] >> 8);
+  return out;
+}
+inline void wave_sync(long site) { (void)wave_exchange(0, site); }
 inline unsigned lane() { return g_threadIdx.x & 63u; }
-inline void wave_sync(int line) { (void)wave_exchange(0, line); }
-inline void block_sync(int line) {
+inline void block_sync(long site) {
+  (void)site;   // (s_barrier counts arrivals: wavefronts may meet at different __syncthreads of the program, e.g. producer / consumer code)
   Block* b = B;
+  Wave& w = b->waves[b->cur >> 6];
   const unsigned g = b->gen;
-  if (b->arrived == 0) b->line = line;
-  else if (b->line != line) fail("__syncthreads reached from different source lines", line);
   ++b->arrived;
+  ++w.at_barrier;
   while (b->gen == g) {
-    if (b->arrived == b->alive) {
+    if (b->arrived >= b->alive) {
       ++b->gen;
       b->arrived = 0;
+      for (Wave& ww : b->waves) ww.at_barrier = 0;
       break;
     }
+    if (w.blocked > 0 && w.blocked + w.at_barrier >= w.alive) release_wave(w);   // lanes of this wavefront wait in a collective
     yield();
   }
 }
@@ -155,18 +236,24 @@ inline void fiber_main() {
   b->done[me] = 1;
   --b->alive;
   --b->waves[me >> 6].alive;
-  // returns to the scheduler through uc_link
+#if EMU_FAST_SWITCH
+  void* dead = nullptr;
+  emu_ctx_switch(&dead, b->sched_sp);   // never resumed
+  abort();
+#endif
+  // (ucontext: returns to the scheduler through uc_link)
 }
 
 // runs body() for every work-item of a grid; blocks one after the other, x fastest
 inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
-  static Block blk;
+  static thread_local Block blk;
   Block* b = &blk;
   B = b;
   const unsigned nt = block.x;
   if (block.y != 1 || block.z != 1 || (nt & 63u)) fail("block shape not supported", 0);
   while (b->stacks.size() < nt) b->stacks.push_back((char*)malloc(kStack));
   b->ctx.resize(nt);
+  b->sp.resize(nt);
   b->done.assign(nt, 0);
   b->waves.assign(nt / 64, Wave());
   b->body = body;
@@ -180,16 +267,28 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         b->arrived = 0;
         b->gen = 0;
         for (unsigned w = 0; w < nt / 64; ++w) {
-          b->waves[w] = Wave();
-          b->waves[w].alive = 64;
+          Wave& ww = b->waves[w];
+          ww.alive = 64;
+          ww.blocked = ww.at_barrier = ww.n_sites = 0;
         }
         for (unsigned t = 0; t < nt; ++t) {
           b->done[t] = 0;
+#if EMU_FAST_SWITCH
+          // the first switch to the fiber pops six zeroed registers and "returns" into fiber_main with the stack
+          // aligned as after a call
+          uintptr_t top = ((uintptr_t)(b->stacks[t] + kStack) & ~(uintptr_t)15) - 16;
+          void** frame = (void**)top;
+          frame[1] = nullptr;                    // fiber_main's (unused) return address
+          frame[0] = (void*)&fiber_main;
+          for (int k = 1; k <= 6; ++k) frame[-k] = nullptr;
+          b->sp[t] = (void*)(frame - 6);
+#else
           getcontext(&b->ctx[t]);
           b->ctx[t].uc_stack.ss_sp = b->stacks[t];
           b->ctx[t].uc_stack.ss_size = kStack;
           b->ctx[t].uc_link = &b->sched;
           makecontext(&b->ctx[t], (void (*)())fiber_main, 0);
+#endif
         }
         unsigned long long idle_passes = 0;
         while (b->alive > 0) {
@@ -199,7 +298,11 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             if (b->done[t]) continue;
             b->cur = (int)t;
             g_threadIdx = dim3(t, 0, 0);
+#if EMU_FAST_SWITCH
+            emu_ctx_switch(&b->sched_sp, b->sp[t]);
+#else
             swapcontext(&b->sched, &b->ctx[t]);
+#endif
           }
           (void)before;
           if (b->alive == alive_before) {
@@ -210,6 +313,26 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         }
       }
 }
+// EMU_PROFILE=1: wall time per kernel name, printed at exit
+struct ProfEntry { const char* name; double s; unsigned long long launches, threads; };
+inline std::vector<ProfEntry>& prof_table() { static std::vector<ProfEntry> t; return t; }
+inline void prof_dump() {
+  for (const ProfEntry& e : prof_table()) fprintf(stderr, "emu: %9.3f s  %6llu launches  %10llu work-items  %s\n", e.s, e.launches, e.threads, e.name);
+}
+inline void launch_named(const char* name, dim3 grid, dim3 block, const std::function<void()>& body) {
+  static const bool on = getenv("EMU_PROFILE") != nullptr;
+  if (!on) { launch(grid, block, body); return; }
+  static bool registered = false;
+  if (!registered) { registered = true; atexit(prof_dump); }
+  timespec a, b;
+  clock_gettime(CLOCK_MONOTONIC, &a);
+  launch(grid, block, body);
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  const double dt = (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+  for (ProfEntry& e : prof_table())
+    if (e.name == name) { e.s += dt; ++e.launches; e.threads += (unsigned long long)grid.x * grid.y * grid.z * block.x; return; }
+  prof_table().push_back(ProfEntry{name, dt, 1, (unsigned long long)grid.x * grid.y * grid.z * block.x});
+}
 }  // namespace emu
 
 #define threadIdx emu::g_threadIdx
@@ -217,14 +340,20 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
 #define blockDim emu::g_blockDim
 #define gridDim emu::g_gridDim
 
-#define __syncthreads() emu::block_sync(__LINE__)
-#define __ballot(emu_p) emu::ballot((emu_p), __LINE__)
-#define __shfl(emu_v, emu_src) emu::shfl_from((emu_v), (int)(emu_src), __LINE__)
-#define __shfl_xor(emu_v, emu_m) emu::shfl_from((emu_v), (int)(emu::lane() ^ (unsigned)(emu_m)), __LINE__)
-#define __shfl_up(emu_v, emu_d) emu::shfl_from((emu_v), (int)emu::lane() - (int)(emu_d), __LINE__)
-#define __shfl_down(emu_v, emu_d) emu::shfl_from((emu_v), (int)emu::lane() + (int)(emu_d), __LINE__)
-#define __builtin_amdgcn_readlane(emu_v, emu_k) emu::shfl_from((emu_v), (int)(emu_k), __LINE__)
-#define KS_WAVE_LDS_ORDER() emu::wave_sync(__LINE__)
+// a collective site = source file + line
+#define EMU_SITE ((long)(((uintptr_t)(const void*)__FILE__) * 1000003ul) ^ (long)__LINE__)
+#define __syncthreads() emu::block_sync(EMU_SITE)
+#define __ballot(emu_p) emu::ballot((emu_p), EMU_SITE)
+#define __shfl(emu_v, emu_src) emu::shfl_from((emu_v), (int)(emu_src), EMU_SITE)
+#define __shfl_xor(emu_v, emu_m) emu::shfl_from((emu_v), (int)(emu::lane() ^ (unsigned)(emu_m)), EMU_SITE)
+#define __shfl_up(emu_v, emu_d) emu::shfl_from((emu_v), (int)emu::lane() - (int)(emu_d), EMU_SITE)
+#define __shfl_down(emu_v, emu_d) emu::shfl_from((emu_v), (int)emu::lane() + (int)(emu_d), EMU_SITE)
+#define __builtin_amdgcn_readlane(emu_v, emu_k) emu::shfl_from((emu_v), (int)(emu_k), EMU_SITE)
+#define __builtin_amdgcn_readfirstlane(emu_v) emu::first_lane((emu_v), EMU_SITE)
+#define __builtin_amdgcn_ds_bpermute(emu_addr, emu_v) emu::shfl_from((emu_v), (int)(((unsigned)(emu_addr)) >> 2) & 63, EMU_SITE)
+#define __builtin_amdgcn_ds_permute(emu_addr, emu_v) emu::permute_fwd((int)(((unsigned)(emu_addr)) >> 2) & 63, (int)(emu_v), EMU_SITE)
+#define __builtin_amdgcn_wave_barrier() emu::wave_sync(EMU_SITE)
+#define KS_WAVE_LDS_ORDER() emu::wave_sync(EMU_SITE)
 #define KS_WAIT_VMEM()
 
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
@@ -246,11 +375,86 @@ template <typename T> inline T atomicOr(T* p, typename emu_same<T>::type v) { co
 template <typename T> inline T atomicAnd(T* p, typename emu_same<T>::type v) { const T o = *p; *p = o & v; return o; }
 template <typename T> inline T atomicExch(T* p, typename emu_same<T>::type v) { const T o = *p; *p = v; return o; }
 template <typename T> inline T atomicCAS(T* p, typename emu_same<T>::type cmp, typename emu_same<T>::type v) { const T o = *p; if (o == cmp) *p = v; return o; }
-inline int max(int a, int b) { return a < b ? b : a; }
-inline int min(int a, int b) { return b < a ? b : a; }
-inline unsigned max(unsigned a, unsigned b) { return a < b ? b : a; }
-inline unsigned min(unsigned a, unsigned b) { return b < a ? b : a; }
+#include <type_traits>
+template <typename A, typename B2, typename = typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B2>::value>::type>
+inline typename std::common_type<A, B2>::type max(A a, B2 b) { typedef typename std::common_type<A, B2>::type T; return (T)a < (T)b ? (T)b : (T)a; }
+template <typename A, typename B2, typename = typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B2>::value>::type>
+inline typename std::common_type<A, B2>::type min(A a, B2 b) { typedef typename std::common_type<A, B2>::type T; return (T)b < (T)a ? (T)b : (T)a; }
+inline float __builtin_amdgcn_fmed3f_emu(float a, float b, float c) {   // v_med3_f32: a NaN operand -> min3 of the others
+  if (a != a || b != b || c != c) {
+    float m = __builtin_inff();
+    if (a == a && a < m) m = a;
+    if (b == b && b < m) m = b;
+    if (c == c && c < m) m = c;
+    return m;
+  }
+  const float lo = a < b ? a : b, hi = a < b ? b : a;
+  return c < lo ? lo : (c > hi ? hi : c);
+}
+#define __builtin_amdgcn_fmed3f(a, b, c) __builtin_amdgcn_fmed3f_emu((a), (b), (c))
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __hip_atomic_fetch_max(p, v, order, scope) emu_fetch_max((p), (v))
 template <typename P, typename T> inline T emu_fetch_max(P p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The slice of the HIP runtime API that kimera_semantics_amd/csrc/ks_hip.hip uses, for the host functional model:
+// device memory is host memory, a launch runs to completion before it returns (streams and events are no-ops),
+// stream capture is refused (the library then launches directly).
+// ---------------------------------------------------------------------------------------------------------------
+typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801, hipErrorUnknown = 999 } hipError_t;
+struct ihipStream_t { int id; };
+struct ihipEvent_t { int id; };
+typedef ihipStream_t* hipStream_t;
+typedef ihipEvent_t* hipEvent_t;
+typedef struct ihipGraph* hipGraph_t;
+typedef struct ihipGraphExec* hipGraphExec_t;
+typedef enum { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 } hipMemcpyKind;
+typedef enum { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamCaptureModeRelaxed = 2 } hipStreamCaptureMode;
+typedef enum { hipMemoryTypeUnregistered = 0, hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeManaged = 3 } hipMemoryType;
+struct hipPointerAttribute_t { hipMemoryType type; int device; void* devicePointer; void* hostPointer; int isManaged; unsigned allocationFlags; };
+#define hipStreamNonBlocking 1u
+#define hipEventDisableTiming 2u
+#define hipHostMallocDefault 0u
+#define HIP_SYMBOL(x) (x)
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hip error (host functional model)"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new ihipStream_t{0}; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = new ihipStream_t{0}; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorNotSupported; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new ihipEvent_t{0}; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new ihipEvent_t{0}; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+template <typename T> inline hipError_t hipMalloc(T** p, size_t bytes) { *p = (T*)aligned_alloc(256, (bytes + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned = 0) { *p = (T*)aligned_alloc(256, (bytes + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+template <typename S> inline hipError_t hipMemcpyFromSymbol(void* d, const S& sym, size_t n) { memcpy(d, &sym, n); return hipSuccess; }
+template <typename S> inline hipError_t hipMemcpyToSymbol(S& sym, const void* s, size_t n) { memcpy(&sym, s, n); return hipSuccess; }
+inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {   // every allocation is "pinned host memory the device can write"
+  a->type = hipMemoryTypeHost; a->device = 0; a->devicePointer = (void*)p; a->hostPointer = (void*)p; a->isManaged = 0; a->allocationFlags = 0;
+  return hipSuccess;
+}
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+  emu::launch_named(#kernel, dim3(grid), dim3(block), [&] { kernel(__VA_ARGS__); })
+#define hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev0, ev1, flags, ...) \
+  emu::launch_named(#kernel, dim3(grid), dim3(block), [&] { kernel(__VA_ARGS__); })

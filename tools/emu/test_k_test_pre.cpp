@@ -17,8 +17,8 @@
 #include "ks_k_march.h"
 
 namespace ksk {
-unsigned long long s_test[64 * 1024 / 8 * 4];
-unsigned long long s_bt[1 << 16];
+thread_local unsigned long long s_test[64 * 1024 / 8 * 4];   // the kernels' dynamic LDS
+thread_local unsigned long long s_bt[1 << 16];
 }  // namespace ksk
 
 using namespace ksk;
