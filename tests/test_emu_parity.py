@@ -55,3 +55,15 @@ def test_prewalk_variant_of_the_leading_phases_equals_oracle(emu_lib):
     """KS_TEST_PRE=1 (k_prewalk + k_test_pre<8/16/32>) end to end: 256x160 = 40 generations, every phase
     is a single sub-run, all three look-up widths are used."""
     run_case(emu_lib, dict(method=0, size=[256, 160], frames=1, cfg=dict(early_out_phase_growth=32)), env_extra={"KS_TEST_PRE": "1"})
+
+
+def test_gpu_tier_cases_unchanged_on_the_functional_model(emu_lib):
+    """A selection of the GPU tier's own tests (tests/test_parity_gpu.py), UNCHANGED, against the functional model:
+    the reference's CHECKs as error codes, saturated weights, degenerate inputs (NaN / zero-length / out-of-range rays),
+    the depth-image entry with u16 depth and colour-coded labels.  (Any other `-m gpu` test runs the same way —
+    minutes instead of seconds: KS_TESTS_ON_FUNCTIONAL_MODEL=1 KS_HIP_LIB=tools/emu/_build/libks_hip_emu.so pytest -m gpu -k ...)"""
+    env = dict(os.environ, KS_HIP_LIB=emu_lib, KS_TESTS_ON_FUNCTIONAL_MODEL="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_parity_gpu.py", "-m", "gpu", "-q", "-x", "-k",
+                        "error_codes or saturated or degenerate or depth_image_u16"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=1200)
+    assert r.returncode == 0 and " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-2000:]
