@@ -186,7 +186,8 @@ struct ks_ctx {
   bool host_prof = false;
   bool export_staged = false;             // KS_EXPORT_STAGED=1: voxel export via a device buffer + copy even for pinned targets
   bool use_graphs = true;                // stage B replayed as a hipGraph (KS_NO_GRAPH=1 or a capture failure: plain launches)
-  bool test_pre = false;                 // early phases through k_test_pre (KS_TEST_PRE=0/1)
+  bool test_pre = false;                 // leading early-out phases through k_prewalk + k_test_pre (KS_TEST_PRE, bit 0)
+  int test_pre_flags = 0;                // KS_TEST_PRE as given (bits 1, 2: variants, see enqueue_stage_b)
   uint64_t buffers_epoch = 1;            // bumped whenever a buffer a captured graph points at is re-allocated
   uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
   uint32_t* d_label_lut = nullptr;  // 256 label -> rgba
@@ -657,9 +658,15 @@ void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipS
         // batch is sized to the work of the phase — about 2.3 chunks of 64 voxels per ray)
         const dim3 grid(kChains, nb), block(64);
         const size_t lds = test_pre_lds_bytes(P.cap);
-        if (g1 - g0 <= 4) hipLaunchKernelGGL(k_test_pre<8>, grid, block, lds, sm, V, g0, g1, P.Gpad, P.cap);
-        else if (g1 - g0 <= 8) hipLaunchKernelGGL(k_test_pre<16>, grid, block, lds, sm, V, g0, g1, P.Gpad, P.cap);
-        else hipLaunchKernelGGL(k_test_pre<32>, grid, block, lds, sm, V, g0, g1, P.Gpad, P.cap);
+        // KS_TEST_PRE bits: 1 on | 2 always 32 look-ups in flight (the build that was measured) | 4 one
+        // shared-set mark per visited voxel instead of the private-set route
+        const uint32_t w = (c->test_pre_flags & 2) ? 32u : g1 - g0 <= 4 ? 8u : g1 - g0 <= 8 ? 16u : 32u;
+        const bool dedup = !(c->test_pre_flags & 4);
+#define KS_LAUNCH_PRE(WW, DD) hipLaunchKernelGGL((k_test_pre<WW, DD>), grid, block, lds, sm, V, g0, g1, P.Gpad, P.cap)
+        if (w == 8u) { if (dedup) KS_LAUNCH_PRE(8, true); else KS_LAUNCH_PRE(8, false); }
+        else if (w == 16u) { if (dedup) KS_LAUNCH_PRE(16, true); else KS_LAUNCH_PRE(16, false); }
+        else { if (dedup) KS_LAUNCH_PRE(32, true); else KS_LAUNCH_PRE(32, false); }
+#undef KS_LAUNCH_PRE
       } else
         hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb, nb), dim3(64 * wpb), lds_wave * wpb, sm, V, g0, g1, steps_cap);
     }
@@ -1554,7 +1561,10 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   // own.  Otherwise stage B stays strictly in frame order.
   const bool frames_independent = !uses_early_out || c->cfg.clear_checks_every_n_frames <= 1;
   c->batch = 1;
-  if (const char* tp = getenv("KS_TEST_PRE")) c->test_pre = atoi(tp) != 0;
+  if (const char* tp = getenv("KS_TEST_PRE")) {
+    c->test_pre_flags = atoi(tp);
+    c->test_pre = (c->test_pre_flags & 1) != 0;
+  }
   if (c->cfg.pipeline_frames >= 2 && frames_independent && !c->exact_early_out && c->cfg.integration_order_mode != KS_ORDER_SORTED) {
     // (measured, 640x480: a batch of 4 behind 8 frames of lag ~ four single-frame sequences on four streams behind 4
     // frames of lag; batches of 2 or 3 lose to both: DESIGN.md)

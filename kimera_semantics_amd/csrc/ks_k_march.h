@@ -502,6 +502,12 @@ typedef __attribute__((address_space(1))) obs_u64x2 obs_global_u64x2;
 __device__ __forceinline__ void obs_atomic_max(obs_global_u64* p, unsigned long long v) {   // = atomicMax, result unused
   (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the shared-set mark of a private-set entry (priv_key: generation << 52 | step << 42 | slot >> 10 << 32 | hash) of chain `chain`
+__device__ __forceinline__ void priv_flush(obs_global_u64* observed, uint32_t tag, uint32_t chain, uint32_t idx, unsigned long long e) {
+  const uint32_t slot = ((uint32_t)((e >> 32) & 1023ull) << 10) | idx;
+  const uint32_t pos = (uint32_t)(e >> 52) * kChains + chain;
+  obs_atomic_max(&observed[2u * slot], (unsigned long long)obs_entry(tag, pos, (uint32_t)e));
+}
 constexpr uint32_t kPreMaxChunks = 128;   // 16 rays x ceil(cap / 64), cap <= 512
 __host__ __device__ inline uint32_t test_pre_cap(uint32_t steps_cap) { return ((steps_cap + 1u + 31u) & ~31u) + 1u; }
 __host__ __device__ inline uint32_t test_pre_bit_words(uint32_t cap) { return (cap + 31u) / 32u; }
@@ -548,7 +554,9 @@ __global__ void __launch_bounds__(64) k_prewalk(BatchView V, uint32_t G, uint32_
   }
 }
 
-template <uint32_t W>   // look-ups per lane in flight (a batch runs all W slots, used or not: sized to the phase by the host)
+// W: look-ups per lane in flight (a batch runs all W slots, used or not: sized to the phase by the host);
+// DEDUP: the shared-set marks go through the private set (below)
+template <uint32_t W, bool DEDUP>
 __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint32_t g1, uint32_t Gpad, uint32_t cap) {
   const SlotView& sv = V.s[blockIdx.y];
   uint32_t* __restrict__ cnt = sv.cnt;
@@ -697,16 +705,35 @@ __global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint3
         break;
       }
     }
-    // the ray's marks (all visited voxels): the chain's private set and the shared set
+    // The ray's marks (all visited voxels) go to the chain's private set.  Their way into the shared set is through it:
+    // in the leading phases every ray reaches the voxels next to the sensor, and one atomicMax per ray and voxel on those
+    // few slots (16 k of them in a 16-generation phase) is what the phase then waits for — same-address atomics
+    // serialise in the L2.  The shared set only keeps the mark of the highest position, and of the rays of this
+    // wavefront that is the one the private set retains: an entry leaves for the shared set when another VOXEL takes its
+    // place (or loses against it), and whatever is left goes out at the end — one atomic per voxel and wavefront.
     for (uint32_t m0 = 0; m0 < visited; m0 += 64u) {
       const uint32_t s = m0 + lane;
       if (s < visited) {
-        const uint32_t h = hj[s], slot = slot_of(h);
-        atomicMax(&priv[slot & (kPrivSlots - 1u)], priv_key(gen_j, s, slot, h));
-        obs_atomic_max(&observed[2u * slot], (unsigned long long)obs_entry(F.obs_tag, pos_j, h));
+        const uint32_t h = hj[s], slot = slot_of(h), idx = slot & (kPrivSlots - 1u);
+        const unsigned long long key = priv_key(gen_j, s, slot, h);
+        const unsigned long long old = atomicMax(&priv[idx], key);
+        if (DEDUP) {
+          const unsigned long long loser = old < key ? old : key, winner = old < key ? key : old;
+          if (loser != 0ull && (loser & 0x3ffffffffffull) != (winner & 0x3ffffffffffull))   // a different voxel (slot bits | hash)
+            priv_flush(observed, F.obs_tag, chain, idx, loser);
+        } else {
+          obs_atomic_max(&observed[2u * slot], (unsigned long long)obs_entry(F.obs_tag, pos_j, h));   // one mark per visited voxel, as k_test
+        }
       }
     }
     if (lane == 0) cnt[pos_j] = updates | (stop >= 0 ? kCntBroke : 0u);
+  }
+  if (DEDUP) {
+    KS_WAVE_LDS_ORDER();   // the last ray's marks
+    for (uint32_t i = lane; i < kPrivSlots; i += 64) {
+      const unsigned long long e = priv[i];
+      if (e != 0ull) priv_flush(observed, F.obs_tag, chain, i, e);
+    }
   }
 #ifdef KS_STATS
   {

@@ -395,7 +395,11 @@ inline float __builtin_amdgcn_fmed3f_emu(float a, float b, float c) {   // v_med
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __hip_atomic_fetch_max(p, v, order, scope) emu_fetch_max((p), (v))
-template <typename P, typename T> inline T emu_fetch_max(P p, T v) { const T o = *p; if (v > o) *p = v; return o; }
+namespace emu { inline void (*global_atomic_hook)(const void*) = nullptr; }   // statistics of a test harness (contention on an address)
+template <typename P, typename T> inline T emu_fetch_max(P p, T v) {
+  if (emu::global_atomic_hook) emu::global_atomic_hook((const void*)p);
+  const T o = *p; if (v > o) *p = v; return o;
+}
 
 
 // ---------------------------------------------------------------------------------------------------------------

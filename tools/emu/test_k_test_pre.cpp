@@ -23,6 +23,11 @@ thread_local unsigned long long s_bt[1 << 16];
 
 using namespace ksk;
 
+// shared-set atomics of the k_test_pre side (obs_atomic_max): how many, and how many on the most contended address
+#include <unordered_map>
+static std::unordered_map<const void*, uint32_t> g_atomics;
+static void count_atomic(const void* p) { ++g_atomics[p]; }
+
 static std::vector<uint32_t> phase_bounds(uint32_t n_gen, int growth) {   // = ks_hip.hip
   std::vector<uint32_t> b{0};
   for (;;) {
@@ -128,10 +133,13 @@ static void run_phase_kernel(const Frame& fr, State& st, uint32_t g0, uint32_t g
   BatchView V = view_of(fr, st);
   const uint32_t n_sub = (g1 - g0 + kSubRun - 1) / kSubRun;
   if (pre) {
-    // = the choice of ks_hip.hip
-    if (g1 - g0 <= 4) emu::launch(dim3(kChains, 1), dim3(64), [&] { k_test_pre<8>(V, g0, g1, Gpad, cap); });
-    else if (g1 - g0 <= 8) emu::launch(dim3(kChains, 1), dim3(64), [&] { k_test_pre<16>(V, g0, g1, Gpad, cap); });
-    else emu::launch(dim3(kChains, 1), dim3(64), [&] { k_test_pre<32>(V, g0, g1, Gpad, cap); });
+    // = the choice of ks_hip.hip (KS_TEST_PRE=1); EMU_PRE_NO_DEDUP=1: one shared-set mark per visited voxel
+    static const bool no_dedup = getenv("EMU_PRE_NO_DEDUP") != nullptr;
+#define LAUNCH_PRE(WW, DD) emu::launch(dim3(kChains, 1), dim3(64), [&] { k_test_pre<WW, DD>(V, g0, g1, Gpad, cap); })
+    if (g1 - g0 <= 4) { if (no_dedup) LAUNCH_PRE(8, false); else LAUNCH_PRE(8, true); }
+    else if (g1 - g0 <= 8) { if (no_dedup) LAUNCH_PRE(16, false); else LAUNCH_PRE(16, true); }
+    else { if (no_dedup) LAUNCH_PRE(32, false); else LAUNCH_PRE(32, true); }
+#undef LAUNCH_PRE
   } else {
     // one wavefront per block (the kernel derives its (chain, sub-run) from blockIdx and blockDim)
     emu::launch(dim3(kChains * n_sub, 1), dim3(64), [&] { k_test(V, g0, g1, fr.steps_cap); });
@@ -179,6 +187,7 @@ static void run_phase_serial(const Frame& fr, State& st, uint32_t g0, uint32_t g
           pe = std::max(pe, priv_key(g, s, slot, h));
           unsigned long long& e = st.observed[2u * slot];
           e = std::max(e, (unsigned long long)obs_entry(F.obs_tag, (uint32_t)p, h));
+          ++g_atomics[&e];   // one atomicMax per visited voxel: what k_test issues
         }
         st.cnt[p] = updates | (stop >= 0 ? kCntBroke : 0u);
       }
@@ -235,8 +244,23 @@ int main(int argc, char** argv) {
       const uint32_t g0 = PB[j], g1 = j + 1 < PB.size() ? PB[j + 1] : n_gen;
       const bool pre = g1 <= G;
       run_phase_kernel(fr, A, g0, g1, false, Gpad, cap);
+      g_atomics.clear();
+      emu::global_atomic_hook = pre ? count_atomic : nullptr;
       run_phase_kernel(fr, B, g0, g1, pre, Gpad, cap);
+      emu::global_atomic_hook = nullptr;
+      if (pre) {
+        size_t total = 0, worst = 0;
+        for (const auto& kv : g_atomics) { total += kv.second; worst = std::max<size_t>(worst, kv.second); }
+        printf("  k_test_pre: %zu shared-set atomics on %zu addresses, %zu on the most contended one\n", total, g_atomics.size(), worst);
+      }
+      g_atomics.clear();
       run_phase_serial(fr, S, g0, g1);
+      {
+        size_t total = 0, worst = 0;
+        for (const auto& kv : g_atomics) { total += kv.second; worst = std::max<size_t>(worst, kv.second); }
+        printf("  one mark per visited voxel (k_test): %zu shared-set atomics on %zu addresses, %zu on the most contended one\n", total,
+               g_atomics.size(), worst);
+      }
       const bool ok1 = same(A, S, "k_test vs serial restatement", g0, g1);
       const bool ok2 = same(B, S, pre ? "k_test_pre vs serial restatement" : "k_test (after k_test_pre phases) vs serial restatement", g0, g1);
       ok = ok1 && ok2;
