@@ -27,6 +27,7 @@
 // Data layout in HBM: 8x8x8-voxel tiles of 128-byte voxel records (dist | weight | colour | label
 // | 21 class priors), addressed through an open-addressing hash table keyed by the packed tile index.
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -168,7 +169,7 @@ struct ks_ctx {
   int64_t reset_counter = 0;
   uint32_t obs_tag = 0, obs_tag_lo = 1;  // frame tag of the observed set's entries (ks_k_march.h)
   Counters* d_retry_counters = nullptr;  // scratch of the pair-buffer overflow retry
-  size_t pairs_hint = 0;                 // largest pair count of a frame so far
+  std::atomic<size_t> pairs_hint{0};     // largest pair count of a frame so far (written by the thread that runs the tails, read by the caller's)
   bool uses_early_out = false;           // fast integrator whose consecutive-collision limit can fire
   // Pipelined contexts enqueue the tail of frame i-lag on a helper thread while the calling thread enqueues
   // stages A and B of frame i (the host, not the GPU, bounds small frames: ~25 launches of ~8 us each per
@@ -885,7 +886,10 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   const size_t steps_max = steps_max_of(cfg, c->voxel_size_inv);
   const bool wide = steps_max > 400;
   S.wide = wide;
-  if ((rc = ensure_pairs_in(c, S, std::max<size_t>(c->pairs_hint + c->pairs_hint / 4, 1 << 20)))) return rc;
+  {
+    const size_t hint = c->pairs_hint.load(std::memory_order_relaxed);
+    if ((rc = ensure_pairs_in(c, S, std::max<size_t>(hint + hint / 4, 1 << 20)))) return rc;
+  }
 
   hipStream_t st = c->stream;
   if (S.tail_recorded && c->stream_tail != c->stream) HIPCHK(c, hipStreamWaitEvent(st, S.tail_done, 0));
@@ -1015,7 +1019,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   const uint32_t tiles_before = c->tiles_initialised;
   const int set = S.prof_set;
   stage_mark(c, set, 6);
-  c->pairs_hint = std::max<size_t>(c->pairs_hint, cnt.n_pairs);
+  c->pairs_hint.store(std::max<size_t>(c->pairs_hint.load(std::memory_order_relaxed), cnt.n_pairs), std::memory_order_relaxed);
   if ((cnt.err & kErrPairs) && !(cnt.err & ~kErrPairs)) {
     // The frame's pairs did not fit the buffer sized from earlier frames: nothing was written and no tile
     // was allocated.  Grow it and repeat the emission (the scan of the counts is still in the slot).
@@ -1670,7 +1674,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
 #undef CRCHK
   // pair buffers start at 4 updates per point of the largest cloud (a frame that needs more grows its buffer and
   // repeats the emission once)
-  c->pairs_hint = (size_t)cfg->max_points * 4;
+  c->pairs_hint.store((size_t)cfg->max_points * 4, std::memory_order_relaxed);
   if (ensure_points(c, cfg->max_points) != KS_OK) {
     g_create_error = c->err;
     ks_destroy(c);

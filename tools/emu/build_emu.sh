@@ -8,9 +8,13 @@ CXX=/opt/rocm/lib/llvm/bin/clang++
 OUT="${1:-$R/tools/emu/_build/libks_hip_emu.so}"
 mkdir -p "$(dirname "$OUT")"
 FLAGS="-std=c++17 -O1 -fPIC -ffp-contract=off -Wno-unused-value -Wno-unknown-attributes -DKS_EMU_BUILD -I $R/tools/emu"
+# EMU_SAN=address: AddressSanitizer over host AND device code (device memory is heap memory here: an out-of-bounds
+# access of a kernel is reported like any other).  Run with
+#   LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0
+if [ -n "$EMU_SAN" ]; then FLAGS="$FLAGS -g -fsanitize=$EMU_SAN -shared-libsan -fno-omit-frame-pointer"; fi
 cd "$R/kimera_semantics_amd/csrc"
 $CXX -x c++ $FLAGS -c -o /tmp/ks_hip_emu.$$.o ks_hip.hip
 $CXX $FLAGS -c -o /tmp/ks_emu_lds.$$.o "$R/tools/emu/emu_lds.cpp"
-$CXX -shared -o "$OUT" /tmp/ks_hip_emu.$$.o /tmp/ks_emu_lds.$$.o -lpthread -ldl
+$CXX -shared ${EMU_SAN:+-fsanitize=$EMU_SAN -shared-libsan} -o "$OUT" /tmp/ks_hip_emu.$$.o /tmp/ks_emu_lds.$$.o -lpthread -ldl
 rm -f /tmp/ks_hip_emu.$$.o /tmp/ks_emu_lds.$$.o
 echo "built $OUT"

@@ -83,6 +83,25 @@ extern "C" void emu_ctx_switch(void** save_sp, void* new_sp);
 #define EMU_FAST_SWITCH 0
 #endif
 
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+extern "C" void __asan_unpoison_memory_region(void const volatile* addr, size_t size);
+#endif
+#endif
+
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#define EMU_TSAN 1
+extern "C" void* __tsan_get_current_fiber(void);
+extern "C" void* __tsan_create_fiber(unsigned flags);
+extern "C" void __tsan_destroy_fiber(void* fiber);
+extern "C" void __tsan_switch_to_fiber(void* fiber, unsigned flags);
+#endif
+#endif
+#ifndef EMU_TSAN
+#define EMU_TSAN 0
+#endif
+
 namespace emu {
 inline thread_local dim3 g_threadIdx, g_blockIdx, g_blockDim, g_gridDim;   // per launching OS thread
 
@@ -104,6 +123,8 @@ struct Wave {
 struct Block {
   std::vector<ucontext_t> ctx;
   std::vector<void*> sp;   // fast switch: saved stack pointers of the fibers
+  std::vector<void*> tfib;   // ThreadSanitizer build: its view of the fibers
+  void* tsched = nullptr;
   void* sched_sp = nullptr;
   std::vector<char*> stacks;
   std::vector<char> done;
@@ -122,6 +143,9 @@ inline void yield() {
   Block* b = B;
   const int me = b->cur;
   ++b->switches;
+#if EMU_TSAN
+  __tsan_switch_to_fiber(b->tsched, 0);
+#endif
 #if EMU_FAST_SWITCH
   emu_ctx_switch(&b->sp[me], b->sched_sp);
 #else
@@ -236,6 +260,9 @@ inline void fiber_main() {
   b->done[me] = 1;
   --b->alive;
   --b->waves[me >> 6].alive;
+#if EMU_TSAN
+  __tsan_switch_to_fiber(b->tsched, 0);
+#endif
 #if EMU_FAST_SWITCH
   void* dead = nullptr;
   emu_ctx_switch(&dead, b->sched_sp);   // never resumed
@@ -254,6 +281,10 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   while (b->stacks.size() < nt) b->stacks.push_back((char*)malloc(kStack));
   b->ctx.resize(nt);
   b->sp.resize(nt);
+#if EMU_TSAN
+  b->tsched = __tsan_get_current_fiber();
+  while (b->tfib.size() < nt) b->tfib.push_back(__tsan_create_fiber(0));
+#endif
   b->done.assign(nt, 0);
   b->waves.assign(nt / 64, Wave());
   b->body = body;
@@ -273,6 +304,11 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         }
         for (unsigned t = 0; t < nt; ++t) {
           b->done[t] = 0;
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+          __asan_unpoison_memory_region(b->stacks[t], kStack);   // (frames abandoned by the previous fiber on this stack)
+#endif
+#endif
 #if EMU_FAST_SWITCH
           // the first switch to the fiber pops six zeroed registers and "returns" into fiber_main with the stack
           // aligned as after a call
@@ -298,6 +334,9 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
             if (b->done[t]) continue;
             b->cur = (int)t;
             g_threadIdx = dim3(t, 0, 0);
+#if EMU_TSAN
+            __tsan_switch_to_fiber(b->tfib[t], 0);
+#endif
 #if EMU_FAST_SWITCH
             emu_ctx_switch(&b->sched_sp, b->sp[t]);
 #else
@@ -408,8 +447,20 @@ template <typename P, typename T> inline T emu_fetch_max(P p, T v) {
 // stream capture is refused (the library then launches directly).
 // ---------------------------------------------------------------------------------------------------------------
 typedef enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotSupported = 801, hipErrorUnknown = 999 } hipError_t;
-struct ihipStream_t { int id; };
-struct ihipEvent_t { int id; };
+#include <atomic>
+// Streams and events carry one atomic each: every operation on a stream (or event) is an acquire-release read-modify-write
+// of it, so that a ThreadSanitizer build sees the happens-before edges the program asks the GPU for — operations of one
+// stream are ordered, hipEventRecord / hipStreamWaitEvent / *Synchronize carry order across streams — and nothing else: a
+// buffer handed from one host thread's launches to another's without such an edge is reported as the race it would be on
+// the GPU.  (Launches of ONE host thread run one after the other here: races between streams fed by the same thread
+// cannot be seen.)
+struct ihipStream_t { std::atomic<long> sync{0}; };
+struct ihipEvent_t { std::atomic<long> sync{0}; };
+namespace emu {
+inline ihipStream_t g_null_stream;
+inline void touch(ihipStream_t* s) { (s ? s : &g_null_stream)->sync.fetch_add(1, std::memory_order_acq_rel); }
+inline void touch(ihipEvent_t* e) { if (e) e->sync.fetch_add(1, std::memory_order_acq_rel); }
+}  // namespace emu
 typedef ihipStream_t* hipStream_t;
 typedef ihipEvent_t* hipEvent_t;
 typedef struct ihipGraph* hipGraph_t;
@@ -427,31 +478,33 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
-inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new ihipStream_t{0}; return hipSuccess; }
-inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = new ihipStream_t{0}; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = new ihipStream_t; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = new ihipStream_t; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t s) { emu::touch(s); return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned) { emu::touch(e); emu::touch(s); return hipSuccess; }
 inline hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
 inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) { *g = nullptr; return hipErrorNotSupported; }
 inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
 inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
 inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
-inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new ihipEvent_t{0}; return hipSuccess; }
-inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new ihipEvent_t{0}; return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new ihipEvent_t; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new ihipEvent_t; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
-inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s) { emu::touch(s); emu::touch(e); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t e) { emu::touch(e); return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
-template <typename T> inline hipError_t hipMalloc(T** p, size_t bytes) { *p = (T*)aligned_alloc(256, (bytes + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
-template <typename T> inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned = 0) { *p = (T*)aligned_alloc(256, (bytes + 255) & ~(size_t)255); return *p ? hipSuccess : hipErrorOutOfMemory; }
+// (exactly `bytes`, 256-byte aligned like the device allocator: a sanitizer build sees every overrun)
+inline void* emu_alloc(size_t bytes) { void* p = nullptr; return posix_memalign(&p, 256, bytes ? bytes : 1) == 0 ? p : nullptr; }
+template <typename T> inline hipError_t hipMalloc(T** p, size_t bytes) { *p = (T*)emu_alloc(bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
+template <typename T> inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned = 0) { *p = (T*)emu_alloc(bytes); return *p ? hipSuccess : hipErrorOutOfMemory; }
 inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
 inline hipError_t hipHostFree(void* p) { free(p); return hipSuccess; }
-inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { emu::touch((ihipStream_t*)nullptr); memmove(d, s, n); emu::touch((ihipStream_t*)nullptr); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st = nullptr) { emu::touch(st); memmove(d, s, n); emu::touch(st); return hipSuccess; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { emu::touch((ihipStream_t*)nullptr); memset(d, v, n); emu::touch((ihipStream_t*)nullptr); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = nullptr) { emu::touch(st); memset(d, v, n); emu::touch(st); return hipSuccess; }
 template <typename S> inline hipError_t hipMemcpyFromSymbol(void* d, const S& sym, size_t n) { memcpy(d, &sym, n); return hipSuccess; }
 template <typename S> inline hipError_t hipMemcpyToSymbol(S& sym, const void* s, size_t n) { memcpy(&sym, s, n); return hipSuccess; }
 inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {   // every allocation is "pinned host memory the device can write"
@@ -459,6 +512,6 @@ inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* 
   return hipSuccess;
 }
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-  emu::launch_named(#kernel, dim3(grid), dim3(block), [&] { kernel(__VA_ARGS__); })
+  (emu::touch(stream), emu::launch_named(#kernel, dim3(grid), dim3(block), [&] { kernel(__VA_ARGS__); }), emu::touch(stream))
 #define hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ev0, ev1, flags, ...) \
-  emu::launch_named(#kernel, dim3(grid), dim3(block), [&] { kernel(__VA_ARGS__); })
+  (emu::touch(stream), emu::launch_named(#kernel, dim3(grid), dim3(block), [&] { kernel(__VA_ARGS__); }), emu::touch(stream))
