@@ -189,6 +189,7 @@ struct ks_ctx {
   bool use_graphs = true;                // stage B replayed as a hipGraph (KS_NO_GRAPH=1 or a capture failure: plain launches)
   bool test_pre = false;                 // leading early-out phases through k_prewalk + k_test_pre (KS_TEST_PRE, bit 0)
   int test_pre_flags = 0;                // KS_TEST_PRE as given (bits 1, 2: variants, see enqueue_stage_b)
+  bool emit_stage = false;               // k_emit_lane stages a ray's first keys in LDS (KS_EMIT_STAGE=1; ks_k_march.h)
   uint64_t buffers_epoch = 1;            // bumped whenever a buffer a captured graph points at is re-allocated
   uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
   uint32_t* d_label_lut = nullptr;  // 256 label -> rgba
@@ -620,10 +621,13 @@ void launch_emit(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipStrea
   const size_t lds = ((2 * n + kScanBlock - 1) / kScanBlock) * sizeof(unsigned long long);
   if (!(c->cfg.method == KS_METHOD_MERGED && c->cfg.enable_anti_grazing)) {
     // bundles and 2 cm rays are long: 8 rays per wavefront; early-out rays are short: one per lane
-    if (wide || c->cfg.method == KS_METHOD_MERGED || !c->uses_early_out)
-      hipLaunchKernelGGL(k_emit_lane<8>, dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, V, c->table, c->pool);
-    else
-      hipLaunchKernelGGL(k_emit_lane<16>, dim3((uint32_t)((n + 63) / 64), nb), dim3(256), lds, st, V, c->table, c->pool);
+    if (wide || c->cfg.method == KS_METHOD_MERGED || !c->uses_early_out) {
+      if (c->emit_stage) hipLaunchKernelGGL((k_emit_lane<8, true>), dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, V, c->table, c->pool);
+      else hipLaunchKernelGGL((k_emit_lane<8, false>), dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, V, c->table, c->pool);
+    } else {
+      if (c->emit_stage) hipLaunchKernelGGL((k_emit_lane<16, true>), dim3((uint32_t)((n + 63) / 64), nb), dim3(256), lds, st, V, c->table, c->pool);
+      else hipLaunchKernelGGL((k_emit_lane<16, false>), dim3((uint32_t)((n + 63) / 64), nb), dim3(256), lds, st, V, c->table, c->pool);
+    }
   } else if (wide) {
     hipLaunchKernelGGL(k_emit<64>, dim3((uint32_t)((n + 3) / 4), nb), dim3(256), lds, st, V, c->table, c->pool);
   } else {
@@ -1565,6 +1569,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   // own.  Otherwise stage B stays strictly in frame order.
   const bool frames_independent = !uses_early_out || c->cfg.clear_checks_every_n_frames <= 1;
   c->batch = 1;
+  if (const char* es = getenv("KS_EMIT_STAGE")) c->emit_stage = atoi(es) != 0;
   if (const char* tp = getenv("KS_TEST_PRE")) {
     c->test_pre_flags = atoi(tp);
     c->test_pre = (c->test_pre_flags & 1) != 0;

@@ -939,13 +939,19 @@ __global__ void __launch_bounds__(256) k_emit(BatchView V, TileTable T, Pool P) 
 // k_emit_lane — the same emission without anti-grazing (every step of a ray emits): ONE LANE PER RAY walks the
 // first 32 voxels serially (consecutive voxels share their tile: one table lookup per tile crossing), the few
 // rays that go further are then taken one at a time by the whole wavefront (exact parallel caster).
-template <int RPW>
+// STAGE (opt-in, KS_EMIT_STAGE=1; checked on the functional model, not yet measured): the owner lanes put the keys of a
+// ray's first 32 voxels into LDS instead of writing them one 8-byte word per lane and step (64 partial lines per store
+// instruction); the wavefront then writes them out 32 consecutive keys per half-wavefront — the rays of a wavefront are
+// consecutive in integration order, so their ranges of the pair list are adjacent.
+constexpr uint32_t kStageStride = kLaneWalk + 1;   // keys per ray in LDS (+1: the owner lanes write to different banks)
+template <int RPW, bool STAGE = false>
 __global__ void __launch_bounds__(256) k_emit_lane(BatchView V, TileTable T, Pool P) {
   KS_SLOT_ARGS(V)
   if (blockIdx.x != 0 && blockIdx.x * 4u * (uint32_t)RPW >= C->n_rays) return;
   extern __shared__ unsigned long long s_bt[];
   __shared__ unsigned long long s_carry;
   __shared__ float s_e[4][3 * kES];
+  __shared__ unsigned long long s_stage[STAGE ? 4 : 1][STAGE ? RPW * kStageStride : 1];
   const uint32_t nb = (scan_length(F) + kScanBlock - 1) / kScanBlock;
   if (threadIdx.x == 0) s_carry = 0ull;
   __syncthreads();
@@ -1028,9 +1034,21 @@ __global__ void __launch_bounds__(256) k_emit_lane(BatchView V, TileTable T, Poo
     if (need_tile) slot = wait_slot(got, hpos);  // (the wave has reconverged)
     if (on) {
       const uint32_t local = (uint32_t)(dda.cx & 7) + 8u * ((uint32_t)(dda.cy & 7) + 8u * (uint32_t)(dda.cz & 7));
-      pairs[base + s] = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | key_lo;
+      const uint64_t key = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | key_lo;
+      if (STAGE && s < kLaneWalk) s_stage[threadIdx.x >> 6][lane * kStageStride + s] = key;
+      else pairs[base + s] = key;
     }
     dda.advance(on);
+  }
+  if (STAGE) {
+    KS_WAVE_LDS_ORDER();
+    const unsigned long long* stage = s_stage[threadIdx.x >> 6];
+    for (uint32_t i = 0; i < (uint32_t)RPW; i += 2) {   // lanes 0..31: ray i, lanes 32..63: ray i + 1
+      const uint32_t rr = i + (lane >> 5), s = lane & 31u;
+      const uint32_t own_r = __shfl(own, (int)rr);
+      const unsigned long long base_r = __shfl(base, (int)rr);
+      if (s < (own_r < kLaneWalk ? own_r : kLaneWalk)) pairs[base_r + s] = stage[rr * kStageStride + s];
+    }
   }
   float* escr = s_e[threadIdx.x >> 6];
   for (unsigned long long todo = by_wave ? long_mask : 0ull; todo != 0ull; todo &= todo - 1ull) {

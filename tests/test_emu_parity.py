@@ -57,6 +57,14 @@ def test_prewalk_variant_of_the_leading_phases_equals_oracle(emu_lib):
     run_case(emu_lib, dict(method=0, size=[256, 160], frames=1, cfg=dict(early_out_phase_growth=32)), env_extra={"KS_TEST_PRE": "1"})
 
 
+def test_staged_pair_emission_equals_oracle(emu_lib):
+    """KS_EMIT_STAGE=1 (k_emit_lane<RPW, true>: a ray's first keys staged in LDS and written out by the wavefront), on a
+    2 cm / 9 m geometry (long rays: owner-lane part + whole-wavefront tails) and on the default geometry with the early-out."""
+    run_case(emu_lib, dict(method=0, size=[64, 48], frames=1, no_early_out=True, max_tiles=16384,
+                           cfg=dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0)), env_extra={"KS_EMIT_STAGE": "1"})
+    run_case(emu_lib, dict(method=0, size=[96, 72], frames=2, cfg=dict(early_out_phase_growth=32)), env_extra={"KS_EMIT_STAGE": "1"})
+
+
 def test_gpu_tier_cases_unchanged_on_the_functional_model(emu_lib):
     """A selection of the GPU tier's own tests (tests/test_parity_gpu.py), UNCHANGED, against the functional model:
     the reference's CHECKs as error codes, saturated weights, degenerate inputs (NaN / zero-length / out-of-range rays),
