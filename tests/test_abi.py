@@ -64,6 +64,9 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_py" not in txt and "ks_oracle" not in txt and "libks_oracle" not in txt, f
+                # nor the host functional model of tools/emu (CPU-tier test tooling; reachable only through the
+                # diagnostics override KS_HIP_LIB that the tests set themselves)
+                assert "libks_hip_emu" not in txt and "emu/_build" not in txt, f
 
 
 def test_ctypes_structs_match_the_c_header(tmp_path):
