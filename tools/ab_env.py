@@ -1,6 +1,9 @@
-"""A/B of an environment switch of libks_hip.so on bench.py's headline workload, in ONE process (the frames are made
-once): python tools/ab_test_pre.py [ENV_NAME] [values...]   default: KS_TEST_PRE 0 1
-Prints ms/frame (median of the regions) for pipeline_frames = 4 and 0, and the per-stage HIP-event times."""
+"""A/B of an environment switch of libks_hip.so on one of bench.py's workloads, in ONE process (the frames are made
+once): python tools/ab_env.py [ENV_NAME] [values...]   default: KS_TEST_PRE 0 1
+    AB_WORKLOAD = C2 (default) | C3 | C4-fast | C4-merged    AB_FRAMES distinct frames (48)    AB_REPS repetitions (2)
+Prints ms/frame (median of the regions) for pipeline_frames = 4 and 0, and the per-stage HIP-event times.
+Switches worth a run (opt-in variants checked on the functional model): KS_TEST_PRE 0 1 7,
+KS_EMIT_STAGE 0 1 (AB_WORKLOAD=C4-fast)."""
 import os
 import statistics
 import sys
@@ -16,16 +19,17 @@ def main():
     from kimera_semantics_amd import binding as B
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    wl = dict(bench.WORKLOADS["C2"], w=640, h=480, method="fast")
+    wl = dict(bench.WORKLOADS[os.environ.get("AB_WORKLOAD", "C2")])
     n_frames = int(os.environ.get("AB_FRAMES", "48"))
     frames = bench.make_frames(wl, list(range(n_frames)))
     ring = bench.FrameRing(frames, torch, dev)
-    K, W, R = 40, 5, 3
+    big = wl["w"] * wl["h"] > 640 * 480
+    K, W, R = (10, 2, 3) if big else (40, 5, 3)
     for rep in range(int(os.environ.get("AB_REPS", "2"))):
         for v in values:
             os.environ[name] = v
             for pipe in (4, 0):
-                m = bench.measure(B, torch, None, dev, wl, ring, W, K, R, pipe, 1 << 13, 1)
+                m = bench.measure(B, torch, None, dev, wl, ring, W, K, R, pipe, (1 << 16) if big else (1 << 13), 1)
                 ms = statistics.median(r["dt"] for r in m["regions"]) / K * 1e3
                 upd = m["regions"][0]["updates"]
                 sp = m["stage_prof"]
