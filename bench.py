@@ -26,7 +26,8 @@ Prints ONE JSON line (rank 0).
           reference order, MEASURED in this run on the first timed frames (outside the timed regions).
   secondary = the same measurement for the exact-serial early-out mode (C2-exact), C3 (`merged`, reference
           bundle order), C4 (1280x720, 2 cm, 10 m; `fast` and `merged`), the host-pointer entry (H2D inside the
-          call: SURVEY.md §8d's frames/s) and the unmodified-server adapter path (N = 1 only).
+          call: SURVEY.md §8d's frames/s), the unmodified-server adapter path, and "<config>-switches": A/B of the
+          library's opt-in switches against its defaults, measured in this run, with a map digest each (N = 1 only).
 """
 from __future__ import annotations
 
@@ -71,6 +72,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--no-secondary", action="store_true", help="skip the sub-records")
+    ap.add_argument("--no-switches", action="store_true", help="skip the A/B sub-records of the library's opt-in switches")
+    ap.add_argument("--switches-child", default="", help=argparse.SUPPRESS)   # the process bench.py runs them in (argument: pickled frames)
     ap.add_argument("--only-secondary", default="", help="comma list of sub-records to run (default: all)")
     ap.add_argument("--no-oracle-count", action="store_true",
                     help="value falls back to the GPU's own update count (marked in the output)")
@@ -325,6 +328,83 @@ def early_out_fidelity(B, dev, wl, frames, max_tiles):
             "how": "this run: the benched schedule (HIP) vs the serial reference order (CPU oracle, 1 thread), same frames, fresh maps"}
 
 
+def map_digest(B, dev, wl, frames, max_tiles, sample_blocks=256, **cfg_extra):
+    """SHA-256 over the map a fresh unpipelined context holds after `frames`: all block indices (sorted) and the voxel
+    records of the first `sample_blocks` of them; plus the GPU's update count.  For switch_records: equal digests =
+    the switch does not change the result on this hardware."""
+    import hashlib
+    import numpy as np
+    integ = B.HipIntegrator(B.default_config(device_id=dev.index or 0, max_tiles=max_tiles, max_points=max(f.xyz.shape[0] for f in frames),
+                                             pipeline_frames=0, **integ_cfg(wl, **cfg_extra)))
+    upd = sum(int(integ.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates) for f in frames)
+    idx = integ.block_indices()
+    h = hashlib.sha256(np.ascontiguousarray(idx).tobytes())
+    _, t, sem = integ.download(np.ascontiguousarray(idx[:sample_blocks]))
+    h.update(np.ascontiguousarray(t).tobytes())
+    h.update(np.ascontiguousarray(sem).tobytes())
+    integ.close()
+    return h.hexdigest()[:16], upd
+
+
+def switch_records(B, torch, dev, pipeline, rings, want):
+    """A/B of the library's opt-in switches (environment variables read by ks_create), measured HERE, on the benched
+    hardware, back to back with the default build of the same context: the record a default is chosen from.  Every
+    variant also integrates two frames into a fresh map whose digest is compared with the default's: switches that
+    must not change the result (KS_TEST_PRE, KS_EMIT_STAGE) say so, on this GPU; KS_SUB_RUN_GENERATIONS=1 is the early-out
+    schedule benched until round 3 (another, equally deterministic, result: tests/test_parity_gpu.py pins both)."""
+    plan = {
+        "C2": (("KS_SUB_RUN_GENERATIONS", "1", False), ("KS_TEST_PRE", "1", True), ("KS_TEST_PRE", "7", True), ("KS_EMIT_STAGE", "1", True)),
+        "C4-fast": (("KS_SUB_RUN_GENERATIONS", "1", False), ("KS_EMIT_STAGE", "1", True)),
+        "C4-merged": (("KS_EMIT_STAGE", "1", True),),
+    }
+    out = []
+    for name, switches in plan.items():
+        if not want(name) or name not in rings:
+            continue
+        ring, first = rings[name]
+        swl = WORKLOADS[name]
+        big = swl["w"] * swl["h"] > 640 * 480
+        K, R, tiles = (6, 3, 1 << 16) if big else (40, 3, 1 << 13)
+
+        def one():
+            m = measure(B, torch, None, dev, swl, ring, 2, K, R, pipeline, tiles, 1)
+            ms = [r["dt"] / K * 1e3 for r in m["regions"]]
+            sp = m["stage_prof"]
+            return {"ms_per_frame": round(statistics.median(ms), 4), "ms_per_frame_all_regions": [round(x, 4) for x in ms],
+                    "stage_ms": {k: round(sp["ms"][k] / max(1, sp["launches"][k]), 4) for k in sp["ms"] if sp["launches"][k]}}
+        probe = [ring.host(first + i) for i in range(2)]
+        rec = {"config": name + "-switches", "pipeline_frames": pipeline, "steps_per_region": K, "regions": R, "variants": []}
+        saved = {k: os.environ.pop(k, None) for k, _, _ in switches}
+        try:
+            base = one()
+            base["map_digest"], base["updates_2_frames"] = map_digest(B, dev, swl, probe, tiles)
+            rec["default"] = base
+            for env, val, same in switches:
+                v = {"switch": f"{env}={val}", "result_must_equal_default": same}
+                try:
+                    os.environ[env] = val
+                    v.update(one())
+                    d, u = map_digest(B, dev, swl, probe, tiles)
+                    v["map_equals_default"] = (d == base["map_digest"] and u == base["updates_2_frames"])
+                    v["updates_2_frames"] = u
+                    v["ms_over_default"] = round(v["ms_per_frame"] / base["ms_per_frame"], 4)
+                except Exception as e:
+                    v["error"] = f"{type(e).__name__}: {e}"
+                finally:
+                    os.environ.pop(env, None)
+                rec["variants"].append(v)
+            again = one()     # the default once more, last: drift over the A/B sequence
+            rec["default_again_ms_per_frame"] = again["ms_per_frame"]
+        except Exception as e:
+            rec["error"] = f"{type(e).__name__}: {e}"
+        finally:
+            for k, v0 in saved.items():
+                if v0 is not None:
+                    os.environ[k] = v0
+        out.append(rec)
+    return out
+
+
 def pmc_traffic(name):
     """HBM bytes per k_apply launch from the committed PMC pass of this command (profiles/r03_pmc_<name>.json,
     written by tools/pmc_bench.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 unit correction applied)."""
@@ -539,6 +619,16 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
+    if args.switches_child:
+        pipeline = int(os.environ.get("KS_BENCH_PIPE", "4"))
+        import pickle
+        with open(args.switches_child, "rb") as fh:
+            fr = pickle.load(fh)
+        rings = {"C2": (FrameRing(fr["C2"], torch, dev), PRIME + 2)}   # (the frames are replayed cyclically)
+        if fr["C4"]:
+            rings["C4-fast"] = rings["C4-merged"] = (FrameRing(fr["C4"], torch, dev), PRIME + 2)
+        os.write(json_fd, (json.dumps(switch_records(B, torch, dev, pipeline, rings, lambda n: True)) + "\n").encode())
+        return
     K, W = args.steps, args.warmup
     R = max(MIN_REPEATS, -(-MIN_TIMED_FRAMES // max(1, K)))
     wl = dict(WORKLOADS["C2"], w=args.width, h=args.height, method=args.method)
@@ -729,12 +819,33 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as e:
                     sec.append({"config": name, "error": f"{type(e).__name__}: {e}"})
+            c4_host = list(c4_ring.frames[:8]) if c4_ring is not None else []
             del c4_ring
+            torch.cuda.empty_cache()
             if want("adapter") and args.method == "fast":
                 try:
                     sec.append(adapter_record([ring.host(PRIME + i) for i in range(12)]))
                 except Exception as e:
                     sec.append({"config": "adapter", "error": f"{type(e).__name__}: {e}"})
+            if want("switches") and not args.no_switches and args.method == "fast" and (args.width, args.height) == (640, 480):
+                # LAST, in a process of its own: some switches select kernels that have only ever run on the host functional
+                # model (tools/emu); whatever they do on this GPU, everything above has been measured and stands
+                import pickle
+                import subprocess
+                import tempfile
+                try:
+                    with tempfile.NamedTemporaryFile(suffix=".pkl") as tf:
+                        pickle.dump({"C2": frames[:24], "C4": c4_host}, tf, protocol=4)
+                        tf.flush()
+                        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--switches-child", tf.name], stdout=subprocess.PIPE,
+                                           stderr=subprocess.PIPE, timeout=420, env=dict(os.environ, KS_BENCH_PIPE=str(pipeline)))
+                    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("[")]
+                    if r.returncode == 0 and lines:
+                        sec.extend(json.loads(lines[-1]))
+                    else:
+                        sec.append({"config": "switches", "error": f"child rc {r.returncode}: " + r.stderr.decode(errors="replace")[-400:]})
+                except Exception as e:
+                    sec.append({"config": "switches", "error": f"{type(e).__name__}: {e}"})
             out["secondary"] = sec
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or (dist.is_available() and dist.is_initialized()):

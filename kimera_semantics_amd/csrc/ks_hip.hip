@@ -190,6 +190,7 @@ struct ks_ctx {
   bool test_pre = false;                 // leading early-out phases through k_prewalk + k_test_pre (KS_TEST_PRE, bit 0)
   int test_pre_flags = 0;                // KS_TEST_PRE as given (bits 1, 2: variants, see enqueue_stage_b)
   bool emit_stage = false;               // k_emit_lane stages a ray's first keys in LDS (KS_EMIT_STAGE=1; ks_k_march.h)
+  bool sub_run_generations = false;      // early-out sub-runs of 16 generations instead of 16 live rays (KS_SUB_RUN_GENERATIONS=1: A/B runs; ks_k_march.h)
   uint64_t buffers_epoch = 1;            // bumped whenever a buffer a captured graph points at is re-allocated
   uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
   uint32_t* d_label_lut = nullptr;  // 256 label -> rgba
@@ -673,7 +674,8 @@ void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipS
         else { if (dedup) KS_LAUNCH_PRE(32, true); else KS_LAUNCH_PRE(32, false); }
 #undef KS_LAUNCH_PRE
       } else
-        hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb, nb), dim3(64 * wpb), lds_wave * wpb, sm, V, g0, g1, steps_cap);
+        hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb, nb), dim3(64 * wpb), lds_wave * wpb, sm, V, g0, g1, steps_cap,
+                           c->sub_run_generations ? 1u : 0u);
     }
   }
   if (part == 1) return;
@@ -1570,6 +1572,9 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   const bool frames_independent = !uses_early_out || c->cfg.clear_checks_every_n_frames <= 1;
   c->batch = 1;
   if (const char* es = getenv("KS_EMIT_STAGE")) c->emit_stage = atoi(es) != 0;
+  // A/B runs: the early-out sub-runs of the schedule measured until round 3 (16 generations instead of 16 live rays;
+  // the CPU checker follows with KO_SUB_RUN_GENERATIONS=1)
+  if (const char* sg = getenv("KS_SUB_RUN_GENERATIONS")) c->sub_run_generations = atoi(sg) != 0;
   if (const char* tp = getenv("KS_TEST_PRE")) {
     c->test_pre_flags = atoi(tp);
     c->test_pre = (c->test_pre_flags & 1) != 0;

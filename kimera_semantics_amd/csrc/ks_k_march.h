@@ -129,9 +129,12 @@ __device__ __forceinline__ int sorted_count(const float* e, float v) {  // #{i <
 // that owns the crossing which follows it.
 template <typename Visit>
 __device__ __forceinline__ void dda_round64(Dda& st, float* E, uint32_t lane, Visit&& visit) {
+  float tx0 = st.tx, ty0 = st.ty, tz0 = st.tz, dx0 = st.dx, dy0 = st.dy, dz0 = st.dz;
+  KS_VALUE_BARRIER(tx0); KS_VALUE_BARRIER(ty0); KS_VALUE_BARRIER(tz0);
+  KS_VALUE_BARRIER(dx0); KS_VALUE_BARRIER(dy0); KS_VALUE_BARRIER(dz0);
   if (lane < 3) {
-    float t = lane == 0 ? st.tx : lane == 1 ? st.ty : st.tz;
-    const float d = lane == 0 ? st.dx : lane == 1 ? st.dy : st.dz;
+    float t = lane == 0 ? tx0 : lane == 1 ? ty0 : tz0;
+    const float d = lane == 0 ? dx0 : lane == 1 ? dy0 : dz0;
     float* e = E + lane * kES;
     for (int i = 0; i < 65; ++i) {
       e[i] = t;
@@ -199,8 +202,13 @@ constexpr uint32_t kCntBroke = 1u << 31;  // cnt[] flag: the ray stopped on a vo
 // ------------------------------------------------------------------------------------------
 // k_test — ORDERED-PHASE early-out (the CPU checker under oracle/ restates it as integrate_fast_phased):
 // integration position s -> chain s % 1024, generation s / 1024; one launch per phase of generations
-// [g0, g1).  Inside a phase a chain's generations are cut into SUB-RUNS of 16; ONE WAVEFRONT owns a
-// (chain, sub-run) and resolves its live rays in generation order.  A ray tests its voxels against (a) the
+// [g0, g1).  Inside a phase a chain's LIVE rays (those that survived the start-voxel dedup: nearly all of the
+// first generations, one in five to one in twenty of the late ones) are cut, in generation order, into SUB-RUNS
+// of 16; ONE WAVEFRONT owns a (chain, sub-run) and resolves its rays in generation order.  The launch covers the worst
+// case (every ray live: one wavefront per 16 generations); a wavefront finds its rays by ranking the chain's live
+// flags of the phase (64 generations per ballot) and ends at once if the chain has fewer than 16 * sub + 1 of them.
+// (by_generation != 0: sub-run = 16 consecutive generations, live or not — the schedule measured until round 3,
+// kept for A/B runs, KS_SUB_RUN_GENERATIONS=1.)  A ray tests its voxels against (a) the
 // marks previous rays of its sub-run made (8 KiB of LDS, newest (generation, step) wins a slot) and
 // (b) the shared set as it stood when the phase began (read-only during the launch).
 //   A  lanes 0..15, one ray each: descriptor, caster set-up, the first 16 voxels walked serially (no lane
@@ -277,7 +285,7 @@ __device__ __forceinline__ bool priv_lookup(const unsigned long long* priv, uint
 // LDS per wavefront: private set | keys of the first 16 voxels of 16 rays | keys of one long ray | per-ray words
 __host__ __device__ inline uint32_t test_lds_words64(uint32_t steps_cap) { return kPrivSlots + 256u + steps_cap + 16u + (3u * kES + 1u) / 2u; }
 
-__global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0, uint32_t g1, uint32_t steps_cap) {
+__global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0, uint32_t g1, uint32_t steps_cap, uint32_t by_generation) {
   // stage B kernels read the frame's parameters from device memory: the launch sequence of a frame slot is
   // then identical from frame to frame and is replayed as a captured graph
   const SlotView& sv = V.s[blockIdx.y];
@@ -308,30 +316,57 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
   unsigned long long* lkeys = keys + 256;              // [steps_cap]          the long ray's voxels from step 16 on
   uint32_t* rinfo = (uint32_t*)(lkeys + steps_cap);    // [16] steps of the ray | [16] shared-set hit mask
   float* escr = (float*)(rinfo + 32);                  // [3 * kES] scratch of the parallel caster
-  for (uint32_t i = lane; i < kPrivSlots; i += 64) priv[i] = 0ull;  // wave-private: no block barrier needed
   if (C->err & (kErrLabel | kErrIndex)) return;
   const uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave;
   const uint32_t chain = w % kChains, sub = w / kChains;
-  const uint32_t gs = g0 + sub * kSubRun;
   {  // the launch covers the slot's capacity: the frame's last generation ends the last phase
     const uint32_t n_gen = (F.n + kChains - 1u) / kChains;
     if (g1 > n_gen) g1 = n_gen;
   }
-  if (gs >= g1) return;
-  const uint32_t ge = gs + kSubRun < g1 ? gs + kSubRun : g1;
+  // ---- which rays: my_gen = generation of the ray lane l < 16 owns (~0u: none) ----
+  uint32_t my_gen = ~0u;
+  if (by_generation) {
+    const uint32_t g = g0 + sub * kSubRun + lane;
+    if (lane < kSubRun && g < g1 && (uint64_t)g * kChains + chain < F.n && live[(uint64_t)g * kChains + chain] != 0) my_gen = g;
+  } else {
+    // rank of every live ray of the chain within the phase; ranks [16 sub, 16 sub + 16) are this wavefront's.  Four
+    // ballots' worth of flags are in flight at a time (a late phase of a 640x480 frame is 128 generations long).
+    const uint32_t r_lo = sub * kSubRun;
+    uint32_t seen = 0;
+    for (uint32_t gb = g0; gb < g1 && seen < r_lo + kSubRun; gb += 256u) {
+      uint8_t fl[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t g = gb + 64u * (uint32_t)q + lane;
+        fl[q] = (g < g1 && (uint64_t)g * kChains + chain < F.n) ? live[(uint64_t)g * kChains + chain] : (uint8_t)0;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const unsigned long long m = __ballot(fl[q] != 0);
+        const uint32_t rank = seen + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        if (fl[q] != 0 && rank >= r_lo && rank < r_lo + kSubRun) rinfo[rank - r_lo] = gb + 64u * (uint32_t)q + lane;
+        seen += (uint32_t)__popcll(m);
+      }
+    }
+    if (seen <= r_lo) return;  // the chain has no 16 * sub + 1 live rays in this phase
+    KS_WAVE_LDS_ORDER();
+    if (lane < kSubRun && lane < seen - r_lo) my_gen = rinfo[lane];
+    KS_WAVE_LDS_ORDER();       // (rinfo is reused below)
+  }
+  if (__ballot(my_gen != ~0u) == 0ull) return;
+  for (uint32_t i = lane; i < kPrivSlots; i += 64) priv[i] = 0ull;  // wave-private: no block barrier needed
   const int lim = F.max_collisions;
 #ifdef KS_STATS
   const unsigned long long t_begin = __builtin_readcyclecounter();
   uint32_t st_long = 0, st_rounds = 0;
 #endif
 
-  // ---- A: lane l < 16 owns the ray of generation gs + l ----
+  // ---- A: lane l < 16 owns a ray ----
   Dda dda{};
   int my_steps = -1;
   {
-    const uint32_t g = gs + lane;
-    const uint64_t p = (uint64_t)g * kChains + chain;
-    const bool is_live = lane < kSubRun && g < ge && p < F.n && live[p] != 0;
+    const uint64_t p = (uint64_t)my_gen * kChains + chain;
+    const bool is_live = my_gen != ~0u;
     if (is_live) {
       const RayDesc d = rays[ray_index(F, (uint32_t)p)];
       dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
@@ -377,7 +412,7 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
     const uint32_t j = (uint32_t)__ffs((int)todo) - 1u;
     const int steps_j = (int)rinfo[j];
     const uint32_t hs = rinfo[16 + j];
-    const uint32_t gen_j = gs + j, pos_j = gen_j * kChains + chain;
+    const uint32_t gen_j = (uint32_t)__shfl((int)my_gen, (int)j), pos_j = gen_j * kChains + chain;
     const bool valid = lane < 16 && (int)lane <= steps_j;
     unsigned long long k = 0ull;
     bool hit = false;

@@ -47,6 +47,12 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 #ifndef KS_WAIT_VMEM
 #define KS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
+// KS_VALUE_BARRIER(x): x is a value in a vector register from here on, whatever it was computed from.  (Selecting one of
+// several fields of a struct by lane number is otherwise folded into ONE load from a lane-dependent address, which
+// pins the whole struct to scratch memory: a round trip through the vector memory path where a v_cndmask would do.)
+#ifndef KS_VALUE_BARRIER
+#define KS_VALUE_BARRIER(x) asm volatile("" : "+v"(x))
+#endif
 
 // Compaction slot for lanes with pred == true: one atomic per wavefront (a same-address
 // returning atomic per lane saturates at ~88/us on MI355X).  Must be called converged.

@@ -610,9 +610,11 @@ struct ko_ctx {
   //   * integration position s -> chain c = s % 1024 (the "mixed" order's group, i.e. a run of
   //     neighbouring points) and generation g = s / 1024;
   //   * generations are cut into phases [B_j, B_j+1), B_0 = 0, B_j+1 = B_j + max(1, B_j (growth-16)/16);
-  //   * within a phase the 1024 chains are independent, and a chain's generations are cut into sub-runs
-  //     of 16 (counted from the phase's first generation) that are independent too; a sub-run walks its
-  //     rays in generation order;
+  //   * within a phase the 1024 chains are independent, and a chain's LIVE rays of the phase (those that
+  //     survived the start-voxel dedup), taken in generation order, are cut into sub-runs of 16 that are
+  //     independent too; a sub-run walks its rays in generation order.  (Until round 3 a sub-run was 16
+  //     GENERATIONS, live or not — KO_SUB_RUN_GENERATIONS=1 / KS_SUB_RUN_GENERATIONS=1 bring that schedule
+  //     back on both sides for A/B runs.  A phase of at most 16 generations is one sub-run either way.)
   //   * a ray tests every voxel of its path against: the marks the PREVIOUS rays of its own sub-run made
   //     (private direct-mapped set of 1024 entries, newest (generation, step) wins an entry), else the
   //     shared set as it stood when the phase began;
@@ -663,6 +665,8 @@ struct ko_ctx {
     std::vector<Mark> marks;
     std::vector<uint64_t> priv((size_t)kChains * kPrivSlots);
     std::vector<uint32_t> priv_sub(kChains);  // sub-run the chain's private set currently belongs to
+    std::vector<uint32_t> live_seen(kChains);  // live rays of the chain the phase has handled so far
+    const bool sub_run_generations = getenv("KO_SUB_RUN_GENERATIONS") && atoi(getenv("KO_SUB_RUN_GENERATIONS")) != 0;  // (read per frame: tests switch it)
     std::vector<std::pair<uint32_t, uint64_t>> own;
     size_t r0 = 0;
     for (size_t j = 0; j < B.size() && r0 < rays.size(); ++j) {
@@ -670,15 +674,16 @@ struct ko_ctx {
       marks.clear();
       std::fill(priv.begin(), priv.end(), 0ull);
       std::fill(priv_sub.begin(), priv_sub.end(), 0u);
+      std::fill(live_seen.begin(), live_seen.end(), 0u);
       size_t r1 = r0;
       // rays are in position order = generation-major; a chain's rays therefore appear in generation order
       for (; r1 < rays.size() && rays[r1].pos < end_pos; ++r1) {
         Ray& r = rays[r1];
         const uint32_t chain = r.pos % kChains, gen = r.pos / kChains;
         uint64_t* pv = &priv[(size_t)chain * kPrivSlots];
-        // (KO_EXP_SUB_RUN: schedule research only — the GPU's sub-runs are kSubRun generations long)
+        // (KO_EXP_SUB_RUN: schedule research only — the GPU's sub-runs are kSubRun rays long)
         static const uint32_t sub_run = getenv("KO_EXP_SUB_RUN") ? (uint32_t)strtoul(getenv("KO_EXP_SUB_RUN"), nullptr, 10) : kSubRun;
-        const uint32_t sub = (gen - B[j]) / sub_run;
+        const uint32_t sub = sub_run_generations ? (gen - B[j]) / sub_run : live_seen[chain]++ / sub_run;
         if (sub != priv_sub[chain]) {  // a new sub-run starts with an empty private set
           std::fill(pv, pv + kPrivSlots, 0ull);
           priv_sub[chain] = sub;

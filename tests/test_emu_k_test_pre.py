@@ -30,3 +30,15 @@ def test_k_test_pre_equals_k_test_and_serial_schedule(harness, n, limit, seed, v
     r = subprocess.run([harness, str(n), str(limit), str(seed), str(voxel)], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert "k_test_pre: identical" in r.stdout and "DIFFERENT" not in r.stdout and r.stdout.strip().endswith("OK")
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_k_test_late_phases_equal_serial_schedule(harness, legacy):
+    """117 generations: phases of 32 and 53 generations, i.e. several (chain, sub-run) wavefronts per chain in k_test —
+    sub-runs over the chain's live rays (default) and over generations (EMU_SUB_RUN_GENERATIONS: the A/B switch)."""
+    env = dict(os.environ)
+    if legacy:
+        env["EMU_SUB_RUN_GENERATIONS"] = "1"
+    r = subprocess.run([harness, "120000", "2", "6", "0.05"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "phase [64,118) k_test    : identical" in r.stdout and "DIFFERENT" not in r.stdout and r.stdout.strip().endswith("OK")

@@ -57,6 +57,14 @@ def test_prewalk_variant_of_the_leading_phases_equals_oracle(emu_lib):
     run_case(emu_lib, dict(method=0, size=[256, 160], frames=1, cfg=dict(early_out_phase_growth=32)), env_extra={"KS_TEST_PRE": "1"})
 
 
+@pytest.mark.parametrize("legacy", ["0", "1"])
+def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_lib, legacy):
+    """320x240 = 75 generations: the phases [32, 64) and [64, 75) have up to two sub-runs per chain, cut over the chain's LIVE
+    rays (default) or over its generations (the schedule until round 3, kept switchable on both sides for A/B runs)."""
+    run_case(emu_lib, dict(method=0, size=[320, 240], frames=2, max_tiles=8192, cfg=dict(early_out_phase_growth=32)),
+             env_extra={"KS_SUB_RUN_GENERATIONS": legacy, "KO_SUB_RUN_GENERATIONS": legacy})
+
+
 def test_staged_pair_emission_equals_oracle(emu_lib):
     """KS_EMIT_STAGE=1 (k_emit_lane<RPW, true>: a ray's first keys staged in LDS and written out by the wavefront), on a
     2 cm / 9 m geometry (long rays: owner-lane part + whole-wavefront tails) and on the default geometry with the early-out."""

@@ -122,6 +122,7 @@ static BatchView view_of(const Frame& fr, State& st) {
   return V;
 }
 
+static const bool g_by_generation = getenv("EMU_SUB_RUN_GENERATIONS") != nullptr;
 static void run_prewalk(const Frame& fr, State& st, uint32_t G, uint32_t Gpad, uint32_t cap) {
   st.pre_hash.assign((size_t)kChains * Gpad * cap, 0xdeadbeefu);
   st.pre_steps.assign((size_t)kChains * Gpad, -7);
@@ -142,7 +143,7 @@ static void run_phase_kernel(const Frame& fr, State& st, uint32_t g0, uint32_t g
 #undef LAUNCH_PRE
   } else {
     // one wavefront per block (the kernel derives its (chain, sub-run) from blockIdx and blockDim)
-    emu::launch(dim3(kChains * n_sub, 1), dim3(64), [&] { k_test(V, g0, g1, fr.steps_cap); });
+    emu::launch(dim3(kChains * n_sub, 1), dim3(64), [&] { k_test(V, g0, g1, fr.steps_cap, g_by_generation ? 1u : 0u); });
   }
 }
 
@@ -154,13 +155,15 @@ static void run_phase_serial(const Frame& fr, State& st, uint32_t g0, uint32_t g
   const std::vector<unsigned long long> snap = st.observed;   // the set as it stood when the phase began
   std::vector<unsigned long long> priv(kPrivSlots);
   std::vector<unsigned long long> keys;
-  for (uint32_t chain = 0; chain < kChains; ++chain)
-    for (uint32_t gs = g0; gs < g1; gs += kSubRun) {
-      std::fill(priv.begin(), priv.end(), 0ull);
-      const uint32_t ge = std::min(gs + kSubRun, g1);
-      for (uint32_t g = gs; g < ge; ++g) {
+  for (uint32_t chain = 0; chain < kChains; ++chain) {
+    uint32_t live_seen = 0;
+    {
+      for (uint32_t g = g0; g < g1; ++g) {
         const uint64_t p = (uint64_t)g * kChains + chain;
+        // a sub-run = 16 live rays of the chain (EMU_SUB_RUN_GENERATIONS=1: 16 generations, the schedule until round 3)
+        if (g_by_generation ? (g - g0) % kSubRun == 0 : (p < F.n && fr.live[p] && live_seen % kSubRun == 0)) std::fill(priv.begin(), priv.end(), 0ull);
         if (p >= F.n || !fr.live[p]) continue;
+        ++live_seen;
         const RayDesc d = fr.rays[ray_index(F, (uint32_t)p)];
         Dda dda{};
         dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, false);
@@ -192,6 +195,7 @@ static void run_phase_serial(const Frame& fr, State& st, uint32_t g0, uint32_t g
         st.cnt[p] = updates | (stop >= 0 ? kCntBroke : 0u);
       }
     }
+  }
 }
 
 static bool same(const State& a, const State& b, const char* what, uint32_t g0, uint32_t g1) {
