@@ -190,6 +190,7 @@ struct ks_ctx {
   bool test_pre = false;                 // leading early-out phases through k_prewalk + k_test_pre (KS_TEST_PRE, bit 0)
   int test_pre_flags = 0;                // KS_TEST_PRE as given (bits 1, 2: variants, see enqueue_stage_b)
   bool emit_stage = false;               // k_emit_lane stages a ray's first keys in LDS (KS_EMIT_STAGE=1; ks_k_march.h)
+  bool test_overlap = true;              // k_test casts a long ray's next 64 voxels while the shared-set entries of the current 64 are in flight (KS_TEST_OVERLAP=0: one after the other, as measured until round 3)
   bool sub_run_generations = false;      // early-out sub-runs of 16 generations instead of 16 live rays (KS_SUB_RUN_GENERATIONS=1: A/B runs; ks_k_march.h)
   uint64_t buffers_epoch = 1;            // bumped whenever a buffer a captured graph points at is re-allocated
   uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
@@ -674,8 +675,12 @@ void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipS
         else { if (dedup) KS_LAUNCH_PRE(32, true); else KS_LAUNCH_PRE(32, false); }
 #undef KS_LAUNCH_PRE
       } else
-        hipLaunchKernelGGL(k_test, dim3(kChains * n_sub / wpb, nb), dim3(64 * wpb), lds_wave * wpb, sm, V, g0, g1, steps_cap,
-                           c->sub_run_generations ? 1u : 0u);
+      {
+        const dim3 grid(kChains * n_sub / wpb, nb), block(64 * wpb);
+        const uint32_t by_gen = c->sub_run_generations ? 1u : 0u;
+        if (c->test_overlap) hipLaunchKernelGGL(k_test<true>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap, by_gen);
+        else hipLaunchKernelGGL(k_test<false>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap, by_gen);
+      }
     }
   }
   if (part == 1) return;
@@ -1575,6 +1580,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   // A/B runs: the early-out sub-runs of the schedule measured until round 3 (16 generations instead of 16 live rays;
   // the CPU checker follows with KO_SUB_RUN_GENERATIONS=1)
   if (const char* sg = getenv("KS_SUB_RUN_GENERATIONS")) c->sub_run_generations = atoi(sg) != 0;
+  if (const char* ov = getenv("KS_TEST_OVERLAP")) c->test_overlap = atoi(ov) != 0;
   if (const char* tp = getenv("KS_TEST_PRE")) {
     c->test_pre_flags = atoi(tp);
     c->test_pre = (c->test_pre_flags & 1) != 0;

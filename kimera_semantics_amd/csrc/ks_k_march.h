@@ -224,6 +224,19 @@ constexpr uint32_t kCntBroke = 1u << 31;  // cnt[] flag: the ray stopped on a vo
 // Output: cnt[s] = number of voxels the ray updates (| kCntBroke).
 // The reference's loop: [K:src/semantic_tsdf_integrator_fast.cpp:110-122].
 // ------------------------------------------------------------------------------------------
+// The shared set is read and written through pointers that SAY global memory: the table's address comes out of a struct in
+// memory (FrameParams), so the compiler would otherwise emit FLAT operations, and a flat load counts as an LDS operation
+// too — every wait for the LDS (s_waitcnt lgkmcnt) would then also wait for the set's entries in flight.
+typedef unsigned long long obs_u64x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) unsigned long long obs_global_u64;
+typedef __attribute__((address_space(1))) obs_u64x2 obs_global_u64x2;
+__device__ __forceinline__ void obs_atomic_max(obs_global_u64* p, unsigned long long v) {   // = atomicMax, result unused
+  (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ ulonglong2 obs_load2(const obs_global_u64* observed, uint32_t slot) {   // {newest, older} of a slot
+  const obs_u64x2 e = ((const obs_global_u64x2*)observed)[slot];
+  return make_ulonglong2(e.x, e.y);
+}
 constexpr int kTestThreads = 256;    // 4 wavefronts per block
 constexpr uint32_t kSubRun = 16;     // generations per (chain, sub-run) wavefront
 #ifdef KS_STATS
@@ -285,6 +298,7 @@ __device__ __forceinline__ bool priv_lookup(const unsigned long long* priv, uint
 // LDS per wavefront: private set | keys of the first 16 voxels of 16 rays | keys of one long ray | per-ray words
 __host__ __device__ inline uint32_t test_lds_words64(uint32_t steps_cap) { return kPrivSlots + 256u + steps_cap + 16u + (3u * kES + 1u) / 2u; }
 
+template <bool OVERLAP>
 __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0, uint32_t g1, uint32_t steps_cap, uint32_t by_generation) {
   // stage B kernels read the frame's parameters from device memory: the launch sequence of a frame slot is
   // then identical from frame to frame and is replayed as a captured graph
@@ -294,21 +308,30 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
   uint32_t* __restrict__ cnt = sv.cnt;
   const Counters* C = sv.C;
   const FrameParams F = *sv.F;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
-  unsigned long long* observed = (unsigned long long*)F.observed;   // [slot] = {newest, older}
+  obs_global_u64* observed = (obs_global_u64*)(unsigned long long*)F.observed;   // [slot] = {newest, older}
   const uint32_t phase_pos0 = g0 * kChains;  // marks at positions >= this one belong to the phase being run
   // slot content as it stood when the phase began (see the set's description above)
   bool my_save = false;  // this lane has issued a save since the wavefront last waited for its saves
-  auto snapshot_decide = [&](const ulonglong2 e, uint32_t slot, uint32_t h) -> bool {
+  // (in two steps, so that a batch of entries can be looked at before the first save goes out: a wait for the next
+  // entry of the batch would otherwise also wait for the save issued in between — memory operations complete in order)
+  auto snapshot_look = [&](const ulonglong2 e, uint32_t h, bool& save) -> bool {
     unsigned long long content = e.x;
     const bool current = (uint32_t)(e.x >> 54) == F.obs_tag && ((uint32_t)(e.x >> 32) & 0x3fffffu) > phase_pos0;
     if (current) content = e.y;
-    else if (e.x != 0ull && e.x != e.y) {
-      atomicMax(&observed[2u * slot + 1u], e.x);
-      my_save = true;
-    }
+    save = !current && e.x != 0ull && e.x != e.y;
     return obs_match(content, h, F.obs_tag_lo, F.obs_tag);
   };
-  auto snapshot_hit = [&](uint32_t slot, uint32_t h) -> bool { return snapshot_decide(((const ulonglong2*)observed)[slot], slot, h); };
+  auto snapshot_save = [&](const ulonglong2 e, uint32_t slot) {
+    obs_atomic_max(&observed[2u * slot + 1u], e.x);
+    my_save = true;
+  };
+  auto snapshot_decide = [&](const ulonglong2 e, uint32_t slot, uint32_t h) -> bool {
+    bool save;
+    const bool hit = snapshot_look(e, h, save);
+    if (save) snapshot_save(e, slot);
+    return hit;
+  };
+  auto snapshot_hit = [&](uint32_t slot, uint32_t h) -> bool { return snapshot_decide(obs_load2(observed, slot), slot, h); };
   extern __shared__ unsigned long long s_test[];
   const uint32_t lane = lane_id(), wave = threadIdx.x >> 6;
   unsigned long long* priv = s_test + (size_t)wave * test_lds_words64(steps_cap);
@@ -337,8 +360,11 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
       uint8_t fl[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        // (unconditional loads from a clamped address: a load under a branch would be waited for before the next is issued)
         const uint32_t g = gb + 64u * (uint32_t)q + lane;
-        fl[q] = (g < g1 && (uint64_t)g * kChains + chain < F.n) ? live[(uint64_t)g * kChains + chain] : (uint8_t)0;
+        const bool in = g < g1 && (uint64_t)g * kChains + chain < F.n;
+        fl[q] = live[in ? (uint64_t)g * kChains + chain : (uint64_t)0];
+        if (!in) fl[q] = 0;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -396,10 +422,18 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
       const uint32_t r = (uint32_t)b * 4u + grp;
       const bool on = ((live_mask >> r) & 1u) && (int)l <= (int)rinfo[r];
       kk[b] = on ? keys[r * 16 + l] : ~0ull;
-      ee[b] = on ? ((const ulonglong2*)observed)[(uint32_t)(kk[b] >> 32)] : make_ulonglong2(0ull, 0ull);
+      ee[b] = on ? obs_load2(observed, (uint32_t)(kk[b] >> 32)) : make_ulonglong2(0ull, 0ull);
+    }
+    KS_WAIT_LOADS();
+    bool sv4[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      sv4[b] = false;
+      hit[b] = kk[b] != ~0ull && snapshot_look(ee[b], (uint32_t)kk[b], sv4[b]);
     }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) hit[b] = kk[b] != ~0ull && snapshot_decide(ee[b], (uint32_t)(kk[b] >> 32), (uint32_t)kk[b]);
+    for (int b = 0; b < 4; ++b)
+      if (kk[b] != ~0ull && sv4[b]) snapshot_save(ee[b], (uint32_t)(kk[b] >> 32));
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       const unsigned long long m = __ballot(hit[b]);
@@ -434,33 +468,56 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
       uint32_t s0 = 16;
       Dda ust = dda_bcast(dda, (int)j);          // the ray's state at step 16, wave-uniform
       const bool par = dda_parallel_ok(ust);
+      // keys of the steps [first, first + 64) of the ray (as far as it goes) -> lkeys
+      auto cast_round = [&](uint32_t first) {
+        const uint32_t n_r = (uint32_t)steps_j + 1u - first < 64u ? (uint32_t)steps_j + 1u - first : 64u;
+        if (par) {  // all 64 lanes: the exact parallel caster
+          dda_round64(ust, escr, lane, [&](uint32_t r, int vx, int vy, int vz) {
+            if (r < n_r) {
+              const uint32_t h = index_hash(vx, vy, vz);
+              const uint32_t slot = (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask);
+              lkeys[first - 16u + r] = ((unsigned long long)slot << 32) | h;
+            }
+          });
+        } else if (lane == j) {  // axis-parallel ray (NaN / inf crossing times): its owner lane walks it
+          for (uint32_t i = 0; i < n_r; ++i) {
+            const uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
+            const uint32_t slot = (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask);
+            lkeys[first - 16u + i] = ((unsigned long long)slot << 32) | h;
+            dda.advance(first + i < (uint32_t)steps_j);
+          }
+        }
+      };
+      if (OVERLAP) cast_round(s0);
       for (;;) {
 #ifdef KS_STATS
         ++st_rounds;
 #endif
         const uint32_t n_round = (uint32_t)steps_j + 1u - s0 < 64u ? (uint32_t)steps_j + 1u - s0 : 64u;
-        if (par) {  // all 64 lanes: the exact parallel caster
-          dda_round64(ust, escr, lane, [&](uint32_t r, int vx, int vy, int vz) {
-            if (r < n_round) {
-              const uint32_t h = index_hash(vx, vy, vz);
-              const uint32_t slot = (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask);
-              lkeys[s0 - 16u + r] = ((unsigned long long)slot << 32) | h;
-            }
-          });
-        } else if (lane == j) {  // axis-parallel ray (NaN / inf crossing times): its owner lane walks it
-          for (uint32_t i = 0; i < n_round; ++i) {
-            const uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
-            const uint32_t slot = (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask);
-            lkeys[s0 - 16u + i] = ((unsigned long long)slot << 32) | h;
-            dda.advance(s0 + i < (uint32_t)steps_j);
-          }
-        }
+        if (!OVERLAP) cast_round(s0);
         KS_WAVE_LDS_ORDER();
         const bool v64 = lane < n_round;
         bool hit64 = false;
-        if (v64) {
-          const unsigned long long k64 = lkeys[s0 - 16u + lane];
-          if (!priv_lookup(priv, (uint32_t)(k64 >> 32), (uint32_t)k64, hit64)) hit64 = snapshot_hit((uint32_t)(k64 >> 32), (uint32_t)k64);
+        if (!OVERLAP) {
+          if (v64) {
+            const unsigned long long k64 = lkeys[s0 - 16u + lane];
+            if (!priv_lookup(priv, (uint32_t)(k64 >> 32), (uint32_t)k64, hit64)) hit64 = snapshot_hit((uint32_t)(k64 >> 32), (uint32_t)k64);
+          }
+        } else {
+          // the shared-set entries of this round are requested, THEN the caster runs the next round (it touches LDS
+          // only), then the entries are looked at: with one such wavefront per SIMD nothing else would fill the round
+          // trip.  A round cast in vain (the ray stops in this one) costs nothing the wait would not have cost.
+          unsigned long long k64 = 0ull;
+          bool need = false;
+          if (v64) {
+            k64 = lkeys[s0 - 16u + lane];
+            need = !priv_lookup(priv, (uint32_t)(k64 >> 32), (uint32_t)k64, hit64);
+          }
+          ulonglong2 e64 = make_ulonglong2(0ull, 0ull);
+          if (need) e64 = obs_load2(observed, (uint32_t)(k64 >> 32));
+          if (s0 + 64u <= (uint32_t)steps_j) cast_round(s0 + 64u);
+          KS_WAIT_LOADS();   // (here, for all lanes: the save below then leaves without anything waiting for it)
+          if (need) hit64 = snapshot_decide(e64, (uint32_t)(k64 >> 32), (uint32_t)k64);
         }
         stop = early_out_stop(__ballot(v64 && hit64), __ballot(v64), lim, c);
         if (stop >= 0) {
@@ -487,13 +544,13 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
       if (s < visited) {
         const unsigned long long k64 = lkeys[s - 16u];
         atomicMax(&priv[(uint32_t)(k64 >> 32) & (kPrivSlots - 1u)], priv_key(gen_j, s, (uint32_t)(k64 >> 32), (uint32_t)k64));
-        atomicMax(&observed[2u * (uint32_t)(k64 >> 32)], (unsigned long long)obs_entry(F.obs_tag, pos_j, (uint32_t)k64));
+        obs_atomic_max(&observed[2u * (uint32_t)(k64 >> 32)], (unsigned long long)obs_entry(F.obs_tag, pos_j, (uint32_t)k64));
       }
     }
     if (lane == 0) cnt[pos_j] = updates | (stop >= 0 ? kCntBroke : 0u);
     if (valid && lane < visited) {
       atomicMax(&priv[(uint32_t)(k >> 32) & (kPrivSlots - 1u)], priv_key(gen_j, lane, (uint32_t)(k >> 32), (uint32_t)k));
-      atomicMax(&observed[2u * (uint32_t)(k >> 32)], (unsigned long long)obs_entry(F.obs_tag, pos_j, (uint32_t)k));
+      obs_atomic_max(&observed[2u * (uint32_t)(k >> 32)], (unsigned long long)obs_entry(F.obs_tag, pos_j, (uint32_t)k));
     }
   }
 #ifdef KS_STATS
@@ -531,12 +588,6 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
 // ray + 1, padded to 1 mod 32: the 16 owner lanes of k_prewalk write to different banks).  One wavefront per block.
 // Checked against k_test and a serial restatement of the schedule without a GPU: tools/emu/test_k_test_pre.cpp.
 // ------------------------------------------------------------------------------------------
-typedef unsigned long long obs_u64x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) unsigned long long obs_global_u64;
-typedef __attribute__((address_space(1))) obs_u64x2 obs_global_u64x2;
-__device__ __forceinline__ void obs_atomic_max(obs_global_u64* p, unsigned long long v) {   // = atomicMax, result unused
-  (void)__hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 // the shared-set mark of a private-set entry (priv_key: generation << 52 | step << 42 | slot >> 10 << 32 | hash) of chain `chain`
 __device__ __forceinline__ void priv_flush(obs_global_u64* observed, uint32_t tag, uint32_t chain, uint32_t idx, unsigned long long e) {
   const uint32_t slot = ((uint32_t)((e >> 32) & 1023ull) << 10) | idx;

@@ -47,6 +47,12 @@ __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 #ifndef KS_WAIT_VMEM
 #define KS_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #endif
+// KS_WAIT_LOADS(): the same wait as an instruction the COMPILER knows (its own bookkeeping of outstanding loads restarts
+// here; after a batch of loads consumed under divergent branches it otherwise re-waits, conservatively, before every later
+// memory operation — and a wait completes everything issued before it, atomics included).
+#ifndef KS_WAIT_LOADS
+#define KS_WAIT_LOADS() __builtin_amdgcn_s_waitcnt(0x0F70)   // vmcnt(0), lgkmcnt / expcnt untouched (gfx9 encoding)
+#endif
 // KS_VALUE_BARRIER(x): x is a value in a vector register from here on, whatever it was computed from.  (Selecting one of
 // several fields of a struct by lane number is otherwise folded into ONE load from a lane-dependent address, which
 // pins the whole struct to scratch memory: a round trip through the vector memory path where a v_cndmask would do.)

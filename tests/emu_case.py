@@ -31,6 +31,22 @@ def main():
     tot_o = tot_g = 0
     for k in range(spec.get("frames", 1)):
         f = synth.render_frame(sc, synth.trajectory_pose(5 * k), w, h, seed=40 + k)
+        if spec.get("cloud") == "axis":
+            # rays with one or two zero components seen from an unrotated sensor (crossing times inf / NaN: the serial
+            # caster of the owner lane instead of the parallel one), among ordinary ones
+            import numpy as np
+            rng = np.random.default_rng(3 + k)
+            n = w * h
+            pts = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32)
+            kind = rng.integers(0, 4, size=n)
+            pts[kind == 0, 1:] = 0
+            pts[kind == 1, 0] = 0
+            pts[kind == 2, :2] = 0
+            pts[np.linalg.norm(pts, axis=1) < 0.3] += 1.0
+            f.xyz = pts
+            f.labels = rng.integers(0, 21, size=n, dtype=np.uint8)
+            f.rgba = synth.default_label_colors()[f.labels]
+            f.T_G_C = np.array([1, 0, 0, 0, 0.3 * k, -0.2 * k, 0.025 * k], np.float32)
         so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
         sg = g.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
         tot_o += so.n_voxel_updates

@@ -65,6 +65,14 @@ def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_lib, legac
              env_extra={"KS_SUB_RUN_GENERATIONS": legacy, "KO_SUB_RUN_GENERATIONS": legacy})
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_axis_parallel_rays_under_the_early_out_equal_oracle(emu_lib, overlap):
+    """Long rays with zero components (the owner lane's serial caster inside k_test's 64-voxel rounds), with the next round
+    cast while the current round's shared-set entries are in flight (default) and one after the other (KS_TEST_OVERLAP=0)."""
+    run_case(emu_lib, dict(method=0, size=[160, 120], frames=2, max_tiles=8192, cloud="axis", cfg=dict(early_out_phase_growth=32)),
+             env_extra={"KS_TEST_OVERLAP": overlap})
+
+
 def test_staged_pair_emission_equals_oracle(emu_lib):
     """KS_EMIT_STAGE=1 (k_emit_lane<RPW, true>: a ray's first keys staged in LDS and written out by the wavefront), on a
     2 cm / 9 m geometry (long rays: owner-lane part + whole-wavefront tails) and on the default geometry with the early-out."""

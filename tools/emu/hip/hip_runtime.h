@@ -394,6 +394,7 @@ inline void launch_named(const char* name, dim3 grid, dim3 block, const std::fun
 #define __builtin_amdgcn_wave_barrier() emu::wave_sync(EMU_SITE)
 #define KS_WAVE_LDS_ORDER() emu::wave_sync(EMU_SITE)
 #define KS_WAIT_VMEM()
+#define KS_WAIT_LOADS()
 #define KS_VALUE_BARRIER(x) (void)(x)
 
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }

@@ -123,6 +123,7 @@ static BatchView view_of(const Frame& fr, State& st) {
 }
 
 static const bool g_by_generation = getenv("EMU_SUB_RUN_GENERATIONS") != nullptr;
+static const bool g_no_overlap = getenv("EMU_TEST_NO_OVERLAP") != nullptr;
 static void run_prewalk(const Frame& fr, State& st, uint32_t G, uint32_t Gpad, uint32_t cap) {
   st.pre_hash.assign((size_t)kChains * Gpad * cap, 0xdeadbeefu);
   st.pre_steps.assign((size_t)kChains * Gpad, -7);
@@ -143,7 +144,7 @@ static void run_phase_kernel(const Frame& fr, State& st, uint32_t g0, uint32_t g
 #undef LAUNCH_PRE
   } else {
     // one wavefront per block (the kernel derives its (chain, sub-run) from blockIdx and blockDim)
-    emu::launch(dim3(kChains * n_sub, 1), dim3(64), [&] { k_test(V, g0, g1, fr.steps_cap, g_by_generation ? 1u : 0u); });
+    emu::launch(dim3(kChains * n_sub, 1), dim3(64), [&] { if (g_no_overlap) k_test<false>(V, g0, g1, fr.steps_cap, g_by_generation ? 1u : 0u); else k_test<true>(V, g0, g1, fr.steps_cap, g_by_generation ? 1u : 0u); });
   }
 }
 
