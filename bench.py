@@ -367,8 +367,8 @@ def switch_records(B, torch, dev, pipeline, rings, want):
         big = swl["w"] * swl["h"] > 640 * 480
         K, R, tiles = (6, 3, 1 << 16) if big else (40, 3, 1 << 13)
 
-        def one():
-            m = measure(B, torch, None, dev, swl, ring, 2, K, R, pipeline, tiles, 1)
+        def one(pipe=pipeline):
+            m = measure(B, torch, None, dev, swl, ring, 2, K, R, pipe, tiles, 1)
             ms = [r["dt"] / K * 1e3 for r in m["regions"]]
             sp = m["stage_prof"]
             return {"ms_per_frame": round(statistics.median(ms), 4), "ms_per_frame_all_regions": [round(x, 4) for x in ms],
@@ -393,6 +393,14 @@ def switch_records(B, torch, dev, pipeline, rings, want):
                     v["error"] = f"{type(e).__name__}: {e}"
                 finally:
                     os.environ.pop(env, None)
+                rec["variants"].append(v)
+            for pipe in ((8, 0) if name == "C2" else ()):   # (not a library switch: ks_config.pipeline_frames; 8 = stage B of four frames per launch)
+                try:
+                    v = {"switch": f"pipeline_frames={pipe}", "result_must_equal_default": True}
+                    v.update(one(pipe))
+                    v["ms_over_default"] = round(v["ms_per_frame"] / base["ms_per_frame"], 4)
+                except Exception as e:
+                    v["error"] = f"{type(e).__name__}: {e}"
                 rec["variants"].append(v)
             again = one()     # the default once more, last: drift over the A/B sequence
             rec["default_again_ms_per_frame"] = again["ms_per_frame"]
