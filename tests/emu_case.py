@@ -37,7 +37,7 @@ def main():
             import numpy as np
             rng = np.random.default_rng(3 + k)
             n = w * h
-            pts = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32)
+            pts = rng.uniform(-2.5, 2.5, size=(n, 3)).astype(np.float32)
             kind = rng.integers(0, 4, size=n)
             pts[kind == 0, 1:] = 0
             pts[kind == 1, 0] = 0

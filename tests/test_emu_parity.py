@@ -69,8 +69,8 @@ def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_lib, legac
 def test_axis_parallel_rays_under_the_early_out_equal_oracle(emu_lib, overlap):
     """Long rays with zero components (the owner lane's serial caster inside k_test's 64-voxel rounds), with the next round
     cast while the current round's shared-set entries are in flight (default) and one after the other (KS_TEST_OVERLAP=0)."""
-    run_case(emu_lib, dict(method=0, size=[160, 120], frames=2, max_tiles=8192, cloud="axis", cfg=dict(early_out_phase_growth=32)),
-             env_extra={"KS_TEST_OVERLAP": overlap})
+    run_case(emu_lib, dict(method=0, size=[96, 72] if overlap == "1" else [64, 48], frames=1, max_tiles=8192, cloud="axis",
+                           cfg=dict(early_out_phase_growth=32)), env_extra={"KS_TEST_OVERLAP": overlap})
 
 
 def test_staged_pair_emission_equals_oracle(emu_lib):
