@@ -339,7 +339,8 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
   unsigned long long* lkeys = keys + 256;              // [steps_cap]          the long ray's voxels from step 16 on
   uint32_t* rinfo = (uint32_t*)(lkeys + steps_cap);    // [16] steps of the ray | [16] shared-set hit mask
   float* escr = (float*)(rinfo + 32);                  // [3 * kES] scratch of the parallel caster
-  if (C->err & (kErrLabel | kErrIndex)) return;
+  // (looked at below: this load and the live flags are in flight together; an atomic load stays where it is written)
+  const uint32_t frame_err = __hip_atomic_load(&C->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave;
   const uint32_t chain = w % kChains, sub = w / kChains;
   {  // the launch covers the slot's capacity: the frame's last generation ends the last phase
@@ -379,7 +380,7 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
     if (lane < kSubRun && lane < seen - r_lo) my_gen = rinfo[lane];
     KS_WAVE_LDS_ORDER();       // (rinfo is reused below)
   }
-  if (__ballot(my_gen != ~0u) == 0ull) return;
+  if (__ballot(my_gen != ~0u) == 0ull || (frame_err & (kErrLabel | kErrIndex))) return;
   for (uint32_t i = lane; i < kPrivSlots; i += 64) priv[i] = 0ull;  // wave-private: no block barrier needed
   const int lim = F.max_collisions;
 #ifdef KS_STATS

@@ -88,6 +88,27 @@ def test_fast_early_out_sub_runs_of_generations_exact(monkeypatch):
     assert counts["0"] != counts["1"]   # (the switch reaches both sides)
 
 
+def test_fast_early_out_rounds_one_after_the_other_exact(monkeypatch):
+    """KS_TEST_OVERLAP=0: k_test casts a long ray's next 64 voxels only after the current 64 have been decided (the code
+    measured until round 3; the default overlaps the two).  Same schedule, same result: both against the oracle, 2 cm voxels
+    and 9 m rays so that rays take many rounds."""
+    geom = dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0)
+    sc = synth.make_scene("hall")
+    frames = [synth.render_frame(sc, synth.trajectory_pose(3 * k), 320, 180, hfov_deg=75.0, seed=70 + k) for k in range(2)]
+    for overlap in ("0", "1"):
+        monkeypatch.setenv("KS_TEST_OVERLAP", overlap)
+        okw = dict(COMMON, method=0, early_out_phase_growth=32, **geom)
+        o = O.Oracle(O.default_config(**okw))
+        h = B.HipIntegrator(B.default_config(max_tiles=1 << 16, max_points=1 << 16, **okw))
+        for f in frames:
+            so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+            sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+            assert (so.n_rays_cast, so.n_voxel_updates) == (sh.n_rays_cast, sh.n_voxel_updates), overlap
+        compare_maps(o, h, exact=True)
+        h.close()
+        o.close()
+
+
 @pytest.mark.parametrize("variant", ["clear_every_3", "sorted_order", "pipelined", "subsample_1", "limit_0", "limit_5"])
 def test_fast_early_out_ordered_phases_variants_exact(variant):
     kw = dict(early_out_phase_growth=32)
