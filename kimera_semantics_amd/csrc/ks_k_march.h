@@ -381,7 +381,6 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
     KS_WAVE_LDS_ORDER();       // (rinfo is reused below)
   }
   if (__ballot(my_gen != ~0u) == 0ull || (frame_err & (kErrLabel | kErrIndex))) return;
-  for (uint32_t i = lane; i < kPrivSlots; i += 64) priv[i] = 0ull;  // wave-private: no block barrier needed
   const int lim = F.max_collisions;
 #ifdef KS_STATS
   const unsigned long long t_begin = __builtin_readcyclecounter();
@@ -425,6 +424,8 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
       kk[b] = on ? keys[r * 16 + l] : ~0ull;
       ee[b] = on ? obs_load2(observed, (uint32_t)(kk[b] >> 32)) : make_ulonglong2(0ull, 0ull);
     }
+    // the private set is cleared while those loads are in flight (wave-private: no block barrier needed; first used in C)
+    for (uint32_t i = lane; i < kPrivSlots; i += 64) priv[i] = 0ull;
     KS_WAIT_LOADS();
     bool sv4[4];
 #pragma unroll
