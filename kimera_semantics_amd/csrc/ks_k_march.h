@@ -216,8 +216,9 @@ constexpr uint32_t kCntBroke = 1u << 31;  // cnt[] flag: the ray stopped on a vo
 //   B  all 64 lanes: the shared-set entries of those <= 256 voxels, four per lane, in flight together
 //   C  the rays one after the other, 16 lanes per ray, LDS only: private-set lookup, the reference's
 //      consecutive-collision rule on the 16-bit hit mask, the ray's marks.  A ray not decided within 16
-//      voxels (the first through its corridor) is walked on by its owner lane 64 voxels at a time and
-//      tested by all 64 lanes.
+//      voxels (the first through its corridor) is cast on 64 voxels at a time by the whole wavefront (exact parallel
+//      caster) and tested by all 64 lanes; OVERLAP: the next 64 voxels are cast while the shared-set entries of
+//      the current 64 are in flight (KS_TEST_OVERLAP=0 = one after the other, the code measured until round 3).
 //   Every ray's marks (all visited voxels: the highest (position, hash) stays in a slot = the reference's last writer
 //   in serial order) enter the shared set as soon as the ray is decided, by the same wavefront, from the keys it holds
 //   in LDS — there is no second walk and no second launch per phase.
@@ -238,7 +239,7 @@ __device__ __forceinline__ ulonglong2 obs_load2(const obs_global_u64* observed, 
   return make_ulonglong2(e.x, e.y);
 }
 constexpr int kTestThreads = 256;    // 4 wavefronts per block
-constexpr uint32_t kSubRun = 16;     // generations per (chain, sub-run) wavefront
+constexpr uint32_t kSubRun = 16;     // rays per (chain, sub-run) wavefront
 #ifdef KS_STATS
 __device__ unsigned long long g_test_stats[16];  // diagnostics build only (tools/test_stats.py)
 #define KS_STAT_ADD(i, v) do { if (lane_id() == 0) atomicAdd(&g_test_stats[i], (unsigned long long)(v)); } while (0)
