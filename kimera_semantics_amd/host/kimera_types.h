@@ -17,9 +17,11 @@
 #include <kimera_semantics/semantic_voxel.h>
 #else
 
+#include <cmath>
 #include <cstdint>
 #include <fstream>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -128,9 +130,39 @@ class SemanticIntegratorBase {
   SemanticIntegratorBase(const SemanticConfig& semantic_config, vxb::Layer<SemanticVoxel>* semantic_layer)
       : semantic_config_(semantic_config), semantic_layer_(semantic_layer) {
     CHECK_NOTNULL(semantic_layer_);
+    // the cached map configuration and the measurement likelihood, as the reference's constructor leaves them
+    // (semantic_integrator_base.cpp:78-128; the GPU keeps its own copies: ks_create evaluates the same two logarithms)
+    semantic_voxel_size_ = semantic_layer_->voxel_size();
+    semantic_block_size_ = semantic_layer_->block_size();
+    semantic_voxels_per_side_ = semantic_layer_->voxels_per_side();
+    semantic_voxel_size_inv_ = 1.0 / semantic_voxel_size_;
+    semantic_block_size_inv_ = 1.0 / semantic_block_size_;
+    semantic_voxels_per_side_inv_ = 1.0 / semantic_voxels_per_side_;
+    const SemanticProbability p = semantic_config_.semantic_measurement_probability_, q = 1.0f - p;
+    CHECK(p > 0.0f && p < 1.0f && q > 0.0f && q < 1.0f);
+    log_match_probability_ = std::log(p);
+    log_non_match_probability_ = std::log(q);
+    CHECK(log_match_probability_ > log_non_match_probability_);
+    for (size_t j = 0; j < kTotalNumberOfLabels; ++j)
+      for (size_t i = 0; i < kTotalNumberOfLabels; ++i)
+        semantic_log_likelihood_(i, j) = j == 0 ? 0.0f   // the unknown label's column carries no evidence
+                                                : (i == j ? log_match_probability_ : log_non_match_probability_);
   }
   const SemanticConfig semantic_config_;
   vxb::Layer<SemanticVoxel>* semantic_layer_;
+  // (the reference's remaining public members, semantic_integrator_base.h:192-225; nothing on this path writes the
+  // temporary block map: blocks are allocated on the GPU and appear in the layer at the next sync)
+  mutable std::mutex temp_semantic_block_mutex_;
+  vxb::Layer<SemanticVoxel>::BlockHashMap temp_semantic_block_map_;
+  SemanticProbability log_match_probability_;
+  SemanticProbability log_non_match_probability_;
+  SemanticLikelihoodFunction semantic_log_likelihood_;
+  vxb::FloatingPoint semantic_voxel_size_;
+  size_t semantic_voxels_per_side_;
+  vxb::FloatingPoint semantic_block_size_;
+  vxb::FloatingPoint semantic_voxel_size_inv_;
+  vxb::FloatingPoint semantic_voxels_per_side_inv_;
+  vxb::FloatingPoint semantic_block_size_inv_;
 };
 
 }  // namespace kimera

@@ -1,5 +1,6 @@
 """Host-side logic that needs no GPU: colour-map loader quirks, synthetic frame source."""
 import numpy as np
+import pytest
 
 from kimera_semantics_amd import synth
 from kimera_semantics_amd.label_color import SemanticLabel2Color
@@ -44,3 +45,45 @@ def test_synth_is_deterministic_and_sane():
 def test_trajectory_moves_5cm_per_frame():
     p0, p1 = synth.trajectory_pose(0)[4:], synth.trajectory_pose(1)[4:]
     assert abs(np.linalg.norm(p1 - p0) - 0.05) < 1e-3
+
+
+def test_stand_in_integrator_base_exposes_the_reference_public_members(tmp_path):
+    """kimera_types.h (the build without the real Kimera headers) carries every public data member of
+    kimera::SemanticIntegratorBase (semantic_integrator_base.h:192-225), initialised as the reference's constructor
+    leaves them (semantic_integrator_base.cpp:78-128): log p / log(1 - p), the 21x21 likelihood with the unknown label's
+    column zeroed, the cached layer geometry.  Host only: nothing here touches the GPU."""
+    import math
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "base_members.cpp"
+    src.write_text(r'''
+#include "kimera_types.h"
+#include <cstdio>
+int main() {
+  voxblox::Layer<kimera::SemanticVoxel> layer(0.05f, 16u);
+  kimera::SemanticIntegratorBase::SemanticConfig cfg;
+  cfg.semantic_measurement_probability_ = 0.8f;
+  kimera::SemanticIntegratorBase b(cfg, &layer);
+  std::printf("%.9g %.9g %.9g %.9g %.9g %.9g\n", (double)b.log_match_probability_, (double)b.log_non_match_probability_,
+              (double)b.semantic_log_likelihood_(3, 3), (double)b.semantic_log_likelihood_(3, 4),
+              (double)b.semantic_log_likelihood_(0, 0), (double)b.semantic_log_likelihood_(5, 0));
+  std::printf("%.9g %zu %.9g %.9g %zu\n", (double)b.semantic_voxel_size_, b.semantic_voxels_per_side_, (double)b.semantic_block_size_,
+              (double)b.semantic_voxel_size_inv_, b.temp_semantic_block_map_.size());
+  std::lock_guard<std::mutex> lk(b.temp_semantic_block_mutex_);
+  return 0;
+}
+''')
+    exe = tmp_path / "base_members"
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "kimera_semantics_amd", "compat"),
+                        "-I", os.path.join(root, "kimera_semantics_amd", "host"), "-o", str(exe), str(src), "-pthread"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    import numpy as np
+    lm, ln = float(np.log(np.float32(0.8))), float(np.log(np.float32(1.0) - np.float32(0.8)))
+    vals = [float(x) for x in out[:6]]
+    assert vals[0] == pytest.approx(lm, abs=1e-7) and vals[1] == pytest.approx(ln, abs=1e-7)
+    assert vals[2] == vals[0] and vals[3] == vals[1] and vals[4] == 0.0 and vals[5] == 0.0
+    assert float(out[6]) == pytest.approx(0.05) and int(out[7]) == 16 and float(out[8]) == pytest.approx(0.8)
+    assert float(out[9]) == pytest.approx(20.0) and int(out[10]) == 0 and not math.isnan(vals[0])
