@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
   cfg.max_ray_length_m = 5.0f;
   cfg.integrator_threads = 1;  // (only the reference's CPU integrators read it: one thread = their deterministic order)
   if (argc > 6) cfg.max_consecutive_ray_collisions = std::atoi(argv[6]);
+  if (const char* b = std::getenv("KS_DEMO_MAX_INTEGRATION_TIME_S")) cfg.max_integration_time_s = (float)std::atof(b);  // (tests)
   kimera::SemanticIntegratorBase::SemanticConfig sc;
   sc.semantic_measurement_probability_ = 0.8f;
   sc.color_mode = static_cast<kimera::ColorMode>(argc > 5 ? std::atoi(argv[5]) : 1);

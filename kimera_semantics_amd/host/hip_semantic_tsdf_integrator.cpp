@@ -131,7 +131,11 @@ void HipSemanticTsdfIntegrator::integratePointCloud(const vxb::Transformation& T
     check(ks_integrate_points(ctx_, T, xyz, nullptr, labels.data(), points_C.size(), freespace_points, &last_stats_),
           "ks_integrate_points");
   } else {
-    check(ks_integrate_points(ctx_, T, xyz, rgba, nullptr, points_C.size(), freespace_points, &last_stats_),
+    // Config::max_integration_time_s [K:src/semantic_tsdf_integrator_fast.cpp:66-70] is a wall-clock budget a 0.3 ms GPU frame never
+    // reaches; its one deterministic case is kept: a budget <= 0 lets no point into the fast integrator's loop (the
+    // frame-level bookkeeping of the sets still happens: a call with zero points)
+    const bool no_budget = method_ == Method::kFast && !(config_.max_integration_time_s > 0.0f);
+    check(ks_integrate_points(ctx_, T, xyz, rgba, nullptr, no_budget ? 0 : points_C.size(), freespace_points, &last_stats_),
           "ks_integrate_points");
   }
   merged_timer.Stop();
@@ -153,7 +157,9 @@ void HipSemanticTsdfIntegrator::integratePointCloud(const vxb::Transformation& T
   vxb::timing::Timer integrate_timer("integrate/semantic_merged");
   check(ks_integrate_points(ctx_, T, points_C.empty() ? nullptr : reinterpret_cast<const float*>(points_C.data()),
                             colors.empty() ? nullptr : reinterpret_cast<const uint8_t*>(colors.data()),
-                            semantic_labels.data(), points_C.size(), freespace_points, &last_stats_),
+                            semantic_labels.data(),
+                            (method_ == Method::kFast && !(config_.max_integration_time_s > 0.0f)) ? 0 : points_C.size(),  // (budget <= 0: see above)
+                            freespace_points, &last_stats_),
         "ks_integrate_points");
   integrate_timer.Stop();
   if (options_.sync_policy == SyncPolicy::kEveryFrame) {

@@ -78,6 +78,26 @@ def test_adapter_matches_oracle(tmp_path, method, color_mode):
     assert np.array_equal(s["color"], os_["color"])
 
 
+def test_adapter_zero_integration_time_budget(tmp_path):
+    """Config::max_integration_time_s <= 0: the reference's fast loop takes no point at all
+    (semantic_tsdf_integrator_fast.cpp:66-70: elapsed < budget is false from the start); `merged` never reads the field."""
+    if not os.path.exists(DEMO):
+        pytest.fail("adapter_demo not built: run __graft_entry__.build()")
+    frames = _frames()
+    csv, fin, fout = str(tmp_path / "labels.csv"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    R.write_label_csv(csv, synth.default_label_colors())
+    _write_in(fin, frames)
+    env = dict(os.environ, KS_DEMO_MAX_INTEGRATION_TIME_S="0")
+    res = subprocess.run([DEMO, "fast", csv, fin, fout, "1", str(NO_EARLY_OUT)], capture_output=True, text=True, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    idx, _, _ = _read_out(fout)
+    assert len(idx) == 0
+    res = subprocess.run([DEMO, "merged", csv, fin, fout, "1", str(NO_EARLY_OUT)], capture_output=True, text=True, env=env)
+    assert res.returncode == 0, res.stdout + res.stderr
+    idx, _, _ = _read_out(fout)
+    assert len(idx) > 0
+
+
 @pytest.mark.parametrize("method", ["fast", "merged"])
 def test_adapter_resumes_from_host_layers(tmp_path, method):
     """A new integrator constructed on non-empty Layers (TsdfServer::loadMap, or a re-created
