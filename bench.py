@@ -367,8 +367,8 @@ def switch_records(B, torch, dev, pipeline, rings, want):
         big = swl["w"] * swl["h"] > 640 * 480
         K, R, tiles = (6, 3, 1 << 16) if big else (40, 3, 1 << 13)
 
-        def one(pipe=pipeline):
-            m = measure(B, torch, None, dev, swl, ring, 2, K, R, pipe, tiles, 1)
+        def one(pipe=pipeline, **cfg):
+            m = measure(B, torch, None, dev, swl, ring, 2, K, R, pipe, tiles, 1, **cfg)
             ms = [r["dt"] / K * 1e3 for r in m["regions"]]
             sp = m["stage_prof"]
             return {"ms_per_frame": round(statistics.median(ms), 4), "ms_per_frame_all_regions": [round(x, 4) for x in ms],
@@ -398,6 +398,15 @@ def switch_records(B, torch, dev, pipeline, rings, want):
                 try:
                     v = {"switch": f"pipeline_frames={pipe}", "result_must_equal_default": True}
                     v.update(one(pipe))
+                    v["ms_over_default"] = round(v["ms_per_frame"] / base["ms_per_frame"], 4)
+                except Exception as e:
+                    v["error"] = f"{type(e).__name__}: {e}"
+                rec["variants"].append(v)
+            for growth in ((24, 48) if swl["method"] == "fast" else ()):   # ks_config.early_out_phase_growth / 16 = 1.5, 3 (default 2): other schedules, other (deterministic) results
+                try:
+                    v = {"switch": f"early_out_phase_growth={growth}", "result_must_equal_default": False}
+                    v.update(one(early_out_phase_growth=growth))
+                    v["updates_2_frames"] = map_digest(B, dev, swl, probe, tiles, early_out_phase_growth=growth)[1]
                     v["ms_over_default"] = round(v["ms_per_frame"] / base["ms_per_frame"], 4)
                 except Exception as e:
                     v["error"] = f"{type(e).__name__}: {e}"
