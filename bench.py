@@ -351,11 +351,11 @@ def switch_records(B, torch, dev, pipeline, rings, want):
     hardware, back to back with the default build of the same context: the record a default is chosen from.  Every
     variant also integrates two frames into a fresh map whose digest is compared with the default's: switches that
     must not change the result (KS_TEST_OVERLAP, KS_TEST_PRE, KS_EMIT_STAGE) say so, on this GPU; KS_SUB_RUN_GENERATIONS=1 is the early-out
-    schedule benched until round 3 (another, equally deterministic, result: tests/test_parity_gpu.py pins both)."""
+    schedule benched until round 3, KS_SUB_RUN_RAYS=8 sub-runs half as long (another, equally deterministic, result: tests/test_parity_gpu.py pins both)."""
     plan = {
-        "C2": (("KS_SUB_RUN_GENERATIONS", "1", False), ("KS_TEST_OVERLAP", "0", True), ("KS_TEST_PRE", "1", True), ("KS_TEST_PRE", "7", True),
+        "C2": (("KS_SUB_RUN_GENERATIONS", "1", False), ("KS_SUB_RUN_RAYS", "8", False), ("KS_TEST_OVERLAP", "0", True), ("KS_TEST_PRE", "1", True), ("KS_TEST_PRE", "7", True),
                ("KS_EMIT_STAGE", "1", True)),
-        "C4-fast": (("KS_SUB_RUN_GENERATIONS", "1", False), ("KS_TEST_OVERLAP", "0", True), ("KS_EMIT_STAGE", "1", True)),
+        "C4-fast": (("KS_SUB_RUN_GENERATIONS", "1", False), ("KS_SUB_RUN_RAYS", "8", False), ("KS_TEST_OVERLAP", "0", True), ("KS_EMIT_STAGE", "1", True)),
         "C4-merged": (("KS_EMIT_STAGE", "1", True),),
     }
     out = []

@@ -191,6 +191,7 @@ struct ks_ctx {
   int test_pre_flags = 0;                // KS_TEST_PRE as given (bits 1, 2: variants, see enqueue_stage_b)
   bool emit_stage = false;               // k_emit_lane stages a ray's first keys in LDS (KS_EMIT_STAGE=1; ks_k_march.h)
   bool test_overlap = true;              // k_test casts a long ray's next 64 voxels while the shared-set entries of the current 64 are in flight (KS_TEST_OVERLAP=0: one after the other, as measured until round 3)
+  uint32_t sub_rays = kSubRun;           // rays per early-out sub-run (KS_SUB_RUN_RAYS = 1..16, experiments: the CPU checker follows with KO_EXP_SUB_RUN)
   bool sub_run_generations = false;      // early-out sub-runs of 16 generations instead of 16 live rays (KS_SUB_RUN_GENERATIONS=1: A/B runs; ks_k_march.h)
   uint64_t buffers_epoch = 1;            // bumped whenever a buffer a captured graph points at is re-allocated
   uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
@@ -656,7 +657,7 @@ void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipS
       hipLaunchKernelGGL(k_prewalk, dim3(kChains * (P.Gpad / kSubRun), nb), dim3(64), prewalk_lds_bytes(P.cap), sm, V, P.G, P.Gpad, P.cap);
     for (size_t j = 0; j < B.size(); ++j) {
       const uint32_t g0 = B[j], g1 = (j + 1 < B.size()) ? B[j + 1] : n_gen;  // k_test ends the frame's last phase at ITS n
-      const uint32_t n_sub = (g1 - g0 + kSubRun - 1) / kSubRun;  // wavefronts per chain
+      const uint32_t n_sub = (g1 - g0 + c->sub_rays - 1) / c->sub_rays;  // wavefronts per chain (worst case: every ray live)
       const uint32_t steps_cap = (uint32_t)((steps_max + 3) & ~(size_t)3);
       const size_t lds_wave = (size_t)test_lds_words64(steps_cap) * sizeof(unsigned long long);
       const uint32_t wpb = lds_wave * 4 <= 60 * 1024 ? 4u : lds_wave * 2 <= 60 * 1024 ? 2u : 1u;  // wavefronts per block
@@ -678,8 +679,8 @@ void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipS
       {
         const dim3 grid(kChains * n_sub / wpb, nb), block(64 * wpb);
         const uint32_t by_gen = c->sub_run_generations ? 1u : 0u;
-        if (c->test_overlap) hipLaunchKernelGGL(k_test<true>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap, by_gen);
-        else hipLaunchKernelGGL(k_test<false>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap, by_gen);
+        if (c->test_overlap) hipLaunchKernelGGL(k_test<true>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap, by_gen, c->sub_rays);
+        else hipLaunchKernelGGL(k_test<false>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap, by_gen, c->sub_rays);
       }
     }
   }
@@ -1581,9 +1582,13 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   // the CPU checker follows with KO_SUB_RUN_GENERATIONS=1)
   if (const char* sg = getenv("KS_SUB_RUN_GENERATIONS")) c->sub_run_generations = atoi(sg) != 0;
   if (const char* ov = getenv("KS_TEST_OVERLAP")) c->test_overlap = atoi(ov) != 0;
+  if (const char* sr = getenv("KS_SUB_RUN_RAYS")) {
+    c->sub_rays = (uint32_t)std::min(16, std::max(1, atoi(sr)));
+    if (c->sub_rays != kSubRun) c->test_pre = false;   // (k_prewalk / k_test_pre are written for sub-runs of 16)
+  }
   if (const char* tp = getenv("KS_TEST_PRE")) {
     c->test_pre_flags = atoi(tp);
-    c->test_pre = (c->test_pre_flags & 1) != 0;
+    c->test_pre = (c->test_pre_flags & 1) != 0 && c->sub_rays == kSubRun;
   }
   if (c->cfg.pipeline_frames >= 2 && frames_independent && !c->exact_early_out && c->cfg.integration_order_mode != KS_ORDER_SORTED) {
     // (measured, 640x480: a batch of 4 behind 8 frames of lag ~ four single-frame sequences on four streams behind 4

@@ -300,7 +300,7 @@ __device__ __forceinline__ bool priv_lookup(const unsigned long long* priv, uint
 __host__ __device__ inline uint32_t test_lds_words64(uint32_t steps_cap) { return kPrivSlots + 256u + steps_cap + 16u + (3u * kES + 1u) / 2u; }
 
 template <bool OVERLAP>
-__global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0, uint32_t g1, uint32_t steps_cap, uint32_t by_generation) {
+__global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0, uint32_t g1, uint32_t steps_cap, uint32_t by_generation, uint32_t sub_rays) {
   // stage B kernels read the frame's parameters from device memory: the launch sequence of a frame slot is
   // then identical from frame to frame and is replayed as a captured graph
   const SlotView& sv = V.s[blockIdx.y];
@@ -351,14 +351,14 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
   // ---- which rays: my_gen = generation of the ray lane l < 16 owns (~0u: none) ----
   uint32_t my_gen = ~0u;
   if (by_generation) {
-    const uint32_t g = g0 + sub * kSubRun + lane;
-    if (lane < kSubRun && g < g1 && (uint64_t)g * kChains + chain < F.n && live[(uint64_t)g * kChains + chain] != 0) my_gen = g;
+    const uint32_t g = g0 + sub * sub_rays + lane;
+    if (lane < sub_rays && g < g0 + (sub + 1u) * sub_rays && g < g1 && (uint64_t)g * kChains + chain < F.n && live[(uint64_t)g * kChains + chain] != 0) my_gen = g;
   } else {
     // rank of every live ray of the chain within the phase; ranks [16 sub, 16 sub + 16) are this wavefront's.  Four
     // ballots' worth of flags are in flight at a time (a late phase of a 640x480 frame is 128 generations long).
-    const uint32_t r_lo = sub * kSubRun;
+    const uint32_t r_lo = sub * sub_rays;   // sub_rays <= 16: rays (or generations) per sub-run, 16 unless an experiment says otherwise
     uint32_t seen = 0;
-    for (uint32_t gb = g0; gb < g1 && seen < r_lo + kSubRun; gb += 256u) {
+    for (uint32_t gb = g0; gb < g1 && seen < r_lo + sub_rays; gb += 256u) {
       uint8_t fl[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -372,13 +372,13 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
       for (int q = 0; q < 4; ++q) {
         const unsigned long long m = __ballot(fl[q] != 0);
         const uint32_t rank = seen + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (fl[q] != 0 && rank >= r_lo && rank < r_lo + kSubRun) rinfo[rank - r_lo] = gb + 64u * (uint32_t)q + lane;
+        if (fl[q] != 0 && rank >= r_lo && rank < r_lo + sub_rays) rinfo[rank - r_lo] = gb + 64u * (uint32_t)q + lane;
         seen += (uint32_t)__popcll(m);
       }
     }
     if (seen <= r_lo) return;  // the chain has no 16 * sub + 1 live rays in this phase
     KS_WAVE_LDS_ORDER();
-    if (lane < kSubRun && lane < seen - r_lo) my_gen = rinfo[lane];
+    if (lane < sub_rays && lane < seen - r_lo) my_gen = rinfo[lane];
     KS_WAVE_LDS_ORDER();       // (rinfo is reused below)
   }
   if (__ballot(my_gen != ~0u) == 0ull || (frame_err & (kErrLabel | kErrIndex))) return;

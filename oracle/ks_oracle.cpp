@@ -682,7 +682,7 @@ struct ko_ctx {
         const uint32_t chain = r.pos % kChains, gen = r.pos / kChains;
         uint64_t* pv = &priv[(size_t)chain * kPrivSlots];
         // (KO_EXP_SUB_RUN: schedule research only — the GPU's sub-runs are kSubRun rays long)
-        static const uint32_t sub_run = getenv("KO_EXP_SUB_RUN") ? (uint32_t)strtoul(getenv("KO_EXP_SUB_RUN"), nullptr, 10) : kSubRun;
+        const uint32_t sub_run = getenv("KO_EXP_SUB_RUN") ? (uint32_t)strtoul(getenv("KO_EXP_SUB_RUN"), nullptr, 10) : kSubRun;   // (read per ray: tests switch it)
         const uint32_t sub = sub_run_generations ? (gen - B[j]) / sub_run : live_seen[chain]++ / sub_run;
         if (sub != priv_sub[chain]) {  // a new sub-run starts with an empty private set
           std::fill(pv, pv + kPrivSlots, 0ull);

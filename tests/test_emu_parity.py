@@ -57,6 +57,12 @@ def test_prewalk_variant_of_the_leading_phases_equals_oracle(emu_lib):
     run_case(emu_lib, dict(method=0, size=[256, 160], frames=1, cfg=dict(early_out_phase_growth=32)), env_extra={"KS_TEST_PRE": "1"})
 
 
+def test_sub_runs_of_eight_rays_equal_oracle(emu_lib):
+    """KS_SUB_RUN_RAYS / KO_EXP_SUB_RUN = 8: the experiment knob for the length of a sub-run (bench.py times it against 16)."""
+    run_case(emu_lib, dict(method=0, size=[256, 160], frames=1, max_tiles=8192, cfg=dict(early_out_phase_growth=32)),
+             env_extra={"KS_SUB_RUN_RAYS": "8", "KO_EXP_SUB_RUN": "8"})
+
+
 @pytest.mark.parametrize("legacy", ["0", "1"])
 def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_lib, legacy):
     """320x240 = 75 generations: the phases [32, 64) and [64, 75) have up to two sub-runs per chain, cut over the chain's LIVE

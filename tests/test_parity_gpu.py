@@ -73,9 +73,11 @@ def test_fast_early_out_sub_runs_of_generations_exact(monkeypatch):
     sc = synth.make_scene("room")
     frames = [synth.render_frame(sc, synth.trajectory_pose(5 * k), 640, 480, seed=30 + k) for k in range(2)]
     counts = {}
-    for legacy in ("1", "0"):
-        monkeypatch.setenv("KS_SUB_RUN_GENERATIONS", legacy)
-        monkeypatch.setenv("KO_SUB_RUN_GENERATIONS", legacy)
+    for legacy in ("1", "0", "0/8"):   # "0/8": sub-runs of 8 live rays (KS_SUB_RUN_RAYS / KO_EXP_SUB_RUN: the other A/B knob of bench.py)
+        monkeypatch.setenv("KS_SUB_RUN_GENERATIONS", legacy[0])
+        monkeypatch.setenv("KO_SUB_RUN_GENERATIONS", legacy[0])
+        monkeypatch.setenv("KS_SUB_RUN_RAYS", legacy[2:] or "16")
+        monkeypatch.setenv("KO_EXP_SUB_RUN", legacy[2:] or "16")
         o, h = _pair(0, early_out_phase_growth=32)
         for k, f in enumerate(frames):
             so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
@@ -85,7 +87,7 @@ def test_fast_early_out_sub_runs_of_generations_exact(monkeypatch):
         compare_maps(o, h, exact=True)
         h.close()
         o.close()
-    assert counts["0"] != counts["1"]   # (the switch reaches both sides)
+    assert counts["0"] != counts["1"] and counts["0"] != counts["0/8"]   # (the switches reach both sides)
 
 
 def test_fast_early_out_rounds_one_after_the_other_exact(monkeypatch):

@@ -144,7 +144,7 @@ static void run_phase_kernel(const Frame& fr, State& st, uint32_t g0, uint32_t g
 #undef LAUNCH_PRE
   } else {
     // one wavefront per block (the kernel derives its (chain, sub-run) from blockIdx and blockDim)
-    emu::launch(dim3(kChains * n_sub, 1), dim3(64), [&] { if (g_no_overlap) k_test<false>(V, g0, g1, fr.steps_cap, g_by_generation ? 1u : 0u); else k_test<true>(V, g0, g1, fr.steps_cap, g_by_generation ? 1u : 0u); });
+    emu::launch(dim3(kChains * n_sub, 1), dim3(64), [&] { if (g_no_overlap) k_test<false>(V, g0, g1, fr.steps_cap, g_by_generation ? 1u : 0u, kSubRun); else k_test<true>(V, g0, g1, fr.steps_cap, g_by_generation ? 1u : 0u, kSubRun); });
   }
 }
 
