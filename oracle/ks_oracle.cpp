@@ -12,6 +12,7 @@
 #include "ks_oracle.h"
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -666,6 +667,8 @@ struct ko_ctx {
     std::vector<uint64_t> priv((size_t)kChains * kPrivSlots);
     std::vector<uint32_t> priv_sub(kChains);  // sub-run the chain's private set currently belongs to
     std::vector<uint32_t> live_seen(kChains);  // live rays of the chain the phase has handled so far
+    const bool wave_stats = getenv("KO_WAVE_STATS") != nullptr;   // schedule research: per phase, the work of the (chain, sub-run) wavefronts -> stderr
+    std::unordered_map<uint64_t, std::array<uint64_t, 3>> wave_work;
     const bool sub_run_generations = getenv("KO_SUB_RUN_GENERATIONS") && atoi(getenv("KO_SUB_RUN_GENERATIONS")) != 0;  // (read per frame: tests switch it)
     std::vector<std::pair<uint32_t, uint64_t>> own;
     size_t r0 = 0;
@@ -712,6 +715,25 @@ struct ko_ctx {
           ++r.cnt;
         }
         for (const auto& o : own) pv[o.first] = std::max(pv[o.first], o.second);
+        if (wave_stats) {  // schedule research (KO_WAVE_STATS=1): what the (chain, sub-run) wavefront of this ray has to do
+          auto& w = wave_work[((uint64_t)chain << 32) | sub];
+          w[0] += 1;                                               // rays
+          if (step > 16) { w[1] += 1; w[2] += (step - 16 + 63) / 64; }   // rays past their first 16 voxels, their 64-voxel rounds
+        }
+      }
+      if (wave_stats) {
+        uint64_t rays_max = 0, rounds = 0, rounds_max = 0, longs = 0, cost_max = 0;
+        for (const auto& kv : wave_work) {
+          rays_max = std::max(rays_max, kv.second[0]);
+          longs += kv.second[1];
+          rounds += kv.second[2];
+          rounds_max = std::max(rounds_max, kv.second[2]);
+          cost_max = std::max(cost_max, 30 + 4 * kv.second[0] + 15 * kv.second[2]);   // ~0.1 us units: fixed + per ray + per round
+        }
+        fprintf(stderr, "KO_WAVE_STATS phase [%u,%u): wavefronts with work %zu, rays %zu (max %llu per wavefront), long rays %llu, rounds %llu (max %llu per wavefront), "
+                "slowest wavefront ~%.1f us (model: 3 + 0.4/ray + 1.5/round)\n", B[j], (j + 1 < B.size()) ? B[j + 1] : n_gen, wave_work.size(), r1 - r0,
+                (unsigned long long)rays_max, (unsigned long long)longs, (unsigned long long)rounds, (unsigned long long)rounds_max, cost_max / 10.0);
+        wave_work.clear();
       }
       // the phase's marks enter the shared set: per slot the highest (position, hash)
       std::sort(marks.begin(), marks.end(), [](const Mark& a, const Mark& b) {
