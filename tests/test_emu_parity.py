@@ -67,7 +67,7 @@ def test_sub_runs_of_eight_rays_equal_oracle(emu_lib):
 def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_lib, legacy):
     """320x240 = 75 generations: the phases [32, 64) and [64, 75) have up to two sub-runs per chain, cut over the chain's LIVE
     rays (default) or over its generations (the schedule until round 3, kept switchable on both sides for A/B runs)."""
-    run_case(emu_lib, dict(method=0, size=[320, 240], frames=2, max_tiles=8192, cfg=dict(early_out_phase_growth=32)),
+    run_case(emu_lib, dict(method=0, size=[320, 240], frames=2 if legacy == "0" else 1, max_tiles=8192, cfg=dict(early_out_phase_growth=32)),
              env_extra={"KS_SUB_RUN_GENERATIONS": legacy, "KO_SUB_RUN_GENERATIONS": legacy})
 
 
