@@ -192,6 +192,29 @@ def test_fast_early_out_c4_geometry():
     compare_maps(o2, h2, exact=True)
 
 
+def test_full_size_c4_default_early_out_exact():
+    """One FULL-SIZE C4 frame (1280x720, 2 cm voxels, 10 m rays) through the DEFAULT fast configuration: 900 generations, the last
+    phase 388 generations long — k_test ranks a chain's live rays over more than one window of 256 generations, up to 25 sub-runs
+    per chain are launched.  Update and ray counts, the allocated block set, and every voxel of a sample of 600 blocks against the
+    restated schedule (the whole map is 3 GB of host layout)."""
+    geom = dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=10.0)
+    f = synth.render_frame(synth.make_scene("hall"), synth.trajectory_pose(3, radius=3.0), 1280, 720, hfov_deg=75.0, seed=3)
+    okw = dict(COMMON, method=0, early_out_phase_growth=32, **geom)
+    o = O.Oracle(O.default_config(**okw))
+    h = B.HipIntegrator(B.default_config(max_tiles=1 << 16, max_points=1280 * 720, **okw))
+    so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    assert (so.n_valid_points, so.n_rays_cast, so.n_voxel_updates) == (sh.n_valid_points, sh.n_rays_cast, sh.n_voxel_updates)
+    oi, hi = o.block_indices(), h.block_indices()
+    assert np.array_equal(oi, hi)
+    sample = np.ascontiguousarray(oi[:: max(1, len(oi) // 600)])
+    _, ot, osem = o.download(sample)
+    _, ht, hsem = h.download(sample)
+    assert (ot["weight"] > 0).sum() > 1e5
+    for a, b in ((ot, ht), (osem, hsem)):
+        assert a.tobytes() == b.tobytes()
+
+
 def test_observed_set_tag_wrap():
     """The early-out set's entries carry a 10-bit frame tag; every ~1000 frames the stale entries are retired
     and the tags restart.  1100 small frames stay bit-exact against the oracle."""
