@@ -1,0 +1,44 @@
+"""CPU tier: properties of the gfx950 code hipcc generates for the kernels (no GPU: `--cuda-device-only -S`).  What
+is pinned here was found by reading that code, costs time on the GPU when it comes back, and is invisible to every parity test:
+  * no kernel keeps anything in scratch memory (selecting a struct field by lane number once pinned the ray caster's
+    state there: a memory round trip per 64-voxel round in seven kernels, ks_types.h KS_VALUE_BARRIER);
+  * k_test reaches the shared set of the early-out with GLOBAL instructions only (FLAT loads count as LDS operations too:
+    every LDS wait of the caster then waits for the set's entries in flight, ks_k_march.h obs_global_u64)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "kimera_semantics_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not found")
+    out = str(tmp_path_factory.mktemp("isa") / "ks_hip.s")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]   # = csrc/Makefile
+    r = subprocess.run(["hipcc", *flags, "--cuda-device-only", "-S", "-o", out, "ks_hip.hip"], cwd=CSRC, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return open(out).read()
+
+
+def test_no_kernel_uses_scratch_memory(asm):
+    per_kernel = re.findall(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)", asm)
+    assert len(per_kernel) > 50
+    bad = {k: int(v) for k, v in per_kernel if int(v) != 0}
+    assert not bad, bad
+    assert "scratch_load" not in asm and "scratch_store" not in asm
+
+
+def test_k_test_reaches_the_shared_set_with_global_instructions(asm):
+    bodies = re.findall(r"^(_ZN3ksk6k_testILb[01]EE\w+):[^\n]*\n(.*?)^\.Lfunc_end", asm, re.S | re.M)
+    assert len(bodies) == 2
+    for name, body in bodies:
+        assert "flat_atomic" not in body and "flat_load_dwordx4" not in body and "flat_store" not in body, name
+        assert body.count("global_atomic_umax_x2") >= 4, name     # the saves of phase B + the marks
+        # (the one FLAT load left reads the integration order of the sorted mode through a pointer kept in FrameParams)
+        assert len(re.findall(r"\bflat_load", body)) <= 1, name
