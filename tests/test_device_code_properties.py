@@ -42,3 +42,18 @@ def test_k_test_reaches_the_shared_set_with_global_instructions(asm):
         assert body.count("global_atomic_umax_x2") >= 4, name     # the saves of phase B + the marks
         # (the one FLAT load left reads the integration order of the sorted mode through a pointer kept in FrameParams)
         assert len(re.findall(r"\bflat_load", body)) <= 1, name
+
+
+def test_k_test_casts_the_next_round_while_the_look_ups_are_in_flight(asm):
+    """k_test<OVERLAP = true>: between the request for a round's shared-set entries (the last 16-byte load of the kernel) and the
+    wait for them lies the ray caster's accumulation of the NEXT round (its 65 crossing times go to LDS two at a time) — the
+    compiler has neither sunk the load nor hoisted the wait.  k_test<false> waits right after the request."""
+    for overlap, want in (("1", True), ("0", False)):
+        m = re.search(r"^_ZN3ksk6k_testILb" + overlap + r"EE\w+:[^\n]*\n(.*?)^\.Lfunc_end", asm, re.S | re.M)
+        lines = m.group(1).split("\n")
+        loads = [i for i, l in enumerate(lines) if "global_load_dwordx4" in l]
+        assert len(loads) >= 5        # four of phase B, one per round of a long ray
+        after = lines[loads[-1] + 1:]
+        wait = next(i for i, l in enumerate(after) if "s_waitcnt" in l and "vmcnt(0)" in l)
+        caster = sum("ds_write2_b32" in l for l in after[:wait])
+        assert (caster >= 5) == want, (overlap, caster, wait)
