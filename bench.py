@@ -173,6 +173,8 @@ def cpu_baseline(args, wl, frames, upd_serial):
     return {"value": round(tried[best][0], 4), "unit": "Mvoxel-updates/s", "cores": best, "kind": kind,
             "frames_per_s": round(tried[best][1], 3), "host_cores": cores, "spread": round(tried[best][2], 4),
             "by_threads": {str(t): round(v[0], 4) for t, v in tried.items()},
+            # the reference's own default is integrator_threads = hardware_concurrency() (all cores); the best count is the reported baseline
+            "reference_default_all_cores_value": round(tried[cores][0], 4),
             "sample": f"first {n} timed frames of the same trajectory through {what}, 'mixed' order, reference defaults; "
                       f"per thread count 1 warm-up + 5 timed passes (fresh integrator each), median; best of "
                       f"integrator_threads in {sorted(tried)}"
@@ -558,7 +560,7 @@ def adapter_record(wl_frames):
     return out
 
 
-def c5_record(B, torch, dist, dev, rank, world, comm):
+def c5_record(B, torch, dist, dev, rank, world, comm, ddev=None):
     """BASELINE.json configs[4]: a batch of 8 overlapping 640x480 frames (arc poses looking at the same wall),
     frame-sharded over the ranks, ONE ks_reduce of the dirty tiles to their owner ranks inside the timed
     region; the owner-sharded result is compared with the same frames integrated sequentially on one GPU
@@ -598,8 +600,8 @@ def c5_record(B, torch, dist, dev, rank, world, comm):
     touched = st["weight"] > 0
     agg = torch.tensor([float(touched.sum()), float(((hs["label"] == ss["label"]) & touched).sum()),
                         float(np.abs(ht["distance"] - st["distance"])[touched].sum()), float(upd), dt,
-                        float(rstats["tiles_sent"]), float(rstats["bytes_sent"])], device=dev, dtype=torch.float64)
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+                        float(rstats["tiles_sent"]), float(rstats["bytes_sent"])], device=ddev or dev, dtype=torch.float64)
+    tmax = torch.tensor([dt], device=ddev or dev, dtype=torch.float64)
     dist.all_reduce(agg, op=dist.ReduceOp.SUM)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     h.close()
@@ -615,9 +617,99 @@ def c5_record(B, torch, dist, dev, rank, world, comm):
                                    "mean_abs_distance_diff": a[2] / max(1.0, a[0])}}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher around it: re-executes itself under torch.distributed.run with N
+    ranks on this node (one per GPU, RCCL) and passes the children's stdout (rank 0's JSON line) through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), KS_BENCH_LAUNCHED="1")
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+def mapped_library():
+    """The libks_hip.so this process has actually mapped (from /proc/self/maps)."""
+    try:
+        for ln in open("/proc/self/maps"):
+            if "libks_hip" in ln:
+                return ln.split()[-1]
+    except OSError:
+        pass
+    return None
+
+
+LINE_LIMIT = 4000   # bytes of the ONE stdout line; everything else goes to the full record (profiles/bench_full_r04.json)
+
+
+def compact_line(out, full_path):
+    """The ONE line printed to stdout: the contract's fields + roofline + cpu_baseline + fidelity, <= LINE_LIMIT bytes.
+    `out` is the full record (written to `full_path`).  Pure function of its arguments (tests/test_host_logic.py)."""
+    def pick(d, keys):
+        return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+    rf = out.get("roofline") or {}
+    line = pick(out, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                      "vs_baseline", "dtype", "data", "frames_per_s", "gpu_counted_value"])
+    cfg = out.get("config") or {}
+    line["config"] = pick(cfg, ["workload", "early_out", "pipeline_frames", "parallelism", "points_per_frame", "rays_per_frame",
+                                "updates_per_frame"])
+    line["roofline"] = pick(rf, ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "dominant_stage"])
+    if "k_apply" in rf:
+        line["roofline"]["k_apply"] = pick(rf["k_apply"], ["achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch"])
+    if "stages" in rf:
+        line["roofline"]["stage_ms"] = {k: v.get("ms_per_frame") for k, v in rf["stages"].items()}
+    if "timing" in out:
+        line["spread"] = out["timing"].get("spread_max_minus_min_over_median")
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = pick(out["cpu_baseline"], ["value", "unit", "cores", "kind", "host_cores", "frames_per_s",
+                                                          "reference_default_all_cores_value", "by_threads", "sample"])
+    if "early_out_fidelity" in out:
+        line["early_out_fidelity"] = pick(out["early_out_fidelity"], ["frames", "touched_jaccard", "label_agreement_common_voxels",
+                                                                      "updates_gpu_over_serial", "bit_exact_vs_serial_reference", "error"])
+    if "reduce" in out:
+        line["reduce"] = out["reduce"]
+    sec = []
+    for r in out.get("secondary", []):
+        if not isinstance(r, dict):
+            continue
+        e = pick(r, ["config", "value", "ms_per_step", "error", "batch_ms", "frames", "skipped"])
+        if isinstance(r.get("roofline"), dict):
+            e["frac"] = r["roofline"].get("frac")
+        if r.get("config") == "adapter":
+            e.update({k: v for k, v in r.items() if k.endswith("_ms_per_frame")})
+        if r.get("config") == "C5":
+            e.update(pick(r, ["reduce", "gpu_counted_value"]))
+        if str(r.get("config", "")).endswith("-switches"):
+            e = {"config": r["config"], "default_ms": (r.get("default") or {}).get("ms_per_frame"),
+                 "variants": {v.get("switch"): v.get("ms_over_default", v.get("error")) for v in r.get("variants", [])}}
+        sec.append(e)
+    if sec:
+        line["secondary"] = sec
+    line["library"] = out.get("library")
+    line["full_record"] = full_path
+    # never longer than the limit: optional parts go first
+    for drop in (("secondary",), ("roofline", "stage_ms"), ("cpu_baseline", "sample"), ("cpu_baseline", "by_threads"),
+                 ("config", "early_out"), ("early_out_fidelity",), ("config", "parallelism")):
+        if len(json.dumps(line)) <= LINE_LIMIT:
+            break
+        d = line
+        for k in drop[:-1]:
+            d = d.get(k, {})
+        d.pop(drop[-1], None)
+    return json.dumps(line)
+
+
 def main():
     t_start = time.time()
     args = parse()
+    if os.environ.get("KS_HIP_LIB"):
+        raise SystemExit("bench.py measures the in-tree kimera_semantics_amd/libks_hip.so only: unset KS_HIP_LIB "
+                         f"(= {os.environ['KS_HIP_LIB']})")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
     # stdout carries exactly ONE line, the JSON record: libraries that print to the C stdout (RCCL's version
     # banner, flushed at exit) are sent to stderr for the rest of the process
     sys.stdout.flush()
@@ -630,16 +722,29 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: the launcher and --gpus disagree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # KS_BENCH_SHARED_GPU=1 (tests only: a development box has ONE GPU): every rank uses cuda:0, torch.distributed runs
+    # over gloo on host tensors, and ks_reduce's communicator is whatever KS_RCCL_LIB names (the test double
+    # tests/mock_rccl: RCCL itself refuses two ranks on one device)
+    shared_gpu = os.environ.get("KS_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    ddev = torch.device("cpu") if shared_gpu else dev   # where tensors of torch.distributed collectives live
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+        assert dist.get_world_size() == args.gpus
 
     if args.switches_child:
-        pipeline = int(os.environ.get("KS_BENCH_PIPE", "4"))
+        pipeline = int(os.environ.get("KS_BENCH_PIPE", "8"))
         import pickle
         with open(args.switches_child, "rb") as fh:
             fr = pickle.load(fh)
@@ -655,7 +760,7 @@ def main():
     n_distinct = min(PRIME + W + R * K, MAX_DISTINCT_FRAMES)
     frames = make_frames(wl, [rank + world * k for k in range(n_distinct)])
     ring = FrameRing(frames, torch, dev)
-    pipeline = 0 if args.no_pipeline else int(os.environ.get("KS_BENCH_PIPE", "4"))   # bag replay = a stream of frames: frame pipelining on
+    pipeline = 0 if args.no_pipeline else int(os.environ.get("KS_BENCH_PIPE", "8"))   # bag replay = a stream of frames: frame pipelining on
 
     reduce_fn = None
     comm = None
@@ -666,16 +771,20 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29517")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         try:
-            comm = PAR.rccl_comm(rank, world, dev)   # an ncclComm_t of the librccl ks_reduce loads (id broadcast over torch.distributed)
+            comm = PAR.rccl_comm(rank, world, ddev)   # an ncclComm_t of the librccl ks_reduce loads (id broadcast over torch.distributed)
         except Exception as e:   # (never take the line down: the same protocol also runs over torch.distributed)
             sys.stderr.write(f"bench: ctypes RCCL communicator unavailable ({type(e).__name__}: {e}); exchange through torch.distributed\n")
             comm = None
         if world > 1:
             # every rank must take the same path
-            ok = torch.tensor([1 if comm is not None else 0], device=dev)
+            ok = torch.tensor([1 if comm is not None else 0], device=ddev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
+                if comm is not None:   # a rank whose communicator DID come up must not keep a half-connected one around
+                    PAR.rccl_abort(comm)
                 comm = None
+        if comm is None and shared_gpu:
+            raise SystemExit("KS_BENCH_SHARED_GPU=1 needs the ks_reduce communicator (KS_RCCL_LIB): the torch.distributed exchange needs one GPU per rank")
     exchange = "ks_reduce (C ABI, RCCL all-to-all of the dirty tiles to hash-owners)" if comm is not None else \
         "parallel.reduce_maps (the same protocol over torch.distributed)"
     if world > 1:
@@ -700,10 +809,10 @@ def main():
     if world > 1:
         # whole-job regions: MAX of the ranks' wall times, SUM of their work
         for r, reg in enumerate(m["regions"]):
-            t = torch.tensor([reg["dt"]], device=dev, dtype=torch.float64)
+            t = torch.tensor([reg["dt"]], device=ddev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             oc = sum(count_of_frame(i) for i in reg["frames"]) if count_of_frame else 0
-            u = torch.tensor([reg["updates"], reg["points"], reg["rays"], oc], device=dev, dtype=torch.float64)
+            u = torch.tensor([reg["updates"], reg["points"], reg["rays"], oc], device=ddev, dtype=torch.float64)
             dist.all_reduce(u, op=dist.ReduceOp.SUM)
             reg["dt"] = float(t.item())
             reg["updates"], reg["points"], reg["rays"] = int(u[0].item()), int(u[1].item()), int(u[2].item())
@@ -719,7 +828,7 @@ def main():
     c5 = None
     if world > 1 or os.environ.get("KS_BENCH_C5") == "1":
         try:
-            c5 = c5_record(B, torch, dist, dev, rank, world, comm)
+            c5 = c5_record(B, torch, dist, dev, rank, world, comm, ddev)
         except Exception as e:   # collective calls above are symmetric; a local failure must not take the line down
             c5 = {"config": "C5", "error": f"{type(e).__name__}: {e}"}
 
@@ -868,7 +977,18 @@ def main():
                 except Exception as e:
                     sec.append({"config": "switches", "error": f"{type(e).__name__}: {e}"})
             out["secondary"] = sec
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        out["library"] = mapped_library()
+        out["bench_seconds"] = round(time.time() - t_start, 1)
+        # the full record (every sub-record, stage table, A/B record) goes to a file; stdout carries ONE short line
+        full_path = os.environ.get("KS_BENCH_FULL") or os.path.join("profiles", "bench_full_r04.json" if world == 1 else f"bench_full_r04_n{world}.json")
+        try:
+            with open(os.path.join(ROOT, full_path) if not os.path.isabs(full_path) else full_path, "w") as fh:
+                json.dump(out, fh, indent=1)
+                fh.write("\n")
+        except OSError as e:
+            sys.stderr.write(f"bench: full record not written ({e})\n")
+            full_path = None
+        os.write(json_fd, (compact_line(out, full_path) + "\n").encode())
     if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.destroy_process_group()
 

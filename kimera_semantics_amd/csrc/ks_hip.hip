@@ -193,7 +193,7 @@ struct ks_ctx {
   bool test_overlap = true;              // k_test casts a long ray's next 64 voxels while the shared-set entries of the current 64 are in flight (KS_TEST_OVERLAP=0: one after the other, as measured until round 3)
   uint32_t sub_rays = kSubRun;           // rays per early-out sub-run (KS_SUB_RUN_RAYS = 1..16, experiments: the CPU checker follows with KO_EXP_SUB_RUN)
   bool sub_run_generations = false;      // early-out sub-runs of 16 generations instead of 16 live rays (KS_SUB_RUN_GENERATIONS=1: A/B runs; ks_k_march.h)
-  uint64_t buffers_epoch = 1;            // bumped whenever a buffer a captured graph points at is re-allocated
+  std::atomic<uint64_t> buffers_epoch{1};  // bumped whenever a buffer a captured graph points at is re-allocated
   uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
   uint32_t* d_label_lut = nullptr;  // 256 label -> rgba
   uint32_t tiles_initialised = 0;
@@ -531,6 +531,7 @@ inline unsigned bits_for(uint64_t n) {  // number of bits needed to represent va
   return b;
 }
 
+int launch_batch(ks_ctx* c);
 // ApproxHashSet::resetApproxSet.  `observed`: the early-out set, whose entries carry a frame tag
 // (ks_k_march.h); its poison value and tag bookkeeping differ from the start-voxel set's raw hashes.
 int reset_set(ks_ctx* c, uint64_t* d_set0, uint64_t* offset, bool observed) {
@@ -539,6 +540,10 @@ int reset_set(ks_ctx* c, uint64_t* d_set0, uint64_t* offset, bool observed) {
   // to run out they are retired in one pass and the tags start over
   const bool retag = observed && !full && c->obs_tag + (uint32_t)c->cfg.clear_checks_every_n_frames + 2u >= kObsMaxTag;
   if (full || retag) {
+    // frames whose stage B still waits for its batch to fill carry the OLD tag / offset in their FrameParams: they go
+    // out before the tables are rewritten (a frame with tag ~1019 running after the retag would leave marks that win
+    // every atomicMax against the restarted tags 1, 2, ...)
+    if (int rc = launch_batch(c)) return rc;
     if (int rc = sync_march(c)) return rc;  // stage B reads the observed set
     if (full) *offset = 0;
     for (int t = 0; t < (observed ? c->n_obs : 1); ++t) {
@@ -797,7 +802,7 @@ int launch_batch(ks_ctx* c) {
     V.s[k] = slot_view(S);
     steps_max = std::max(steps_max, S.steps_max);
   }
-  const uint64_t key = ((uint64_t)c->cap_points << 24) ^ (c->buffers_epoch << 4) ^ (S0.wide ? 1u : 0u) ^ ((uint64_t)nb << 1);
+  const uint64_t key = ((uint64_t)c->cap_points << 24) ^ (c->buffers_epoch.load() << 4) ^ (S0.wide ? 1u : 0u) ^ ((uint64_t)nb << 1);
   bool replayed = false;
   int rc;
   if (c->exact_early_out) {

@@ -164,20 +164,39 @@ def rccl_comm(rank: int, world: int, device, timeout: float = 120.0):
     C.memmove(C.byref(uid), raw, 128)
     comm = C.c_void_p()
     lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
-    torch.cuda.set_device(device)
+    on_gpu = getattr(device, "type", str(device)) == "cuda" or str(device).startswith("cuda")
+    if on_gpu:
+        torch.cuda.set_device(device)
     # the collective initialisation runs on a helper thread with a deadline: a caller (bench.py) can fall back to the
     # torch.distributed exchange instead of hanging if the bootstrap of a second communicator does not complete
     import threading
     box = {}
 
     def init():
-        torch.cuda.set_device(device)
+        if on_gpu:
+            torch.cuda.set_device(device)
         box["rc"] = lib.ncclCommInitRank(C.byref(comm), world, uid, rank)
     th = threading.Thread(target=init, daemon=True)
     th.start()
     th.join(timeout)
     if th.is_alive():
-        raise TimeoutError(f"ncclCommInitRank did not return within {timeout} s")
+        # the bootstrap is stuck inside the library with the unique id consumed: there is no way to take part in a later
+        # collective cleanly from this process, so say so and leave (the caller's fallback would hang on the next barrier
+        # while other ranks may still complete their side of the bootstrap)
+        import sys
+        sys.stderr.write(f"ncclCommInitRank did not return within {timeout} s on rank {rank}: exiting\n")
+        os._exit(3)
     if box.get("rc", -1) != 0:
         raise RuntimeError(f"ncclCommInitRank: {box.get('rc')}")
     return comm.value
+
+
+def rccl_abort(comm: int) -> None:
+    """Tears down a communicator made by rccl_comm without the collective handshake of ncclCommDestroy."""
+    import ctypes as C
+    import os
+    lib = C.CDLL(os.environ.get("KS_RCCL_LIB") or "librccl.so.1")
+    fn = getattr(lib, "ncclCommAbort", None)
+    if fn is not None and comm:
+        fn.argtypes = [C.c_void_p]
+        fn(C.c_void_p(comm))

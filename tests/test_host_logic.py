@@ -87,3 +87,52 @@ int main() {
     assert vals[2] == vals[0] and vals[3] == vals[1] and vals[4] == 0.0 and vals[5] == 0.0
     assert float(out[6]) == pytest.approx(0.05) and int(out[7]) == 16 and float(out[8]) == pytest.approx(0.8)
     assert float(out[9]) == pytest.approx(20.0) and int(out[10]) == 0 and not math.isnan(vals[0])
+
+
+def test_bench_line_is_one_short_parseable_line():
+    """bench.py's stdout line: built from a (worst-case sized) canned full record, it must stay under 4 KB, parse, and
+    carry the fields the driver reads (round 3's 25 KB line was not parsed: BENCH_r03.json `parsed: null`)."""
+    import json
+
+    import bench
+    stage = {k: {"ms_per_frame": 0.1234, "share_of_kernel_time": 0.1234, "achieved": 1234.5, "frac": 0.12345}
+             for k in ("points", "sort_points", "rays", "march", "emit", "sort_pairs", "apply", "apply_long")}
+    roof = {"bound": "hbm", "kernel": "whole frame (all stages, wall clock of the median timed region)", "achieved": 437.12, "peak": 8000.0,
+            "unit": "GB/s", "frac": 0.05464, "traffic": 96300000, "traffic_note": "x" * 300, "algorithmic_bytes_per_frame": 132400000,
+            "dominant_stage": "march", "stages": stage, "stage_note": "y" * 300,
+            "k_apply": {"achieved": 2390.1, "frac": 0.2988, "avg_launch_ms": 0.0575, "algorithmic_bytes_per_launch": 137200000,
+                        "timed_launches": 50, "note": "z" * 200}}
+    sub = {"config": "C4-merged", "workload": "w" * 200, "value": 10000.123, "unit": "Mvoxel-updates/s", "updates_counted_by": "u" * 300,
+           "gpu_counted_value": 10000.1, "ms_per_step": 7.78, "frames_per_s": 128.5, "steps": 30, "repeats": 5, "spread": 0.05,
+           "ms_per_step_all_regions": [7.7] * 5, "roofline": roof, "note": "n" * 300}
+    switches = {"config": "C2-switches", "default": {"ms_per_frame": 0.25, "stage_ms": {k: 0.1 for k in stage}},
+                "variants": [{"switch": f"KS_SWITCH_{i}=1", "ms_over_default": 1.05, "stage_ms": {k: 0.1 for k in stage}} for i in range(8)]}
+    full = {"metric": bench.METRIC, "value": 2019.123, "unit": "Mvoxel-updates/s", "n_gpus": 1, "steps": 40, "warmup": 5, "ms_per_step": 0.3029,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "frames_per_s": 3301.2,
+            "gpu_counted_value": 2200.5, "updates_counted_by": "c" * 200,
+            "timing": {"spread_max_minus_min_over_median": 0.03, "ms_per_step_all_regions": [0.3] * 5},
+            "config": {"workload": "bag-replay stand-in: " + "w" * 150, "frames_per_gpu": 40, "pipeline_frames": 8, "points_per_frame": 305667,
+                       "rays_per_frame": 47900, "updates_per_frame": 611496, "gpu_updates_per_frame": 611496, "early_out": "e" * 300,
+                       "bundle_order": "n/a (fast)", "parallelism": "frame-sharded x1"},
+            "roofline": roof, "host_ms_per_frame": {"in_call": 0.2, "of_which_waiting_for_snapshot": 0.05},
+            "early_out_fidelity": {"frames": 2, "touched_jaccard": 1.0, "block_jaccard": 1.0, "label_agreement_common_voxels": 1.0,
+                                   "updates_gpu_over_serial": 1.0, "how": "h" * 200},
+            "cpu_baseline": {"value": 5.2, "unit": "Mvoxel-updates/s", "cores": 8, "kind": "reference", "frames_per_s": 8.5, "host_cores": 192,
+                             "spread": 0.02, "by_threads": {"1": 4.8, "8": 5.2, "192": 1.9}, "reference_default_all_cores_value": 1.9, "sample": "s" * 400},
+            "secondary": [dict(sub, config=c) for c in ("C2-ordered-phases", "C3", "C2-host-inputs", "C4-fast", "C4-fast-exact", "C4-merged")]
+            + [{"config": "adapter", "workload": "a" * 200, "fast_every_frame_sync_ms_per_frame": 3.56, "fast_on_demand_sync_pipelined_ms_per_frame": 0.31,
+                "merged_every_frame_sync_ms_per_frame": 4.4, "merged_on_demand_sync_pipelined_ms_per_frame": 0.33},
+               {"config": "C5", "frames": 8, "batch_ms": 3.2, "gpu_counted_value": 1000.0, "reduce": {"tiles_sent": 100, "bytes_sent": 6553600}},
+               switches, dict(switches, config="C4-fast-switches"), dict(switches, config="C4-merged-switches")],
+            "library": "/root/repo/kimera_semantics_amd/libks_hip.so", "bench_seconds": 120.0}
+    assert len(json.dumps(full)) > 8000                      # the canned record is of the size that broke the driver's parser
+    line = bench.compact_line(full, "profiles/bench_full_r04.json")
+    assert "\n" not in line and len(line) < 4096
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert k in d, k
+    assert d["config"]["workload"] and set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert set(("value", "unit", "cores", "kind")) <= set(d["cpu_baseline"])
+    assert d["full_record"] == "profiles/bench_full_r04.json"
+    # degenerate: nothing optional present
+    assert json.loads(bench.compact_line({"metric": "m", "value": 1.0}, None))["value"] == 1.0
