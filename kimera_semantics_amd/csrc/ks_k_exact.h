@@ -55,9 +55,12 @@ __global__ void __launch_bounds__(256) k_eo_total(const FrameParams* __restrict_
 }
 
 // exclusive scan of the visited lengths over integration positions, blocks of kScanBlock (as k_scan_local)
+// (cnt_b / ux / dirty: the event-driven path's per-position state, initialised here — next lengths = current lengths,
+// steps covered by marks = visited length, nobody dirty)
 __global__ void __launch_bounds__(1024) k_eo_scan(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ cnt,
                                                   uint32_t* __restrict__ lp, unsigned long long* __restrict__ bt,
-                                                  EoState* __restrict__ st) {
+                                                  EoState* __restrict__ st, uint32_t* __restrict__ cnt_b = nullptr,
+                                                  uint32_t* __restrict__ ux = nullptr, uint32_t* __restrict__ dirty = nullptr) {
   __shared__ uint32_t s_wave[16];
   const uint32_t n = Fp->n;
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // this iteration's counters
@@ -69,7 +72,15 @@ __global__ void __launch_bounds__(1024) k_eo_scan(const FrameParams* __restrict_
   const uint32_t i0 = blockIdx.x * kScanBlock + threadIdx.x * 4u;
   uint32_t v[4];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = (i0 + k < n) ? eo_visited(cnt[i0 + k]) : 0u;
+  for (int k = 0; k < 4; ++k) {
+    const uint32_t cv = (i0 + k < n) ? cnt[i0 + k] : 0u;
+    v[k] = eo_visited(cv);
+    if (cnt_b && i0 + k < n) {
+      cnt_b[i0 + k] = cv;
+      ux[i0 + k] = v[k];
+      dirty[i0 + k] = 0u;
+    }
+  }
   const uint32_t mine = v[0] + v[1] + v[2] + v[3];
   uint32_t x = mine;
 #pragma unroll
@@ -124,14 +135,18 @@ __global__ void __launch_bounds__(256) k_eo_emit(const FrameParams* __restrict__
                                                  const RayDesc* __restrict__ rays, const uint32_t* __restrict__ cnt,
                                                  const uint32_t* __restrict__ lp, const unsigned long long* __restrict__ bt,
                                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                 unsigned long long cap, const Counters* C, EoState* __restrict__ st) {
+                                                 unsigned long long cap, const Counters* C, EoState* __restrict__ st,
+                                                 uint32_t* __restrict__ fail = nullptr) {
   extern __shared__ unsigned long long s_bt[];
   __shared__ float s_e[4][3 * kES];
   const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   if (blockIdx.x != 0 && blockIdx.x * 4u * (uint32_t)RPW >= C->n_rays) return;
   const unsigned long long total = eo_fold_totals(bt, (F.n + kScanBlock - 1u) / kScanBlock, s_bt);
   if (blockIdx.x == 0 && threadIdx.x == 0) st->n_marks = total;
-  if (total > cap) return;  // (the host sized the buffers from the count it read back: cannot happen)
+  if (total > cap) {  // (host-driven loop: the host sized the buffers from the count it read back; event-driven: the frame falls back to it)
+    if (fail && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(fail, 1u /* kEoFailMarks */);
+    return;
+  }
   const uint32_t lane = lane_id();
   const uint32_t r = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)RPW + lane;
   uint32_t pos = 0, visited = 0;
@@ -307,6 +322,429 @@ __global__ void __launch_bounds__(256) k_eo_commit(unsigned long long n_marks, c
   if (i >= n_marks) return;
   const uint32_t slot = (uint32_t)(keys[i] >> 44);
   if (i + 1 == n_marks || (uint32_t)(keys[i + 1] >> 44) != slot) plain[slot] = (uint64_t)vals[i];
+}
+
+
+// ==========================================================================================================
+// EVENT-DRIVEN fix point (the default of the exact mode since round 4): no host in the loop, work proportional to what changes.
+//
+// The host-driven loop above re-emits, re-sorts and re-evaluates ALL marks per iteration and reads a counter back.
+// Here the marks of the SEED are emitted and sorted ONCE (M: a ray's mark is "potential": it counts while its step is below
+// the ray's current visited length), and the iteration is carried by events:
+//   * a round evaluates only DIRTY rays (round 0: all of them) against the marks that are valid under the current
+//     lengths A[] — a slot's content at (position, step) is the hash of the last valid mark before it: binary search in
+//     the slot's range of M, then backwards to the first valid mark; plus the slot's chain of X marks;
+//   * a ray that outgrows the steps it has marks for appends X marks (a lock-free list per slot; they are few: the
+//     seed's lengths are almost right) — nothing is ever re-sorted;
+//   * a ray whose length changed TOGGLES the validity of its marks between the old and the new length; each toggled mark
+//     can change what exactly one reader sees — the next valid mark of its slot — so the propagation dirties the owners
+//     of the marks that follow it in its slot up to and including the first one that is valid under the NEW lengths B[]
+//     (and the owners of the slot's later X marks), then makes the new length current.
+// Rounds are Jacobi steps (evaluate against A, write B; propagate against B, copy to A), every hand-over crosses a kernel
+// boundary (or a workgroup barrier in the finisher): only the dirty flags, the list counters and the X chains are touched
+// by atomics.  The fixed point is unique (ks_k_exact.h, top), so the order of the lists does not matter.
+// A fixed number of bulk rounds is enqueued; k_eo2_finish (ONE workgroup) then iterates until nothing is dirty.
+// oracle/ks_oracle.cpp: ko_sim_fixpoint is the CPU study of this scheme (round counts, list sizes, X marks).
+// ==========================================================================================================
+constexpr uint32_t kEoBulkMax = 40;          // bulk rounds a launch sequence can hold
+constexpr uint32_t kEoFailMarks = 1u, kEoFailX = 2u, kEoFailRounds = 4u, kEoFailChain = 8u;
+constexpr uint32_t kEoFinishRounds = 4096;   // rounds of the finisher before it gives up (the host-driven loop takes over)
+
+struct EoCtl {
+  EoState st;                     // n_marks (k_eo_emit) ...
+  uint32_t n_x;                   // X nodes handed out (node 0 = end of chain)
+  uint32_t fail;                  // kEoFail*
+  uint32_t rounds;                // rounds run (statistics)
+  uint32_t n_consulted;           // rays whose result depends on what EARLIER FRAMES left in the table
+  uint32_t fin_in[2], fin_chg;    // the finisher's list counters
+  uint32_t pad;
+  uint32_t n_in[kEoBulkMax + 2];  // dirty rays entering bulk round r
+  uint32_t n_chg[kEoBulkMax + 2]; // rays whose length changed in bulk round r
+};
+
+struct EoView {
+  const FrameParams* F;
+  const uint32_t* ray_list;
+  const RayDesc* rays;
+  Counters* C;
+  uint32_t* cnt_a;                // current lengths (the slot's cnt[]: updates | kCntBroke) — the result
+  uint32_t* cnt_b;                // next lengths
+  uint32_t* ux;                   // per position: steps that have a mark (in M or X)
+  uint32_t* dirty;                // per position: queued for the next round
+  const uint64_t* keys;           // M, sorted by slot (time order inside a slot): [63:44] slot | [43:22] position | [21:0] step
+  const uint32_t* vals;           //    ... voxel hashes
+  uint4* tab;                     // per set slot: {begin, end} in M, head of the X chain, unused
+  unsigned long long* xnode;      // X marks, 2 words per node: position << 22 | step ;  hash | next << 32
+  uint32_t cap_x;
+  uint32_t* list[2];              // dirty rays (positions), ping-pong
+  uint32_t* chg;                  // rays whose length changed this round
+  uint32_t* consulted;
+  uint64_t* plain;                // the reference's table as earlier frames left it
+  uint32_t* committed;            // frames [0, *committed) have entered `plain`
+  uint32_t frame;                 // this frame's number
+  EoCtl* ctl;
+};
+
+__device__ __forceinline__ uint32_t eo2_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long eo2_ld64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// per slot: [begin, end) of its marks in M (the table is clear: k_eo2_commit leaves it so)
+__global__ void __launch_bounds__(256) k_eo2_index(EoView E) {
+  const unsigned long long n = E.ctl->st.n_marks;
+  if (E.ctl->fail) return;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull) {
+    const uint32_t slot = (uint32_t)(E.keys[i] >> 44);
+    if (i == 0 || (uint32_t)(E.keys[i - 1] >> 44) != slot) E.tab[slot].x = (uint32_t)i;
+    if (i + 1 == n || (uint32_t)(E.keys[i + 1] >> 44) != slot) E.tab[slot].y = (uint32_t)(i + 1);
+  }
+}
+
+// What slot `slot` holds at time t = position << 22 | step, for the ray at `pos` (its own earlier marks count whatever its
+// length is; marks of other rays count while their step is below the ray's length in len[]).  fresh: read the head of the X
+// chain past the caches (the caller pushed to it in this kernel).  Returns false if no mark of this frame precedes t.
+__device__ __forceinline__ bool eo2_content(const EoView& E, const uint32_t* __restrict__ len, uint32_t slot, uint64_t t, uint32_t pos,
+                                            bool fresh, uint32_t& hash) {
+  const uint4 e = E.tab[slot];
+  uint32_t lo = e.x, hi = e.y;  // first mark of the slot at or after t
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((E.keys[mid] & kEoLow44) < t) lo = mid + 1;
+    else hi = mid;
+  }
+  bool found = false;
+  uint64_t best = 0;
+  while (lo > e.x) {
+    --lo;
+    const uint64_t k = E.keys[lo] & kEoLow44;
+    const uint32_t p = (uint32_t)(k >> 22), st = (uint32_t)k & 0x3fffffu;
+    if (p == pos || st < eo_visited(len[p])) {
+      found = true;
+      best = k;
+      hash = E.vals[lo];
+      break;
+    }
+  }
+  uint32_t xi = fresh ? eo2_ld(&E.tab[slot].z) : e.z;
+  while (xi != 0u) {
+    const unsigned long long k = eo2_ld64(&E.xnode[2u * xi]), hn = eo2_ld64(&E.xnode[2u * xi + 1u]);
+    const uint32_t p = (uint32_t)(k >> 22), st = (uint32_t)k & 0x3fffffu;
+    if (k < t && (p == pos || st < eo_visited(len[p])) && (!found || k > best)) {
+      found = true;
+      best = k;
+      hash = (uint32_t)hn;
+    }
+    xi = (uint32_t)(hn >> 32);
+  }
+  return found;
+}
+
+// LDS of a wavefront of the round kernels
+struct EoWaveLds {
+  unsigned long long keys[64];  // slot << 32 | hash of the 64 steps being looked at
+  float e[3 * kES];             // scratch of the parallel caster
+};
+
+// keys of the steps [first, first + 64) of a ray (as far as it goes: full = its step count) -> W.keys; `ust` = wave-uniform
+// caster state at `first` (advanced), `ser` = the same state for the serial walk of an axis-parallel ray (lane 0's copy is used)
+__device__ __forceinline__ void eo2_cast64(const FrameParams& F, Dda& ust, bool par, uint32_t first, uint32_t full, EoWaveLds& W, uint32_t lane) {
+  const uint32_t n_r = full - first < 64u ? full - first : 64u;
+  if (par) {
+    dda_round64(ust, W.e, lane, [&](uint32_t r, int vx, int vy, int vz) {
+      if (r < n_r) {
+        const uint32_t h = index_hash(vx, vy, vz);
+        const uint32_t slot = (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask);
+        W.keys[r] = ((unsigned long long)slot << 32) | h;
+      }
+    });
+  } else {
+    // (NaN / inf crossing times: every lane walks the same serial caster — the state stays wave-uniform — lane 0 writes)
+    for (uint32_t i = 0; i < n_r; ++i) {
+      if (lane == 0) {
+        const uint32_t h = index_hash(ust.cx, ust.cy, ust.cz);
+        const uint32_t slot = (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask);
+        W.keys[i] = ((unsigned long long)slot << 32) | h;
+      }
+      ust.advance(first + i + 1u < full);
+    }
+  }
+  KS_WAVE_LDS_ORDER();
+}
+
+__device__ __forceinline__ void eo2_setup(const EoView& E, const FrameParams& F, uint32_t pos, Dda& dda, uint32_t& full) {
+  const RayDesc d = E.rays[ray_index(F, pos)];
+  dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, false);
+  full = (uint32_t)dda.steps + 1u;
+}
+
+// ONE ray evaluated by a whole wavefront (all operands wave-uniform): how far it gets against the marks valid under A.
+// Appends X marks for the visited steps it has no mark for yet; a changed length goes to B and the ray to the change list.
+__device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams& F, uint32_t pos, EoWaveLds& W, uint32_t* n_chg) {
+  const uint32_t lane = lane_id();
+  if (lane == 0) E.dirty[pos] = 0u;
+  Dda ust{};
+  uint32_t full;
+  eo2_setup(E, F, pos, ust, full);
+  const bool par = dda_parallel_ok(ust);
+  const uint32_t old = E.cnt_a[pos];
+  const uint32_t ux0 = E.ux[pos];
+  const int lim = F.max_collisions;
+  int c = 0, stop = -1;
+  bool consulted = false, pushed = false;
+  uint32_t visited = full;
+  for (uint32_t s0 = 0; s0 < full; s0 += 64) {
+    const uint32_t n_round = full - s0 < 64u ? full - s0 : 64u;
+    eo2_cast64(F, ust, par, s0, full, W, lane);
+    const bool v64 = lane < n_round;
+    bool hit = false;
+    const uint32_t k = s0 + lane;
+    unsigned long long key = 0ull;
+    if (v64) {
+      key = W.keys[lane];
+      const uint32_t slot = (uint32_t)(key >> 32), h = (uint32_t)key;
+      bool own = false;
+      if (k >= ux0) {
+        // steps of this round that have no mark yet: the ray's own latest earlier visit of the slot among them, if any
+        const uint32_t l0 = ux0 > s0 ? ux0 - s0 : 0u;
+        for (uint32_t l2 = lane; l2 > l0 && !own;) {
+          --l2;
+          const unsigned long long k2 = W.keys[l2];
+          if ((uint32_t)(k2 >> 32) == slot) {
+            own = true;
+            hit = (uint32_t)k2 == h;
+          }
+        }
+      }
+      if (!own) {
+        uint32_t content = 0;
+        if (eo2_content(E, E.cnt_a, slot, ((uint64_t)pos << 22) | k, pos, pushed, content)) hit = content == h;
+        else {
+          hit = E.plain[slot] == (uint64_t)h;
+          consulted |= h == 0u;   // (the only hash an entry of an EARLIER offset can equal: the zero-initialised slot)
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int st_r = early_out_stop(__ballot(v64 && hit), __ballot(v64), lim, c);
+    const uint32_t n_vis = st_r >= 0 ? (uint32_t)st_r + 1u : n_round;   // steps of this round the ray visits
+    // X marks for the visited steps without a mark
+    const bool need = v64 && lane < n_vis && k >= ux0;
+    const unsigned long long nm = __ballot(need);
+    if (nm != 0ull) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&E.ctl->n_x, (uint32_t)__popcll(nm));
+      base = (uint32_t)__shfl((int)base, 0);
+      if (base + (uint32_t)__popcll(nm) > E.cap_x) {
+        if (lane == 0) atomicOr(&E.ctl->fail, kEoFailX);
+      } else if (need) {
+        const uint32_t xi = base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
+        const uint32_t slot = (uint32_t)(key >> 32);
+        __hip_atomic_store(&E.xnode[2u * xi], ((unsigned long long)pos << 22) | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t head = eo2_ld(&E.tab[slot].z);
+        for (;;) {
+          __hip_atomic_store(&E.xnode[2u * xi + 1u], (unsigned long long)(uint32_t)key | ((unsigned long long)head << 32), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+          __threadfence();
+          const uint32_t seen = atomicCAS(&E.tab[slot].z, head, xi);
+          if (seen == head) break;
+          head = seen;
+        }
+      }
+      pushed = true;
+      __threadfence();
+    }
+    if (st_r >= 0) {
+      stop = (int)s0 + st_r;
+      visited = (uint32_t)stop + 1u;
+      break;
+    }
+  }
+  const bool any_consulted = __ballot(consulted) != 0ull;
+  if (lane == 0) {
+    if (visited > ux0) E.ux[pos] = visited;
+    const uint32_t now = stop >= 0 ? ((uint32_t)stop | kCntBroke) : full;
+    if (now != old) {
+      E.cnt_b[pos] = now;
+      E.chg[atomicAdd(n_chg, 1u)] = pos;
+    }
+    if (any_consulted) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos | 0x80000000u;   // (bit 31: flag for the dedup below)
+  }
+}
+
+__device__ __forceinline__ void eo2_mark_dirty(const EoView& E, uint32_t p, uint32_t* out, uint32_t* n_out) {
+  if (atomicExch(&E.dirty[p], 1u) == 0u) out[atomicAdd(n_out, 1u)] = p;
+}
+
+// ONE changed ray, by a whole wavefront: its marks between the old and the new length toggled — dirty their readers;
+// then the new length becomes current.
+__device__ __forceinline__ void eo2_propagate_ray(const EoView& E, const FrameParams& F, uint32_t pos, EoWaveLds& W, uint32_t* out, uint32_t* n_out) {
+  const uint32_t lane = lane_id();
+  const uint32_t old = E.cnt_a[pos], now = E.cnt_b[pos];
+  const uint32_t vo = eo_visited(old), vn = eo_visited(now);
+  const uint32_t lo = vo < vn ? vo : vn, hi = vo < vn ? vn : vo;
+  Dda ust{};
+  uint32_t full;
+  eo2_setup(E, F, pos, ust, full);
+  const bool par = dda_parallel_ok(ust);
+  for (uint32_t s0 = 0; s0 < hi; s0 += 64) {
+    eo2_cast64(F, ust, par, s0, full, W, lane);
+    const uint32_t k = s0 + lane;
+    if (k >= lo && k < hi) {
+      const uint32_t slot = (uint32_t)(W.keys[lane] >> 32);
+      const uint64_t t = ((uint64_t)pos << 22) | k;
+      const uint4 e = E.tab[slot];
+      uint32_t a = e.x, b = e.y;  // first mark of the slot after t
+      while (a < b) {
+        const uint32_t mid = (a + b) >> 1;
+        if ((E.keys[mid] & kEoLow44) <= t) a = mid + 1;
+        else b = mid;
+      }
+      for (; a < e.y; ++a) {
+        const uint64_t km = E.keys[a] & kEoLow44;
+        const uint32_t p = (uint32_t)(km >> 22), st = (uint32_t)km & 0x3fffffu;
+        if (p != pos) eo2_mark_dirty(E, p, out, n_out);
+        if (st < eo_visited(E.cnt_b[p])) break;   // valid under the new lengths: later readers see this one
+      }
+      for (uint32_t xi = eo2_ld(&E.tab[slot].z); xi != 0u;) {
+        const unsigned long long kx = eo2_ld64(&E.xnode[2u * xi]), hn = eo2_ld64(&E.xnode[2u * xi + 1u]);
+        const uint32_t p = (uint32_t)(kx >> 22);
+        if (kx > t && p != pos) eo2_mark_dirty(E, p, out, n_out);
+        xi = (uint32_t)(hn >> 32);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (lane == 0) E.cnt_a[pos] = now;
+}
+
+// One bulk round = two launches (grid-stride over the list, one wavefront per ray):
+//   k_eo2_eval      : rays of list[r & 1] (round 0: every ray of the frame) -> change list
+//   k_eo2_propagate : change list -> list[(r + 1) & 1]
+__global__ void __launch_bounds__(256) k_eo2_eval(EoView E, uint32_t round) {
+  __shared__ EoWaveLds s_w[4];
+  EoCtl* ctl = E.ctl;
+  if (ctl->fail) return;
+  const uint32_t n = round == 0 ? E.C->n_rays : ctl->n_in[round];
+  const uint32_t* list = round == 0 ? E.ray_list : E.list[round & 1u];
+  const uint32_t wave = threadIdx.x >> 6, w0 = blockIdx.x * 4u + wave, nw = gridDim.x * 4u;
+  if (w0 >= n) return;
+  const FrameParams F = *E.F;
+  for (uint32_t i = w0; i < n; i += nw) eo2_eval_ray(E, F, list[i], s_w[wave], &ctl->n_chg[round]);
+}
+__global__ void __launch_bounds__(256) k_eo2_propagate(EoView E, uint32_t round) {
+  __shared__ EoWaveLds s_w[4];
+  EoCtl* ctl = E.ctl;
+  if (ctl->fail) return;
+  const uint32_t n = ctl->n_chg[round];
+  const uint32_t wave = threadIdx.x >> 6, w0 = blockIdx.x * 4u + wave, nw = gridDim.x * 4u;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n) ctl->rounds = round + 1u;
+  if (w0 >= n) return;
+  const FrameParams F = *E.F;
+  for (uint32_t i = w0; i < n; i += nw) eo2_propagate_ray(E, F, E.chg[i], s_w[wave], E.list[(round + 1u) & 1u], &ctl->n_in[round + 1u]);
+}
+
+// The remaining rounds, by ONE workgroup (barriers instead of launches), until nothing is dirty.  Enqueued after the
+// PREVIOUS frame's marks have entered `plain`: rays whose result depends on what earlier frames left there go first.
+constexpr uint32_t kEoFinishThreads = 1024;
+__global__ void __launch_bounds__(kEoFinishThreads) k_eo2_finish(EoView E, uint32_t first_round, uint32_t chained) {
+  __shared__ EoWaveLds s_w[kEoFinishThreads / 64];
+  __shared__ uint32_t s_n, s_stop;
+  EoCtl* ctl = E.ctl;
+  const uint32_t wave = threadIdx.x >> 6, nw = kEoFinishThreads / 64;
+  const FrameParams F = *E.F;
+  uint32_t cur = first_round & 1u;
+  if (threadIdx.x == 0) {
+    // (a predecessor that fell back to the host-driven loop has not entered its marks yet: this frame follows it there)
+    if (chained && eo2_ld(E.committed) != E.frame) atomicOr(&ctl->fail, kEoFailChain);
+    ctl->fin_in[cur] = ctl->n_in[first_round];
+    ctl->fin_in[cur ^ 1u] = 0u;
+    ctl->fin_chg = 0u;
+    s_stop = ctl->fail;
+  }
+  __syncthreads();
+  if (s_stop) {
+    if (threadIdx.x == 0) atomicOr(&E.C->err, kErrExact);
+    return;
+  }
+  if (chained) {
+    const uint32_t nc = ctl->n_consulted;
+    for (uint32_t i = threadIdx.x; i < nc; i += kEoFinishThreads) eo2_mark_dirty(E, E.consulted[i] & 0x7fffffffu, E.list[cur], &ctl->fin_in[cur]);
+    __threadfence();
+    __syncthreads();
+  }
+  for (uint32_t it = 0;; ++it) {
+    if (threadIdx.x == 0) {
+      s_n = eo2_ld(&ctl->fin_in[cur]);
+      s_stop = eo2_ld(&ctl->fail) | (it >= kEoFinishRounds ? kEoFailRounds : 0u);
+      if (s_n && !s_stop) ctl->rounds += 1u;
+    }
+    __syncthreads();
+    const uint32_t n = s_n;
+    if (n == 0u || s_stop) break;
+    for (uint32_t i = wave; i < n; i += nw) eo2_eval_ray(E, F, E.list[cur][i], s_w[wave], &ctl->fin_chg);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      s_n = eo2_ld(&ctl->fin_chg);
+      ctl->fin_in[cur] = 0u;
+    }
+    __syncthreads();
+    const uint32_t nc = s_n;
+    for (uint32_t i = wave; i < nc; i += nw) eo2_propagate_ray(E, F, E.chg[i], s_w[wave], E.list[cur ^ 1u], &ctl->fin_in[cur ^ 1u]);
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) ctl->fin_chg = 0u;
+    cur ^= 1u;
+  }
+  if (threadIdx.x == 0 && s_stop) {
+    atomicOr(&ctl->fail, s_stop);
+    atomicOr(&E.C->err, kErrExact);
+  }
+}
+
+// The frame's marks enter the reference's table: per slot, the hash of the last valid mark in time order; the slot's
+// entry of the per-frame table is cleared for the frame slot's next frame.  After a failure only the clearing happens.
+__global__ void __launch_bounds__(256) k_eo2_commit(EoView E) {
+  const bool ok = E.ctl->fail == 0u;
+  for (uint32_t slot = blockIdx.x * 256u + threadIdx.x; slot < (1u << kSetBits); slot += gridDim.x * 256u) {
+    const uint4 e = E.tab[slot];
+    if (e.x == e.y && e.z == 0u) continue;
+    E.tab[slot] = make_uint4(0u, 0u, 0u, 0u);
+    if (!ok) continue;
+    bool found = false;
+    uint64_t best = 0;
+    uint32_t hash = 0;
+    for (uint32_t j = e.y; j > e.x;) {
+      --j;
+      const uint64_t k = E.keys[j] & kEoLow44;
+      if (((uint32_t)k & 0x3fffffu) < eo_visited(E.cnt_a[(uint32_t)(k >> 22)])) {
+        found = true;
+        best = k;
+        hash = E.vals[j];
+        break;
+      }
+    }
+    for (uint32_t xi = e.z; xi != 0u;) {
+      const unsigned long long k = E.xnode[2u * xi], hn = E.xnode[2u * xi + 1u];
+      if (((uint32_t)k & 0x3fffffu) < eo_visited(E.cnt_a[(uint32_t)(k >> 22)]) && (!found || k > best)) {
+        found = true;
+        best = k;
+        hash = (uint32_t)hn;
+      }
+      xi = (uint32_t)(hn >> 32);
+    }
+    if (found) E.plain[slot] = (uint64_t)hash;
+  }
+  if (ok && blockIdx.x == 0 && threadIdx.x == 0) *E.committed = E.frame + 1u;
+}
+
+// start of a frame's fix point: counters (n_x = 1: node 0 is the end of a chain)
+__global__ void __launch_bounds__(64) k_eo2_begin(EoCtl* ctl) {
+  uint32_t* w = (uint32_t*)ctl;
+  for (uint32_t i = threadIdx.x; i < sizeof(EoCtl) / 4u; i += 64) w[i] = 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) ctl->n_x = 1u;
 }
 
 }  // namespace ksk

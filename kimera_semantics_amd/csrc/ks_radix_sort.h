@@ -48,10 +48,11 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, unsigned l
 template <typename K, int RB>
 __global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uint32_t n, int passes, int begin_bit,
                                                  uint32_t* __restrict__ hist, uint32_t* __restrict__ zero_ptr,
-                                                 uint32_t zero_words) {
+                                                 uint32_t zero_words, const unsigned long long* __restrict__ n_dev = nullptr) {
   constexpr int kBins = 1 << RB;
   extern __shared__ uint32_t s_hist[];  // [passes][kBins]
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  if (n_dev) n = (uint32_t)(*n_dev < (unsigned long long)n ? *n_dev : (unsigned long long)n);   // sort_dev: the key count lives on the device (n = capacity)
   for (uint32_t i = blockIdx.x * 256u + tid; i < zero_words / 4u; i += gridDim.x * 256u)
     ((uint4*)zero_ptr)[i] = make_uint4(0u, 0u, 0u, 0u);
   for (int i = tid; i < passes * kBins; i += 256) s_hist[i] = 0;
@@ -96,11 +97,13 @@ __global__ void __launch_bounds__(THREADS) k_rs_pass(const K* __restrict__ keys_
                                                      const uint32_t* __restrict__ vals_in,
                                                      uint32_t* __restrict__ vals_out, uint32_t n, int shift,
                                                      const uint32_t* __restrict__ bin_hist,
-                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ ticket) {
+                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
+                                                     const unsigned long long* __restrict__ n_dev = nullptr) {
   constexpr int kBins = 1 << RB;
   constexpr int kChunks = kBins / 64;
   constexpr int kWaves = THREADS / 64;
   constexpr int kTile = THREADS * ITEMS;
+  if (n_dev) n = (uint32_t)(*n_dev < (unsigned long long)n ? *n_dev : (unsigned long long)n);   // sort_dev (the grid covers the capacity)
   __shared__ uint32_t s_cnt[kWaves][kBins];  // per-wave digit counters, later exclusive wave bases
   __shared__ uint32_t s_off[kBins];          // global offset of this tile's first key of each digit
   __shared__ uint32_t s_chunk[kChunks];      // sums of 64-bin chunks of the pass histogram
@@ -116,6 +119,9 @@ __global__ void __launch_bounds__(THREADS) k_rs_pass(const K* __restrict__ keys_
   for (int i = tid; i < kWaves * kBins; i += THREADS) (&s_cnt[0][0])[i] = 0;
   __syncthreads();
   const uint32_t tile = s_tile;
+  // (sort_dev: tickets are handed out in arrival order, so the tiles past the last key are exactly those that arrive
+  // after every tile with keys has its ticket: nothing ever looks back at them)
+  if (n_dev && (unsigned long long)tile * kTile >= (unsigned long long)n) return;
   const uint32_t wbase = tile * kTile + wave * (ITEMS * 64);
 
   K key[ITEMS];
@@ -339,6 +345,51 @@ inline hipError_t sort_rb(Workspace& w, K* keys_a, K* keys_b, uint32_t* vals_a, 
   else launch_passes<K, HAS_VALUES, 512, 32, RB>(w, kin, kout, vin, vout, n, passes, tiles, begin_bit, stream);
   *keys_result = kin;
   if (vals_result) *vals_result = vin;
+  return hipGetLastError();
+}
+
+// The same sort with the key count in DEVICE memory and nothing on the host that changes from call to call: the launch
+// sequence depends only on `cap` (capacity of the buffers) and can be captured into a graph and replayed.  `ws` holds
+// ws_words_dev(cap, passes) words and is cleared by a memset node at the head of the sequence.  Keys + values, tiles of
+// 2048 (cap <= 2^20) / 8192 / 16384 keys.  The result is in (keys_b, vals_b) after an odd number of passes, else in (a).
+inline size_t dev_tile(size_t cap) { return cap <= (1u << 20) ? 2048 : cap <= (1u << 24) ? 8192 : 16384; }
+inline size_t ws_words_dev(size_t cap, int passes) { return kHeadWords + (size_t)passes * ((cap + dev_tile(cap) - 1) / dev_tile(cap)) * 256; }
+template <typename K>
+inline hipError_t sort_dev(uint32_t* ws, size_t ws_words, K* keys_a, K* keys_b, uint32_t* vals_a, uint32_t* vals_b,
+                           const unsigned long long* n_dev, size_t cap, unsigned begin_bit, unsigned end_bit, hipStream_t stream,
+                           K** keys_result, uint32_t** vals_result) {
+  constexpr int RB = 8;
+  constexpr int kBins = 1 << RB;
+  const int passes = (int)((end_bit - begin_bit + RB - 1) / RB);
+  const size_t tile = dev_tile(cap);
+  const uint32_t tiles = (uint32_t)((cap + tile - 1) / tile);
+  if (kHeadWords + (size_t)passes * tiles * kBins > ws_words) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(ws, 0, (kHeadWords + (size_t)passes * tiles * kBins) * sizeof(uint32_t), stream);
+  if (e != hipSuccess) return e;
+  uint32_t* hist = ws;
+  uint32_t* tickets = ws + (size_t)kMaxPasses * kMaxBins;
+  uint32_t* status = ws + kHeadWords;
+  hipLaunchKernelGGL((k_rs_hist<K, RB>), dim3((uint32_t)std::min<size_t>((cap + 2047) / 2048, kHistBlocks)), dim3(256),
+                     (size_t)passes * kBins * sizeof(uint32_t), stream, (const K*)keys_a, (uint32_t)cap, passes, (int)begin_bit, hist,
+                     (uint32_t*)nullptr, 0u, n_dev);
+  K* kin = keys_a;
+  K* kout = keys_b;
+  uint32_t* vin = vals_a;
+  uint32_t* vout = vals_b;
+  for (int p = 0; p < passes; ++p) {
+#define KS_RS_DEV_PASS(THREADS, ITEMS)                                                                                                 \
+  hipLaunchKernelGGL((k_rs_pass<K, true, THREADS, ITEMS, RB>), dim3(tiles), dim3(THREADS), 0, stream, (const K*)kin, kout,             \
+                     (const uint32_t*)vin, vout, (uint32_t)cap, (int)begin_bit + p * RB, (const uint32_t*)(hist + (size_t)p * kMaxBins), \
+                     status + (size_t)p * tiles * kBins, tickets + p, n_dev)
+    if (tile == 2048) KS_RS_DEV_PASS(256, 8);
+    else if (tile == 8192) KS_RS_DEV_PASS(512, 16);
+    else KS_RS_DEV_PASS(512, 32);
+#undef KS_RS_DEV_PASS
+    K* tk = kin; kin = kout; kout = tk;
+    uint32_t* tv = vin; vin = vout; vout = tv;
+  }
+  *keys_result = kin;
+  *vals_result = vin;
   return hipGetLastError();
 }
 

@@ -20,7 +20,8 @@ constexpr int kCoordBias = 1 << 20;                            // voxel coordina
 constexpr int kTileBias = 1 << 17;                             // tile coordinates packed as 18-bit fields
 
 // error bits raised by kernels
-enum : uint32_t { kErrLabel = 1u, kErrPool = 2u, kErrIndex = 4u, kErrTable = 8u, kErrPairs = 16u /* pair buffer too small: the host grows it and repeats the emission */ };
+enum : uint32_t { kErrLabel = 1u, kErrPool = 2u, kErrIndex = 4u, kErrTable = 8u, kErrPairs = 16u /* pair buffer too small: the host grows it and repeats the emission */,
+                 kErrExact = 32u /* exact early-out: the device-driven fix point gave up, the host-driven loop repeats the frame's stage B */ };
 
 struct Counters {
   unsigned long long n_pairs;

@@ -1249,6 +1249,231 @@ size_t ko_sim_early_out(const ko_config* cfg, const float Tq[7], const float* xy
   return keys.size();
 }
 
+
+// Design study (tools/fixpoint_study.py) of the GPU's EVENT-DRIVEN fix point for the serial early-out
+// (kimera_semantics_amd/csrc/ks_k_exact.h): seed lengths L0 from the chain schedule with doubling phases, potential
+// marks for the first min(full, L0 + pad) steps of every ray sorted by (slot, time); per round every dirty ray walks
+// again (a mark is valid iff its step < the CURRENT length of its ray; lengths are updated in place, rays in a
+// shuffled order), and every mark whose validity toggled dirties the owners of the marks that follow it in its slot
+// up to and including the first valid one.  Prints per-round statistics to stderr and returns the number of rays whose
+// final length differs from the serial reference's (0 = exact), or SIZE_MAX if a ray outgrew its potential marks.
+size_t ko_sim_fixpoint(const ko_config* cfg, const float Tq[7], const float* xyz, const uint8_t* labels, size_t n,
+                       uint32_t pad, uint32_t seed_mode, uint64_t* stats, size_t n_stats) {
+  ko_ctx* c = nullptr;
+  if (ko_create(cfg, &c) != 0) return 0;
+  Transform T;
+  T.w = Tq[0];
+  T.v = {Tq[1], Tq[2], Tq[3]};
+  T.t = {Tq[4], Tq[5], Tq[6]};
+  c->start_voxel_set.reset();
+  c->voxel_observed_set.reset();
+  IndexGetter getter;
+  getter.init(cfg->integration_order_mode, xyz, n);
+  struct Step { uint32_t slot, h; };
+  std::vector<std::vector<Step>> path;
+  std::vector<uint32_t> posv;
+  ApproxHashSet& S = c->voxel_observed_set;
+  size_t idx;
+  uint32_t pos = 0;
+  while (getter.next(&idx)) {
+    const uint32_t p = pos++;
+    const V3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+    bool clr;
+    if (!c->is_point_valid(pc, false, &clr) || !c->is_semantic_label_valid(labels[idx])) continue;
+    const V3 pg = transform_point(T, pc);
+    const I3 g = grid_index_from_point(pg, cfg->start_voxel_subsampling_factor * c->voxel_size_inv);
+    if (!c->start_voxel_set.replace_hash(LongIndexHash()(g))) continue;
+    RayCaster caster(T.t, pg, clr, cfg->voxel_carving_enabled != 0, cfg->max_ray_length_m, c->voxel_size_inv, cfg->truncation_distance, false);
+    std::vector<Step> st;
+    I3 v;
+    while (caster.next(&v)) {
+      const size_t h = LongIndexHash()(v);
+      st.push_back({(uint32_t)((h + S.offset) & ApproxHashSet::kMask), (uint32_t)h});
+    }
+    path.push_back(std::move(st));
+    posv.push_back(p);
+  }
+  const size_t R = path.size();
+  const int64_t lim = cfg->max_consecutive_ray_collisions;
+  auto plain = [&](uint32_t slot) { return S.slots[slot].load(std::memory_order_relaxed); };
+  // ---- the serial reference ----
+  std::vector<uint32_t> Lref(R);
+  {
+    std::unordered_map<uint32_t, size_t> cur;
+    for (size_t i = 0; i < R; ++i) {
+      int64_t cc = 0;
+      uint32_t vis = 0;
+      for (const Step& st : path[i]) {
+        auto it = cur.find(st.slot);
+        const size_t content = it != cur.end() ? it->second : plain(st.slot);
+        cc = content == st.h ? cc + 1 : 0;
+        cur[st.slot] = st.h;
+        ++vis;
+        if (cc > lim) break;
+      }
+      Lref[i] = vis;
+    }
+  }
+  // ---- seed ----
+  std::vector<uint32_t> L(R);
+  if (seed_mode == 0) {
+    for (size_t i = 0; i < R; ++i) L[i] = (uint32_t)path[i].size();
+  } else {
+    // chain schedule, phases of generations doubling (seed_mode = growth in 1/16ths, 32 = doubling), private set per chain and phase
+    std::vector<uint32_t> B{0};
+    const uint32_t n_gen = (uint32_t)((n + 1023) / 1024);
+    for (;;) {
+      const uint64_t inc = std::max<uint64_t>(1, (uint64_t)B.back() * (seed_mode - 16) / 16);
+      if (B.back() + inc >= n_gen) break;
+      B.push_back((uint32_t)(B.back() + inc));
+    }
+    std::unordered_map<uint32_t, size_t> shared;
+    size_t r0 = 0;
+    for (size_t ph = 0; ph < B.size(); ++ph) {
+      const uint32_t g1 = ph + 1 < B.size() ? B[ph + 1] : 0xffffffffu;
+      std::map<uint32_t, std::unordered_map<uint32_t, size_t>> priv;
+      std::vector<std::pair<uint32_t, size_t>> marks;
+      size_t r1 = r0;
+      for (; r1 < R && posv[r1] / 1024 < g1; ++r1) {
+        auto& pm = priv[posv[r1] % 1024];
+        int64_t cc = 0;
+        uint32_t vis = 0;
+        std::vector<std::pair<uint32_t, size_t>> own;
+        for (const Step& st : path[r1]) {
+          auto it = pm.find(st.slot);
+          size_t content;
+          if (it != pm.end()) content = it->second;
+          else {
+            auto is = shared.find(st.slot);
+            content = is != shared.end() ? is->second : plain(st.slot);
+          }
+          cc = content == st.h ? cc + 1 : 0;
+          own.push_back({st.slot, st.h});
+          ++vis;
+          if (cc > lim) break;
+        }
+        for (auto& m : own) { pm[m.first] = m.second; marks.push_back(m); }
+        L[r1] = vis;
+      }
+      for (auto& m : marks) shared[m.first] = m.second;
+      r0 = r1;
+    }
+  }
+  size_t seed_wrong = 0, seed_marks = 0;
+  for (size_t i = 0; i < R; ++i) { seed_wrong += L[i] != Lref[i]; seed_marks += L[i]; }
+  // ---- potential marks ----
+  std::vector<uint32_t> U(R);
+  struct Mark { uint32_t ray, step, h; };
+  std::unordered_map<uint32_t, std::vector<Mark>> M;
+  size_t n_pot = 0;
+  for (size_t i = 0; i < R; ++i) {
+    U[i] = (uint32_t)std::min<size_t>(path[i].size(), (size_t)L[i] + pad);
+    for (uint32_t k = 0; k < U[i]; ++k) M[path[i][k].slot].push_back({(uint32_t)i, k, path[i][k].h});
+    n_pot += U[i];
+  }  // (rays are visited in serial order and steps ascending: every slot's marks are in time order)
+  auto find_mark = [&](const std::vector<Mark>& v, uint32_t ray, uint32_t step) {   // first mark at or after (ray, step)
+    size_t lo = 0, hi = v.size();
+    while (lo < hi) {
+      const size_t mid = (lo + hi) / 2;
+      if (v[mid].ray < ray || (v[mid].ray == ray && v[mid].step < step)) lo = mid + 1;
+      else hi = mid;
+    }
+    return lo;
+  };
+  // marks past a ray's potential ones (it outgrew its seed length + pad): appended per slot, unsorted ("X" marks)
+  std::unordered_map<uint32_t, std::vector<Mark>> X;
+  std::vector<uint32_t> UX(U);
+  size_t n_x = 0;
+  std::vector<uint8_t> dirty(R, 1);
+  std::vector<uint32_t> work(R);
+  for (size_t i = 0; i < R; ++i) work[i] = (uint32_t)i;
+  uint64_t rng = 88172645463325252ull;
+  auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+  bool overflow = false;
+  size_t round = 0, n_out = 0;
+  uint64_t tot_steps = 0, tot_back = 0, tot_fwd = 0;
+  auto before = [](uint32_t r1, uint32_t k1, uint32_t r2, uint32_t k2) { return r1 < r2 || (r1 == r2 && k1 < k2); };
+  static const std::vector<Mark> kNone;
+  while (!work.empty() && round < 1000) {
+    for (size_t i = work.size(); i > 1; --i) std::swap(work[i - 1], work[rnd() % i]);
+    for (uint32_t i : work) dirty[i] = 0;
+    std::vector<uint32_t> next;
+    size_t changed = 0, steps = 0, back = 0, fwd = 0, toggled = 0;
+    for (uint32_t i : work) {
+      int64_t cc = 0;
+      uint32_t vis = 0;
+      for (uint32_t k = 0; k < path[i].size(); ++k) {
+        const Step& st = path[i][k];
+        if (k >= UX[i]) { X[st.slot].push_back({i, k, st.h}); ++n_x; }
+        auto im = M.find(st.slot);
+        const std::vector<Mark>& v = im != M.end() ? im->second : kNone;
+        size_t j = find_mark(v, i, k);
+        size_t content = plain(st.slot);
+        bool have = false;
+        uint32_t br = 0, bk = 0;
+        while (j > 0) {
+          --j;
+          ++back;
+          if (v[j].ray == i || v[j].step < L[v[j].ray]) { content = v[j].h; have = true; br = v[j].ray; bk = v[j].step; break; }
+        }
+        auto ix = X.find(st.slot);
+        if (ix != X.end())
+          for (const Mark& m : ix->second) {
+            ++back;
+            if (!before(m.ray, m.step, i, k)) continue;
+            if (!(m.ray == i || m.step < L[m.ray])) continue;
+            if (!have || before(br, bk, m.ray, m.step)) { content = m.h; have = true; br = m.ray; bk = m.step; }
+          }
+        cc = content == st.h ? cc + 1 : 0;
+        ++vis;
+        ++steps;
+        if (cc > lim) break;
+      }
+      UX[i] = std::max(UX[i], vis);
+      const uint32_t old = L[i];
+      if (vis != old) {
+        ++changed;
+        L[i] = vis;
+        for (uint32_t k = std::min(old, vis); k < std::max(old, vis); ++k) {
+          ++toggled;
+          auto im = M.find(path[i][k].slot);
+          if (im != M.end()) {
+            const std::vector<Mark>& v = im->second;
+            size_t j = find_mark(v, i, k);
+            if (j < v.size() && v[j].ray == i && v[j].step == k) ++j;
+            for (; j < v.size(); ++j) {
+              ++fwd;
+              const uint32_t o = v[j].ray;
+              if (o != i && !dirty[o]) { dirty[o] = 1; next.push_back(o); }
+              if (v[j].step < L[o]) break;
+            }
+          }
+          auto ix = X.find(path[i][k].slot);
+          if (ix != X.end())
+            for (const Mark& m : ix->second) {
+              ++fwd;
+              if (!before(i, k, m.ray, m.step)) continue;
+              if (m.ray != i && !dirty[m.ray]) { dirty[m.ray] = 1; next.push_back(m.ray); }
+            }
+        }
+      }
+    }
+    fprintf(stderr, "  round %2zu: dirty %7zu changed %6zu toggled %7zu walk steps %8zu back-scan %8zu fwd-scan %7zu  X marks %zu\n", round, work.size(), changed,
+            toggled, steps, back, fwd, n_x);
+    if (n_out + 3 <= n_stats) { stats[n_out++] = work.size(); stats[n_out++] = changed; stats[n_out++] = steps; }
+    tot_steps += steps; tot_back += back; tot_fwd += fwd;
+    work.swap(next);
+    ++round;
+  }
+  size_t wrong = 0, ref_marks = 0;
+  for (size_t i = 0; i < R; ++i) { wrong += L[i] != Lref[i]; ref_marks += Lref[i]; }
+  fprintf(stderr, "fixpoint study: rays %zu, serial marks %zu, seed marks %zu (seed wrong on %zu rays), potential marks %zu (pad %u), rounds %zu, "
+                  "total walk steps %llu back %llu fwd %llu, overflow %d, WRONG %zu\n", R, ref_marks, seed_marks, seed_wrong, n_pot, pad, round,
+          (unsigned long long)tot_steps, (unsigned long long)tot_back, (unsigned long long)tot_fwd, (int)overflow, wrong);
+  ko_destroy(c);
+  return overflow ? (size_t)-1 : wrong;
+}
+
 size_t ko_num_blocks(ko_ctx* ctx) { return ctx->tsdf_layer.blocks.size(); }
 size_t ko_num_semantic_blocks(ko_ctx* ctx) { return ctx->semantic_layer.blocks.size(); }
 
