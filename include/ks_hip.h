@@ -82,16 +82,19 @@ typedef struct ks_config {
   uint8_t label_rgba[256][4];       /* label -> colour (SemanticLabel2Color::semantic_label_to_color_map_) */
   /* fast integrator with the early-out enabled (max_consecutive_ray_collisions below the ray length):
    * the reference's loop (semantic_tsdf_integrator_fast.cpp:110-122) is serial by construction — ray k
-   * stops on the marks rays 1..k-1 left in the approximate set.  The GPU runs the ORDERED-PHASE schedule
-   * (restated for the CPU in oracle/ks_oracle.cpp, against which it is bit-exact):
-   * integration positions are cut into phases whose length grows by this factor (in 1/16ths) — 32 =
-   * doubling (default, also chosen by 0), 16 = one generation of 1024 positions per phase (closest to
-   * the serial order, one pair of kernel launches per generation).  Deterministic for every value.
-   * KS_EARLY_OUT_EXACT: the reference's SERIAL result itself (what integrator_threads = 1 produces, bit for bit,
-   * including the ApproxHashSet's zero-initialised slots that "contain" hash 0): the ordered-phase result is only
-   * the seed of a fix-point iteration over the rays' visited lengths (csrc/ks_k_exact.h; ~10 iterations of
-   * emit marks / sort / re-test per 640x480 frame).  The iteration count is data dependent and read back by the
-   * host, so pipeline_frames is ignored (treated as 0) in this mode. */
+   * stops on the marks rays 1..k-1 left in the approximate set.
+   * 0 (default) or KS_EARLY_OUT_EXACT: the reference's SERIAL result itself (what integrator_threads = 1 produces, bit
+   *    for bit, including the ApproxHashSet's zero-initialised slots that "contain" hash 0).  The serial result is the
+   *    unique fixed point of "how far does every ray get against the marks of the rays before it"; the GPU reaches it
+   *    with an event-driven iteration on the device (csrc/ks_k_exact.h: the seed's marks sorted once, then only rays
+   *    whose inputs changed are re-evaluated; no host read in the loop), pipelined like every other mode when
+   *    clear_checks_every_n_frames = 1 (with a larger value a frame's marks are inputs of the next frame's loop:
+   *    pipeline_frames is then treated as 0).
+   * 16 .. 4096: the ORDERED-PHASE schedule alone (restated for the CPU in oracle/ks_oracle.cpp, against
+   *    which it is bit-exact): integration positions are cut into phases whose length grows by this factor (in
+   *    1/16ths) — 32 = doubling, 16 = one generation of 1024 positions per phase.  Deterministic for every value, a few
+   *    launches cheaper per frame than the exact mode, and NOT the reference's map (touched-voxel Jaccard 0.976-0.995
+   *    against the serial order): a throughput option for callers who accept that. */
   int32_t early_out_phase_growth;
   /* ---- device sizing ---- */
   int32_t device_id;                /* HIP device ordinal */
@@ -281,8 +284,11 @@ int ks_flush(ks_ctx* ctx, ks_frame_stats* stats);
  * bubbles per frame); 2: only the k_apply dispatch of every 4th frame is timed (a few us/frame).
  * Events are resolved lazily, never by a host wait inside a frame. */
 int ks_profile_enable(ks_ctx* ctx, int level);
-/* KS_EARLY_OUT_EXACT contexts: frames integrated and fix-point iterations run so far (either may be NULL). */
+/* Exact early-out contexts: frames integrated and fix-point rounds run so far (either may be NULL). */
 int ks_early_out_iterations(ks_ctx* ctx, uint64_t* frames, uint64_t* iterations);
+/* ... and out[0] = frames, out[1] = rounds, out[2] = frames that fell back to the host-driven loop (buffers that had to
+ * grow, round limit), out[3] = 1 if the event-driven loop is in use, out[4] = 1 if frames are pipelined (returns KS_OK). */
+int ks_early_out_stats(ks_ctx* ctx, uint64_t out[5]);
 int ks_profile_get(ks_ctx* ctx, ks_profile* out, int reset);
 
 #ifdef __cplusplus

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "ks_integrate_points", "ks_integrate_points_device", "ks_integrate_depth", "ks_integrate_depth_device", "ks_num_blocks", "ks_get_block_indices",
     "ks_get_updated_block_indices", "ks_count_updated_voxels", "ks_download_updated_voxels", "ks_download_blocks", "ks_upload_blocks", "ks_host_alloc", "ks_host_free", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear", "ks_reset_tiles", "ks_tile_owner", "ks_reduce",
     "ks_debug_radix_sort", "ks_synchronize", "ks_flush", "ks_stream",
-    "ks_profile_enable", "ks_profile_get", "ks_early_out_iterations",
+    "ks_profile_enable", "ks_profile_get", "ks_early_out_iterations", "ks_early_out_stats",
 ]
 
 
@@ -138,6 +138,7 @@ def lib():
         L.ks_profile_enable.argtypes = [vp, C.c_int]
         L.ks_profile_get.argtypes = [vp, C.POINTER(KsProfile), C.c_int]
         L.ks_early_out_iterations.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.ks_early_out_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -359,6 +360,12 @@ class HipIntegrator:
     def profile_enable(self, level=1):
         """0 off, 1 all stages, 2 sampled k_apply dispatches only (see ks_hip.h)."""
         self._chk(lib().ks_profile_enable(self._h, int(level)))
+
+    def early_out_stats(self):
+        """Exact early-out: dict(frames, rounds, fallbacks, event_driven, pipelined)."""
+        out = (C.c_uint64 * 5)()
+        self._chk(lib().ks_early_out_stats(self._h, out))
+        return dict(frames=int(out[0]), rounds=int(out[1]), fallbacks=int(out[2]), event_driven=bool(out[3]), pipelined=bool(out[4]))
 
     def early_out_iterations(self):
         """(frames, fix-point iterations) of a KS_EARLY_OUT_EXACT context."""

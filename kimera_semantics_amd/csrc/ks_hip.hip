@@ -111,6 +111,23 @@ struct FrameSlot {
   uint64_t *d_gkeys = nullptr, *d_rkeys = nullptr;  // anti-grazing: this frame's sorted end-voxel keys / key per bundle
   hipGraphExec_t b_graph = nullptr; // stage B of this slot as a captured graph ...
   uint64_t b_graph_key = 0;         // ... valid for this (point count, buffers) key
+  // exact early-out, event-driven fix point (ks_k_exact.h): the slot's marks, per-slot table, X marks, lists; stage B is
+  // then THREE graphs (seed + marks + bulk rounds | finisher + commit | scan + emission) with the wait for the previous
+  // frame's commit between the first two
+  hipGraphExec_t b_graph2 = nullptr, b_graph3 = nullptr;
+  uint64_t* d_eo_keys[2] = {nullptr, nullptr};
+  uint32_t* d_eo_vals[2] = {nullptr, nullptr};
+  size_t eo_cap_marks = 0;
+  uint4* d_eo_tab = nullptr;
+  unsigned long long* d_eo_xnode = nullptr;
+  size_t eo_cap_x = 0;
+  uint32_t *d_eo_cnt_b = nullptr, *d_eo_ux = nullptr, *d_eo_dirty = nullptr, *d_eo_list[2] = {nullptr, nullptr}, *d_eo_chg = nullptr,
+           *d_eo_consulted = nullptr, *d_eo_lp = nullptr;
+  unsigned long long* d_eo_bt = nullptr;
+  EoCtl* d_eo_ctl = nullptr;
+  uint32_t* d_eo_sort_ws = nullptr;
+  size_t eo_sort_words = 0;
+  hipEvent_t eo_committed = nullptr;  // the frame's marks have entered the shared table
   Counters* d_counters = nullptr;   // inside ks_ctx::d_state
   uint32_t* d_ray_list = nullptr;   // rays to march (written by stage A, read by B)
   HostSnap* h_snap = nullptr;       // pinned + device-visible: written by k_publish at the end of B
@@ -235,6 +252,15 @@ struct ks_ctx {
   EoState* d_eo_state = nullptr;
   EoState* h_eo_state = nullptr;         // pinned
   uint64_t eo_iterations = 0, eo_frames = 0;  // statistics (ks_exact_early_out_stats)
+  // ... event-driven (the default; KS_EXACT_HOST_LOOP=1: every frame through the host-driven loop above)
+  bool eo_device = false;
+  int eo_bulk_rounds = 6;                // rounds enqueued as launches before the one-workgroup finisher takes over
+  uint32_t* d_eo_committed = nullptr;    // frames [0, *d_eo_committed) of the exact path have entered d_eo_plain
+  uint32_t eo_frame_no = 0;              // frames launched through the exact path
+  hipEvent_t eo_last_commit = nullptr;   // commit event of the previous frame (nullptr: nothing to wait for)
+  std::atomic<size_t> eo_want_marks{0}, eo_want_x{0};   // capacities a failed frame asked for (grown by the caller's thread between frames)
+  size_t eo_cap_marks = 0, eo_cap_x = 0; // per-slot capacities in use
+  uint64_t eo_fallbacks = 0;             // frames that fell back to the host-driven loop
   // merged in the reference's bundle order (ks_k_bundle_order.h): scratch of the rank computation, one slab
   bool use_bundle_rank = false;
   BoCtx bo{};
@@ -425,6 +451,7 @@ PrePlan pre_plan(const ks_ctx* c, size_t cap_points) {
   return P;
 }
 
+int ensure_exact_points(ks_ctx* c, size_t cap);
 int ensure_points(ks_ctx* c, size_t n) {
   if (n <= c->cap_points) return KS_OK;
   // the create-time size is exact; a cloud that outgrows it gets head-room (growing completes the frames in
@@ -478,6 +505,7 @@ int ensure_points(ks_ctx* c, size_t n) {
   if (c->exact_early_out) {
     if ((rc = dev_alloc(c, &c->d_eo_lp, cap))) return rc;
     if ((rc = dev_alloc(c, &c->d_eo_bt, cap / kScanBlock + 2))) return rc;
+    if ((rc = ensure_exact_points(c, cap))) return rc;
   }
   c->cap_points = cap;
   return KS_OK;
@@ -618,6 +646,7 @@ SlotView slot_view(const FrameSlot& S, Counters* counters = nullptr) {
   v.host_snap = (uint32_t*)S.h_snap;
   v.pre_hash = S.d_pre_hash;
   v.pre_steps = S.d_pre_steps;
+  v.eo_stats = S.d_eo_ctl ? &S.d_eo_ctl->n_x : nullptr;
   return v;
 }
 
@@ -713,8 +742,9 @@ int ensure_marks(ks_ctx* c, size_t n) {
   return KS_OK;
 }
 constexpr int kEoMaxIterations = 4096;
-int exact_early_out(ks_ctx* c, FrameSlot& S, hipStream_t st) {
+int exact_early_out(ks_ctx* c, FrameSlot& S, hipStream_t st, Counters* counters = nullptr) {
   const size_t n = S.n;
+  Counters* const d_counters = counters ? counters : S.d_counters;   // (the fallback of the event-driven path runs after k_publish has cleared the slot's own)
   const FrameParams* dF = S.d_F;
   EoState* hs = c->h_eo_state;
   HIPCHK(c, hipMemsetAsync(c->d_eo_state, 0, sizeof(EoState), st));
@@ -736,11 +766,11 @@ int exact_early_out(ks_ctx* c, FrameSlot& S, hipStream_t st) {
     hipLaunchKernelGGL(k_eo_scan, dim3(nb4k), dim3(1024), 0, st, dF, (const uint32_t*)S.d_cnt, c->d_eo_lp, c->d_eo_bt, c->d_eo_state);
     if (S.wide)
       hipLaunchKernelGGL(k_eo_emit<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), lds, st, dF, S.d_ray_list, S.d_rays, S.d_cnt,
-                         c->d_eo_lp, c->d_eo_bt, c->d_eo_keys[0], c->d_eo_vals[0], (unsigned long long)c->cap_marks, S.d_counters,
+                         c->d_eo_lp, c->d_eo_bt, c->d_eo_keys[0], c->d_eo_vals[0], (unsigned long long)c->cap_marks, d_counters,
                          c->d_eo_state);
     else
       hipLaunchKernelGGL(k_eo_emit<64>, dim3((uint32_t)((n + 255) / 256)), dim3(256), lds, st, dF, S.d_ray_list, S.d_rays, S.d_cnt,
-                         c->d_eo_lp, c->d_eo_bt, c->d_eo_keys[0], c->d_eo_vals[0], (unsigned long long)c->cap_marks, S.d_counters,
+                         c->d_eo_lp, c->d_eo_bt, c->d_eo_keys[0], c->d_eo_vals[0], (unsigned long long)c->cap_marks, d_counters,
                          c->d_eo_state);
     // stable sort on the slot bits only: a slot's marks stay in (position, step) order
     HIPCHK(c, (ksrs::sort<uint64_t, true>(c->sort_ws, c->d_eo_keys[0], c->d_eo_keys[1], c->d_eo_vals[0], c->d_eo_vals[1],
@@ -750,10 +780,10 @@ int exact_early_out(ks_ctx* c, FrameSlot& S, hipStream_t st) {
     EoBuf E{kres, vres, c->d_eo_range, c->d_eo_plain};
     if (S.wide)
       hipLaunchKernelGGL(k_eo_eval<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), 0, st, dF, S.d_ray_list, S.d_rays, S.d_cnt, E,
-                         S.d_counters, c->d_eo_state);
+                         d_counters, c->d_eo_state);
     else
       hipLaunchKernelGGL(k_eo_eval<16>, dim3((uint32_t)((n + 63) / 64)), dim3(256), 0, st, dF, S.d_ray_list, S.d_rays, S.d_cnt, E,
-                         S.d_counters, c->d_eo_state);
+                         d_counters, c->d_eo_state);
     HIPCHK(c, hipMemcpyAsync(hs, c->d_eo_state, sizeof(EoState), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
     if (hs->n_marks != n_marks) {
@@ -773,6 +803,119 @@ int exact_early_out(ks_ctx* c, FrameSlot& S, hipStream_t st) {
     hipLaunchKernelGGL(k_eo_commit, dim3((uint32_t)((n_marks + 255) / 256)), dim3(256), 0, st, n_marks, (const uint64_t*)kres,
                        (const uint32_t*)vres, c->d_eo_plain);
   return KS_OK;
+}
+
+// ---- exact early-out, event-driven (ks_k_exact.h) ----------------------------------------------------------------
+// Per-slot buffers: the marks are sized from what earlier frames needed (a frame that does not fit falls back to the
+// host-driven loop and asks for more: eo_want_*), everything else from the slot capacity.
+int ensure_exact_slots(ks_ctx* c, size_t cap_marks, size_t cap_x) {
+  if (!c->eo_device) return KS_OK;
+  int rc;
+  const int n_slots = c->cfg.pipeline_frames ? kSlots : 1;
+  for (int i = 0; i < n_slots; ++i) {
+    FrameSlot& S = c->slot[i];
+    if (!S.d_eo_ctl) {
+      if ((rc = dev_alloc(c, &S.d_eo_ctl, 1))) return rc;
+      if ((rc = dev_alloc(c, &S.d_eo_tab, (size_t)1 << kSetBits))) return rc;
+      HIPCHK(c, hipMemsetAsync(S.d_eo_tab, 0, sizeof(uint4) << kSetBits, c->stream));
+      HIPCHK(c, hipEventCreateWithFlags(&S.eo_committed, hipEventDisableTiming));
+    }
+    if (S.eo_cap_marks < cap_marks) {
+      for (int b = 0; b < 2; ++b) {
+        if ((rc = dev_alloc(c, &S.d_eo_keys[b], cap_marks))) return rc;
+        if ((rc = dev_alloc(c, &S.d_eo_vals[b], cap_marks))) return rc;
+      }
+      S.eo_sort_words = ksrs::ws_words_dev(cap_marks, 3);
+      if ((rc = dev_alloc(c, &S.d_eo_sort_ws, S.eo_sort_words))) return rc;
+      S.eo_cap_marks = cap_marks;
+    }
+    if (S.eo_cap_x < cap_x) {
+      if ((rc = dev_alloc(c, &S.d_eo_xnode, 2 * cap_x))) return rc;
+      S.eo_cap_x = cap_x;
+    }
+  }
+  c->eo_cap_marks = cap_marks;
+  c->eo_cap_x = cap_x;
+  ++c->buffers_epoch;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return KS_OK;
+}
+int ensure_exact_points(ks_ctx* c, size_t cap) {   // the per-position arrays (called by ensure_points)
+  if (!c->eo_device) return KS_OK;
+  int rc;
+  for (int i = 0; i < (c->cfg.pipeline_frames ? kSlots : 1); ++i) {
+    FrameSlot& S = c->slot[i];
+    for (uint32_t** p : {&S.d_eo_cnt_b, &S.d_eo_ux, &S.d_eo_dirty, &S.d_eo_list[0], &S.d_eo_list[1], &S.d_eo_chg, &S.d_eo_consulted, &S.d_eo_lp})
+      if ((rc = dev_alloc(c, p, cap))) return rc;
+    if ((rc = dev_alloc(c, &S.d_eo_bt, cap / kScanBlock + 2))) return rc;
+  }
+  return KS_OK;
+}
+EoView eo_view(ks_ctx* c, const FrameSlot& S) {
+  EoView E{};
+  E.F = S.d_F;
+  E.ray_list = S.d_ray_list;
+  E.rays = S.d_rays;
+  E.C = S.d_counters;
+  E.cnt_a = S.d_cnt;
+  E.cnt_b = S.d_eo_cnt_b;
+  E.ux = S.d_eo_ux;
+  E.dirty = S.d_eo_dirty;
+  E.keys = S.d_eo_keys[1];   // three radix passes: the sorted marks end up in the second buffer set
+  E.vals = S.d_eo_vals[1];
+  E.tab = S.d_eo_tab;
+  E.xnode = S.d_eo_xnode;
+  E.cap_x = (uint32_t)S.eo_cap_x;
+  E.list[0] = S.d_eo_list[0];
+  E.list[1] = S.d_eo_list[1];
+  E.chg = S.d_eo_chg;
+  E.consulted = S.d_eo_consulted;
+  E.plain = c->d_eo_plain;
+  E.committed = c->d_eo_committed;
+  E.ctl = S.d_eo_ctl;
+  return E;
+}
+// part 1: the seed's marks, sorted by slot, and the bulk rounds (after the ordered phases, which leave the seed in S.d_cnt)
+int enqueue_exact_rounds(ks_ctx* c, FrameSlot& S, hipStream_t st) {
+  const size_t n = c->cap_points;   // (grids by capacity: the kernels read the frame's own counts)
+  const uint32_t nb4k = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
+  const size_t lds = (size_t)nb4k * sizeof(unsigned long long);
+  EoCtl* ctl = S.d_eo_ctl;
+  hipLaunchKernelGGL(k_eo2_begin, dim3(1), dim3(64), 0, st, ctl);
+  hipLaunchKernelGGL(k_eo_scan, dim3(nb4k), dim3(1024), 0, st, (const FrameParams*)S.d_F, (const uint32_t*)S.d_cnt, S.d_eo_lp, S.d_eo_bt, &ctl->st,
+                     S.d_eo_cnt_b, S.d_eo_ux, S.d_eo_dirty);
+  if (S.wide)
+    hipLaunchKernelGGL(k_eo_emit<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), lds, st, (const FrameParams*)S.d_F, (const uint32_t*)S.d_ray_list,
+                       (const RayDesc*)S.d_rays, (const uint32_t*)S.d_cnt, (const uint32_t*)S.d_eo_lp, (const unsigned long long*)S.d_eo_bt,
+                       S.d_eo_keys[0], S.d_eo_vals[0], (unsigned long long)S.eo_cap_marks, (const Counters*)S.d_counters, &ctl->st, &ctl->fail);
+  else
+    hipLaunchKernelGGL(k_eo_emit<64>, dim3((uint32_t)((n + 255) / 256)), dim3(256), lds, st, (const FrameParams*)S.d_F, (const uint32_t*)S.d_ray_list,
+                       (const RayDesc*)S.d_rays, (const uint32_t*)S.d_cnt, (const uint32_t*)S.d_eo_lp, (const unsigned long long*)S.d_eo_bt,
+                       S.d_eo_keys[0], S.d_eo_vals[0], (unsigned long long)S.eo_cap_marks, (const Counters*)S.d_counters, &ctl->st, &ctl->fail);
+  uint64_t* kres = nullptr;
+  uint32_t* vres = nullptr;
+  // stable sort on the slot bits only: a slot's marks stay in (position, step) order
+  HIPCHK(c, ksrs::sort_dev<uint64_t>(S.d_eo_sort_ws, S.eo_sort_words, S.d_eo_keys[0], S.d_eo_keys[1], S.d_eo_vals[0], S.d_eo_vals[1],
+                                     (const unsigned long long*)&ctl->st.n_marks, S.eo_cap_marks, 44, 64, st, &kres, &vres));
+  if (kres != S.d_eo_keys[1] || vres != S.d_eo_vals[1]) {
+    c->err = "exact early-out: the mark sort ended in the wrong buffer";
+    return KS_ERR_HIP;
+  }
+  const EoView E = eo_view(c, S);
+  const uint32_t gm = (uint32_t)std::min<size_t>((S.eo_cap_marks + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_eo2_index, dim3(gm), dim3(256), 0, st, E);
+  const uint32_t gr = (uint32_t)std::min<size_t>((n + 3) / 4, 2048);   // wavefront per ray, grid-stride
+  for (int r = 0; r < c->eo_bulk_rounds; ++r) {
+    hipLaunchKernelGGL(k_eo2_eval, dim3(r == 0 ? gr : std::min(gr, 512u)), dim3(256), 0, st, E, (uint32_t)r);
+    hipLaunchKernelGGL(k_eo2_propagate, dim3(std::min(gr, 512u)), dim3(256), 0, st, E, (uint32_t)r);
+  }
+  return KS_OK;
+}
+// part 2: what is left, by one workgroup, and the frame's marks into the shared table
+void enqueue_exact_finish(ks_ctx* c, FrameSlot& S, hipStream_t st) {
+  const EoView E = eo_view(c, S);
+  hipLaunchKernelGGL(k_eo2_finish, dim3(1), dim3(kEoFinishThreads), 0, st, E, (uint32_t)c->eo_bulk_rounds, 1u);
+  hipLaunchKernelGGL(k_eo2_commit, dim3(1024), dim3(256), 0, st, E);
 }
 
 // Stage B of the frames whose stage A has been enqueued (consecutive frames, at most kBatchMax): ONE sequence of
@@ -798,6 +941,7 @@ int launch_batch(ks_ctx* c) {
   for (uint32_t k = 0; k < nb; ++k) {
     FrameSlot& S = *slots[k];
     S.F.observed = observed_table(c, S.frame_no);
+    if (c->exact_early_out) S.F.eo_frame = c->eo_frame_no++;
     hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sm, S.F, S.d_F);
     V.s[k] = slot_view(S);
     steps_max = std::max(steps_max, S.steps_max);
@@ -805,7 +949,61 @@ int launch_batch(ks_ctx* c) {
   const uint64_t key = ((uint64_t)c->cap_points << 24) ^ (c->buffers_epoch.load() << 4) ^ (S0.wide ? 1u : 0u) ^ ((uint64_t)nb << 1);
   bool replayed = false;
   int rc;
-  if (c->exact_early_out) {
+  if (c->exact_early_out && c->eo_device) {
+    // (batches of one) the ordered phases give the seed; the event-driven fix point makes it the serial result, on the
+    // device: three replayed graphs, the wait for the previous frame's marks between the first two
+    bool graphs = c->use_graphs;
+    if (graphs && (S0.b_graph_key != key || !S0.b_graph || !S0.b_graph2 || !S0.b_graph3)) {
+      std::lock_guard<std::mutex> cap(c->capture_mu);
+      for (hipGraphExec_t* g : {&S0.b_graph, &S0.b_graph2, &S0.b_graph3}) {
+        if (*g) (void)hipGraphExecDestroy(*g);
+        *g = nullptr;
+      }
+      S0.b_graph_key = 0;
+      int part_rc = KS_OK;
+      auto capture = [&](hipGraphExec_t* out, int part) -> bool {
+        hipGraph_t g = nullptr;
+        bool ok = hipStreamBeginCapture(sm, hipStreamCaptureModeRelaxed) == hipSuccess;
+        if (ok) {
+          if (part == 1) {
+            enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
+            part_rc = enqueue_exact_rounds(c, S0, sm);
+          } else if (part == 2) {
+            enqueue_exact_finish(c, S0, sm);
+          } else {
+            enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 2);
+          }
+          ok = hipStreamEndCapture(sm, &g) == hipSuccess && g != nullptr && part_rc == KS_OK;
+        }
+        if (ok) ok = hipGraphInstantiate(out, g, nullptr, nullptr, 0) == hipSuccess;
+        if (g) (void)hipGraphDestroy(g);
+        return ok;
+      };
+      if (capture(&S0.b_graph, 1) && capture(&S0.b_graph2, 2) && capture(&S0.b_graph3, 3)) {
+        S0.b_graph_key = key;
+      } else {
+        (void)hipGetLastError();
+        for (hipGraphExec_t* g : {&S0.b_graph, &S0.b_graph2, &S0.b_graph3}) {
+          if (*g) (void)hipGraphExecDestroy(*g);
+          *g = nullptr;
+        }
+        c->use_graphs = graphs = false;  // plain launches from now on
+      }
+    }
+    if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph, sm));
+    else {
+      enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
+      if ((rc = enqueue_exact_rounds(c, S0, sm))) return rc;
+    }
+    if (c->eo_last_commit && c->eo_last_commit != S0.eo_committed) HIPCHK(c, hipStreamWaitEvent(sm, c->eo_last_commit, 0));
+    if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph2, sm));
+    else enqueue_exact_finish(c, S0, sm);
+    HIPCHK(c, hipEventRecord(S0.eo_committed, sm));
+    c->eo_last_commit = S0.eo_committed;
+    if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph3, sm));
+    else enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 2);
+    replayed = true;
+  } else if (c->exact_early_out) {
     // (batches of one) the ordered phases give the seed; the fix-point iteration (host waits inside) makes it the serial result
     enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
     if ((rc = exact_early_out(c, S0, sm))) return rc;
@@ -1036,6 +1234,42 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   const uint32_t tiles_before = c->tiles_initialised;
   const int set = S.prof_set;
   stage_mark(c, set, 6);
+  if (c->eo_device) {
+    c->eo_frames += 1;
+    c->eo_iterations += S.h_snap->pad[2];   // rounds of the event-driven fix point (k_publish)
+  }
+  if ((cnt.err & kErrExact) && !(cnt.err & (kErrLabel | kErrIndex))) {
+    // The device-driven fix point gave up (marks or X marks did not fit, the finisher ran out of rounds, or the frame
+    // before this one fell back and had not entered its marks yet): the host-driven loop repeats the fix point from
+    // whatever lengths the slot holds (any seed converges), enters the marks, and scan + emission run again — as after a
+    // pair-buffer overflow, on the tail stream only.  Nothing was emitted and no tile was allocated by this frame.
+    int rc;
+    HIPCHK(c, hipStreamSynchronize(st));
+    EoCtl hctl;
+    HIPCHK(c, hipMemcpy(&hctl, S.d_eo_ctl, sizeof(hctl), hipMemcpyDeviceToHost));
+    if (hctl.fail & kEoFailMarks)
+      c->eo_want_marks.store(std::max<size_t>(2 * c->eo_cap_marks, (size_t)hctl.st.n_marks + (size_t)hctl.st.n_marks / 4), std::memory_order_relaxed);
+    if (hctl.fail & kEoFailX) c->eo_want_x.store(4 * c->eo_cap_x, std::memory_order_relaxed);
+    ++c->eo_fallbacks;
+    Counters rcnt{};
+    rcnt.n_rays = cnt.n_rays;
+    HIPCHK(c, hipMemcpyAsync(c->d_retry_counters, &rcnt, sizeof(rcnt), hipMemcpyHostToDevice, st));
+    if ((rc = exact_early_out(c, S, st, c->d_retry_counters))) return rc;
+    HIPCHK(c, hipMemsetD32Async((hipDeviceptr_t)c->d_eo_committed, (int)(S.F.eo_frame + 1u), 1, st));
+    {
+      BatchView V{};
+      V.s[0] = slot_view(S, c->d_retry_counters);
+      hipLaunchKernelGGL(k_scan_local, dim3((uint32_t)((c->cap_points + kScanBlock - 1) / kScanBlock), 1), dim3(1024), 0, st, V);
+      launch_emit(c, V, 1, S.wide, st);
+    }
+    HIPCHK(c, hipMemcpyAsync(&rcnt, c->d_retry_counters, sizeof(rcnt), hipMemcpyDeviceToHost, st));
+    uint32_t nt = 0;
+    HIPCHK(c, hipMemcpyAsync(&nt, c->table.n_tiles, sizeof(nt), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    cnt.err = rcnt.err;
+    cnt.n_pairs = rcnt.n_pairs;
+    new_tiles = std::min(nt, c->cfg.max_tiles);
+  }
   c->pairs_hint.store(std::max<size_t>(c->pairs_hint.load(std::memory_order_relaxed), cnt.n_pairs), std::memory_order_relaxed);
   if ((cnt.err & kErrPairs) && !(cnt.err & ~kErrPairs)) {
     // The frame's pairs did not fit the buffer sized from earlier frames: nothing was written and no tile
@@ -1361,6 +1595,13 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
     if ((rc = quiesce(c))) return rc;
     if ((rc = ensure_points(c, n))) return rc;
   }
+  if (c->eo_device) {
+    const size_t wm = c->eo_want_marks.load(std::memory_order_relaxed), wx = c->eo_want_x.load(std::memory_order_relaxed);
+    if (wm > c->eo_cap_marks || wx > c->eo_cap_x) {
+      if ((rc = quiesce(c))) return rc;
+      if ((rc = ensure_exact_slots(c, std::max(wm, c->eo_cap_marks), std::max(wx, c->eo_cap_x)))) return rc;
+    }
+  }
   if (!pipelined) {
     if ((rc = quiesce(c))) return rc;
     FrameSlot& S = c->slot[0];
@@ -1528,7 +1769,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   }
   if (cfg->early_out_phase_growth != 0 && cfg->early_out_phase_growth != KS_EARLY_OUT_EXACT &&
       (cfg->early_out_phase_growth < 16 || cfg->early_out_phase_growth > 4096)) {
-    g_create_error = "early_out_phase_growth must be 0 (default: 32 = doubling phases), KS_EARLY_OUT_EXACT, or 16..4096 (in 1/16ths)";
+    g_create_error = "early_out_phase_growth must be 0 / KS_EARLY_OUT_EXACT (the reference's serial result) or 16..4096 (ordered phases, growth in 1/16ths)";
     return KS_ERR_INVALID_ARG;
   }
   // the early-out can never fire if the threshold exceeds the longest possible ray
@@ -1545,9 +1786,23 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   }
   ks_ctx* c = new ks_ctx();
   c->cfg = *cfg;
-  c->exact_early_out = uses_early_out && cfg->early_out_phase_growth == KS_EARLY_OUT_EXACT;
-  if (c->cfg.early_out_phase_growth == 0 || c->exact_early_out) c->cfg.early_out_phase_growth = 32;  // (exact: the seed's schedule)
-  if (c->exact_early_out) c->cfg.pipeline_frames = 0;  // the fix-point iteration waits for the device: one frame at a time
+  const bool want_exact = cfg->early_out_phase_growth == 0 || cfg->early_out_phase_growth == KS_EARLY_OUT_EXACT;
+  c->exact_early_out = uses_early_out && want_exact;
+  if (want_exact) {
+    c->cfg.early_out_phase_growth = 32;  // the seed's schedule
+    if (const char* sg = getenv("KS_EXACT_SEED_GROWTH")) c->cfg.early_out_phase_growth = std::min(4096, std::max(16, atoi(sg)));   // tuning runs
+  }
+  {
+    const char* hl = getenv("KS_EXACT_HOST_LOOP");   // diagnostics / A-B: the host-driven fix-point loop of round 3 for every frame
+    c->eo_device = c->exact_early_out && !(hl && hl[0] == '1');
+    // The host-driven loop waits for the device per iteration: one frame at a time.  The event-driven fix point is
+    // pipelined as long as a frame's marks are never seen by the next one (every frame bumps the set offset): what is left
+    // of the dependence between frames — the zero-initialised slot — is carried by the commit events.
+    if (c->exact_early_out && (!c->eo_device || c->cfg.clear_checks_every_n_frames > 1)) c->cfg.pipeline_frames = 0;
+    const bool wide_rays = steps_max_of(c->cfg, (float)(1.0 / cfg->voxel_size)) > 400;
+    c->eo_bulk_rounds = wide_rays ? 24 : 6;
+    if (const char* br = getenv("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
+  }
   c->uses_early_out = uses_early_out;
   c->use_bundle_rank = cfg->method == KS_METHOD_MERGED && cfg->bundle_order == KS_BUNDLE_ORDER_REFERENCE;
   {
@@ -1671,6 +1926,8 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipMemcpy(c->d_start_set, &poison, 8, hipMemcpyHostToDevice));
   CRCHK(hipMalloc((void**)&c->d_retry_counters, sizeof(Counters)));
   if (c->exact_early_out) {
+    CRCHK(hipMalloc((void**)&c->d_eo_committed, 64));
+    CRCHK(hipMemset(c->d_eo_committed, 0, 64));
     CRCHK(hipMalloc((void**)&c->d_eo_range, sizeof(uint2) << kSetBits));
     CRCHK(hipMalloc((void**)&c->d_eo_plain, sizeof(uint64_t) << kSetBits));
     CRCHK(hipMemset(c->d_eo_plain, 0, sizeof(uint64_t) << kSetBits));
@@ -1701,7 +1958,11 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   // pair buffers start at 4 updates per point of the largest cloud (a frame that needs more grows its buffer and
   // repeats the emission once)
   c->pairs_hint.store((size_t)cfg->max_points * 4, std::memory_order_relaxed);
-  if (ensure_points(c, cfg->max_points) != KS_OK) {
+  size_t eo_marks0 = std::max<size_t>((size_t)1 << 20, 4 * (size_t)cfg->max_points), eo_x0 = std::max<size_t>((size_t)1 << 16, (size_t)cfg->max_points / 2);
+  // (tests: start small, so that the overflow -> host-driven loop -> grow path is exercised)
+  if (const char* e = getenv("KS_EXACT_CAP_MARKS")) eo_marks0 = std::max<size_t>(64, (size_t)atoll(e));
+  if (const char* e = getenv("KS_EXACT_CAP_X")) eo_x0 = std::max<size_t>(8, (size_t)atoll(e));
+  if (ensure_points(c, cfg->max_points) != KS_OK || ensure_exact_slots(c, eo_marks0, eo_x0) != KS_OK) {
     g_create_error = c->err;
     ks_destroy(c);
     return KS_ERR_HIP;
@@ -1743,10 +2004,18 @@ void ks_destroy(ks_ctx* c) {
                   c->d_eo_state, c->d_rx_counts, c->d_tx_keys, c->d_rx_keys, c->d_tx_slots, c->d_tx_payload, c->d_rx_payload};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  for (auto& S : c->slot)
+  for (auto& S : c->slot) {
     for (void* p : {(void*)S.d_rays, (void*)S.d_deltas, (void*)S.d_ray_list, (void*)S.d_pairs, (void*)S.d_cnt, (void*)S.d_lp,
-                    (void*)S.d_bt, (void*)S.d_live, (void*)S.d_F, (void*)S.d_gkeys, (void*)S.d_rkeys, (void*)S.d_pre_hash, (void*)S.d_pre_steps})
+                    (void*)S.d_bt, (void*)S.d_live, (void*)S.d_F, (void*)S.d_gkeys, (void*)S.d_rkeys, (void*)S.d_pre_hash, (void*)S.d_pre_steps,
+                    (void*)S.d_eo_keys[0], (void*)S.d_eo_keys[1], (void*)S.d_eo_vals[0], (void*)S.d_eo_vals[1], (void*)S.d_eo_tab, (void*)S.d_eo_xnode,
+                    (void*)S.d_eo_cnt_b, (void*)S.d_eo_ux, (void*)S.d_eo_dirty, (void*)S.d_eo_list[0], (void*)S.d_eo_list[1], (void*)S.d_eo_chg,
+                    (void*)S.d_eo_consulted, (void*)S.d_eo_lp, (void*)S.d_eo_bt, (void*)S.d_eo_ctl, (void*)S.d_eo_sort_ws})
       if (p) (void)hipFree(p);
+    if (S.b_graph2) (void)hipGraphExecDestroy(S.b_graph2);
+    if (S.b_graph3) (void)hipGraphExecDestroy(S.b_graph3);
+    if (S.eo_committed) (void)hipEventDestroy(S.eo_committed);
+  }
+  if (c->d_eo_committed) (void)hipFree(c->d_eo_committed);
   if (c->h_eo_state) (void)hipHostFree(c->h_eo_state);
   ksrs::release(c->sort_ws);
   ksrs::release(c->sort_ws_tail);
@@ -2420,6 +2689,9 @@ int ks_clear(ks_ctx* c) {
   if (c->d_eo_plain) {
     HIPCHK(c, hipMemset(c->d_eo_plain, 0, sizeof(uint64_t) << kSetBits));
     HIPCHK(c, hipMemcpy(c->d_eo_plain, &poison, 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemset(c->d_eo_committed, 0, 64));
+    c->eo_frame_no = 0;
+    c->eo_last_commit = nullptr;
   }
   c->start_offset = c->observed_offset = 0;
   c->reset_counter = 0;
@@ -2463,6 +2735,16 @@ int ks_early_out_iterations(ks_ctx* c, uint64_t* frames, uint64_t* iterations) {
   if (!c) return KS_ERR_INVALID_ARG;
   if (frames) *frames = c->eo_frames;
   if (iterations) *iterations = c->eo_iterations;
+  return KS_OK;
+}
+
+int ks_early_out_stats(ks_ctx* c, uint64_t out[5]) {
+  if (!c || !out) return KS_ERR_INVALID_ARG;
+  out[0] = c->eo_frames;
+  out[1] = c->eo_iterations;
+  out[2] = c->eo_fallbacks;
+  out[3] = c->eo_device ? 1 : 0;
+  out[4] = (c->exact_early_out && c->cfg.pipeline_frames > 0) ? 1 : 0;
   return KS_OK;
 }
 

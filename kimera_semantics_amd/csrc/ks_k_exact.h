@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(256) k_eo_commit(unsigned long long n_marks, c
 // boundary (or a workgroup barrier in the finisher): only the dirty flags, the list counters and the X chains are touched
 // by atomics.  The fixed point is unique (ks_k_exact.h, top), so the order of the lists does not matter.
 // A fixed number of bulk rounds is enqueued; k_eo2_finish (ONE workgroup) then iterates until nothing is dirty.
-// oracle/ks_oracle.cpp: ko_sim_fixpoint is the CPU study of this scheme (round counts, list sizes, X marks).
+// (tools/fixpoint_study.py is the CPU study of this scheme: round counts, list sizes, X marks.)
 // ==========================================================================================================
 constexpr uint32_t kEoBulkMax = 40;          // bulk rounds a launch sequence can hold
 constexpr uint32_t kEoFailMarks = 1u, kEoFailX = 2u, kEoFailRounds = 4u, kEoFailChain = 8u;
@@ -380,8 +380,7 @@ struct EoView {
   uint32_t* chg;                  // rays whose length changed this round
   uint32_t* consulted;
   uint64_t* plain;                // the reference's table as earlier frames left it
-  uint32_t* committed;            // frames [0, *committed) have entered `plain`
-  uint32_t frame;                 // this frame's number
+  uint32_t* committed;            // frames [0, *committed) have entered `plain` (this frame's number: FrameParams::eo_frame)
   EoCtl* ctl;
 };
 
@@ -656,7 +655,7 @@ __global__ void __launch_bounds__(kEoFinishThreads) k_eo2_finish(EoView E, uint3
   uint32_t cur = first_round & 1u;
   if (threadIdx.x == 0) {
     // (a predecessor that fell back to the host-driven loop has not entered its marks yet: this frame follows it there)
-    if (chained && eo2_ld(E.committed) != E.frame) atomicOr(&ctl->fail, kEoFailChain);
+    if (chained && eo2_ld(E.committed) != F.eo_frame) atomicOr(&ctl->fail, kEoFailChain);
     ctl->fin_in[cur] = ctl->n_in[first_round];
     ctl->fin_in[cur ^ 1u] = 0u;
     ctl->fin_chg = 0u;
@@ -736,7 +735,7 @@ __global__ void __launch_bounds__(256) k_eo2_commit(EoView E) {
     }
     if (found) E.plain[slot] = (uint64_t)hash;
   }
-  if (ok && blockIdx.x == 0 && threadIdx.x == 0) *E.committed = E.frame + 1u;
+  if (ok && blockIdx.x == 0 && threadIdx.x == 0) *E.committed = E.F->eo_frame + 1u;
 }
 
 // start of a frame's fix point: counters (n_x = 1: node 0 is the end of a chain)

@@ -188,6 +188,7 @@ struct SlotView {
   unsigned long long pairs_cap;
   Counters* C;
   uint32_t* host_snap;           // pinned snapshot (k_publish)
+  const uint32_t* eo_stats;      // exact early-out, event-driven: {X marks + 1, failure bits, rounds} of the frame (else nullptr)
   uint32_t* pre_hash;            // k_prewalk -> k_test_pre: voxel hashes of the rays of the first generations, [chain][generation][cap]
   int* pre_steps;                //   and their step counts (-1 = no ray), [chain][generation]
 };
@@ -955,7 +956,7 @@ __global__ void __launch_bounds__(256) k_emit(BatchView V, TileTable T, Pool P) 
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&C->err, kErrPairs);
     return;
   }
-  if (C->err & (kErrLabel | kErrIndex)) return;
+  if (C->err & (kErrLabel | kErrIndex | kErrExact)) return;
   const LaneGroup<LPR> G;
   const uint32_t n_rays = C->n_rays;
   const uint32_t r = (blockIdx.x * 256u + threadIdx.x) / LPR;
@@ -1069,7 +1070,7 @@ __global__ void __launch_bounds__(256) k_emit_lane(BatchView V, TileTable T, Poo
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&C->err, kErrPairs);
     return;
   }
-  if (C->err & (kErrLabel | kErrIndex)) return;
+  if (C->err & (kErrLabel | kErrIndex | kErrExact)) return;
   const uint32_t lane = lane_id();
   const uint32_t n_rays = C->n_rays;
   const uint32_t r = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)RPW + lane;
@@ -1218,6 +1219,8 @@ __global__ void __launch_bounds__(64) k_publish(BatchView V, const uint32_t* __r
     ((uint32_t*)C)[threadIdx.x] = 0u;
   }
   if (threadIdx.x == 8) host_snap[8] = *n_tiles;
+  const uint32_t* eo_stats = V.s[blockIdx.x].eo_stats;
+  if (eo_stats && threadIdx.x >= 9 && threadIdx.x < 12) host_snap[threadIdx.x] = eo_stats[threadIdx.x - 9];
 }
 
 __global__ void __launch_bounds__(512) k_init_tiles(Pool P, uint32_t first_slot) {

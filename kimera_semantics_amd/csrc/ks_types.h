@@ -160,6 +160,7 @@ struct FrameParams {
   uint32_t seq_bits;         // low bits of a pair key hold the ray sequence
   uint32_t point_mask;       // (1 << bits_for(n)) - 1
   uint32_t clear_bit;        // merged: sequence bit that orders clearing bundles last
+  uint32_t eo_frame;         // fast, exact early-out: number of the frame among those of the exact path (ks_k_exact.h)
   uint8_t dynamic_labels[32];
 };
 

@@ -1,5 +1,5 @@
-"""-m gpu: `fast` with the early-out enabled in the reference's SERIAL order (KS_EARLY_OUT_EXACT,
-csrc/ks_k_exact.h).  The reference's loop (semantic_tsdf_integrator_fast.cpp:110-122) is serial by construction;
+"""-m gpu: `fast` with the early-out enabled in the reference's SERIAL order (the library's default since round 4;
+KS_EARLY_OUT_EXACT / early_out_phase_growth = 0, csrc/ks_k_exact.h).  The reference's loop (semantic_tsdf_integrator_fast.cpp:110-122) is serial by construction;
 at integrator_threads = 1 it is deterministic, and that result is what this mode must reproduce bit for bit:
 against the oracle's serial restatement (several frames, configuration variants, the zero-hash slot artefact of
 ApproxHashSet), against the REAL reference sources (oracle/_ref), and against the golden digest generated
@@ -45,7 +45,7 @@ def test_exact_early_out_equals_serial_oracle(size, frames):
     print(f"exact early-out {size}: {it / nf:.1f} fix-point iterations per frame")
 
 
-@pytest.mark.parametrize("variant", ["clear_every_3", "sorted_order", "subsample_1", "limit_0", "limit_5", "no_carving", "pipeline_ignored"])
+@pytest.mark.parametrize("variant", ["clear_every_3", "sorted_order", "subsample_1", "limit_0", "limit_5", "no_carving", "pipelined_3", "clear_every_3_pipelined"])
 def test_exact_early_out_variants(variant):
     kw = {}
     pipe = 0
@@ -61,8 +61,11 @@ def test_exact_early_out_variants(variant):
         kw["max_consecutive_ray_collisions"] = 5
     elif variant == "no_carving":
         kw["voxel_carving_enabled"] = 0
-    elif variant == "pipeline_ignored":
+    elif variant == "pipelined_3":
         pipe = 3
+    elif variant == "clear_every_3_pipelined":   # (a frame's marks are inputs of the next frame: the library runs one frame at a time)
+        kw["clear_checks_every_n_frames"] = 3
+        pipe = 4
     okw = dict(COMMON, method=0, **kw)
     o = O.Oracle(O.default_config(**okw))
     h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, pipeline_frames=pipe,
@@ -130,3 +133,103 @@ def test_exact_early_out_reproduces_reference_golden():
     name = "ref_fast_default_640x480"
     _check(B.HipIntegrator(B.default_config(max_tiles=1 << 15, max_points=1 << 19, early_out_phase_growth=B.KS_EARLY_OUT_EXACT,
                                             **_cfg(name))), name)
+
+
+def _frames(n, size=(320, 240), first=0):
+    sc = synth.make_scene("room")
+    return [synth.render_frame(sc, synth.trajectory_pose(first + 3 * k), size[0], size[1], seed=70 + k) for k in range(n)]
+
+
+def _totals(o, h, frames):
+    to = tg = 0
+    for f in frames:
+        to += o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
+        tg += h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
+    tg += h.flush().n_voxel_updates
+    assert to == tg
+    return compare_maps(o, h, exact=True)
+
+
+def test_default_configuration_is_the_serial_result():
+    """early_out_phase_growth = 0 (ks_default_config): the reference's serial result, by the event-driven loop."""
+    okw = dict(COMMON, method=0)
+    o = O.Oracle(O.default_config(**okw))
+    h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 17, **okw))
+    _totals(o, h, _frames(3))
+    st = h.early_out_stats()
+    assert st["event_driven"] and st["frames"] == 3 and st["fallbacks"] == 0 and st["rounds"] >= 3, st
+
+
+@pytest.mark.parametrize("pipe", [2, 4, 8])
+def test_exact_early_out_pipelined(pipe):
+    """frames in flight: the fix point of frame i + 1 runs beside that of frame i; what is left of the dependence
+    between frames (the table earlier frames leave behind) is carried by the commit events."""
+    okw = dict(COMMON, method=0)
+    o = O.Oracle(O.default_config(**okw))
+    h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 17, pipeline_frames=pipe, **okw))
+    _totals(o, h, _frames(14))
+    st = h.early_out_stats()
+    assert st["event_driven"] and st["pipelined"] and st["frames"] == 14 and st["fallbacks"] == 0, st
+    print(f"pipeline {pipe}: {st['rounds'] / st['frames']:.1f} rounds per frame")
+
+
+def test_exact_early_out_zero_hash_slot_artefact_pipelined():
+    okw = dict(COMMON, method=0)
+    o = O.Oracle(O.default_config(**okw))
+    h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 17, pipeline_frames=4, **okw))
+    sc = synth.make_scene("room")
+    frames = [synth.render_frame(sc, synth.pose_to_T((-1.5 + 0.1 * k, 0.02, 1.5), 0.0, math.radians(45.0)), 200, 150, seed=k) for k in range(9)]
+    _totals(o, h, frames)
+    assert h.early_out_stats()["fallbacks"] == 0
+
+
+@pytest.mark.parametrize("pipe", [0, 4])
+def test_exact_early_out_falls_back_to_the_host_loop_and_grows(monkeypatch, pipe):
+    """marks / X marks that do not fit: the frame (and the frames in flight behind it) repeat their fix point through
+    the host-driven loop, the buffers grow, later frames run on the device again — same map."""
+    monkeypatch.setenv("KS_EXACT_CAP_MARKS", "30000")
+    monkeypatch.setenv("KS_EXACT_CAP_X", "16")
+    okw = dict(COMMON, method=0)
+    o = O.Oracle(O.default_config(**okw))
+    h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 17, pipeline_frames=pipe, **okw))
+    monkeypatch.delenv("KS_EXACT_CAP_MARKS")
+    monkeypatch.delenv("KS_EXACT_CAP_X")
+    _totals(o, h, _frames(12))
+    st = h.early_out_stats()
+    assert 0 < st["fallbacks"] < 12, st
+
+
+def test_exact_early_out_host_loop_switch(monkeypatch):
+    monkeypatch.setenv("KS_EXACT_HOST_LOOP", "1")
+    okw = dict(COMMON, method=0)
+    o = O.Oracle(O.default_config(**okw))
+    h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 17, pipeline_frames=4, **okw))
+    monkeypatch.delenv("KS_EXACT_HOST_LOOP")
+    _totals(o, h, _frames(3))
+    st = h.early_out_stats()
+    assert not st["event_driven"] and not st["pipelined"], st
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
+def test_full_size_c4_frame_exact_early_out_vs_real_reference(tmp_path):
+    """One FULL-SIZE C4 frame (1280x720, 2 cm voxels, 10 m rays, 75 deg), default `fast` (early-out after 2 consecutive
+    observed voxels): HIP == the real reference sources at integrator_threads = 1, every voxel."""
+    geom = dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=10.0)
+    csv = str(tmp_path / "labels.csv")
+    R.write_label_csv(csv, synth.default_label_colors())
+    r = R.Reference("fast", csv, voxel_size=geom["voxel_size"], truncation=geom["truncation_distance"], max_ray=geom["max_ray_length_m"])
+    h = B.HipIntegrator(B.default_config(max_tiles=1 << 16, max_points=1280 * 720, **dict(COMMON, method=0, **geom)))
+    f = synth.render_frame(synth.make_scene("hall"), synth.trajectory_pose(3, radius=3.0), 1280, 720, hfov_deg=75.0, seed=3)
+    r.integrate(f.T_G_C, f.xyz, f.rgba)
+    st = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    assert st.n_voxel_updates > 1e7
+    print("C4 frame, exact early-out:", st.n_voxel_updates, "updates;", h.early_out_stats())
+    ri, hi = r.block_indices(), h.block_indices()
+    assert np.array_equal(ri, hi)
+    _, rt, rs = r.download(ri)
+    _, ht, hs = h.download(ri)
+    assert np.array_equal(rs["label"], hs["label"])
+    assert np.array_equal(rs["priors"].view(np.uint32), hs["priors"].view(np.uint32))
+    assert np.array_equal(rt["distance"].view(np.uint32), ht["distance"].view(np.uint32))
+    assert np.array_equal(rt["weight"].view(np.uint32), ht["weight"].view(np.uint32))
+    assert np.array_equal(rt["color"], ht["color"]) and np.array_equal(rs["color"], hs["color"])

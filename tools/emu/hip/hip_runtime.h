@@ -433,6 +433,7 @@ inline float __builtin_amdgcn_fmed3f_emu(float a, float b, float c) {   // v_med
   return c < lo ? lo : (c > hi ? hi : c);
 }
 #define __builtin_amdgcn_fmed3f(a, b, c) __builtin_amdgcn_fmed3f_emu((a), (b), (c))
+inline void __threadfence() {}   // (blocks run one after the other, lanes between two rendezvous points too: nothing to order)
 #define __hip_atomic_load(p, order, scope) (*(p))
 #define __hip_atomic_store(p, v, order, scope) (*(p) = (v))
 #define __hip_atomic_fetch_max(p, v, order, scope) emu_fetch_max((p), (v))
@@ -507,6 +508,13 @@ inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { e
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t st = nullptr) { emu::touch(st); memmove(d, s, n); emu::touch(st); return hipSuccess; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { emu::touch((ihipStream_t*)nullptr); memset(d, v, n); emu::touch((ihipStream_t*)nullptr); return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = nullptr) { emu::touch(st); memset(d, v, n); emu::touch(st); return hipSuccess; }
+typedef void* hipDeviceptr_t;
+inline hipError_t hipMemsetD32Async(hipDeviceptr_t d, int v, size_t count, hipStream_t st = nullptr) {
+  emu::touch(st);
+  for (size_t i = 0; i < count; ++i) ((int*)d)[i] = v;
+  emu::touch(st);
+  return hipSuccess;
+}
 template <typename S> inline hipError_t hipMemcpyFromSymbol(void* d, const S& sym, size_t n) { memcpy(d, &sym, n); return hipSuccess; }
 template <typename S> inline hipError_t hipMemcpyToSymbol(S& sym, const void* s, size_t n) { memcpy(&sym, s, n); return hipSuccess; }
 inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p) {   // every allocation is "pinned host memory the device can write"
