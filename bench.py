@@ -5,7 +5,9 @@ Workload (BASELINE.json configs[1], the config the metric is quoted on): replay 
 640x480 depth+label trajectory ("kimera_semantics_demo.bag" stand-in, synthetic — the bag
 is not in the reference repository), `fast` integrator with the reference's default
 parameters (5 cm voxels, 5 m rays, truncation 4 voxels, early-out after 2 consecutive
-already-observed voxels, p=0.8, dynamic label 20).  One step = one frame integrated into
+already-observed voxels, p=0.8, dynamic label 20) in the library's default mode: the map the
+reference produces at integrator_threads = 1, bit for bit (the serial early-out reproduced by an
+event-driven fix point on the device, csrc/ks_k_exact.h).  One step = one frame integrated into
 the GPU-resident map through the C ABI, inputs already resident in HBM.
 
 Timing.  Every context first integrates PRIME untimed frames (one per frame slot and pipeline stage: per-slot
@@ -13,21 +15,21 @@ graph capture and buffer growth happen there), then the W warm-up steps, then R 
 steps each, every region bracketed by barrier + synchronize; the line reports the MEDIAN region (value,
 ms_per_step) and the spread over the regions.
 
-Prints ONE JSON line (rank 0).
+Prints ONE short JSON line (rank 0, < 4 KB); the full record (every sub-record, stage table) goes to
+profiles/bench_full_r04.json.
   value = voxel updates/s over the whole job, where a voxel update is one (ray, voxel) pair for which
           the reference runs updateTsdfVoxel + updateSemanticVoxel (semantic_tsdf_integrator_fast.cpp:128-140)
           and N_updates is the count the SERIAL REFERENCE ORDER (CPU oracle, one thread) gives for the timed
-          frames; whenever the GPU performs FEWER updates than that, the GPU's own count is
-          credited instead (no credit for skipped work).  gpu_counted_value is always the GPU's own count.
+          frames — in the default mode the GPU performs exactly those.
   roofline = the whole frame against the HBM roofline (lead figure), every stage's share of the frame, and
           the per-voxel update kernel (k_apply) on its own, all from HIP events of this run; traffic = HBM
           bytes per k_apply launch from the committed PMC pass of this same command (profiles/), or null.
-  early_out_fidelity = touched-voxel Jaccard / label agreement of the benched schedule against the serial
-          reference order, MEASURED in this run on the first timed frames (outside the timed regions).
-  secondary = the same measurement for the exact-serial early-out mode (C2-exact), C3 (`merged`, reference
-          bundle order), C4 (1280x720, 2 cm, 10 m; `fast` and `merged`), the host-pointer entry (H2D inside the
-          call: SURVEY.md §8d's frames/s), the unmodified-server adapter path, and "<config>-switches": A/B of the
-          library's opt-in switches against its defaults, measured in this run, with a map digest each (N = 1 only).
+  early_out_fidelity = the benched mode against the serial reference order, MEASURED in this run on the first timed
+          frames (outside the timed regions): bit-exact, or the touched-voxel Jaccard / label agreement if not.
+  secondary (full record; the line carries value / ms / frac of each) = the ordered-phase schedule alone
+          (C2-ordered-phases: the throughput option, not the reference's map), the unpipelined context, C3 (`merged`,
+          reference bundle order), C4 (1280x720, 2 cm, 10 m; `fast` in both modes and `merged`), the host-pointer entry
+          (H2D inside the call: SURVEY.md §8d's frames/s), the unmodified-server adapter path.
 """
 from __future__ import annotations
 
@@ -72,8 +74,6 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=4)
     ap.add_argument("--no-secondary", action="store_true", help="skip the sub-records")
-    ap.add_argument("--no-switches", action="store_true", help="skip the A/B sub-records of the library's opt-in switches")
-    ap.add_argument("--switches-child", default="", help=argparse.SUPPRESS)   # the process bench.py runs them in (argument: pickled frames)
     ap.add_argument("--only-secondary", default="", help="comma list of sub-records to run (default: all)")
     ap.add_argument("--no-oracle-count", action="store_true",
                     help="value falls back to the GPU's own update count (marked in the output)")
@@ -320,109 +320,18 @@ def early_out_fidelity(B, dev, wl, frames, max_tiles):
         if only:
             _, t, _ = integ.download(np.array(sorted(only), dtype=np.int32).reshape(-1, 3))
             extra += int((t["weight"] > 0).sum())
+    union = int((to | th).sum()) + extra
     o.close()
     h.close()
-    union = int((to | th).sum()) + extra
-    return {"frames": len(frames), "touched_jaccard": round(float(both.sum()) / max(1, union), 5),
+    same = (so == sh and np.array_equal(osem["label"], hsem["label"]) and np.array_equal(osem["priors"].view(np.uint32), hsem["priors"].view(np.uint32))
+            and np.array_equal(ot["distance"].view(np.uint32), ht["distance"].view(np.uint32)) and np.array_equal(ot["weight"].view(np.uint32), ht["weight"].view(np.uint32))
+            and np.array_equal(ot["color"], ht["color"]) and uo == uh)
+    return {"frames": len(frames), "bit_exact_vs_serial_reference": bool(same), "touched_jaccard": round(float(both.sum()) / max(1, union), 5),
             "block_jaccard": round(len(so & sh) / max(1, len(so | sh)), 5),
             "label_agreement_common_voxels": round(float((osem["label"] == hsem["label"])[both].mean()) if both.any() else 1.0, 5),
             "updates_gpu_over_serial": round(uh / max(1, uo), 4),
-            "how": "this run: the benched schedule (HIP) vs the serial reference order (CPU oracle, 1 thread), same frames, fresh maps"}
-
-
-def map_digest(B, dev, wl, frames, max_tiles, sample_blocks=256, **cfg_extra):
-    """SHA-256 over the map a fresh unpipelined context holds after `frames`: all block indices (sorted) and the voxel
-    records of the first `sample_blocks` of them; plus the GPU's update count.  For switch_records: equal digests =
-    the switch does not change the result on this hardware."""
-    import hashlib
-    import numpy as np
-    integ = B.HipIntegrator(B.default_config(device_id=dev.index or 0, max_tiles=max_tiles, max_points=max(f.xyz.shape[0] for f in frames),
-                                             pipeline_frames=0, **integ_cfg(wl, **cfg_extra)))
-    upd = sum(int(integ.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates) for f in frames)
-    idx = integ.block_indices()
-    h = hashlib.sha256(np.ascontiguousarray(idx).tobytes())
-    _, t, sem = integ.download(np.ascontiguousarray(idx[:sample_blocks]))
-    h.update(np.ascontiguousarray(t).tobytes())
-    h.update(np.ascontiguousarray(sem).tobytes())
-    integ.close()
-    return h.hexdigest()[:16], upd
-
-
-def switch_records(B, torch, dev, pipeline, rings, want):
-    """A/B of the library's opt-in switches (environment variables read by ks_create), measured HERE, on the benched
-    hardware, back to back with the default build of the same context: the record a default is chosen from.  Every
-    variant also integrates two frames into a fresh map whose digest is compared with the default's: switches that
-    must not change the result (KS_TEST_OVERLAP, KS_TEST_PRE, KS_EMIT_STAGE) say so, on this GPU; KS_SUB_RUN_GENERATIONS=1 is the early-out
-    schedule benched until round 3, KS_SUB_RUN_RAYS=8 sub-runs half as long (another, equally deterministic, result: tests/test_parity_gpu.py pins both)."""
-    plan = {
-        "C2": (("KS_SUB_RUN_GENERATIONS", "1", False), ("KS_SUB_RUN_RAYS", "8", False), ("KS_TEST_OVERLAP", "0", True), ("KS_TEST_PRE", "1", True), ("KS_TEST_PRE", "7", True),
-               ("KS_EMIT_STAGE", "1", True)),
-        "C4-fast": (("KS_SUB_RUN_GENERATIONS", "1", False), ("KS_SUB_RUN_RAYS", "8", False), ("KS_TEST_OVERLAP", "0", True), ("KS_EMIT_STAGE", "1", True)),
-        "C4-merged": (("KS_EMIT_STAGE", "1", True),),
-    }
-    out = []
-    for name, switches in plan.items():
-        if not want(name) or name not in rings:
-            continue
-        ring, first = rings[name]
-        swl = WORKLOADS[name]
-        big = swl["w"] * swl["h"] > 640 * 480
-        K, R, tiles = (6, 3, 1 << 16) if big else (40, 3, 1 << 13)
-
-        def one(pipe=pipeline, **cfg):
-            m = measure(B, torch, None, dev, swl, ring, 2, K, R, pipe, tiles, 1, **cfg)
-            ms = [r["dt"] / K * 1e3 for r in m["regions"]]
-            sp = m["stage_prof"]
-            return {"ms_per_frame": round(statistics.median(ms), 4), "ms_per_frame_all_regions": [round(x, 4) for x in ms],
-                    "stage_ms": {k: round(sp["ms"][k] / max(1, sp["launches"][k]), 4) for k in sp["ms"] if sp["launches"][k]}}
-        probe = [ring.host(first + i) for i in range(2)]
-        rec = {"config": name + "-switches", "pipeline_frames": pipeline, "steps_per_region": K, "regions": R, "variants": []}
-        saved = {k: os.environ.pop(k, None) for k, _, _ in switches}
-        try:
-            base = one()
-            base["map_digest"], base["updates_2_frames"] = map_digest(B, dev, swl, probe, tiles)
-            rec["default"] = base
-            for env, val, same in switches:
-                v = {"switch": f"{env}={val}", "result_must_equal_default": same}
-                try:
-                    os.environ[env] = val
-                    v.update(one())
-                    d, u = map_digest(B, dev, swl, probe, tiles)
-                    v["map_equals_default"] = (d == base["map_digest"] and u == base["updates_2_frames"])
-                    v["updates_2_frames"] = u
-                    v["ms_over_default"] = round(v["ms_per_frame"] / base["ms_per_frame"], 4)
-                except Exception as e:
-                    v["error"] = f"{type(e).__name__}: {e}"
-                finally:
-                    os.environ.pop(env, None)
-                rec["variants"].append(v)
-            for pipe in ((8, 0) if name == "C2" else ()):   # (not a library switch: ks_config.pipeline_frames; 8 = stage B of four frames per launch)
-                try:
-                    v = {"switch": f"pipeline_frames={pipe}", "result_must_equal_default": True}
-                    v.update(one(pipe))
-                    v["ms_over_default"] = round(v["ms_per_frame"] / base["ms_per_frame"], 4)
-                except Exception as e:
-                    v["error"] = f"{type(e).__name__}: {e}"
-                rec["variants"].append(v)
-            for growth in ((24, 48) if swl["method"] == "fast" else ()):   # ks_config.early_out_phase_growth / 16 = 1.5, 3 (default 2): other schedules, other (deterministic) results
-                try:
-                    v = {"switch": f"early_out_phase_growth={growth}", "result_must_equal_default": False}
-                    v.update(one(early_out_phase_growth=growth))
-                    v["updates_2_frames"] = map_digest(B, dev, swl, probe, tiles, early_out_phase_growth=growth)[1]
-                    v["ms_over_default"] = round(v["ms_per_frame"] / base["ms_per_frame"], 4)
-                except Exception as e:
-                    v["error"] = f"{type(e).__name__}: {e}"
-                rec["variants"].append(v)
-            again = one()     # the default once more, last: drift over the A/B sequence
-            rec["default_again_ms_per_frame"] = again["ms_per_frame"]
-        except Exception as e:
-            rec["error"] = f"{type(e).__name__}: {e}"
-        finally:
-            for k, v0 in saved.items():
-                if v0 is not None:
-                    os.environ[k] = v0
-        out.append(rec)
-    return out
+            "how": "this run: the benched mode (HIP) vs the serial reference order (CPU oracle, 1 thread), same frames, fresh maps; bit_exact = same "
+                   "blocks, every voxel's label / priors / distance / weight / colour identical"}
 
 
 def pmc_traffic(name):
@@ -682,9 +591,6 @@ def compact_line(out, full_path):
             e.update({k: v for k, v in r.items() if k.endswith("_ms_per_frame")})
         if r.get("config") == "C5":
             e.update(pick(r, ["reduce", "gpu_counted_value"]))
-        if str(r.get("config", "")).endswith("-switches"):
-            e = {"config": r["config"], "default_ms": (r.get("default") or {}).get("ms_per_frame"),
-                 "variants": {v.get("switch"): v.get("ms_over_default", v.get("error")) for v in r.get("variants", [])}}
         sec.append(e)
     if sec:
         line["secondary"] = sec
@@ -743,16 +649,6 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         assert dist.get_world_size() == args.gpus
 
-    if args.switches_child:
-        pipeline = int(os.environ.get("KS_BENCH_PIPE", "8"))
-        import pickle
-        with open(args.switches_child, "rb") as fh:
-            fr = pickle.load(fh)
-        rings = {"C2": (FrameRing(fr["C2"], torch, dev), PRIME + 2)}   # (the frames are replayed cyclically)
-        if fr["C4"]:
-            rings["C4-fast"] = rings["C4-merged"] = (FrameRing(fr["C4"], torch, dev), PRIME + 2)
-        os.write(json_fd, (json.dumps(switch_records(B, torch, dev, pipeline, rings, lambda n: True)) + "\n").encode())
-        return
     K, W = args.steps, args.warmup
     R = max(MIN_REPEATS, -(-MIN_TIMED_FRAMES // max(1, K)))
     wl = dict(WORKLOADS["C2"], w=args.width, h=args.height, method=args.method)
@@ -853,9 +749,10 @@ def main():
                        "frames_per_gpu": K, "pipeline_frames": pipeline, "distinct_frames_replayed_cyclically": n_distinct,
                        "points_per_frame": rec["points_per_frame"], "rays_per_frame": rec["rays_per_frame"],
                        "updates_per_frame": rec["updates_per_frame"], "gpu_updates_per_frame": rec["gpu_updates_per_frame"],
-                       "early_out": ("ordered-phase schedule, doubling phases (the throughput default): deterministic, bit-exact vs its "
-                                     "CPU restatement; distance from the serial reference order: early_out_fidelity (measured in this "
-                                     "run); the serial result itself: secondary C2-exact") if args.method == "fast" else "n/a (merged)",
+                       "early_out": ("the reference's serial result (library default): event-driven fix point on the device, pipelined; "
+                                     "early_out_fidelity = checked in this run; the ordered-phase schedule alone: secondary C2-ordered-phases"
+                                     if int(os.environ.get("KS_BENCH_GROWTH", "0")) == 0 else
+                                     "ordered-phase schedule (KS_BENCH_GROWTH): not the reference's map") if args.method == "fast" else "n/a (merged)",
                        "bundle_order": "reference (std::unordered_map iteration order, computed on the GPU)" if args.method == "merged" else "n/a (fast)",
                        "parallelism": f"frame-sharded x{world}" + (
                            f" + one exchange at the end of every timed region: {exchange}"
@@ -886,7 +783,8 @@ def main():
             # ---- the exact serial early-out mode, the merged integrator, the host-pointer entry (640x480) ----
             n_sub = min(24, n_distinct)     # these records replay the first n_sub frames cyclically
             sub_ring = FrameRing(frames[:n_sub], torch, dev)
-            for name, swl, kw in (("C2-exact", WORKLOADS["C2"], dict(cfg=dict(early_out_phase_growth=B.KS_EARLY_OUT_EXACT), pipe=0)),
+            for name, swl, kw in (("C2-ordered-phases", WORKLOADS["C2"], dict(cfg=dict(early_out_phase_growth=32), pipe=pipeline)),
+                                  ("C2-unpipelined", WORKLOADS["C2"], dict(cfg={}, pipe=0)),
                                   ("C3", WORKLOADS["C3"], dict(cfg={}, pipe=pipeline)),
                                   ("C2-host-inputs", WORKLOADS["C2"], dict(cfg={}, pipe=pipeline, entry="host"))):
                 if not want(name) or args.method != "fast" or (args.width, args.height) != (640, 480):
@@ -901,17 +799,18 @@ def main():
                         cof = lambda i, oc=oc: oc[i % len(oc)]   # noqa: E731
                         show = "serial reference order (CPU oracle, 1 thread), every timed frame"
                     note = None
-                    if name == "C2-exact":
-                        nf, it = sm["early_out_iterations"]
-                        note = (f"KS_EARLY_OUT_EXACT: the reference's serial early-out result (bit-exact: tests/test_exact_early_out_gpu.py); "
-                                f"{it / max(1, nf):.1f} fix-point iterations per frame; unpipelined (the host reads a counter per iteration)")
+                    if name == "C2-ordered-phases":
+                        note = ("early_out_phase_growth = 32: the ordered-phase schedule alone (deterministic, bit-exact vs its CPU restatement, "
+                                "NOT the reference's map: touched-voxel Jaccard ~0.98 against the serial order)")
+                    elif name == "C2-unpipelined":
+                        note = "pipeline_frames = 0: every call completes its own frame (the latency of one frame, host wait included)"
                     elif name == "C2-host-inputs":
                         note = ("ks_integrate_points on page-locked HOST buffers: the H2D copy of every frame is inside the call "
                                 "(SURVEY.md §8d's frames/s definition); never the headline value")
                     elif name == "C3":
                         note = "bundles integrated in the reference's std::unordered_map iteration order (bit-exact vs the real sources)"
                     srec, _ = record(name, swl, sm, sK, cof, show, note=note, pmc_name="c3" if name == "C3" else None)
-                    if name == "C2-exact" and cof is not None:
+                    if name == "C2-unpipelined" and cof is not None:
                         srec["gpu_count_equals_serial_reference_count"] = all(
                             r["updates"] == sum(cof(i) for i in r["frames"]) for r in sm["regions"])
                     sec.append(srec)
@@ -920,20 +819,23 @@ def main():
             del sub_ring
             # ---- C4: 1280x720, 2 cm voxels, 10 m rays (both integrators on the same frames) ----
             c4_ring = None
-            for name, steps, tiles in (("C4-fast", 6, 1 << 16), ("C4-merged", 6, 1 << 16)):
+            for name, steps, tiles, c4cfg in (("C4-fast", 12, 1 << 16, {}), ("C4-fast-ordered-phases", 30, 1 << 16, dict(early_out_phase_growth=32)),
+                                              ("C4-merged", 30, 1 << 16, {})):
                 if not want(name):
                     continue
                 try:
-                    swl = WORKLOADS[name]
-                    if c4_ring is None:
-                        c4_ring = FrameRing(make_frames(swl, range(PRIME + 2 + steps)), torch, dev)
-                    sm = measure(B, torch, dist, dev, swl, c4_ring, 2, steps, MIN_REPEATS, pipeline, tiles, 1)
+                    swl = WORKLOADS["C4-merged" if name == "C4-merged" else "C4-fast"]
+                    if c4_ring is None:   # 24 distinct frames, replayed cyclically
+                        c4_ring = FrameRing(make_frames(swl, range(24)), torch, dev)
+                    sm = measure(B, torch, dist, dev, swl, c4_ring, 2, steps, MIN_REPEATS, pipeline, tiles, 1, **c4cfg)
                     scale, show = 1.0, "GPU's own count (oracle count skipped)"
                     if not args.no_oracle_count:
                         # the serial oracle needs ~10 s per C4 frame: count ONE timed frame, compare with the GPU's count of it
                         i0 = PRIME + 2
-                        oc = oracle_counts(swl, [c4_ring.host(i0)])[0]
-                        g = gpu_counts(B, dev, swl, [c4_ring.host(i0)], tiles)[0]
+                        if "c4_oracle_count" not in locals():
+                            c4_oracle_count = oracle_counts(swl, [c4_ring.host(i0)])[0] if swl["method"] == "fast" else None
+                        oc = c4_oracle_count if swl["method"] == "fast" else oracle_counts(swl, [c4_ring.host(i0)])[0]
+                        g = gpu_counts(B, dev, swl, [c4_ring.host(i0)], tiles, **c4cfg)[0]
                         ratio = oc / max(1, g)
                         if ratio >= 1.0:
                             show = (f"GPU's own count: on the first timed frame the serial reference order performs x{ratio:.4f} the GPU's "
@@ -947,7 +849,6 @@ def main():
                     torch.cuda.empty_cache()
                 except Exception as e:
                     sec.append({"config": name, "error": f"{type(e).__name__}: {e}"})
-            c4_host = list(c4_ring.frames[:8]) if c4_ring is not None else []
             del c4_ring
             torch.cuda.empty_cache()
             if want("adapter") and args.method == "fast":
@@ -955,27 +856,6 @@ def main():
                     sec.append(adapter_record([ring.host(PRIME + i) for i in range(12)]))
                 except Exception as e:
                     sec.append({"config": "adapter", "error": f"{type(e).__name__}: {e}"})
-            if want("switches") and not args.no_switches and time.time() - t_start > 420.0:
-                sec.append({"config": "switches", "skipped": f"the run is {time.time() - t_start:.0f} s old: the A/B records (another ~60 s) are left out"})
-            elif want("switches") and not args.no_switches and args.method == "fast" and (args.width, args.height) == (640, 480):
-                # LAST, in a process of its own: some switches select kernels that have only ever run on the host functional
-                # model (tools/emu); whatever they do on this GPU, everything above has been measured and stands
-                import pickle
-                import subprocess
-                import tempfile
-                try:
-                    with tempfile.NamedTemporaryFile(suffix=".pkl") as tf:
-                        pickle.dump({"C2": frames[:24], "C4": c4_host}, tf, protocol=4)
-                        tf.flush()
-                        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--switches-child", tf.name], stdout=subprocess.PIPE,
-                                           stderr=subprocess.PIPE, timeout=300, env=dict(os.environ, KS_BENCH_PIPE=str(pipeline)))
-                    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("[")]
-                    if r.returncode == 0 and lines:
-                        sec.extend(json.loads(lines[-1]))
-                    else:
-                        sec.append({"config": "switches", "error": f"child rc {r.returncode}: " + r.stderr.decode(errors="replace")[-400:]})
-                except Exception as e:
-                    sec.append({"config": "switches", "error": f"{type(e).__name__}: {e}"})
             out["secondary"] = sec
         out["library"] = mapped_library()
         out["bench_seconds"] = round(time.time() - t_start, 1)

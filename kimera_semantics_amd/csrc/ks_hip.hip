@@ -104,8 +104,6 @@ struct FrameSlot {
   uint32_t* d_lp = nullptr;         // exclusive prefix of d_cnt inside blocks of kScanBlock
   unsigned long long* d_bt = nullptr;  // block totals of that scan
   uint8_t* d_live = nullptr;        // fast: position holds a ray that survived start-voxel dedup
-  uint32_t* d_pre_hash = nullptr;   // k_prewalk -> k_test_pre (ks_k_march.h); allocated when the context uses them
-  int* d_pre_steps = nullptr;
   bool wide = false;                // stage B uses a whole wavefront per ray (long rays)
   FrameParams* d_F = nullptr;       // the frame's parameters in device memory (stage B reads them from there)
   uint64_t *d_gkeys = nullptr, *d_rkeys = nullptr;  // anti-grazing: this frame's sorted end-voxel keys / key per bundle
@@ -127,6 +125,11 @@ struct FrameSlot {
   EoCtl* d_eo_ctl = nullptr;
   uint32_t* d_eo_sort_ws = nullptr;
   size_t eo_sort_words = 0;
+  uint32_t *d_eo_hseq = nullptr, *d_eo_where = nullptr;   // per seed mark in emission order: voxel hash | index in M
+  uint4 *d_eo_rinfo = nullptr, *d_eo_ckpt = nullptr;      // per position: {u0, um, length, checkpoint step} | caster state there
+  uint8_t* d_eo_hitb = nullptr;            // first iteration: per mark in emission order, the visit is a hit
+  uint32_t* d_eo_fcnt = nullptr;           // ... surviving marks per filter block
+  unsigned long long* d_eo_btp = nullptr;  // ... exclusive prefix of the scan's block totals
   hipEvent_t eo_committed = nullptr;  // the frame's marks have entered the shared table
   Counters* d_counters = nullptr;   // inside ks_ctx::d_state
   uint32_t* d_ray_list = nullptr;   // rays to march (written by stage A, read by B)
@@ -204,12 +207,7 @@ struct ks_ctx {
   bool host_prof = false;
   bool export_staged = false;             // KS_EXPORT_STAGED=1: voxel export via a device buffer + copy even for pinned targets
   bool use_graphs = true;                // stage B replayed as a hipGraph (KS_NO_GRAPH=1 or a capture failure: plain launches)
-  bool test_pre = false;                 // leading early-out phases through k_prewalk + k_test_pre (KS_TEST_PRE, bit 0)
-  int test_pre_flags = 0;                // KS_TEST_PRE as given (bits 1, 2: variants, see enqueue_stage_b)
-  bool emit_stage = false;               // k_emit_lane stages a ray's first keys in LDS (KS_EMIT_STAGE=1; ks_k_march.h)
   bool test_overlap = true;              // k_test casts a long ray's next 64 voxels while the shared-set entries of the current 64 are in flight (KS_TEST_OVERLAP=0: one after the other, as measured until round 3)
-  uint32_t sub_rays = kSubRun;           // rays per early-out sub-run (KS_SUB_RUN_RAYS = 1..16, experiments: the CPU checker follows with KO_EXP_SUB_RUN)
-  bool sub_run_generations = false;      // early-out sub-runs of 16 generations instead of 16 live rays (KS_SUB_RUN_GENERATIONS=1: A/B runs; ks_k_march.h)
   std::atomic<uint64_t> buffers_epoch{1};  // bumped whenever a buffer a captured graph points at is re-allocated
   uint8_t* d_color_lut = nullptr;   // 16 MiB rgb -> label
   uint32_t* d_label_lut = nullptr;  // 256 label -> rgba
@@ -423,34 +421,6 @@ size_t steps_max_of(const ks_config& cfg, float voxel_size_inv) {
   const double max_len = (double)cfg.max_ray_length_m + 2.0 * (double)cfg.truncation_distance;
   return (size_t)std::ceil(1.7321 * max_len * (double)voxel_size_inv) + 8;
 }
-// The leading early-out phases of one sub-run per chain go through k_prewalk + k_test_pre when the context asks for it
-// and a wavefront's LDS holds the rays of a sub-run: generations [0, G), rows of `cap` hashes, Gpad generations per chain.
-struct PrePlan {
-  bool on = false;
-  uint32_t G = 0, Gpad = 0, cap = 0;
-};
-PrePlan pre_plan(const ks_ctx* c, size_t cap_points) {
-  PrePlan P;
-  if (!c->test_pre || !c->uses_early_out || cap_points == 0) return P;
-  const uint32_t steps_cap = (uint32_t)((steps_max_of(c->cfg, c->voxel_size_inv) + 3) & ~(size_t)3);
-  const uint32_t cap = test_pre_cap(steps_cap);
-  if (test_pre_lds_bytes(cap) > 64 * 1024 || (cap + 63) / 64 * 16 > kPreMaxChunks) return P;
-  const uint32_t n_gen = (uint32_t)((cap_points + kChains - 1) / kChains);
-  const std::vector<uint32_t> B = phase_bounds(n_gen, c->cfg.early_out_phase_growth);
-  uint32_t G = 0;
-  for (size_t j = 0; j < B.size(); ++j) {
-    const uint32_t g0 = B[j], g1 = (j + 1 < B.size()) ? B[j + 1] : n_gen;
-    if (g1 - g0 > kSubRun) break;
-    G = g1;
-  }
-  if (G == 0) return P;
-  P.on = true;
-  P.G = G;
-  P.Gpad = (G + kSubRun - 1) / kSubRun * kSubRun;
-  P.cap = cap;
-  return P;
-}
-
 int ensure_exact_points(ks_ctx* c, size_t cap);
 int ensure_points(ks_ctx* c, size_t n) {
   if (n <= c->cap_points) return KS_OK;
@@ -470,13 +440,6 @@ int ensure_points(ks_ctx* c, size_t n) {
     if ((rc = dev_alloc(c, &c->slot[i].d_lp, scan_cap))) return rc;
     if ((rc = dev_alloc(c, &c->slot[i].d_bt, scan_cap / kScanBlock + 2))) return rc;
     if (c->cfg.method == KS_METHOD_FAST && (rc = dev_alloc(c, &c->slot[i].d_live, cap))) return rc;
-    {
-      const PrePlan P = pre_plan(c, cap);
-      if (P.on) {
-        if ((rc = dev_alloc(c, &c->slot[i].d_pre_hash, (size_t)kChains * P.Gpad * P.cap))) return rc;
-        if ((rc = dev_alloc(c, &c->slot[i].d_pre_steps, (size_t)kChains * P.Gpad))) return rc;
-      }
-    }
     if (c->cfg.enable_anti_grazing && c->cfg.method == KS_METHOD_MERGED) {
       if ((rc = dev_alloc(c, &c->slot[i].d_gkeys, cap))) return rc;
       if ((rc = dev_alloc(c, &c->slot[i].d_rkeys, cap))) return rc;
@@ -644,8 +607,6 @@ SlotView slot_view(const FrameSlot& S, Counters* counters = nullptr) {
   v.pairs_cap = (unsigned long long)S.cap_pairs_in;
   v.C = counters ? counters : S.d_counters;
   v.host_snap = (uint32_t*)S.h_snap;
-  v.pre_hash = S.d_pre_hash;
-  v.pre_steps = S.d_pre_steps;
   v.eo_stats = S.d_eo_ctl ? &S.d_eo_ctl->n_x : nullptr;
   return v;
 }
@@ -659,11 +620,9 @@ void launch_emit(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipStrea
   if (!(c->cfg.method == KS_METHOD_MERGED && c->cfg.enable_anti_grazing)) {
     // bundles and 2 cm rays are long: 8 rays per wavefront; early-out rays are short: one per lane
     if (wide || c->cfg.method == KS_METHOD_MERGED || !c->uses_early_out) {
-      if (c->emit_stage) hipLaunchKernelGGL((k_emit_lane<8, true>), dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, V, c->table, c->pool);
-      else hipLaunchKernelGGL((k_emit_lane<8, false>), dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, V, c->table, c->pool);
+      hipLaunchKernelGGL(k_emit_lane<8>, dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, V, c->table, c->pool);
     } else {
-      if (c->emit_stage) hipLaunchKernelGGL((k_emit_lane<16, true>), dim3((uint32_t)((n + 63) / 64), nb), dim3(256), lds, st, V, c->table, c->pool);
-      else hipLaunchKernelGGL((k_emit_lane<16, false>), dim3((uint32_t)((n + 63) / 64), nb), dim3(256), lds, st, V, c->table, c->pool);
+      hipLaunchKernelGGL(k_emit_lane<16>, dim3((uint32_t)((n + 63) / 64), nb), dim3(256), lds, st, V, c->table, c->pool);
     }
   } else if (wide) {
     hipLaunchKernelGGL(k_emit<64>, dim3((uint32_t)((n + 3) / 4), nb), dim3(256), lds, st, V, c->table, c->pool);
@@ -685,37 +644,15 @@ void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipS
     // stood when the phase began and enters their marks (ks_k_march.h)
     const uint32_t n_gen = (uint32_t)((n + kChains - 1) / kChains);
     const std::vector<uint32_t> B = phase_bounds(n_gen, cfg.early_out_phase_growth);
-    // the leading phases of one sub-run per chain: all their rays walked once, up front (ks_k_march.h)
-    const PrePlan P = pre_plan(c, n);
-    if (P.on)
-      hipLaunchKernelGGL(k_prewalk, dim3(kChains * (P.Gpad / kSubRun), nb), dim3(64), prewalk_lds_bytes(P.cap), sm, V, P.G, P.Gpad, P.cap);
     for (size_t j = 0; j < B.size(); ++j) {
       const uint32_t g0 = B[j], g1 = (j + 1 < B.size()) ? B[j + 1] : n_gen;  // k_test ends the frame's last phase at ITS n
-      const uint32_t n_sub = (g1 - g0 + c->sub_rays - 1) / c->sub_rays;  // wavefronts per chain (worst case: every ray live)
+      const uint32_t n_sub = (g1 - g0 + kSubRun - 1) / kSubRun;  // wavefronts per chain (worst case: every ray live)
       const uint32_t steps_cap = (uint32_t)((steps_max + 3) & ~(size_t)3);
       const size_t lds_wave = (size_t)test_lds_words64(steps_cap) * sizeof(unsigned long long);
       const uint32_t wpb = lds_wave * 4 <= 60 * 1024 ? 4u : lds_wave * 2 <= 60 * 1024 ? 2u : 1u;  // wavefronts per block
-      if (P.on && g1 <= P.G) {
-        // (with one wavefront per SIMD every instruction of the unrolled look-up batch is paid for, used or not: the
-        // batch is sized to the work of the phase — about 2.3 chunks of 64 voxels per ray)
-        const dim3 grid(kChains, nb), block(64);
-        const size_t lds = test_pre_lds_bytes(P.cap);
-        // KS_TEST_PRE bits: 1 on | 2 always 32 look-ups in flight (the build that was measured) | 4 one
-        // shared-set mark per visited voxel instead of the private-set route
-        const uint32_t w = (c->test_pre_flags & 2) ? 32u : g1 - g0 <= 4 ? 8u : g1 - g0 <= 8 ? 16u : 32u;
-        const bool dedup = !(c->test_pre_flags & 4);
-#define KS_LAUNCH_PRE(WW, DD) hipLaunchKernelGGL((k_test_pre<WW, DD>), grid, block, lds, sm, V, g0, g1, P.Gpad, P.cap)
-        if (w == 8u) { if (dedup) KS_LAUNCH_PRE(8, true); else KS_LAUNCH_PRE(8, false); }
-        else if (w == 16u) { if (dedup) KS_LAUNCH_PRE(16, true); else KS_LAUNCH_PRE(16, false); }
-        else { if (dedup) KS_LAUNCH_PRE(32, true); else KS_LAUNCH_PRE(32, false); }
-#undef KS_LAUNCH_PRE
-      } else
-      {
-        const dim3 grid(kChains * n_sub / wpb, nb), block(64 * wpb);
-        const uint32_t by_gen = c->sub_run_generations ? 1u : 0u;
-        if (c->test_overlap) hipLaunchKernelGGL(k_test<true>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap, by_gen, c->sub_rays);
-        else hipLaunchKernelGGL(k_test<false>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap, by_gen, c->sub_rays);
-      }
+      const dim3 grid(kChains * n_sub / wpb, nb), block(64 * wpb);
+      if (c->test_overlap) hipLaunchKernelGGL(k_test<true>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap);
+      else hipLaunchKernelGGL(k_test<false>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap);
     }
   }
   if (part == 1) return;
@@ -773,7 +710,9 @@ int exact_early_out(ks_ctx* c, FrameSlot& S, hipStream_t st, Counters* counters 
                          c->d_eo_lp, c->d_eo_bt, c->d_eo_keys[0], c->d_eo_vals[0], (unsigned long long)c->cap_marks, d_counters,
                          c->d_eo_state);
     // stable sort on the slot bits only: a slot's marks stay in (position, step) order
-    HIPCHK(c, (ksrs::sort<uint64_t, true>(c->sort_ws, c->d_eo_keys[0], c->d_eo_keys[1], c->d_eo_vals[0], c->d_eo_vals[1],
+    // (as the fallback of the event-driven path this runs on the tail's thread and stream, beside stage A of later frames:
+    // the tail's sort workspace, not stage A's)
+    HIPCHK(c, (ksrs::sort<uint64_t, true>(counters ? c->sort_ws_tail : c->sort_ws, c->d_eo_keys[0], c->d_eo_keys[1], c->d_eo_vals[0], c->d_eo_vals[1],
                                           (size_t)n_marks, 64, st, &kres, &vres, 44)));
     hipLaunchKernelGGL(k_eo_index, dim3((uint32_t)((n_marks + 255) / 256)), dim3(256), 0, st, n_marks, (const uint64_t*)kres,
                        c->d_eo_range);
@@ -798,7 +737,7 @@ int exact_early_out(ks_ctx* c, FrameSlot& S, hipStream_t st, Counters* counters 
     return KS_ERR_UNSUPPORTED;
   }
   c->eo_iterations += (uint64_t)it;
-  c->eo_frames += 1;
+  if (!counters) c->eo_frames += 1;   // (as the fallback the frame has been counted)
   if (n_marks)
     hipLaunchKernelGGL(k_eo_commit, dim3((uint32_t)((n_marks + 255) / 256)), dim3(256), 0, st, n_marks, (const uint64_t*)kres,
                        (const uint32_t*)vres, c->d_eo_plain);
@@ -827,6 +766,10 @@ int ensure_exact_slots(ks_ctx* c, size_t cap_marks, size_t cap_x) {
       }
       S.eo_sort_words = ksrs::ws_words_dev(cap_marks, 3);
       if ((rc = dev_alloc(c, &S.d_eo_sort_ws, S.eo_sort_words))) return rc;
+      if ((rc = dev_alloc(c, &S.d_eo_hitb, cap_marks))) return rc;
+      if ((rc = dev_alloc(c, &S.d_eo_hseq, cap_marks))) return rc;
+      if ((rc = dev_alloc(c, &S.d_eo_where, cap_marks))) return rc;
+      if ((rc = dev_alloc(c, &S.d_eo_fcnt, cap_marks / kEoFilterBlock + 2))) return rc;
       S.eo_cap_marks = cap_marks;
     }
     if (S.eo_cap_x < cap_x) {
@@ -848,6 +791,9 @@ int ensure_exact_points(ks_ctx* c, size_t cap) {   // the per-position arrays (c
     for (uint32_t** p : {&S.d_eo_cnt_b, &S.d_eo_ux, &S.d_eo_dirty, &S.d_eo_list[0], &S.d_eo_list[1], &S.d_eo_chg, &S.d_eo_consulted, &S.d_eo_lp})
       if ((rc = dev_alloc(c, p, cap))) return rc;
     if ((rc = dev_alloc(c, &S.d_eo_bt, cap / kScanBlock + 2))) return rc;
+    if ((rc = dev_alloc(c, &S.d_eo_btp, cap / kScanBlock + 2))) return rc;
+    if ((rc = dev_alloc(c, &S.d_eo_rinfo, cap))) return rc;
+    if ((rc = dev_alloc(c, &S.d_eo_ckpt, 3 * cap))) return rc;
   }
   return KS_OK;
 }
@@ -861,8 +807,16 @@ EoView eo_view(ks_ctx* c, const FrameSlot& S) {
   E.cnt_b = S.d_eo_cnt_b;
   E.ux = S.d_eo_ux;
   E.dirty = S.d_eo_dirty;
-  E.keys = S.d_eo_keys[1];   // three radix passes: the sorted marks end up in the second buffer set
-  E.vals = S.d_eo_vals[1];
+  // three radix passes leave the sorted seed marks in the second buffer set; the first iteration's compaction puts what is
+  // left of them back into the first
+  E.keys = S.d_eo_keys[0];
+  E.vals = S.d_eo_vals[0];
+  E.lp = S.d_eo_lp;
+  E.btp = S.d_eo_btp;
+  E.hseq = S.d_eo_hseq;
+  E.where = S.d_eo_where;
+  E.rinfo = S.d_eo_rinfo;
+  E.ckpt = S.d_eo_ckpt;
   E.tab = S.d_eo_tab;
   E.xnode = S.d_eo_xnode;
   E.cap_x = (uint32_t)S.eo_cap_x;
@@ -887,11 +841,11 @@ int enqueue_exact_rounds(ks_ctx* c, FrameSlot& S, hipStream_t st) {
   if (S.wide)
     hipLaunchKernelGGL(k_eo_emit<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), lds, st, (const FrameParams*)S.d_F, (const uint32_t*)S.d_ray_list,
                        (const RayDesc*)S.d_rays, (const uint32_t*)S.d_cnt, (const uint32_t*)S.d_eo_lp, (const unsigned long long*)S.d_eo_bt,
-                       S.d_eo_keys[0], S.d_eo_vals[0], (unsigned long long)S.eo_cap_marks, (const Counters*)S.d_counters, &ctl->st, &ctl->fail);
+                       S.d_eo_keys[0], S.d_eo_vals[0], (unsigned long long)S.eo_cap_marks, (const Counters*)S.d_counters, &ctl->st, &ctl->fail, S.d_eo_btp, S.d_eo_hseq, S.d_eo_rinfo, S.d_eo_ckpt);
   else
     hipLaunchKernelGGL(k_eo_emit<64>, dim3((uint32_t)((n + 255) / 256)), dim3(256), lds, st, (const FrameParams*)S.d_F, (const uint32_t*)S.d_ray_list,
                        (const RayDesc*)S.d_rays, (const uint32_t*)S.d_cnt, (const uint32_t*)S.d_eo_lp, (const unsigned long long*)S.d_eo_bt,
-                       S.d_eo_keys[0], S.d_eo_vals[0], (unsigned long long)S.eo_cap_marks, (const Counters*)S.d_counters, &ctl->st, &ctl->fail);
+                       S.d_eo_keys[0], S.d_eo_vals[0], (unsigned long long)S.eo_cap_marks, (const Counters*)S.d_counters, &ctl->st, &ctl->fail, S.d_eo_btp, S.d_eo_hseq, S.d_eo_rinfo, S.d_eo_ckpt);
   uint64_t* kres = nullptr;
   uint32_t* vres = nullptr;
   // stable sort on the slot bits only: a slot's marks stay in (position, step) order
@@ -903,18 +857,35 @@ int enqueue_exact_rounds(ks_ctx* c, FrameSlot& S, hipStream_t st) {
   }
   const EoView E = eo_view(c, S);
   const uint32_t gm = (uint32_t)std::min<size_t>((S.eo_cap_marks + 255) / 256, 2048);
+  // the first iteration, full and streaming: hit bits of the sorted seed marks, stop rule per ray, compaction
+  EoPhase1 P{};
+  P.keys0 = S.d_eo_keys[1];
+  P.vals0 = S.d_eo_vals[1];
+  P.keys1 = S.d_eo_keys[0];
+  P.vals1 = S.d_eo_vals[0];
+  P.lp = S.d_eo_lp;
+  P.btp = S.d_eo_btp;
+  P.hitb = S.d_eo_hitb;
+  P.fcnt = S.d_eo_fcnt;
+  const uint32_t gf = (uint32_t)((S.eo_cap_marks + kEoFilterBlock - 1) / kEoFilterBlock);
+  hipLaunchKernelGGL(k_eo2_hits, dim3(gm), dim3(256), 0, st, E, P);
+  hipLaunchKernelGGL(k_eo2_stop0, dim3((uint32_t)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, E, P);
+  hipLaunchKernelGGL(k_eo2_fcount, dim3(gf), dim3(256), 0, st, E, P);
+  hipLaunchKernelGGL(k_eo2_fscan, dim3(1), dim3(1024), 0, st, E, P);
+  hipLaunchKernelGGL(k_eo2_fscatter, dim3(gf), dim3(256), 0, st, E, P);
   hipLaunchKernelGGL(k_eo2_index, dim3(gm), dim3(256), 0, st, E);
+  // the event-driven rounds (round 0 was the full iteration above)
   const uint32_t gr = (uint32_t)std::min<size_t>((n + 3) / 4, 2048);   // wavefront per ray, grid-stride
-  for (int r = 0; r < c->eo_bulk_rounds; ++r) {
-    hipLaunchKernelGGL(k_eo2_eval, dim3(r == 0 ? gr : std::min(gr, 512u)), dim3(256), 0, st, E, (uint32_t)r);
-    hipLaunchKernelGGL(k_eo2_propagate, dim3(std::min(gr, 512u)), dim3(256), 0, st, E, (uint32_t)r);
+  for (int r = 1; r <= c->eo_bulk_rounds; ++r) {
+    hipLaunchKernelGGL(k_eo2_eval, dim3(gr), dim3(256), 0, st, E, (uint32_t)r);
+    hipLaunchKernelGGL(k_eo2_propagate, dim3(gr), dim3(256), 0, st, E, (uint32_t)r);
   }
   return KS_OK;
 }
 // part 2: what is left, by one workgroup, and the frame's marks into the shared table
 void enqueue_exact_finish(ks_ctx* c, FrameSlot& S, hipStream_t st) {
   const EoView E = eo_view(c, S);
-  hipLaunchKernelGGL(k_eo2_finish, dim3(1), dim3(kEoFinishThreads), 0, st, E, (uint32_t)c->eo_bulk_rounds, 1u);
+  hipLaunchKernelGGL(k_eo2_finish, dim3(1), dim3(kEoFinishThreads), 0, st, E, (uint32_t)c->eo_bulk_rounds + 1u, 1u);
   hipLaunchKernelGGL(k_eo2_commit, dim3(1024), dim3(256), 0, st, E);
 }
 
@@ -1237,6 +1208,8 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   if (c->eo_device) {
     c->eo_frames += 1;
     c->eo_iterations += S.h_snap->pad[2];   // rounds of the event-driven fix point (k_publish)
+    if (getenv("KS_EXACT_DEBUG"))
+      fprintf(stderr, "[ks exact] frame %u: X marks %u, fail bits %u, rounds %u, rays %u\n", S.F.eo_frame, S.h_snap->pad[0] - 1u, S.h_snap->pad[1], S.h_snap->pad[2], cnt.n_rays);
   }
   if ((cnt.err & kErrExact) && !(cnt.err & (kErrLabel | kErrIndex))) {
     // The device-driven fix point gave up (marks or X marks did not fit, the finisher ran out of rounds, or the frame
@@ -1249,8 +1222,11 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     HIPCHK(c, hipMemcpy(&hctl, S.d_eo_ctl, sizeof(hctl), hipMemcpyDeviceToHost));
     if (hctl.fail & kEoFailMarks)
       c->eo_want_marks.store(std::max<size_t>(2 * c->eo_cap_marks, (size_t)hctl.st.n_marks + (size_t)hctl.st.n_marks / 4), std::memory_order_relaxed);
-    if (hctl.fail & kEoFailX) c->eo_want_x.store(4 * c->eo_cap_x, std::memory_order_relaxed);
+    if (hctl.fail & kEoFailX) c->eo_want_x.store(std::max<size_t>(4 * c->eo_cap_x, 4 * (size_t)hctl.n_x), std::memory_order_relaxed);
     ++c->eo_fallbacks;
+    if (getenv("KS_EXACT_DEBUG"))
+      fprintf(stderr, "[ks exact] frame %u falls back to the host-driven loop: fail bits %u (1 marks, 2 X marks, 4 rounds, 8 predecessor), marks %llu of %zu, X %u of %zu, rounds %u\n",
+              S.F.eo_frame, hctl.fail, (unsigned long long)hctl.st.n_marks, c->eo_cap_marks, hctl.n_x, c->eo_cap_x, hctl.rounds);
     Counters rcnt{};
     rcnt.n_rays = cnt.n_rays;
     HIPCHK(c, hipMemcpyAsync(c->d_retry_counters, &rcnt, sizeof(rcnt), hipMemcpyHostToDevice, st));
@@ -1800,7 +1776,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // of the dependence between frames — the zero-initialised slot — is carried by the commit events.
     if (c->exact_early_out && (!c->eo_device || c->cfg.clear_checks_every_n_frames > 1)) c->cfg.pipeline_frames = 0;
     const bool wide_rays = steps_max_of(c->cfg, (float)(1.0 / cfg->voxel_size)) > 400;
-    c->eo_bulk_rounds = wide_rays ? 24 : 6;
+    c->eo_bulk_rounds = wide_rays ? 32 : 10;
     if (const char* br = getenv("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
   }
   c->uses_early_out = uses_early_out;
@@ -1837,19 +1813,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   // own.  Otherwise stage B stays strictly in frame order.
   const bool frames_independent = !uses_early_out || c->cfg.clear_checks_every_n_frames <= 1;
   c->batch = 1;
-  if (const char* es = getenv("KS_EMIT_STAGE")) c->emit_stage = atoi(es) != 0;
-  // A/B runs: the early-out sub-runs of the schedule measured until round 3 (16 generations instead of 16 live rays;
-  // the CPU checker follows with KO_SUB_RUN_GENERATIONS=1)
-  if (const char* sg = getenv("KS_SUB_RUN_GENERATIONS")) c->sub_run_generations = atoi(sg) != 0;
-  if (const char* ov = getenv("KS_TEST_OVERLAP")) c->test_overlap = atoi(ov) != 0;
-  if (const char* sr = getenv("KS_SUB_RUN_RAYS")) {
-    c->sub_rays = (uint32_t)std::min(16, std::max(1, atoi(sr)));
-    if (c->sub_rays != kSubRun) c->test_pre = false;   // (k_prewalk / k_test_pre are written for sub-runs of 16)
-  }
-  if (const char* tp = getenv("KS_TEST_PRE")) {
-    c->test_pre_flags = atoi(tp);
-    c->test_pre = (c->test_pre_flags & 1) != 0 && c->sub_rays == kSubRun;
-  }
+  if (const char* ov = getenv("KS_TEST_OVERLAP")) c->test_overlap = atoi(ov) != 0;   // diagnostics: the same schedule and result, rounds one after the other
   if (c->cfg.pipeline_frames >= 2 && frames_independent && !c->exact_early_out && c->cfg.integration_order_mode != KS_ORDER_SORTED) {
     // (measured, 640x480: a batch of 4 behind 8 frames of lag ~ four single-frame sequences on four streams behind 4
     // frames of lag; batches of 2 or 3 lose to both: DESIGN.md)
@@ -1958,7 +1922,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   // pair buffers start at 4 updates per point of the largest cloud (a frame that needs more grows its buffer and
   // repeats the emission once)
   c->pairs_hint.store((size_t)cfg->max_points * 4, std::memory_order_relaxed);
-  size_t eo_marks0 = std::max<size_t>((size_t)1 << 20, 4 * (size_t)cfg->max_points), eo_x0 = std::max<size_t>((size_t)1 << 16, (size_t)cfg->max_points / 2);
+  size_t eo_marks0 = std::max<size_t>((size_t)1 << 20, 4 * (size_t)cfg->max_points), eo_x0 = std::max<size_t>((size_t)1 << 17, (size_t)cfg->max_points);
   // (tests: start small, so that the overflow -> host-driven loop -> grow path is exercised)
   if (const char* e = getenv("KS_EXACT_CAP_MARKS")) eo_marks0 = std::max<size_t>(64, (size_t)atoll(e));
   if (const char* e = getenv("KS_EXACT_CAP_X")) eo_x0 = std::max<size_t>(8, (size_t)atoll(e));
@@ -2006,10 +1970,10 @@ void ks_destroy(ks_ctx* c) {
     if (p) (void)hipFree(p);
   for (auto& S : c->slot) {
     for (void* p : {(void*)S.d_rays, (void*)S.d_deltas, (void*)S.d_ray_list, (void*)S.d_pairs, (void*)S.d_cnt, (void*)S.d_lp,
-                    (void*)S.d_bt, (void*)S.d_live, (void*)S.d_F, (void*)S.d_gkeys, (void*)S.d_rkeys, (void*)S.d_pre_hash, (void*)S.d_pre_steps,
+                    (void*)S.d_bt, (void*)S.d_live, (void*)S.d_F, (void*)S.d_gkeys, (void*)S.d_rkeys,
                     (void*)S.d_eo_keys[0], (void*)S.d_eo_keys[1], (void*)S.d_eo_vals[0], (void*)S.d_eo_vals[1], (void*)S.d_eo_tab, (void*)S.d_eo_xnode,
                     (void*)S.d_eo_cnt_b, (void*)S.d_eo_ux, (void*)S.d_eo_dirty, (void*)S.d_eo_list[0], (void*)S.d_eo_list[1], (void*)S.d_eo_chg,
-                    (void*)S.d_eo_consulted, (void*)S.d_eo_lp, (void*)S.d_eo_bt, (void*)S.d_eo_ctl, (void*)S.d_eo_sort_ws})
+                    (void*)S.d_eo_consulted, (void*)S.d_eo_lp, (void*)S.d_eo_bt, (void*)S.d_eo_ctl, (void*)S.d_eo_sort_ws, (void*)S.d_eo_hitb, (void*)S.d_eo_fcnt, (void*)S.d_eo_btp, (void*)S.d_eo_hseq, (void*)S.d_eo_where, (void*)S.d_eo_rinfo, (void*)S.d_eo_ckpt})
       if (p) (void)hipFree(p);
     if (S.b_graph2) (void)hipGraphExecDestroy(S.b_graph2);
     if (S.b_graph3) (void)hipGraphExecDestroy(S.b_graph3);

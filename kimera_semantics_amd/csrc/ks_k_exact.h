@@ -136,13 +136,17 @@ __global__ void __launch_bounds__(256) k_eo_emit(const FrameParams* __restrict__
                                                  const uint32_t* __restrict__ lp, const unsigned long long* __restrict__ bt,
                                                  uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
                                                  unsigned long long cap, const Counters* C, EoState* __restrict__ st,
-                                                 uint32_t* __restrict__ fail = nullptr) {
+                                                 uint32_t* __restrict__ fail = nullptr, unsigned long long* __restrict__ btp = nullptr,
+                                                 uint32_t* __restrict__ hseq = nullptr, uint4* __restrict__ rinfo = nullptr,
+                                                 uint4* __restrict__ ckpt = nullptr) {
   extern __shared__ unsigned long long s_bt[];
   __shared__ float s_e[4][3 * kES];
   const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   if (blockIdx.x != 0 && blockIdx.x * 4u * (uint32_t)RPW >= C->n_rays) return;
   const unsigned long long total = eo_fold_totals(bt, (F.n + kScanBlock - 1u) / kScanBlock, s_bt);
   if (blockIdx.x == 0 && threadIdx.x == 0) st->n_marks = total;
+  if (btp && blockIdx.x == 0)   // the exclusive prefix of the block totals, for the kernels that map a mark back to its place in emission order
+    for (uint32_t b = threadIdx.x; b < (F.n + kScanBlock - 1u) / kScanBlock; b += 256) btp[b] = s_bt[b];
   if (total > cap) {  // (host-driven loop: the host sized the buffers from the count it read back; event-driven: the frame falls back to it)
     if (fail && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(fail, 1u /* kEoFailMarks */);
     return;
@@ -164,6 +168,16 @@ __global__ void __launch_bounds__(256) k_eo_emit(const FrameParams* __restrict__
     const uint64_t slot = ((uint64_t)h + F.observed_offset) & kSetMask;
     keys[at] = (slot << 44) | ((uint64_t)p << 22) | (uint64_t)step;
     vals[at] = h;
+    if (hseq) hseq[at] = h;   // (stays in emission order: a ray's hashes are contiguous)
+  };
+  // event-driven path: what a later look at the ray needs without casting it again — how many steps have a mark, its
+  // length, and the caster's state at step cs <= visited (from where it is cast on if it outgrows its marks)
+  auto checkpoint = [&](const Dda& d, uint32_t cs) {
+    if (!rinfo) return;
+    rinfo[pos] = make_uint4(visited, visited, (uint32_t)d.steps + 1u, cs);
+    ckpt[3u * pos] = make_uint4((uint32_t)d.cx, (uint32_t)d.cy, (uint32_t)d.cz, (uint32_t)(d.sx + 1) | ((uint32_t)(d.sy + 1) << 2) | ((uint32_t)(d.sz + 1) << 4));
+    ckpt[3u * pos + 1u] = make_uint4(__float_as_uint(d.tx), __float_as_uint(d.ty), __float_as_uint(d.tz), __float_as_uint(d.dx));
+    ckpt[3u * pos + 2u] = make_uint4(__float_as_uint(d.dy), __float_as_uint(d.dz), 0u, 0u);
   };
   const unsigned long long long_mask = __ballot(visited > kLaneWalk);
   const bool by_wave = tails_by_wavefront(long_mask, visited);
@@ -172,6 +186,8 @@ __global__ void __launch_bounds__(256) k_eo_emit(const FrameParams* __restrict__
     if (s < own) put(base + s, pos, s, dda.cx, dda.cy, dda.cz);
     dda.advance(s < own);
   }
+  const bool is_ray = lane < (uint32_t)RPW && r < C->n_rays;
+  if (is_ray) checkpoint(dda, own);   // (state after `own` steps; a ray whose tail is walked below by its owner lane overwrites it)
   float* escr = s_e[threadIdx.x >> 6];
   for (unsigned long long todo = by_wave ? long_mask : 0ull; todo != 0ull; todo &= todo - 1ull) {
     const int j = __ffsll((long long)todo) - 1;
@@ -189,6 +205,7 @@ __global__ void __launch_bounds__(256) k_eo_emit(const FrameParams* __restrict__
         put(base + s, pos, s, dda.cx, dda.cy, dda.cz);
         dda.advance();
       }
+      checkpoint(dda, visited);
     }
   }
 }
@@ -358,6 +375,7 @@ struct EoCtl {
   uint32_t n_consulted;           // rays whose result depends on what EARLIER FRAMES left in the table
   uint32_t fin_in[2], fin_chg;    // the finisher's list counters
   uint32_t pad;
+  unsigned long long n_marks1;    // marks left after the first (full) iteration's compaction
   uint32_t n_in[kEoBulkMax + 2];  // dirty rays entering bulk round r
   uint32_t n_chg[kEoBulkMax + 2]; // rays whose length changed in bulk round r
 };
@@ -381,6 +399,12 @@ struct EoView {
   uint32_t* consulted;
   uint64_t* plain;                // the reference's table as earlier frames left it
   uint32_t* committed;            // frames [0, *committed) have entered `plain` (this frame's number: FrameParams::eo_frame)
+  const uint32_t* lp;             // scan of the seed's visited lengths ...
+  const unsigned long long* btp;  // ... exclusive prefix of its block totals: a ray's place in emission order = btp[pos / 4096] + lp[pos]
+  const uint32_t* hseq;           // voxel hashes of the seed's marks in emission order
+  uint32_t* where;                // per seed mark in emission order: its index in M (valid for a ray's first `um` steps)
+  uint4* rinfo;                   // per position: {u0 = steps the seed has marks for, um = leading steps with a mark in M, ray length, checkpoint step}
+  const uint4* ckpt;              // per position: the caster's state at the checkpoint step (3 words of 16 bytes)
   EoCtl* ctl;
 };
 
@@ -389,9 +413,187 @@ __device__ __forceinline__ unsigned long long eo2_ld64(const unsigned long long*
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- the FIRST iteration is a full one, and streams -----------------------------------------------------------------
+// Every mark of the seed is valid, so whether a visit is a hit is a property of the SORTED mark list alone: the mark
+// before it in its slot holds the same hash (or, first of its slot, what earlier frames left there).
+//   k_eo2_hits   : per sorted mark, that bit -> hitb[place of the mark in emission order]
+//   k_eo2_stop0  : per ray (a lane each), the reference's stop rule over its contiguous bits -> new length (in place: nothing
+//                  reads lengths here); a ray that used to stop and does not any more within the steps it has marks for
+//                  goes on in round 1
+//   k_eo2_fcount / fscan / fscatter : the marks the new lengths leave invalid are REMOVED (an order-preserving compaction
+//                  of the sorted list: no second sort), and the owner of every surviving mark whose predecessor in its
+//                  slot was removed is dirty — exactly the readers whose input changed.
+// The event-driven rounds then start from a list in which every mark is valid again (their scans over a slot's marks
+// stop at the first valid one: near the sensor hundreds of seed marks share a slot).
+constexpr uint32_t kEoFilterBlock = 1024;   // marks per workgroup of the filter kernels (256 threads x 4)
+struct EoPhase1 {
+  const uint64_t* keys0;                 // the seed's marks, sorted
+  const uint32_t* vals0;
+  uint64_t* keys1;                       // what is left of them (= EoView::keys)
+  uint32_t* vals1;
+  const uint32_t* lp;                    // scan of the seed's visited lengths (k_eo_scan) ...
+  const unsigned long long* btp;         // ... and the exclusive prefix of its block totals
+  uint8_t* hitb;                         // per mark in emission order: the visit is a hit
+  uint32_t* fcnt;                        // per filter block: surviving marks (then their exclusive prefix)
+};
+__device__ __forceinline__ void eo2_mark_dirty(const EoView& E, uint32_t p, uint32_t* out, uint32_t* n_out);
+
+__global__ void __launch_bounds__(256) k_eo2_hits(EoView E, EoPhase1 P) {
+  const unsigned long long n = E.ctl->st.n_marks;
+  if (E.ctl->fail) return;
+  for (unsigned long long j = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * 256ull) {
+    const uint64_t key = P.keys0[j];
+    const uint32_t slot = (uint32_t)(key >> 44), pos = (uint32_t)(key >> 22) & 0x3fffffu, step = (uint32_t)key & 0x3fffffu;
+    const uint32_t h = P.vals0[j];
+    bool hit;
+    if (j > 0 && (uint32_t)(P.keys0[j - 1] >> 44) == slot) {
+      hit = P.vals0[j - 1] == h;
+    } else {
+      hit = E.plain[slot] == (uint64_t)h;
+      // (the only hash an entry of an EARLIER offset can equal is that of the zero-initialised slot: the ray is looked at
+      // again once the frames before this one have entered their marks)
+      if (h == 0u && !(atomicOr(&E.ux[pos], 0x80000000u) >> 31)) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos;
+    }
+    P.hitb[P.btp[pos / kScanBlock] + P.lp[pos] + step] = hit ? 1 : 0;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_eo2_stop0(EoView E, EoPhase1 P) {
+  if (E.ctl->fail) return;
+  const uint32_t n = E.C->n_rays;
+  const int lim = E.F->max_collisions;
+  for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
+    const uint32_t pos = E.ray_list[r];
+    const uint32_t cv = E.cnt_a[pos], v0 = eo_visited(cv);
+    const uint8_t* hb = P.hitb + (P.btp[pos / kScanBlock] + P.lp[pos]);
+    int c = 0, stop = -1;
+    for (uint32_t k = 0; k < v0; ++k) {
+      c = hb[k] ? c + 1 : 0;
+      if (c > lim) {
+        stop = (int)k;
+        break;
+      }
+    }
+    // no stop: every step that has a mark is visited and updated; if the ray used to stop there it goes on in round 1
+    const uint32_t now = stop >= 0 ? ((uint32_t)stop | kCntBroke) : v0;
+    if (now != cv) {
+      E.cnt_a[pos] = now;
+      E.cnt_b[pos] = now;
+      E.ux[pos] = (E.ux[pos] & 0x80000000u) | eo_visited(now);
+      E.rinfo[pos].y = eo_visited(now);   // marks past the new length leave M below
+    }
+    if (stop < 0 && (cv & kCntBroke)) eo2_mark_dirty(E, pos, E.list[1], &E.ctl->n_in[1]);
+  }
+}
+
+// does mark `key` survive the first iteration?
+__device__ __forceinline__ bool eo2_survives(const EoView& E, uint64_t key) {
+  return ((uint32_t)key & 0x3fffffu) < eo_visited(E.cnt_a[(uint32_t)(key >> 22) & 0x3fffffu]);
+}
+__global__ void __launch_bounds__(256) k_eo2_fcount(EoView E, EoPhase1 P) {
+  __shared__ uint32_t s_w[4];
+  const unsigned long long n = E.ctl->st.n_marks;
+  if (E.ctl->fail || (unsigned long long)blockIdx.x * kEoFilterBlock >= n) return;
+  const unsigned long long j0 = (unsigned long long)blockIdx.x * kEoFilterBlock + threadIdx.x * 4ull;
+  // the mark before this thread's four, then the four
+  uint64_t kprev = 0;
+  bool vprev = true;
+  if (j0 > 0 && j0 < n) {
+    kprev = P.keys0[j0 - 1];
+    vprev = eo2_survives(E, kprev);
+  }
+  uint32_t mine = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const unsigned long long j = j0 + q;
+    if (j >= n) break;
+    const uint64_t key = P.keys0[j];
+    const bool v = eo2_survives(E, key);
+    mine += v ? 1u : 0u;
+    // its predecessor in the slot is gone: what this visit finds in the slot has changed
+    if (v && !vprev && j > 0 && (uint32_t)(kprev >> 44) == (uint32_t)(key >> 44)) eo2_mark_dirty(E, (uint32_t)(key >> 22) & 0x3fffffu, E.list[1], &E.ctl->n_in[1]);
+    kprev = key;
+    vprev = v;
+  }
+  uint32_t x = mine;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+  if (lane_id() == 0) s_w[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) P.fcnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+// exclusive prefix of the block counts, in place; the total = the new mark count (one workgroup)
+__global__ void __launch_bounds__(1024) k_eo2_fscan(EoView E, EoPhase1 P) {
+  __shared__ uint32_t s_w[16];
+  __shared__ unsigned long long s_carry;
+  const unsigned long long n = E.ctl->st.n_marks;
+  if (E.ctl->fail) return;
+  const uint32_t nb = (uint32_t)((n + kEoFilterBlock - 1) / kEoFilterBlock);
+  if (threadIdx.x == 0) s_carry = 0ull;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
+    const uint32_t b = b0 + threadIdx.x;
+    const uint32_t v = b < nb ? P.fcnt[b] : 0u;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t y = __shfl_up(x, o);
+      if (lane_id() >= (uint32_t)o) x += y;
+    }
+    if (lane_id() == 63) s_w[threadIdx.x >> 6] = x;
+    __syncthreads();
+    uint32_t wb = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wb += s_w[w];
+    const unsigned long long carry = s_carry;
+    if (b < nb) P.fcnt[b] = (uint32_t)(carry + wb + x - v);
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + wb + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) E.ctl->n_marks1 = s_carry;
+}
+__global__ void __launch_bounds__(256) k_eo2_fscatter(EoView E, EoPhase1 P) {
+  __shared__ uint32_t s_w[4];
+  const unsigned long long n = E.ctl->st.n_marks;
+  if (E.ctl->fail || (unsigned long long)blockIdx.x * kEoFilterBlock >= n) return;
+  const unsigned long long j0 = (unsigned long long)blockIdx.x * kEoFilterBlock + threadIdx.x * 4ull;
+  uint64_t key[4];
+  bool v[4];
+  uint32_t mine = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    v[q] = false;
+    key[q] = 0;
+    if (j0 + q < n) {
+      key[q] = P.keys0[j0 + q];
+      v[q] = eo2_survives(E, key[q]);
+    }
+    mine += v[q] ? 1u : 0u;
+  }
+  uint32_t x = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t y = __shfl_up(x, o);
+    if (lane_id() >= (uint32_t)o) x += y;
+  }
+  if (lane_id() == 63) s_w[threadIdx.x >> 6] = x;
+  __syncthreads();
+  uint32_t at = P.fcnt[blockIdx.x] + x - mine;
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) at += s_w[w];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (v[q]) {
+      P.keys1[at] = key[q];
+      P.vals1[at] = P.vals0[j0 + q];
+      const uint32_t pos = (uint32_t)(key[q] >> 22) & 0x3fffffu;
+      E.where[P.btp[pos / kScanBlock] + P.lp[pos] + ((uint32_t)key[q] & 0x3fffffu)] = at;
+      ++at;
+    }
+}
+
 // per slot: [begin, end) of its marks in M (the table is clear: k_eo2_commit leaves it so)
 __global__ void __launch_bounds__(256) k_eo2_index(EoView E) {
-  const unsigned long long n = E.ctl->st.n_marks;
+  const unsigned long long n = E.ctl->n_marks1;
   if (E.ctl->fail) return;
   for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull) {
     const uint32_t slot = (uint32_t)(E.keys[i] >> 44);
@@ -446,7 +648,7 @@ struct EoWaveLds {
 };
 
 // keys of the steps [first, first + 64) of a ray (as far as it goes: full = its step count) -> W.keys; `ust` = wave-uniform
-// caster state at `first` (advanced), `ser` = the same state for the serial walk of an axis-parallel ray (lane 0's copy is used)
+// caster state at `first` (advanced)
 __device__ __forceinline__ void eo2_cast64(const FrameParams& F, Dda& ust, bool par, uint32_t first, uint32_t full, EoWaveLds& W, uint32_t lane) {
   const uint32_t n_r = full - first < 64u ? full - first : 64u;
   if (par) {
@@ -467,14 +669,105 @@ __device__ __forceinline__ void eo2_cast64(const FrameParams& F, Dda& ust, bool 
       }
       ust.advance(first + i + 1u < full);
     }
+    for (uint32_t i = n_r; i < 64u; ++i) ust.advance(false);
   }
   KS_WAVE_LDS_ORDER();
 }
 
-__device__ __forceinline__ void eo2_setup(const EoView& E, const FrameParams& F, uint32_t pos, Dda& dda, uint32_t& full) {
-  const RayDesc d = E.rays[ray_index(F, pos)];
-  dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, false);
-  full = (uint32_t)dda.steps + 1u;
+// A ray's steps in batches of up to 64 consecutive ones, WITHOUT casting it for the steps the seed has marks for: their
+// hashes are contiguous in hseq (the slot follows from the hash).  Past them the ray is cast on from its checkpoint
+// (rounds of 64 steps on the checkpoint's grid).  All members wave-uniform.
+struct EoWalk {
+  unsigned long long base;  // the ray's place in emission order
+  uint32_t u0, um, full, cs, pos;
+  uint32_t k0;              // first step of the next batch's grid
+  bool cast;                // past the seed's steps
+  bool par;
+  Dda ust;
+  __device__ __forceinline__ void begin(const EoView& E, uint32_t p) {
+    pos = p;
+    const uint4 ri = E.rinfo[p];
+    u0 = ri.x; um = ri.y; full = ri.z; cs = ri.w;
+    base = E.btp[p / kScanBlock] + E.lp[p];
+    k0 = 0;
+    cast = false;
+    par = false;
+  }
+  // next batch of steps below `limit`: W.keys[k - g] = slot << 32 | hash for the steps k in [a, b) (b - a <= 64, g <= a the
+  // batch's grid origin: lane l holds step g + l); false when there is none
+  __device__ __forceinline__ bool next(const EoView& E, const FrameParams& F, EoWaveLds& W, uint32_t lane, uint32_t limit, uint32_t& g, uint32_t& a,
+                                       uint32_t& b) {
+    if (limit > full) limit = full;
+    for (;;) {
+      if (!cast) {
+        const uint32_t end = u0 < limit ? u0 : limit;
+        if (k0 < end) {
+          g = a = k0;
+          b = k0 + 64u < end ? k0 + 64u : end;
+          if (a + lane < b) {
+            const uint32_t h = E.hseq[base + a + lane];
+            W.keys[lane] = ((unsigned long long)(uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask) << 32) | h;
+          }
+          KS_WAVE_LDS_ORDER();
+          k0 += 64u;
+          return true;
+        }
+        if (u0 >= limit) return false;
+        // the ray goes on past the steps the seed walked: its caster's state at step cs <= u0
+        const uint4 c0 = E.ckpt[3u * pos], c1 = E.ckpt[3u * pos + 1u], c2 = E.ckpt[3u * pos + 2u];
+        ust.cx = (int)c0.x; ust.cy = (int)c0.y; ust.cz = (int)c0.z;
+        ust.sx = (int)(c0.w & 3u) - 1; ust.sy = (int)((c0.w >> 2) & 3u) - 1; ust.sz = (int)((c0.w >> 4) & 3u) - 1;
+        ust.tx = __uint_as_float(c1.x); ust.ty = __uint_as_float(c1.y); ust.tz = __uint_as_float(c1.z);
+        ust.dx = __uint_as_float(c1.w); ust.dy = __uint_as_float(c2.x); ust.dz = __uint_as_float(c2.y);
+        ust.steps = (int)full - 1;
+        ust.in_range = true;
+        par = dda_parallel_ok(ust);
+        cast = true;
+        k0 = cs;
+      } else {
+        if (k0 >= limit) return false;
+        eo2_cast64(F, ust, par, k0, full, W, lane);
+        g = k0;
+        a = k0 > u0 ? k0 : u0;
+        b = k0 + 64u < limit ? k0 + 64u : limit;
+        k0 += 64u;
+        if (a < b) return true;
+      }
+    }
+  }
+};
+
+// What slot `slot` holds just before the ray's own mark at index j of M (the mark of step k < um): the marks before it in
+// its slot, newest first, until a valid one; plus the slot's X marks.
+__device__ __forceinline__ bool eo2_content_at(const EoView& E, const uint32_t* __restrict__ len, uint32_t j, uint32_t slot, uint64_t t, uint32_t pos,
+                                               bool fresh, uint32_t& hash) {
+  bool found = false;
+  uint64_t best = 0;
+  for (uint32_t i = j; i > 0u;) {
+    --i;
+    const uint64_t key = E.keys[i];
+    if ((uint32_t)(key >> 44) != slot) break;
+    const uint32_t p = (uint32_t)(key >> 22) & 0x3fffffu, st = (uint32_t)key & 0x3fffffu;
+    if (p == pos || st < eo_visited(len[p])) {
+      found = true;
+      best = key & kEoLow44;
+      hash = E.vals[i];
+      break;
+    }
+  }
+  uint32_t xi = eo2_ld(&E.tab[slot].z);
+  (void)fresh;
+  while (xi != 0u) {
+    const unsigned long long k = eo2_ld64(&E.xnode[2u * xi]), hn = eo2_ld64(&E.xnode[2u * xi + 1u]);
+    const uint32_t p = (uint32_t)(k >> 22), st = (uint32_t)k & 0x3fffffu;
+    if (k < t && (p == pos || st < eo_visited(len[p])) && (!found || k > best)) {
+      found = true;
+      best = k;
+      hash = (uint32_t)hn;
+    }
+    xi = (uint32_t)(hn >> 32);
+  }
+  return found;
 }
 
 // ONE ray evaluated by a whole wavefront (all operands wave-uniform): how far it gets against the marks valid under A.
@@ -482,31 +775,31 @@ __device__ __forceinline__ void eo2_setup(const EoView& E, const FrameParams& F,
 __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams& F, uint32_t pos, EoWaveLds& W, uint32_t* n_chg) {
   const uint32_t lane = lane_id();
   if (lane == 0) E.dirty[pos] = 0u;
-  Dda ust{};
-  uint32_t full;
-  eo2_setup(E, F, pos, ust, full);
-  const bool par = dda_parallel_ok(ust);
+  EoWalk wk;
+  wk.begin(E, pos);
+  const uint32_t full = wk.full, um = wk.um;
   const uint32_t old = E.cnt_a[pos];
-  const uint32_t ux0 = E.ux[pos];
+  const uint32_t ux_word = E.ux[pos];          // [31] the ray is in the list of rays that consulted earlier frames' marks
+  const uint32_t ux0 = ux_word & 0x7fffffffu;
   const int lim = F.max_collisions;
   int c = 0, stop = -1;
   bool consulted = false, pushed = false;
   uint32_t visited = full;
-  for (uint32_t s0 = 0; s0 < full; s0 += 64) {
-    const uint32_t n_round = full - s0 < 64u ? full - s0 : 64u;
-    eo2_cast64(F, ust, par, s0, full, W, lane);
-    const bool v64 = lane < n_round;
+  uint32_t g, a, b;
+  while (wk.next(E, F, W, lane, full, g, a, b)) {
+    const uint32_t k = g + lane;
+    const bool act = k >= a && k < b;
     bool hit = false;
-    const uint32_t k = s0 + lane;
     unsigned long long key = 0ull;
-    if (v64) {
+    if (act) {
       key = W.keys[lane];
       const uint32_t slot = (uint32_t)(key >> 32), h = (uint32_t)key;
+      const uint64_t t = ((uint64_t)pos << 22) | k;
       bool own = false;
       if (k >= ux0) {
-        // steps of this round that have no mark yet: the ray's own latest earlier visit of the slot among them, if any
-        const uint32_t l0 = ux0 > s0 ? ux0 - s0 : 0u;
-        for (uint32_t l2 = lane; l2 > l0 && !own;) {
+        // steps of this batch that have no mark yet: the ray's own latest earlier visit of the slot among them, if any
+        const uint32_t first = (ux0 > a ? ux0 : a) - g;
+        for (uint32_t l2 = lane; l2 > first && !own;) {
           --l2;
           const unsigned long long k2 = W.keys[l2];
           if ((uint32_t)(k2 >> 32) == slot) {
@@ -517,7 +810,9 @@ __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams&
       }
       if (!own) {
         uint32_t content = 0;
-        if (eo2_content(E, E.cnt_a, slot, ((uint64_t)pos << 22) | k, pos, pushed, content)) hit = content == h;
+        const bool found = k < um ? eo2_content_at(E, E.cnt_a, E.where[wk.base + k], slot, t, pos, pushed, content)
+                                  : eo2_content(E, E.cnt_a, slot, t, pos, true, content);
+        if (found) hit = content == h;
         else {
           hit = E.plain[slot] == (uint64_t)h;
           consulted |= h == 0u;   // (the only hash an entry of an EARLIER offset can equal: the zero-initialised slot)
@@ -525,19 +820,20 @@ __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams&
       }
     }
     __builtin_amdgcn_wave_barrier();
-    const int st_r = early_out_stop(__ballot(v64 && hit), __ballot(v64), lim, c);
-    const uint32_t n_vis = st_r >= 0 ? (uint32_t)st_r + 1u : n_round;   // steps of this round the ray visits
+    const uint32_t sh = a - g;
+    const int st_r = early_out_stop(__ballot(act && hit) >> sh, __ballot(act) >> sh, lim, c);
+    const uint32_t n_vis = st_r >= 0 ? (uint32_t)st_r + 1u : b - a;   // steps of this batch the ray visits
     // X marks for the visited steps without a mark
-    const bool need = v64 && lane < n_vis && k >= ux0;
+    const bool need = act && k - a < n_vis && k >= ux0;
     const unsigned long long nm = __ballot(need);
     if (nm != 0ull) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&E.ctl->n_x, (uint32_t)__popcll(nm));
-      base = (uint32_t)__shfl((int)base, 0);
-      if (base + (uint32_t)__popcll(nm) > E.cap_x) {
+      uint32_t xb = 0;
+      if (lane == 0) xb = atomicAdd(&E.ctl->n_x, (uint32_t)__popcll(nm));
+      xb = (uint32_t)__shfl((int)xb, 0);
+      if (xb + (uint32_t)__popcll(nm) > E.cap_x) {
         if (lane == 0) atomicOr(&E.ctl->fail, kEoFailX);
       } else if (need) {
-        const uint32_t xi = base + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
+        const uint32_t xi = xb + (uint32_t)__popcll(nm & ((1ull << lane) - 1ull));
         const uint32_t slot = (uint32_t)(key >> 32);
         __hip_atomic_store(&E.xnode[2u * xi], ((unsigned long long)pos << 22) | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         uint32_t head = eo2_ld(&E.tab[slot].z);
@@ -554,20 +850,21 @@ __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams&
       __threadfence();
     }
     if (st_r >= 0) {
-      stop = (int)s0 + st_r;
+      stop = (int)(a + (uint32_t)st_r);
       visited = (uint32_t)stop + 1u;
       break;
     }
   }
   const bool any_consulted = __ballot(consulted) != 0ull;
   if (lane == 0) {
-    if (visited > ux0) E.ux[pos] = visited;
+    const bool list_it = any_consulted && !(ux_word >> 31);
+    if (visited > ux0 || list_it) E.ux[pos] = (visited > ux0 ? visited : ux0) | (any_consulted ? 0x80000000u : (ux_word & 0x80000000u));
     const uint32_t now = stop >= 0 ? ((uint32_t)stop | kCntBroke) : full;
     if (now != old) {
       E.cnt_b[pos] = now;
       E.chg[atomicAdd(n_chg, 1u)] = pos;
     }
-    if (any_consulted) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos | 0x80000000u;   // (bit 31: flag for the dedup below)
+    if (list_it) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos;
   }
 }
 
@@ -582,26 +879,34 @@ __device__ __forceinline__ void eo2_propagate_ray(const EoView& E, const FramePa
   const uint32_t old = E.cnt_a[pos], now = E.cnt_b[pos];
   const uint32_t vo = eo_visited(old), vn = eo_visited(now);
   const uint32_t lo = vo < vn ? vo : vn, hi = vo < vn ? vn : vo;
-  Dda ust{};
-  uint32_t full;
-  eo2_setup(E, F, pos, ust, full);
-  const bool par = dda_parallel_ok(ust);
-  for (uint32_t s0 = 0; s0 < hi; s0 += 64) {
-    eo2_cast64(F, ust, par, s0, full, W, lane);
-    const uint32_t k = s0 + lane;
-    if (k >= lo && k < hi) {
+  EoWalk wk;
+  wk.begin(E, pos);
+  // (the steps below lo are not looked at: the walk starts at the batch that holds lo — a multiple of 64 below the seed's steps)
+  wk.k0 = lo < wk.u0 ? (lo & ~63u) : wk.u0;
+  uint32_t g, a, b;
+  while (wk.next(E, F, W, lane, hi, g, a, b)) {
+    const uint32_t k = g + lane;
+    if (k >= a && k < b && k >= lo) {
       const uint32_t slot = (uint32_t)(W.keys[lane] >> 32);
       const uint64_t t = ((uint64_t)pos << 22) | k;
-      const uint4 e = E.tab[slot];
-      uint32_t a = e.x, b = e.y;  // first mark of the slot after t
-      while (a < b) {
-        const uint32_t mid = (a + b) >> 1;
-        if ((E.keys[mid] & kEoLow44) <= t) a = mid + 1;
-        else b = mid;
+      uint32_t m;   // first mark of the slot after t
+      if (k < wk.um) {
+        m = E.where[wk.base + k] + 1u;
+      } else {
+        const uint4 e = E.tab[slot];
+        uint32_t x = e.x, y = e.y;
+        while (x < y) {
+          const uint32_t mid = (x + y) >> 1;
+          if ((E.keys[mid] & kEoLow44) <= t) x = mid + 1;
+          else y = mid;
+        }
+        m = x;
       }
-      for (; a < e.y; ++a) {
-        const uint64_t km = E.keys[a] & kEoLow44;
-        const uint32_t p = (uint32_t)(km >> 22), st = (uint32_t)km & 0x3fffffu;
+      const uint32_t n_m = (uint32_t)E.ctl->n_marks1;
+      for (; m < n_m; ++m) {
+        const uint64_t key = E.keys[m];
+        if ((uint32_t)(key >> 44) != slot) break;
+        const uint32_t p = (uint32_t)(key >> 22) & 0x3fffffu, st = (uint32_t)key & 0x3fffffu;
         if (p != pos) eo2_mark_dirty(E, p, out, n_out);
         if (st < eo_visited(E.cnt_b[p])) break;   // valid under the new lengths: later readers see this one
       }
@@ -624,8 +929,8 @@ __global__ void __launch_bounds__(256) k_eo2_eval(EoView E, uint32_t round) {
   __shared__ EoWaveLds s_w[4];
   EoCtl* ctl = E.ctl;
   if (ctl->fail) return;
-  const uint32_t n = round == 0 ? E.C->n_rays : ctl->n_in[round];
-  const uint32_t* list = round == 0 ? E.ray_list : E.list[round & 1u];
+  const uint32_t n = ctl->n_in[round];
+  const uint32_t* list = E.list[round & 1u];
   const uint32_t wave = threadIdx.x >> 6, w0 = blockIdx.x * 4u + wave, nw = gridDim.x * 4u;
   if (w0 >= n) return;
   const FrameParams F = *E.F;
@@ -668,7 +973,7 @@ __global__ void __launch_bounds__(kEoFinishThreads) k_eo2_finish(EoView E, uint3
   }
   if (chained) {
     const uint32_t nc = ctl->n_consulted;
-    for (uint32_t i = threadIdx.x; i < nc; i += kEoFinishThreads) eo2_mark_dirty(E, E.consulted[i] & 0x7fffffffu, E.list[cur], &ctl->fin_in[cur]);
+    for (uint32_t i = threadIdx.x; i < nc; i += kEoFinishThreads) eo2_mark_dirty(E, E.consulted[i], E.list[cur], &ctl->fin_in[cur]);
     __threadfence();
     __syncthreads();
   }

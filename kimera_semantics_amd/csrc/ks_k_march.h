@@ -189,8 +189,6 @@ struct SlotView {
   Counters* C;
   uint32_t* host_snap;           // pinned snapshot (k_publish)
   const uint32_t* eo_stats;      // exact early-out, event-driven: {X marks + 1, failure bits, rounds} of the frame (else nullptr)
-  uint32_t* pre_hash;            // k_prewalk -> k_test_pre: voxel hashes of the rays of the first generations, [chain][generation][cap]
-  int* pre_steps;                //   and their step counts (-1 = no ray), [chain][generation]
 };
 struct BatchView {
   SlotView s[kBatchMax];
@@ -208,8 +206,7 @@ constexpr uint32_t kCntBroke = 1u << 31;  // cnt[] flag: the ray stopped on a vo
 // of 16; ONE WAVEFRONT owns a (chain, sub-run) and resolves its rays in generation order.  The launch covers the worst
 // case (every ray live: one wavefront per 16 generations); a wavefront finds its rays by ranking the chain's live
 // flags of the phase (64 generations per ballot) and ends at once if the chain has fewer than 16 * sub + 1 of them.
-// (by_generation != 0: sub-run = 16 consecutive generations, live or not — the schedule measured until round 3,
-// kept for A/B runs, KS_SUB_RUN_GENERATIONS=1.)  A ray tests its voxels against (a) the
+// A ray tests its voxels against (a) the
 // marks previous rays of its sub-run made (8 KiB of LDS, newest (generation, step) wins a slot) and
 // (b) the shared set as it stood when the phase began (read-only during the launch).
 //   A  lanes 0..15, one ray each: descriptor, caster set-up, the first 16 voxels walked serially (no lane
@@ -301,7 +298,7 @@ __device__ __forceinline__ bool priv_lookup(const unsigned long long* priv, uint
 __host__ __device__ inline uint32_t test_lds_words64(uint32_t steps_cap) { return kPrivSlots + 256u + steps_cap + 16u + (3u * kES + 1u) / 2u; }
 
 template <bool OVERLAP>
-__global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0, uint32_t g1, uint32_t steps_cap, uint32_t by_generation, uint32_t sub_rays) {
+__global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0, uint32_t g1, uint32_t steps_cap) {
   // stage B kernels read the frame's parameters from device memory: the launch sequence of a frame slot is
   // then identical from frame to frame and is replayed as a captured graph
   const SlotView& sv = V.s[blockIdx.y];
@@ -351,15 +348,12 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
   }
   // ---- which rays: my_gen = generation of the ray lane l < 16 owns (~0u: none) ----
   uint32_t my_gen = ~0u;
-  if (by_generation) {
-    const uint32_t g = g0 + sub * sub_rays + lane;
-    if (lane < sub_rays && g < g0 + (sub + 1u) * sub_rays && g < g1 && (uint64_t)g * kChains + chain < F.n && live[(uint64_t)g * kChains + chain] != 0) my_gen = g;
-  } else {
+  {
     // rank of every live ray of the chain within the phase; ranks [16 sub, 16 sub + 16) are this wavefront's.  Four
     // ballots' worth of flags are in flight at a time (a late phase of a 640x480 frame is 128 generations long).
-    const uint32_t r_lo = sub * sub_rays;   // sub_rays <= 16: rays (or generations) per sub-run, 16 unless an experiment says otherwise
+    const uint32_t r_lo = sub * kSubRun;
     uint32_t seen = 0;
-    for (uint32_t gb = g0; gb < g1 && seen < r_lo + sub_rays; gb += 256u) {
+    for (uint32_t gb = g0; gb < g1 && seen < r_lo + kSubRun; gb += 256u) {
       uint8_t fl[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -373,13 +367,13 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
       for (int q = 0; q < 4; ++q) {
         const unsigned long long m = __ballot(fl[q] != 0);
         const uint32_t rank = seen + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-        if (fl[q] != 0 && rank >= r_lo && rank < r_lo + sub_rays) rinfo[rank - r_lo] = gb + 64u * (uint32_t)q + lane;
+        if (fl[q] != 0 && rank >= r_lo && rank < r_lo + kSubRun) rinfo[rank - r_lo] = gb + 64u * (uint32_t)q + lane;
         seen += (uint32_t)__popcll(m);
       }
     }
     if (seen <= r_lo) return;  // the chain has no 16 * sub + 1 live rays in this phase
     KS_WAVE_LDS_ORDER();
-    if (lane < sub_rays && lane < seen - r_lo) my_gen = rinfo[lane];
+    if (lane < kSubRun && lane < seen - r_lo) my_gen = rinfo[lane];
     KS_WAVE_LDS_ORDER();       // (rinfo is reused below)
   }
   if (__ballot(my_gen != ~0u) == 0ull || (frame_err & (kErrLabel | kErrIndex))) return;
@@ -567,275 +561,6 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
     KS_STAT_ADD(5, st_long);
     KS_STAT_ADD(6, st_rounds);
     KS_STAT_MAX(7, st_rounds);
-  }
-#endif
-}
-
-// ------------------------------------------------------------------------------------------
-// k_prewalk + k_test_pre — the same phases, same schedule, same result as k_test, for the LEADING phases of at most
-// one sub-run per chain (generations [0, G), G = 32 with the default growth).  There hardly any mark exists yet, nearly
-// every ray is walked to its end, and k_test spends such a phase on one ray after the other: caster rounds, then a
-// round trip to the shared set, per 64 voxels, up to 16 rays in sequence, on a chip that holds exactly one such
-// wavefront per SIMD (measured: 16 / 22 / 44 / 54 us for phases of 2 / 4 / 8 / 16 generations at 640x480).  Nothing of
-// that depends on the previous rays of the chain except the private-set lookup, and the walk does not depend on the
-// set at all.  So:
-//   k_prewalk (once per frame): the voxel hashes of ALL steps of every ray of generations [0, G), one ray per lane of
-//      the first 16 lanes, 16 generations of a chain per wavefront; staged in LDS, written out as rows
-//      pre_hash[(chain * Gpad + generation) * cap + step] (a chain's generations are adjacent: what a phase reads
-//      is one contiguous range), pre_steps[chain * Gpad + generation] = steps of the ray, -1 = no ray
-//   k_test_pre (per phase), one wavefront per chain:
-//      B  all 64 lanes: the rays' hashes (global -> registers, and LDS for C) and the shared-set entries of all
-//         their voxels, W (8 / 16 / 32) of each per lane in flight; the snapshot verdict goes to a bitmap in LDS; older-phase entries
-//         are saved exactly as in k_test; ONE wait for the saves
-//      C  the rays in generation order, LDS only: private set, else the stored verdict; collision rule; marks
-// LDS per k_test_pre wavefront: private set (8 KiB) + 16 x cap hashes + 16 x cap verdict bits (cap = longest possible
-// ray + 1, padded to 1 mod 32: the 16 owner lanes of k_prewalk write to different banks).  One wavefront per block.
-// Checked against k_test and a serial restatement of the schedule without a GPU: tools/emu/test_k_test_pre.cpp.
-// ------------------------------------------------------------------------------------------
-// the shared-set mark of a private-set entry (priv_key: generation << 52 | step << 42 | slot >> 10 << 32 | hash) of chain `chain`
-__device__ __forceinline__ void priv_flush(obs_global_u64* observed, uint32_t tag, uint32_t chain, uint32_t idx, unsigned long long e) {
-  const uint32_t slot = ((uint32_t)((e >> 32) & 1023ull) << 10) | idx;
-  const uint32_t pos = (uint32_t)(e >> 52) * kChains + chain;
-  obs_atomic_max(&observed[2u * slot], (unsigned long long)obs_entry(tag, pos, (uint32_t)e));
-}
-constexpr uint32_t kPreMaxChunks = 128;   // 16 rays x ceil(cap / 64), cap <= 512
-__host__ __device__ inline uint32_t test_pre_cap(uint32_t steps_cap) { return ((steps_cap + 1u + 31u) & ~31u) + 1u; }
-__host__ __device__ inline uint32_t test_pre_bit_words(uint32_t cap) { return (cap + 31u) / 32u; }
-__host__ __device__ inline uint32_t test_pre_lds_bytes(uint32_t cap) {
-  return kPrivSlots * 8u + 16u * cap * 4u + 16u * test_pre_bit_words(cap) * 4u + 64u + kPreMaxChunks * 4u;
-}
-__host__ __device__ inline uint32_t prewalk_lds_bytes(uint32_t cap) { return 16u * cap * 4u; }
-
-__global__ void __launch_bounds__(64) k_prewalk(BatchView V, uint32_t G, uint32_t Gpad, uint32_t cap) {
-  const SlotView& sv = V.s[blockIdx.y];
-  const uint8_t* __restrict__ live = sv.live;
-  const RayDesc* __restrict__ rays = sv.rays;
-  const FrameParams F = *sv.F;
-  extern __shared__ unsigned long long s_test[];
-  uint32_t* rows = (uint32_t*)s_test;   // [16 rays][cap]
-  if (sv.C->err & (kErrLabel | kErrIndex)) return;
-  const uint32_t lane = lane_id();
-  const uint32_t chain = blockIdx.x % kChains, gs = (blockIdx.x / kChains) * kSubRun;
-  int my_steps = -1;
-  if (lane < kSubRun) {
-    const uint32_t g = gs + lane;
-    const uint64_t p = (uint64_t)g * kChains + chain;
-    if (g < G && p < F.n && live[p] != 0) {
-      const RayDesc d = rays[ray_index(F, (uint32_t)p)];
-      Dda dda{};
-      dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc,
-                /*cast_from_origin=*/false);
-      my_steps = dda.steps < (int)cap ? dda.steps : (int)cap - 1;   // (cap covers the longest possible ray)
-      uint32_t h = index_hash(dda.cx, dda.cy, dda.cz);
-      const uint32_t hx = (uint32_t)dda.sx, hy = (uint32_t)dda.sy * 17191u, hz = (uint32_t)dda.sz * 295530481u;
-      uint32_t* mine = rows + (size_t)lane * cap;
-      for (int s = 0; s <= my_steps; ++s) {   // (no collective inside: every lane runs its own trip count; the state
-        mine[s] = h;                          //  after the last voxel is not used)
-        dda.advance_hashed(h, hx, hy, hz);
-      }
-    }
-    sv.pre_steps[(size_t)chain * Gpad + g] = my_steps;
-  }
-  __syncthreads();   // (one wavefront: orders the LDS writes above against the reads below)
-  uint32_t* __restrict__ out = sv.pre_hash + ((size_t)chain * Gpad + gs) * cap;
-  for (uint32_t r = 0; r < kSubRun; ++r) {
-    const int steps_r = __shfl(my_steps, (int)r);
-    for (int i = (int)lane; i <= steps_r; i += 64) out[r * cap + (uint32_t)i] = rows[r * cap + (uint32_t)i];
-  }
-}
-
-// W: look-ups per lane in flight (a batch runs all W slots, used or not: sized to the phase by the host);
-// DEDUP: the shared-set marks go through the private set (below)
-template <uint32_t W, bool DEDUP>
-__global__ void __launch_bounds__(64) k_test_pre(BatchView V, uint32_t g0, uint32_t g1, uint32_t Gpad, uint32_t cap) {
-  const SlotView& sv = V.s[blockIdx.y];
-  uint32_t* __restrict__ cnt = sv.cnt;
-  const Counters* C = sv.C;
-  const FrameParams F = *sv.F;
-  // [slot] = {newest, older}.  The table pointer comes out of a struct in memory, i.e. as a generic pointer; accesses
-  // through it would be FLAT operations, which the compiler must order conservatively against LDS traffic (a full
-  // s_waitcnt after every save).  It is device memory: say so.
-  obs_global_u64* observed = (obs_global_u64*)(unsigned long long*)F.observed;
-  const uint32_t phase_pos0 = g0 * kChains;
-  extern __shared__ unsigned long long s_test[];
-  const uint32_t lane = lane_id();
-  const uint32_t hw = test_pre_bit_words(cap);
-  unsigned long long* priv = s_test;
-  uint32_t* ahash = (uint32_t*)(priv + kPrivSlots);     // [16 rays][cap]  voxel hashes
-  uint32_t* hbits = ahash + 16u * cap;                  // [16 rays][hw]   bit s: the shared set (phase start) holds voxel s
-  int* rsteps = (int*)(hbits + 16u * hw);               // [16] steps of the ray, -1 = no ray
-  uint32_t* clist = (uint32_t*)(rsteps + 16);           // [<= kPreMaxChunks] ray << 8 | 64-voxel chunk of the ray
-  for (uint32_t i = lane; i < kPrivSlots; i += 64) priv[i] = 0ull;
-  for (uint32_t i = lane; i < 16u * hw; i += 64) hbits[i] = 0u;
-  if (C->err & (kErrLabel | kErrIndex)) return;
-  const uint32_t chain = blockIdx.x;   // the phase is one sub-run: one wavefront per chain
-  const uint32_t gs = g0;
-  {
-    const uint32_t n_gen = (F.n + kChains - 1u) / kChains;
-    if (g1 > n_gen) g1 = n_gen;
-  }
-  if (gs >= g1) return;
-  const uint32_t ge = gs + kSubRun < g1 ? gs + kSubRun : g1;
-  const int lim = F.max_collisions;
-  auto slot_of = [&](uint32_t h) -> uint32_t { return (uint32_t)(((uint64_t)h + F.observed_offset) & kSetMask); };
-#ifdef KS_STATS
-  const unsigned long long tp0 = __builtin_readcyclecounter(), tw0 = wall_clock64();
-  unsigned long long tp1 = 0, tp2 = 0;
-  uint32_t st_steps = 0, st_chunks = 0;
-#endif
-  {
-    // ---- the rays of the sub-run: lane l < 16 holds the one of generation gs + l ----
-    int my_steps = -1;
-    if (lane < kSubRun && gs + lane < ge) my_steps = sv.pre_steps[(size_t)chain * Gpad + gs + lane];
-    if (lane < 16) rsteps[lane] = my_steps;
-    // 64-voxel chunks of the live rays, ray after ray (no collective: lane 0 alone; <= 128 entries)
-    int max_steps = my_steps;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      const int other = __shfl_xor(max_steps, o);
-      max_steps = other > max_steps ? other : max_steps;
-    }
-    if (max_steps < 0) return;   // no live ray in this sub-run (wave-uniform)
-    uint32_t n_chunks = 0;
-    for (uint32_t r = 0; r < kSubRun; ++r) {
-      const int steps_r = __shfl(my_steps, (int)r);
-      if (steps_r < 0) continue;   // (wave-uniform)
-      const uint32_t nc = ((uint32_t)steps_r + 64u) >> 6;
-      if (lane < nc && n_chunks + lane < kPreMaxChunks) clist[n_chunks + lane] = (r << 8) | lane;
-      n_chunks += nc;
-    }
-    if (n_chunks > kPreMaxChunks) n_chunks = kPreMaxChunks;   // (cannot happen: cap <= 512)
-    __syncthreads();   // (one wavefront: orders the LDS writes above against the reads below)
-#ifdef KS_STATS
-    tp1 = __builtin_readcyclecounter();
-    st_steps = (uint32_t)max_steps + 1u;
-    st_chunks = n_chunks;
-#endif
-    // ---- B: hashes, and the shared set as it stood when the phase began, for every voxel of every ray ----
-    const uint32_t* __restrict__ gh = sv.pre_hash + ((size_t)chain * Gpad + gs) * cap;
-    for (uint32_t q0 = 0; q0 < n_chunks; q0 += W) {
-      uint32_t hh[W];
-      uint32_t on_m = 0u;
-      obs_u64x2 ee[W];
-#pragma unroll
-      for (uint32_t b = 0; b < W; ++b) {   // the hashes first, all in flight
-        const uint32_t q = q0 + b;
-        const uint32_t e = q < n_chunks ? clist[q] : 0u;
-        const uint32_t r = e >> 8, s = (e & 255u) * 64u + lane;
-        const bool on = q < n_chunks && (int)s <= rsteps[r];
-        on_m |= on ? (1u << b) : 0u;
-        hh[b] = on ? gh[r * cap + s] : 0u;
-      }
-#pragma unroll
-      for (uint32_t b = 0; b < W; ++b) {   // then the set entries, all in flight; the hashes to LDS for C
-        const bool on = ((on_m >> b) & 1u) != 0u;
-        if (on) {
-          const uint32_t e = clist[q0 + b];
-          ahash[(e >> 8) * cap + (e & 255u) * 64u + lane] = hh[b];
-        }
-        ee[b] = on ? ((const obs_global_u64x2*)observed)[slot_of(hh[b])] : obs_u64x2{0ull, 0ull};
-      }
-      // verdicts first, without a branch around a use of the loaded data (the compiler then waits for exactly the load
-      // a verdict needs; behind a branch it would wait for everything in flight, saves included, verdict after verdict)
-      uint32_t save_m = 0u, hit_m = 0u;
-#pragma unroll
-      for (uint32_t b = 0; b < W; ++b) {
-        const obs_u64x2 e = ee[b];
-        const bool valid = ((on_m >> b) & 1u) != 0u;
-        const bool current = (uint32_t)(e.x >> 54) == F.obs_tag && ((uint32_t)(e.x >> 32) & 0x3fffffu) > phase_pos0;
-        const unsigned long long content = current ? e.y : e.x;
-        save_m |= (valid && !current && e.x != 0ull && e.x != e.y) ? (1u << b) : 0u;
-        hit_m |= (valid && obs_match(content, hh[b], F.obs_tag_lo, F.obs_tag)) ? (1u << b) : 0u;
-      }
-#pragma unroll
-      for (uint32_t b = 0; b < W; ++b) {
-        if ((save_m >> b) & 1u) obs_atomic_max(&observed[2u * slot_of(hh[b]) + 1u], ee[b].x);   // save the older-phase mark
-        if ((hit_m >> b) & 1u) {
-          const uint32_t e = clist[q0 + b];
-          const uint32_t r = e >> 8, s = (e & 255u) * 64u + lane;
-          atomicOr(&hbits[r * hw + (s >> 5)], 1u << (s & 31u));
-        }
-      }
-    }
-    // every save of this wavefront has been performed before any of its marks goes out
-    KS_WAIT_VMEM();
-    __syncthreads();
-#ifdef KS_STATS
-    tp2 = __builtin_readcyclecounter();
-#endif
-  }
-  // ---- C: the rays in generation order ----
-  for (uint32_t j = 0; j < kSubRun; ++j) {
-    const int steps_j = rsteps[j];
-    if (steps_j < 0) continue;   // (wave-uniform)
-    KS_WAVE_LDS_ORDER();         // the previous ray's marks in the private set
-    const uint32_t gen_j = gs + j, pos_j = gen_j * kChains + chain;
-    const uint32_t* hj = ahash + (size_t)j * cap;
-    const uint32_t* bj = hbits + (size_t)j * hw;
-    int c = 0, stop = -1;
-    uint32_t updates = 0, visited = 0;
-    for (uint32_t s0 = 0;; s0 += 64u) {
-      const uint32_t left = (uint32_t)steps_j + 1u - s0;
-      const uint32_t n_round = left < 64u ? left : 64u;
-      const bool v = lane < n_round;
-      bool hit = false;
-      if (v) {
-        const uint32_t s = s0 + lane, h = hj[s];
-        if (!priv_lookup(priv, slot_of(h), h, hit)) hit = ((bj[s >> 5] >> (s & 31u)) & 1u) != 0u;
-      }
-      stop = early_out_stop(__ballot(v && hit), __ballot(v), lim, c);
-      if (stop >= 0) {
-        updates = s0 + (uint32_t)stop;
-        visited = updates + 1u;
-        break;
-      }
-      if (s0 + 64u > (uint32_t)steps_j) {
-        updates = (uint32_t)steps_j + 1u;
-        visited = updates;
-        break;
-      }
-    }
-    // The ray's marks (all visited voxels) go to the chain's private set.  Their way into the shared set is through it:
-    // in the leading phases every ray reaches the voxels next to the sensor, and one atomicMax per ray and voxel on those
-    // few slots (16 k of them in a 16-generation phase) is what the phase then waits for — same-address atomics
-    // serialise in the L2.  The shared set only keeps the mark of the highest position, and of the rays of this
-    // wavefront that is the one the private set retains: an entry leaves for the shared set when another VOXEL takes its
-    // place (or loses against it), and whatever is left goes out at the end — one atomic per voxel and wavefront.
-    for (uint32_t m0 = 0; m0 < visited; m0 += 64u) {
-      const uint32_t s = m0 + lane;
-      if (s < visited) {
-        const uint32_t h = hj[s], slot = slot_of(h), idx = slot & (kPrivSlots - 1u);
-        const unsigned long long key = priv_key(gen_j, s, slot, h);
-        const unsigned long long old = atomicMax(&priv[idx], key);
-        if (DEDUP) {
-          const unsigned long long loser = old < key ? old : key, winner = old < key ? key : old;
-          if (loser != 0ull && (loser & 0x3ffffffffffull) != (winner & 0x3ffffffffffull))   // a different voxel (slot bits | hash)
-            priv_flush(observed, F.obs_tag, chain, idx, loser);
-        } else {
-          obs_atomic_max(&observed[2u * slot], (unsigned long long)obs_entry(F.obs_tag, pos_j, h));   // one mark per visited voxel, as k_test
-        }
-      }
-    }
-    if (lane == 0) cnt[pos_j] = updates | (stop >= 0 ? kCntBroke : 0u);
-  }
-  if (DEDUP) {
-    KS_WAVE_LDS_ORDER();   // the last ray's marks
-    for (uint32_t i = lane; i < kPrivSlots; i += 64) {
-      const unsigned long long e = priv[i];
-      if (e != 0ull) priv_flush(observed, F.obs_tag, chain, i, e);
-    }
-  }
-#ifdef KS_STATS
-  {
-    const unsigned long long tp3 = __builtin_readcyclecounter(), tw3 = wall_clock64();
-    KS_STAT_ADD(8, tp1 - tp0);
-    KS_STAT_ADD(9, tp2 - tp1);
-    KS_STAT_ADD(10, tp3 - tp2);
-    KS_STAT_ADD(11, 1);
-    KS_STAT_ADD(12, tw3 - tw0);
-    KS_STAT_ADD(13, st_steps);
-    KS_STAT_ADD(14, st_chunks);
-    KS_STAT_MAX(15, tw3 - tw0);
   }
 #endif
 }
@@ -1029,19 +754,13 @@ __global__ void __launch_bounds__(256) k_emit(BatchView V, TileTable T, Pool P) 
 // k_emit_lane — the same emission without anti-grazing (every step of a ray emits): ONE LANE PER RAY walks the
 // first 32 voxels serially (consecutive voxels share their tile: one table lookup per tile crossing), the few
 // rays that go further are then taken one at a time by the whole wavefront (exact parallel caster).
-// STAGE (opt-in, KS_EMIT_STAGE=1; checked on the functional model, not yet measured): the owner lanes put the keys of a
-// ray's first 32 voxels into LDS instead of writing them one 8-byte word per lane and step (64 partial lines per store
-// instruction); the wavefront then writes them out 32 consecutive keys per half-wavefront — the rays of a wavefront are
-// consecutive in integration order, so their ranges of the pair list are adjacent.
-constexpr uint32_t kStageStride = kLaneWalk + 1;   // keys per ray in LDS (+1: the owner lanes write to different banks)
-template <int RPW, bool STAGE = false>
+template <int RPW>
 __global__ void __launch_bounds__(256) k_emit_lane(BatchView V, TileTable T, Pool P) {
   KS_SLOT_ARGS(V)
   if (blockIdx.x != 0 && blockIdx.x * 4u * (uint32_t)RPW >= C->n_rays) return;
   extern __shared__ unsigned long long s_bt[];
   __shared__ unsigned long long s_carry;
   __shared__ float s_e[4][3 * kES];
-  __shared__ unsigned long long s_stage[STAGE ? 4 : 1][STAGE ? RPW * kStageStride : 1];
   const uint32_t nb = (scan_length(F) + kScanBlock - 1) / kScanBlock;
   if (threadIdx.x == 0) s_carry = 0ull;
   __syncthreads();
@@ -1125,20 +844,9 @@ __global__ void __launch_bounds__(256) k_emit_lane(BatchView V, TileTable T, Poo
     if (on) {
       const uint32_t local = (uint32_t)(dda.cx & 7) + 8u * ((uint32_t)(dda.cy & 7) + 8u * (uint32_t)(dda.cz & 7));
       const uint64_t key = ((uint64_t)(slot * (uint32_t)kTileVoxels + local) << F.seq_bits) | key_lo;
-      if (STAGE && s < kLaneWalk) s_stage[threadIdx.x >> 6][lane * kStageStride + s] = key;
-      else pairs[base + s] = key;
+      pairs[base + s] = key;
     }
     dda.advance(on);
-  }
-  if (STAGE) {
-    KS_WAVE_LDS_ORDER();
-    const unsigned long long* stage = s_stage[threadIdx.x >> 6];
-    for (uint32_t i = 0; i < (uint32_t)RPW; i += 2) {   // lanes 0..31: ray i, lanes 32..63: ray i + 1
-      const uint32_t rr = i + (lane >> 5), s = lane & 31u;
-      const uint32_t own_r = __shfl(own, (int)rr);
-      const unsigned long long base_r = __shfl(base, (int)rr);
-      if (s < (own_r < kLaneWalk ? own_r : kLaneWalk)) pairs[base_r + s] = stage[rr * kStageStride + s];
-    }
   }
   float* escr = s_e[threadIdx.x >> 6];
   for (unsigned long long todo = by_wave ? long_mask : 0ull; todo != 0ull; todo &= todo - 1ull) {

@@ -52,6 +52,7 @@ ks_config makeConfig(HipSemanticTsdfIntegrator::Method method, const vxb::TsdfIn
     k.label_rgba[kv.first][2] = kv.second.b;
     k.label_rgba[kv.first][3] = kv.second.a;
   }
+  k.early_out_phase_growth = o.early_out_phase_growth;
   k.device_id = o.device_id;
   k.max_tiles = o.max_tiles;
   k.max_points = o.max_points;

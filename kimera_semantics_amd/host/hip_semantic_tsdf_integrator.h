@@ -46,6 +46,11 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
     /// syncLayers() moves only the VOXELS written since the previous sync (ks_download_updated_voxels: 120-byte
     /// records scattered into the host blocks) instead of whole updated blocks (ks_download_blocks).
     bool voxel_sync = true;
+    /// `fast` with the early-out enabled (ks_config.early_out_phase_growth): 0 = the map the reference produces at
+    /// integrator_threads = 1 (its deterministic case), bit for bit — the default, whatever Config::integrator_threads
+    /// says (with more threads the reference itself is racy: any of its results is within its own spread of this
+    /// one); 16..4096 = the ordered-phase schedule alone (a few launches cheaper, not the reference's map).
+    int early_out_phase_growth = 0;
   };
 
   HipSemanticTsdfIntegrator(Method method, const Config& config, const SemanticConfig& semantic_config,

@@ -613,9 +613,7 @@ struct ko_ctx {
   //   * generations are cut into phases [B_j, B_j+1), B_0 = 0, B_j+1 = B_j + max(1, B_j (growth-16)/16);
   //   * within a phase the 1024 chains are independent, and a chain's LIVE rays of the phase (those that
   //     survived the start-voxel dedup), taken in generation order, are cut into sub-runs of 16 that are
-  //     independent too; a sub-run walks its rays in generation order.  (Until round 3 a sub-run was 16
-  //     GENERATIONS, live or not — KO_SUB_RUN_GENERATIONS=1 / KS_SUB_RUN_GENERATIONS=1 bring that schedule
-  //     back on both sides for A/B runs.  A phase of at most 16 generations is one sub-run either way.)
+  //     independent too; a sub-run walks its rays in generation order;
   //   * a ray tests every voxel of its path against: the marks the PREVIOUS rays of its own sub-run made
   //     (private direct-mapped set of 1024 entries, newest (generation, step) wins an entry), else the
   //     shared set as it stood when the phase began;
@@ -629,10 +627,8 @@ struct ko_ctx {
   static constexpr size_t kMarkFlag = size_t(1) << 40;  // set in every mark the phased schedule stores in the shared set
   static std::vector<uint32_t> phase_bounds(uint32_t n_gen, int growth) {
     std::vector<uint32_t> b{0};
-    // schedule research only (tests/early_out_fidelity.py): KO_EXP_FIRST_PHASE = generations in the first phase
-    static const uint64_t first = getenv("KO_EXP_FIRST_PHASE") ? strtoull(getenv("KO_EXP_FIRST_PHASE"), nullptr, 10) : 1;
     for (;;) {
-      const uint64_t inc = std::max<uint64_t>(b.back() == 0 ? first : 1, (uint64_t)b.back() * (uint64_t)(growth - 16) / 16);
+      const uint64_t inc = std::max<uint64_t>(1, (uint64_t)b.back() * (uint64_t)(growth - 16) / 16);
       if (b.back() + inc >= n_gen) break;
       b.push_back((uint32_t)(b.back() + inc));
     }
@@ -669,7 +665,6 @@ struct ko_ctx {
     std::vector<uint32_t> live_seen(kChains);  // live rays of the chain the phase has handled so far
     const bool wave_stats = getenv("KO_WAVE_STATS") != nullptr;   // schedule research: per phase, the work of the (chain, sub-run) wavefronts -> stderr
     std::unordered_map<uint64_t, std::array<uint64_t, 3>> wave_work;
-    const bool sub_run_generations = getenv("KO_SUB_RUN_GENERATIONS") && atoi(getenv("KO_SUB_RUN_GENERATIONS")) != 0;  // (read per frame: tests switch it)
     std::vector<std::pair<uint32_t, uint64_t>> own;
     size_t r0 = 0;
     for (size_t j = 0; j < B.size() && r0 < rays.size(); ++j) {
@@ -684,9 +679,7 @@ struct ko_ctx {
         Ray& r = rays[r1];
         const uint32_t chain = r.pos % kChains, gen = r.pos / kChains;
         uint64_t* pv = &priv[(size_t)chain * kPrivSlots];
-        // (KO_EXP_SUB_RUN: schedule research only — the GPU's sub-runs are kSubRun rays long)
-        const uint32_t sub_run = getenv("KO_EXP_SUB_RUN") ? (uint32_t)strtoul(getenv("KO_EXP_SUB_RUN"), nullptr, 10) : kSubRun;   // (read per ray: tests switch it)
-        const uint32_t sub = sub_run_generations ? (gen - B[j]) / sub_run : live_seen[chain]++ / sub_run;
+        const uint32_t sub = live_seen[chain]++ / kSubRun;
         if (sub != priv_sub[chain]) {  // a new sub-run starts with an empty private set
           std::fill(pv, pv + kPrivSlots, 0ull);
           priv_sub[chain] = sub;
@@ -1394,11 +1387,37 @@ size_t ko_sim_fixpoint(const ko_config* cfg, const float Tq[7], const float* xyz
   uint64_t tot_steps = 0, tot_back = 0, tot_fwd = 0;
   auto before = [](uint32_t r1, uint32_t k1, uint32_t r2, uint32_t k2) { return r1 < r2 || (r1 == r2 && k1 < k2); };
   static const std::vector<Mark> kNone;
+  const bool jacobi = getenv("KO_STUDY_JACOBI") != nullptr;   // rounds as the GPU runs them: evaluate all against the old lengths, then apply + propagate
   while (!work.empty() && round < 1000) {
     for (size_t i = work.size(); i > 1; --i) std::swap(work[i - 1], work[rnd() % i]);
     for (uint32_t i : work) dirty[i] = 0;
     std::vector<uint32_t> next;
     size_t changed = 0, steps = 0, back = 0, fwd = 0, toggled = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> pending;   // (ray, new length) of the Jacobi round
+    auto propagate = [&](uint32_t i, uint32_t old, uint32_t vis) {
+      for (uint32_t k = std::min(old, vis); k < std::max(old, vis); ++k) {
+        ++toggled;
+        auto im = M.find(path[i][k].slot);
+        if (im != M.end()) {
+          const std::vector<Mark>& v = im->second;
+          size_t j = find_mark(v, i, k);
+          if (j < v.size() && v[j].ray == i && v[j].step == k) ++j;
+          for (; j < v.size(); ++j) {
+            ++fwd;
+            const uint32_t o = v[j].ray;
+            if (o != i && !dirty[o]) { dirty[o] = 1; next.push_back(o); }
+            if (v[j].step < L[o]) break;
+          }
+        }
+        auto ix = X.find(path[i][k].slot);
+        if (ix != X.end())
+          for (const Mark& m : ix->second) {
+            ++fwd;
+            if (!before(i, k, m.ray, m.step)) continue;
+            if (m.ray != i && !dirty[m.ray]) { dirty[m.ray] = 1; next.push_back(m.ray); }
+          }
+      }
+    };
     for (uint32_t i : work) {
       int64_t cc = 0;
       uint32_t vis = 0;
@@ -1433,30 +1452,17 @@ size_t ko_sim_fixpoint(const ko_config* cfg, const float Tq[7], const float* xyz
       const uint32_t old = L[i];
       if (vis != old) {
         ++changed;
-        L[i] = vis;
-        for (uint32_t k = std::min(old, vis); k < std::max(old, vis); ++k) {
-          ++toggled;
-          auto im = M.find(path[i][k].slot);
-          if (im != M.end()) {
-            const std::vector<Mark>& v = im->second;
-            size_t j = find_mark(v, i, k);
-            if (j < v.size() && v[j].ray == i && v[j].step == k) ++j;
-            for (; j < v.size(); ++j) {
-              ++fwd;
-              const uint32_t o = v[j].ray;
-              if (o != i && !dirty[o]) { dirty[o] = 1; next.push_back(o); }
-              if (v[j].step < L[o]) break;
-            }
-          }
-          auto ix = X.find(path[i][k].slot);
-          if (ix != X.end())
-            for (const Mark& m : ix->second) {
-              ++fwd;
-              if (!before(i, k, m.ray, m.step)) continue;
-              if (m.ray != i && !dirty[m.ray]) { dirty[m.ray] = 1; next.push_back(m.ray); }
-            }
+        if (jacobi) pending.push_back({i, vis});
+        else {
+          L[i] = vis;
+          propagate(i, old, vis);
         }
       }
+    }
+    if (jacobi) {
+      std::vector<uint32_t> olds;
+      for (auto& pr : pending) { olds.push_back(L[pr.first]); L[pr.first] = pr.second; }
+      for (size_t q = 0; q < pending.size(); ++q) propagate(pending[q].first, olds[q], pending[q].second);
     }
     fprintf(stderr, "  round %2zu: dirty %7zu changed %6zu toggled %7zu walk steps %8zu back-scan %8zu fwd-scan %7zu  X marks %zu\n", round, work.size(), changed,
             toggled, steps, back, fwd, n_x);
@@ -1464,6 +1470,17 @@ size_t ko_sim_fixpoint(const ko_config* cfg, const float Tq[7], const float* xyz
     tot_steps += steps; tot_back += back; tot_fwd += fwd;
     work.swap(next);
     ++round;
+  }
+  {
+    size_t max_x = 0, max_m = 0, x_slots = 0;
+    for (auto& kv : X) { max_x = std::max(max_x, kv.second.size()); ++x_slots; }
+    for (auto& kv : M) max_m = std::max(max_m, kv.second.size());
+    std::vector<size_t> xs;
+    for (auto& kv : X) xs.push_back(kv.second.size());
+    std::sort(xs.rbegin(), xs.rend());
+    fprintf(stderr, "longest X chain %zu (slots with X marks %zu; top:", max_x, x_slots);
+    for (size_t i = 0; i < std::min<size_t>(8, xs.size()); ++i) fprintf(stderr, " %zu", xs[i]);
+    fprintf(stderr, "), longest M range %zu\n", max_m);
   }
   size_t wrong = 0, ref_marks = 0;
   for (size_t i = 0; i < R; ++i) { wrong += L[i] != Lref[i]; ref_marks += Lref[i]; }

@@ -51,24 +51,26 @@ def test_device_code_on_the_host_equals_oracle(emu_lib, name):
     run_case(emu_lib, CASES[name])
 
 
-def test_prewalk_variant_of_the_leading_phases_equals_oracle(emu_lib):
-    """KS_TEST_PRE=1 (k_prewalk + k_test_pre<8/16/32>) end to end: 256x160 = 40 generations, every phase
-    is a single sub-run, all three look-up widths are used."""
-    run_case(emu_lib, dict(method=0, size=[256, 160], frames=1, cfg=dict(early_out_phase_growth=32)), env_extra={"KS_TEST_PRE": "1"})
+def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_lib):
+    """320x240 = 75 generations: the phases [32, 64) and [64, 75) have up to two sub-runs per chain, cut over the chain's LIVE rays."""
+    run_case(emu_lib, dict(method=0, size=[320, 240], frames=2, max_tiles=8192, cfg=dict(early_out_phase_growth=32)))
 
 
-def test_sub_runs_of_eight_rays_equal_oracle(emu_lib):
-    """KS_SUB_RUN_RAYS / KO_EXP_SUB_RUN = 8: the experiment knob for the length of a sub-run (bench.py times it against 16)."""
-    run_case(emu_lib, dict(method=0, size=[256, 160], frames=1, max_tiles=8192, cfg=dict(early_out_phase_growth=32)),
-             env_extra={"KS_SUB_RUN_RAYS": "8", "KO_EXP_SUB_RUN": "8"})
+@pytest.mark.parametrize("spec", [
+    dict(method=0, size=[160, 120], frames=3),                                   # the default: the reference's serial result, event-driven
+    dict(method=0, size=[128, 96], frames=5, pipeline=4),                        # frames in flight, commit chain
+    dict(method=0, size=[96, 72], frames=4, cfg=dict(clear_checks_every_n_frames=3)),   # a frame's marks are inputs of the next frame
+    dict(method=0, size=[96, 72], frames=2, cloud="axis", max_tiles=8192),       # axis-parallel rays: the serial caster inside the rounds
+    dict(method=0, size=[64, 36], frames=2, max_tiles=32768, cfg=dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0)),
+], ids=["default", "pipelined", "clear_every_3", "axis_parallel", "long_rays"])
+def test_event_driven_exact_early_out_equals_serial_oracle(emu_lib, spec):
+    run_case(emu_lib, spec)
 
 
-@pytest.mark.parametrize("legacy", ["0", "1"])
-def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_lib, legacy):
-    """320x240 = 75 generations: the phases [32, 64) and [64, 75) have up to two sub-runs per chain, cut over the chain's LIVE
-    rays (default) or over its generations (the schedule until round 3, kept switchable on both sides for A/B runs)."""
-    run_case(emu_lib, dict(method=0, size=[320, 240], frames=2 if legacy == "0" else 1, max_tiles=8192, cfg=dict(early_out_phase_growth=32)),
-             env_extra={"KS_SUB_RUN_GENERATIONS": legacy, "KO_SUB_RUN_GENERATIONS": legacy})
+@pytest.mark.parametrize("pipeline", [0, 4])
+def test_exact_early_out_overflow_falls_back_to_the_host_loop(emu_lib, pipeline):
+    """marks and X marks that do not fit their buffers: host-driven loop for the frame (and those in flight behind it), buffers grow."""
+    run_case(emu_lib, dict(method=0, size=[96, 72], frames=4, pipeline=pipeline), env_extra={"KS_EXACT_CAP_MARKS": "20000", "KS_EXACT_CAP_X": "16"})
 
 
 @pytest.mark.parametrize("overlap", ["1", "0"])
@@ -77,14 +79,6 @@ def test_axis_parallel_rays_under_the_early_out_equal_oracle(emu_lib, overlap):
     cast while the current round's shared-set entries are in flight (default) and one after the other (KS_TEST_OVERLAP=0)."""
     run_case(emu_lib, dict(method=0, size=[96, 72] if overlap == "1" else [64, 48], frames=1, max_tiles=8192, cloud="axis",
                            cfg=dict(early_out_phase_growth=32)), env_extra={"KS_TEST_OVERLAP": overlap})
-
-
-def test_staged_pair_emission_equals_oracle(emu_lib):
-    """KS_EMIT_STAGE=1 (k_emit_lane<RPW, true>: a ray's first keys staged in LDS and written out by the wavefront), on a
-    2 cm / 9 m geometry (long rays: owner-lane part + whole-wavefront tails) and on the default geometry with the early-out."""
-    run_case(emu_lib, dict(method=0, size=[64, 48], frames=1, no_early_out=True, max_tiles=16384,
-                           cfg=dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0)), env_extra={"KS_EMIT_STAGE": "1"})
-    run_case(emu_lib, dict(method=0, size=[96, 72], frames=2, cfg=dict(early_out_phase_growth=32)), env_extra={"KS_EMIT_STAGE": "1"})
 
 
 def test_gpu_tier_cases_unchanged_on_the_functional_model(emu_lib):

@@ -194,9 +194,9 @@ def test_exact_early_out_falls_back_to_the_host_loop_and_grows(monkeypatch, pipe
     h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 17, pipeline_frames=pipe, **okw))
     monkeypatch.delenv("KS_EXACT_CAP_MARKS")
     monkeypatch.delenv("KS_EXACT_CAP_X")
-    _totals(o, h, _frames(12))
+    _totals(o, h, _frames(24))
     st = h.early_out_stats()
-    assert 0 < st["fallbacks"] < 12, st
+    assert 0 < st["fallbacks"] < 24, st
 
 
 def test_exact_early_out_host_loop_switch(monkeypatch):

@@ -66,30 +66,6 @@ def test_fast_early_out_ordered_phases_exact(growth, size):
     compare_maps(o, h, exact=True)
 
 
-def test_fast_early_out_sub_runs_of_generations_exact(monkeypatch):
-    """The schedule benched until round 3 (a sub-run = 16 GENERATIONS of a chain instead of its next 16 live rays) stays
-    selectable for A/B runs: KS_SUB_RUN_GENERATIONS=1 on the library, KO_SUB_RUN_GENERATIONS=1 on the checker.  At 640x480
-    the late phases have 2 to 8 sub-runs per chain, and the two schedules differ there (and only there)."""
-    sc = synth.make_scene("room")
-    frames = [synth.render_frame(sc, synth.trajectory_pose(5 * k), 640, 480, seed=30 + k) for k in range(2)]
-    counts = {}
-    for legacy in ("1", "0", "0/8"):   # "0/8": sub-runs of 8 live rays (KS_SUB_RUN_RAYS / KO_EXP_SUB_RUN: the other A/B knob of bench.py)
-        monkeypatch.setenv("KS_SUB_RUN_GENERATIONS", legacy[0])
-        monkeypatch.setenv("KO_SUB_RUN_GENERATIONS", legacy[0])
-        monkeypatch.setenv("KS_SUB_RUN_RAYS", legacy[2:] or "16")
-        monkeypatch.setenv("KO_EXP_SUB_RUN", legacy[2:] or "16")
-        o, h = _pair(0, early_out_phase_growth=32)
-        for k, f in enumerate(frames):
-            so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
-            sh = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
-            assert (so.n_rays_cast, so.n_voxel_updates) == (sh.n_rays_cast, sh.n_voxel_updates), (legacy, k)
-            counts.setdefault(legacy, []).append(sh.n_voxel_updates)
-        compare_maps(o, h, exact=True)
-        h.close()
-        o.close()
-    assert counts["0"] != counts["1"] and counts["0"] != counts["0/8"]   # (the switches reach both sides)
-
-
 def test_fast_early_out_rounds_one_after_the_other_exact(monkeypatch):
     """KS_TEST_OVERLAP=0: k_test casts a long ray's next 64 voxels only after the current 64 have been decided (the code
     measured until round 3; the default overlaps the two).  Same schedule, same result: both against the oracle, 2 cm voxels
