@@ -128,7 +128,7 @@ struct FrameSlot {
   uint32_t *d_eo_hseq = nullptr, *d_eo_where = nullptr;   // per seed mark in emission order: voxel hash | index in M
   uint4 *d_eo_rinfo = nullptr, *d_eo_ckpt = nullptr;      // per position: {u0, um, length, checkpoint step} | caster state there
   uint8_t* d_eo_hitb = nullptr;            // first iteration: per mark in emission order, the visit is a hit
-  uint32_t* d_eo_fcnt = nullptr;           // ... surviving marks per filter block
+  unsigned long long *d_eo_bits_a = nullptr, *d_eo_bits_b = nullptr;   // per mark of M: it counts under the current / next lengths
   unsigned long long* d_eo_btp = nullptr;  // ... exclusive prefix of the scan's block totals
   hipEvent_t eo_committed = nullptr;  // the frame's marks have entered the shared table
   Counters* d_counters = nullptr;   // inside ks_ctx::d_state
@@ -769,7 +769,8 @@ int ensure_exact_slots(ks_ctx* c, size_t cap_marks, size_t cap_x) {
       if ((rc = dev_alloc(c, &S.d_eo_hitb, cap_marks))) return rc;
       if ((rc = dev_alloc(c, &S.d_eo_hseq, cap_marks))) return rc;
       if ((rc = dev_alloc(c, &S.d_eo_where, cap_marks))) return rc;
-      if ((rc = dev_alloc(c, &S.d_eo_fcnt, cap_marks / kEoFilterBlock + 2))) return rc;
+      if ((rc = dev_alloc(c, &S.d_eo_bits_a, cap_marks / 64 + 2))) return rc;
+      if ((rc = dev_alloc(c, &S.d_eo_bits_b, cap_marks / 64 + 2))) return rc;
       S.eo_cap_marks = cap_marks;
     }
     if (S.eo_cap_x < cap_x) {
@@ -807,10 +808,10 @@ EoView eo_view(ks_ctx* c, const FrameSlot& S) {
   E.cnt_b = S.d_eo_cnt_b;
   E.ux = S.d_eo_ux;
   E.dirty = S.d_eo_dirty;
-  // three radix passes leave the sorted seed marks in the second buffer set; the first iteration's compaction puts what is
-  // left of them back into the first
-  E.keys = S.d_eo_keys[0];
-  E.vals = S.d_eo_vals[0];
+  E.keys = S.d_eo_keys[1];   // three radix passes leave the sorted marks in the second buffer set
+  E.vals = S.d_eo_vals[1];
+  E.bits_a = S.d_eo_bits_a;
+  E.bits_b = S.d_eo_bits_b;
   E.lp = S.d_eo_lp;
   E.btp = S.d_eo_btp;
   E.hseq = S.d_eo_hseq;
@@ -857,22 +858,12 @@ int enqueue_exact_rounds(ks_ctx* c, FrameSlot& S, hipStream_t st) {
   }
   const EoView E = eo_view(c, S);
   const uint32_t gm = (uint32_t)std::min<size_t>((S.eo_cap_marks + 255) / 256, 2048);
-  // the first iteration, full and streaming: hit bits of the sorted seed marks, stop rule per ray, compaction
+  // the first iteration, full and streaming: hit bits of the sorted seed marks, stop rule per ray, validity bitmaps
   EoPhase1 P{};
-  P.keys0 = S.d_eo_keys[1];
-  P.vals0 = S.d_eo_vals[1];
-  P.keys1 = S.d_eo_keys[0];
-  P.vals1 = S.d_eo_vals[0];
-  P.lp = S.d_eo_lp;
-  P.btp = S.d_eo_btp;
   P.hitb = S.d_eo_hitb;
-  P.fcnt = S.d_eo_fcnt;
-  const uint32_t gf = (uint32_t)((S.eo_cap_marks + kEoFilterBlock - 1) / kEoFilterBlock);
   hipLaunchKernelGGL(k_eo2_hits, dim3(gm), dim3(256), 0, st, E, P);
   hipLaunchKernelGGL(k_eo2_stop0, dim3((uint32_t)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, E, P);
-  hipLaunchKernelGGL(k_eo2_fcount, dim3(gf), dim3(256), 0, st, E, P);
-  hipLaunchKernelGGL(k_eo2_fscan, dim3(1), dim3(1024), 0, st, E, P);
-  hipLaunchKernelGGL(k_eo2_fscatter, dim3(gf), dim3(256), 0, st, E, P);
+  hipLaunchKernelGGL(k_eo2_bits, dim3(gm), dim3(256), 0, st, E);
   hipLaunchKernelGGL(k_eo2_index, dim3(gm), dim3(256), 0, st, E);
   // the event-driven rounds (round 0 was the full iteration above)
   const uint32_t gr = (uint32_t)std::min<size_t>((n + 3) / 4, 2048);   // wavefront per ray, grid-stride
@@ -1973,7 +1964,7 @@ void ks_destroy(ks_ctx* c) {
                     (void*)S.d_bt, (void*)S.d_live, (void*)S.d_F, (void*)S.d_gkeys, (void*)S.d_rkeys,
                     (void*)S.d_eo_keys[0], (void*)S.d_eo_keys[1], (void*)S.d_eo_vals[0], (void*)S.d_eo_vals[1], (void*)S.d_eo_tab, (void*)S.d_eo_xnode,
                     (void*)S.d_eo_cnt_b, (void*)S.d_eo_ux, (void*)S.d_eo_dirty, (void*)S.d_eo_list[0], (void*)S.d_eo_list[1], (void*)S.d_eo_chg,
-                    (void*)S.d_eo_consulted, (void*)S.d_eo_lp, (void*)S.d_eo_bt, (void*)S.d_eo_ctl, (void*)S.d_eo_sort_ws, (void*)S.d_eo_hitb, (void*)S.d_eo_fcnt, (void*)S.d_eo_btp, (void*)S.d_eo_hseq, (void*)S.d_eo_where, (void*)S.d_eo_rinfo, (void*)S.d_eo_ckpt})
+                    (void*)S.d_eo_consulted, (void*)S.d_eo_lp, (void*)S.d_eo_bt, (void*)S.d_eo_ctl, (void*)S.d_eo_sort_ws, (void*)S.d_eo_hitb, (void*)S.d_eo_bits_a, (void*)S.d_eo_bits_b, (void*)S.d_eo_btp, (void*)S.d_eo_hseq, (void*)S.d_eo_where, (void*)S.d_eo_rinfo, (void*)S.d_eo_ckpt})
       if (p) (void)hipFree(p);
     if (S.b_graph2) (void)hipGraphExecDestroy(S.b_graph2);
     if (S.b_graph3) (void)hipGraphExecDestroy(S.b_graph3);

@@ -346,22 +346,26 @@ __global__ void __launch_bounds__(256) k_eo_commit(unsigned long long n_marks, c
 // EVENT-DRIVEN fix point (the default of the exact mode since round 4): no host in the loop, work proportional to what changes.
 //
 // The host-driven loop above re-emits, re-sorts and re-evaluates ALL marks per iteration and reads a counter back.
-// Here the marks of the SEED are emitted and sorted ONCE (M: a ray's mark is "potential": it counts while its step is below
-// the ray's current visited length), and the iteration is carried by events:
-//   * a round evaluates only DIRTY rays (round 0: all of them) against the marks that are valid under the current
-//     lengths A[] — a slot's content at (position, step) is the hash of the last valid mark before it: binary search in
-//     the slot's range of M, then backwards to the first valid mark; plus the slot's chain of X marks;
-//   * a ray that outgrows the steps it has marks for appends X marks (a lock-free list per slot; they are few: the
-//     seed's lengths are almost right) — nothing is ever re-sorted;
-//   * a ray whose length changed TOGGLES the validity of its marks between the old and the new length; each toggled mark
-//     can change what exactly one reader sees — the next valid mark of its slot — so the propagation dirties the owners
-//     of the marks that follow it in its slot up to and including the first one that is valid under the NEW lengths B[]
-//     (and the owners of the slot's later X marks), then makes the new length current.
-// Rounds are Jacobi steps (evaluate against A, write B; propagate against B, copy to A), every hand-over crosses a kernel
-// boundary (or a workgroup barrier in the finisher): only the dirty flags, the list counters and the X chains are touched
-// by atomics.  The fixed point is unique (ks_k_exact.h, top), so the order of the lists does not matter.
+// Here the marks of the SEED are emitted and sorted ONCE (M; where[] maps a mark's place in emission order — a ray's steps
+// are contiguous there — to its index in M), and a mark COUNTS while its step is below its ray's current visited length:
+// one validity bit per mark, in two bitmaps (A: under the current lengths, B: under the next ones).
+//   * the FIRST iteration is a full one and streams: every seed mark is valid, so whether a visit is a hit is a property of
+//     the sorted list alone (k_eo2_hits), the stop rule runs over a ray's contiguous hit bits (k_eo2_stop0), and
+//     k_eo2_bits builds the bitmaps from the new lengths and finds the readers whose predecessor in their slot went away;
+//   * a round evaluates only DIRTY rays: a visit's slot content is the mark of the highest set bit below the visit's own
+//     index in M — a bit scan, however many dead marks of rays that went too far in the seed sit in between (near the
+//     sensor hundreds of seed marks share a slot) — or a mark of the slot's chain of X marks, or what earlier frames left;
+//   * a ray that outgrows the steps the seed walked appends X marks (a lock-free list per slot; few: the seed's lengths
+//     are almost right) and is cast on from a checkpoint of its caster; nothing is ever re-sorted;
+//   * a ray whose length changed flips the bits of its marks between the old and the new length in B; each flipped mark
+//     can change what exactly one reader sees — the next valid mark of its slot — so the propagation dirties the owner of
+//     the next set bit of B in the slot (and the owners of the slot's later X marks), then flips A and makes the new length
+//     current.
+// Rounds are Jacobi steps (evaluate against A, propagate against B), every hand-over crosses a kernel boundary (or a
+// workgroup barrier in the finisher): only bit flips, dirty flags, list counters and the X chains are touched by atomics.
+// The fixed point is unique (ks_k_exact.h, top), so the order of the lists does not matter.
 // A fixed number of bulk rounds is enqueued; k_eo2_finish (ONE workgroup) then iterates until nothing is dirty.
-// (tools/fixpoint_study.py is the CPU study of this scheme: round counts, list sizes, X marks.)
+// (tools/fixpoint_study.py is the CPU study of this scheme: round counts, list sizes, X marks, scan lengths.)
 // ==========================================================================================================
 constexpr uint32_t kEoBulkMax = 40;          // bulk rounds a launch sequence can hold
 constexpr uint32_t kEoFailMarks = 1u, kEoFailX = 2u, kEoFailRounds = 4u, kEoFailChain = 8u;
@@ -391,6 +395,8 @@ struct EoView {
   uint32_t* dirty;                // per position: queued for the next round
   const uint64_t* keys;           // M, sorted by slot (time order inside a slot): [63:44] slot | [43:22] position | [21:0] step
   const uint32_t* vals;           //    ... voxel hashes
+  unsigned long long* bits_a;     // per mark of M: it counts under the current lengths
+  unsigned long long* bits_b;     //                ... under the next lengths
   uint4* tab;                     // per set slot: {begin, end} in M, head of the X chain, unused
   unsigned long long* xnode;      // X marks, 2 words per node: position << 22 | step ;  hash | next << 32
   uint32_t cap_x;
@@ -402,8 +408,8 @@ struct EoView {
   const uint32_t* lp;             // scan of the seed's visited lengths ...
   const unsigned long long* btp;  // ... exclusive prefix of its block totals: a ray's place in emission order = btp[pos / 4096] + lp[pos]
   const uint32_t* hseq;           // voxel hashes of the seed's marks in emission order
-  uint32_t* where;                // per seed mark in emission order: its index in M (valid for a ray's first `um` steps)
-  uint4* rinfo;                   // per position: {u0 = steps the seed has marks for, um = leading steps with a mark in M, ray length, checkpoint step}
+  uint32_t* where;                // per seed mark in emission order: its index in M
+  uint4* rinfo;                   // per position: {u0 = steps the seed has marks for, -, ray length, checkpoint step}
   const uint4* ckpt;              // per position: the caster's state at the checkpoint step (3 words of 16 bytes)
   EoCtl* ctl;
 };
@@ -414,50 +420,37 @@ __device__ __forceinline__ unsigned long long eo2_ld64(const unsigned long long*
 }
 
 // ---- the FIRST iteration is a full one, and streams -----------------------------------------------------------------
-// Every mark of the seed is valid, so whether a visit is a hit is a property of the SORTED mark list alone: the mark
-// before it in its slot holds the same hash (or, first of its slot, what earlier frames left there).
-//   k_eo2_hits   : per sorted mark, that bit -> hitb[place of the mark in emission order]
-//   k_eo2_stop0  : per ray (a lane each), the reference's stop rule over its contiguous bits -> new length (in place: nothing
-//                  reads lengths here); a ray that used to stop and does not any more within the steps it has marks for
-//                  goes on in round 1
-//   k_eo2_fcount / fscan / fscatter : the marks the new lengths leave invalid are REMOVED (an order-preserving compaction
-//                  of the sorted list: no second sort), and the owner of every surviving mark whose predecessor in its
-//                  slot was removed is dirty — exactly the readers whose input changed.
-// The event-driven rounds then start from a list in which every mark is valid again (their scans over a slot's marks
-// stop at the first valid one: near the sensor hundreds of seed marks share a slot).
-constexpr uint32_t kEoFilterBlock = 1024;   // marks per workgroup of the filter kernels (256 threads x 4)
 struct EoPhase1 {
-  const uint64_t* keys0;                 // the seed's marks, sorted
-  const uint32_t* vals0;
-  uint64_t* keys1;                       // what is left of them (= EoView::keys)
-  uint32_t* vals1;
-  const uint32_t* lp;                    // scan of the seed's visited lengths (k_eo_scan) ...
-  const unsigned long long* btp;         // ... and the exclusive prefix of its block totals
   uint8_t* hitb;                         // per mark in emission order: the visit is a hit
-  uint32_t* fcnt;                        // per filter block: surviving marks (then their exclusive prefix)
 };
 __device__ __forceinline__ void eo2_mark_dirty(const EoView& E, uint32_t p, uint32_t* out, uint32_t* n_out);
 
+// per sorted mark: is the visit a hit (the mark before it in its slot holds the same hash; first of its slot: what earlier
+// frames left there)?  -> hitb[its place in emission order]; and where[] of that place = the mark's index
 __global__ void __launch_bounds__(256) k_eo2_hits(EoView E, EoPhase1 P) {
   const unsigned long long n = E.ctl->st.n_marks;
   if (E.ctl->fail) return;
   for (unsigned long long j = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * 256ull) {
-    const uint64_t key = P.keys0[j];
+    const uint64_t key = E.keys[j];
     const uint32_t slot = (uint32_t)(key >> 44), pos = (uint32_t)(key >> 22) & 0x3fffffu, step = (uint32_t)key & 0x3fffffu;
-    const uint32_t h = P.vals0[j];
+    const uint32_t h = E.vals[j];
     bool hit;
-    if (j > 0 && (uint32_t)(P.keys0[j - 1] >> 44) == slot) {
-      hit = P.vals0[j - 1] == h;
+    if (j > 0 && (uint32_t)(E.keys[j - 1] >> 44) == slot) {
+      hit = E.vals[j - 1] == h;
     } else {
       hit = E.plain[slot] == (uint64_t)h;
       // (the only hash an entry of an EARLIER offset can equal is that of the zero-initialised slot: the ray is looked at
       // again once the frames before this one have entered their marks)
       if (h == 0u && !(atomicOr(&E.ux[pos], 0x80000000u) >> 31)) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos;
     }
-    P.hitb[P.btp[pos / kScanBlock] + P.lp[pos] + step] = hit ? 1 : 0;
+    const unsigned long long at = E.btp[pos / kScanBlock] + E.lp[pos] + step;
+    P.hitb[at] = hit ? 1 : 0;
+    E.where[at] = (uint32_t)j;
   }
 }
 
+// per ray (a lane each): the reference's stop rule over its contiguous hit bits -> new length, in place (nothing reads
+// lengths here).  A ray that used to stop and does not any more within the steps it has marks for goes on in round 1.
 __global__ void __launch_bounds__(256) k_eo2_stop0(EoView E, EoPhase1 P) {
   if (E.ctl->fail) return;
   const uint32_t n = E.C->n_rays;
@@ -465,7 +458,7 @@ __global__ void __launch_bounds__(256) k_eo2_stop0(EoView E, EoPhase1 P) {
   for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
     const uint32_t pos = E.ray_list[r];
     const uint32_t cv = E.cnt_a[pos], v0 = eo_visited(cv);
-    const uint8_t* hb = P.hitb + (P.btp[pos / kScanBlock] + P.lp[pos]);
+    const uint8_t* hb = P.hitb + (E.btp[pos / kScanBlock] + E.lp[pos]);
     int c = 0, stop = -1;
     for (uint32_t k = 0; k < v0; ++k) {
       c = hb[k] ? c + 1 : 0;
@@ -479,121 +472,47 @@ __global__ void __launch_bounds__(256) k_eo2_stop0(EoView E, EoPhase1 P) {
     if (now != cv) {
       E.cnt_a[pos] = now;
       E.cnt_b[pos] = now;
-      E.ux[pos] = (E.ux[pos] & 0x80000000u) | eo_visited(now);
-      E.rinfo[pos].y = eo_visited(now);   // marks past the new length leave M below
     }
     if (stop < 0 && (cv & kCntBroke)) eo2_mark_dirty(E, pos, E.list[1], &E.ctl->n_in[1]);
   }
 }
 
-// does mark `key` survive the first iteration?
-__device__ __forceinline__ bool eo2_survives(const EoView& E, uint64_t key) {
-  return ((uint32_t)key & 0x3fffffu) < eo_visited(E.cnt_a[(uint32_t)(key >> 22) & 0x3fffffu]);
-}
-__global__ void __launch_bounds__(256) k_eo2_fcount(EoView E, EoPhase1 P) {
-  __shared__ uint32_t s_w[4];
-  const unsigned long long n = E.ctl->st.n_marks;
-  if (E.ctl->fail || (unsigned long long)blockIdx.x * kEoFilterBlock >= n) return;
-  const unsigned long long j0 = (unsigned long long)blockIdx.x * kEoFilterBlock + threadIdx.x * 4ull;
-  // the mark before this thread's four, then the four
-  uint64_t kprev = 0;
-  bool vprev = true;
-  if (j0 > 0 && j0 < n) {
-    kprev = P.keys0[j0 - 1];
-    vprev = eo2_survives(E, kprev);
-  }
-  uint32_t mine = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const unsigned long long j = j0 + q;
-    if (j >= n) break;
-    const uint64_t key = P.keys0[j];
-    const bool v = eo2_survives(E, key);
-    mine += v ? 1u : 0u;
-    // its predecessor in the slot is gone: what this visit finds in the slot has changed
-    if (v && !vprev && j > 0 && (uint32_t)(kprev >> 44) == (uint32_t)(key >> 44)) eo2_mark_dirty(E, (uint32_t)(key >> 22) & 0x3fffffu, E.list[1], &E.ctl->n_in[1]);
-    kprev = key;
-    vprev = v;
-  }
-  uint32_t x = mine;
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
-  if (lane_id() == 0) s_w[threadIdx.x >> 6] = x;
-  __syncthreads();
-  if (threadIdx.x == 0) P.fcnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-// exclusive prefix of the block counts, in place; the total = the new mark count (one workgroup)
-__global__ void __launch_bounds__(1024) k_eo2_fscan(EoView E, EoPhase1 P) {
-  __shared__ uint32_t s_w[16];
-  __shared__ unsigned long long s_carry;
+// The validity bitmaps under the new lengths (a wavefront's ballot is a word), and the readers whose input changed: the
+// owner of every valid mark whose predecessor in its slot is not valid any more.
+__global__ void __launch_bounds__(256) k_eo2_bits(EoView E) {
   const unsigned long long n = E.ctl->st.n_marks;
   if (E.ctl->fail) return;
-  const uint32_t nb = (uint32_t)((n + kEoFilterBlock - 1) / kEoFilterBlock);
-  if (threadIdx.x == 0) s_carry = 0ull;
-  __syncthreads();
-  for (uint32_t b0 = 0; b0 < nb; b0 += 1024) {
-    const uint32_t b = b0 + threadIdx.x;
-    const uint32_t v = b < nb ? P.fcnt[b] : 0u;
-    uint32_t x = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t y = __shfl_up(x, o);
-      if (lane_id() >= (uint32_t)o) x += y;
+  const unsigned long long n_pad = (n + 63ull) & ~63ull;
+  for (unsigned long long j = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; j < n_pad; j += (unsigned long long)gridDim.x * 256ull) {
+    bool v = false;
+    uint64_t key = 0;
+    if (j < n) {
+      key = E.keys[j];
+      v = ((uint32_t)key & 0x3fffffu) < eo_visited(E.cnt_a[(uint32_t)(key >> 22) & 0x3fffffu]);
     }
-    if (lane_id() == 63) s_w[threadIdx.x >> 6] = x;
-    __syncthreads();
-    uint32_t wb = 0;
-    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) wb += s_w[w];
-    const unsigned long long carry = s_carry;
-    if (b < nb) P.fcnt[b] = (uint32_t)(carry + wb + x - v);
-    __syncthreads();
-    if (threadIdx.x == 1023) s_carry = carry + wb + x;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) E.ctl->n_marks1 = s_carry;
-}
-__global__ void __launch_bounds__(256) k_eo2_fscatter(EoView E, EoPhase1 P) {
-  __shared__ uint32_t s_w[4];
-  const unsigned long long n = E.ctl->st.n_marks;
-  if (E.ctl->fail || (unsigned long long)blockIdx.x * kEoFilterBlock >= n) return;
-  const unsigned long long j0 = (unsigned long long)blockIdx.x * kEoFilterBlock + threadIdx.x * 4ull;
-  uint64_t key[4];
-  bool v[4];
-  uint32_t mine = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    v[q] = false;
-    key[q] = 0;
-    if (j0 + q < n) {
-      key[q] = P.keys0[j0 + q];
-      v[q] = eo2_survives(E, key[q]);
+    const unsigned long long word = __ballot(v);
+    if (lane_id() == 0) {
+      E.bits_a[j >> 6] = word;
+      E.bits_b[j >> 6] = word;
     }
-    mine += v[q] ? 1u : 0u;
-  }
-  uint32_t x = mine;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t y = __shfl_up(x, o);
-    if (lane_id() >= (uint32_t)o) x += y;
-  }
-  if (lane_id() == 63) s_w[threadIdx.x >> 6] = x;
-  __syncthreads();
-  uint32_t at = P.fcnt[blockIdx.x] + x - mine;
-  for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) at += s_w[w];
-#pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if (v[q]) {
-      P.keys1[at] = key[q];
-      P.vals1[at] = P.vals0[j0 + q];
-      const uint32_t pos = (uint32_t)(key[q] >> 22) & 0x3fffffu;
-      E.where[P.btp[pos / kScanBlock] + P.lp[pos] + ((uint32_t)key[q] & 0x3fffffu)] = at;
-      ++at;
+    if (v && j > 0) {
+      bool vprev;
+      uint64_t kprev;
+      if (lane_id() != 0) {
+        vprev = (word >> (lane_id() - 1u)) & 1ull;
+        kprev = E.keys[j - 1];
+      } else {
+        kprev = E.keys[j - 1];
+        vprev = ((uint32_t)kprev & 0x3fffffu) < eo_visited(E.cnt_a[(uint32_t)(kprev >> 22) & 0x3fffffu]);
+      }
+      if (!vprev && (uint32_t)(kprev >> 44) == (uint32_t)(key >> 44)) eo2_mark_dirty(E, (uint32_t)(key >> 22) & 0x3fffffu, E.list[1], &E.ctl->n_in[1]);
     }
+  }
 }
 
 // per slot: [begin, end) of its marks in M (the table is clear: k_eo2_commit leaves it so)
 __global__ void __launch_bounds__(256) k_eo2_index(EoView E) {
-  const unsigned long long n = E.ctl->n_marks1;
+  const unsigned long long n = E.ctl->st.n_marks;
   if (E.ctl->fail) return;
   for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull) {
     const uint32_t slot = (uint32_t)(E.keys[i] >> 44);
@@ -602,36 +521,59 @@ __global__ void __launch_bounds__(256) k_eo2_index(EoView E) {
   }
 }
 
-// What slot `slot` holds at time t = position << 22 | step, for the ray at `pos` (its own earlier marks count whatever its
-// length is; marks of other rays count while their step is below the ray's length in len[]).  fresh: read the head of the X
-// chain past the caches (the caller pushed to it in this kernel).  Returns false if no mark of this frame precedes t.
-__device__ __forceinline__ bool eo2_content(const EoView& E, const uint32_t* __restrict__ len, uint32_t slot, uint64_t t, uint32_t pos,
-                                            bool fresh, uint32_t& hash) {
-  const uint4 e = E.tab[slot];
-  uint32_t lo = e.x, hi = e.y;  // first mark of the slot at or after t
-  while (lo < hi) {
-    const uint32_t mid = (lo + hi) >> 1;
-    if ((E.keys[mid] & kEoLow44) < t) lo = mid + 1;
-    else hi = mid;
+// index of the highest set bit below index j of a bitmap (-1: none) / of the lowest set bit at or above j (n_words * 64: none)
+__device__ __forceinline__ long long eo2_prev_set(const unsigned long long* __restrict__ bits, uint32_t j) {
+  if (j == 0u) return -1;
+  uint32_t w = (j - 1u) >> 6;
+  unsigned long long x = bits[w] & (~0ull >> (63u - ((j - 1u) & 63u)));
+  for (;;) {
+    if (x != 0ull) return (long long)w * 64 + (63 - __clzll((long long)x));
+    if (w == 0u) return -1;
+    --w;
+    x = bits[w];
   }
+}
+__device__ __forceinline__ unsigned long long eo2_next_set(const unsigned long long* __restrict__ bits, unsigned long long j, unsigned long long n) {
+  const unsigned long long n_words = (n + 63ull) >> 6;
+  unsigned long long w = j >> 6;
+  if (w >= n_words) return n;
+  unsigned long long x = bits[w] & (~0ull << (j & 63ull));
+  for (;;) {
+    if (x != 0ull) {
+      const unsigned long long at = w * 64ull + (unsigned long long)(__ffsll((long long)x) - 1);
+      return at < n ? at : n;
+    }
+    if (++w >= n_words) return n;
+    x = bits[w];
+  }
+}
+
+// What slot `slot` holds at time t = position << 22 | step, for the ray at `pos`, given the index j of the first mark of M at
+// or after t (the ray's own mark of that step, if it has one in M).  The mark right before j counts if it is the ray's
+// own (an earlier step of this walk: marks between two marks of one ray are that ray's); else the mark of the highest set
+// bit of A below j, if it is of this slot; plus the slot's X marks (valid by their ray's current length, or the ray's own).
+__device__ __forceinline__ bool eo2_content_at(const EoView& E, uint32_t j, uint32_t slot, uint64_t t, uint32_t pos, uint32_t& hash) {
   bool found = false;
   uint64_t best = 0;
-  while (lo > e.x) {
-    --lo;
-    const uint64_t k = E.keys[lo] & kEoLow44;
-    const uint32_t p = (uint32_t)(k >> 22), st = (uint32_t)k & 0x3fffffu;
-    if (p == pos || st < eo_visited(len[p])) {
-      found = true;
-      best = k;
-      hash = E.vals[lo];
-      break;
+  if (j > 0u) {
+    const uint64_t kp = E.keys[j - 1u];
+    long long i = -1;
+    if ((uint32_t)(kp >> 44) == slot && ((uint32_t)(kp >> 22) & 0x3fffffu) == pos) i = (long long)j - 1;
+    else i = eo2_prev_set(E.bits_a, j);
+    if (i >= 0) {
+      const uint64_t key = i == (long long)j - 1 ? kp : E.keys[i];
+      if ((uint32_t)(key >> 44) == slot) {
+        found = true;
+        best = key & kEoLow44;
+        hash = E.vals[i];
+      }
     }
   }
-  uint32_t xi = fresh ? eo2_ld(&E.tab[slot].z) : e.z;
+  uint32_t xi = eo2_ld(&E.tab[slot].z);
   while (xi != 0u) {
     const unsigned long long k = eo2_ld64(&E.xnode[2u * xi]), hn = eo2_ld64(&E.xnode[2u * xi + 1u]);
     const uint32_t p = (uint32_t)(k >> 22), st = (uint32_t)k & 0x3fffffu;
-    if (k < t && (p == pos || st < eo_visited(len[p])) && (!found || k > best)) {
+    if (k < t && (p == pos || st < eo_visited(E.cnt_a[p])) && (!found || k > best)) {
       found = true;
       best = k;
       hash = (uint32_t)hn;
@@ -639,6 +581,18 @@ __device__ __forceinline__ bool eo2_content(const EoView& E, const uint32_t* __r
     xi = (uint32_t)(hn >> 32);
   }
   return found;
+}
+// index of the first mark of M at or after time t in slot `slot` (binary search in the slot's range; for steps without a
+// mark of their own in M)
+__device__ __forceinline__ uint32_t eo2_lower_bound(const EoView& E, uint32_t slot, uint64_t t) {
+  const uint4 e = E.tab[slot];
+  uint32_t lo = e.x, hi = e.y;
+  while (lo < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if ((E.keys[mid] & kEoLow44) < t) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
 }
 
 // LDS of a wavefront of the round kernels
@@ -737,39 +691,6 @@ struct EoWalk {
   }
 };
 
-// What slot `slot` holds just before the ray's own mark at index j of M (the mark of step k < um): the marks before it in
-// its slot, newest first, until a valid one; plus the slot's X marks.
-__device__ __forceinline__ bool eo2_content_at(const EoView& E, const uint32_t* __restrict__ len, uint32_t j, uint32_t slot, uint64_t t, uint32_t pos,
-                                               bool fresh, uint32_t& hash) {
-  bool found = false;
-  uint64_t best = 0;
-  for (uint32_t i = j; i > 0u;) {
-    --i;
-    const uint64_t key = E.keys[i];
-    if ((uint32_t)(key >> 44) != slot) break;
-    const uint32_t p = (uint32_t)(key >> 22) & 0x3fffffu, st = (uint32_t)key & 0x3fffffu;
-    if (p == pos || st < eo_visited(len[p])) {
-      found = true;
-      best = key & kEoLow44;
-      hash = E.vals[i];
-      break;
-    }
-  }
-  uint32_t xi = eo2_ld(&E.tab[slot].z);
-  (void)fresh;
-  while (xi != 0u) {
-    const unsigned long long k = eo2_ld64(&E.xnode[2u * xi]), hn = eo2_ld64(&E.xnode[2u * xi + 1u]);
-    const uint32_t p = (uint32_t)(k >> 22), st = (uint32_t)k & 0x3fffffu;
-    if (k < t && (p == pos || st < eo_visited(len[p])) && (!found || k > best)) {
-      found = true;
-      best = k;
-      hash = (uint32_t)hn;
-    }
-    xi = (uint32_t)(hn >> 32);
-  }
-  return found;
-}
-
 // ONE ray evaluated by a whole wavefront (all operands wave-uniform): how far it gets against the marks valid under A.
 // Appends X marks for the visited steps it has no mark for yet; a changed length goes to B and the ray to the change list.
 __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams& F, uint32_t pos, EoWaveLds& W, uint32_t* n_chg) {
@@ -777,13 +698,14 @@ __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams&
   if (lane == 0) E.dirty[pos] = 0u;
   EoWalk wk;
   wk.begin(E, pos);
-  const uint32_t full = wk.full, um = wk.um;
-  const uint32_t old = E.cnt_a[pos];
-  const uint32_t ux_word = E.ux[pos];          // [31] the ray is in the list of rays that consulted earlier frames' marks
+  const uint32_t full = wk.full, u0 = wk.u0;
+  // (wave-uniform addresses whose content changes inside the one-workgroup finisher: read past the scalar cache)
+  const uint32_t old = eo2_ld(&E.cnt_a[pos]);
+  const uint32_t ux_word = eo2_ld(&E.ux[pos]);          // [31] the ray is in the list of rays that consulted earlier frames' marks
   const uint32_t ux0 = ux_word & 0x7fffffffu;
   const int lim = F.max_collisions;
   int c = 0, stop = -1;
-  bool consulted = false, pushed = false;
+  bool consulted = false;
   uint32_t visited = full;
   uint32_t g, a, b;
   while (wk.next(E, F, W, lane, full, g, a, b)) {
@@ -810,8 +732,8 @@ __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams&
       }
       if (!own) {
         uint32_t content = 0;
-        const bool found = k < um ? eo2_content_at(E, E.cnt_a, E.where[wk.base + k], slot, t, pos, pushed, content)
-                                  : eo2_content(E, E.cnt_a, slot, t, pos, true, content);
+        const uint32_t j = k < u0 ? E.where[wk.base + k] : eo2_lower_bound(E, slot, t);
+        const bool found = eo2_content_at(E, j, slot, t, pos, content);
         if (found) hit = content == h;
         else {
           hit = E.plain[slot] == (uint64_t)h;
@@ -840,14 +762,14 @@ __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams&
         for (;;) {
           __hip_atomic_store(&E.xnode[2u * xi + 1u], (unsigned long long)(uint32_t)key | ((unsigned long long)head << 32), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
-          __threadfence();
+          // the node's two words (agent-scope stores: they do not stay in a cache other CUs cannot see) have been performed
+          // before the head names the node.  (Not a fence: an agent-scope release would write back the whole L2 — per push.)
+          KS_WAIT_VMEM();
           const uint32_t seen = atomicCAS(&E.tab[slot].z, head, xi);
           if (seen == head) break;
           head = seen;
         }
       }
-      pushed = true;
-      __threadfence();
     }
     if (st_r >= 0) {
       stop = (int)(a + (uint32_t)st_r);
@@ -866,6 +788,16 @@ __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams&
     }
     if (list_it) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos;
   }
+  // the ray's marks between the old and the new length count / stop counting under the NEXT lengths
+  {
+    const uint32_t vo = eo_visited(old);
+    const uint32_t lo = vo < visited ? vo : visited, hi0 = vo < visited ? visited : vo, hi = hi0 < u0 ? hi0 : u0;
+    for (uint32_t k = lo + lane; k < hi; k += 64u) {
+      const uint32_t j = E.where[wk.base + k];
+      if (visited > vo) atomicOr(&E.bits_b[j >> 6], 1ull << (j & 63u));
+      else atomicAnd(&E.bits_b[j >> 6], ~(1ull << (j & 63u)));
+    }
+  }
 }
 
 __device__ __forceinline__ void eo2_mark_dirty(const EoView& E, uint32_t p, uint32_t* out, uint32_t* n_out) {
@@ -876,45 +808,38 @@ __device__ __forceinline__ void eo2_mark_dirty(const EoView& E, uint32_t p, uint
 // then the new length becomes current.
 __device__ __forceinline__ void eo2_propagate_ray(const EoView& E, const FrameParams& F, uint32_t pos, EoWaveLds& W, uint32_t* out, uint32_t* n_out) {
   const uint32_t lane = lane_id();
-  const uint32_t old = E.cnt_a[pos], now = E.cnt_b[pos];
+  const uint32_t old = eo2_ld(&E.cnt_a[pos]), now = eo2_ld(&E.cnt_b[pos]);
   const uint32_t vo = eo_visited(old), vn = eo_visited(now);
   const uint32_t lo = vo < vn ? vo : vn, hi = vo < vn ? vn : vo;
   EoWalk wk;
   wk.begin(E, pos);
   // (the steps below lo are not looked at: the walk starts at the batch that holds lo — a multiple of 64 below the seed's steps)
   wk.k0 = lo < wk.u0 ? (lo & ~63u) : wk.u0;
+  const unsigned long long n_m = E.ctl->st.n_marks;
   uint32_t g, a, b;
   while (wk.next(E, F, W, lane, hi, g, a, b)) {
     const uint32_t k = g + lane;
     if (k >= a && k < b && k >= lo) {
       const uint32_t slot = (uint32_t)(W.keys[lane] >> 32);
       const uint64_t t = ((uint64_t)pos << 22) | k;
-      uint32_t m;   // first mark of the slot after t
-      if (k < wk.um) {
-        m = E.where[wk.base + k] + 1u;
-      } else {
-        const uint4 e = E.tab[slot];
-        uint32_t x = e.x, y = e.y;
-        while (x < y) {
-          const uint32_t mid = (x + y) >> 1;
-          if ((E.keys[mid] & kEoLow44) <= t) x = mid + 1;
-          else y = mid;
-        }
-        m = x;
-      }
-      const uint32_t n_m = (uint32_t)E.ctl->n_marks1;
-      for (; m < n_m; ++m) {
+      // the next mark of the slot that counts under the new lengths: its owner reads something else now
+      const unsigned long long j = k < wk.u0 ? (unsigned long long)E.where[wk.base + k] + 1ull : (unsigned long long)eo2_lower_bound(E, slot, t);
+      const unsigned long long m = eo2_next_set(E.bits_b, j, n_m);
+      if (m < n_m) {
         const uint64_t key = E.keys[m];
-        if ((uint32_t)(key >> 44) != slot) break;
-        const uint32_t p = (uint32_t)(key >> 22) & 0x3fffffu, st = (uint32_t)key & 0x3fffffu;
-        if (p != pos) eo2_mark_dirty(E, p, out, n_out);
-        if (st < eo_visited(E.cnt_b[p])) break;   // valid under the new lengths: later readers see this one
+        const uint32_t p = (uint32_t)(key >> 22) & 0x3fffffu;
+        if ((uint32_t)(key >> 44) == slot && p != pos) eo2_mark_dirty(E, p, out, n_out);
       }
       for (uint32_t xi = eo2_ld(&E.tab[slot].z); xi != 0u;) {
         const unsigned long long kx = eo2_ld64(&E.xnode[2u * xi]), hn = eo2_ld64(&E.xnode[2u * xi + 1u]);
         const uint32_t p = (uint32_t)(kx >> 22);
         if (kx > t && p != pos) eo2_mark_dirty(E, p, out, n_out);
         xi = (uint32_t)(hn >> 32);
+      }
+      if (k < wk.u0) {   // the mark's bit under the current lengths follows
+        const uint32_t jm = E.where[wk.base + k];
+        if (vn > vo) atomicOr(&E.bits_a[jm >> 6], 1ull << (jm & 63u));
+        else atomicAnd(&E.bits_a[jm >> 6], ~(1ull << (jm & 63u)));
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -972,9 +897,8 @@ __global__ void __launch_bounds__(kEoFinishThreads) k_eo2_finish(EoView E, uint3
     return;
   }
   if (chained) {
-    const uint32_t nc = ctl->n_consulted;
-    for (uint32_t i = threadIdx.x; i < nc; i += kEoFinishThreads) eo2_mark_dirty(E, E.consulted[i], E.list[cur], &ctl->fin_in[cur]);
-    __threadfence();
+    const uint32_t nc = eo2_ld(&ctl->n_consulted);
+    for (uint32_t i = threadIdx.x; i < nc; i += kEoFinishThreads) eo2_mark_dirty(E, eo2_ld(&E.consulted[i]), E.list[cur], &ctl->fin_in[cur]);
     __syncthreads();
   }
   for (uint32_t it = 0;; ++it) {
@@ -986,8 +910,7 @@ __global__ void __launch_bounds__(kEoFinishThreads) k_eo2_finish(EoView E, uint3
     __syncthreads();
     const uint32_t n = s_n;
     if (n == 0u || s_stop) break;
-    for (uint32_t i = wave; i < n; i += nw) eo2_eval_ray(E, F, E.list[cur][i], s_w[wave], &ctl->fin_chg);
-    __threadfence();
+    for (uint32_t i = wave; i < n; i += nw) eo2_eval_ray(E, F, eo2_ld(&E.list[cur][i]), s_w[wave], &ctl->fin_chg);
     __syncthreads();
     if (threadIdx.x == 0) {
       s_n = eo2_ld(&ctl->fin_chg);
@@ -995,8 +918,7 @@ __global__ void __launch_bounds__(kEoFinishThreads) k_eo2_finish(EoView E, uint3
     }
     __syncthreads();
     const uint32_t nc = s_n;
-    for (uint32_t i = wave; i < nc; i += nw) eo2_propagate_ray(E, F, E.chg[i], s_w[wave], E.list[cur ^ 1u], &ctl->fin_in[cur ^ 1u]);
-    __threadfence();
+    for (uint32_t i = wave; i < nc; i += nw) eo2_propagate_ray(E, F, eo2_ld(&E.chg[i]), s_w[wave], E.list[cur ^ 1u], &ctl->fin_in[cur ^ 1u]);
     __syncthreads();
     if (threadIdx.x == 0) ctl->fin_chg = 0u;
     cur ^= 1u;
@@ -1019,14 +941,12 @@ __global__ void __launch_bounds__(256) k_eo2_commit(EoView E) {
     bool found = false;
     uint64_t best = 0;
     uint32_t hash = 0;
-    for (uint32_t j = e.y; j > e.x;) {
-      --j;
-      const uint64_t k = E.keys[j] & kEoLow44;
-      if (((uint32_t)k & 0x3fffffu) < eo_visited(E.cnt_a[(uint32_t)(k >> 22)])) {
+    if (e.y > e.x) {
+      const long long j = eo2_prev_set(E.bits_a, e.y);
+      if (j >= (long long)e.x) {
         found = true;
-        best = k;
+        best = E.keys[j] & kEoLow44;
         hash = E.vals[j];
-        break;
       }
     }
     for (uint32_t xi = e.z; xi != 0u;) {

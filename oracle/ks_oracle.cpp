@@ -1392,7 +1392,7 @@ size_t ko_sim_fixpoint(const ko_config* cfg, const float Tq[7], const float* xyz
     for (size_t i = work.size(); i > 1; --i) std::swap(work[i - 1], work[rnd() % i]);
     for (uint32_t i : work) dirty[i] = 0;
     std::vector<uint32_t> next;
-    size_t changed = 0, steps = 0, back = 0, fwd = 0, toggled = 0;
+    size_t changed = 0, steps = 0, back = 0, fwd = 0, toggled = 0, max_fwd = 0, max_back = 0, max_len = 0;
     std::vector<std::pair<uint32_t, uint32_t>> pending;   // (ray, new length) of the Jacobi round
     auto propagate = [&](uint32_t i, uint32_t old, uint32_t vis) {
       for (uint32_t k = std::min(old, vis); k < std::max(old, vis); ++k) {
@@ -1402,12 +1402,14 @@ size_t ko_sim_fixpoint(const ko_config* cfg, const float Tq[7], const float* xyz
           const std::vector<Mark>& v = im->second;
           size_t j = find_mark(v, i, k);
           if (j < v.size() && v[j].ray == i && v[j].step == k) ++j;
+          size_t one = 0;
           for (; j < v.size(); ++j) {
-            ++fwd;
+            ++fwd; ++one;
             const uint32_t o = v[j].ray;
             if (o != i && !dirty[o]) { dirty[o] = 1; next.push_back(o); }
             if (v[j].step < L[o]) break;
           }
+          max_fwd = std::max(max_fwd, one);
         }
         auto ix = X.find(path[i][k].slot);
         if (ix != X.end())
@@ -1430,11 +1432,13 @@ size_t ko_sim_fixpoint(const ko_config* cfg, const float Tq[7], const float* xyz
         size_t content = plain(st.slot);
         bool have = false;
         uint32_t br = 0, bk = 0;
+        size_t one = 0;
         while (j > 0) {
           --j;
-          ++back;
+          ++back; ++one;
           if (v[j].ray == i || v[j].step < L[v[j].ray]) { content = v[j].h; have = true; br = v[j].ray; bk = v[j].step; break; }
         }
+        max_back = std::max(max_back, one);
         auto ix = X.find(st.slot);
         if (ix != X.end())
           for (const Mark& m : ix->second) {
@@ -1448,6 +1452,7 @@ size_t ko_sim_fixpoint(const ko_config* cfg, const float Tq[7], const float* xyz
         ++steps;
         if (cc > lim) break;
       }
+      max_len = std::max<size_t>(max_len, vis);
       UX[i] = std::max(UX[i], vis);
       const uint32_t old = L[i];
       if (vis != old) {
@@ -1464,6 +1469,14 @@ size_t ko_sim_fixpoint(const ko_config* cfg, const float Tq[7], const float* xyz
       for (auto& pr : pending) { olds.push_back(L[pr.first]); L[pr.first] = pr.second; }
       for (size_t q = 0; q < pending.size(); ++q) propagate(pending[q].first, olds[q], pending[q].second);
     }
+    if (round == 0 && getenv("KO_STUDY_COMPACT")) {   // as the GPU does after its first (full) iteration: invalid marks leave M
+      for (auto& kv : M) {
+        auto& v = kv.second;
+        v.erase(std::remove_if(v.begin(), v.end(), [&](const Mark& m) { return m.step >= L[m.ray]; }), v.end());
+      }
+      for (size_t i = 0; i < R; ++i) UX[i] = std::max<uint32_t>(std::min(UX[i], L[i]), 0);
+    }
+    fprintf(stderr, "      longest single scans: forward %zu, backward %zu; longest walk %zu steps\n", max_fwd, max_back, max_len);
     fprintf(stderr, "  round %2zu: dirty %7zu changed %6zu toggled %7zu walk steps %8zu back-scan %8zu fwd-scan %7zu  X marks %zu\n", round, work.size(), changed,
             toggled, steps, back, fwd, n_x);
     if (n_out + 3 <= n_stats) { stats[n_out++] = work.size(); stats[n_out++] = changed; stats[n_out++] = steps; }

@@ -40,4 +40,6 @@ PY
 python $R/tools/exact_overlap.py $O/pipe8 | tee $O/pipe8_overlap.txt
 find $O -name "*.csv" -size +1M -delete
 cd $R
-timeout 300 python tools/exact_tune.py C2 "pipe=8" "pipe=8,KS_MARCH_STREAMS=2" "pipe=8,KS_MARCH_STREAMS=3" "pipe=8,KS_NO_GRAPH=1" "pipe=2" 2>&1 | grep "^C2"
+timeout 600 python -m pytest tests/test_exact_early_out_gpu.py -m gpu -q -x 2>&1 | tail -4
+timeout 300 python tools/exact_tune.py C2 "pipe=0" "pipe=8" "pipe=8,KS_EXACT_BULK_ROUNDS=6" "pipe=8,KS_EXACT_BULK_ROUNDS=14" "pipe=8,KS_EXACT_SEED_GROWTH=64" 2>&1 | grep "^C2"
+
