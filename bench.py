@@ -42,6 +42,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the HIP runtime's hardware queues (default 4; streams that share one run one after the other): ks_create asks for 8, but
+# the setting only takes effect before the process first touches the runtime — here, before torch does.  Scheduling only.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_UPDATE = 208         # R+W of TsdfVoxel (12 B) + SemanticVoxel (92 B), SURVEY.md §8d

@@ -836,7 +836,8 @@ int enqueue_exact_rounds(ks_ctx* c, FrameSlot& S, hipStream_t st) {
   const uint32_t nb4k = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
   const size_t lds = (size_t)nb4k * sizeof(unsigned long long);
   EoCtl* ctl = S.d_eo_ctl;
-  hipLaunchKernelGGL(k_eo2_begin, dim3(1), dim3(64), 0, st, ctl);
+  const EoView E = eo_view(c, S);
+  hipLaunchKernelGGL(k_eo2_begin, dim3(1), dim3(64), 0, st, E);
   hipLaunchKernelGGL(k_eo_scan, dim3(nb4k), dim3(1024), 0, st, (const FrameParams*)S.d_F, (const uint32_t*)S.d_cnt, S.d_eo_lp, S.d_eo_bt, &ctl->st,
                      S.d_eo_cnt_b, S.d_eo_ux, S.d_eo_dirty);
   if (S.wide)
@@ -856,7 +857,6 @@ int enqueue_exact_rounds(ks_ctx* c, FrameSlot& S, hipStream_t st) {
     c->err = "exact early-out: the mark sort ended in the wrong buffer";
     return KS_ERR_HIP;
   }
-  const EoView E = eo_view(c, S);
   const uint32_t gm = (uint32_t)std::min<size_t>((S.eo_cap_marks + 255) / 256, 2048);
   // the first iteration, full and streaming: hit bits of the sorted seed marks, stop rule per ray, validity bitmaps
   EoPhase1 P{};
@@ -1746,6 +1746,10 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     g_create_error = "fast integrator with the early-out enabled supports clear_checks_every_n_frames <= 256";
     return KS_ERR_UNSUPPORTED;
   }
+  // The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
+  // run one after the other: a pipelined context keeps up to seven streams busy.  Takes effect if this is the process's
+  // first use of the HIP runtime; a value the caller has set is left alone.  Scheduling only — never a result.
+  (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device_id >= ndev) {
     g_create_error = "no HIP device (the MI355X path has no CPU fallback)";
@@ -1767,7 +1771,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // of the dependence between frames — the zero-initialised slot — is carried by the commit events.
     if (c->exact_early_out && (!c->eo_device || c->cfg.clear_checks_every_n_frames > 1)) c->cfg.pipeline_frames = 0;
     const bool wide_rays = steps_max_of(c->cfg, (float)(1.0 / cfg->voxel_size)) > 400;
-    c->eo_bulk_rounds = wide_rays ? 32 : 10;
+    c->eo_bulk_rounds = wide_rays ? 32 : 14;
     if (const char* br = getenv("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
   }
   c->uses_early_out = uses_early_out;
@@ -1814,6 +1818,9 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   if (c->cfg.pipeline_frames) {
     // (shared early-out table: stage B of consecutive frames stays in order on one stream)
     c->n_march = (!frames_independent || c->batch > 1) ? 1 : std::min(kMarchStreams, std::max(4, c->cfg.pipeline_frames));
+    // (exact early-out: a frame's stage B is a chain of ~60 small launches, ~1.5 ms long; four of them side by side, each on
+    // a hardware queue of its own — measured: 8 streams over the runtime's queues lose to 4)
+    if (c->exact_early_out && c->n_march > 4) c->n_march = 4;
     if (const char* ms = getenv("KS_MARCH_STREAMS")) c->n_march = std::min(kMarchStreams, std::max(1, atoi(ms)));  // diagnostics
     {
       // KS_STREAM_PRIORITY (diagnostics): m = march streams at the highest priority, t = tail, l = long at the lowest

@@ -379,7 +379,7 @@ struct EoCtl {
   uint32_t n_consulted;           // rays whose result depends on what EARLIER FRAMES left in the table
   uint32_t fin_in[2], fin_chg;    // the finisher's list counters
   uint32_t pad;
-  unsigned long long n_marks1;    // marks left after the first (full) iteration's compaction
+  unsigned long long assumed0;    // what the slot of hash 0 held (as earlier frames left it) when the fix point began — see k_eo2_finish
   uint32_t n_in[kEoBulkMax + 2];  // dirty rays entering bulk round r
   uint32_t n_chg[kEoBulkMax + 2]; // rays whose length changed in bulk round r
 };
@@ -438,9 +438,10 @@ __global__ void __launch_bounds__(256) k_eo2_hits(EoView E, EoPhase1 P) {
     if (j > 0 && (uint32_t)(E.keys[j - 1] >> 44) == slot) {
       hit = E.vals[j - 1] == h;
     } else {
-      hit = E.plain[slot] == (uint64_t)h;
-      // (the only hash an entry of an EARLIER offset can equal is that of the zero-initialised slot: the ray is looked at
-      // again once the frames before this one have entered their marks)
+      // (the only hash an entry of an EARLIER offset can equal is that of the zero-initialised slot; what that slot held
+      // when the fix point began is the assumption every evaluation uses — k_eo2_finish checks it once the frames before
+      // this one have entered their marks, and looks at these rays again if it was wrong)
+      hit = h == 0u ? E.ctl->assumed0 == 0ull : E.plain[slot] == (uint64_t)h;
       if (h == 0u && !(atomicOr(&E.ux[pos], 0x80000000u) >> 31)) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos;
     }
     const unsigned long long at = E.btp[pos / kScanBlock] + E.lp[pos] + step;
@@ -736,7 +737,7 @@ __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams&
         const bool found = eo2_content_at(E, j, slot, t, pos, content);
         if (found) hit = content == h;
         else {
-          hit = E.plain[slot] == (uint64_t)h;
+          hit = h == 0u ? eo2_ld64(&E.ctl->assumed0) == 0ull : E.plain[slot] == (uint64_t)h;
           consulted |= h == 0u;   // (the only hash an entry of an EARLIER offset can equal: the zero-initialised slot)
         }
       }
@@ -897,8 +898,18 @@ __global__ void __launch_bounds__(kEoFinishThreads) k_eo2_finish(EoView E, uint3
     return;
   }
   if (chained) {
-    const uint32_t nc = eo2_ld(&ctl->n_consulted);
-    for (uint32_t i = threadIdx.x; i < nc; i += kEoFinishThreads) eo2_mark_dirty(E, eo2_ld(&E.consulted[i]), E.list[cur], &ctl->fin_in[cur]);
+    // every frame before this one has entered its marks: was the assumption about the slot of hash 0 right?
+    __shared__ uint32_t s_redo;
+    if (threadIdx.x == 0) {
+      const unsigned long long actual = E.plain[(uint32_t)(F.observed_offset & kSetMask)];
+      s_redo = actual != ctl->assumed0 ? 1u : 0u;
+      ctl->assumed0 = actual;
+    }
+    __syncthreads();
+    if (s_redo) {
+      const uint32_t nc = eo2_ld(&ctl->n_consulted);
+      for (uint32_t i = threadIdx.x; i < nc; i += kEoFinishThreads) eo2_mark_dirty(E, eo2_ld(&E.consulted[i]), E.list[cur], &ctl->fin_in[cur]);
+    }
     __syncthreads();
   }
   for (uint32_t it = 0;; ++it) {
@@ -964,11 +975,15 @@ __global__ void __launch_bounds__(256) k_eo2_commit(EoView E) {
 }
 
 // start of a frame's fix point: counters (n_x = 1: node 0 is the end of a chain)
-__global__ void __launch_bounds__(64) k_eo2_begin(EoCtl* ctl) {
+__global__ void __launch_bounds__(64) k_eo2_begin(EoView E) {
+  EoCtl* ctl = E.ctl;
   uint32_t* w = (uint32_t*)ctl;
   for (uint32_t i = threadIdx.x; i < sizeof(EoCtl) / 4u; i += 64) w[i] = 0u;
   __syncthreads();
-  if (threadIdx.x == 0) ctl->n_x = 1u;
+  if (threadIdx.x == 0) {
+    ctl->n_x = 1u;
+    ctl->assumed0 = E.plain[(uint32_t)(E.F->observed_offset & kSetMask)];
+  }
 }
 
 }  // namespace ksk
