@@ -259,6 +259,8 @@ struct ks_ctx {
   std::atomic<size_t> eo_want_marks{0}, eo_want_x{0};   // capacities a failed frame asked for (grown by the caller's thread between frames)
   size_t eo_cap_marks = 0, eo_cap_x = 0; // per-slot capacities in use
   uint64_t eo_fallbacks = 0;             // frames that fell back to the host-driven loop
+  std::atomic<int> eo_hopeless{0};       // consecutive frames the device loop gave up on for reasons growing a buffer does not cure
+  bool eo_device_off = false;            // ... three of them: the context stays with the host-driven loop (one frame at a time)
   // merged in the reference's bundle order (ks_k_bundle_order.h): scratch of the rank computation, one slab
   bool use_bundle_rank = false;
   BoCtx bo{};
@@ -911,7 +913,7 @@ int launch_batch(ks_ctx* c) {
   const uint64_t key = ((uint64_t)c->cap_points << 24) ^ (c->buffers_epoch.load() << 4) ^ (S0.wide ? 1u : 0u) ^ ((uint64_t)nb << 1);
   bool replayed = false;
   int rc;
-  if (c->exact_early_out && c->eo_device) {
+  if (c->exact_early_out && c->eo_device && !c->eo_device_off) {
     // (batches of one) the ordered phases give the seed; the event-driven fix point makes it the serial result, on the
     // device: three replayed graphs, the wait for the previous frame's marks between the first two
     bool graphs = c->use_graphs;
@@ -1196,12 +1198,13 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   const uint32_t tiles_before = c->tiles_initialised;
   const int set = S.prof_set;
   stage_mark(c, set, 6);
-  if (c->eo_device) {
+  if (c->eo_device && !c->eo_device_off) {
     c->eo_frames += 1;
     c->eo_iterations += S.h_snap->pad[2];   // rounds of the event-driven fix point (k_publish)
     if (getenv("KS_EXACT_DEBUG"))
       fprintf(stderr, "[ks exact] frame %u: X marks %u, fail bits %u, rounds %u, rays %u\n", S.F.eo_frame, S.h_snap->pad[0] - 1u, S.h_snap->pad[1], S.h_snap->pad[2], cnt.n_rays);
   }
+  if (c->eo_device && !c->eo_device_off && !(cnt.err & kErrExact)) c->eo_hopeless.store(0, std::memory_order_relaxed);
   if ((cnt.err & kErrExact) && !(cnt.err & (kErrLabel | kErrIndex))) {
     // The device-driven fix point gave up (marks or X marks did not fit, the finisher ran out of rounds, or the frame
     // before this one fell back and had not entered its marks yet): the host-driven loop repeats the fix point from
@@ -1213,7 +1216,13 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     HIPCHK(c, hipMemcpy(&hctl, S.d_eo_ctl, sizeof(hctl), hipMemcpyDeviceToHost));
     if (hctl.fail & kEoFailMarks)
       c->eo_want_marks.store(std::max<size_t>(2 * c->eo_cap_marks, (size_t)hctl.st.n_marks + (size_t)hctl.st.n_marks / 4), std::memory_order_relaxed);
-    if (hctl.fail & kEoFailX) c->eo_want_x.store(std::max<size_t>(4 * c->eo_cap_x, 4 * (size_t)hctl.n_x), std::memory_order_relaxed);
+    // X marks are for the few rays the seed stopped too early; a frame that wants more of them than an eighth of its
+    // marks (2 cm voxels / 10 m rays: the approximate set is overwhelmed, the seed is wrong on most rays) is not a sparse
+    // problem, and neither is one whose lists are still long after the bulk rounds
+    const bool dense = ((hctl.fail & kEoFailX) && (size_t)hctl.n_x > (size_t)hctl.st.n_marks / 8) || (hctl.fail & kEoFailRounds);
+    if ((hctl.fail & kEoFailX) && !dense) c->eo_want_x.store(std::max<size_t>(4 * c->eo_cap_x, 4 * (size_t)hctl.n_x), std::memory_order_relaxed);
+    if (dense) c->eo_hopeless.fetch_add(1, std::memory_order_relaxed);
+    else if (!(hctl.fail & kEoFailChain)) c->eo_hopeless.store(0, std::memory_order_relaxed);
     ++c->eo_fallbacks;
     if (getenv("KS_EXACT_DEBUG"))
       fprintf(stderr, "[ks exact] frame %u falls back to the host-driven loop: fail bits %u (1 marks, 2 X marks, 4 rounds, 8 predecessor), marks %llu of %zu, X %u of %zu, rounds %u\n",
@@ -1533,9 +1542,15 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
   }
   const ks_config& cfg = c->cfg;
   if (stats) std::memset(stats, 0, sizeof(*stats));
+  int rc;
+  if (c->eo_device && !c->eo_device_off && c->eo_hopeless.load(std::memory_order_relaxed) >= 3) {
+    // the device loop keeps giving up on this context's frames: the host-driven loop from here on, one frame at a time
+    if ((rc = quiesce(c))) return rc;
+    c->eo_device_off = true;
+    c->cfg.pipeline_frames = 0;
+  }
   // sorted integration order keeps its permutation in single buffers: not pipelined
   const bool pipelined = cfg.pipeline_frames && cfg.integration_order_mode != KS_ORDER_SORTED;
-  int rc;
 
   // frame-level bookkeeping of the fast integrator [K:src/semantic_tsdf_integrator_fast.cpp:165-170]
   if (cfg.method == KS_METHOD_FAST) {
@@ -1562,7 +1577,7 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
     if ((rc = quiesce(c))) return rc;
     if ((rc = ensure_points(c, n))) return rc;
   }
-  if (c->eo_device) {
+  if (c->eo_device && !c->eo_device_off) {
     const size_t wm = c->eo_want_marks.load(std::memory_order_relaxed), wx = c->eo_want_x.load(std::memory_order_relaxed);
     if (wm > c->eo_cap_marks || wx > c->eo_cap_x) {
       if ((rc = quiesce(c))) return rc;
@@ -2705,7 +2720,7 @@ int ks_early_out_stats(ks_ctx* c, uint64_t out[5]) {
   out[0] = c->eo_frames;
   out[1] = c->eo_iterations;
   out[2] = c->eo_fallbacks;
-  out[3] = c->eo_device ? 1 : 0;
+  out[3] = (c->eo_device && !c->eo_device_off) ? 1 : 0;
   out[4] = (c->exact_early_out && c->cfg.pipeline_frames > 0) ? 1 : 0;
   return KS_OK;
 }

@@ -369,7 +369,9 @@ __global__ void __launch_bounds__(256) k_eo_commit(unsigned long long n_marks, c
 // ==========================================================================================================
 constexpr uint32_t kEoBulkMax = 40;          // bulk rounds a launch sequence can hold
 constexpr uint32_t kEoFailMarks = 1u, kEoFailX = 2u, kEoFailRounds = 4u, kEoFailChain = 8u;
-constexpr uint32_t kEoFinishRounds = 4096;   // rounds of the finisher before it gives up (the host-driven loop takes over)
+constexpr uint32_t kEoFinishRounds = 256;    // rounds of the finisher before it gives up (the host-driven loop takes over)
+constexpr uint32_t kEoFinishRays = 2048;     // ... and the longest list ONE workgroup takes on (a frame whose lists are still long after the bulk
+                                             // rounds is not converging like a sparse problem: 2 cm voxels / 10 m rays, where the approximate set is overwhelmed)
 
 struct EoCtl {
   EoState st;                     // n_marks (k_eo_emit) ...
@@ -915,7 +917,7 @@ __global__ void __launch_bounds__(kEoFinishThreads) k_eo2_finish(EoView E, uint3
   for (uint32_t it = 0;; ++it) {
     if (threadIdx.x == 0) {
       s_n = eo2_ld(&ctl->fin_in[cur]);
-      s_stop = eo2_ld(&ctl->fail) | (it >= kEoFinishRounds ? kEoFailRounds : 0u);
+      s_stop = eo2_ld(&ctl->fail) | ((it >= kEoFinishRounds || s_n > kEoFinishRays) ? kEoFailRounds : 0u);
       if (s_n && !s_stop) ctl->rounds += 1u;
     }
     __syncthreads();

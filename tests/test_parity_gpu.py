@@ -809,14 +809,14 @@ def test_cloud_outgrows_max_points_with_frames_in_flight(method, early_out):
 
 @pytest.mark.parametrize("method", [0, 1])
 def test_benched_configuration_map_is_exact(method):
-    """EXACTLY what bench.py times: pipeline_frames = 4, 640x480, reference defaults (fast: early-out on, the
-    ordered-phase schedule; merged: reference bundle order), device-pointer entry, 18 trajectory frames so that
-    every frame slot, march stream and captured stage-B graph is reused — final map bit-for-bit against the oracle
-    (fast: the restatement of the schedule, early_out_phase_growth = 32; merged: unordered_map order)."""
+    """EXACTLY what bench.py times: pipeline_frames = 8, 640x480, reference defaults (fast: early-out on, the library's
+    default mode = the reference's serial result; merged: reference bundle order), device-pointer entry, 18 trajectory
+    frames so that every frame slot, march stream and captured stage-B graph is reused — final map bit-for-bit against
+    the oracle (fast: the serial loop, one thread; merged: unordered_map order)."""
     import torch
     kw = dict(COMMON, method=method, voxel_size=0.05, voxels_per_side=16, truncation_distance=0.2, max_ray_length_m=5.0)
-    o = O.Oracle(O.default_config(early_out_phase_growth=32 if method == 0 else 0, **kw))
-    h = B.HipIntegrator(B.default_config(max_tiles=1 << 13, max_points=640 * 480, pipeline_frames=4, **kw))
+    o = O.Oracle(O.default_config(integrator_threads=1, **kw))
+    h = B.HipIntegrator(B.default_config(max_tiles=1 << 13, max_points=640 * 480, pipeline_frames=8, **kw))
     sc = synth.make_scene("room")
     n_frames = 18 if method == 0 else 8
     upd_o = upd_h = 0
@@ -832,6 +832,9 @@ def test_benched_configuration_map_is_exact(method):
     assert upd_o == upd_h
     rep = compare_maps(o, h, exact=True)
     assert rep["oracle_touched"] > 200000
+    if method == 0:
+        st = h.early_out_stats()
+        assert st["event_driven"] and st["pipelined"] and st["fallbacks"] == 0, st
 
 
 @pytest.mark.parametrize("method", [0, 1])

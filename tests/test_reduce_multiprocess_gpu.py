@@ -108,3 +108,31 @@ def test_ks_reduce_multi_rank_equals_emulation(tmp_path, world):
             if own[i] != r:
                 assert (got["rec"][i][:, 3] == 255).all(), f"rank {r} kept content of tile {k} it does not own"
     assert total_sent == total_recv
+
+
+def test_bench_gpus_2_spawns_its_ranks_and_reports_the_exchange(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under torch.distributed.run with two
+    ranks (here: two processes sharing the one GPU, torch.distributed over gloo, ks_reduce through the librccl test double —
+    KS_BENCH_SHARED_GPU=1), the line says n_gpus = 2, carries the per-region exchange and the C5 record, and what ks_reduce
+    reports as sent is whole tiles (the 64 KiB record + the 8-byte key of every dirty tile)."""
+    import json
+    if not os.path.exists(MOCK):
+        pytest.fail("tests/mock_rccl/libmock_rccl.so not built: run __graft_entry__.build()")
+    full = str(tmp_path / "full.json")
+    env = dict(os.environ, KS_BENCH_SHARED_GPU="1", KS_RCCL_LIB=MOCK, KS_BENCH_FULL=full)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-secondary", "--width", "320", "--height", "240"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["reduce"]["tiles_sent"] > 0 and d["reduce"]["bytes_sent"] == d["reduce"]["tiles_sent"] * (65536 + 8)
+    c5 = [s for s in d["secondary"] if s["config"] == "C5"]
+    assert len(c5) == 1 and "error" not in c5[0], c5
+    assert c5[0]["reduce"]["tiles_sent"] > 0 and c5[0]["reduce"]["bytes_sent"] == c5[0]["reduce"]["tiles_sent"] * (65536 + 8)
+    fullrec = json.load(open(full))
+    assert fullrec["n_gpus"] == 2 and "ks_reduce" in fullrec["config"]["parallelism"]
