@@ -815,7 +815,14 @@ EoView eo_view(ks_ctx* c, const FrameSlot& S) {
   E.bits_a = S.d_eo_bits_a;
   E.bits_b = S.d_eo_bits_b;
   E.lp = S.d_eo_lp;
+  E.bt = S.d_eo_bt;
   E.btp = S.d_eo_btp;
+  E.keys0 = S.d_eo_keys[0];
+  E.vals0 = S.d_eo_vals[0];
+  E.cap_marks = (unsigned long long)S.eo_cap_marks;
+  E.hitb = S.d_eo_hitb;
+  E.hseq_w = S.d_eo_hseq;
+  E.wide = S.wide ? 1u : 0u;
   E.hseq = S.d_eo_hseq;
   E.where = S.d_eo_where;
   E.rinfo = S.d_eo_rinfo;
@@ -832,46 +839,46 @@ EoView eo_view(ks_ctx* c, const FrameSlot& S) {
   E.ctl = S.d_eo_ctl;
   return E;
 }
-// part 1: the seed's marks, sorted by slot, and the bulk rounds (after the ordered phases, which leave the seed in S.d_cnt)
-int enqueue_exact_rounds(ks_ctx* c, FrameSlot& S, hipStream_t st) {
+// part 1: the seeds' marks, sorted by slot, the full first iteration and the bulk rounds — for all nb frames of the batch
+// per launch (after the ordered phases, which leave the seeds in the slots' d_cnt)
+int enqueue_exact_rounds(ks_ctx* c, FrameSlot* const* slots, uint32_t nb, hipStream_t st) {
   const size_t n = c->cap_points;   // (grids by capacity: the kernels read the frame's own counts)
   const uint32_t nb4k = (uint32_t)((n + kScanBlock - 1) / kScanBlock);
   const size_t lds = (size_t)nb4k * sizeof(unsigned long long);
-  EoCtl* ctl = S.d_eo_ctl;
-  const EoView E = eo_view(c, S);
-  hipLaunchKernelGGL(k_eo2_begin, dim3(1), dim3(64), 0, st, E);
-  hipLaunchKernelGGL(k_eo_scan, dim3(nb4k), dim3(1024), 0, st, (const FrameParams*)S.d_F, (const uint32_t*)S.d_cnt, S.d_eo_lp, S.d_eo_bt, &ctl->st,
-                     S.d_eo_cnt_b, S.d_eo_ux, S.d_eo_dirty);
-  if (S.wide)
-    hipLaunchKernelGGL(k_eo_emit<8>, dim3((uint32_t)((n + 31) / 32)), dim3(256), lds, st, (const FrameParams*)S.d_F, (const uint32_t*)S.d_ray_list,
-                       (const RayDesc*)S.d_rays, (const uint32_t*)S.d_cnt, (const uint32_t*)S.d_eo_lp, (const unsigned long long*)S.d_eo_bt,
-                       S.d_eo_keys[0], S.d_eo_vals[0], (unsigned long long)S.eo_cap_marks, (const Counters*)S.d_counters, &ctl->st, &ctl->fail, S.d_eo_btp, S.d_eo_hseq, S.d_eo_rinfo, S.d_eo_ckpt);
-  else
-    hipLaunchKernelGGL(k_eo_emit<64>, dim3((uint32_t)((n + 255) / 256)), dim3(256), lds, st, (const FrameParams*)S.d_F, (const uint32_t*)S.d_ray_list,
-                       (const RayDesc*)S.d_rays, (const uint32_t*)S.d_cnt, (const uint32_t*)S.d_eo_lp, (const unsigned long long*)S.d_eo_bt,
-                       S.d_eo_keys[0], S.d_eo_vals[0], (unsigned long long)S.eo_cap_marks, (const Counters*)S.d_counters, &ctl->st, &ctl->fail, S.d_eo_btp, S.d_eo_hseq, S.d_eo_rinfo, S.d_eo_ckpt);
-  uint64_t* kres = nullptr;
-  uint32_t* vres = nullptr;
-  // stable sort on the slot bits only: a slot's marks stay in (position, step) order
-  HIPCHK(c, ksrs::sort_dev<uint64_t>(S.d_eo_sort_ws, S.eo_sort_words, S.d_eo_keys[0], S.d_eo_keys[1], S.d_eo_vals[0], S.d_eo_vals[1],
-                                     (const unsigned long long*)&ctl->st.n_marks, S.eo_cap_marks, 44, 64, st, &kres, &vres));
-  if (kres != S.d_eo_keys[1] || vres != S.d_eo_vals[1]) {
-    c->err = "exact early-out: the mark sort ended in the wrong buffer";
-    return KS_ERR_HIP;
+  EoBatch Bt{};
+  ksrs::DevBatch<uint64_t> Rs{};
+  const FrameSlot& S0 = *slots[0];
+  for (uint32_t k = 0; k < nb; ++k) {
+    const FrameSlot& S = *slots[k];
+    Bt.v[k] = eo_view(c, S);
+    Rs.keys_a[k] = S.d_eo_keys[0];
+    Rs.keys_b[k] = S.d_eo_keys[1];
+    Rs.vals_a[k] = S.d_eo_vals[0];
+    Rs.vals_b[k] = S.d_eo_vals[1];
+    Rs.n_dev[k] = (const unsigned long long*)&S.d_eo_ctl->st.n_marks;
+    Rs.ws[k] = S.d_eo_sort_ws;
   }
-  const uint32_t gm = (uint32_t)std::min<size_t>((S.eo_cap_marks + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_eo2_begin, dim3(nb), dim3(64), 0, st, Bt);
+  hipLaunchKernelGGL(k_eo2_scan, dim3(nb4k, nb), dim3(1024), 0, st, Bt);
+  if (S0.wide) hipLaunchKernelGGL(k_eo2_emit<8>, dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, Bt);
+  else hipLaunchKernelGGL(k_eo2_emit<64>, dim3((uint32_t)((n + 255) / 256), nb), dim3(256), lds, st, Bt);
+  // stable sort on the slot bits only: a slot's marks stay in (position, step) order; three passes: the result is in the
+  // second buffer set (eo_view)
+  HIPCHK(c, ksrs::sort_dev_batch<uint64_t>(Rs, (int)nb, S0.eo_sort_words, S0.eo_cap_marks, 44, 64, st));
+  const uint32_t gm = (uint32_t)std::min<size_t>((S0.eo_cap_marks + 255) / 256, 2048);
   // the first iteration, full and streaming: hit bits of the sorted seed marks, stop rule per ray, validity bitmaps
-  EoPhase1 P{};
-  P.hitb = S.d_eo_hitb;
-  hipLaunchKernelGGL(k_eo2_hits, dim3(gm), dim3(256), 0, st, E, P);
-  hipLaunchKernelGGL(k_eo2_stop0, dim3((uint32_t)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, E, P);
-  hipLaunchKernelGGL(k_eo2_bits, dim3(gm), dim3(256), 0, st, E);
-  hipLaunchKernelGGL(k_eo2_index, dim3(gm), dim3(256), 0, st, E);
+  hipLaunchKernelGGL(k_eo2_hits, dim3(gm, nb), dim3(256), 0, st, Bt);
+  hipLaunchKernelGGL(k_eo2_stop0, dim3((uint32_t)std::min<size_t>((n + 255) / 256, 2048), nb), dim3(256), 0, st, Bt);
+  hipLaunchKernelGGL(k_eo2_bits, dim3(gm, nb), dim3(256), 0, st, Bt);
+  hipLaunchKernelGGL(k_eo2_index, dim3(gm, nb), dim3(256), 0, st, Bt);
   // the event-driven rounds (round 0 was the full iteration above)
-  const uint32_t gr = (uint32_t)std::min<size_t>((n + 3) / 4, 2048);   // wavefront per ray, grid-stride
+  // (wavefront per ray, grid-stride.  The lists shrink geometrically — ~3000 / 1000 / 600 / ... rays at 640x480 — and a
+  // launch costs its workgroups: the later rounds get by with fewer, unless rays are long and lists stay long: 2 cm voxels)
+  const uint32_t gr = (uint32_t)std::min<size_t>((n + 3) / 4, 2048);
   for (int r = 1; r <= c->eo_bulk_rounds; ++r) {
-    hipLaunchKernelGGL(k_eo2_eval, dim3(gr), dim3(256), 0, st, E, (uint32_t)r);
-    hipLaunchKernelGGL(k_eo2_propagate, dim3(gr), dim3(256), 0, st, E, (uint32_t)r);
+    const uint32_t g = S0.wide ? gr : std::min(gr, r == 1 ? 2048u : r == 2 ? 1024u : r <= 4 ? 512u : 256u);
+    hipLaunchKernelGGL(k_eo2_eval, dim3(g, nb), dim3(256), 0, st, Bt, (uint32_t)r);
+    hipLaunchKernelGGL(k_eo2_propagate, dim3(g, nb), dim3(256), 0, st, Bt, (uint32_t)r);
   }
   return KS_OK;
 }
@@ -893,7 +900,7 @@ int launch_batch(ks_ctx* c) {
   const uint32_t nb = (uint32_t)slots.size();
   FrameSlot& S0 = *slots[0];
   hipStream_t st = c->stream;
-  hipStream_t sm = c->batch > 1 ? c->stream_march_[0] : march_stream(c, S0.frame_no);
+  hipStream_t sm = c->batch > 1 ? c->stream_march_[(S0.frame_no / (uint64_t)c->batch) % (uint64_t)c->n_march] : march_stream(c, S0.frame_no);
   c->prof_march_stream = sm;
   if (sm != st) HIPCHK(c, hipStreamWaitEvent(sm, slots[nb - 1]->a_done, 0));  // stage A is one in-order stream: the last frame's event covers all
   const bool stage_events = nb == 1 && S0.prof_set >= 0 && c->pset[S0.prof_set].stages;
@@ -931,9 +938,9 @@ int launch_batch(ks_ctx* c) {
         if (ok) {
           if (part == 1) {
             enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
-            part_rc = enqueue_exact_rounds(c, S0, sm);
+            part_rc = enqueue_exact_rounds(c, slots.data(), nb, sm);
           } else if (part == 2) {
-            enqueue_exact_finish(c, S0, sm);
+            for (uint32_t k = 0; k < nb; ++k) enqueue_exact_finish(c, *slots[k], sm);   // (in frame order: a frame's finisher sees the marks of the one before)
           } else {
             enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 2);
           }
@@ -957,12 +964,13 @@ int launch_batch(ks_ctx* c) {
     if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph, sm));
     else {
       enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
-      if ((rc = enqueue_exact_rounds(c, S0, sm))) return rc;
+      if ((rc = enqueue_exact_rounds(c, slots.data(), nb, sm))) return rc;
     }
     if (c->eo_last_commit && c->eo_last_commit != S0.eo_committed) HIPCHK(c, hipStreamWaitEvent(sm, c->eo_last_commit, 0));
     if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph2, sm));
-    else enqueue_exact_finish(c, S0, sm);
-    HIPCHK(c, hipEventRecord(S0.eo_committed, sm));
+    else
+      for (uint32_t k = 0; k < nb; ++k) enqueue_exact_finish(c, *slots[k], sm);
+    HIPCHK(c, hipEventRecord(S0.eo_committed, sm));   // (after the LAST frame's commit: the batch's frames finish in order on this stream)
     c->eo_last_commit = S0.eo_committed;
     if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph3, sm));
     else enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 2);
@@ -1824,7 +1832,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   const bool frames_independent = !uses_early_out || c->cfg.clear_checks_every_n_frames <= 1;
   c->batch = 1;
   if (const char* ov = getenv("KS_TEST_OVERLAP")) c->test_overlap = atoi(ov) != 0;   // diagnostics: the same schedule and result, rounds one after the other
-  if (c->cfg.pipeline_frames >= 2 && frames_independent && !c->exact_early_out && c->cfg.integration_order_mode != KS_ORDER_SORTED) {
+  if (c->cfg.pipeline_frames >= 2 && frames_independent && (!c->exact_early_out || c->eo_device) && c->cfg.integration_order_mode != KS_ORDER_SORTED) {
     // (measured, 640x480: a batch of 4 behind 8 frames of lag ~ four single-frame sequences on four streams behind 4
     // frames of lag; batches of 2 or 3 lose to both: DESIGN.md)
     c->batch = c->cfg.pipeline_frames >= 8 ? kBatchMax : 1;
@@ -1833,9 +1841,11 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   if (c->cfg.pipeline_frames) {
     // (shared early-out table: stage B of consecutive frames stays in order on one stream)
     c->n_march = (!frames_independent || c->batch > 1) ? 1 : std::min(kMarchStreams, std::max(4, c->cfg.pipeline_frames));
-    // (exact early-out: a frame's stage B is a chain of ~60 small launches, ~1.5 ms long; four of them side by side, each on
-    // a hardware queue of its own — measured: 8 streams over the runtime's queues lose to 4)
+    // (exact early-out: a frame's stage B is a chain of ~75 small launches, ~1.5 ms long, and the hardware runs two or three
+    // such chains side by side at best — measured: 8 streams lose to 4.  With pipeline_frames = 8 the chain is shared by
+    // the four frames of a batch, and two batches alternate over two streams.)
     if (c->exact_early_out && c->n_march > 4) c->n_march = 4;
+    if (c->exact_early_out && c->batch > 1) c->n_march = 2;
     if (const char* ms = getenv("KS_MARCH_STREAMS")) c->n_march = std::min(kMarchStreams, std::max(1, atoi(ms)));  // diagnostics
     {
       // KS_STREAM_PRIORITY (diagnostics): m = march streams at the highest priority, t = tail, l = long at the lowest
@@ -1892,7 +1902,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipMalloc((void**)&c->pool.dirty, mt));
   CRCHK(hipMemset(c->pool.dirty, 0, mt));
   CRCHK(hipMalloc((void**)&c->d_start_set, sizeof(uint64_t) << kSetBits));
-  c->n_obs = (uses_early_out && frames_independent) ? std::max(c->n_march, c->batch) : 1;
+  c->n_obs = (uses_early_out && frames_independent) ? std::min(kMarchStreams, std::max(c->n_march, c->batch * c->n_march)) : 1;
   for (int t = 0; t < c->n_obs; ++t) {
     CRCHK(hipMalloc((void**)&c->d_observed_[t], 2 * (sizeof(uint64_t) << kSetBits)));   // {newest, older} per slot
     CRCHK(hipMemset(c->d_observed_[t], 0, 2 * (sizeof(uint64_t) << kSetBits)));

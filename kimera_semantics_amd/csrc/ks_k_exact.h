@@ -57,10 +57,10 @@ __global__ void __launch_bounds__(256) k_eo_total(const FrameParams* __restrict_
 // exclusive scan of the visited lengths over integration positions, blocks of kScanBlock (as k_scan_local)
 // (cnt_b / ux / dirty: the event-driven path's per-position state, initialised here — next lengths = current lengths,
 // steps covered by marks = visited length, nobody dirty)
-__global__ void __launch_bounds__(1024) k_eo_scan(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ cnt,
-                                                  uint32_t* __restrict__ lp, unsigned long long* __restrict__ bt,
-                                                  EoState* __restrict__ st, uint32_t* __restrict__ cnt_b = nullptr,
-                                                  uint32_t* __restrict__ ux = nullptr, uint32_t* __restrict__ dirty = nullptr) {
+__device__ __forceinline__ void eo_scan_body(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ cnt,
+                                             uint32_t* __restrict__ lp, unsigned long long* __restrict__ bt,
+                                             EoState* __restrict__ st, uint32_t* __restrict__ cnt_b,
+                                             uint32_t* __restrict__ ux, uint32_t* __restrict__ dirty) {
   __shared__ uint32_t s_wave[16];
   const uint32_t n = Fp->n;
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // this iteration's counters
@@ -100,6 +100,11 @@ __global__ void __launch_bounds__(1024) k_eo_scan(const FrameParams* __restrict_
   }
   if (threadIdx.x == 1023) bt[blockIdx.x] = (unsigned long long)(wbase + x);
 }
+__global__ void __launch_bounds__(1024) k_eo_scan(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ cnt,
+                                                  uint32_t* __restrict__ lp, unsigned long long* __restrict__ bt,
+                                                  EoState* __restrict__ st) {
+  eo_scan_body(Fp, cnt, lp, bt, st, nullptr, nullptr, nullptr);
+}
 
 // prefix of the scan's block totals into LDS (every workgroup redundantly); returns the grand total
 __device__ __forceinline__ unsigned long long eo_fold_totals(const unsigned long long* __restrict__ bt, uint32_t nb,
@@ -131,14 +136,14 @@ __device__ __forceinline__ unsigned long long eo_fold_totals(const unsigned long
 
 // every live ray writes the marks of its visited voxels at its offset of the scan (work split as k_mark)
 template <int RPW>
-__global__ void __launch_bounds__(256) k_eo_emit(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ ray_list,
-                                                 const RayDesc* __restrict__ rays, const uint32_t* __restrict__ cnt,
-                                                 const uint32_t* __restrict__ lp, const unsigned long long* __restrict__ bt,
-                                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                 unsigned long long cap, const Counters* C, EoState* __restrict__ st,
-                                                 uint32_t* __restrict__ fail = nullptr, unsigned long long* __restrict__ btp = nullptr,
-                                                 uint32_t* __restrict__ hseq = nullptr, uint4* __restrict__ rinfo = nullptr,
-                                                 uint4* __restrict__ ckpt = nullptr) {
+__device__ __forceinline__ void eo_emit_body(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ ray_list,
+                                             const RayDesc* __restrict__ rays, const uint32_t* __restrict__ cnt,
+                                             const uint32_t* __restrict__ lp, const unsigned long long* __restrict__ bt,
+                                             uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                             unsigned long long cap, const Counters* C, EoState* __restrict__ st,
+                                             uint32_t* __restrict__ fail, unsigned long long* __restrict__ btp,
+                                             uint32_t* __restrict__ hseq, uint4* __restrict__ rinfo,
+                                             uint4* __restrict__ ckpt) {
   extern __shared__ unsigned long long s_bt[];
   __shared__ float s_e[4][3 * kES];
   const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
@@ -208,6 +213,14 @@ __global__ void __launch_bounds__(256) k_eo_emit(const FrameParams* __restrict__
       checkpoint(dda, visited);
     }
   }
+}
+template <int RPW>
+__global__ void __launch_bounds__(256) k_eo_emit(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ ray_list,
+                                                 const RayDesc* __restrict__ rays, const uint32_t* __restrict__ cnt,
+                                                 const uint32_t* __restrict__ lp, const unsigned long long* __restrict__ bt,
+                                                 uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                 unsigned long long cap, const Counters* C, EoState* __restrict__ st) {
+  eo_emit_body<RPW>(Fp, ray_list, rays, cnt, lp, bt, keys, vals, cap, C, st, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 __global__ void __launch_bounds__(256) k_eo_index(unsigned long long n_marks, const uint64_t* __restrict__ keys,
@@ -407,14 +420,36 @@ struct EoView {
   uint32_t* consulted;
   uint64_t* plain;                // the reference's table as earlier frames left it
   uint32_t* committed;            // frames [0, *committed) have entered `plain` (this frame's number: FrameParams::eo_frame)
-  const uint32_t* lp;             // scan of the seed's visited lengths ...
-  const unsigned long long* btp;  // ... exclusive prefix of its block totals: a ray's place in emission order = btp[pos / 4096] + lp[pos]
+  uint32_t* lp;                   // scan of the seed's visited lengths (block-local) ...
+  unsigned long long* bt;         // ... its block totals ...
+  unsigned long long* btp;        // ... and their exclusive prefix: a ray's place in emission order = btp[pos / 4096] + lp[pos]
+  uint64_t* keys0;                // the marks as emitted (the sort's input buffers)
+  uint32_t* vals0;
+  unsigned long long cap_marks;
+  uint8_t* hitb;                  // first iteration: per mark in emission order, the visit is a hit
   const uint32_t* hseq;           // voxel hashes of the seed's marks in emission order
+  uint32_t* hseq_w;               // (hseq, for the kernel that writes it)
   uint32_t* where;                // per seed mark in emission order: its index in M
   uint4* rinfo;                   // per position: {u0 = steps the seed has marks for, -, ray length, checkpoint step}
-  const uint4* ckpt;              // per position: the caster's state at the checkpoint step (3 words of 16 bytes)
+  uint4* ckpt;                    // per position: the caster's state at the checkpoint step (3 words of 16 bytes)
+  uint32_t wide;                  // long rays (2 cm voxels): 8 rays per wavefront in the mark emission
   EoCtl* ctl;
 };
+
+// The frames of a batch (ks_k_march.h: BatchView) share every launch of the fix point up to the finisher: blockIdx.y = frame.
+struct EoBatch {
+  EoView v[kBatchMax];
+};
+__global__ void __launch_bounds__(1024) k_eo2_scan(EoBatch Bt) {
+  const EoView& E = Bt.v[blockIdx.y];
+  eo_scan_body(E.F, E.cnt_a, E.lp, E.bt, &E.ctl->st, E.cnt_b, E.ux, E.dirty);
+}
+template <int RPW>
+__global__ void __launch_bounds__(256) k_eo2_emit(EoBatch Bt) {
+  const EoView& E = Bt.v[blockIdx.y];
+  eo_emit_body<RPW>(E.F, E.ray_list, E.rays, E.cnt_a, E.lp, E.bt, E.keys0, E.vals0, E.cap_marks, E.C, &E.ctl->st, &E.ctl->fail, E.btp, E.hseq_w,
+                    E.rinfo, E.ckpt);
+}
 
 __device__ __forceinline__ uint32_t eo2_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ unsigned long long eo2_ld64(const unsigned long long* p) {
@@ -422,14 +457,12 @@ __device__ __forceinline__ unsigned long long eo2_ld64(const unsigned long long*
 }
 
 // ---- the FIRST iteration is a full one, and streams -----------------------------------------------------------------
-struct EoPhase1 {
-  uint8_t* hitb;                         // per mark in emission order: the visit is a hit
-};
 __device__ __forceinline__ void eo2_mark_dirty(const EoView& E, uint32_t p, uint32_t* out, uint32_t* n_out);
 
 // per sorted mark: is the visit a hit (the mark before it in its slot holds the same hash; first of its slot: what earlier
 // frames left there)?  -> hitb[its place in emission order]; and where[] of that place = the mark's index
-__global__ void __launch_bounds__(256) k_eo2_hits(EoView E, EoPhase1 P) {
+__global__ void __launch_bounds__(256) k_eo2_hits(EoBatch Bt) {
+  const EoView& E = Bt.v[blockIdx.y];
   const unsigned long long n = E.ctl->st.n_marks;
   if (E.ctl->fail) return;
   for (unsigned long long j = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * 256ull) {
@@ -447,21 +480,22 @@ __global__ void __launch_bounds__(256) k_eo2_hits(EoView E, EoPhase1 P) {
       if (h == 0u && !(atomicOr(&E.ux[pos], 0x80000000u) >> 31)) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos;
     }
     const unsigned long long at = E.btp[pos / kScanBlock] + E.lp[pos] + step;
-    P.hitb[at] = hit ? 1 : 0;
+    E.hitb[at] = hit ? 1 : 0;
     E.where[at] = (uint32_t)j;
   }
 }
 
 // per ray (a lane each): the reference's stop rule over its contiguous hit bits -> new length, in place (nothing reads
 // lengths here).  A ray that used to stop and does not any more within the steps it has marks for goes on in round 1.
-__global__ void __launch_bounds__(256) k_eo2_stop0(EoView E, EoPhase1 P) {
+__global__ void __launch_bounds__(256) k_eo2_stop0(EoBatch Bt) {
+  const EoView& E = Bt.v[blockIdx.y];
   if (E.ctl->fail) return;
   const uint32_t n = E.C->n_rays;
   const int lim = E.F->max_collisions;
   for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
     const uint32_t pos = E.ray_list[r];
     const uint32_t cv = E.cnt_a[pos], v0 = eo_visited(cv);
-    const uint8_t* hb = P.hitb + (E.btp[pos / kScanBlock] + E.lp[pos]);
+    const uint8_t* hb = E.hitb + (E.btp[pos / kScanBlock] + E.lp[pos]);
     int c = 0, stop = -1;
     for (uint32_t k = 0; k < v0; ++k) {
       c = hb[k] ? c + 1 : 0;
@@ -482,7 +516,8 @@ __global__ void __launch_bounds__(256) k_eo2_stop0(EoView E, EoPhase1 P) {
 
 // The validity bitmaps under the new lengths (a wavefront's ballot is a word), and the readers whose input changed: the
 // owner of every valid mark whose predecessor in its slot is not valid any more.
-__global__ void __launch_bounds__(256) k_eo2_bits(EoView E) {
+__global__ void __launch_bounds__(256) k_eo2_bits(EoBatch Bt) {
+  const EoView& E = Bt.v[blockIdx.y];
   const unsigned long long n = E.ctl->st.n_marks;
   if (E.ctl->fail) return;
   const unsigned long long n_pad = (n + 63ull) & ~63ull;
@@ -514,7 +549,8 @@ __global__ void __launch_bounds__(256) k_eo2_bits(EoView E) {
 }
 
 // per slot: [begin, end) of its marks in M (the table is clear: k_eo2_commit leaves it so)
-__global__ void __launch_bounds__(256) k_eo2_index(EoView E) {
+__global__ void __launch_bounds__(256) k_eo2_index(EoBatch Bt) {
+  const EoView& E = Bt.v[blockIdx.y];
   const unsigned long long n = E.ctl->st.n_marks;
   if (E.ctl->fail) return;
   for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull) {
@@ -853,8 +889,9 @@ __device__ __forceinline__ void eo2_propagate_ray(const EoView& E, const FramePa
 // One bulk round = two launches (grid-stride over the list, one wavefront per ray):
 //   k_eo2_eval      : rays of list[r & 1] (round 0: every ray of the frame) -> change list
 //   k_eo2_propagate : change list -> list[(r + 1) & 1]
-__global__ void __launch_bounds__(256) k_eo2_eval(EoView E, uint32_t round) {
+__global__ void __launch_bounds__(256) k_eo2_eval(EoBatch Bt, uint32_t round) {
   __shared__ EoWaveLds s_w[4];
+  const EoView& E = Bt.v[blockIdx.y];
   EoCtl* ctl = E.ctl;
   if (ctl->fail) return;
   const uint32_t n = ctl->n_in[round];
@@ -864,8 +901,9 @@ __global__ void __launch_bounds__(256) k_eo2_eval(EoView E, uint32_t round) {
   const FrameParams F = *E.F;
   for (uint32_t i = w0; i < n; i += nw) eo2_eval_ray(E, F, list[i], s_w[wave], &ctl->n_chg[round]);
 }
-__global__ void __launch_bounds__(256) k_eo2_propagate(EoView E, uint32_t round) {
+__global__ void __launch_bounds__(256) k_eo2_propagate(EoBatch Bt, uint32_t round) {
   __shared__ EoWaveLds s_w[4];
+  const EoView& E = Bt.v[blockIdx.y];
   EoCtl* ctl = E.ctl;
   if (ctl->fail) return;
   const uint32_t n = ctl->n_chg[round];
@@ -977,7 +1015,8 @@ __global__ void __launch_bounds__(256) k_eo2_commit(EoView E) {
 }
 
 // start of a frame's fix point: counters (n_x = 1: node 0 is the end of a chain)
-__global__ void __launch_bounds__(64) k_eo2_begin(EoView E) {
+__global__ void __launch_bounds__(64) k_eo2_begin(EoBatch Bt) {
+  const EoView& E = Bt.v[blockIdx.x];   // one workgroup per frame of the batch
   EoCtl* ctl = E.ctl;
   uint32_t* w = (uint32_t*)ctl;
   for (uint32_t i = threadIdx.x; i < sizeof(EoCtl) / 4u; i += 64) w[i] = 0u;

@@ -46,11 +46,10 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, unsigned l
 // It also clears the workspace half the PREVIOUS sort used (zero_ptr, zero_words: a multiple of 4),
 // which becomes the next sort's workspace: no memset launch per sort.
 template <typename K, int RB>
-__global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uint32_t n, int passes, int begin_bit,
-                                                 uint32_t* __restrict__ hist, uint32_t* __restrict__ zero_ptr,
-                                                 uint32_t zero_words, const unsigned long long* __restrict__ n_dev = nullptr) {
+__device__ __forceinline__ void rs_hist_body(const K* __restrict__ keys, uint32_t n, int passes, int begin_bit,
+                                             uint32_t* __restrict__ hist, uint32_t* __restrict__ zero_ptr,
+                                             uint32_t zero_words, const unsigned long long* __restrict__ n_dev, uint32_t* s_hist) {
   constexpr int kBins = 1 << RB;
-  extern __shared__ uint32_t s_hist[];  // [passes][kBins]
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   if (n_dev) n = (uint32_t)(*n_dev < (unsigned long long)n ? *n_dev : (unsigned long long)n);   // sort_dev: the key count lives on the device (n = capacity)
   for (uint32_t i = blockIdx.x * 256u + tid; i < zero_words / 4u; i += gridDim.x * 256u)
@@ -88,17 +87,41 @@ __global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uin
     if (c) atomicAdd(&hist[(i / kBins) * kMaxBins + (i % kBins)], c);
   }
 }
+template <typename K, int RB>
+__global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uint32_t n, int passes, int begin_bit,
+                                                 uint32_t* __restrict__ hist, uint32_t* __restrict__ zero_ptr,
+                                                 uint32_t zero_words, const unsigned long long* __restrict__ n_dev = nullptr) {
+  extern __shared__ uint32_t s_hist[];  // [passes][kBins]
+  rs_hist_body<K, RB>(keys, n, passes, begin_bit, hist, zero_ptr, zero_words, n_dev, s_hist);
+}
+// Up to kRsBatch independent sorts of the same capacity per launch (blockIdx.y = sort): their launches are latency bound,
+// and a launch costs the same for one sort or four.
+constexpr int kRsBatch = 4;
+template <typename K>
+struct DevBatch {
+  K* keys_a[kRsBatch];
+  K* keys_b[kRsBatch];
+  uint32_t* vals_a[kRsBatch];
+  uint32_t* vals_b[kRsBatch];
+  const unsigned long long* n_dev[kRsBatch];
+  uint32_t* ws[kRsBatch];
+};
+template <typename K, int RB>
+__global__ void __launch_bounds__(256) k_rs_hist_b(DevBatch<K> B, uint32_t cap, int passes, int begin_bit) {
+  extern __shared__ uint32_t s_hist[];
+  rs_hist_body<K, RB>(B.keys_a[blockIdx.y], cap, passes, begin_bit, B.ws[blockIdx.y], nullptr, 0u, B.n_dev[blockIdx.y], s_hist);
+}
 
 // One pass.  THREADS x ITEMS keys per tile.  REORDER (keys only, large inputs): the tile's keys are first put in
 // digit order in LDS and leave from there, so that neighbouring lanes write neighbouring addresses (runs of
 // ~tile/256 keys per digit) instead of 8-byte scatters — the direct scatter wrote 2.6x its bytes at 3e7 keys.
 template <typename K, bool HAS_VALUES, int THREADS, int ITEMS, int RB, bool REORDER = false>
-__global__ void __launch_bounds__(THREADS) k_rs_pass(const K* __restrict__ keys_in, K* __restrict__ keys_out,
-                                                     const uint32_t* __restrict__ vals_in,
-                                                     uint32_t* __restrict__ vals_out, uint32_t n, int shift,
-                                                     const uint32_t* __restrict__ bin_hist,
-                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
-                                                     const unsigned long long* __restrict__ n_dev = nullptr) {
+__device__ __forceinline__ void rs_pass_body(const K* __restrict__ keys_in, K* __restrict__ keys_out,
+                                             const uint32_t* __restrict__ vals_in,
+                                             uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                             const uint32_t* __restrict__ bin_hist,
+                                             uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
+                                             const unsigned long long* __restrict__ n_dev) {
   constexpr int kBins = 1 << RB;
   constexpr int kChunks = kBins / 64;
   constexpr int kWaves = THREADS / 64;
@@ -260,6 +283,27 @@ __global__ void __launch_bounds__(THREADS) k_rs_pass(const K* __restrict__ keys_
   }
 }
 
+template <typename K, bool HAS_VALUES, int THREADS, int ITEMS, int RB, bool REORDER = false>
+__global__ void __launch_bounds__(THREADS) k_rs_pass(const K* __restrict__ keys_in, K* __restrict__ keys_out,
+                                                     const uint32_t* __restrict__ vals_in,
+                                                     uint32_t* __restrict__ vals_out, uint32_t n, int shift,
+                                                     const uint32_t* __restrict__ bin_hist,
+                                                     uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
+                                                     const unsigned long long* __restrict__ n_dev = nullptr) {
+  rs_pass_body<K, HAS_VALUES, THREADS, ITEMS, RB, REORDER>(keys_in, keys_out, vals_in, vals_out, n, shift, bin_hist, status, ticket, n_dev);
+}
+// pass p of the batched sorts: odd passes read the b buffers
+template <typename K, int THREADS, int ITEMS, int RB>
+__global__ void __launch_bounds__(THREADS) k_rs_pass_b(DevBatch<K> B, uint32_t cap, int begin_bit, int p, uint32_t tiles) {
+  const uint32_t y = blockIdx.y;
+  uint32_t* ws = B.ws[y];
+  const bool odd = (p & 1) != 0;
+  rs_pass_body<K, true, THREADS, ITEMS, RB, false>(odd ? B.keys_b[y] : B.keys_a[y], odd ? B.keys_a[y] : B.keys_b[y], odd ? B.vals_b[y] : B.vals_a[y],
+                                                   odd ? B.vals_a[y] : B.vals_b[y], cap, begin_bit + p * RB, ws + (size_t)p * kMaxBins,
+                                                   ws + ((size_t)kMaxPasses * kMaxBins + kMaxPasses) + (size_t)p * tiles * (1 << RB),
+                                                   ws + (size_t)kMaxPasses * kMaxBins + p, B.n_dev[y]);
+}
+
 // Host-side workspace + launcher.  Sorts bits [begin_bit, end_bit) of the keys; the result is
 // in (*keys_result, *vals_result), each pointing at one of the two ping-pong buffers.
 // Two halves used alternately: while a sort runs in one half its histogram kernel clears what the
@@ -390,6 +434,30 @@ inline hipError_t sort_dev(uint32_t* ws, size_t ws_words, K* keys_a, K* keys_b, 
   }
   *keys_result = kin;
   *vals_result = vin;
+  return hipGetLastError();
+}
+
+// nb sorts of the same capacity in one launch sequence (memset per workspace, then hist + passes with blockIdx.y = sort).
+// Results as sort_dev: in the b buffers after an odd number of passes.
+template <typename K>
+inline hipError_t sort_dev_batch(const DevBatch<K>& B, int nb, size_t ws_words, size_t cap, unsigned begin_bit, unsigned end_bit, hipStream_t stream) {
+  constexpr int RB = 8;
+  constexpr int kBins = 1 << RB;
+  const int passes = (int)((end_bit - begin_bit + RB - 1) / RB);
+  const size_t tile = dev_tile(cap);
+  const uint32_t tiles = (uint32_t)((cap + tile - 1) / tile);
+  if (kHeadWords + (size_t)passes * tiles * kBins > ws_words || nb < 1 || nb > kRsBatch) return hipErrorInvalidValue;
+  for (int y = 0; y < nb; ++y) {
+    hipError_t e = hipMemsetAsync(B.ws[y], 0, (kHeadWords + (size_t)passes * tiles * kBins) * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL((k_rs_hist_b<K, RB>), dim3((uint32_t)std::min<size_t>((cap + 2047) / 2048, kHistBlocks), (uint32_t)nb), dim3(256),
+                     (size_t)passes * kBins * sizeof(uint32_t), stream, B, (uint32_t)cap, passes, (int)begin_bit);
+  for (int p = 0; p < passes; ++p) {
+    if (tile == 2048) hipLaunchKernelGGL((k_rs_pass_b<K, 256, 8, RB>), dim3(tiles, (uint32_t)nb), dim3(256), 0, stream, B, (uint32_t)cap, (int)begin_bit, p, tiles);
+    else if (tile == 8192) hipLaunchKernelGGL((k_rs_pass_b<K, 512, 16, RB>), dim3(tiles, (uint32_t)nb), dim3(512), 0, stream, B, (uint32_t)cap, (int)begin_bit, p, tiles);
+    else hipLaunchKernelGGL((k_rs_pass_b<K, 512, 32, RB>), dim3(tiles, (uint32_t)nb), dim3(512), 0, stream, B, (uint32_t)cap, (int)begin_bit, p, tiles);
+  }
   return hipGetLastError();
 }
 

@@ -79,6 +79,11 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
   /// from the map the host holds exactly like the CPU integrators do.
   void uploadLayers();
 
+  /// Switch between the strict and the on-demand policy at run time (integration/server.patch: a server that calls
+  /// syncLayers() where it reads the Layers selects kOnDemand right after the factory handed the integrator out).
+  void setSyncPolicy(SyncPolicy policy) { options_.sync_policy = policy; }
+  SyncPolicy syncPolicy() const { return options_.sync_policy; }
+
   ks_ctx* context() { return ctx_; }
   const ks_frame_stats& lastFrameStats() const { return last_stats_; }
 
