@@ -372,6 +372,18 @@ void probe_rehash_schedule(size_t n_max, BoSchedule* out) {
 int ensure_bundle_order(ks_ctx* c, size_t cap) {
   probe_rehash_schedule(cap, &c->bo_sched);
   const BoSchedule& S = c->bo_sched;
+  {
+    // The closed form of the iteration order (ks_k_bundle_order.h) is that of libstdc++'s unordered_map — the container the
+    // reference is built with — and k_bo_small knows its tenth bucket count.  A library built against another standard
+    // library (another prime policy) would compute some other, self-consistent order: refuse instead.
+    static const uint32_t kLibstdcxxBuckets[] = {13, 29, 59, 127, 257, 541, 1109, 2357, 5087, 10273, 20753, 42043, 85229, 172933};
+    for (uint32_t e = 0; e < S.n_epochs && e < sizeof(kLibstdcxxBuckets) / sizeof(uint32_t); ++e)
+      if (S.b[e] != kLibstdcxxBuckets[e] || (e > 0 && S.t[e] != kLibstdcxxBuckets[e - 1])) {
+        c->err = "bundle_order = KS_BUNDLE_ORDER_REFERENCE needs libstdc++'s unordered_map rehash schedule (13, 29, 59, ...): this build's standard "
+                 "library differs; use KS_BUNDLE_ORDER_CANONICAL";
+        return KS_ERR_UNSUPPORTED;
+      }
+  }
   c->bo_epochs = (int)S.n_epochs;
   size_t heads = 0;
   for (uint32_t e = 0; e < S.n_epochs; ++e) heads += S.b[e];
