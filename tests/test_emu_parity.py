@@ -57,20 +57,21 @@ def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_lib):
 
 
 @pytest.mark.parametrize("spec", [
-    dict(method=0, size=[160, 120], frames=3),                                   # the default: the reference's serial result, event-driven
-    dict(method=0, size=[128, 96], frames=5, pipeline=4),                        # frames in flight, commit chain
-    dict(method=0, size=[96, 72], frames=4, cfg=dict(clear_checks_every_n_frames=3)),   # a frame's marks are inputs of the next frame
+    dict(method=0, size=[128, 96], frames=2),                                    # the default: the reference's serial result, event-driven
+    dict(method=0, size=[64, 48], frames=5, pipeline=4),                         # frames in flight, commit chain
+    dict(method=0, size=[64, 48], frames=6, pipeline=8),                         # batches of four frames per launch
+    dict(method=0, size=[64, 48], frames=4, cfg=dict(clear_checks_every_n_frames=3)),   # a frame's marks are inputs of the next frame
     dict(method=0, size=[96, 72], frames=2, cloud="axis", max_tiles=8192),       # axis-parallel rays: the serial caster inside the rounds
-    dict(method=0, size=[64, 36], frames=2, max_tiles=32768, cfg=dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0)),
-], ids=["default", "pipelined", "clear_every_3", "axis_parallel", "long_rays"])
+    dict(method=0, size=[48, 27], frames=2, max_tiles=32768, cfg=dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0)),
+], ids=["default", "pipelined", "batched", "clear_every_3", "axis_parallel", "long_rays"])
 def test_event_driven_exact_early_out_equals_serial_oracle(emu_lib, spec):
     run_case(emu_lib, spec)
 
 
-@pytest.mark.parametrize("pipeline", [0, 4])
+@pytest.mark.parametrize("pipeline", [4])
 def test_exact_early_out_overflow_falls_back_to_the_host_loop(emu_lib, pipeline):
     """marks and X marks that do not fit their buffers: host-driven loop for the frame (and those in flight behind it), buffers grow."""
-    run_case(emu_lib, dict(method=0, size=[96, 72], frames=4, pipeline=pipeline), env_extra={"KS_EXACT_CAP_MARKS": "20000", "KS_EXACT_CAP_X": "16"})
+    run_case(emu_lib, dict(method=0, size=[64, 48], frames=3, pipeline=pipeline), env_extra={"KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "16"})
 
 
 @pytest.mark.parametrize("overlap", ["1", "0"])
