@@ -34,4 +34,4 @@ def test_event_driven_fix_point_reaches_the_serial_lengths(monkeypatch, mode, se
     assert wrong == 0
     rounds = int((stats[0::3] > 0).sum())
     assert 2 <= rounds <= 40 and int(stats[0]) > 5000          # every ray in round 0, then a shrinking tail
-    assert int(stats[3]) < int(stats[0]) // 2                    # round 1 looks at a fraction of the rays
+    assert int(stats[3]) < int(stats[0]) * (1 if seed_growth > 32 else 0.5)   # round 1 looks at a fraction of the rays (a coarse seed: most of them)
