@@ -259,6 +259,12 @@ struct ks_ctx {
   std::atomic<size_t> eo_want_marks{0}, eo_want_x{0};   // capacities a failed frame asked for (grown by the caller's thread between frames)
   size_t eo_cap_marks = 0, eo_cap_x = 0; // per-slot capacities in use
   uint64_t eo_fallbacks = 0;             // frames that fell back to the host-driven loop
+  // Where the approximate set is overwhelmed (2 cm voxels / 10 m rays: ~30 marks per slot and frame) the reference's early-out
+  // hardly fires and the ordered-phase seed — whose rays stop on their own chain's marks — is too short on most rays: they
+  // would all have to grow through X marks.  Such a context seeds the fix point with the FULL rays instead (k_dedup has left
+  // them in cnt[]: the phases are simply skipped): every step has a mark, nothing grows, rays only ever get shorter.
+  std::atomic<bool> eo_seed_full_want{false};
+  bool eo_seed_full = false;
   std::atomic<int> eo_hopeless{0};       // consecutive frames the device loop gave up on for reasons growing a buffer does not cure
   bool eo_device_off = false;            // ... three of them: the context stays with the host-driven loop (one frame at a time)
   // merged in the reference's bundle order (ks_k_bundle_order.h): scratch of the rank computation, one slab
@@ -949,7 +955,7 @@ int launch_batch(ks_ctx* c) {
         bool ok = hipStreamBeginCapture(sm, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
           if (part == 1) {
-            enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
+            if (!c->eo_seed_full) enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
             part_rc = enqueue_exact_rounds(c, slots.data(), nb, sm);
           } else if (part == 2) {
             for (uint32_t k = 0; k < nb; ++k) enqueue_exact_finish(c, *slots[k], sm);   // (in frame order: a frame's finisher sees the marks of the one before)
@@ -975,7 +981,7 @@ int launch_batch(ks_ctx* c) {
     }
     if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph, sm));
     else {
-      enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
+      if (!c->eo_seed_full) enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
       if ((rc = enqueue_exact_rounds(c, slots.data(), nb, sm))) return rc;
     }
     if (c->eo_last_commit && c->eo_last_commit != S0.eo_committed) HIPCHK(c, hipStreamWaitEvent(sm, c->eo_last_commit, 0));
@@ -1222,7 +1228,8 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     c->eo_frames += 1;
     c->eo_iterations += S.h_snap->pad[2];   // rounds of the event-driven fix point (k_publish)
     if (getenv("KS_EXACT_DEBUG"))
-      fprintf(stderr, "[ks exact] frame %u: X marks %u, fail bits %u, rounds %u, rays %u\n", S.F.eo_frame, S.h_snap->pad[0] - 1u, S.h_snap->pad[1], S.h_snap->pad[2], cnt.n_rays);
+      fprintf(stderr, "[ks exact] frame %u: X marks %u, fail bits %u, rounds %u, rays %u%s\n", S.F.eo_frame, S.h_snap->pad[0] - 1u, S.h_snap->pad[1], S.h_snap->pad[2], cnt.n_rays,
+              c->eo_seed_full ? " (seed: full rays)" : "");
   }
   if (c->eo_device && !c->eo_device_off && !(cnt.err & kErrExact)) c->eo_hopeless.store(0, std::memory_order_relaxed);
   if ((cnt.err & kErrExact) && !(cnt.err & (kErrLabel | kErrIndex))) {
@@ -1239,9 +1246,11 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     // X marks are for the few rays the seed stopped too early; a frame that wants more of them than an eighth of its
     // marks (2 cm voxels / 10 m rays: the approximate set is overwhelmed, the seed is wrong on most rays) is not a sparse
     // problem, and neither is one whose lists are still long after the bulk rounds
-    const bool dense = ((hctl.fail & kEoFailX) && (size_t)hctl.n_x > (size_t)hctl.st.n_marks / 8) || (hctl.fail & kEoFailRounds);
+    const bool x_dense = (hctl.fail & kEoFailX) && (size_t)hctl.n_x > (size_t)hctl.st.n_marks / 8;
+    const bool dense = x_dense || (hctl.fail & kEoFailRounds);
     if ((hctl.fail & kEoFailX) && !dense) c->eo_want_x.store(std::max<size_t>(4 * c->eo_cap_x, 4 * (size_t)hctl.n_x), std::memory_order_relaxed);
-    if (dense) c->eo_hopeless.fetch_add(1, std::memory_order_relaxed);
+    if (x_dense && !c->eo_seed_full) c->eo_seed_full_want.store(true, std::memory_order_relaxed);   // (first: the other seed)
+    else if (dense) c->eo_hopeless.fetch_add(1, std::memory_order_relaxed);
     else if (!(hctl.fail & kEoFailChain)) c->eo_hopeless.store(0, std::memory_order_relaxed);
     ++c->eo_fallbacks;
     if (getenv("KS_EXACT_DEBUG"))
@@ -1597,6 +1606,11 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
     if ((rc = quiesce(c))) return rc;
     if ((rc = ensure_points(c, n))) return rc;
   }
+  if (c->eo_device && !c->eo_device_off && !c->eo_seed_full && c->eo_seed_full_want.load(std::memory_order_relaxed)) {
+    if ((rc = quiesce(c))) return rc;
+    c->eo_seed_full = true;
+    ++c->buffers_epoch;   // the captured launch sequences hold the phases
+  }
   if (c->eo_device && !c->eo_device_off) {
     const size_t wm = c->eo_want_marks.load(std::memory_order_relaxed), wx = c->eo_want_x.load(std::memory_order_relaxed);
     if (wm > c->eo_cap_marks || wx > c->eo_cap_x) {
@@ -1805,6 +1819,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // pipelined as long as a frame's marks are never seen by the next one (every frame bumps the set offset): what is left
     // of the dependence between frames — the zero-initialised slot — is carried by the commit events.
     if (c->exact_early_out && (!c->eo_device || c->cfg.clear_checks_every_n_frames > 1)) c->cfg.pipeline_frames = 0;
+    if (const char* sf = getenv("KS_EXACT_SEED_FULL")) c->eo_seed_full = atoi(sf) != 0;   // tests: the full-ray seed from the first frame on
     const bool wide_rays = steps_max_of(c->cfg, (float)(1.0 / cfg->voxel_size)) > 400;
     c->eo_bulk_rounds = wide_rays ? 32 : 14;
     if (const char* br = getenv("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
