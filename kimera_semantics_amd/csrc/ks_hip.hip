@@ -259,11 +259,10 @@ struct ks_ctx {
   std::atomic<size_t> eo_want_marks{0}, eo_want_x{0};   // capacities a failed frame asked for (grown by the caller's thread between frames)
   size_t eo_cap_marks = 0, eo_cap_x = 0; // per-slot capacities in use
   uint64_t eo_fallbacks = 0;             // frames that fell back to the host-driven loop
-  // Where the approximate set is overwhelmed (2 cm voxels / 10 m rays: ~30 marks per slot and frame) the reference's early-out
-  // hardly fires and the ordered-phase seed — whose rays stop on their own chain's marks — is too short on most rays: they
-  // would all have to grow through X marks.  Such a context seeds the fix point with the FULL rays instead (k_dedup has left
-  // them in cnt[]: the phases are simply skipped): every step has a mark, nothing grows, rays only ever get shorter.
-  std::atomic<bool> eo_seed_full_want{false};
+  // KS_EXACT_SEED_FULL=1 (experiments): the fix point seeded with the FULL rays (k_dedup has left them in cnt[]: the phases are
+  // simply skipped) — every step has a mark, nothing grows through X marks, rays only ever get shorter.  Exact like any
+  // seed; measured: 5x the marks and more rounds at 640x480 (2.7 vs 0.48 ms/frame), and at 1280x720 / 2 cm / 10 m rays
+  // 2.3e8 marks per frame that still have long dirty lists after 32 rounds — not a way out for that geometry.
   bool eo_seed_full = false;
   std::atomic<int> eo_hopeless{0};       // consecutive frames the device loop gave up on for reasons growing a buffer does not cure
   bool eo_device_off = false;            // ... three of them: the context stays with the host-driven loop (one frame at a time)
@@ -1249,8 +1248,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     const bool x_dense = (hctl.fail & kEoFailX) && (size_t)hctl.n_x > (size_t)hctl.st.n_marks / 8;
     const bool dense = x_dense || (hctl.fail & kEoFailRounds);
     if ((hctl.fail & kEoFailX) && !dense) c->eo_want_x.store(std::max<size_t>(4 * c->eo_cap_x, 4 * (size_t)hctl.n_x), std::memory_order_relaxed);
-    if (x_dense && !c->eo_seed_full) c->eo_seed_full_want.store(true, std::memory_order_relaxed);   // (first: the other seed)
-    else if (dense) c->eo_hopeless.fetch_add(1, std::memory_order_relaxed);
+    if (dense) c->eo_hopeless.fetch_add(1, std::memory_order_relaxed);
     else if (!(hctl.fail & kEoFailChain)) c->eo_hopeless.store(0, std::memory_order_relaxed);
     ++c->eo_fallbacks;
     if (getenv("KS_EXACT_DEBUG"))
@@ -1605,11 +1603,6 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
   if (n > c->cap_points) {  // growing frees buffers a pending tail still needs
     if ((rc = quiesce(c))) return rc;
     if ((rc = ensure_points(c, n))) return rc;
-  }
-  if (c->eo_device && !c->eo_device_off && !c->eo_seed_full && c->eo_seed_full_want.load(std::memory_order_relaxed)) {
-    if ((rc = quiesce(c))) return rc;
-    c->eo_seed_full = true;
-    ++c->buffers_epoch;   // the captured launch sequences hold the phases
   }
   if (c->eo_device && !c->eo_device_off) {
     const size_t wm = c->eo_want_marks.load(std::memory_order_relaxed), wx = c->eo_want_x.load(std::memory_order_relaxed);
