@@ -1,4 +1,6 @@
 """Host-side logic that needs no GPU: colour-map loader quirks, synthetic frame source."""
+import os
+
 import numpy as np
 import pytest
 
@@ -136,3 +138,13 @@ def test_bench_line_is_one_short_parseable_line():
     assert d["full_record"] == "profiles/bench_full_r04.json"
     # degenerate: nothing optional present
     assert json.loads(bench.compact_line({"metric": "m", "value": 1.0}, None))["value"] == 1.0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/kimera_semantics_ros/src"), reason="the reference tree is only in the build container")
+def test_server_patch_applies_and_compiles():
+    """integration/server.patch (on-demand layer sync in the reference's SemanticTsdfServer) applies to the reference's
+    sources and the patched server compiles against the real Kimera-Semantics headers + the adapter's header."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["sh", os.path.join(root, "integration", "check_server_patch.sh"), "/root/reference"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "compiles" in r.stdout, r.stdout + r.stderr
