@@ -1,5 +1,5 @@
 """Work per (chain, sub-run) wavefront of k_test and phase, from the CPU checker (oracle: KO_WAVE_STATS=1 -> stderr):
-    KO_WAVE_STATS=1 [KO_SUB_RUN_GENERATIONS=1] [KO_EXP_SUB_RUN=8] python tools/wave_stats.py
+    KO_WAVE_STATS=1 python tools/wave_stats.py
 profiles/r03_k_test_wavefront_work_cpu_model.txt holds the three schedules DESIGN.md 3.2 compares."""
 import sys
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
