@@ -191,18 +191,24 @@ def test_full_size_c4_default_early_out_exact():
         assert a.tobytes() == b.tobytes()
 
 
-def test_observed_set_tag_wrap():
+@pytest.mark.parametrize("pipe,growth", [(1, 32), (8, 32), (8, 0)])
+def test_observed_set_tag_wrap(pipe, growth):
     """The early-out set's entries carry a 10-bit frame tag; every ~1000 frames the stale entries are retired
-    and the tags restart.  1100 small frames stay bit-exact against the oracle."""
-    okw = dict(COMMON, method=0, early_out_phase_growth=32)
-    o = O.Oracle(O.default_config(**okw))
-    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 12, pipeline_frames=1, **okw))
+    and the tags restart.  1100 small frames stay bit-exact against the oracle — also with batches of four frames per
+    launch (pipeline_frames = 8) whose alignment a query in mid-stream has shifted, so that frames are waiting for their
+    batch to fill when the retag comes: they go out with their OLD tag before the tables are rewritten (reset_set);
+    and in the default mode (growth 0), whose seed runs on the same tables."""
+    okw = dict(COMMON, method=0, early_out_phase_growth=growth)
+    o = O.Oracle(O.default_config(integrator_threads=1, **okw))
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 12, pipeline_frames=pipe, **okw))
     sc = synth.make_scene("room")
     frames = [synth.render_frame(sc, synth.trajectory_pose(k), 48, 36, seed=k) for k in range(8)]
     for k in range(1100):
         f = frames[k % 8]
         o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
         h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        if pipe > 1 and k in (5, 1001, 1015):
+            h.block_indices()   # (completes the frames in flight: the next batch starts off the multiple of four)
     h.flush()
     compare_maps(o, h, exact=True)
 

@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_r04
 rm -rf $O; mkdir -p $O
 cd $R
-timeout 600 python -m pytest tests/test_parity_gpu.py tests/test_exact_early_out_gpu.py tests/test_host_adapter_gpu.py -m gpu -q -x -k "benched or falls_back or default_configuration or real_factory_default" 2>&1 | tail -4
+timeout 600 python -m pytest tests/test_parity_gpu.py tests/test_exact_early_out_gpu.py tests/test_host_adapter_gpu.py -m gpu -q -k "benched or falls_back or default_configuration or real_factory_default or tag_wrap" 2>&1 | tail -6
 timeout 700 python bench.py > $O/bench_line.json 2> $O/bench.err
 tail -c 600 $O/bench.err | grep -v amdgpu.ids
 wc -c $O/bench_line.json; cat $O/bench_line.json
