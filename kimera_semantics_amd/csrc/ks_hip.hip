@@ -2096,7 +2096,9 @@ int ks_integrate_points(ks_ctx* c, const float T[7], const float* xyz, const uin
   return integrate_device(c, T, c->d_xyz, rgba ? c->d_rgba : nullptr, labels ? c->d_labels : nullptr, n, freespace, stats);
 }
 
-static int integrate_depth_impl(ks_ctx* c, const float T[7], DepthParams D, int freespace, ks_frame_stats* stats) {
+// n_known: the number of valid pixels if the caller has counted them (the host-pointer entry: the image is in host memory
+// anyway), else -1: the compacted count is read back from the device before the frame is enqueued.
+static int integrate_depth_impl(ks_ctx* c, const float T[7], DepthParams D, int freespace, ks_frame_stats* stats, long long n_known = -1) {
   const size_t n_px = (size_t)D.width * D.height;
   int rc;
   if (n_px > c->cap_points && (rc = quiesce(c))) return rc;  // growing frees buffers a pending tail still needs
@@ -2113,8 +2115,12 @@ static int integrate_depth_impl(ks_ctx* c, const float T[7], DepthParams D, int 
   hipLaunchKernelGGL(k_depth_compact, dim3(nb), dim3(1024), 0, st, D, (uint32_t)n_px, c->d_depth_blocks, c->d_label_lut,
                      c->d_xyz, c->d_rgba, c->d_labels);
   uint32_t n = 0;
-  HIPCHK(c, hipMemcpyAsync(&n, c->d_depth_blocks + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipStreamSynchronize(st));
+  if (n_known >= 0) {
+    n = (uint32_t)n_known;   // (the integration order and the sort-key layout depend on n: the host needs it to enqueue the frame)
+  } else {
+    HIPCHK(c, hipMemcpyAsync(&n, c->d_depth_blocks + nb, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+  }
   if (!have_labels && !(D.rgba_img && c->d_color_lut)) {
     c->err = "ks_integrate_depth: need a label image, or a colour image plus ks_set_color_to_label";
     return KS_ERR_INVALID_ARG;
@@ -2157,7 +2163,17 @@ int ks_integrate_depth(ks_ctx* c, const float T[7], const void* depth, int depth
   const double unit = depth_fmt == 0 ? 1.0 : 0.001;
   D.constant_x = (float)(unit / (double)K[0]);
   D.constant_y = (float)(unit / (double)K[1]);
-  return integrate_depth_impl(c, T, D, freespace, stats);
+  // the valid pixels (ks_k_io.h: depth_pixel — finite f32 / non-zero u16), counted here while the copies are in flight: no
+  // read-back of the compacted count, no host wait before the frame is enqueued
+  long long n_valid = 0;
+  if (depth_fmt == 0) {
+    const float* d = (const float*)depth;
+    for (size_t i = 0; i < n_px; ++i) n_valid += std::isfinite(d[i]) ? 1 : 0;
+  } else {
+    const uint16_t* d = (const uint16_t*)depth;
+    for (size_t i = 0; i < n_px; ++i) n_valid += d[i] != 0 ? 1 : 0;
+  }
+  return integrate_depth_impl(c, T, D, freespace, stats, n_valid);
 }
 
 int ks_integrate_depth_device(ks_ctx* c, const float T[7], const void* d_depth, int depth_fmt, const uint8_t* d_label_img,
