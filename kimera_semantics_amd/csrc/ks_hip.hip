@@ -138,6 +138,7 @@ struct FrameSlot {
   hipEvent_t ready = nullptr;       // snapshot has landed
   hipEvent_t tail_done = nullptr;   // the tail has consumed this slot's buffers
   hipEvent_t fork = nullptr, join = nullptr;  // tail: pairs sorted and long runs listed | long runs applied
+  hipEvent_t join_x = nullptr;                // the runs of more than kXLongRun updates applied (stream_xlong)
   bool tail_recorded = false;
   bool join_recorded = false;
   bool b_launched = false;    // stage B of the frame has been enqueued (with its batch)
@@ -177,6 +178,8 @@ struct ks_ctx {
   hipStream_t prof_march_stream = nullptr;  // march stream of the frame being enqueued (stage events)
   hipStream_t stream_tail = nullptr;   // stage T; == stream unless pipelined
   hipStream_t stream_long = nullptr;   // the long-run voxel update, beside k_apply (always its own stream)
+  hipStream_t stream_xlong = nullptr;  // the runs of more than kXLongRun updates, beside both (xlong_pf != 0)
+  int xlong_pf = 0;                    // batches of ray descriptors their kernel keeps in flight (0: no separate list)
   float voxel_size_inv = 0.f, log_match = 0.f, log_non_match = 0.f;
   int vps_shift = 1;  // log2(vps / 8)
 
@@ -511,10 +514,12 @@ int ensure_pairs_out(ks_ctx* c, size_t n) {
   const size_t cap = std::max<size_t>(n + n / 4, 1 << 20);
   int rc;
   if (c->stream_long) HIPCHK(c, hipStreamSynchronize(c->stream_long));  // long runs of the previous frame may still read them
+  if (c->stream_xlong) HIPCHK(c, hipStreamSynchronize(c->stream_xlong));
   if (c->stream_tail) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
   for (int b = 0; b < 2; ++b) {
     if ((rc = dev_alloc(c, &c->d_pairs2_[b], cap))) return rc;
-    if ((rc = dev_alloc(c, &c->d_long_list_[b], cap / kLongRun + 64))) return rc;
+    // heads of the long runs, then (from cap / kLongRun + 64 on) the heads of the runs of more than kXLongRun updates
+    if ((rc = dev_alloc(c, &c->d_long_list_[b], cap / kLongRun + 64 + cap / kXLongRun + 64))) return rc;
   }
   c->cap_pairs = cap;
   return KS_OK;
@@ -1356,16 +1361,20 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     if (time_apply) c->pset[set].applied = true;
     // long runs (voxels next to the sensor) are listed first; then the two update kernels run side by side:
     // k_apply on the tail stream, k_apply_long on its own stream (disjoint voxels)
-    hipLaunchKernelGGL(k_find_long, dim3((uint32_t)((n_pairs + 256 * kFindLongItems - 1) / (256 * kFindLongItems))), dim3(256), 0, st,
-                       F.seq_bits, n_pairs, (const uint64_t*)sp, d_long_list,
-                       S.d_counters);
     hipStream_t sl = c->stream_long ? c->stream_long : st;
+    hipStream_t sx = (sl != st && c->stream_xlong) ? c->stream_xlong : nullptr;
+    unsigned long long* const d_xlong_list = sx ? d_long_list + (c->cap_pairs / kLongRun + 64) : nullptr;
+    hipLaunchKernelGGL(k_find_long, dim3((uint32_t)((n_pairs + 256 * kFindLongItems - 1) / (256 * kFindLongItems))), dim3(256), 0, st,
+                       F.seq_bits, n_pairs, (const uint64_t*)sp, d_long_list, d_xlong_list,
+                       S.d_counters);
+    const uint32_t xb = (uint32_t)std::min<unsigned long long>(n_pairs / kXLongRun + 1, 512);
     if (sl != st) {
       // the previous frame's long runs end before any voxel of this frame is touched
       if (c->pending_join) HIPCHK(c, hipStreamWaitEvent(st, c->pending_join, 0));
       c->pending_join = nullptr;
       HIPCHK(c, hipEventRecord(S.fork, st));
       HIPCHK(c, hipStreamWaitEvent(sl, S.fork, 0));
+      if (sx) HIPCHK(c, hipStreamWaitEvent(sx, S.fork, 0));
     }
 #define KS_LAUNCH_APPLY_M(MODE, MERGED)                                                                              \
   if (time_apply)                                                                                                    \
@@ -1382,7 +1391,13 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     KS_LAUNCH_APPLY_M(MODE, false);                                                                                  \
   }                                                                                                                  \
   stage_mark(c, set, 9);                                                                                             \
-  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(128), 0, sl, F, n_pairs, sp, S.d_rays, S.d_deltas,             \
+  if (sx && c->xlong_pf >= 16)                                                                                       \
+    hipLaunchKernelGGL((k_apply_long<MODE, 16, true>), dim3(xb), dim3(128), 0, sx, F, n_pairs, sp, S.d_rays, S.d_deltas, \
+                       c->table, c->pool, c->d_label_lut, d_xlong_list, S.d_counters);                                 \
+  else if (sx)                                                                                                       \
+    hipLaunchKernelGGL((k_apply_long<MODE, 8, true>), dim3(xb), dim3(128), 0, sx, F, n_pairs, sp, S.d_rays, S.d_deltas,  \
+                       c->table, c->pool, c->d_label_lut, d_xlong_list, S.d_counters);                                 \
+  hipLaunchKernelGGL((k_apply_long<MODE, 4, false>), dim3(lb), dim3(128), 0, sl, F, n_pairs, sp, S.d_rays, S.d_deltas,  \
                      c->table, c->pool, c->d_label_lut, d_long_list, S.d_counters)
     switch (c->cfg.color_mode) {
       case KS_COLOR_MODE_COLOR: KS_LAUNCH_APPLY(KS_COLOR_MODE_COLOR); break;
@@ -1392,6 +1407,10 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
 #undef KS_LAUNCH_APPLY
 #undef KS_LAUNCH_APPLY_M
     if (sl != st) {
+      if (sx) {  // S.join stands for both lists
+        HIPCHK(c, hipEventRecord(S.join_x, sx));
+        HIPCHK(c, hipStreamWaitEvent(sl, S.join_x, 0));
+      }
       HIPCHK(c, hipEventRecord(S.join, sl));
       S.join_recorded = true;
       // deferred: the tail stream goes on with the next frame's tile initialisation, pair sort and long-run
@@ -1902,6 +1921,11 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     const char* nl = getenv("KS_NO_LONG_STREAM");   // diagnostics: long runs on the tail stream, after k_apply
     if (nl && nl[0] == '1') c->stream_long = nullptr;
     else CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
+    // KS_XLONG_PF = 8 | 16: the runs of more than kXLongRun updates (the voxels next to the sensor) on a stream of their own,
+    // walked with that many batches of ray descriptors in flight.  Same arithmetic, same order: the map does not change.
+    const char* xp = getenv("KS_XLONG_PF");
+    c->xlong_pf = xp ? atoi(xp) : 0;
+    if (c->xlong_pf && c->stream_long) CRCHK(hipStreamCreateWithFlags(&c->stream_xlong, hipStreamNonBlocking));
   }
   for (auto& P : c->pset) {
     for (auto& e : P.ev) CRCHK(hipEventCreate(&e));
@@ -1960,6 +1984,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     CRCHK(hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&S.join_x, hipEventDisableTiming));
   }
 #undef CRCHK
   // pair buffers start at 4 updates per point of the largest cloud (a frame that needs more grows its buffer and
@@ -2033,6 +2058,7 @@ void ks_destroy(ks_ctx* c) {
     if (S.tail_done) (void)hipEventDestroy(S.tail_done);
     if (S.fork) (void)hipEventDestroy(S.fork);
     if (S.join) (void)hipEventDestroy(S.join);
+    if (S.join_x) (void)hipEventDestroy(S.join_x);
     if (S.a_done) (void)hipEventDestroy(S.a_done);
   }
   for (auto& P : c->pset) {
@@ -2045,6 +2071,7 @@ void ks_destroy(ks_ctx* c) {
   for (auto sm : c->stream_march_)
     if (sm && sm != c->stream) (void)hipStreamDestroy(sm);
   if (c->stream_long) (void)hipStreamDestroy(c->stream_long);
+  if (c->stream_xlong) (void)hipStreamDestroy(c->stream_xlong);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

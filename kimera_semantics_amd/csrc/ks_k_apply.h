@@ -277,16 +277,23 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
 }
 
 // Heads of runs of >= kLongRun updates, found before either apply kernel runs: k_apply (short runs) and
-// k_apply_long (long runs) touch disjoint voxels and are launched side by side on two streams.
+// k_apply_long (long runs) touch disjoint voxels and are launched side by side on two streams.  Runs of more than
+// kXLongRun updates go to a list of their own when the caller passes one (xlong_list != nullptr): the handful of voxels
+// next to the sensor, whose single chains of 1e4 .. 1e5 updates bound the frame's update stage.
 constexpr uint32_t kFindLongItems = 8;  // pairs per thread
 __global__ void __launch_bounds__(256) k_find_long(uint32_t seq_bits, unsigned long long n_pairs,
                                                    const uint64_t* __restrict__ pairs,
-                                                   unsigned long long* __restrict__ long_list, Counters* C) {
+                                                   unsigned long long* __restrict__ long_list,
+                                                   unsigned long long* __restrict__ xlong_list, Counters* C) {
   // heads of long runs are more than kLongRun apart: at most 2048 / 33 + 1 of them per workgroup
   __shared__ unsigned long long s_list[2048 / kLongRun + 2];
-  __shared__ uint32_t s_n, s_base;
+  __shared__ unsigned long long s_xlist[2048 / kXLongRun + 2];
+  __shared__ uint32_t s_n, s_base, s_xn, s_xbase;
   static_assert(kLongRun >= 32, "s_list size");
-  if (threadIdx.x == 0) s_n = 0u;
+  if (threadIdx.x == 0) {
+    s_n = 0u;
+    s_xn = 0u;
+  }
   __syncthreads();
   const unsigned long long base = (unsigned long long)blockIdx.x * (256ull * kFindLongItems);
 #pragma unroll
@@ -295,19 +302,29 @@ __global__ void __launch_bounds__(256) k_find_long(uint32_t seq_bits, unsigned l
     if (i < n_pairs) {
       const uint32_t vox = (uint32_t)(pairs[i] >> seq_bits);
       const bool head = (i == 0) || ((uint32_t)(pairs[i - 1] >> seq_bits) != vox);
-      if (head && (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> seq_bits) == vox))
-        s_list[atomicAdd(&s_n, 1u)] = i;
+      if (head && (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> seq_bits) == vox)) {
+        const bool xl = xlong_list != nullptr && (i + kXLongRun < n_pairs) && ((uint32_t)(pairs[i + kXLongRun] >> seq_bits) == vox);
+        if (xl) s_xlist[atomicAdd(&s_xn, 1u)] = i;
+        else s_list[atomicAdd(&s_n, 1u)] = i;
+      }
     }
   }
   __syncthreads();
-  const uint32_t n_l = s_n;
-  if (n_l == 0u) return;
-  if (threadIdx.x == 0) s_base = atomicAdd(&C->n_long, n_l);
+  const uint32_t n_l = s_n, n_x = s_xn;
+  if (n_l == 0u && n_x == 0u) return;
+  if (threadIdx.x == 0) {
+    if (n_l) s_base = atomicAdd(&C->n_long, n_l);
+    if (n_x) s_xbase = atomicAdd(&C->n_xlong, n_x);
+  }
   __syncthreads();
   if (threadIdx.x < n_l) long_list[s_base + threadIdx.x] = s_list[threadIdx.x];
+  if (threadIdx.x < n_x) xlong_list[s_xbase + threadIdx.x] = s_xlist[threadIdx.x];
 }
 
-template <int COLOR_MODE>
+// PF: batches (of 64 updates) whose ray descriptors are in flight while one batch is applied.  XLONG selects the list
+// (and its counter): the runs of more than kXLongRun updates are walked by a second instance with a deeper pipeline, on a
+// stream of its own.
+template <int COLOR_MODE, int PF, bool XLONG>
 __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long long n_pairs,
                                                    const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
                                                    const float* __restrict__ deltas, TileTable T, Pool P,
@@ -323,7 +340,7 @@ __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long
   __shared__ int s_cnt[2];                    // updates in the batch (0: the run has ended)
   __shared__ uint32_t s_best;
   __shared__ float s_best_val;
-  const uint32_t n_long = C->n_long;
+  const uint32_t n_long = XLONG ? C->n_xlong : C->n_long;
   const int lane = (int)lane_id();
   const bool consumer = (threadIdx.x >> 6) != 0u;
   const int cls = lane < kNumLabels ? lane : 0;
@@ -379,33 +396,33 @@ __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long
                   ((float)v.vz + 0.5f) * Pm.voxel_size};
     const f3 v_voxel_origin = sub3(c, F.T.t);
 
-    // software pipeline: the ray descriptors of the next kPf batches and the pair keys of the one after them are in
+    // software pipeline: the ray descriptors of the next PF batches and the pair keys of the PF after them are in
     // flight while batch b is applied (a batch is applied in well under the latency of its random 32-byte gathers:
     // with one batch of look-ahead the voxel next to the sensor — one run of ~1e4 .. 1e5 updates — ran at memory
     // latency per 64 updates).  All loads of the pipeline are UNCONDITIONAL (indices clamped): a load under a
-    // divergent branch makes the compiler drain vmcnt at the join, which serialises the prefetch.
-    constexpr int kPf = 4;
+    // divergent branch makes the compiler drain vmcnt at the join, which serialises the prefetch.  The queue is a
+    // ring with compile-time slot numbers (the batch loop is unrolled PF times): nothing moves between registers.
     const unsigned long long last = n_pairs - 1ull;
     unsigned long long base = start;
-    uint64_t key_q[kPf + 1];  // key_q[i]: batch b + i
-    RayDesc d_q[kPf];
+    uint64_t key_q[PF], key_n[PF];  // key_q[j]: the batch in slot j; key_n[j]: the batch PF after it
+    RayDesc d_q[PF];
 #pragma unroll
-    for (int i = 0; i <= kPf; ++i) key_q[i] = pairs[min(base + 64ull * i + lane, last)];
+    for (int i = 0; i < PF; ++i) {
+      key_q[i] = pairs[min(base + 64ull * i + lane, last)];
+      key_n[i] = pairs[min(base + 64ull * (PF + i) + lane, last)];
+    }
 #pragma unroll
-    for (int i = 0; i < kPf; ++i) d_q[i] = rays[ray_index(F, (uint32_t)key_q[i] & F.point_mask)];
-    for (;;) {
-      const uint64_t key_cur = key_q[0];
-      const RayDesc d = d_q[0];
+    for (int i = 0; i < PF; ++i) d_q[i] = rays[ray_index(F, (uint32_t)key_q[i] & F.point_mask)];
+
+    // one batch; returns false when the run has ended
+    auto batch = [&](const uint64_t key_cur, const RayDesc& d) -> bool {
       const bool in = (base + lane < n_pairs) && ((uint32_t)(key_cur >> F.seq_bits) == vox);
       const int cnt = (int)__popcll(__ballot(in));  // sorted => the in-lanes form a prefix
       if (cnt == 0) {
         if (lane == 0) s_cnt[buf] = 0;
         __syncthreads();
-        break;
+        return false;
       }
-      const RayDesc d_new = rays[ray_index(F, (uint32_t)key_q[kPf] & F.point_mask)];     // batch b + kPf
-      const uint64_t key_new = pairs[min(base + 64ull * (kPf + 1) + lane, last)];      // batch b + kPf + 1
-
       // ---- per-lane, voxel-state-independent part: computeDistance + weight drop-off ----
       float sdf = 0.f, uw = 0.f;
       if (in) {
@@ -480,14 +497,22 @@ __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long
       if (lane == 0) s_cnt[buf] = cnt;
       __syncthreads();
       buf ^= 1;
-      if (cnt < 64) break;
+      return cnt == 64;
+    };
+    for (bool more = true; more;) {
 #pragma unroll
-      for (int i = 0; i + 1 < kPf; ++i) d_q[i] = d_q[i + 1];
-      d_q[kPf - 1] = d_new;
-#pragma unroll
-      for (int i = 0; i < kPf; ++i) key_q[i] = key_q[i + 1];
-      key_q[kPf] = key_new;
-      base += 64;
+      for (int j = 0; j < PF; ++j) {
+        const uint64_t key_cur = key_q[j];
+        const RayDesc d = d_q[j];
+        // slot j takes the batch PF after the one it held: its keys arrived a ring ago, its descriptors are requested
+        // now, and the keys of the batch after that one follow
+        key_q[j] = key_n[j];
+        d_q[j] = rays[ray_index(F, (uint32_t)key_n[j] & F.point_mask)];
+        key_n[j] = pairs[min(base + 64ull * (2 * PF) + lane, last)];
+        more = batch(key_cur, d);
+        if (!more) break;
+        base += 64;
+      }
     }
     __syncthreads();  // the consumer has the label
     const uint32_t best = s_best;

@@ -27,13 +27,14 @@ struct Counters {
   unsigned long long n_pairs;
   uint32_t n_valid;
   uint32_t n_rays;
-  uint32_t pad0;
+  uint32_t n_xlong;   // of them, runs of more than kXLongRun updates (listed apart: their kernel looks further ahead)
   uint32_t err;
   uint32_t n_long;    // voxel runs handed to the wave-per-run apply kernel
   uint32_t n_long_bundles;
 };
 
 constexpr uint32_t kLongRun = 32;        // runs of >= kLongRun updates get a whole wavefront
+constexpr uint32_t kXLongRun = 1024;     // runs of more than this many updates: the voxels next to the sensor (one chain of 1e4..1e5 updates)
 constexpr uint32_t kInvalidSlot = 1u << kSetBits;  // sort key of dropped points (sorts last)
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }

@@ -233,6 +233,25 @@ def test_close_up_long_runs_exact(method, color_mode):
         compare_maps(o, h, exact=True)
 
 
+@pytest.mark.parametrize("pf", [8, 16])
+@pytest.mark.parametrize("method,color_mode,pipe", [(1, 1, 0), (1, 0, 4), (0, 1, 8)])
+def test_runs_next_to_the_sensor_on_their_own_list_exact(monkeypatch, method, color_mode, pipe, pf):
+    """KS_XLONG_PF: the runs of more than 1024 updates (the voxels next to the sensor: every ray of `merged` starts there)
+    are listed apart and walked by the k_apply_long instance that keeps 8 / 16 batches of ray descriptors in flight, on a
+    stream of its own.  Same arithmetic in the same order: the map is the oracle's bit for bit, over frames that share voxels."""
+    monkeypatch.setenv("KS_XLONG_PF", str(pf))
+    sc = synth.make_scene("room")
+    okw = dict(COMMON, method=method, max_consecutive_ray_collisions=NO_EARLY_OUT, color_mode=color_mode)
+    o = O.Oracle(O.default_config(integrator_threads=1, **okw))
+    h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=320 * 240, pipeline_frames=pipe, **okw))
+    for k, T in enumerate((synth.pose_to_T((3.5, 0.3, 1.2), 0.1), synth.trajectory_pose(1), synth.trajectory_pose(1), synth.trajectory_pose(2))):
+        f = synth.render_frame(sc, T, 320, 240, seed=k)
+        o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    h.flush()
+    compare_maps(o, h, exact=True)
+
+
 @pytest.mark.parametrize("method", [0, 1])
 def test_sorted_integration_order_exact(method):
     f = small_frame(seed=5, w=96, h=72)
