@@ -301,6 +301,15 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
   if (work) ray_list[pos] = first_p;
 }
 
+// One wavefront per long bundle (>= kLongRun points in one voxel: thousands when a wall is close).  The merge is the
+// reference's serial recurrence [K:src/semantic_tsdf_integrator_merged.cpp:231-262 via voxblox's weighted mean]:
+//     den = w + pw;  mean = (mean * w + p * pw) / den;  w = den           (per point, in input order, f32, no FMA)
+// and what bounds the kernel is the number of instructions the ONE wave issues per point, so per 64-point batch:
+//   pass 1  the weight recurrence runs through the lanes: 63 DPP adds (lane k takes lane k-1's sum), after which lane k
+//           holds the weight before and after its point; one reciprocal per lane, off the chain;
+//   pass 2  lanes 0/1/2 walk the x/y/z chains: the operands of point k come from an LDS table the 64 lanes wrote
+//           side by side (one 16-byte broadcast read + one 4-byte read per point, requested eight points ahead):
+//           five dependent operations per point (multiply, add, and the three of the division by a known reciprocal).
 __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64_t* __restrict__ skeys,
                                                      const uint32_t* __restrict__ svals,
                                                      const float4* __restrict__ g_pw, const uint2* __restrict__ g_lc,
@@ -309,8 +318,12 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
                                                      const uint32_t* __restrict__ long_list,
                                                      uint64_t* __restrict__ ray_keys, uint32_t* __restrict__ cnt,
                                                      BoCtx X, bool use_rank, Counters* C) {
+  __shared__ float4 s_w[64];  // per point of the batch: weight before it, weight after it, reciprocal of that, its own weight
+  __shared__ float4 s_a[64];  // x * w, y * w, z * w, colour
   const uint32_t n_long = C->n_long_bundles;
   const int lane = (int)lane_id();
+  const int comp = lane < 3 ? lane : 0;
+  const bool colour = F.color_mode == KS_COLOR_MODE_COLOR;
   for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
     const uint32_t start = long_list[run];
     const uint64_t key = skeys[start];
@@ -327,8 +340,8 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
     float4 q = in ? g_pw[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     uint2 lc = in ? g_lc[j] : make_uint2(0u, 0u);
     while (!done) {
-      const int cnt = (int)__popcll(__ballot(in));
-      if (cnt == 0) break;
+      const int n_in = (int)__popcll(__ballot(in));
+      if (n_in == 0) break;
       const uint32_t jn = base + 64u + (uint32_t)lane;
       const bool in_n = (jn < F.n) && (skeys[jn] == key);
       const float4 q_n = in_n ? g_pw[jn] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -341,34 +354,66 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
         done = true;
       }
       const bool use = valid && ((vmask >> lane) & 1ull);
-      // pass 1: weight recurrence; lane k keeps (weight before, denominator)
-      float my_mw = 0.0f, my_den = 1.0f;
-      for (unsigned long long m = vmask; m; m &= m - 1ull) {
-        const int k = __ffsll((long long)m) - 1;
-        const float den = mw + bcast_f(q.w, k);
-        if (lane == k) { my_mw = mw; my_den = den; }
-        mw = den;
+      // pass 1: s_k = s_(k-1) + pw_k in lane order (a point that is not used adds +0: the sum stays what it was, bit for bit)
+      const float pw = use ? q.w : 0.0f;
+      const float step = (lane == 0) ? 0.0f : pw;
+      float s = (lane == 0) ? mw + pw : pw;
+#pragma unroll
+      for (int t = 0; t < 63; ++t) s = step + lane_below_f(s, s);
+      const float before = lane_below_f(s, mw);
+      mw = bcast_f(s, 63);
+      s_w[lane] = make_float4(before, s, 1.0f / s, q.w);
+      s_a[lane] = make_float4(q.x * q.w, q.y * q.w, q.z * q.w, __uint_as_float(lc.y));
+      KS_WAVE_LDS_ORDER();
+      // pass 2: the weighted-mean recurrence, lanes 0,1,2 one component each
+      auto point = [&](const float4 w, const float a, const float4 ac) {
+        mpc = div_by_recip(mpc * w.x + a, w.y, w.z);
+        if (colour) merged_color = blend_two_colors(merged_color, w.x, __float_as_uint(ac.w), w.w);
+      };
+      const unsigned long long full = (n_in == 64) ? ~0ull : ((1ull << n_in) - 1ull);
+      if (n_in == 64 && vmask == full && !colour) {
+        // the common batch: every point used.  Operands of the next eight points are requested while eight are applied.
+        float4 w0[8], w1[8];
+        float a0[8], a1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          w0[i] = s_w[i];
+          a0[i] = ((const float*)&s_a[i])[comp];
+        }
+#pragma unroll
+        for (int g = 0; g < 8; g += 2) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            w1[i] = s_w[8 * (g + 1) + i];
+            a1[i] = ((const float*)&s_a[8 * (g + 1) + i])[comp];
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) mpc = div_by_recip(mpc * w0[i].x + a0[i], w0[i].y, w0[i].z);
+          if (g + 2 < 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              w0[i] = s_w[8 * (g + 2) + i];
+              a0[i] = ((const float*)&s_a[8 * (g + 2) + i])[comp];
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) mpc = div_by_recip(mpc * w1[i].x + a1[i], w1[i].y, w1[i].z);
+        }
+      } else {
+        for (unsigned long long m = vmask; m; m &= m - 1ull) {
+          const int k = __ffsll((long long)m) - 1;
+          const float4 ac = s_a[k];
+          point(s_w[k], (lane == 0) ? ac.x : (lane == 1) ? ac.y : ac.z, ac);
+        }
       }
-      const float my_r = 1.0f / my_den;
-      const float ax = q.x * q.w, ay = q.y * q.w, az = q.z * q.w;
-      // pass 2: weighted-mean recurrence; lanes 0,1,2 each walk ONE component chain (x, y, z),
-      // so a step is one multiply-add + one reciprocal-based division for the whole wave
-      for (unsigned long long m = vmask; m; m &= m - 1ull) {
-        const int k = __ffsll((long long)m) - 1;
-        const float mw_k = bcast_f(my_mw, k), den_k = bcast_f(my_den, k), r_k = bcast_f(my_r, k);
-        const float ax_k = bcast_f(ax, k), ay_k = bcast_f(ay, k), az_k = bcast_f(az, k);
-        const float a_k = (lane == 0) ? ax_k : (lane == 1) ? ay_k : az_k;
-        mpc = div_by_recip(mpc * mw_k + a_k, den_k, r_k);
-        if (F.color_mode == KS_COLOR_MODE_COLOR)
-          merged_color = blend_two_colors(merged_color, mw_k, bcast_u(lc.y, k), bcast_f(q.w, k));
-      }
+      KS_WAVE_LDS_ORDER();  // the table is rewritten by the next batch
       // label histogram: counts are order independent and exact in f32
 #pragma unroll
       for (int l = 0; l < kNumLabels; ++l) {
         const unsigned long long lm = __ballot(use && lc.x == (uint32_t)l);
         if (lane == l) freq += (float)__popcll(lm);
       }
-      if (cnt < 64) break;
+      if (n_in < 64) break;
       in = in_n;
       q = q_n;
       lc = lc_n;

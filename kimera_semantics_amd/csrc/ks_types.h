@@ -310,6 +310,14 @@ __device__ __forceinline__ float bcast_f(float x, int k) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), k));
 }
 __device__ __forceinline__ uint32_t bcast_u(uint32_t x, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)x, k); }
+// x of the lane below; lane 0 reads `first`.  One DPP move (wave_shr:1): no LDS, no scalar round trip — the step of a
+// recurrence that runs THROUGH the lanes (lane k's value from lane k-1's).
+#ifndef KS_LANE_BELOW
+#define KS_LANE_BELOW(first_i, x_i) __builtin_amdgcn_update_dpp((first_i), (x_i), 0x138, 0xf, 0xf, false)
+#endif
+__device__ __forceinline__ float lane_below_f(float x, float first) {
+  return __int_as_float(KS_LANE_BELOW(__float_as_int(first), __float_as_int(x)));
+}
 
 // Correctly rounded a / b given r = RN(1/b) (Markstein): q0 = RN(a r); rem = a - q0 b (exact
 // with FMA); q = RN(q0 + rem r).  Outside a comfortable exponent window fall back to the
