@@ -301,47 +301,121 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
   if (work) ray_list[pos] = first_p;
 }
 
-// One wavefront per long bundle (>= kLongRun points in one voxel: thousands when a wall is close).  The merge is the
+// Two wavefronts per long bundle (>= kLongRun points in one voxel: thousands when a wall is close).  The merge is the
 // reference's serial recurrence [K:src/semantic_tsdf_integrator_merged.cpp:231-262 via voxblox's weighted mean]:
 //     den = w + pw;  mean = (mean * w + p * pw) / den;  w = den           (per point, in input order, f32, no FMA)
-// and what bounds the kernel is the number of instructions the ONE wave issues per point, so per 64-point batch:
-//   pass 1  the weight recurrence runs through the lanes: 63 DPP adds (lane k takes lane k-1's sum), after which lane k
-//           holds the weight before and after its point; one reciprocal per lane, off the chain;
-//   pass 2  lanes 0/1/2 walk the x/y/z chains: the operands of point k come from an LDS table the 64 lanes wrote
-//           side by side (one 16-byte broadcast read + one 4-byte read per point, requested eight points ahead):
-//           five dependent operations per point (multiply, add, and the three of the division by a known reciprocal).
-__global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64_t* __restrict__ skeys,
-                                                     const uint32_t* __restrict__ svals,
-                                                     const float4* __restrict__ g_pw, const uint2* __restrict__ g_lc,
-                                                     RayDesc* __restrict__ rays, float* __restrict__ deltas,
-                                                     uint32_t* __restrict__ ray_list,
-                                                     const uint32_t* __restrict__ long_list,
-                                                     uint64_t* __restrict__ ray_keys, uint32_t* __restrict__ cnt,
-                                                     BoCtx X, bool use_rank, Counters* C) {
-  __shared__ float4 s_w[64];  // per point of the batch: weight before it, weight after it, reciprocal of that, its own weight
-  __shared__ float4 s_a[64];  // x * w, y * w, z * w, colour
+// and what bounds the kernel is the number of instructions ONE wave issues per point of the longest bundle, so:
+//   wave 0  per 64-point batch: the weight recurrence runs through the lanes — 63 DPP adds (lane k takes lane k-1's sum),
+//           after which lane k holds the weight before and after its point; one reciprocal per lane; the label histogram;
+//           the operands of the batch go to an LDS table (double-buffered, one workgroup barrier per batch);
+//   wave 1  lanes 0/1/2 walk the x/y/z chains of the PREVIOUS batch at the same time: one 16-byte broadcast read + one
+//           4-byte read per point, requested eight points ahead, then five dependent operations per point (multiply, add,
+//           and the three of the division by a known reciprocal).  The exponent-window test of that division is taken
+//           off the chain: eight points are applied without it, and repeated one by one if any of them fell outside.
+__global__ void __launch_bounds__(128) k_bundles_long(FrameParams F, const uint64_t* __restrict__ skeys,
+                                                      const uint32_t* __restrict__ svals,
+                                                      const float4* __restrict__ g_pw, const uint2* __restrict__ g_lc,
+                                                      RayDesc* __restrict__ rays, float* __restrict__ deltas,
+                                                      uint32_t* __restrict__ ray_list,
+                                                      const uint32_t* __restrict__ long_list,
+                                                      uint64_t* __restrict__ ray_keys, uint32_t* __restrict__ cnt,
+                                                      BoCtx X, bool use_rank, Counters* C) {
+  __shared__ float4 s_w[2][64];  // per point of the batch: weight before it, weight after it, reciprocal of that, its own weight
+  __shared__ float4 s_a[2][64];  // x * w, y * w, z * w, colour
+  __shared__ unsigned long long s_use[2];  // the points of the batch that are merged
+  __shared__ int s_last[2];                // 1: the bundle ends with this batch
+  __shared__ float s_mp[4];                // the merged point (+ the blended colour) back to wave 0
   const uint32_t n_long = C->n_long_bundles;
   const int lane = (int)lane_id();
+  const bool back = (threadIdx.x >> 6) != 0u;
   const int comp = lane < 3 ? lane : 0;
   const bool colour = F.color_mode == KS_COLOR_MODE_COLOR;
   for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
+    if (back) {
+      // ---- wave 1: the weighted-mean recurrence, lanes 0,1,2 one component each ----
+      float mpc = 0.0f;
+      uint32_t merged_color = 0;
+      for (int buf = 0;; buf ^= 1) {
+        __syncthreads();  // batch `buf` is complete
+        const unsigned long long vmask = s_use[buf];
+        const int last = s_last[buf];
+        const float4* tw = s_w[buf];
+        const float4* ta = s_a[buf];
+        if (vmask == ~0ull && !colour) {
+          // the common batch: every point used.  Operands of the next eight points are requested while eight are applied.
+          float4 w0[8], w1[8];
+          float a0[8], a1[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            w0[i] = tw[i];
+            a0[i] = ((const float*)&ta[i])[comp];
+          }
+          auto eight = [&](const float4 (&w)[8], const float (&a)[8]) {
+            const float at_start = mpc;
+            bool in_window = true;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float num = mpc * w[i].x + a[i];
+              const float an = fabsf(num);
+              in_window = in_window && (an >= 1e-20f) && (an <= 1e20f);
+              const float q0 = num * w[i].z;
+              const float rem = __builtin_fmaf(-q0, w[i].y, num);
+              mpc = __builtin_fmaf(rem, w[i].z, q0);
+            }
+            if (__ballot(!in_window) != 0ull) {  // (a coordinate that is exactly 0, ...): one by one, with the test
+              mpc = at_start;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) mpc = div_by_recip(mpc * w[i].x + a[i], w[i].y, w[i].z);
+            }
+          };
+#pragma unroll
+          for (int g = 0; g < 8; g += 2) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              w1[i] = tw[8 * (g + 1) + i];
+              a1[i] = ((const float*)&ta[8 * (g + 1) + i])[comp];
+            }
+            eight(w0, a0);
+            if (g + 2 < 8) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                w0[i] = tw[8 * (g + 2) + i];
+                a0[i] = ((const float*)&ta[8 * (g + 2) + i])[comp];
+              }
+            }
+            eight(w1, a1);
+          }
+        } else {
+          for (unsigned long long m = vmask; m; m &= m - 1ull) {
+            const int k = __ffsll((long long)m) - 1;
+            const float4 w = tw[k], ac = ta[k];
+            mpc = div_by_recip(mpc * w.x + ((lane == 0) ? ac.x : (lane == 1) ? ac.y : ac.z), w.y, w.z);
+            if (colour) merged_color = blend_two_colors(merged_color, w.x, __float_as_uint(ac.w), w.w);
+          }
+        }
+        if (last) break;
+      }
+      if (lane < 3) s_mp[lane] = mpc;
+      if (lane == 3) s_mp[3] = __uint_as_float(merged_color);
+      __syncthreads();  // the merged point for wave 0
+      __syncthreads();  // LDS free for the next bundle
+      continue;
+    }
+    // ---- wave 0: everything else ----
     const uint32_t start = long_list[run];
     const uint64_t key = skeys[start];
     const bool clearing = (key >> 63) != 0;
-    float mpc = 0.0f;  // lane 0/1/2: x/y/z of the running weighted mean
     float mw = 0.0f;
-    uint32_t merged_color = 0;
     float freq = 0.0f;  // lane l < 21 counts label l
-    bool done = false;
     uint32_t base = start;
+    int buf = 0;
     // prefetch one batch ahead (contiguous, coalesced)
     uint32_t j = base + (uint32_t)lane;
     bool in = (j < F.n) && (skeys[j] == key);
     float4 q = in ? g_pw[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     uint2 lc = in ? g_lc[j] : make_uint2(0u, 0u);
-    while (!done) {
-      const int n_in = (int)__popcll(__ballot(in));
-      if (n_in == 0) break;
+    for (;;) {
+      const int n_in = (int)__popcll(__ballot(in));  // >= 1 in the first batch (a long bundle has >= kLongRun points)
       const uint32_t jn = base + 64u + (uint32_t)lane;
       const bool in_n = (jn < F.n) && (skeys[jn] == key);
       const float4 q_n = in_n ? g_pw[jn] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -349,12 +423,13 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
 
       const bool valid = in && !(q.w < kEps);
       unsigned long long vmask = __ballot(valid);
+      bool last = n_in < 64;
       if (clearing && vmask) {  // only the first usable point of a clearing bundle is integrated
         vmask &= (~vmask + 1ull);
-        done = true;
+        last = true;
       }
       const bool use = valid && ((vmask >> lane) & 1ull);
-      // pass 1: s_k = s_(k-1) + pw_k in lane order (a point that is not used adds +0: the sum stays what it was, bit for bit)
+      // s_k = s_(k-1) + pw_k in lane order (a point that is not used adds +0: the sum stays what it was, bit for bit)
       const float pw = use ? q.w : 0.0f;
       const float step = (lane == 0) ? 0.0f : pw;
       float s = (lane == 0) ? mw + pw : pw;
@@ -362,64 +437,37 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
       for (int t = 0; t < 63; ++t) s = step + lane_below_f(s, s);
       const float before = lane_below_f(s, mw);
       mw = bcast_f(s, 63);
-      s_w[lane] = make_float4(before, s, 1.0f / s, q.w);
-      s_a[lane] = make_float4(q.x * q.w, q.y * q.w, q.z * q.w, __uint_as_float(lc.y));
-      KS_WAVE_LDS_ORDER();
-      // pass 2: the weighted-mean recurrence, lanes 0,1,2 one component each
-      auto point = [&](const float4 w, const float a, const float4 ac) {
-        mpc = div_by_recip(mpc * w.x + a, w.y, w.z);
-        if (colour) merged_color = blend_two_colors(merged_color, w.x, __float_as_uint(ac.w), w.w);
-      };
-      const unsigned long long full = (n_in == 64) ? ~0ull : ((1ull << n_in) - 1ull);
-      if (n_in == 64 && vmask == full && !colour) {
-        // the common batch: every point used.  Operands of the next eight points are requested while eight are applied.
-        float4 w0[8], w1[8];
-        float a0[8], a1[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          w0[i] = s_w[i];
-          a0[i] = ((const float*)&s_a[i])[comp];
-        }
-#pragma unroll
-        for (int g = 0; g < 8; g += 2) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            w1[i] = s_w[8 * (g + 1) + i];
-            a1[i] = ((const float*)&s_a[8 * (g + 1) + i])[comp];
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i) mpc = div_by_recip(mpc * w0[i].x + a0[i], w0[i].y, w0[i].z);
-          if (g + 2 < 8) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              w0[i] = s_w[8 * (g + 2) + i];
-              a0[i] = ((const float*)&s_a[8 * (g + 2) + i])[comp];
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 8; ++i) mpc = div_by_recip(mpc * w1[i].x + a1[i], w1[i].y, w1[i].z);
-        }
-      } else {
-        for (unsigned long long m = vmask; m; m &= m - 1ull) {
-          const int k = __ffsll((long long)m) - 1;
-          const float4 ac = s_a[k];
-          point(s_w[k], (lane == 0) ? ac.x : (lane == 1) ? ac.y : ac.z, ac);
-        }
+      s_w[buf][lane] = make_float4(before, s, 1.0f / s, q.w);
+      s_a[buf][lane] = make_float4(q.x * q.w, q.y * q.w, q.z * q.w, __uint_as_float(lc.y));
+      if (lane == 0) {
+        s_use[buf] = vmask;
+        s_last[buf] = last ? 1 : 0;
       }
-      KS_WAVE_LDS_ORDER();  // the table is rewritten by the next batch
       // label histogram: counts are order independent and exact in f32
 #pragma unroll
       for (int l = 0; l < kNumLabels; ++l) {
         const unsigned long long lm = __ballot(use && lc.x == (uint32_t)l);
         if (lane == l) freq += (float)__popcll(lm);
       }
-      if (n_in < 64) break;
+      __syncthreads();  // hand the batch to wave 1
+      buf ^= 1;
+      if (last) break;
       in = in_n;
       q = q_n;
       lc = lc_n;
       base += 64u;
+      if (__ballot(in) == 0ull) {  // the bundle ended on a batch boundary: an empty last batch
+        if (lane == 0) {
+          s_use[buf] = 0ull;
+          s_last[buf] = 1;
+        }
+        __syncthreads();
+        break;
+      }
     }
-    const f3 mp = {bcast_f(mpc, 0), bcast_f(mpc, 1), bcast_f(mpc, 2)};
+    __syncthreads();  // wave 1 has the merged point
+    const f3 mp = {s_mp[0], s_mp[1], s_mp[2]};
+    const uint32_t merged_color = __float_as_uint(s_mp[3]);
     const uint32_t first_p = bundle_id(X, use_rank, svals, start, clearing);
     const unsigned long long present = __ballot(lane >= 1 && lane < kNumLabels && freq > 0.0f);
     const int n_labels = (int)__popcll(present);
@@ -438,6 +486,7 @@ __global__ void __launch_bounds__(64) k_bundles_long(FrameParams F, const uint64
       if (ray_keys) ray_keys[first_p] = key & ~(1ull << 63);
       ray_list[atomicAdd(&C->n_rays, 1u)] = first_p;
     }
+    __syncthreads();  // LDS free for the next bundle
   }
 }
 

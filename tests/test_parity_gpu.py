@@ -515,6 +515,41 @@ def test_degenerate_inputs_exact(method):
     assert np.array_equal(ot["weight"].view(np.uint32), ht["weight"].view(np.uint32))
 
 
+@pytest.mark.parametrize("color_mode", [1, 0])
+def test_long_bundles_edge_cases_exact(color_mode):
+    """`merged`, bundles of >= 32 points (one workgroup each, 64 points per step): bundles of exactly 64 / 128 / 192 points (the
+    bundle ends on a step boundary), of 33 and 65, zero-weight points (|z| <= 1e-6 after the pose) inside a long bundle, points
+    whose coordinate is exactly 0 (the exponent window of the division), and long bundles of points beyond the ray-length limit
+    (clearing rays: the first usable point only)."""
+    o, h = _pair(1, max_consecutive_ray_collisions=NO_EARLY_OUT, color_mode=color_mode)
+    T = np.array([1, 0, 0, 0, 0, 0, 0], np.float32)    # identity: the cloud's z is the weight's z
+    rng = np.random.default_rng(11)
+    vs = 0.05   # (the default voxel size; max_ray_length_m = 5)
+
+    def cluster(center, n, spread=0.4):
+        c = (np.floor(np.asarray(center) / vs) + 0.5) * vs
+        return (c + rng.uniform(-spread, spread, size=(n, 3)) * vs).astype(np.float32)
+
+    parts = [cluster((0.8, 0.3, 1.5), 64), cluster((-0.6, 0.2, 1.2), 128), cluster((0.1, -0.7, 2.0), 192),
+             cluster((1.1, 1.0, 0.9), 33), cluster((-1.0, -0.5, 1.7), 65), cluster((0.4, 0.9, 2.6), 1000)]
+    zero_w = cluster((0.52, 0.52, 0.0), 80, spread=0.45)          # voxel around z = 0: some weights 1/z^2 are huge, some points
+    zero_w[::3, 2] = 0.0                                          # have z = 0 exactly: zero weight, skipped inside the bundle
+    on_axis = cluster((0.0, 0.0, 1.0), 100)
+    on_axis[::2, 0] = 0.0                                         # x exactly 0: the mean's numerator is 0 in the first steps
+    on_axis[:10, 1] = 0.0
+    far = cluster((3.0, 4.0, 12.0), 150)                          # beyond max_ray_length: clearing bundle, long
+    pts = np.concatenate(parts + [zero_w, on_axis, far]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    labels = rng.integers(1, 21, size=len(pts), dtype=np.uint8)
+    rgba = synth.default_label_colors()[labels].copy()
+    rgba[:, :3] = rng.integers(0, 255, size=(len(pts), 3), dtype=np.uint8)
+    for rep in range(2):
+        so = o.integrate(T, pts, rgba, labels)
+        sh = h.integrate(T, pts, rgba, labels)
+        assert (so.n_valid_points, so.n_rays_cast, so.n_voxel_updates) == (sh.n_valid_points, sh.n_rays_cast, sh.n_voxel_updates)
+    compare_maps(o, h, exact=True)
+
+
 def test_out_of_range_coordinates_are_reported():
     h = B.HipIntegrator(B.default_config(max_tiles=1024, max_points=1 << 12, **dict(COMMON, method=1, max_ray_length_m=1e9)))
     T = np.array([1, 0, 0, 0, 0, 0, 0], np.float32)
