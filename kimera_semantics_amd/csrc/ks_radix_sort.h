@@ -115,33 +115,6 @@ __global__ void __launch_bounds__(256) k_rs_hist_b(DevBatch<K> B, uint32_t cap, 
 // One pass.  THREADS x ITEMS keys per tile.  REORDER (keys only, large inputs): the tile's keys are first put in
 // digit order in LDS and leave from there, so that neighbouring lanes write neighbouring addresses (runs of
 // ~tile/256 keys per digit) instead of 8-byte scatters — the direct scatter wrote 2.6x its bytes at 3e7 keys.
-// Decoupled look-back of one digit over the tiles with index <= t; WINDOW predecessor loads are kept in flight.
-// Tile "-1" reads as an inclusive prefix of zero.
-template <int WINDOW, int BINS>
-__device__ __forceinline__ uint32_t look_back(const uint32_t* st, int t) {
-  uint32_t prefix = 0;
-  bool done = false;
-  while (!done) {
-    uint32_t s[WINDOW];
-#pragma unroll
-    for (int j = 0; j < WINDOW; ++j)
-      s[j] = (t - j >= 0) ? __hip_atomic_load(st + (size_t)(t - j) * BINS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                          : kFlagPrefix;
-    int consumed = 0;
-#pragma unroll
-    for (int j = 0; j < WINDOW; ++j) {
-      if (done || consumed != j) continue;
-      const uint32_t flag = s[j] >> 30;
-      if (flag == 0u) continue;  // not published yet: retry from here
-      prefix += s[j] & kCountMask;
-      ++consumed;
-      if (flag == 2u) done = true;
-    }
-    t -= consumed;
-  }
-  return prefix;
-}
-
 template <typename K, bool HAS_VALUES, int THREADS, int ITEMS, int RB, bool REORDER = false>
 __device__ __forceinline__ void rs_pass_body(const K* __restrict__ keys_in, K* __restrict__ keys_out,
                                              const uint32_t* __restrict__ vals_in,
@@ -211,12 +184,27 @@ __device__ __forceinline__ void rs_pass_body(const K* __restrict__ keys_in, K* _
     uint32_t* st = status + d;
     uint32_t prefix = 0;
     __hip_atomic_store(st + (size_t)tile * kBins, total | kFlagLocal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // A small sort (a few hundred tiles: a frame's points, its pairs at 640x480) has ALL its tiles resident at once: nobody
-    // finds a finished prefix, the last tile adds up every predecessor's local count, and a pass lasts as long as that walk:
-    // tiles / window dependent round trips to L2.  Such a sort looks back 32 tiles at a time (a wave's loads of one step are
-    // one 256-byte row each); a large one, whose early tiles have long finished, keeps the short window (less traffic).
-    if (gridDim.x <= 1024u) prefix = look_back<32, kBins>(st, (int)tile - 1);
-    else prefix = look_back<8, kBins>(st, (int)tile - 1);
+    constexpr int kWindow = 8;
+    int t = (int)tile - 1;
+    bool done = false;
+    while (!done) {
+      uint32_t s[kWindow];
+#pragma unroll
+      for (int j = 0; j < kWindow; ++j)
+        s[j] = (t - j >= 0) ? __hip_atomic_load(st + (size_t)(t - j) * kBins, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                            : kFlagPrefix;
+      int consumed = 0;
+#pragma unroll
+      for (int j = 0; j < kWindow; ++j) {
+        if (done || consumed != j) continue;
+        const uint32_t flag = s[j] >> 30;
+        if (flag == 0u) continue;  // not published yet: retry from here
+        prefix += s[j] & kCountMask;
+        ++consumed;
+        if (flag == 2u) done = true;
+      }
+      t -= consumed;
+    }
     __hip_atomic_store(st + (size_t)tile * kBins, (prefix + total) | kFlagPrefix, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
     s_off[d] = prefix;
