@@ -178,8 +178,8 @@ struct ks_ctx {
   hipStream_t prof_march_stream = nullptr;  // march stream of the frame being enqueued (stage events)
   hipStream_t stream_tail = nullptr;   // stage T; == stream unless pipelined
   hipStream_t stream_long = nullptr;   // the long-run voxel update, beside k_apply (always its own stream)
-  hipStream_t stream_xlong = nullptr;  // the runs of more than kXLongRun updates, beside both (xlong_pf != 0)
-  int xlong_pf = 0;                    // batches of ray descriptors their kernel keeps in flight (0: no separate list)
+  hipStream_t stream_xlong = nullptr;  // the runs of more than kXLongRun updates, beside both (k_apply_xlong)
+  bool xlong = true;
   float voxel_size_inv = 0.f, log_match = 0.f, log_non_match = 0.f;
   int vps_shift = 1;  // log2(vps / 8)
 
@@ -1391,13 +1391,10 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     KS_LAUNCH_APPLY_M(MODE, false);                                                                                  \
   }                                                                                                                  \
   stage_mark(c, set, 9);                                                                                             \
-  if (sx && c->xlong_pf >= 16)                                                                                       \
-    hipLaunchKernelGGL((k_apply_long<MODE, 16, true>), dim3(xb), dim3(128), 0, sx, F, n_pairs, sp, S.d_rays, S.d_deltas, \
+  if (sx)                                                                                                            \
+    hipLaunchKernelGGL(k_apply_xlong<MODE>, dim3(xb), dim3(256), 0, sx, F, n_pairs, sp, S.d_rays, S.d_deltas,            \
                        c->table, c->pool, c->d_label_lut, d_xlong_list, S.d_counters);                                 \
-  else if (sx)                                                                                                       \
-    hipLaunchKernelGGL((k_apply_long<MODE, 8, true>), dim3(xb), dim3(128), 0, sx, F, n_pairs, sp, S.d_rays, S.d_deltas,  \
-                       c->table, c->pool, c->d_label_lut, d_xlong_list, S.d_counters);                                 \
-  hipLaunchKernelGGL((k_apply_long<MODE, 4, false>), dim3(lb), dim3(128), 0, sl, F, n_pairs, sp, S.d_rays, S.d_deltas,  \
+  hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(128), 0, sl, F, n_pairs, sp, S.d_rays, S.d_deltas,               \
                      c->table, c->pool, c->d_label_lut, d_long_list, S.d_counters)
     switch (c->cfg.color_mode) {
       case KS_COLOR_MODE_COLOR: KS_LAUNCH_APPLY(KS_COLOR_MODE_COLOR); break;
@@ -1921,11 +1918,11 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     const char* nl = getenv("KS_NO_LONG_STREAM");   // diagnostics: long runs on the tail stream, after k_apply
     if (nl && nl[0] == '1') c->stream_long = nullptr;
     else CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
-    // KS_XLONG_PF = 8 | 16: the runs of more than kXLongRun updates (the voxels next to the sensor) on a stream of their own,
-    // walked with that many batches of ray descriptors in flight.  Same arithmetic, same order: the map does not change.
-    const char* xp = getenv("KS_XLONG_PF");
-    c->xlong_pf = xp ? atoi(xp) : 0;
-    if (c->xlong_pf && c->stream_long) CRCHK(hipStreamCreateWithFlags(&c->stream_xlong, hipStreamNonBlocking));
+    // the runs of more than kXLongRun updates (the voxels next to the sensor) on a stream of their own, four waves per run
+    // (k_apply_xlong).  Same arithmetic, same order: the map does not change.  KS_XLONG=0 (diagnostics): one list, k_apply_long.
+    const char* xp = getenv("KS_XLONG");
+    c->xlong = xp ? atoi(xp) != 0 : true;
+    if (c->xlong && c->stream_long) CRCHK(hipStreamCreateWithFlags(&c->stream_xlong, hipStreamNonBlocking));
   }
   for (auto& P : c->pset) {
     for (auto& e : P.ev) CRCHK(hipEventCreate(&e));

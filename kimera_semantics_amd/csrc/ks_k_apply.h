@@ -279,7 +279,7 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
 // Heads of runs of >= kLongRun updates, found before either apply kernel runs: k_apply (short runs) and
 // k_apply_long (long runs) touch disjoint voxels and are launched side by side on two streams.  Runs of more than
 // kXLongRun updates go to a list of their own when the caller passes one (xlong_list != nullptr): the handful of voxels
-// next to the sensor, whose single chains of 1e4 .. 1e5 updates bound the frame's update stage.
+// next to the sensor, whose single chains of 1e4 .. 1e5 updates bound the frame's update stage (k_apply_xlong).
 constexpr uint32_t kFindLongItems = 8;  // pairs per thread
 __global__ void __launch_bounds__(256) k_find_long(uint32_t seq_bits, unsigned long long n_pairs,
                                                    const uint64_t* __restrict__ pairs,
@@ -321,10 +321,7 @@ __global__ void __launch_bounds__(256) k_find_long(uint32_t seq_bits, unsigned l
   if (threadIdx.x < n_x) xlong_list[s_xbase + threadIdx.x] = s_xlist[threadIdx.x];
 }
 
-// PF: batches (of 64 updates) whose ray descriptors are in flight while one batch is applied.  XLONG selects the list
-// (and its counter): the runs of more than kXLongRun updates are walked by a second instance with a deeper pipeline, on a
-// stream of its own.
-template <int COLOR_MODE, int PF, bool XLONG>
+template <int COLOR_MODE>
 __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long long n_pairs,
                                                    const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
                                                    const float* __restrict__ deltas, TileTable T, Pool P,
@@ -340,7 +337,8 @@ __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long
   __shared__ int s_cnt[2];                    // updates in the batch (0: the run has ended)
   __shared__ uint32_t s_best;
   __shared__ float s_best_val;
-  const uint32_t n_long = XLONG ? C->n_xlong : C->n_long;
+  constexpr int PF = 4;  // batches (of 64 updates) whose ray descriptors are in flight while one batch is applied (8 / 16: measured no faster)
+  const uint32_t n_long = C->n_long;
   const int lane = (int)lane_id();
   const bool consumer = (threadIdx.x >> 6) != 0u;
   const int cls = lane < kNumLabels ? lane : 0;
@@ -513,6 +511,229 @@ __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long
         if (!more) break;
         base += 64;
       }
+    }
+    __syncthreads();  // the consumer has the label
+    const uint32_t best = s_best;
+    const float m = s_best_val;
+    if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = label_lut[best];
+    else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY)
+      color = rainbow_color_map((double)(float)exp((double)m));
+    if (lane == 0) {
+      *(uint4*)rec = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, best);
+      rec[25] = 1u;  // updated since the last voxel-level host sync
+    }
+    __syncthreads();  // LDS free for the next run
+  }
+}
+
+// The runs of more than kXLongRun updates — the handful of voxels next to the sensor, ONE chain of 1e4 .. 1e5 updates each
+// in `merged` (every bundle's ray starts there) — bound the update stage, and what bounds such a chain is the number of
+// instructions ONE wave issues per 64 updates (k_apply_long's producer: ~350).  Here the work of a batch is spread over
+// FOUR waves of a workgroup that meet at one barrier per batch ("step"):
+//   waves 2, 3  take the batches alternately.  A batch is prepared over two steps: first the gather of its ray descriptors
+//               (requested four batches ahead) and the state-independent half of the TSDF update per lane — sdf, weight —
+//               into a table in LDS; in the next step its 64 x 21 class increments (laid out so that the consumer reads the
+//               increments of four consecutive updates of one class with one 16-byte load);
+//   wave 0      walks the weight / distance recurrences of the batch prepared two steps ago (operands from the table);
+//   wave 1      folds that batch's increments into the 21 class sums, in order.
+// Same operations in the same order as k_apply_long: the voxel's record is bit for bit what the single chain leaves.
+template <int COLOR_MODE>
+__global__ void __launch_bounds__(256) k_apply_xlong(FrameParams F, unsigned long long n_pairs,
+                                                    const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
+                                                    const float* __restrict__ deltas, TileTable T, Pool P,
+                                                    const uint32_t* __restrict__ label_lut,
+                                                    const unsigned long long* __restrict__ xlong_list, const Counters* C) {
+  __shared__ float s_inc[2][16][kNumLabels][4];  // [batch parity][update / 4][class][update % 4]
+  __shared__ float4 s_tab[3][64];                // per update of a batch: sdf, update weight, colour
+  __shared__ int s_cnt[3];                       // updates in the batch (< 64: the run ends with it)
+  __shared__ uint32_t s_best;
+  __shared__ float s_best_val;
+  const uint32_t n_x = C->n_xlong;
+  const int lane = (int)lane_id();
+  const int role = (int)(threadIdx.x >> 6);
+  const int cls = lane < kNumLabels ? lane : 0;
+  const TsdfParams& Pm = F.tsdf;
+  for (uint32_t run = blockIdx.x; run < n_x; run += gridDim.x) {
+    const unsigned long long start = xlong_list[run];
+    const uint32_t vox = (uint32_t)(pairs[start] >> F.seq_bits);
+    uint32_t* rec = (uint32_t*)(P.vox + (size_t)vox * 8);
+    if (role >= 2) {
+      // ---- waves 2, 3: the batches f, f + 2, f + 4, ... ----
+      const int f = role - 2;
+      const VoxelRef v = voxel_ref(T, vox);
+      const f3 c = {((float)v.vx + 0.5f) * Pm.voxel_size, ((float)v.vy + 0.5f) * Pm.voxel_size,
+                    ((float)v.vz + 0.5f) * Pm.voxel_size};
+      const f3 v_voxel_origin = sub3(c, F.T.t);
+      const unsigned long long last = n_pairs - 1ull;
+      // own batch j is batch f + 2 j of the run.  Descriptors of two own batches in flight, keys of the two after them
+      // (all loads unconditional, indices clamped: ks_k_apply.h, k_apply_long)
+      auto key_of = [&](unsigned long long own) { return pairs[min(start + 64ull * ((unsigned long long)f + 2ull * own) + lane, last)]; };
+      uint64_t key_q[2] = {key_of(0), key_of(1)}, key_n[2] = {key_of(2), key_of(3)};
+      RayDesc d_q[2] = {rays[ray_index(F, (uint32_t)key_q[0] & F.point_mask)], rays[ray_index(F, (uint32_t)key_q[1] & F.point_mask)]};
+      unsigned long long own = 0;  // the own batch whose first half comes next
+      // what the second half of a batch needs of the first
+      bool h_in = false;
+      uint32_t h_kind = 0, h_lab = 0, h_rp = 0;
+      float h_a = 0.f, h_b = 0.f;
+      auto first_half = [&]() {
+        const unsigned long long b = (unsigned long long)f + 2ull * own;
+        const uint64_t key_cur = key_q[0];
+        const RayDesc d = d_q[0];
+        const RayDesc d_new = rays[ray_index(F, (uint32_t)key_n[0] & F.point_mask)];
+        const uint64_t key_new = key_of(own + 4ull);
+        const bool in = (start + 64ull * b + lane < n_pairs) && ((uint32_t)(key_cur >> F.seq_bits) == vox);
+        const int cnt = (int)__popcll(__ballot(in));  // sorted => the in-lanes form a prefix
+        float sdf = 0.f, uw = 0.f;
+        if (in) {
+          const f3 v_point_origin = sub3({d.px, d.py, d.pz}, F.T.t);
+          const float dist_G = norm3(v_point_origin);
+          const float dist_G_V = dot3(v_voxel_origin, v_point_origin) / dist_G;
+          sdf = dist_G - dist_G_V;
+          uw = d.weight;
+          if (Pm.use_dropoff && sdf < -Pm.voxel_size) {
+            uw = d.weight * (Pm.trunc + sdf) / Pm.dropoff_denominator;
+            uw = std_max(uw, 0.0f);
+          }
+          if (Pm.use_sparsity) {
+            if (fabsf(sdf) < Pm.trunc) uw *= Pm.sparsity_factor;
+          }
+        }
+        s_tab[b % 3ull][lane] = make_float4(sdf, uw, __uint_as_float(d.color), 0.0f);
+        if (lane == 0) s_cnt[b % 3ull] = cnt;
+        h_in = in;
+        h_kind = (d.info >> 8) & 3u;
+        h_lab = d.info & 0xffu;
+        h_rp = (uint32_t)key_cur & F.point_mask;
+        h_a = (h_kind == 1u) ? d.d_match : 0.0f;
+        h_b = (h_kind == 1u) ? d.d_non : 0.0f;
+        key_q[0] = key_q[1];
+        d_q[0] = d_q[1];
+        key_q[1] = key_n[0];
+        d_q[1] = d_new;
+        key_n[0] = key_n[1];
+        key_n[1] = key_new;
+      };
+      auto second_half = [&]() {
+        const unsigned long long b = (unsigned long long)f + 2ull * own;
+        float* inc = &s_inc[b & 1ull][lane >> 2][0][lane & 3];
+        if (h_in) {
+          if (h_kind == 2u) {
+            const float* dl = deltas + (size_t)h_rp * kNumLabels;
+#pragma unroll
+            for (int l = 0; l < kNumLabels; ++l) inc[4 * l] = dl[l];
+          } else {
+            float a = h_a, b = h_b;   // values in registers: a select between two captured variables is otherwise folded into
+            KS_VALUE_BARRIER(a);      // ONE load from a selected ADDRESS, which pins both to scratch memory (ks_types.h)
+            KS_VALUE_BARRIER(b);
+#pragma unroll
+            for (int l = 0; l < kNumLabels; ++l) inc[4 * l] = ((uint32_t)l == h_lab) ? a : b;
+          }
+        }
+        ++own;
+      };
+      if (f == 0) first_half();  // batch 0, before step 0
+      for (unsigned long long s = 0;; ++s) {
+        if ((int)(s & 1ull) == f) second_half();  // batch s
+        else first_half();                        // batch s + 1
+        const int cnt_prev = s >= 1ull ? s_cnt[(s - 1ull) % 3ull] : 64;
+        __syncthreads();  // step s
+        if (cnt_prev < 64) break;
+      }
+      __syncthreads();  // (the label for the record head)
+      __syncthreads();  // LDS free for the next run
+      continue;
+    }
+    if (role == 1) {
+      // ---- wave 1: the semantic log-likelihood sums, lane l owns class l ----
+      float pri = (lane < kNumLabels) ? __uint_as_float(rec[4 + lane]) : 0.0f;
+      __syncthreads();  // step 0
+      for (unsigned long long s = 1;; ++s) {
+        const unsigned long long b = s - 1ull;
+        const int cnt = s_cnt[b % 3ull];
+        if (cnt == 64) {
+          // full batch: all increments are requested from LDS before the first dependent add
+          float4 x[16];
+#pragma unroll
+          for (int g = 0; g < 16; ++g) x[g] = *(const float4*)&s_inc[b & 1ull][g][cls][0];
+#pragma unroll
+          for (int g = 0; g < 16; ++g) {
+            pri += x[g].x;
+            pri += x[g].y;
+            pri += x[g].z;
+            pri += x[g].w;
+          }
+        } else {
+#pragma unroll 4
+          for (int k = 0; k < cnt; ++k) pri += s_inc[b & 1ull][k >> 2][cls][k & 3];
+        }
+        __syncthreads();  // step s
+        if (cnt < 64) break;
+      }
+      // argmax over lanes 0..20, first strict maximum
+      int best = 0;
+      float m = bcast_f(pri, 0);
+#pragma unroll
+      for (int l = 1; l < kNumLabels; ++l) {
+        const float x = bcast_f(pri, l);
+        if (x > m) { m = x; best = l; }
+      }
+      if (lane < kNumLabels) rec[4 + lane] = __float_as_uint(pri);
+      if (lane == 0) {
+        s_best = (uint32_t)best;
+        s_best_val = m;
+      }
+      __syncthreads();  // label for the record head
+      __syncthreads();  // LDS free for the next run
+      continue;
+    }
+    // ---- wave 0: the weight and distance recurrences ----
+    float dist = __uint_as_float(rec[0]), weight = __uint_as_float(rec[1]);
+    uint32_t color = rec[2];
+    __syncthreads();  // step 0
+    for (unsigned long long s = 1;; ++s) {
+      const unsigned long long b = s - 1ull;
+      const int cnt = s_cnt[b % 3ull];
+      const float4 t = s_tab[b % 3ull][lane];
+      const bool in = lane < cnt;
+      const float sdf = t.x, uw = t.y;
+      const uint32_t d_color = __float_as_uint(t.z);
+      if (cnt > 0) {
+        // ---- pass 1: the weight recurrence (independent of the distance) ----
+        float my_w = 0.0f, my_nw = 1.0f;
+        if (weight == Pm.max_weight && __ballot(in && !(uw >= 0.0f)) == 0ull) {
+          my_w = weight;   // (k_apply_long: weight clamped at max_weight, increments non-negative: 64 independent additions)
+          my_nw = weight + uw;
+        } else {
+          float w_run = weight;
+          for (int k = 0; k < cnt; ++k) {
+            const float nw = w_run + bcast_f(uw, k);
+            if (lane == k) { my_w = w_run; my_nw = nw; }
+            if (!(nw < kEps)) w_run = std_min(Pm.max_weight, nw);
+          }
+          weight = w_run;
+        }
+        const bool my_skip = my_nw < kEps;
+        const float my_r = 1.0f / my_nw;
+        const float my_p = sdf * uw;
+        const bool my_sat = my_skip || ((sdf - Pm.trunc) * uw >= 1e-6f * Pm.trunc * my_nw);
+        const bool all_sat = (__ballot(in && !my_sat) == 0ull);
+        if (!(all_sat && dist == Pm.trunc && COLOR_MODE != KS_COLOR_MODE_COLOR)) {
+          // ---- pass 2: the distance recurrence ----
+          for (int k = 0; k < cnt; ++k) {
+            if (bcast_u(my_skip ? 1u : 0u, k)) continue;
+            const float w_k = bcast_f(my_w, k), nw_k = bcast_f(my_nw, k), r_k = bcast_f(my_r, k);
+            const float num = bcast_f(my_p, k) + dist * w_k;
+            const float q = div_by_recip(num, nw_k, r_k);
+            if (COLOR_MODE == KS_COLOR_MODE_COLOR) {
+              if (fabsf(bcast_f(sdf, k)) < Pm.trunc)
+                color = blend_two_colors(color, w_k, bcast_u(d_color, k), bcast_f(uw, k));
+            }
+            dist = (q > 0.0f) ? std_min(Pm.trunc, q) : std_max(-Pm.trunc, q);
+          }
+        }
+      }
+      __syncthreads();  // step s
+      if (cnt < 64) break;
     }
     __syncthreads();  // the consumer has the label
     const uint32_t best = s_best;
