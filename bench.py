@@ -245,7 +245,15 @@ def measure(B, torch, dist, dev, wl, ring, W, K, R, pipeline, max_tiles, world, 
     integ.profile(reset=True)
     regions = []
     base = prime + W
+
+    def eo_stats():   # (counters of the library: no synchronisation)
+        try:
+            return integ.early_out_stats()
+        except Exception:
+            return {}
+
     for r in range(R):
+        eo0 = eo_stats()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -268,8 +276,10 @@ def measure(B, torch, dist, dev, wl, ring, W, K, R, pipeline, max_tiles, world, 
         dt = time.perf_counter() - t0
         want_points = sum(int(ring.host(i).xyz.shape[0]) for i in range(base + r * K, base + (r + 1) * K))
         assert points == want_points, f"statistics cover {points} points, the timed frames hold {want_points}"
+        eo1 = eo_stats()
         regions.append(dict(dt=dt, updates=updates, points=points, rays=rays, reduce=reduce_stats,
-                            frames=list(range(base + r * K, base + (r + 1) * K))))
+                            frames=list(range(base + r * K, base + (r + 1) * K)),
+                            early_out={k: eo1[k] - eo0[k] for k in ("frames", "rounds", "fallbacks") if k in eo0 and k in eo1}))
     prof = integ.profile(reset=True)
     # per-stage breakdown: separate untimed pass over a few frames with events around every stage
     integ.profile_enable(1)
@@ -422,6 +432,7 @@ def record(name, wl, m, K, count_of_frame, how, world=1, pmc_name=None, note=Non
         "ms_per_step": round(dt / (K / world) * 1e3, 4), "frames_per_s": round(K / dt, 2), "steps": K // world,
         "repeats": len(rates), "spread": round(spread, 4),
         "ms_per_step_all_regions": [round(r["dt"] / (K / world) * 1e3, 4) for r in m["regions"]],
+        "early_out_all_regions": [r.get("early_out") for r in m["regions"]],   # fix-point rounds / frames the host-driven loop repeated, per region
         "points_per_frame": int(reg["points"] / K), "rays_per_frame": int(reg["rays"] / K),
         "updates_per_frame": int(counted / K), "gpu_updates_per_frame": int(gpu_upd / K), "tiles": m["tiles"],
         "roofline": roofline_of(m, reg, K // world, counted / world, world, pmc_name),
@@ -748,7 +759,8 @@ def main():
             "updates_counted_by": rec["updates_counted_by"],
             "timing": {"untimed_frames_before_t0": PRIME + W, "timed_regions": R, "steps_per_region": K,
                        "reported": "median region", "spread_max_minus_min_over_median": rec["spread"],
-                       "ms_per_step_all_regions": rec["ms_per_step_all_regions"]},
+                       "ms_per_step_all_regions": rec["ms_per_step_all_regions"],
+                       "early_out_all_regions": rec["early_out_all_regions"]},
             "config": {"workload": "bag-replay stand-in: " + rec["workload"],
                        "frames_per_gpu": K, "pipeline_frames": pipeline, "distinct_frames_replayed_cyclically": n_distinct,
                        "points_per_frame": rec["points_per_frame"], "rays_per_frame": rec["rays_per_frame"],

@@ -548,7 +548,6 @@ __global__ void __launch_bounds__(256) k_apply_xlong(FrameParams F, unsigned lon
   __shared__ int s_cnt[3];                       // updates in the batch (< 64: the run ends with it)
   __shared__ uint32_t s_best;
   __shared__ float s_best_val;
-  KS_CHAIN_PRIORITY();
   const uint32_t n_x = C->n_xlong;
   const int lane = (int)lane_id();
   const int role = (int)(threadIdx.x >> 6);

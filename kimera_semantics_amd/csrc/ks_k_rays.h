@@ -325,7 +325,6 @@ __global__ void __launch_bounds__(128) k_bundles_long(FrameParams F, const uint6
   __shared__ unsigned long long s_use[2];  // the points of the batch that are merged
   __shared__ int s_last[2];                // 1: the bundle ends with this batch
   __shared__ float s_mp[4];                // the merged point (+ the blended colour) back to wave 0
-  KS_CHAIN_PRIORITY();
   const uint32_t n_long = C->n_long_bundles;
   const int lane = (int)lane_id();
   const bool back = (threadIdx.x >> 6) != 0u;

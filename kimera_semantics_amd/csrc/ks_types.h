@@ -310,12 +310,6 @@ __device__ __forceinline__ float bcast_f(float x, int k) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), k));
 }
 __device__ __forceinline__ uint32_t bcast_u(uint32_t x, int k) { return (uint32_t)__builtin_amdgcn_readlane((int)x, k); }
-// KS_CHAIN_PRIORITY(): the wavefront runs ONE dependent chain that bounds its kernel (a long run, a long bundle) while the
-// waves it shares its SIMD with belong to throughput kernels: its next instruction issues as soon as it is ready instead of
-// waiting for its turn among up to eight waves.
-#ifndef KS_CHAIN_PRIORITY
-#define KS_CHAIN_PRIORITY() __builtin_amdgcn_s_setprio(3)
-#endif
 // x of the lane below; lane 0 reads `first`.  One DPP move (wave_shr:1): no LDS, no scalar round trip — the step of a
 // recurrence that runs THROUGH the lanes (lane k's value from lane k-1's).
 #ifndef KS_LANE_BELOW
