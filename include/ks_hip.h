@@ -172,7 +172,13 @@ int ks_set_color_to_label(ks_ctx* ctx, const uint8_t* rgba_keys, const uint8_t* 
  * overload merged.h:82-86.  Host pointers.  T_G_C = {qw,qx,qy,qz,tx,ty,tz}.
  * labels == NULL -> labels are derived from rgba through the colour map (the reference's
  * serial host loop, fast.cpp:150-158).  rgba == NULL -> colours are (0,0,0,0) (what the
- * reference's merged colour overload effectively integrates, merged.cpp:70,92-93). */
+ * reference's merged colour overload effectively integrates, merged.cpp:70,92-93).
+ * Lifetime of the host buffers: pageable memory is staged before the call returns and may be reused at once; page-locked
+ * memory (ks_host_alloc, hipHostMalloc, hipHostRegister) is read by the copy engine and may still be in use when a call of
+ * a PIPELINED context returns (pipeline_frames = 0: the call completes its frame, the buffer is free): leave it unchanged
+ * until `pipeline_frames` further integrate calls have returned (the call that finishes a frame has waited for it), or
+ * until a call that completes outstanding work (ks_synchronize, ks_flush, any query) — i.e. rotate pipeline_frames + 1
+ * buffers. */
 int ks_integrate_points(ks_ctx* ctx, const float T_G_C[7], const float* xyz, const uint8_t* rgba,
                         const uint8_t* labels, size_t n, int freespace, ks_frame_stats* stats);
 /* Same, but xyz/rgba/labels are DEVICE pointers already resident in HBM (bench timed region). */
@@ -186,7 +192,9 @@ int ks_integrate_points_device(ks_ctx* ctx, const float T_G_C[7], const float* d
  * order, then integrates exactly as ks_integrate_points would on the resulting cloud.
  * depth_fmt 0 = float32 metres (invalid: non-finite), 1 = uint16 millimetres (invalid: 0).
  * label_img (u8 per pixel) is preferred; with label_img == NULL the rgba8 segmentation image is
- * decoded through the colour map.  Host pointers / device pointers respectively. */
+ * decoded through the colour map.  Host pointers / device pointers respectively.  The host-pointer entry counts the valid
+ * pixels itself while its copies are in flight (no read-back, no host wait; buffer lifetime as for ks_integrate_points);
+ * the device-pointer entry reads the compacted count back (4 bytes, one stream synchronisation) before it enqueues the frame. */
 int ks_integrate_depth(ks_ctx* ctx, const float T_G_C[7], const void* depth, int depth_fmt, const uint8_t* label_img,
                        const uint8_t* rgba_img, int width, int height, const float K[4], int freespace,
                        ks_frame_stats* stats);

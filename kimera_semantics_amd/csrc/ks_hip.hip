@@ -208,7 +208,6 @@ struct ks_ctx {
   bool use_tail_thread = false;
   double hp_a = 0, hp_b = 0, hp_t = 0, hp_sort = 0;   // KS_HOST_PROF=1: host seconds spent enqueueing stage A / B / T, radix sorts (of A+T)
   bool host_prof = false;
-  bool export_staged = false;             // KS_EXPORT_STAGED=1: voxel export via a device buffer + copy even for pinned targets
   bool use_graphs = true;                // stage B replayed as a hipGraph (KS_NO_GRAPH=1 or a capture failure: plain launches)
   bool test_overlap = true;              // k_test casts a long ray's next 64 voxels while the shared-set entries of the current 64 are in flight (KS_TEST_OVERLAP=0: one after the other, as measured until round 3)
   std::atomic<uint64_t> buffers_epoch{1};  // bumped whenever a buffer a captured graph points at is re-allocated
@@ -237,7 +236,7 @@ struct ks_ctx {
   uint32_t *d_okeys = nullptr, *d_okeys2 = nullptr, *d_ovals = nullptr;
   size_t cap_pairs = 0;
   uint64_t* d_pairs2_[2] = {nullptr, nullptr};
-  bool defer_join = false;               // k_apply_long of frame f overlaps the pair sort of frame f+1 (KS_NO_DEFER_JOIN=1: off)
+  bool defer_join = false;               // k_apply_long of frame f overlaps the pair sort of frame f+1 (pipelined contexts)
   hipEvent_t pending_join = nullptr;     // recorded on stream_long; the next k_apply / k_apply_long wait for it
   ksrs::Workspace sort_ws, sort_ws_tail;
   // fast, early-out in the reference's serial order (ks_k_exact.h): marks (two sets for the sort), slot ranges,
@@ -262,11 +261,6 @@ struct ks_ctx {
   std::atomic<size_t> eo_want_marks{0}, eo_want_x{0};   // capacities a failed frame asked for (grown by the caller's thread between frames)
   size_t eo_cap_marks = 0, eo_cap_x = 0; // per-slot capacities in use
   uint64_t eo_fallbacks = 0;             // frames that fell back to the host-driven loop
-  // KS_EXACT_SEED_FULL=1 (experiments): the fix point seeded with the FULL rays (k_dedup has left them in cnt[]: the phases are
-  // simply skipped) — every step has a mark, nothing grows through X marks, rays only ever get shorter.  Exact like any
-  // seed; measured: 5x the marks and more rounds at 640x480 (2.7 vs 0.48 ms/frame), and at 1280x720 / 2 cm / 10 m rays
-  // 2.3e8 marks per frame that still have long dirty lists after 32 rounds — not a way out for that geometry.
-  bool eo_seed_full = false;
   std::atomic<int> eo_hopeless{0};       // consecutive frames the device loop gave up on for reasons growing a buffer does not cure
   bool eo_device_off = false;            // ... three of them: the context stays with the host-driven loop (one frame at a time)
   // merged in the reference's bundle order (ks_k_bundle_order.h): scratch of the rank computation, one slab
@@ -959,7 +953,7 @@ int launch_batch(ks_ctx* c) {
         bool ok = hipStreamBeginCapture(sm, hipStreamCaptureModeRelaxed) == hipSuccess;
         if (ok) {
           if (part == 1) {
-            if (!c->eo_seed_full) enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
+            enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
             part_rc = enqueue_exact_rounds(c, slots.data(), nb, sm);
           } else if (part == 2) {
             for (uint32_t k = 0; k < nb; ++k) enqueue_exact_finish(c, *slots[k], sm);   // (in frame order: a frame's finisher sees the marks of the one before)
@@ -985,7 +979,7 @@ int launch_batch(ks_ctx* c) {
     }
     if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph, sm));
     else {
-      if (!c->eo_seed_full) enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
+      enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
       if ((rc = enqueue_exact_rounds(c, slots.data(), nb, sm))) return rc;
     }
     if (c->eo_last_commit && c->eo_last_commit != S0.eo_committed) HIPCHK(c, hipStreamWaitEvent(sm, c->eo_last_commit, 0));
@@ -1170,8 +1164,6 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
       // epochs whose bucket count fits one workgroup's LDS: one launch for all of them (both maps)
       int e_small = 0;
       while (e_small < c->bo_epochs && c->bo_sched.b[e_small] <= kBoSmallBuckets) ++e_small;
-      static const bool no_small = getenv("KS_BO_NO_SMALL") != nullptr;  // diagnostics: every epoch through the global kernels
-      if (no_small) e_small = 0;
       if (e_small > 0) hipLaunchKernelGGL(k_bo_small, dim3(2), dim3(kBoBlock), 0, st, c->bo, e_small);
       for (int e = e_small; e <= c->bo_epochs; ++e) {
         if (e > 0 && c->bo_sched.t[e - 1] >= n) break;  // no map of this frame reaches epoch e - 1
@@ -1231,9 +1223,6 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   if (c->eo_device && !c->eo_device_off) {
     c->eo_frames += 1;
     c->eo_iterations += S.h_snap->pad[2];   // rounds of the event-driven fix point (k_publish)
-    if (getenv("KS_EXACT_DEBUG"))
-      fprintf(stderr, "[ks exact] frame %u: X marks %u, fail bits %u, rounds %u, rays %u%s\n", S.F.eo_frame, S.h_snap->pad[0] - 1u, S.h_snap->pad[1], S.h_snap->pad[2], cnt.n_rays,
-              c->eo_seed_full ? " (seed: full rays)" : "");
   }
   if (c->eo_device && !c->eo_device_off && !(cnt.err & kErrExact)) c->eo_hopeless.store(0, std::memory_order_relaxed);
   if ((cnt.err & kErrExact) && !(cnt.err & (kErrLabel | kErrIndex))) {
@@ -1256,9 +1245,6 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     if (dense) c->eo_hopeless.fetch_add(1, std::memory_order_relaxed);
     else if (!(hctl.fail & kEoFailChain)) c->eo_hopeless.store(0, std::memory_order_relaxed);
     ++c->eo_fallbacks;
-    if (getenv("KS_EXACT_DEBUG"))
-      fprintf(stderr, "[ks exact] frame %u falls back to the host-driven loop: fail bits %u (1 marks, 2 X marks, 4 rounds, 8 predecessor), marks %llu of %zu, X %u of %zu, rounds %u\n",
-              S.F.eo_frame, hctl.fail, (unsigned long long)hctl.st.n_marks, c->eo_cap_marks, hctl.n_x, c->eo_cap_x, hctl.rounds);
     Counters rcnt{};
     rcnt.n_rays = cnt.n_rays;
     HIPCHK(c, hipMemcpyAsync(c->d_retry_counters, &rcnt, sizeof(rcnt), hipMemcpyHostToDevice, st));
@@ -1828,7 +1814,6 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // pipelined as long as a frame's marks are never seen by the next one (every frame bumps the set offset): what is left
     // of the dependence between frames — the zero-initialised slot — is carried by the commit events.
     if (c->exact_early_out && (!c->eo_device || c->cfg.clear_checks_every_n_frames > 1)) c->cfg.pipeline_frames = 0;
-    if (const char* sf = getenv("KS_EXACT_SEED_FULL")) c->eo_seed_full = atoi(sf) != 0;   // tests: the full-ray seed from the first frame on
     const bool wide_rays = steps_max_of(c->cfg, (float)(1.0 / cfg->voxel_size)) > 400;
     c->eo_bulk_rounds = wide_rays ? 32 : 14;
     if (const char* br = getenv("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
@@ -1840,10 +1825,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     c->host_prof = hpf && hpf[0] == '1';
     const char* ng = getenv("KS_NO_GRAPH");
     c->use_graphs = !(ng && ng[0] == '1');
-    const char* dj = getenv("KS_NO_DEFER_JOIN");
-    c->defer_join = !(dj && dj[0] == '1');
-    const char* es = getenv("KS_EXPORT_STAGED");
-    c->export_staged = es && es[0] == '1';
+    c->defer_join = true;
   }
   c->log_match = lm;
   c->log_non_match = lnm;
@@ -1884,27 +1866,17 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     if (c->exact_early_out && c->batch > 1) c->n_march = 2;
     if (const char* ms = getenv("KS_MARCH_STREAMS")) c->n_march = std::min(kMarchStreams, std::max(1, atoi(ms)));  // diagnostics
     {
-      // KS_STREAM_PRIORITY (diagnostics): m = march streams at the highest priority, t = tail, l = long at the lowest
-      const char* sp = getenv("KS_STREAM_PRIORITY");
-      int lo = 0, hi = 0;
-      CRCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      auto mk = [&](hipStream_t* st, char tag) {
-        if (sp && strchr(sp, tag)) return hipStreamCreateWithPriority(st, hipStreamNonBlocking, tag == 'l' ? lo : hi);
-        return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
-      };
+      auto mk = [&](hipStream_t* st, char) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
       // without an early-out stage B is short (scan + emission): it follows stage A on the same stream, and the three
       // streams that remain (A+B, T, long runs) map onto hardware queues of their own
-      static const bool merged_own_march = getenv("KS_MERGED_OWN_MARCH") != nullptr;  // experiments
-      if (!uses_early_out && !merged_own_march) {
+      if (!uses_early_out) {
         c->n_march = 1;
         c->stream_march_[0] = c->stream;
       } else {
         for (int i = 0; i < c->n_march; ++i) CRCHK(mk(&c->stream_march_[i], 'm'));
       }
       {
-        const char* tm = getenv("KS_TAIL_ON_MAIN");  // experiments: stage T shares stage A's stream
-        if (tm && tm[0] == '1') c->stream_tail = c->stream;
-        else CRCHK(mk(&c->stream_tail, 't'));
+        CRCHK(mk(&c->stream_tail, 't'));
       }
     }
   } else {
@@ -1914,7 +1886,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // Created LAST.  The runtime spreads streams over its hardware queues in creation order, and kernels of streams that
     // share a hardware queue run one after the other: the heavy chains (stage B, stage T) must not share one.  With
     // the default of four hardware queues — one of which other streams of the process use — stage A and the long
-    // runs (the two lightest: ~90 + ~65 us per 640x480 frame) are the pair that shares.  KS_STREAM_ORDER: experiments.
+    // runs (the two lightest: ~90 + ~65 us per 640x480 frame) are the pair that shares.
     const char* nl = getenv("KS_NO_LONG_STREAM");   // diagnostics: long runs on the tail stream, after k_apply
     if (nl && nl[0] == '1') c->stream_long = nullptr;
     else CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
@@ -2379,7 +2351,6 @@ static int updated_voxels_impl(ks_ctx* c, void* out, size_t cap, size_t* n, bool
   // pinned host targets (ks_host_alloc) are written by the kernel itself: no staging copy
   uint8_t* rec_direct = (uint8_t*)device_view_of_pinned(out);
   uint32_t* run_direct = runs ? (uint32_t*)device_view_of_pinned(runs) : nullptr;
-  if (c->export_staged) rec_direct = nullptr, run_direct = nullptr;
   const size_t bytes = (size_t)h_cnt[1] * kVoxRecBytes;
   const size_t run_bytes = (size_t)n_list * sizeof(ks_voxel_run);
   const size_t need = (rec_direct ? 0 : bytes + bytes / 4) + (run_direct ? 0 : 2 * run_bytes) + 64;

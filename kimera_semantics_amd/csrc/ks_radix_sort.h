@@ -363,8 +363,7 @@ inline hipError_t sort_rb(Workspace& w, K* keys_a, K* keys_b, uint32_t* vals_a, 
   // tile size: 2048 keys keeps per-tile latency low for per-frame sizes; larger tiles shorten
   // the look-back chain for million-scale inputs
   // keys-only sorts of more than 2^20 keys (the pair sort of large frames) take the LDS-reordering variant
-  static const bool no_reorder = getenv("KS_RS_NO_REORDER") != nullptr;  // diagnostics
-  const bool reorder = !HAS_VALUES && n > (1u << 20) && !no_reorder;
+  const bool reorder = !HAS_VALUES && n > (1u << 20);
   const int tile = (n <= (1u << 20)) ? 2048 : (reorder || n <= (1u << 24)) ? 8192 : 16384;
   const uint32_t tiles = (uint32_t)((n + tile - 1) / tile);
   const size_t words = kHeadWords + (size_t)passes * tiles * kBins;

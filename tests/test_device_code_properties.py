@@ -57,3 +57,12 @@ def test_k_test_casts_the_next_round_while_the_look_ups_are_in_flight(asm):
         wait = next(i for i, l in enumerate(after) if "s_waitcnt" in l and "vmcnt(0)" in l)
         caster = sum("ds_write2_b32" in l for l in after[:wait])
         assert (caster >= 5) == want, (overlap, caster, wait)
+
+
+def test_k_bundles_long_runs_the_weight_recurrence_through_the_lanes(asm):
+    """k_bundles_long: the weights of a 64-point batch are summed in order by 63 DPP steps (wave_shr:1: lane k takes lane k-1's
+    sum) plus the one that hands every lane the weight before its point — no LDS round trip, no scalar broadcast per point."""
+    m = re.search(r"^_ZN3ksk14k_bundles_long\w+:[^\n]*\n(.*?)^\.Lfunc_end", asm, re.S | re.M)
+    body = m.group(1)
+    assert body.count("wave_shr:1") >= 64
+    assert "v_readlane_b32" not in body.split("wave_shr:1")[1]     # nothing scalar between two steps of the chain
