@@ -1,8 +1,7 @@
-"""A/B of KS_XLONG_PF (the runs of more than 1024 updates on a list and a stream of their own, walked with 8 / 16 batches of
-ray descriptors in flight) on the `merged` workloads whose update stage those runs bound: C3 (640x480) and, with --c4,
-C4-merged (1280x720).  Same map in every variant (tests/test_parity_gpu.py::test_runs_next_to_the_sensor_on_their_own_list_exact);
-this tool only reads the clock.  One JSON line per variant; run it under `rocprofv3 --kernel-trace --stats` for the
-kernel durations (the instances differ in their template arguments).
+"""A/B of KS_XLONG (1, the default: the runs of more than 1024 updates on a list and a stream of their own, four waves per run —
+k_apply_xlong; 0: one list, k_apply_long) on the `merged` workloads: C3 (640x480) and, with --c4, C4-merged (1280x720).
+Same map in every variant (tests/test_parity_gpu.py::test_runs_next_to_the_sensor_on_their_own_list_exact); this tool only
+reads the clock.  One JSON line per variant; run it under `rocprofv3 --kernel-trace --stats` for the kernel durations.
 
     python tools/xlong_ab.py [--c4] [--steps K] [--repeats R]
 """
@@ -21,7 +20,7 @@ def main():
     ap.add_argument("--c4", action="store_true")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=3)
-    ap.add_argument("--variants", default="0,16,8")
+    ap.add_argument("--variants", default="1,0")
     args = ap.parse_args()
     import torch
     import bench
@@ -34,20 +33,17 @@ def main():
     for name, wl, n_frames, K, tiles in plans:
         ring = bench.FrameRing(bench.make_frames(wl, range(n_frames)), torch, dev)
         for pf in args.variants.split(","):
-            if pf == "0":
-                os.environ.pop("KS_XLONG_PF", None)
-            else:
-                os.environ["KS_XLONG_PF"] = pf
+            os.environ["KS_XLONG"] = pf
             m = bench.measure(B, torch, None, dev, wl, ring, 2, K, args.repeats, 8, tiles, 1, prime=8 if name != "C3" else None)
             ms = sorted(r["dt"] / K * 1e3 for r in m["regions"])
             sp = m["stage_prof"]
             st = {k: round(v / max(1, sp["frames"]), 4) for k, v in sp["ms"].items()}
-            print(json.dumps({"config": name, "KS_XLONG_PF": int(pf), "ms_per_frame_median": round(ms[len(ms) // 2], 4),
+            print(json.dumps({"config": name, "KS_XLONG": int(pf), "ms_per_frame_median": round(ms[len(ms) // 2], 4),
                               "ms_per_frame_all": [round(x, 4) for x in ms], "updates_per_frame": m["regions"][0]["updates"] // K,
                               "stage_ms": st}), flush=True)
         del ring
         torch.cuda.empty_cache()
-    os.environ.pop("KS_XLONG_PF", None)
+    os.environ.pop("KS_XLONG", None)
 
 
 if __name__ == "__main__":
