@@ -30,7 +30,8 @@ def main():
     sc = synth.make_scene("room")
     tot_o = tot_g = 0
     for k in range(spec.get("frames", 1)):
-        f = synth.render_frame(sc, synth.trajectory_pose(5 * k), w, h, seed=40 + k)
+        T = synth.pose_to_T((3.5, 0.3, 1.2), 0.1) if (spec.get("close_up_first") and k == 0) else synth.trajectory_pose(5 * k)
+        f = synth.render_frame(sc, T, w, h, seed=40 + k)   # (close_up_first: 0.45 m from a wall — bundles of thousands of points)
         if spec.get("cloud") == "axis":
             # rays with one or two zero components seen from an unrotated sensor (crossing times inf / NaN: the serial
             # caster of the owner lane instead of the parallel one), among ordinary ones

@@ -43,6 +43,9 @@ CASES = {
                                       cfg=dict(integration_order_mode=1, max_consecutive_ray_collisions=0, early_out_phase_growth=32)),
     "random_knobs_fast": dict(method=0, size=[64, 48], frames=2, random_combo=3, cfg=dict(early_out_phase_growth=32)),
     "random_knobs_merged": dict(method=1, size=[64, 48], frames=2, random_combo=5),
+    # k_bundles_long (two waves per >= 32-point bundle: the first frame looks at a wall from 0.45 m) and k_apply_xlong (four waves
+    # per run of more than 1024 updates: the voxels next to the sensor once a frame has more than 1024 bundles), frames in flight
+    "merged_long_bundles_and_long_runs": dict(method=1, size=[192, 144], frames=3, pipeline=2, max_tiles=8192, close_up_first=True),
 }
 
 
