@@ -124,6 +124,7 @@ struct Block {
   std::vector<ucontext_t> ctx;
   std::vector<void*> sp;   // fast switch: saved stack pointers of the fibers
   std::vector<void*> tfib;   // ThreadSanitizer build: its view of the fibers
+  std::vector<unsigned> tfib_uses;   // work-items each of them has run (a fiber is replaced every 256: its shadow call stack fills up)
   void* tsched = nullptr;
   void* sched_sp = nullptr;
   std::vector<char*> stacks;
@@ -283,7 +284,7 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
   b->sp.resize(nt);
 #if EMU_TSAN
   b->tsched = __tsan_get_current_fiber();
-  while (b->tfib.size() < nt) b->tfib.push_back(__tsan_create_fiber(0));
+  while (b->tfib.size() < nt) b->tfib.push_back(nullptr);
 #endif
   b->done.assign(nt, 0);
   b->waves.assign(nt / 64, Wave());
@@ -304,6 +305,17 @@ inline void launch(dim3 grid, dim3 block, const std::function<void()>& body) {
         }
         for (unsigned t = 0; t < nt; ++t) {
           b->done[t] = 0;
+#if EMU_TSAN
+          // a work-item leaves its fiber without returning through the frames it entered: the sanitizer's shadow call stack of
+          // a fiber that is used again keeps them (64 Ki entries: it overflows after some thousand work-items).  A fresh
+          // fiber every 256 uses.
+          if (b->tfib_uses.size() < b->tfib.size()) b->tfib_uses.resize(b->tfib.size(), 0u);
+          if (!b->tfib[t] || ++b->tfib_uses[t] >= 256u) {
+            if (b->tfib[t]) __tsan_destroy_fiber(b->tfib[t]);
+            b->tfib[t] = __tsan_create_fiber(0);
+            b->tfib_uses[t] = 0u;
+          }
+#endif
 #if defined(__has_feature)
 #if __has_feature(address_sanitizer)
           __asan_unpoison_memory_region(b->stacks[t], kStack);   // (frames abandoned by the previous fiber on this stack)
@@ -360,6 +372,8 @@ inline void prof_dump() {
 }
 inline void launch_named(const char* name, dim3 grid, dim3 block, const std::function<void()>& body) {
   static const bool on = getenv("EMU_PROFILE") != nullptr;
+  static const bool trace = getenv("EMU_TRACE") != nullptr;   // EMU_TRACE=1: every launch, before it runs (which kernel was it?)
+  if (trace) fprintf(stderr, "emu: launch %s grid %u x %u block %u\n", name, grid.x, grid.y, block.x);
   if (!on) { launch(grid, block, body); return; }
   static bool registered = false;
   if (!registered) { registered = true; atexit(prof_dump); }
