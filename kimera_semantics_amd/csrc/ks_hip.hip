@@ -260,7 +260,8 @@ struct ks_ctx {
   hipEvent_t eo_last_commit = nullptr;   // commit event of the previous frame (nullptr: nothing to wait for)
   std::atomic<size_t> eo_want_marks{0}, eo_want_x{0};   // capacities a failed frame asked for (grown by the caller's thread between frames)
   size_t eo_cap_marks = 0, eo_cap_x = 0; // per-slot capacities in use
-  uint64_t eo_fallbacks = 0;             // frames that fell back to the host-driven loop
+  std::atomic<uint64_t> eo_fallbacks{0}; // frames that fell back to the host-driven loop (counted by the thread that runs the tails)
+  uint64_t eo_fallbacks_seen = 0;        // ... as of the caller's last look
   std::atomic<int> eo_hopeless{0};       // consecutive frames the device loop gave up on for reasons growing a buffer does not cure
   bool eo_device_off = false;            // ... three of them: the context stays with the host-driven loop (one frame at a time)
   // merged in the reference's bundle order (ks_k_bundle_order.h): scratch of the rank computation, one slab
@@ -1234,17 +1235,24 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     HIPCHK(c, hipStreamSynchronize(st));
     EoCtl hctl;
     HIPCHK(c, hipMemcpy(&hctl, S.d_eo_ctl, sizeof(hctl), hipMemcpyDeviceToHost));
+    // (the largest request of the frames that failed since the buffers last grew: a later frame's smaller one must not replace it)
+    auto want_at_least = [](std::atomic<size_t>& w, size_t v) {
+      size_t cur = w.load(std::memory_order_relaxed);
+      while (cur < v && !w.compare_exchange_weak(cur, v, std::memory_order_relaxed)) {}
+    };
     if (hctl.fail & kEoFailMarks)
-      c->eo_want_marks.store(std::max<size_t>(2 * c->eo_cap_marks, (size_t)hctl.st.n_marks + (size_t)hctl.st.n_marks / 4), std::memory_order_relaxed);
+      want_at_least(c->eo_want_marks, std::max<size_t>(2 * c->eo_cap_marks, (size_t)hctl.st.n_marks + (size_t)hctl.st.n_marks / 4));
     // X marks are for the few rays the seed stopped too early; a frame that wants more of them than an eighth of its
     // marks (2 cm voxels / 10 m rays: the approximate set is overwhelmed, the seed is wrong on most rays) is not a sparse
     // problem, and neither is one whose lists are still long after the bulk rounds
     const bool x_dense = (hctl.fail & kEoFailX) && (size_t)hctl.n_x > (size_t)hctl.st.n_marks / 8;
     const bool dense = x_dense || (hctl.fail & kEoFailRounds);
-    if ((hctl.fail & kEoFailX) && !dense) c->eo_want_x.store(std::max<size_t>(4 * c->eo_cap_x, 4 * (size_t)hctl.n_x), std::memory_order_relaxed);
+    // (the count at the moment of the failure is a lower bound — the rounds stop there — and every growth costs the frames in
+    // flight a repetition on the host: grow generously, a node is 16 bytes)
+    if ((hctl.fail & kEoFailX) && !dense) want_at_least(c->eo_want_x, std::max<size_t>(16 * c->eo_cap_x, 8 * (size_t)hctl.n_x));
     if (dense) c->eo_hopeless.fetch_add(1, std::memory_order_relaxed);
     else if (!(hctl.fail & kEoFailChain)) c->eo_hopeless.store(0, std::memory_order_relaxed);
-    ++c->eo_fallbacks;
+    c->eo_fallbacks.fetch_add(1, std::memory_order_relaxed);
     Counters rcnt{};
     rcnt.n_rays = cnt.n_rays;
     HIPCHK(c, hipMemcpyAsync(c->d_retry_counters, &rcnt, sizeof(rcnt), hipMemcpyHostToDevice, st));
@@ -1580,6 +1588,16 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
   }
   // sorted integration order keeps its permutation in single buffers: not pipelined
   const bool pipelined = cfg.pipeline_frames && cfg.integration_order_mode != KS_ORDER_SORTED;
+  if (pipelined && c->eo_device && !c->eo_device_off) {
+    // A frame that fell back enters its marks when its tail runs, `pipeline_frames` calls after its stage B — so the frames
+    // in flight behind it find their predecessor's marks missing when their finisher runs and follow it to the host-driven
+    // loop, and so would every frame after them, for ever.  Complete what is in flight once and start afresh.
+    const uint64_t fb = c->eo_fallbacks.load(std::memory_order_relaxed);
+    if (fb != c->eo_fallbacks_seen) {
+      if ((rc = quiesce(c))) return rc;
+      c->eo_fallbacks_seen = c->eo_fallbacks.load(std::memory_order_relaxed);
+    }
+  }
 
   // frame-level bookkeeping of the fast integrator [K:src/semantic_tsdf_integrator_fast.cpp:165-170]
   if (cfg.method == KS_METHOD_FAST) {
@@ -1607,10 +1625,11 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
     if ((rc = ensure_points(c, n))) return rc;
   }
   if (c->eo_device && !c->eo_device_off) {
-    const size_t wm = c->eo_want_marks.load(std::memory_order_relaxed), wx = c->eo_want_x.load(std::memory_order_relaxed);
-    if (wm > c->eo_cap_marks || wx > c->eo_cap_x) {
-      if ((rc = quiesce(c))) return rc;
+    if (c->eo_want_marks.load(std::memory_order_relaxed) > c->eo_cap_marks || c->eo_want_x.load(std::memory_order_relaxed) > c->eo_cap_x) {
+      if ((rc = quiesce(c))) return rc;   // (the frames in flight may ask for more while they are completed)
+      const size_t wm = c->eo_want_marks.load(std::memory_order_relaxed), wx = c->eo_want_x.load(std::memory_order_relaxed);
       if ((rc = ensure_exact_slots(c, std::max(wm, c->eo_cap_marks), std::max(wx, c->eo_cap_x)))) return rc;
+      c->eo_fallbacks_seen = c->eo_fallbacks.load(std::memory_order_relaxed);
     }
   }
   if (!pipelined) {
@@ -2760,7 +2779,7 @@ int ks_early_out_stats(ks_ctx* c, uint64_t out[5]) {
   if (!c || !out) return KS_ERR_INVALID_ARG;
   out[0] = c->eo_frames;
   out[1] = c->eo_iterations;
-  out[2] = c->eo_fallbacks;
+  out[2] = c->eo_fallbacks.load(std::memory_order_relaxed);
   out[3] = (c->eo_device && !c->eo_device_off) ? 1 : 0;
   out[4] = (c->exact_early_out && c->cfg.pipeline_frames > 0) ? 1 : 0;
   return KS_OK;

@@ -77,6 +77,13 @@ def test_exact_early_out_overflow_falls_back_to_the_host_loop(emu_lib, pipeline)
     run_case(emu_lib, dict(method=0, size=[64, 48], frames=3, pipeline=pipeline), env_extra={"KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "16"})
 
 
+def test_a_fallback_does_not_drag_every_later_frame_with_it(emu_lib):
+    """Frames in flight behind a frame that fell back follow it (their predecessor's marks are not in the table yet); the next
+    call completes them all once, and the frames after that run on the device again: fewer fallbacks than frames."""
+    run_case(emu_lib, dict(method=0, size=[64, 48], frames=12, pipeline=4, fallbacks_below=7),
+             env_extra={"KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "4096"})
+
+
 @pytest.mark.parametrize("overlap", ["1", "0"])
 def test_axis_parallel_rays_under_the_early_out_equal_oracle(emu_lib, overlap):
     """Long rays with zero components (the owner lane's serial caster inside k_test's 64-voxel rounds), with the next round
