@@ -255,6 +255,7 @@ struct ks_ctx {
   // ... event-driven (the default; KS_EXACT_HOST_LOOP=1: every frame through the host-driven loop above)
   bool eo_device = false;
   int eo_bulk_rounds = 6;                // rounds enqueued as launches before the one-workgroup finisher takes over
+  std::atomic<int> eo_want_bulk{0};      // ... as a frame whose finisher was handed too long a list asks for (applied by the caller's thread between frames)
   uint32_t* d_eo_committed = nullptr;    // frames [0, *d_eo_committed) of the exact path have entered d_eo_plain
   uint32_t eo_frame_no = 0;              // frames launched through the exact path
   hipEvent_t eo_last_commit = nullptr;   // commit event of the previous frame (nullptr: nothing to wait for)
@@ -1246,7 +1247,14 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     // marks (2 cm voxels / 10 m rays: the approximate set is overwhelmed, the seed is wrong on most rays) is not a sparse
     // problem, and neither is one whose lists are still long after the bulk rounds
     const bool x_dense = (hctl.fail & kEoFailX) && (size_t)hctl.n_x > (size_t)hctl.st.n_marks / 8;
-    const bool dense = x_dense || (hctl.fail & kEoFailRounds);
+    // lists still long when the finisher takes over: more rounds as launches for the frames to come, while there is room
+    const bool more_bulk = (hctl.fail & kEoFailRounds) && !x_dense && c->eo_bulk_rounds < (int)kEoBulkMax;
+    if (more_bulk) {
+      const int w = std::min((int)kEoBulkMax, c->eo_bulk_rounds + std::max(4, c->eo_bulk_rounds / 2));
+      int cur = c->eo_want_bulk.load(std::memory_order_relaxed);
+      while (cur < w && !c->eo_want_bulk.compare_exchange_weak(cur, w, std::memory_order_relaxed)) {}
+    }
+    const bool dense = x_dense || ((hctl.fail & kEoFailRounds) && !more_bulk);
     // (the count at the moment of the failure is a lower bound — the rounds stop there — and every growth costs the frames in
     // flight a repetition on the host: grow generously, a node is 16 bytes)
     if ((hctl.fail & kEoFailX) && !dense) want_at_least(c->eo_want_x, std::max<size_t>(16 * c->eo_cap_x, 8 * (size_t)hctl.n_x));
@@ -1630,6 +1638,11 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
       const size_t wm = c->eo_want_marks.load(std::memory_order_relaxed), wx = c->eo_want_x.load(std::memory_order_relaxed);
       if ((rc = ensure_exact_slots(c, std::max(wm, c->eo_cap_marks), std::max(wx, c->eo_cap_x)))) return rc;
       c->eo_fallbacks_seen = c->eo_fallbacks.load(std::memory_order_relaxed);
+    }
+    if (const int wb = c->eo_want_bulk.load(std::memory_order_relaxed); wb > c->eo_bulk_rounds) {
+      if ((rc = quiesce(c))) return rc;   // (the helper thread reads eo_bulk_rounds while it runs a tail)
+      c->eo_bulk_rounds = wb;
+      ++c->buffers_epoch;                 // the captured launch sequences hold the old number of rounds
     }
   }
   if (!pipelined) {
