@@ -71,16 +71,11 @@ def test_event_driven_exact_early_out_equals_serial_oracle(emu_lib, spec):
     run_case(emu_lib, spec)
 
 
-@pytest.mark.parametrize("pipeline", [4])
-def test_exact_early_out_overflow_falls_back_to_the_host_loop(emu_lib, pipeline):
-    """marks and X marks that do not fit their buffers: host-driven loop for the frame (and those in flight behind it), buffers grow."""
-    run_case(emu_lib, dict(method=0, size=[64, 48], frames=3, pipeline=pipeline), env_extra={"KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "16"})
-
-
-def test_a_fallback_does_not_drag_every_later_frame_with_it(emu_lib):
-    """Frames in flight behind a frame that fell back follow it (their predecessor's marks are not in the table yet); the next
-    call completes them all once, and the frames after that run on the device again: fewer fallbacks than frames."""
-    run_case(emu_lib, dict(method=0, size=[64, 48], frames=12, pipeline=4, fallbacks_below=7),
+def test_overflow_falls_back_to_the_host_loop_and_the_device_loop_takes_over_again(emu_lib):
+    """Marks that do not fit their buffer: host-driven loop for the frame AND for the frames in flight behind it (their
+    predecessor's marks are not in the table when their finisher runs); the next call completes them all once, the buffers
+    grow, and the frames after that run on the device again: fewer fallbacks than frames, same map."""
+    run_case(emu_lib, dict(method=0, size=[48, 36], frames=9, pipeline=4, fallbacks_below=7),
              env_extra={"KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "4096"})
 
 
