@@ -79,12 +79,12 @@ std::string g_create_error;
 // ks_config.pipeline_frames the stages of a frame run on separate streams,
 //   A  points -> sort -> dedup / bundles                  (stream)
 //   B  early-out phases, scan, emission, snapshot          (one of the march streams: frame % n_march)
-//   T  init tiles -> sort pairs -> find_long -> apply       (stream_tail; k_apply_long beside it on stream_long),
-//      enqueued by a helper thread 1..4 calls later
+//   T  init tiles -> sort pairs -> find_long -> apply       (stream_tail; k_apply_long beside it on stream_long, k_apply_xlong
+//      on stream_xlong), enqueued by a helper thread 1..8 calls later
 // so that A, B and T of neighbouring frames execute concurrently: B is a chain of small dependent launches
 // (replayed as a graph captured once per slot), the sorts are bound by dependent-launch latency, the voxel
 // update by memory latency, and neither A nor B touches voxel data.  The host's one wait per frame (for the
-// snapshot that sizes T) never idles the GPU.  Six slots rotate; stage A of a frame waits for the tail (and
+// snapshot that sizes T) never idles the GPU.  Twelve slots rotate; stage A of a frame waits for the tail (and
 // the long runs) that last used its slot.
 constexpr int kMaxLag = 8;           // largest ks_config.pipeline_frames
 constexpr int kSlots = kMaxLag + 4;  // frame slots: the tail may lag up to kMaxLag calls
