@@ -40,7 +40,16 @@ enum {
 
 enum { KS_METHOD_FAST = 0, KS_METHOD_MERGED = 1 };          /* factory names "fast"/"merged", semantic_tsdf_integrator_factory.h:49-54 */
 enum { KS_COLOR_MODE_COLOR = 0, KS_COLOR_MODE_SEMANTIC = 1, KS_COLOR_MODE_SEMANTIC_PROBABILITY = 2 }; /* ColorMode, semantic_integrator_base.h:54-58 */
-enum { KS_ORDER_MIXED = 0, KS_ORDER_SORTED = 1 };           /* voxblox integration_order_mode */
+/* voxblox integration_order_mode (vxb::ThreadSafeIndexFactory::get, called at semantic_tsdf_integrator_fast.cpp:172-174 and
+ * semantic_tsdf_integrator_merged.cpp:115-117).  Voxblox is not part of the reference tree (un-pinned upstream), so the
+ * permutation behind "mixed" cannot be read there; both readings of MixedThreadSafeIndex::getNextIndexImpl are implemented,
+ * with q = N / 1024 and positions s >= q * 1024 mapping to themselves:
+ *   KS_ORDER_MIXED             idx = (s % q) * 1024 + s / q     upstream as published (number_of_groups_ = N / step_size_,
+ *                              group_num = s % number_of_groups_, position_in_group = s / number_of_groups_)
+ *   KS_ORDER_MIXED_1024_GROUPS idx = (s % 1024) * q + s / 1024  (what rounds 1-4 of this library assumed)
+ * The C++ adapter does not guess: it reads the sequence of the ThreadSafeIndexFactory it is compiled against and selects
+ * the matching value, or aborts (host/hip_semantic_tsdf_integrator.cpp: probe_mixed_order). */
+enum { KS_ORDER_MIXED = 0, KS_ORDER_SORTED = 1, KS_ORDER_MIXED_1024_GROUPS = 2 };
 /* merged: the order the ray bundles are integrated in.
  * REFERENCE (default): the iteration order of the libstdc++ std::unordered_map the reference keeps them in
  *   (semantic_tsdf_integrator_merged.cpp:108-124, 200-232; VoxelMap, common.h:37) — what the reference does at

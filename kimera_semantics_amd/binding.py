@@ -18,7 +18,7 @@ NUM_LABELS = 21
 
 KS_METHOD_FAST, KS_METHOD_MERGED = 0, 1
 KS_COLOR_MODE_COLOR, KS_COLOR_MODE_SEMANTIC, KS_COLOR_MODE_SEMANTIC_PROBABILITY = 0, 1, 2
-KS_ORDER_MIXED, KS_ORDER_SORTED = 0, 1
+KS_ORDER_MIXED, KS_ORDER_SORTED, KS_ORDER_MIXED_1024_GROUPS = 0, 1, 2   # include/ks_hip.h
 KS_BUNDLE_ORDER_REFERENCE, KS_BUNDLE_ORDER_CANONICAL = 0, 1
 KS_EARLY_OUT_EXACT = 1   # value of KsConfig.early_out_phase_growth: the reference's serial early-out result
 KS_ERR_LABEL_RANGE, KS_ERR_PROBABILITY, KS_ERR_POOL_FULL, KS_ERR_NO_DEVICE, KS_ERR_UNSUPPORTED = -2, -3, -5, -7, -8

@@ -423,7 +423,20 @@ int ensure_bundle_order(ks_ctx* c, size_t cap) {
   return KS_OK;
 }
 
-// phase boundaries (in generations of 1024 integration positions) of the ordered-phase early-out
+// chains of the ordered-phase schedule = the groups of the frame's integration order (ks_types.h: FrameParams::chains)
+inline uint32_t order_chains(int order_mode, size_t n) {
+  const size_t q = n / kOrderStep;
+  return (order_mode == KS_ORDER_MIXED && q >= 1) ? (uint32_t)q : kOrderStep;
+}
+// ... and what a frame of at most `cap` points can reach: stage B's launches are sized by the slot's capacity
+inline uint32_t order_chains_cap(int order_mode, size_t cap) { return std::max(order_chains(order_mode, cap), order_mode == KS_ORDER_MIXED ? kOrderStep : 0u); }
+inline uint32_t order_generations_cap(int order_mode, size_t cap) {
+  // KS_ORDER_MIXED: n / (n / 1024) < 2048 generations for every n >= 1024; one generation below that.
+  // The other orders: 1024 chains, ceil(n / 1024) generations.
+  if (order_mode == KS_ORDER_MIXED) return cap >= kOrderStep ? 2u * kOrderStep - 1u : 1u;
+  return (uint32_t)((cap + kOrderStep - 1) / kOrderStep);
+}
+// phase boundaries (in generations: one integration position per chain) of the ordered-phase early-out
 std::vector<uint32_t> phase_bounds(uint32_t n_gen, int growth) {
   std::vector<uint32_t> b{0};
   for (;;) {
@@ -662,7 +675,8 @@ void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipS
   if (c->uses_early_out && part != 2) {
     // ordered-phase early-out: per phase, k_test decides how far the phase's rays get against the set as it
     // stood when the phase began and enters their marks (ks_k_march.h)
-    const uint32_t n_gen = (uint32_t)((n + kChains - 1) / kChains);
+    const uint32_t n_gen = order_generations_cap(cfg.integration_order_mode, n);
+    const uint32_t chains_cap = order_chains_cap(cfg.integration_order_mode, n);
     const std::vector<uint32_t> B = phase_bounds(n_gen, cfg.early_out_phase_growth);
     for (size_t j = 0; j < B.size(); ++j) {
       const uint32_t g0 = B[j], g1 = (j + 1 < B.size()) ? B[j + 1] : n_gen;  // k_test ends the frame's last phase at ITS n
@@ -670,7 +684,9 @@ void enqueue_stage_b(ks_ctx* c, const BatchView& V, uint32_t nb, bool wide, hipS
       const uint32_t steps_cap = (uint32_t)((steps_max + 3) & ~(size_t)3);
       const size_t lds_wave = (size_t)test_lds_words64(steps_cap) * sizeof(unsigned long long);
       const uint32_t wpb = lds_wave * 4 <= 60 * 1024 ? 4u : lds_wave * 2 <= 60 * 1024 ? 2u : 1u;  // wavefronts per block
-      const dim3 grid(kChains * n_sub / wpb, nb), block(64 * wpb);
+      // (a frame with fewer chains than the capacity allows finds its (chain, sub-run) pairs among the first wavefronts; the rest
+      // see no live ray and end)
+      const dim3 grid((chains_cap * n_sub + wpb - 1) / wpb, nb), block(64 * wpb);
       if (c->test_overlap) hipLaunchKernelGGL(k_test<true>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap);
       else hipLaunchKernelGGL(k_test<false>, grid, block, lds_wave * wpb, sm, V, g0, g1, steps_cap);
     }
@@ -1066,7 +1082,13 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   F.obs_tag_lo = c->obs_tag_lo;
   F.max_collisions = cfg.max_consecutive_ray_collisions;
   F.n = (uint32_t)n;
-  F.per_group = (uint32_t)(n / 1024);
+  {
+    const uint32_t q = (uint32_t)(n / kOrderStep);
+    const bool by_1024 = c->cfg.integration_order_mode == KS_ORDER_MIXED_1024_GROUPS;
+    F.order_groups = q == 0 ? 1u : by_1024 ? kOrderStep : q;
+    F.order_per = q == 0 ? 0u : by_1024 ? q : kOrderStep;
+    F.chains = order_chains(c->cfg.integration_order_mode, n);
+  }
   F.carving = cfg.voxel_carving_enabled;
   F.allow_clear = cfg.allow_clear;
   F.freespace = freespace;
@@ -1822,10 +1844,15 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     g_create_error = "fast integrator with the early-out enabled supports clear_checks_every_n_frames <= 256";
     return KS_ERR_UNSUPPORTED;
   }
-  // The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams that share a queue
-  // run one after the other: a pipelined context keeps up to seven streams busy.  Takes effect if this is the process's
-  // first use of the HIP runtime; a value the caller has set is left alone.  Scheduling only — never a result.
-  (void)setenv("GPU_MAX_HW_QUEUES", "8", /*overwrite=*/0);
+  if (cfg->integration_order_mode != KS_ORDER_MIXED && cfg->integration_order_mode != KS_ORDER_SORTED &&
+      cfg->integration_order_mode != KS_ORDER_MIXED_1024_GROUPS) {
+    g_create_error = "integration_order_mode must be KS_ORDER_MIXED, KS_ORDER_SORTED or KS_ORDER_MIXED_1024_GROUPS";
+    return KS_ERR_INVALID_ARG;
+  }
+  // (The runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues, default 4, and kernels of streams that share a queue
+  // run one after the other; a pipelined context keeps up to seven streams busy and runs best with 8.  That is the HOST
+  // PROCESS's setting, read by the HIP runtime when it initialises: the library does not touch the environment —
+  // INTEGRATION.md 4.2 says where the embedding process sets it; bench.py and the demos do so before their first HIP call.)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device_id >= ndev) {
     g_create_error = "no HIP device (the MI355X path has no CPU fallback)";

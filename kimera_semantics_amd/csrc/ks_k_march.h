@@ -194,13 +194,14 @@ struct BatchView {
   SlotView s[kBatchMax];
 };
 
-constexpr uint32_t kChains = 1024;      // = the 1024 groups of the "mixed" integration order
+constexpr uint32_t kOrderStep = 1024;   // vxb::MixedThreadSafeIndex::step_size_
 constexpr uint32_t kPrivSlots = 1024;   // chain-private direct-mapped set (8 KiB of LDS per chain)
 constexpr uint32_t kCntBroke = 1u << 31;  // cnt[] flag: the ray stopped on a voxel it visited but did not update
 
 // ------------------------------------------------------------------------------------------
 // k_test — ORDERED-PHASE early-out (the CPU checker under oracle/ restates it as integrate_fast_phased):
-// integration position s -> chain s % 1024, generation s / 1024; one launch per phase of generations
+// integration position s -> chain s % chains, generation s / chains (chains = the groups of the "mixed" order,
+// FrameParams::chains: N / 1024 in the upstream form, 1024 in the other one); one launch per phase of generations
 // [g0, g1).  Inside a phase a chain's LIVE rays (those that survived the start-voxel dedup: nearly all of the
 // first generations, one in five to one in twenty of the late ones) are cut, in generation order, into SUB-RUNS
 // of 16; ONE WAVEFRONT owns a (chain, sub-run) and resolves its rays in generation order.  The launch covers the worst
@@ -308,7 +309,8 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
   const Counters* C = sv.C;
   const FrameParams F = *sv.F;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
   obs_global_u64* observed = (obs_global_u64*)(unsigned long long*)F.observed;   // [slot] = {newest, older}
-  const uint32_t phase_pos0 = g0 * kChains;  // marks at positions >= this one belong to the phase being run
+  const uint32_t n_chains = F.chains;
+  const uint32_t phase_pos0 = g0 * n_chains;  // marks at positions >= this one belong to the phase being run
   // slot content as it stood when the phase began (see the set's description above)
   bool my_save = false;  // this lane has issued a save since the wavefront last waited for its saves
   // (in two steps, so that a batch of entries can be looked at before the first save goes out: a wait for the next
@@ -341,9 +343,9 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
   // (looked at below: this load and the live flags are in flight together; an atomic load stays where it is written)
   const uint32_t frame_err = __hip_atomic_load(&C->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const uint32_t w = blockIdx.x * (blockDim.x >> 6) + wave;
-  const uint32_t chain = w % kChains, sub = w / kChains;
+  const uint32_t chain = w % n_chains, sub = w / n_chains;
   {  // the launch covers the slot's capacity: the frame's last generation ends the last phase
-    const uint32_t n_gen = (F.n + kChains - 1u) / kChains;
+    const uint32_t n_gen = (F.n + n_chains - 1u) / n_chains;
     if (g1 > n_gen) g1 = n_gen;
   }
   // ---- which rays: my_gen = generation of the ray lane l < 16 owns (~0u: none) ----
@@ -359,8 +361,8 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
       for (int q = 0; q < 4; ++q) {
         // (unconditional loads from a clamped address: a load under a branch would be waited for before the next is issued)
         const uint32_t g = gb + 64u * (uint32_t)q + lane;
-        const bool in = g < g1 && (uint64_t)g * kChains + chain < F.n;
-        fl[q] = live[in ? (uint64_t)g * kChains + chain : (uint64_t)0];
+        const bool in = g < g1 && (uint64_t)g * n_chains + chain < F.n;
+        fl[q] = live[in ? (uint64_t)g * n_chains + chain : (uint64_t)0];
         if (!in) fl[q] = 0;
       }
 #pragma unroll
@@ -387,7 +389,7 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
   Dda dda{};
   int my_steps = -1;
   {
-    const uint64_t p = (uint64_t)my_gen * kChains + chain;
+    const uint64_t p = (uint64_t)my_gen * n_chains + chain;
     const bool is_live = my_gen != ~0u;
     if (is_live) {
       const RayDesc d = rays[ray_index(F, (uint32_t)p)];
@@ -444,7 +446,7 @@ __global__ void __launch_bounds__(kTestThreads) k_test(BatchView V, uint32_t g0,
     const uint32_t j = (uint32_t)__ffs((int)todo) - 1u;
     const int steps_j = (int)rinfo[j];
     const uint32_t hs = rinfo[16 + j];
-    const uint32_t gen_j = (uint32_t)__shfl((int)my_gen, (int)j), pos_j = gen_j * kChains + chain;
+    const uint32_t gen_j = (uint32_t)__shfl((int)my_gen, (int)j), pos_j = gen_j * n_chains + chain;
     const bool valid = lane < 16 && (int)lane <= steps_j;
     unsigned long long k = 0ull;
     bool hit = false;

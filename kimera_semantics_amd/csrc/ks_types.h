@@ -150,7 +150,14 @@ struct FrameParams {
   uint64_t* observed;            // the early-out table this frame uses (one per march stream)
   int32_t max_collisions;
   uint32_t n;                // points this frame
-  uint32_t per_group;        // n / 1024 (mixed order)
+  // "mixed" order (vxb::MixedThreadSafeIndex): position s < order_groups * order_per is point
+  // (s % order_groups) * order_per + s / order_groups, later positions are their own point.
+  //   KS_ORDER_MIXED (upstream as published): order_groups = n / 1024, order_per = 1024
+  //   KS_ORDER_MIXED_1024_GROUPS:             order_groups = 1024,     order_per = n / 1024
+  // (n < 1024: order_groups = 1, order_per = 0 — the identity).  The groups are the chains of the ordered-phase
+  // schedule (ks_k_march.h): position s = chain s % chains, generation s / chains.
+  uint32_t order_groups, order_per;
+  uint32_t chains;
   int carving, allow_clear, freespace, use_const_weight;
   int method, color_mode, early_out, sorted_order;
   int n_dynamic;
@@ -168,8 +175,8 @@ struct FrameParams {
 __device__ __forceinline__ uint32_t point_order(const FrameParams& F, const uint32_t* order, uint32_t p) {
   // vxb::MixedThreadSafeIndex — [K:src/semantic_tsdf_integrator_fast.cpp:172-174]
   if (F.sorted_order) return order[p];
-  if (1024u * F.per_group <= p) return p;
-  return (p % 1024u) * F.per_group + p / 1024u;
+  if (F.order_groups * F.order_per <= p) return p;
+  return (p % F.order_groups) * F.order_per + p / F.order_groups;
 }
 
 // Anti-grazing (vxb Config::enable_anti_grazing, off by default): a bundle's ray skips voxels that
@@ -201,8 +208,8 @@ __device__ __forceinline__ uint32_t ray_index(const FrameParams& F, uint32_t p) 
 // inverse of point_order: integration position of the point stored at index idx
 __device__ __forceinline__ uint32_t point_position(const FrameParams& F, const uint32_t* inv_order, uint32_t idx) {
   if (F.sorted_order) return inv_order[idx];
-  if (1024u * F.per_group <= idx) return idx;
-  return (idx % F.per_group) * 1024u + idx / F.per_group;
+  if (F.order_groups * F.order_per <= idx) return idx;
+  return (idx % F.order_per) * F.order_groups + idx / F.order_per;
 }
 
 __host__ __device__ __forceinline__ uint64_t pack_tile(int tx, int ty, int tz) {

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "hip_semantic_tsdf_integrator.h"
@@ -24,6 +25,16 @@
 namespace vxb = voxblox;
 
 int main(int argc, char** argv) {
+#ifdef KS_DEMO_REAL_FACTORY
+  // (tests) which of its two permutations the reference-side Voxblox shim's "mixed" index produces — the adapter must
+  // FIND OUT, it is not told (oracle/ref_shim/voxblox/integrator/integrator_utils.h)
+  if (const char* form = std::getenv("KS_DEMO_SHIM_MIXED_FORM")) vxb::shim_mixed_order_form() = std::atoi(form);
+#endif
+  if (argc >= 2 && std::string(argv[1]) == "--probe-order") {
+    // what HipSemanticTsdfIntegrator::probeMixedOrder() reads from the ThreadSafeIndexFactory of this build (no GPU needed)
+    std::printf("probeMixedOrder: %d\n", kimera::HipSemanticTsdfIntegrator::probeMixedOrder());
+    return 0;
+  }
   if (argc < 5) {
     std::fprintf(stderr, "usage: %s method labels.csv in.bin out.bin [color_mode] [max_collisions]\n", argv[0]);
     return 2;

@@ -9,8 +9,43 @@
 #include <algorithm>
 
 #include <voxblox/utils/timing.h>
+// Builds against a real Voxblox tree (or the reference-side shim, which has the same class) can ASK the integration order
+// instead of assuming it: see probeMixedOrder below.
+#if defined(__has_include)
+#if __has_include(<voxblox/integrator/integrator_utils.h>)
+#include <voxblox/integrator/integrator_utils.h>
+#define KS_HAVE_VOXBLOX_THREAD_SAFE_INDEX 1
+#endif
+#endif
 
 namespace kimera {
+
+// Which permutation does vxb::ThreadSafeIndexFactory::get("mixed", ...) — the call the CPU integrators make at
+// [K:src/semantic_tsdf_integrator_fast.cpp:172-174] and [K:src/semantic_tsdf_integrator_merged.cpp:115-117] — hand out in THIS
+// build?  Voxblox is an un-pinned upstream dependency of the reference; the order decides which ray meets which ray's
+// early-out marks and the f32 summation order of every voxel, i.e. every bit of the map.  The real index is driven over a
+// cloud of 5 * 1024 + 7 points (groups, group size and the unpermuted tail all differ between the two known forms) and
+// compared with both closed forms of include/ks_hip.h.
+int HipSemanticTsdfIntegrator::probeMixedOrder() {
+#ifdef KS_HAVE_VOXBLOX_THREAD_SAFE_INDEX
+  const size_t n = 5 * 1024 + 7, q = n / 1024;
+  const vxb::Pointcloud cloud(n, vxb::Point(0.0f, 0.0f, 1.0f));
+  std::unique_ptr<vxb::ThreadSafeIndex> index_getter(vxb::ThreadSafeIndexFactory::get("mixed", cloud));
+  bool upstream = true, by_1024 = true;
+  size_t idx = 0, s = 0;
+  for (; index_getter->getNextIndex(&idx); ++s) {
+    if (s >= n) return -1;
+    const size_t a = s < q * 1024 ? (s % q) * 1024 + s / q : s;
+    const size_t b = s < q * 1024 ? (s % 1024) * q + s / 1024 : s;
+    upstream = upstream && idx == a;
+    by_1024 = by_1024 && idx == b;
+  }
+  if (s != n) return -1;
+  return upstream ? KS_ORDER_MIXED : by_1024 ? KS_ORDER_MIXED_1024_GROUPS : -1;
+#else
+  return -2;  // no Voxblox in this build (the interface-only stand-in headers): nothing to ask
+#endif
+}
 
 namespace {
 ks_config makeConfig(HipSemanticTsdfIntegrator::Method method, const vxb::TsdfIntegratorBase::Config& c,
@@ -34,8 +69,15 @@ ks_config makeConfig(HipSemanticTsdfIntegrator::Method method, const vxb::TsdfIn
   k.start_voxel_subsampling_factor = c.start_voxel_subsampling_factor;
   k.max_consecutive_ray_collisions = c.max_consecutive_ray_collisions;
   k.clear_checks_every_n_frames = c.clear_checks_every_n_frames;
-  if (c.integration_order_mode == "mixed") k.integration_order_mode = KS_ORDER_MIXED;
-  else if (c.integration_order_mode == "sorted") k.integration_order_mode = KS_ORDER_SORTED;
+  if (c.integration_order_mode == "mixed") {
+    static const int probed = HipSemanticTsdfIntegrator::probeMixedOrder();
+    if (probed == -1)
+      LOG(FATAL) << "vxb::ThreadSafeIndexFactory::get(\"mixed\", ...) of this build produces neither of the two permutations the "
+                    "GPU integrator implements (include/ks_hip.h: KS_ORDER_MIXED, KS_ORDER_MIXED_1024_GROUPS): its results would "
+                    "not be the CPU integrators'.";
+    // (-2: built without Voxblox, against the stand-in headers — the form upstream publishes; o.mixed_order overrides)
+    k.integration_order_mode = o.mixed_order >= 0 ? o.mixed_order : probed >= 0 ? probed : KS_ORDER_MIXED;
+  } else if (c.integration_order_mode == "sorted") k.integration_order_mode = KS_ORDER_SORTED;
   else LOG(FATAL) << "Unknown integration order mode: '" << c.integration_order_mode << "'!";
   k.integrator_threads = static_cast<int32_t>(c.integrator_threads);
   k.method = static_cast<int32_t>(method);

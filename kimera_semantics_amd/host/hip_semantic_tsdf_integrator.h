@@ -51,7 +51,14 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
     /// says (with more threads the reference itself is racy: any of its results is within its own spread of this
     /// one); 16..4096 = the ordered-phase schedule alone (a few launches cheaper, not the reference's map).
     int early_out_phase_growth = 0;
+    /// integration_order_mode "mixed": -1 (default) = the permutation probeMixedOrder() reads from the Voxblox this build
+    /// links (LOG(FATAL) if it is neither known form); KS_ORDER_MIXED / KS_ORDER_MIXED_1024_GROUPS force one.
+    int mixed_order = -1;
   };
+
+  /// The permutation vxb::ThreadSafeIndexFactory::get("mixed", ...) of this build hands out: KS_ORDER_MIXED,
+  /// KS_ORDER_MIXED_1024_GROUPS, -1 (neither), -2 (built against the interface-only stand-in headers: no Voxblox to ask).
+  static int probeMixedOrder();
 
   HipSemanticTsdfIntegrator(Method method, const Config& config, const SemanticConfig& semantic_config,
                             vxb::Layer<vxb::TsdfVoxel>* tsdf_layer, vxb::Layer<SemanticVoxel>* semantic_layer,

@@ -339,15 +339,27 @@ struct IndexGetter {
   size_t n = 0;
   bool sorted = false;
   std::vector<size_t> sorted_indices;
-  static constexpr size_t kGroups = 1024;
+  int mode_ = KO_ORDER_MIXED;
+  static constexpr size_t kStep = 1024;
 
-  static size_t mixed_index(size_t s, size_t n) {
-    const size_t per_group = n / kGroups;
-    if (kGroups * per_group <= s) return s;
-    return (s % kGroups) * per_group + s / kGroups;
+  // "mixed": Voxblox's MixedThreadSafeIndex::getNextIndexImpl.  Voxblox is not in /root/reference (un-pinned upstream),
+  // so both readings of it exist (ks_oracle.h: KO_ORDER_MIXED = upstream as published, KO_ORDER_MIXED_1024_GROUPS = what
+  // this repository assumed until round 4); the shim behind the real Kimera sources has the same switch.
+  static size_t mixed_index(size_t s, size_t n, int mode) {
+    const size_t q = n / kStep;
+    if (q * kStep <= s) return s;
+    if (mode == KO_ORDER_MIXED_1024_GROUPS) return (s % kStep) * q + s / kStep;
+    return (s % q) * kStep + s / q;   // group_num * step_size_ + position_in_group, number_of_groups_ = q
+  }
+  // the groups of the order = the chains of the ordered-phase schedule (position s: chain s % chains, generation
+  // s / chains); a frame of fewer than 1024 points (identity order) and the sorted order are cut into 1024 chains
+  static uint32_t mixed_chains(size_t n, int mode) {
+    const size_t q = n / kStep;
+    return (mode == KO_ORDER_MIXED && q >= 1) ? (uint32_t)q : (uint32_t)kStep;
   }
   void init(int mode, const float* xyz, size_t num) {
     n = num;
+    mode_ = mode;
     sorted = (mode == KO_ORDER_SORTED);
     if (sorted) {
       // upstream uses std::sort on (idx, squaredNorm) by norm; ties are unspecified
@@ -365,7 +377,7 @@ struct IndexGetter {
   bool next(size_t* idx) {
     const size_t s = atomic_idx.fetch_add(1);
     if (s >= n) return false;
-    *idx = sorted ? sorted_indices[s] : mixed_index(s, n);
+    *idx = sorted ? sorted_indices[s] : mixed_index(s, n, mode_);
     return true;
   }
 };
@@ -608,10 +620,11 @@ struct ko_ctx {
   // [K:semantic_tsdf_integrator_fast.cpp:110-122] is enabled, so that the GPU can be checked bit for
   // bit against a CPU.  The reference's loop is inherently serial (ray k stops on marks rays 1..k-1
   // left in voxel_observed_approx_set_); the schedule keeps the dependencies that matter and cuts the rest:
-  //   * integration position s -> chain c = s % 1024 (the "mixed" order's group, i.e. a run of
-  //     neighbouring points) and generation g = s / 1024;
+  //   * integration position s -> chain c = s % chains (the "mixed" order's group, i.e. a run of
+  //     neighbouring points; chains = N / 1024 in the upstream form of the order, 1024 in the other form, in sorted
+  //     order and for frames of fewer than 1024 points: IndexGetter::mixed_chains) and generation g = s / chains;
   //   * generations are cut into phases [B_j, B_j+1), B_0 = 0, B_j+1 = B_j + max(1, B_j (growth-16)/16);
-  //   * within a phase the 1024 chains are independent, and a chain's LIVE rays of the phase (those that
+  //   * within a phase the chains are independent, and a chain's LIVE rays of the phase (those that
   //     survived the start-voxel dedup), taken in generation order, are cut into sub-runs of 16 that are
   //     independent too; a sub-run walks its rays in generation order;
   //   * a ray tests every voxel of its path against: the marks the PREVIOUS rays of its own sub-run made
@@ -623,7 +636,7 @@ struct ko_ctx {
   //     "contain" hash 0: that one-voxel artefact is not reproduced; marks are stored with a flag bit).
   // Start-voxel dedup, the ray caster, the consecutive-collision rule and the per-voxel update order
   // (integration position) are the reference's.  growth 16 = one generation per phase.
-  static constexpr uint32_t kChains = 1024, kPrivSlots = 1024, kSubRun = 16;
+  static constexpr uint32_t kPrivSlots = 1024, kSubRun = 16;
   static constexpr size_t kMarkFlag = size_t(1) << 40;  // set in every mark the phased schedule stores in the shared set
   static std::vector<uint32_t> phase_bounds(uint32_t n_gen, int growth) {
     std::vector<uint32_t> b{0};
@@ -654,6 +667,7 @@ struct ko_ctx {
       if (!start_voxel_set.replace_hash(LongIndexHash()(g))) continue;
       rays.push_back({point_idx, p, point_G, is_clearing, 0});
     }
+    const uint32_t kChains = IndexGetter::mixed_chains(n, cfg.integration_order_mode);
     const uint32_t n_gen = (uint32_t)((n + kChains - 1) / kChains);
     const std::vector<uint32_t> B = phase_bounds(n_gen, cfg.early_out_phase_growth);
     ApproxHashSet& S = voxel_observed_set;
@@ -1314,7 +1328,8 @@ size_t ko_sim_fixpoint(const ko_config* cfg, const float Tq[7], const float* xyz
   } else {
     // chain schedule, phases of generations doubling (seed_mode = growth in 1/16ths, 32 = doubling), private set per chain and phase
     std::vector<uint32_t> B{0};
-    const uint32_t n_gen = (uint32_t)((n + 1023) / 1024);
+    const uint32_t chains = IndexGetter::mixed_chains(n, cfg->integration_order_mode);
+    const uint32_t n_gen = (uint32_t)((n + chains - 1) / chains);
     for (;;) {
       const uint64_t inc = std::max<uint64_t>(1, (uint64_t)B.back() * (seed_mode - 16) / 16);
       if (B.back() + inc >= n_gen) break;
@@ -1327,8 +1342,8 @@ size_t ko_sim_fixpoint(const ko_config* cfg, const float Tq[7], const float* xyz
       std::map<uint32_t, std::unordered_map<uint32_t, size_t>> priv;
       std::vector<std::pair<uint32_t, size_t>> marks;
       size_t r1 = r0;
-      for (; r1 < R && posv[r1] / 1024 < g1; ++r1) {
-        auto& pm = priv[posv[r1] % 1024];
+      for (; r1 < R && posv[r1] / chains < g1; ++r1) {
+        auto& pm = priv[posv[r1] % chains];
         int64_t cc = 0;
         uint32_t vis = 0;
         std::vector<std::pair<uint32_t, size_t>> own;
@@ -1579,7 +1594,8 @@ void ko_log_likelihood(float p_match, float* out) {
     for (int j = 0; j < kNumLabels; ++j) out[i * kNumLabels + j] = tmp.L[i][j];
 }
 uint32_t ko_long_index_hash(const int64_t idx[3]) { return index_hash(idx[0], idx[1], idx[2]); }
-size_t ko_mixed_index(size_t s, size_t n) { return IndexGetter::mixed_index(s, n); }
+size_t ko_mixed_index(size_t s, size_t n, int mode) { return IndexGetter::mixed_index(s, n, mode); }
+uint32_t ko_mixed_chains(size_t n, int mode) { return IndexGetter::mixed_chains(n, mode); }
 void ko_update_tsdf_voxel(const ko_config* cfg, const float origin[3], const float point_G[3],
                           const int64_t vi[3], const uint8_t rgba[4], float weight, float* distance,
                           float* voxel_weight, uint8_t voxel_rgba[4]) {

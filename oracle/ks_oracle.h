@@ -37,7 +37,12 @@ extern "C" {
 
 enum { KO_METHOD_FAST = 0, KO_METHOD_MERGED = 1 };
 enum { KO_COLOR_MODE_COLOR = 0, KO_COLOR_MODE_SEMANTIC = 1, KO_COLOR_MODE_SEMANTIC_PROBABILITY = 2 };
-enum { KO_ORDER_MIXED = 0, KO_ORDER_SORTED = 1 };
+/* "mixed" = Voxblox's MixedThreadSafeIndex (un-pinned upstream, absent from /root/reference).  Two readings exist:
+ *   KO_ORDER_MIXED             idx = (s % q) * 1024 + s / q, q = N / 1024   (upstream as published: number_of_groups_ = N /
+ *                              step_size_, group_num = s % number_of_groups_, position_in_group = s / number_of_groups_)
+ *   KO_ORDER_MIXED_1024_GROUPS idx = (s % 1024) * q + s / 1024              (rounds 1-4 of this repository)
+ * positions >= q * 1024 map to themselves in both. */
+enum { KO_ORDER_MIXED = 0, KO_ORDER_SORTED = 1, KO_ORDER_MIXED_1024_GROUPS = 2 };
 /* merged: order in which bundles are integrated.
  * REFERENCE = iteration order of std::unordered_map<GlobalIndex, vector, LongIndexHash>
  *             (what the reference does, semantic_tsdf_integrator_merged.cpp:210-231,
@@ -125,7 +130,8 @@ size_t ko_cast_ray(const float origin[3], const float point_G[3], int is_clearin
                    float truncation, int cast_from_origin, int64_t* out_xyz, size_t cap);
 void ko_log_likelihood(float p_match, float out_21x21_rowmajor[KO_NUM_LABELS * KO_NUM_LABELS]);
 uint32_t ko_long_index_hash(const int64_t idx[3]);
-size_t ko_mixed_index(size_t sequential_idx, size_t num_elements);
+size_t ko_mixed_index(size_t sequential_idx, size_t num_elements, int mode /* KO_ORDER_MIXED* */);
+uint32_t ko_mixed_chains(size_t num_elements, int mode); /* chains of the ordered-phase schedule */
 /* One updateTsdfVoxel step on a caller-held voxel (distance, weight, rgba). */
 void ko_update_tsdf_voxel(const ko_config* cfg, const float origin[3], const float point_G[3],
                           const int64_t voxel_idx[3], const uint8_t rgba[4], float weight,

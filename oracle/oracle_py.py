@@ -84,8 +84,10 @@ def lib():
         L.ko_log_likelihood.argtypes = [C.c_float, C.c_void_p]
         L.ko_long_index_hash.argtypes = [C.c_void_p]
         L.ko_long_index_hash.restype = C.c_uint32
-        L.ko_mixed_index.argtypes = [C.c_size_t, C.c_size_t]
+        L.ko_mixed_index.argtypes = [C.c_size_t, C.c_size_t, C.c_int]
         L.ko_mixed_index.restype = C.c_size_t
+        L.ko_mixed_chains.argtypes = [C.c_size_t, C.c_int]
+        L.ko_mixed_chains.restype = C.c_uint32
         L.ko_update_tsdf_voxel.argtypes = [C.POINTER(KoConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ko_blend_two_colors.argtypes = [C.c_void_p, C.c_float, C.c_void_p, C.c_float, C.c_void_p]
@@ -228,8 +230,15 @@ def long_index_hash(idx):
     return int(lib().ko_long_index_hash(_ptr(i)))
 
 
-def mixed_index(s, n):
-    return int(lib().ko_mixed_index(s, n))
+ORDER_MIXED, ORDER_SORTED, ORDER_MIXED_1024_GROUPS = 0, 1, 2   # ks_oracle.h KO_ORDER_*
+
+
+def mixed_index(s, n, mode=ORDER_MIXED):
+    return int(lib().ko_mixed_index(s, n, mode))
+
+
+def mixed_chains(n, mode=ORDER_MIXED):
+    return int(lib().ko_mixed_chains(n, mode))
 
 
 def update_tsdf_voxel(cfg, origin, point_G, voxel_idx, rgba, weight, distance, voxel_weight, voxel_rgba):

@@ -38,6 +38,9 @@ def lib():
         L.kr_block_indices.argtypes = [C.c_void_p, C.c_void_p]
         L.kr_get_block.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.kr_get_block.restype = C.c_int
+        L.kr_set_mixed_order_form.argtypes = [C.c_int]
+        L.kr_get_mixed_order_form.restype = C.c_int
+        L.kr_mixed_sequence.argtypes = [C.c_size_t, C.c_void_p]
         _lib = L
     return _lib
 
@@ -50,11 +53,29 @@ def write_label_csv(path: str, label_rgba: np.ndarray, n_labels: int = 21):
             fh.write(f"label{i},{r},{g},{b},{a},{i}\n")
 
 
+def set_mixed_order_form(form: int):
+    """0 = upstream Voxblox as published (the default), 1 = 1024 groups of N/1024 (what this repository assumed until
+    round 4): which permutation the shim's MixedThreadSafeIndex behind the real Kimera sources produces.  Process-wide."""
+    lib().kr_set_mixed_order_form(int(form))
+
+
+def mixed_sequence(n: int) -> np.ndarray:
+    out = np.zeros(n, dtype=np.uint64)
+    lib().kr_mixed_sequence(n, out.ctypes.data)
+    return out
+
+
 class Reference:
+    """order_mode: "mixed" | "sorted" | "mixed_1024_groups" (= "mixed" with the shim switched to form 1 for the lifetime
+    of every integrate call of this object)."""
+
     def __init__(self, method: str, label_csv: str, voxel_size=0.05, vps=16, truncation=0.2, max_ray=5.0, p_match=0.8,
                  color_mode=1, dynamic_labels=(20,), threads=1, max_consecutive_ray_collisions=2, order_mode="mixed",
                  **extra):
         self.vps = vps
+        self._form = 1 if order_mode == "mixed_1024_groups" else 0
+        if order_mode == "mixed_1024_groups":
+            order_mode = "mixed"
         dyn = np.array(list(dynamic_labels), dtype=np.uint8)
         self._h = lib().kr_create(method.encode(), voxel_size, vps, truncation, max_ray, p_match, color_mode,
                                   dyn.ctypes.data if len(dyn) else None, len(dyn), threads,
@@ -76,6 +97,7 @@ class Reference:
         T = np.ascontiguousarray(T_G_C, dtype=np.float32)
         xyz = np.ascontiguousarray(xyz, dtype=np.float32)
         rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+        lib().kr_set_mixed_order_form(self._form)
         lib().kr_integrate(self._h, T.ctypes.data, xyz.ctypes.data, rgba.ctypes.data, xyz.shape[0], int(freespace))
 
     def block_indices(self) -> np.ndarray:

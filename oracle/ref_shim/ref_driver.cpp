@@ -77,6 +77,18 @@ kr_ctx* kr_create(const char* method, float voxel_size, int vps, float truncatio
 
 void kr_destroy(kr_ctx* c) { delete c; }
 
+// Which permutation the shim's MixedThreadSafeIndex produces (0 = upstream as published, 1 = 1024 groups; see
+// voxblox/integrator/integrator_utils.h).  Process-wide; read when an index is constructed, i.e. per frame.
+void kr_set_mixed_order_form(int form) { voxblox::shim_mixed_order_form() = form; }
+int kr_get_mixed_order_form() { return voxblox::shim_mixed_order_form(); }
+// The sequence ThreadSafeIndexFactory::get("mixed", cloud of n points) hands out (what the adapter's probe reads).
+void kr_mixed_sequence(size_t n, size_t* out) {
+  vxb::Pointcloud pts(n, vxb::Point(0.f, 0.f, 1.f));
+  std::unique_ptr<vxb::ThreadSafeIndex> index_getter(vxb::ThreadSafeIndexFactory::get("mixed", pts));
+  size_t idx, k = 0;
+  while (index_getter->getNextIndex(&idx)) out[k++] = idx;
+}
+
 // The virtual the server calls: labels come from the colours through the CSV map.
 void kr_integrate(kr_ctx* c, const float* T, const float* xyz, const unsigned char* rgba, size_t n, int freespace) {
   vxb::Transformation T_G_C(T[0], T[1], T[2], T[3], vxb::Point(T[4], T[5], T[6]));

@@ -31,22 +31,40 @@ class ThreadSafeIndex {
   const size_t number_of_points_;
 };
 
+// "mixed" order.  Voxblox is NOT in /root/reference (un-vendored, un-pinned), so which permutation upstream's
+// MixedThreadSafeIndex::getNextIndexImpl produces cannot be read here.  Both readings are implemented:
+//   form 0 (default; upstream as published, voxblox/integrator/integrator_utils.cc):
+//        number_of_groups_ = N / step_size_, step_size_ = 1024;
+//        group_num = s % number_of_groups_; position_in_group = s / number_of_groups_;
+//        idx = group_num * step_size_ + position_in_group        (consecutive positions are 1024 points apart)
+//   form 1 (what rounds 1-4 of this repository assumed): 1024 groups of N / 1024 points,
+//        idx = (s % 1024) * (N / 1024) + s / 1024                (consecutive positions are N / 1024 points apart)
+// The product's adapter probes the ThreadSafeIndexFactory it is built against and selects the matching form
+// (kimera_semantics_amd/host/hip_semantic_tsdf_integrator.cpp: probe_mixed_order); this switch is how the tests
+// put either behaviour behind the real Kimera sources.
+inline int& shim_mixed_order_form() {
+  static int form = 0;
+  return form;
+}
+
 class MixedThreadSafeIndex : public ThreadSafeIndex {
  public:
   explicit MixedThreadSafeIndex(size_t number_of_points)
-      : ThreadSafeIndex(number_of_points), number_of_groups_(number_of_points / step_size_) {}
+      : ThreadSafeIndex(number_of_points), form_(shim_mixed_order_form()), number_of_groups_(number_of_points / step_size_) {}
 
  protected:
   size_t getNextIndexImpl(size_t sequential_idx) override {
     if (number_of_groups_ * step_size_ <= sequential_idx) return sequential_idx;
-    const size_t group_num = sequential_idx % step_size_;
-    const size_t position_in_group = sequential_idx / step_size_;
-    return group_num * number_of_groups_ + position_in_group;
+    if (form_ == 1) return (sequential_idx % step_size_) * number_of_groups_ + sequential_idx / step_size_;
+    const size_t group_num = sequential_idx % number_of_groups_;
+    const size_t position_in_group = sequential_idx / number_of_groups_;
+    return group_num * step_size_ + position_in_group;
   }
 
  private:
   static constexpr size_t step_size_ = 1024;
-  const size_t number_of_groups_;  // points per group
+  const int form_;
+  const size_t number_of_groups_;
 };
 
 class SortedThreadSafeIndex : public ThreadSafeIndex {

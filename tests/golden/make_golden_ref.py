@@ -49,18 +49,24 @@ def block_digests(t, s):
     return out
 
 
+# The "mixed" integration order comes from Voxblox, which is not in the reference tree: one set of fixtures per reading of
+# MixedThreadSafeIndex (oracle/ref_shim/voxblox/integrator/integrator_utils.h).  "" = upstream as published (the default).
+FORMS = {"": ("mixed", 0), "__mixed_1024_groups": ("mixed_1024_groups", 2)}   # suffix: (ref_py order_mode, KO_/KS_ORDER_* value)
+
+
 def main():
     tmp = tempfile.mkdtemp()
     csv = os.path.join(tmp, "labels.csv")
     R.write_label_csv(csv, synth.default_label_colors())
     for name, (method, geom, *_rest, kw) in CASES.items():
         f = frame_of(name)
-        r = R.Reference(method, csv, **geom, **kw)
-        r.integrate(f.T_G_C, f.xyz, f.rgba)
-        idx, t, s = r.download()
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), block_indices=idx.astype(np.int32), digests=block_digests(t, s),
-                            touched=np.int64((t["weight"] > 0).sum()), n_points=np.int64(f.xyz.shape[0]))
-        print(name, "blocks", len(idx), "touched", int((t["weight"] > 0).sum()))
+        for suffix, (order_mode, _) in FORMS.items():
+            r = R.Reference(method, csv, order_mode=order_mode, **geom, **kw)
+            r.integrate(f.T_G_C, f.xyz, f.rgba)
+            idx, t, s = r.download()
+            np.savez_compressed(os.path.join(HERE, name + suffix + ".npz"), block_indices=idx.astype(np.int32), digests=block_digests(t, s),
+                                touched=np.int64((t["weight"] > 0).sum()), n_points=np.int64(f.xyz.shape[0]))
+            print(name + suffix, "blocks", len(idx), "touched", int((t["weight"] > 0).sum()))
 
 
 if __name__ == "__main__":

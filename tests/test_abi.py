@@ -91,3 +91,23 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
             B.KsProfile.host_wait_ms.offset, B.KsConfig.early_out_phase_growth.offset, ctypes.sizeof(B.KsReduceStats),
             20, 12, 120]  # ks_voxel_run {int32 block[3]; uint32 first, count}; 16 B header + 12 B TsdfVoxel + 92 B SemanticVoxel
     assert got == want
+
+
+REAL_DEMO = os.path.join(ROOT, "integration", "_build", "adapter_demo_real")
+STANDIN_DEMO = os.path.join(ROOT, "kimera_semantics_amd", "host", "adapter_demo")
+
+
+@pytest.mark.skipif(not os.path.exists(REAL_DEMO), reason="integration/_build not built (needs /root/reference at build time)")
+def test_adapter_probes_the_mixed_order_of_the_voxblox_it_is_built_against():
+    """Voxblox (and with it MixedThreadSafeIndex, the order every `fast` / `merged` frame is integrated in) is an un-pinned
+    upstream dependency absent from the reference tree.  The adapter does not assume which permutation it produces:
+    HipSemanticTsdfIntegrator::probeMixedOrder() drives vxb::ThreadSafeIndexFactory::get("mixed", ...) of its own build and
+    selects the matching ks_config.integration_order_mode.  Here the build is the one against the real Kimera headers, the
+    index is the reference-side shim's, switched between its two readings: the probe must follow (no GPU involved)."""
+    import subprocess
+    for form, expect in (("0", B.KS_ORDER_MIXED), ("1", B.KS_ORDER_MIXED_1024_GROUPS)):
+        r = subprocess.run([REAL_DEMO, "--probe-order"], capture_output=True, text=True, env=dict(os.environ, KS_DEMO_SHIM_MIXED_FORM=form))
+        assert r.returncode == 0 and r.stdout.strip() == f"probeMixedOrder: {expect}", r.stdout + r.stderr
+    if os.path.exists(STANDIN_DEMO):   # built against the interface-only stand-in headers: nothing to ask (-2)
+        r = subprocess.run([STANDIN_DEMO, "--probe-order"], capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout.strip() == "probeMixedOrder: -2", r.stdout + r.stderr

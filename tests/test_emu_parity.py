@@ -41,6 +41,10 @@ CASES = {
     "fast_exact_serial_early_out": dict(method=0, size=[64, 48], frames=1, exact=True),
     "fast_sorted_order_limit_0": dict(method=0, size=[64, 48], frames=1,
                                       cfg=dict(integration_order_mode=1, max_consecutive_ray_collisions=0, early_out_phase_growth=32)),
+    # the other reading of Voxblox's "mixed" order (1024 groups of N / 1024 points): schedule alone, and the serial result
+    "fast_ordered_phases_mixed_1024_groups": dict(method=0, size=[96, 72], frames=2, cfg=dict(early_out_phase_growth=32, integration_order_mode=2)),
+    "fast_exact_mixed_1024_groups": dict(method=0, size=[96, 72], frames=2, exact=True, cfg=dict(integration_order_mode=2)),
+    "merged_mixed_1024_groups": dict(method=1, size=[64, 48], frames=2, cfg=dict(integration_order_mode=2)),
     "random_knobs_fast": dict(method=0, size=[64, 48], frames=2, random_combo=3, cfg=dict(early_out_phase_growth=32)),
     "random_knobs_merged": dict(method=1, size=[64, 48], frames=2, random_combo=5),
     # k_bundles_long (two waves per >= 32-point bundle: the first frame looks at a wall from 0.45 m) and k_apply_xlong (four waves
@@ -76,7 +80,7 @@ def test_overflow_falls_back_to_the_host_loop_and_the_device_loop_takes_over_aga
     predecessor's marks are not in the table when their finisher runs); the next call completes them all once, the buffers
     grow, and the frames after that run on the device again: fewer fallbacks than frames, same map."""
     run_case(emu_lib, dict(method=0, size=[48, 36], frames=9, pipeline=4, fallbacks_below=7),
-             env_extra={"KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "4096"})
+             env_extra={"KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "16384"})
 
 
 @pytest.mark.parametrize("overlap", ["1", "0"])

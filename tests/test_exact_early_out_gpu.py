@@ -104,13 +104,15 @@ def test_exact_early_out_c4_geometry():
 
 
 @pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
-def test_exact_early_out_equals_real_reference_sources(tmp_path):
-    """default fast (max_consecutive_ray_collisions = 2) over 3 frames at 640x480: HIP == the real sources."""
+@pytest.mark.parametrize("order", [pytest.param(0, id="mixed_upstream"), pytest.param(2, id="mixed_1024_groups")])
+def test_exact_early_out_equals_real_reference_sources(tmp_path, order):
+    """default fast (max_consecutive_ray_collisions = 2) over 3 frames at 640x480: HIP == the real sources, in either
+    reading of Voxblox's "mixed" order (the early-out is where the order matters most: which ray meets which ray's marks)."""
     csv = str(tmp_path / "labels.csv")
     R.write_label_csv(csv, synth.default_label_colors())
-    r = R.Reference("fast", csv)
+    r = R.Reference("fast", csv, order_mode="mixed" if order == 0 else "mixed_1024_groups")
     h = B.HipIntegrator(B.default_config(max_tiles=1 << 14, max_points=1 << 19, early_out_phase_growth=B.KS_EARLY_OUT_EXACT,
-                                         **dict(COMMON, method=0)))
+                                         integration_order_mode=order, **dict(COMMON, method=0)))
     sc = synth.make_scene("room")
     for k in range(3):
         f = synth.render_frame(sc, synth.trajectory_pose(5 + 2 * k), 640, 480, seed=5 + k)

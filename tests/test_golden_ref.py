@@ -10,7 +10,7 @@ import pytest
 
 from kimera_semantics_amd import synth
 from oracle import oracle_py as O
-from tests.golden.make_golden_ref import CASES, block_digests, frame_of
+from tests.golden.make_golden_ref import CASES, FORMS, block_digests, frame_of
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -22,8 +22,8 @@ def _cfg(name):
                 label_rgba=synth.default_label_colors(), **kw)
 
 
-def _check(integ, name):
-    g = np.load(os.path.join(HERE, name + ".npz"))
+def _check(integ, name, suffix=""):
+    g = np.load(os.path.join(HERE, name + suffix + ".npz"))
     f = frame_of(name)
     assert f.xyz.shape[0] == int(g["n_points"])
     integ.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
@@ -34,14 +34,17 @@ def _check(integ, name):
     assert np.array_equal(block_digests(t, s), g["digests"]), name
 
 
+@pytest.mark.parametrize("form", sorted(FORMS))
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_oracle_reproduces_reference_golden(name):
+def test_oracle_reproduces_reference_golden(name, form):
     extra = dict(bundle_order=0) if CASES[name][0] == "merged" else {}
-    _check(O.Oracle(O.default_config(**_cfg(name), **extra)), name)
+    _check(O.Oracle(O.default_config(integration_order_mode=FORMS[form][1], **_cfg(name), **extra)), name, form)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(n for n in CASES if "noearlyout" in n or "merged" in n))
-def test_hip_reproduces_reference_golden(name):
+@pytest.mark.parametrize("form", sorted(FORMS))
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hip_reproduces_reference_golden(name, form):
+    """All five cases, in both readings of the "mixed" order (`fast` with the early-out: the default mode = the serial result)."""
     from kimera_semantics_amd import binding as B
-    _check(B.HipIntegrator(B.default_config(max_tiles=1 << 15, max_points=1 << 19, **_cfg(name))), name)
+    _check(B.HipIntegrator(B.default_config(max_tiles=1 << 15, max_points=1 << 19, integration_order_mode=FORMS[form][1], **_cfg(name))), name, form)

@@ -29,12 +29,18 @@ def _frame(geom, size):
     return synth.render_frame(synth.make_scene("hall"), synth.trajectory_pose(3, radius=3.0), size[0], size[1], hfov_deg=75.0, seed=3)
 
 
-def _pair(tmp_path, method, geom, **kw):
+# Voxblox's "mixed" order is not in the reference tree: both readings of it, on both sides (the shim behind the real Kimera
+# sources is switched per Reference object; include/ks_hip.h KS_ORDER_MIXED / KS_ORDER_MIXED_1024_GROUPS)
+ORDERS = [pytest.param(0, id="mixed_upstream"), pytest.param(2, id="mixed_1024_groups")]
+
+
+def _pair(tmp_path, method, geom, order=0, **kw):
     csv = str(tmp_path / "labels.csv")
     R.write_label_csv(csv, synth.default_label_colors())
     r = R.Reference("fast" if method == 0 else "merged", csv, voxel_size=geom["voxel_size"], truncation=geom["truncation_distance"],
-                    max_ray=geom["max_ray_length_m"], **kw)
-    h = B.HipIntegrator(B.default_config(max_tiles=1 << 15, max_points=1 << 19, **dict(COMMON, method=method, **geom, **kw)))
+                    max_ray=geom["max_ray_length_m"], order_mode={0: "mixed", 1: "sorted", 2: "mixed_1024_groups"}[order], **kw)
+    h = B.HipIntegrator(B.default_config(max_tiles=1 << 15, max_points=1 << 19, integration_order_mode=order,
+                                         **dict(COMMON, method=method, **geom, **kw)))
     return r, h
 
 
@@ -46,10 +52,11 @@ def _maps(r, h):
     return rt, rs, ht, hs
 
 
+@pytest.mark.parametrize("order", ORDERS)
 @pytest.mark.parametrize("geom,size", [(C2, (640, 480)), (C4, (320, 180))])
-def test_fast_no_early_out_bit_exact_vs_real_reference(tmp_path, geom, size):
+def test_fast_no_early_out_bit_exact_vs_real_reference(tmp_path, geom, size, order):
     f = _frame(geom, size)
-    r, h = _pair(tmp_path, 0, geom, max_consecutive_ray_collisions=NO_EARLY_OUT)
+    r, h = _pair(tmp_path, 0, geom, order=order, max_consecutive_ray_collisions=NO_EARLY_OUT)
     r.integrate(f.T_G_C, f.xyz, f.rgba)
     h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
     rt, rs, ht, hs = _maps(r, h)
@@ -69,10 +76,11 @@ def _assert_identical(rt, rs, ht, hs):
     assert np.array_equal(rt["color"], ht["color"]) and np.array_equal(rs["color"], hs["color"])
 
 
+@pytest.mark.parametrize("order", ORDERS)
 @pytest.mark.parametrize("geom,size,frames", [(C2, (640, 480), 3), (C4, (320, 180), 2), (C2, (97, 61), 4)])
-def test_merged_bit_exact_vs_real_reference(tmp_path, geom, size, frames):
+def test_merged_bit_exact_vs_real_reference(tmp_path, geom, size, frames, order):
     """merged, default configuration: every voxel identical to the real reference sources' result."""
-    r, h = _pair(tmp_path, 1, geom)
+    r, h = _pair(tmp_path, 1, geom, order=order)
     sc = synth.make_scene("room" if geom is C2 else "hall")
     for k in range(frames):
         if geom is C2:

@@ -184,21 +184,25 @@ def test_adapter_through_the_real_kimera_factory(tmp_path, method):
 
 
 @pytest.mark.skipif(not os.path.exists(REAL_DEMO), reason="integration/_build not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("shim_form", [0, 1])
 @pytest.mark.parametrize("method", ["fast_hip", "enum:3", "fast"])
-def test_real_factory_default_fast_early_out_is_the_reference_result(tmp_path, method):
+def test_real_factory_default_fast_early_out_is_the_reference_result(tmp_path, method, shim_form):
     """The reference's default `fast` configuration (early-out after 2 consecutive observed voxels,
     semantic_tsdf_integrator_fast.cpp:110-122) through the reference's own factory: create("fast_hip") returns the map the
     reference's CPU integrator produces at integrator_threads = 1 ("fast" through the same binary), bit for bit —
-    both equal the serial oracle."""
+    both equal the serial oracle.  shim_form: which permutation the Voxblox stand-in behind the reference hands out for
+    "mixed" (Voxblox is un-pinned upstream) — the adapter is NOT told: it probes vxb::ThreadSafeIndexFactory and follows."""
     sc = synth.make_scene("room")
     frames = [synth.render_frame(sc, synth.trajectory_pose(4 * k), 200, 150, seed=80 + k) for k in range(3)]
     csv, fin, fout = str(tmp_path / "labels.csv"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
     R.write_label_csv(csv, synth.default_label_colors())
     _write_in(fin, frames)
-    res = subprocess.run([REAL_DEMO, method, csv, fin, fout, "1", "2"], capture_output=True, text=True)
+    res = subprocess.run([REAL_DEMO, method, csv, fin, fout, "1", "2"], capture_output=True, text=True,
+                         env=dict(os.environ, KS_DEMO_SHIM_MIXED_FORM=str(shim_form)))
     assert res.returncode == 0, res.stdout + res.stderr
     idx, t, s = _read_out(fout)
-    o = O.Oracle(O.default_config(**dict(COMMON, method=0, color_mode=1, integrator_threads=1)))   # max_consecutive_ray_collisions = 2, serial order
+    o = O.Oracle(O.default_config(**dict(COMMON, method=0, color_mode=1, integrator_threads=1,   # max_consecutive_ray_collisions = 2, serial order
+                                         integration_order_mode=O.ORDER_MIXED if shim_form == 0 else O.ORDER_MIXED_1024_GROUPS)))
     for f in frames:
         o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
     oi, ot, os_ = o.download()

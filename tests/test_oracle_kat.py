@@ -47,12 +47,20 @@ def test_grid_index_negative_and_boundary():
 
 
 def test_mixed_index_permutation():
-    n = 2048 + 5  # 1024 groups of 2, 5 stragglers
+    # upstream form: number_of_groups_ = n / 1024 = 2 groups of step_size_ = 1024 points, 5 stragglers
+    n = 2048 + 5
     seq = [O.mixed_index(s, n) for s in range(n)]
+    assert sorted(seq) == list(range(n))
+    assert seq[:4] == [0, 1024, 1, 1025] and seq[2046:2048] == [1023, 2047]
+    assert seq[2048:] == [2048, 2049, 2050, 2051, 2052]
+    assert [O.mixed_index(s, 10) for s in range(10)] == list(range(10))  # fewer points than one group
+    assert O.mixed_chains(n) == 2 and O.mixed_chains(10) == 1024 and O.mixed_chains(640 * 480) == 300
+    # the other reading (rounds 1-4): 1024 groups of n / 1024 = 2 points
+    seq = [O.mixed_index(s, n, O.ORDER_MIXED_1024_GROUPS) for s in range(n)]
     assert sorted(seq) == list(range(n))
     assert seq[0] == 0 and seq[1] == 2 and seq[1024] == 1 and seq[1025] == 3
     assert seq[2048:] == [2048, 2049, 2050, 2051, 2052]
-    assert [O.mixed_index(s, 10) for s in range(10)] == list(range(10))  # fewer points than groups
+    assert O.mixed_chains(n, O.ORDER_MIXED_1024_GROUPS) == 1024
 
 
 def test_transform_point_quaternion():

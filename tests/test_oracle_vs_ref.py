@@ -77,6 +77,38 @@ def test_sorted_order_and_close_up_match_reference(tmp_path):
         _same(o, r)
 
 
+def test_mixed_order_both_forms_match_the_index_behind_the_reference(tmp_path):
+    """Voxblox's MixedThreadSafeIndex is not in the reference tree: both readings of it exist on every side.  The sequence
+    the shim hands the REAL Kimera sources (ThreadSafeIndexFactory::get("mixed", ...)) equals the oracle's closed form in
+    either setting, and whole maps (fast with the early-out = the order-sensitive case, and merged) agree bit for bit."""
+    import numpy as np
+    for form, mode in ((0, O.ORDER_MIXED), (1, O.ORDER_MIXED_1024_GROUPS)):
+        R.set_mixed_order_form(form)
+        try:
+            for n in (5 * 1024 + 7, 1023, 1024, 2048, 640 * 480):
+                seq = R.mixed_sequence(n)
+                assert sorted(seq.tolist()) == list(range(n))
+                step = max(1, n // 5000)
+                assert all(int(seq[s]) == O.mixed_index(s, n, mode) for s in list(range(0, n, step)) + [n - 1]), (form, n)
+        finally:
+            R.set_mixed_order_form(0)
+    assert O.mixed_index(1, 5 * 1024, O.ORDER_MIXED) == 1024 and O.mixed_index(1, 5 * 1024, O.ORDER_MIXED_1024_GROUPS) == 5
+    csv = _csv(tmp_path)
+    sc = synth.make_scene("room")
+    for method, name in ((0, "fast"), (1, "merged")):
+        maps = []
+        for mode, rname in ((0, "mixed"), (2, "mixed_1024_groups")):
+            o = O.Oracle(O.default_config(**dict(COMMON, method=method, bundle_order=0, integration_order_mode=mode)))
+            r = R.Reference(name, csv, order_mode=rname)
+            for k in range(2):
+                f = synth.render_frame(sc, synth.trajectory_pose(4 * k), 128, 96, seed=70 + k)
+                o.integrate(f.T_G_C, f.xyz, f.rgba if method == 0 else None, f.labels)
+                r.integrate(f.T_G_C, f.xyz, f.rgba)
+            assert _same(o, r) > 1000
+            maps.append(o.download()[2]["priors"].copy())
+        assert maps[0].shape != maps[1].shape or not np.array_equal(maps[0], maps[1]), "the two forms are different orders: the maps must differ somewhere"
+
+
 from tests.variants import VARIANTS  # noqa: E402
 
 
@@ -111,7 +143,7 @@ def test_config_variants_match_reference(tmp_path, name, method):
     assert _same(o, r) > 300
 
 
-from tests.variants import random_combo  # noqa: E402
+from tests.variants import ORDER_MODE_NAMES, random_combo  # noqa: E402
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -125,7 +157,7 @@ def test_random_knob_combinations_match_reference(tmp_path, seed, method):
     okw.update(v)
     rkw = dict(v)
     ref_args = {"color_mode": rkw.pop("color_mode"),
-                "order_mode": "sorted" if rkw.pop("integration_order_mode") == 1 else "mixed"}
+                "order_mode": ORDER_MODE_NAMES[rkw.pop("integration_order_mode")]}
     for src, dst in (("voxel_size", "voxel_size"), ("truncation_distance", "truncation"), ("max_ray_length_m", "max_ray"),
                      ("semantic_measurement_probability", "p_match")):
         if src in rkw:

@@ -18,6 +18,9 @@ VARIANTS = {
 }
 
 
+ORDER_MODE_NAMES = {0: "mixed", 1: "sorted", 2: "mixed_1024_groups"}   # oracle/ref_py.Reference(order_mode=...)
+
+
 def random_combo(seed: int) -> dict:
     """A seeded random COMBINATION of the knobs above (interactions between options: carving x
     clearing x drop-off x weights x ray limits x set bookkeeping x colour mode)."""
@@ -33,5 +36,5 @@ def random_combo(seed: int) -> dict:
     if "start_voxel_subsampling_factor" not in kw and rng.random() < 0.3:
         kw["start_voxel_subsampling_factor"] = float(rng.choice([1.5, 3.0]))
     kw["color_mode"] = int(rng.integers(0, 3))
-    kw["integration_order_mode"] = int(rng.integers(0, 2))
+    kw["integration_order_mode"] = int(rng.integers(0, 3))   # mixed (upstream form) | sorted | mixed, 1024 groups
     return kw
