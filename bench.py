@@ -10,13 +10,15 @@ reference produces at integrator_threads = 1, bit for bit (the serial early-out 
 event-driven fix point on the device, csrc/ks_k_exact.h).  One step = one frame integrated into
 the GPU-resident map through the C ABI, inputs already resident in HBM.
 
-Timing.  Every context first integrates PRIME untimed frames (one per frame slot and pipeline stage: per-slot
-graph capture and buffer growth happen there), then the W warm-up steps, then R >= 5 timed regions of EXACTLY K
-steps each, every region bracketed by barrier + synchronize; the line reports the MEDIAN region (value,
-ms_per_step) and the spread over the regions.
+Timing.  The trajectory is a ring of EXACTLY K distinct frames.  Every context first integrates >= PRIME + W untimed
+frames (whole turns of the ring: one frame per frame slot and pipeline stage — per-slot graph capture and buffer growth
+happen there), then R >= 9 timed regions, each ONE turn of the ring = the same K frames in the same order, every region
+bracketed by barrier + synchronize.  The early-out sets are per frame and no update count depends on the map, so every
+region does exactly the same work: the spread over the regions measures the code and the machine, not the trajectory.
+The line reports the MEDIAN region (value, ms_per_step) and the spread.  All 640x480 sub-records replay the same ring.
 
 Prints ONE short JSON line (rank 0, < 4 KB); the full record (every sub-record, stage table) goes to
-profiles/bench_full_r04.json.
+profiles/bench_full_r05.json.
   value = voxel updates/s over the whole job, where a voxel update is one (ray, voxel) pair for which
           the reference runs updateTsdfVoxel + updateSemanticVoxel (semantic_tsdf_integrator_fast.cpp:128-140)
           and N_updates is the count the SERIAL REFERENCE ORDER (CPU oracle, one thread) gives for the timed
@@ -53,7 +55,7 @@ PRIME = 20                     # untimed frames per context before the warm-up: 
 MIN_REPEATS = 5
 MIN_REPEATS_PRIMARY = 9        # timed regions of the headline: the stretches of the trajectory differ by +-30 % (fix-point rounds), the median of nine moves less between runs than the median of five
 MIN_TIMED_FRAMES = 100
-MAX_DISTINCT_FRAMES = 96       # the trajectory is replayed cyclically beyond this many frames
+C4_STEPS = 12                  # frames per C4 region = distinct C4 frames (ring), 1280x720 each
 try:
     METRIC = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
 except Exception:
@@ -76,7 +78,7 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=4)
+    ap.add_argument("--cpu-frames", type=int, default=10)
     ap.add_argument("--no-secondary", action="store_true", help="skip the sub-records")
     ap.add_argument("--only-secondary", default="", help="comma list of sub-records to run (default: all)")
     ap.add_argument("--no-oracle-count", action="store_true",
@@ -236,7 +238,9 @@ def measure(B, torch, dist, dev, wl, ring, W, K, R, pipeline, max_tiles, world, 
         return integ.integrate_device(ring.host(i).T_G_C, x.data_ptr(), c.data_ptr(), l.data_ptr(), x.shape[0])
 
     prime = PRIME if prime is None else prime
-    for i in range(prime + W):
+    # whole turns of the ring before t0, so that every timed region is the ring's frames 0 .. K-1 in order
+    base = -(-(prime + W) // len(ring)) * len(ring) if K == len(ring) else prime + W
+    for i in range(base):
         step(i)
     integ.flush()             # completes the untimed frames AND hands their statistics over (discarded):
     integ.synchronize()       # nothing is pending or owed at t0
@@ -245,7 +249,6 @@ def measure(B, torch, dist, dev, wl, ring, W, K, R, pipeline, max_tiles, world, 
     integ.profile_enable(2)
     integ.profile(reset=True)
     regions = []
-    base = prime + W
 
     def eo_stats():   # (counters of the library: no synchronisation)
         try:
@@ -567,7 +570,7 @@ def mapped_library():
     return None
 
 
-LINE_LIMIT = 4000   # bytes of the ONE stdout line; everything else goes to the full record (profiles/bench_full_r04.json)
+LINE_LIMIT = 4000   # bytes of the ONE stdout line; everything else goes to the full record (profiles/bench_full_r05.json)
 
 
 def compact_line(out, full_path):
@@ -594,6 +597,8 @@ def compact_line(out, full_path):
     if "early_out_fidelity" in out:
         line["early_out_fidelity"] = pick(out["early_out_fidelity"], ["frames", "touched_jaccard", "label_agreement_common_voxels",
                                                                       "updates_gpu_over_serial", "bit_exact_vs_serial_reference", "error"])
+    if "host_inputs_h2d_inside" in out:
+        line["host_inputs_h2d_inside"] = pick(out["host_inputs_h2d_inside"], ["value", "ms_per_step", "frames_per_s", "spread"])
     if "reduce" in out:
         line["reduce"] = out["reduce"]
     sec = []
@@ -668,8 +673,9 @@ def main():
     K, W = args.steps, args.warmup
     R = max(MIN_REPEATS_PRIMARY, -(-MIN_TIMED_FRAMES // max(1, K)))
     wl = dict(WORKLOADS["C2"], w=args.width, h=args.height, method=args.method)
-    # frame-sharded: rank r integrates trajectory frames r, r+world, ... (weak scaling: the same number of frames per GPU)
-    n_distinct = min(PRIME + W + R * K, MAX_DISTINCT_FRAMES)
+    # frame-sharded: rank r integrates trajectory frames r, r+world, ... (weak scaling: the same number of frames per GPU);
+    # a ring of exactly K frames per rank: every timed region is one turn of it
+    n_distinct = K
     frames = make_frames(wl, [rank + world * k for k in range(n_distinct)])
     ring = FrameRing(frames, torch, dev)
     pipeline = 0 if args.no_pipeline else int(os.environ.get("KS_BENCH_PIPE", "8"))   # bag replay = a stream of frames: frame pipelining on
@@ -758,7 +764,8 @@ def main():
             "frames_per_s": rec["frames_per_s"],
             "gpu_counted_value": rec["gpu_counted_value"],
             "updates_counted_by": rec["updates_counted_by"],
-            "timing": {"untimed_frames_before_t0": PRIME + W, "timed_regions": R, "steps_per_region": K,
+            "timing": {"untimed_frames_before_t0": -(-(PRIME + W) // K) * K, "timed_regions": R, "steps_per_region": K,
+                       "every_region_integrates": "the same K frames, in the same order (one turn of the ring)",
                        "reported": "median region", "spread_max_minus_min_over_median": rec["spread"],
                        "ms_per_step_all_regions": rec["ms_per_step_all_regions"],
                        "early_out_all_regions": rec["early_out_all_regions"]},
@@ -784,11 +791,11 @@ def main():
             out.setdefault("secondary", []).append(c5)
         if world == 1 and args.method == "fast" and upd_serial is not None:
             try:
-                out["early_out_fidelity"] = early_out_fidelity(B, dev, wl, [ring.host(PRIME + W + i) for i in range(2)], 1 << 13)
+                out["early_out_fidelity"] = early_out_fidelity(B, dev, wl, [ring.host(i) for i in range(2)], 1 << 13)
             except Exception as e:
                 out["early_out_fidelity"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline and world == 1 and upd_serial is not None:   # reported on rank 0 at N=1 only
-            first = [(PRIME + W + i) % n_distinct for i in range(args.cpu_frames)]
+            first = [i % n_distinct for i in range(min(args.cpu_frames, n_distinct))]
             out["cpu_baseline"] = cpu_baseline(args, wl, [frames[i] for i in first], [upd_serial[i] for i in first])
         if world == 1 and not args.no_secondary:
             sec = out.get("secondary", [])
@@ -798,8 +805,8 @@ def main():
                 return not only or name in only
 
             # ---- the exact serial early-out mode, the merged integrator, the host-pointer entry (640x480) ----
-            n_sub = min(24, n_distinct)     # these records replay the first n_sub frames cyclically
-            sub_ring = FrameRing(frames[:n_sub], torch, dev)
+            n_sub = n_distinct              # the same ring as the headline: the records are comparable with it and with each other
+            sub_ring = ring
             for name, swl, kw in (("C2-ordered-phases", WORKLOADS["C2"], dict(cfg=dict(early_out_phase_growth=32), pipe=pipeline)),
                                   ("C2-unpipelined", WORKLOADS["C2"], dict(cfg={}, pipe=0)),
                                   ("C3", WORKLOADS["C3"], dict(cfg={}, pipe=pipeline)),
@@ -807,7 +814,7 @@ def main():
                 if not want(name) or args.method != "fast" or (args.width, args.height) != (640, 480):
                     continue
                 try:
-                    sK, sR = 20, MIN_REPEATS
+                    sK, sR = K, MIN_REPEATS
                     sm = measure(B, torch, dist, dev, swl, sub_ring, 2, sK, sR, kw["pipe"], 1 << 13, 1,
                                  entry=kw.get("entry", "device"), **kw["cfg"])
                     cof, show = None, "GPU's own count (oracle count skipped)"
@@ -833,20 +840,19 @@ def main():
                     sec.append(srec)
                 except Exception as e:   # a secondary record must never take the primary line down
                     sec.append({"config": name, "error": f"{type(e).__name__}: {e}"})
-            del sub_ring
             # ---- C4: 1280x720, 2 cm voxels, 10 m rays (both integrators on the same frames) ----
             c4_ring = None
             # (C4-fast in the default mode: at 2 cm voxels / 10 m rays the approximate set is overwhelmed — ~30 marks per slot and
             # frame — and the serial early-out is reproduced by the host-driven loop, tens of full iterations per frame: a few
             # frames only)
-            for name, steps, tiles, c4cfg in (("C4-fast", 3, 1 << 16, {}), ("C4-fast-ordered-phases", 30, 1 << 16, dict(early_out_phase_growth=32)),
-                                              ("C4-merged", 30, 1 << 16, {})):
+            for name, steps, tiles, c4cfg in (("C4-fast", C4_STEPS, 1 << 16, {}), ("C4-fast-ordered-phases", C4_STEPS, 1 << 16, dict(early_out_phase_growth=32)),
+                                              ("C4-merged", C4_STEPS, 1 << 16, {})):
                 if not want(name):
                     continue
                 try:
                     swl = WORKLOADS["C4-merged" if name == "C4-merged" else "C4-fast"]
-                    if c4_ring is None:   # 24 distinct frames, replayed cyclically
-                        c4_ring = FrameRing(make_frames(swl, range(24)), torch, dev)
+                    if c4_ring is None:   # a ring of C4_STEPS distinct frames: every region is one turn of it
+                        c4_ring = FrameRing(make_frames(swl, range(C4_STEPS)), torch, dev)
                     if time.time() - t_start > 600.0:
                         sec.append({"config": name, "skipped": f"the run is {time.time() - t_start:.0f} s old"})
                         continue
@@ -859,7 +865,7 @@ def main():
                                 "(tests/test_exact_early_out_gpu.py::test_full_size_c4_frame_exact_early_out_vs_real_reference)")
                     elif not args.no_oracle_count:
                         # the serial oracle needs ~10 s per C4 frame: count ONE timed frame, compare with the GPU's count of it
-                        i0 = PRIME + 2
+                        i0 = 2
                         oc = oracle_counts(swl, [c4_ring.host(i0)])[0]
                         g = gpu_counts(B, dev, swl, [c4_ring.host(i0)], tiles, **c4cfg)[0]
                         ratio = oc / max(1, g)
@@ -879,14 +885,21 @@ def main():
             torch.cuda.empty_cache()
             if want("adapter") and args.method == "fast":
                 try:
-                    sec.append(adapter_record([ring.host(PRIME + i) for i in range(12)]))
+                    sec.append(adapter_record([ring.host(i) for i in range(12)]))
                 except Exception as e:
                     sec.append({"config": "adapter", "error": f"{type(e).__name__}: {e}"})
             out["secondary"] = sec
+            # SURVEY.md §8(d) defines frames/s as the call "including H2D of the frame": the same K frames through the
+            # host-pointer entry (page-locked buffers, the copy inside the call), beside the device-resident headline
+            for r in sec:
+                if isinstance(r, dict) and r.get("config") == "C2-host-inputs" and "value" in r:
+                    out["host_inputs_h2d_inside"] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                                                     "frames_per_s": r["frames_per_s"], "spread": r["spread"],
+                                                     "note": "same K frames as the headline, ks_integrate_points on page-locked host buffers"}
         out["library"] = mapped_library()
         out["bench_seconds"] = round(time.time() - t_start, 1)
         # the full record (every sub-record, stage table, A/B record) goes to a file; stdout carries ONE short line
-        full_path = os.environ.get("KS_BENCH_FULL") or os.path.join("profiles", "bench_full_r04.json" if world == 1 else f"bench_full_r04_n{world}.json")
+        full_path = os.environ.get("KS_BENCH_FULL") or os.path.join("profiles", "bench_full_r05.json" if world == 1 else f"bench_full_r05_n{world}.json")
         try:
             with open(os.path.join(ROOT, full_path) if not os.path.isabs(full_path) else full_path, "w") as fh:
                 json.dump(out, fh, indent=1)

@@ -28,13 +28,14 @@ def main():
         last = t
         depth += dlt
     # frame markers: the first kernel of a frame (k_points_fast / k_points_merged).  bench.py --steps 20 --warmup 2:
-    # frames [22, 122) of the first context are the five timed regions (PRIME = 20 untimed frames + 2 warm-up steps)
+    # 40 untimed frames (two turns of the ring of 20: >= PRIME + warm-up), then the timed regions: frames [40, 140) = five of them
     first = sorted(int(r["Start_Timestamp"]) for r in tr if "k_points_" in r["Kernel_Name"])
     hist = {}
-    if len(first) >= 122:
-        per = (first[121] - first[22]) / 99 / 1e3
-        print(f"\n# frame period inside the timed regions (k_points start to start, frames 22..121), with tracing on: {per:.1f} us")
-        lo, hi = first[22], first[121]
+    B0, B1 = 40, 140
+    if len(first) >= B1:
+        per = (first[B1 - 1] - first[B0]) / (B1 - 1 - B0) / 1e3
+        print(f"\n# frame period inside the timed regions (k_points start to start, frames {B0}..{B1 - 1}), with tracing on: {per:.1f} us")
+        lo, hi = first[B0], first[B1 - 1]
         depth, last = 0, lo
         for t, dlt in ev:
             if t > hi:
@@ -45,8 +46,8 @@ def main():
             depth += dlt
     ap = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
                 for r in tr if "k_apply<" in r["Kernel_Name"] and "k_apply_long" not in r["Kernel_Name"])
-    if len(ap) >= 122:
-        timed = [d for _, d in ap[22:122]]
+    if len(ap) >= B1:
+        timed = [d for _, d in ap[B0:B1]]
         print(f"# k_apply average duration: {sum(timed) / len(timed) / 1e3:.2f} us over the 100 timed (pipelined, overlapped) launches "
               f"(bench.py's roofline.k_apply.avg_launch_ms of the same run is in the log line below)")
     tot = sum(hist.values()) or 1
