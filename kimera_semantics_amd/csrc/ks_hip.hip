@@ -904,7 +904,6 @@ int enqueue_exact_rounds(ks_ctx* c, FrameSlot* const* slots, uint32_t nb, hipStr
   hipLaunchKernelGGL(k_eo2_hits, dim3(gm, nb), dim3(256), 0, st, Bt);
   hipLaunchKernelGGL(k_eo2_stop0, dim3((uint32_t)std::min<size_t>((n + 255) / 256, 2048), nb), dim3(256), 0, st, Bt);
   hipLaunchKernelGGL(k_eo2_bits, dim3(gm, nb), dim3(256), 0, st, Bt);
-  hipLaunchKernelGGL(k_eo2_index, dim3(gm, nb), dim3(256), 0, st, Bt);
   // the event-driven rounds (round 0 was the full iteration above)
   // (wavefront per ray, grid-stride.  The lists shrink geometrically — ~3000 / 1000 / 600 / ... rays at 640x480 — and a
   // launch costs its workgroups: the later rounds get by with fewer, unless rays are long and lists stay long: 2 cm voxels)
@@ -1874,7 +1873,10 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // of the dependence between frames — the zero-initialised slot — is carried by the commit events.
     if (c->exact_early_out && (!c->eo_device || c->cfg.clear_checks_every_n_frames > 1)) c->cfg.pipeline_frames = 0;
     const bool wide_rays = steps_max_of(c->cfg, (float)(1.0 / cfg->voxel_size)) > 400;
-    c->eo_bulk_rounds = wide_rays ? 32 : 14;
+    // (rounds the fix point needs from the doubling seed, 640x480 / 5 cm, tools/fixpoint_study.py: 7 in the upstream form of the
+    // "mixed" order, 11-13 in the 1024-group form; a frame that needs more hands the rest to the finisher, and a finisher that
+    // is handed too long a list asks for more rounds as launches: eo_want_bulk)
+    c->eo_bulk_rounds = wide_rays ? 32 : cfg->integration_order_mode == KS_ORDER_MIXED ? 8 : 14;
     if (const char* br = getenv("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
   }
   c->uses_early_out = uses_early_out;

@@ -457,10 +457,12 @@ __device__ __forceinline__ unsigned long long eo2_ld64(const unsigned long long*
 }
 
 // ---- the FIRST iteration is a full one, and streams -----------------------------------------------------------------
-__device__ __forceinline__ void eo2_mark_dirty(const EoView& E, uint32_t p, uint32_t* out, uint32_t* n_out);
+constexpr uint32_t kEoStepMax = 0x3fffffu;
+__device__ __forceinline__ void eo2_mark_dirty(const EoView& E, uint32_t p, uint32_t step, uint32_t* out, uint32_t* n_out);
 
 // per sorted mark: is the visit a hit (the mark before it in its slot holds the same hash; first of its slot: what earlier
-// frames left there)?  -> hitb[its place in emission order]; and where[] of that place = the mark's index
+// frames left there)?  -> hitb[its place in emission order]; and where[] of that place = the mark's index; and the slot's
+// range in M (its first and its last mark write them)
 __global__ void __launch_bounds__(256) k_eo2_hits(EoBatch Bt) {
   const EoView& E = Bt.v[blockIdx.y];
   const unsigned long long n = E.ctl->st.n_marks;
@@ -469,8 +471,12 @@ __global__ void __launch_bounds__(256) k_eo2_hits(EoBatch Bt) {
     const uint64_t key = E.keys[j];
     const uint32_t slot = (uint32_t)(key >> 44), pos = (uint32_t)(key >> 22) & 0x3fffffu, step = (uint32_t)key & 0x3fffffu;
     const uint32_t h = E.vals[j];
+    const bool first_of_slot = j == 0 || (uint32_t)(E.keys[j - 1] >> 44) != slot;
+    // per slot: [begin, end) of its marks in M (the table is clear: k_eo2_commit leaves it so)
+    if (first_of_slot) E.tab[slot].x = (uint32_t)j;
+    if (j + 1 == n || (uint32_t)(E.keys[j + 1] >> 44) != slot) E.tab[slot].y = (uint32_t)(j + 1);
     bool hit;
-    if (j > 0 && (uint32_t)(E.keys[j - 1] >> 44) == slot) {
+    if (!first_of_slot) {
       hit = E.vals[j - 1] == h;
     } else {
       // (the only hash an entry of an EARLIER offset can equal is that of the zero-initialised slot; what that slot held
@@ -510,7 +516,7 @@ __global__ void __launch_bounds__(256) k_eo2_stop0(EoBatch Bt) {
       E.cnt_a[pos] = now;
       E.cnt_b[pos] = now;
     }
-    if (stop < 0 && (cv & kCntBroke)) eo2_mark_dirty(E, pos, E.list[1], &E.ctl->n_in[1]);
+    if (stop < 0 && (cv & kCntBroke)) eo2_mark_dirty(E, pos, v0, E.list[1], &E.ctl->n_in[1]);
   }
 }
 
@@ -543,20 +549,8 @@ __global__ void __launch_bounds__(256) k_eo2_bits(EoBatch Bt) {
         kprev = E.keys[j - 1];
         vprev = ((uint32_t)kprev & 0x3fffffu) < eo_visited(E.cnt_a[(uint32_t)(kprev >> 22) & 0x3fffffu]);
       }
-      if (!vprev && (uint32_t)(kprev >> 44) == (uint32_t)(key >> 44)) eo2_mark_dirty(E, (uint32_t)(key >> 22) & 0x3fffffu, E.list[1], &E.ctl->n_in[1]);
+      if (!vprev && (uint32_t)(kprev >> 44) == (uint32_t)(key >> 44)) eo2_mark_dirty(E, (uint32_t)(key >> 22) & 0x3fffffu, (uint32_t)key & 0x3fffffu, E.list[1], &E.ctl->n_in[1]);
     }
-  }
-}
-
-// per slot: [begin, end) of its marks in M (the table is clear: k_eo2_commit leaves it so)
-__global__ void __launch_bounds__(256) k_eo2_index(EoBatch Bt) {
-  const EoView& E = Bt.v[blockIdx.y];
-  const unsigned long long n = E.ctl->st.n_marks;
-  if (E.ctl->fail) return;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull) {
-    const uint32_t slot = (uint32_t)(E.keys[i] >> 44);
-    if (i == 0 || (uint32_t)(E.keys[i - 1] >> 44) != slot) E.tab[slot].x = (uint32_t)i;
-    if (i + 1 == n || (uint32_t)(E.keys[i + 1] >> 44) != slot) E.tab[slot].y = (uint32_t)(i + 1);
   }
 }
 
@@ -734,15 +728,34 @@ struct EoWalk {
 // Appends X marks for the visited steps it has no mark for yet; a changed length goes to B and the ray to the change list.
 __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams& F, uint32_t pos, EoWaveLds& W, uint32_t* n_chg) {
   const uint32_t lane = lane_id();
-  if (lane == 0) E.dirty[pos] = 0u;
+  // the earliest step whose input changed since the ray was last evaluated (eo2_mark_dirty); the flag goes down BEFORE
+  // anything is read, so a change that lands during this evaluation queues the ray again
+  uint32_t dword = 0u;
+  if (lane == 0) dword = atomicExch(&E.dirty[pos], 0u);
+  dword = (uint32_t)__shfl((int)dword, 0);
+  uint32_t r_min = dword ? kEoStepMax - (dword & kEoStepMax) : 0u;
   EoWalk wk;
   wk.begin(E, pos);
   const uint32_t full = wk.full, u0 = wk.u0;
+  const int lim = F.max_collisions;
   // (wave-uniform addresses whose content changes inside the one-workgroup finisher: read past the scalar cache)
   const uint32_t old = eo2_ld(&E.cnt_a[pos]);
+  {
+    // (the owners of a slot's later X marks are queued whether or not the ray still gets that far: a step past the ray's
+    // last visit is no visit — what the ray's last visit saw is then what may have changed)
+    const uint32_t vo = eo_visited(old);
+    if (r_min + 1u > vo) r_min = vo ? vo - 1u : 0u;
+  }
+  // Nothing below r_min changed, and the ray did not stop there (it owns a visit at r_min): its walk is taken up 64 steps
+  // before r_min — the consecutive-hit counter at r_min is the length of a run that ended inside those 64 steps, since a
+  // longer run would have stopped the ray (lim < 32) — but never inside the part that has to be cast (the caster's
+  // checkpoint is at or below u0).
+  if (lim >= 0 && lim < 32 && r_min > 64u) {
+    const uint32_t from = r_min - 64u, cap = u0 > 64u ? u0 - 64u : 0u;
+    wk.k0 = from < cap ? from : cap;
+  }
   const uint32_t ux_word = eo2_ld(&E.ux[pos]);          // [31] the ray is in the list of rays that consulted earlier frames' marks
   const uint32_t ux0 = ux_word & 0x7fffffffu;
-  const int lim = F.max_collisions;
   int c = 0, stop = -1;
   bool consulted = false;
   uint32_t visited = full;
@@ -839,8 +852,12 @@ __device__ __forceinline__ void eo2_eval_ray(const EoView& E, const FrameParams&
   }
 }
 
-__device__ __forceinline__ void eo2_mark_dirty(const EoView& E, uint32_t p, uint32_t* out, uint32_t* n_out) {
-  if (atomicExch(&E.dirty[p], 1u) == 0u) out[atomicAdd(n_out, 1u)] = p;
+// Queue ray p for the next round: the input of its visit of step `step` changed.  dirty[p] = 0: not queued; else
+// [31] | 0x3fffff - (the EARLIEST such step): atomicMax keeps the smallest step, and the ray is evaluated again from there
+// (eo2_eval_ray) instead of from its first voxel.
+__device__ __forceinline__ void eo2_mark_dirty(const EoView& E, uint32_t p, uint32_t step, uint32_t* out, uint32_t* n_out) {
+  const uint32_t v = 0x80000000u | (kEoStepMax - (step < kEoStepMax ? step : kEoStepMax));
+  if (atomicMax(&E.dirty[p], v) == 0u) out[atomicAdd(n_out, 1u)] = p;
 }
 
 // ONE changed ray, by a whole wavefront: its marks between the old and the new length toggled — dirty their readers;
@@ -867,12 +884,12 @@ __device__ __forceinline__ void eo2_propagate_ray(const EoView& E, const FramePa
       if (m < n_m) {
         const uint64_t key = E.keys[m];
         const uint32_t p = (uint32_t)(key >> 22) & 0x3fffffu;
-        if ((uint32_t)(key >> 44) == slot && p != pos) eo2_mark_dirty(E, p, out, n_out);
+        if ((uint32_t)(key >> 44) == slot && p != pos) eo2_mark_dirty(E, p, (uint32_t)key & 0x3fffffu, out, n_out);
       }
       for (uint32_t xi = eo2_ld(&E.tab[slot].z); xi != 0u;) {
         const unsigned long long kx = eo2_ld64(&E.xnode[2u * xi]), hn = eo2_ld64(&E.xnode[2u * xi + 1u]);
         const uint32_t p = (uint32_t)(kx >> 22);
-        if (kx > t && p != pos) eo2_mark_dirty(E, p, out, n_out);
+        if (kx > t && p != pos) eo2_mark_dirty(E, p, (uint32_t)kx & 0x3fffffu, out, n_out);
         xi = (uint32_t)(hn >> 32);
       }
       if (k < wk.u0) {   // the mark's bit under the current lengths follows
@@ -948,7 +965,7 @@ __global__ void __launch_bounds__(kEoFinishThreads) k_eo2_finish(EoView E, uint3
     __syncthreads();
     if (s_redo) {
       const uint32_t nc = eo2_ld(&ctl->n_consulted);
-      for (uint32_t i = threadIdx.x; i < nc; i += kEoFinishThreads) eo2_mark_dirty(E, eo2_ld(&E.consulted[i]), E.list[cur], &ctl->fin_in[cur]);
+      for (uint32_t i = threadIdx.x; i < nc; i += kEoFinishThreads) eo2_mark_dirty(E, eo2_ld(&E.consulted[i]), 0u, E.list[cur], &ctl->fin_in[cur]);
     }
     __syncthreads();
   }
