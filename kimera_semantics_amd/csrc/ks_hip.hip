@@ -255,6 +255,7 @@ struct ks_ctx {
   // ... event-driven (the default; KS_EXACT_HOST_LOOP=1: every frame through the host-driven loop above)
   bool eo_device = false;
   int eo_bulk_rounds = 6;                // rounds enqueued as launches before the one-workgroup finisher takes over
+  int eo_epochs = 3, eo_dense = 5;       // long rays: emissions of the marks over the rays' views, dense iterations per emission (ks_k_exact.h)
   std::atomic<int> eo_want_bulk{0};      // ... as a frame whose finisher was handed too long a list asks for (applied by the caller's thread between frames)
   uint32_t* d_eo_committed = nullptr;    // frames [0, *d_eo_committed) of the exact path have entered d_eo_plain
   uint32_t eo_frame_no = 0;              // frames launched through the exact path
@@ -556,6 +557,7 @@ inline unsigned bits_for(uint64_t n) {  // number of bits needed to represent va
 }
 
 int launch_batch(ks_ctx* c);
+int quiesce(ks_ctx* c);
 // ApproxHashSet::resetApproxSet.  `observed`: the early-out set, whose entries carry a frame tag
 // (ks_k_march.h); its poison value and tag bookkeeping differ from the start-voxel set's raw hashes.
 int reset_set(ks_ctx* c, uint64_t* d_set0, uint64_t* offset, bool observed) {
@@ -568,6 +570,11 @@ int reset_set(ks_ctx* c, uint64_t* d_set0, uint64_t* offset, bool observed) {
     // out before the tables are rewritten (a frame with tag ~1019 running after the retag would leave marks that win
     // every atomicMax against the restarted tags 1, 2, ...)
     if (int rc = launch_batch(c)) return rc;
+    if (full && c->exact_early_out) {
+      // the table the exact mode keeps verbatim is rewritten below: a frame in flight whose device fix point gave up repeats
+      // it on the tail stream LATER, reading and committing into that table — complete every pending tail first
+      if (int rc = quiesce(c)) return rc;
+    }
     if (int rc = sync_march(c)) return rc;  // stage B reads the observed set
     if (full) *offset = 0;
     for (int t = 0; t < (observed ? c->n_obs : 1); ++t) {
@@ -857,6 +864,7 @@ EoView eo_view(ks_ctx* c, const FrameSlot& S) {
   E.hitb = S.d_eo_hitb;
   E.hseq_w = S.d_eo_hseq;
   E.wide = S.wide ? 1u : 0u;
+  E.live = S.d_live;
   E.hseq = S.d_eo_hseq;
   E.where = S.d_eo_where;
   E.rinfo = S.d_eo_rinfo;
@@ -893,17 +901,37 @@ int enqueue_exact_rounds(ks_ctx* c, FrameSlot* const* slots, uint32_t nb, hipStr
     Rs.ws[k] = S.d_eo_sort_ws;
   }
   hipLaunchKernelGGL(k_eo2_begin, dim3(nb), dim3(64), 0, st, Bt);
-  hipLaunchKernelGGL(k_eo2_scan, dim3(nb4k, nb), dim3(1024), 0, st, Bt);
-  if (S0.wide) hipLaunchKernelGGL(k_eo2_emit<8>, dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, Bt);
-  else hipLaunchKernelGGL(k_eo2_emit<64>, dim3((uint32_t)((n + 255) / 256), nb), dim3(256), lds, st, Bt);
-  // stable sort on the slot bits only: a slot's marks stay in (position, step) order; three passes: the result is in the
-  // second buffer set (eo_view)
-  HIPCHK(c, ksrs::sort_dev_batch<uint64_t>(Rs, (int)nb, S0.eo_sort_words, S0.eo_cap_marks, 44, 64, st));
   const uint32_t gm = (uint32_t)std::min<size_t>((S0.eo_cap_marks + 255) / 256, 2048);
-  // the first iteration, full and streaming: hit bits of the sorted seed marks, stop rule per ray, validity bitmaps
-  hipLaunchKernelGGL(k_eo2_hits, dim3(gm, nb), dim3(256), 0, st, Bt);
-  hipLaunchKernelGGL(k_eo2_stop0, dim3((uint32_t)std::min<size_t>((n + 255) / 256, 2048), nb), dim3(256), 0, st, Bt);
-  hipLaunchKernelGGL(k_eo2_bits, dim3(gm, nb), dim3(256), 0, st, Bt);
+  const uint32_t gn = (uint32_t)std::min<size_t>((n + 255) / 256, 2048);
+  if (S0.wide) {
+    // long rays: marks over the rays' VIEWS, and dense iterations (two streaming passes per Jacobi step) over what has been
+    // sorted once per epoch; the last of them hands over to the event-driven rounds through k_eo2_propagate (ks_k_exact.h)
+    hipLaunchKernelGGL(k_eo2_full, dim3(gn, nb), dim3(256), 0, st, Bt);
+    for (int e = 0; e < c->eo_epochs; ++e) {
+      if (e > 0)   // the slots' ranges in the previous epoch's M (a slot may have no mark in this one)
+        for (uint32_t k = 0; k < nb; ++k) HIPCHK(c, hipMemsetAsync(slots[k]->d_eo_tab, 0, sizeof(uint4) << kSetBits, st));
+      hipLaunchKernelGGL(k_eo2_scan, dim3(nb4k, nb), dim3(1024), 0, st, Bt);
+      hipLaunchKernelGGL(k_eo2_emit<8>, dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, Bt);
+      HIPCHK(c, ksrs::sort_dev_batch<uint64_t>(Rs, (int)nb, S0.eo_sort_words, S0.eo_cap_marks, 44, 64, st));
+      hipLaunchKernelGGL(k_eo2_bits, dim3(gm, nb), dim3(256), 0, st, Bt, 0u);
+      for (int d = 0; d < c->eo_dense; ++d) {
+        hipLaunchKernelGGL(k_eo2_hits_b, dim3(gm, nb), dim3(256), 0, st, Bt);
+        hipLaunchKernelGGL(k_eo2_stopv, dim3(gn, nb), dim3(256), 0, st, Bt, (e + 1 == c->eo_epochs && d + 1 == c->eo_dense) ? 1u : 0u);
+      }
+    }
+    hipLaunchKernelGGL(k_eo2_propagate, dim3((uint32_t)std::min<size_t>((n + 3) / 4, 2048), nb), dim3(256), 0, st, Bt, 0u);
+  } else {
+    hipLaunchKernelGGL(k_eo2_scan, dim3(nb4k, nb), dim3(1024), 0, st, Bt);
+    hipLaunchKernelGGL(k_eo2_emit<64>, dim3((uint32_t)((n + 255) / 256), nb), dim3(256), lds, st, Bt);
+    // stable sort on the slot bits only: a slot's marks stay in (position, step) order; three passes: the result is in the
+    // second buffer set (eo_view)
+    HIPCHK(c, ksrs::sort_dev_batch<uint64_t>(Rs, (int)nb, S0.eo_sort_words, S0.eo_cap_marks, 44, 64, st));
+    // the first iteration, full and streaming: hit bits of the sorted seed marks (and the slots' ranges), stop rule per ray,
+    // validity bitmaps
+    hipLaunchKernelGGL(k_eo2_hits, dim3(gm, nb), dim3(256), 0, st, Bt);
+    hipLaunchKernelGGL(k_eo2_stop0, dim3(gn, nb), dim3(256), 0, st, Bt);
+    hipLaunchKernelGGL(k_eo2_bits, dim3(gm, nb), dim3(256), 0, st, Bt, 1u);
+  }
   // the event-driven rounds (round 0 was the full iteration above)
   // (wavefront per ray, grid-stride.  The lists shrink geometrically — ~3000 / 1000 / 600 / ... rays at 640x480 — and a
   // launch costs its workgroups: the later rounds get by with fewer, unless rays are long and lists stay long: 2 cm voxels)
@@ -1656,8 +1684,19 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
   if (c->eo_device && !c->eo_device_off) {
     if (c->eo_want_marks.load(std::memory_order_relaxed) > c->eo_cap_marks || c->eo_want_x.load(std::memory_order_relaxed) > c->eo_cap_x) {
       if ((rc = quiesce(c))) return rc;   // (the frames in flight may ask for more while they are completed)
-      const size_t wm = c->eo_want_marks.load(std::memory_order_relaxed), wx = c->eo_want_x.load(std::memory_order_relaxed);
-      if ((rc = ensure_exact_slots(c, std::max(wm, c->eo_cap_marks), std::max(wx, c->eo_cap_x)))) return rc;
+      const size_t wm = std::max(c->eo_want_marks.load(std::memory_order_relaxed), c->eo_cap_marks);
+      // (a frame that wants more X marks than an eighth of its marks is not helped by room for them — frame_tail counts it
+      // as hopeless — so the X buffers never need more than that)
+      const size_t wx = std::max(std::min(c->eo_want_x.load(std::memory_order_relaxed), std::max<size_t>(wm / 8, (size_t)1 << 17)), c->eo_cap_x);
+      if (ensure_exact_slots(c, wm, wx) != KS_OK) {
+        // no memory for it: this context stays with the host-driven loop (one frame at a time, the buffers of ensure_marks)
+        // instead of failing the frame.  The slots' buffers may be gone: nothing of the event-driven path is touched again.
+        (void)hipGetLastError();
+        c->eo_device_off = true;
+        c->cfg.pipeline_frames = 0;
+        c->err.clear();
+      }
+      c->eo_want_x.store(0, std::memory_order_relaxed);   // (what was asked for has been looked at: a clamped request must not come back every frame)
       c->eo_fallbacks_seen = c->eo_fallbacks.load(std::memory_order_relaxed);
     }
     if (const int wb = c->eo_want_bulk.load(std::memory_order_relaxed); wb > c->eo_bulk_rounds) {
@@ -1878,6 +1917,8 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // is handed too long a list asks for more rounds as launches: eo_want_bulk)
     c->eo_bulk_rounds = wide_rays ? 32 : cfg->integration_order_mode == KS_ORDER_MIXED ? 8 : 14;
     if (const char* br = getenv("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
+    if (const char* ep = getenv("KS_EXACT_EPOCHS")) c->eo_epochs = std::min(8, std::max(1, atoi(ep)));      // (tuning runs: any value gives the same map)
+    if (const char* dn = getenv("KS_EXACT_DENSE")) c->eo_dense = std::min(16, std::max(1, atoi(dn)));
   }
   c->uses_early_out = uses_early_out;
   c->use_bundle_rank = cfg->method == KS_METHOD_MERGED && cfg->bundle_order == KS_BUNDLE_ORDER_REFERENCE;

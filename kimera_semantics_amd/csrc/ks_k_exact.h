@@ -57,10 +57,18 @@ __global__ void __launch_bounds__(256) k_eo_total(const FrameParams* __restrict_
 // exclusive scan of the visited lengths over integration positions, blocks of kScanBlock (as k_scan_local)
 // (cnt_b / ux / dirty: the event-driven path's per-position state, initialised here — next lengths = current lengths,
 // steps covered by marks = visited length, nobody dirty)
+// (view: long rays — per position {-, pad, ray length, -}: the marks emitted for a ray cover its VIEW, min(ray length,
+// visited + pad) steps, so that an evaluation over the sorted marks can let the ray get further than it does now; see
+// the dense iterations below.  nullptr: exactly the visited steps.)
+__device__ __forceinline__ uint32_t eo_view_length(uint32_t visited, const uint4 ri) {
+  const uint32_t v = visited + ri.y;
+  return v < ri.z ? v : ri.z;
+}
 __device__ __forceinline__ void eo_scan_body(const FrameParams* __restrict__ Fp, const uint32_t* __restrict__ cnt,
                                              uint32_t* __restrict__ lp, unsigned long long* __restrict__ bt,
                                              EoState* __restrict__ st, uint32_t* __restrict__ cnt_b,
-                                             uint32_t* __restrict__ ux, uint32_t* __restrict__ dirty) {
+                                             uint32_t* __restrict__ ux, uint32_t* __restrict__ dirty,
+                                             const uint4* __restrict__ view = nullptr) {
   __shared__ uint32_t s_wave[16];
   const uint32_t n = Fp->n;
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // this iteration's counters
@@ -75,6 +83,7 @@ __device__ __forceinline__ void eo_scan_body(const FrameParams* __restrict__ Fp,
   for (int k = 0; k < 4; ++k) {
     const uint32_t cv = (i0 + k < n) ? cnt[i0 + k] : 0u;
     v[k] = eo_visited(cv);
+    if (view && i0 + k < n) v[k] = eo_view_length(v[k], view[i0 + k]);
     if (cnt_b && i0 + k < n) {
       cnt_b[i0 + k] = cv;
       ux[i0 + k] = v[k];
@@ -143,7 +152,7 @@ __device__ __forceinline__ void eo_emit_body(const FrameParams* __restrict__ Fp,
                                              unsigned long long cap, const Counters* C, EoState* __restrict__ st,
                                              uint32_t* __restrict__ fail, unsigned long long* __restrict__ btp,
                                              uint32_t* __restrict__ hseq, uint4* __restrict__ rinfo,
-                                             uint4* __restrict__ ckpt) {
+                                             uint4* __restrict__ ckpt, bool view = false) {
   extern __shared__ unsigned long long s_bt[];
   __shared__ float s_e[4][3 * kES];
   const FrameParams F = *Fp;  // a COPY: through the pointer every loop iteration would re-load the fields it uses (they may alias the stores)
@@ -158,12 +167,17 @@ __device__ __forceinline__ void eo_emit_body(const FrameParams* __restrict__ Fp,
   }
   const uint32_t lane = lane_id();
   const uint32_t r = (blockIdx.x * 4u + (threadIdx.x >> 6)) * (uint32_t)RPW + lane;
-  uint32_t pos = 0, visited = 0;
+  uint32_t pos = 0, visited = 0, pad = 0;   // visited: the steps marks are emitted for (the ray's view, see eo_scan_body)
   unsigned long long base = 0;
   Dda dda{};
   if (lane < (uint32_t)RPW && r < C->n_rays) {
     pos = ray_list[r];
     visited = eo_visited(cnt[pos]);
+    if (view) {
+      const uint4 ri = rinfo[pos];
+      pad = ri.y;
+      visited = eo_view_length(visited, ri);
+    }
     base = s_bt[pos / kScanBlock] + lp[pos];
     const RayDesc d = rays[ray_index(F, pos)];
     dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, false);
@@ -179,7 +193,7 @@ __device__ __forceinline__ void eo_emit_body(const FrameParams* __restrict__ Fp,
   // length, and the caster's state at step cs <= visited (from where it is cast on if it outgrows its marks)
   auto checkpoint = [&](const Dda& d, uint32_t cs) {
     if (!rinfo) return;
-    rinfo[pos] = make_uint4(visited, visited, (uint32_t)d.steps + 1u, cs);
+    rinfo[pos] = make_uint4(visited, pad, (uint32_t)d.steps + 1u, cs);
     ckpt[3u * pos] = make_uint4((uint32_t)d.cx, (uint32_t)d.cy, (uint32_t)d.cz, (uint32_t)(d.sx + 1) | ((uint32_t)(d.sy + 1) << 2) | ((uint32_t)(d.sz + 1) << 4));
     ckpt[3u * pos + 1u] = make_uint4(__float_as_uint(d.tx), __float_as_uint(d.ty), __float_as_uint(d.tz), __float_as_uint(d.dx));
     ckpt[3u * pos + 2u] = make_uint4(__float_as_uint(d.dy), __float_as_uint(d.dz), 0u, 0u);
@@ -430,9 +444,10 @@ struct EoView {
   const uint32_t* hseq;           // voxel hashes of the seed's marks in emission order
   uint32_t* hseq_w;               // (hseq, for the kernel that writes it)
   uint32_t* where;                // per seed mark in emission order: its index in M
-  uint4* rinfo;                   // per position: {u0 = steps the seed has marks for, -, ray length, checkpoint step}
+  uint4* rinfo;                   // per position: {u0 = steps M has marks for (the view), pad of the next view, ray length, checkpoint step}
   uint4* ckpt;                    // per position: the caster's state at the checkpoint step (3 words of 16 bytes)
-  uint32_t wide;                  // long rays (2 cm voxels): 8 rays per wavefront in the mark emission
+  uint32_t wide;                  // long rays (2 cm voxels): 8 rays per wavefront in the mark emission, views + dense iterations
+  const uint8_t* live;            // per position: it holds a ray
   EoCtl* ctl;
 };
 
@@ -442,13 +457,13 @@ struct EoBatch {
 };
 __global__ void __launch_bounds__(1024) k_eo2_scan(EoBatch Bt) {
   const EoView& E = Bt.v[blockIdx.y];
-  eo_scan_body(E.F, E.cnt_a, E.lp, E.bt, &E.ctl->st, E.cnt_b, E.ux, E.dirty);
+  eo_scan_body(E.F, E.cnt_a, E.lp, E.bt, &E.ctl->st, E.cnt_b, E.ux, E.dirty, E.wide ? E.rinfo : nullptr);
 }
 template <int RPW>
 __global__ void __launch_bounds__(256) k_eo2_emit(EoBatch Bt) {
   const EoView& E = Bt.v[blockIdx.y];
   eo_emit_body<RPW>(E.F, E.ray_list, E.rays, E.cnt_a, E.lp, E.bt, E.keys0, E.vals0, E.cap_marks, E.C, &E.ctl->st, &E.ctl->fail, E.btp, E.hseq_w,
-                    E.rinfo, E.ckpt);
+                    E.rinfo, E.ckpt, E.wide != 0u);
 }
 
 __device__ __forceinline__ uint32_t eo2_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -522,7 +537,7 @@ __global__ void __launch_bounds__(256) k_eo2_stop0(EoBatch Bt) {
 
 // The validity bitmaps under the new lengths (a wavefront's ballot is a word), and the readers whose input changed: the
 // owner of every valid mark whose predecessor in its slot is not valid any more.
-__global__ void __launch_bounds__(256) k_eo2_bits(EoBatch Bt) {
+__global__ void __launch_bounds__(256) k_eo2_bits(EoBatch Bt, uint32_t detect) {
   const EoView& E = Bt.v[blockIdx.y];
   const unsigned long long n = E.ctl->st.n_marks;
   if (E.ctl->fail) return;
@@ -539,7 +554,7 @@ __global__ void __launch_bounds__(256) k_eo2_bits(EoBatch Bt) {
       E.bits_a[j >> 6] = word;
       E.bits_b[j >> 6] = word;
     }
-    if (v && j > 0) {
+    if (detect && v && j > 0) {
       bool vprev;
       uint64_t kprev;
       if (lane_id() != 0) {
@@ -626,6 +641,132 @@ __device__ __forceinline__ uint32_t eo2_lower_bound(const EoView& E, uint32_t sl
     else hi = mid;
   }
   return lo;
+}
+
+// ---- long rays (2 cm voxels, 10 m: stage B is "wide"): DENSE iterations before the event-driven rounds ------------------
+// At that geometry the approximate set is overwhelmed (tens of marks per slot and frame), the seed is wrong on most rays,
+// and a third of the final marks lie beyond the steps the seed walked: as X marks they would make every slot's chain tens
+// of nodes long.  So the marks of M cover a ray's VIEW — its visited steps plus a pad (k_eo2_scan / k_eo2_emit) — and a
+// full Jacobi step is two streaming passes over what has been sorted ONCE:
+//   k_eo2_hits_b : per mark of M (valid or not: the ray may get there), is the visit a hit?  Its slot's content is the mark
+//                  of the highest set bit of A below it (or the ray's own previous visit of the slot, or what earlier frames
+//                  left) -> hit bit at the mark's place in emission order
+//   k_eo2_stopv  : per ray, the reference's stop rule over the view's contiguous hit bits -> new length; the marks between
+//                  the old and the new length change their bit in A
+// A few of these per EPOCH (emission + sort); a ray whose view ends before it stops gets a larger pad in the next epoch.
+// The last k_eo2_stopv leaves its changes to k_eo2_propagate (round 0), from where the event-driven rounds take over —
+// with few rays left to look at, and few steps left without a mark.
+constexpr uint32_t kEoPadBroken = 16;     // view of a ray that stops: this many steps past its stop
+constexpr uint32_t kEoPadGrow = 64;       // a ray whose view ended before it stopped: at least this much more, doubling
+constexpr uint32_t kEoPadMax = 4096;
+
+// per position: the ray's length in steps and its first pad (dead positions: an empty view)
+__global__ void __launch_bounds__(256) k_eo2_full(EoBatch Bt) {
+  const EoView& E = Bt.v[blockIdx.y];
+  const FrameParams F = *E.F;
+  for (uint32_t pos = blockIdx.x * 256u + threadIdx.x; pos < F.n; pos += gridDim.x * 256u) {
+    uint4 ri = make_uint4(0u, 0u, 0u, 0u);
+    if (E.live[pos]) {
+      const RayDesc d = E.rays[ray_index(F, pos)];
+      Dda dda{};
+      dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, false);
+      ri = make_uint4(0u, kEoPadBroken, (uint32_t)dda.steps + 1u, 0u);
+    }
+    E.rinfo[pos] = ri;
+  }
+}
+
+__global__ void __launch_bounds__(256) k_eo2_hits_b(EoBatch Bt) {
+  const EoView& E = Bt.v[blockIdx.y];
+  const unsigned long long n = E.ctl->st.n_marks;
+  if (E.ctl->fail) return;
+  for (unsigned long long j = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * 256ull) {
+    const uint64_t key = E.keys[j];
+    const uint32_t slot = (uint32_t)(key >> 44), pos = (uint32_t)(key >> 22) & 0x3fffffu, step = (uint32_t)key & 0x3fffffu;
+    const uint32_t h = E.vals[j];
+    long long i = -1;
+    bool first_of_slot = true;
+    if (j > 0) {
+      const uint64_t kp = E.keys[j - 1];
+      if ((uint32_t)(kp >> 44) == slot) {
+        first_of_slot = false;
+        if (((uint32_t)(kp >> 22) & 0x3fffffu) == pos) i = (long long)j - 1;   // the ray's own previous visit of the slot
+        else {
+          i = eo2_prev_set(E.bits_a, (uint32_t)j);
+          if (i >= 0 && (uint32_t)(E.keys[i] >> 44) != slot) i = -1;
+        }
+      }
+    }
+    if (first_of_slot) E.tab[slot].x = (uint32_t)j;
+    if (j + 1 == n || (uint32_t)(E.keys[j + 1] >> 44) != slot) E.tab[slot].y = (uint32_t)(j + 1);
+    bool hit;
+    if (i >= 0) {
+      hit = E.vals[i] == h;
+    } else {   // (as k_eo2_hits: the zero-initialised slot is the one entry of an earlier offset that can match)
+      hit = h == 0u ? E.ctl->assumed0 == 0ull : E.plain[slot] == (uint64_t)h;
+      if (h == 0u && !(atomicOr(&E.ux[pos], 0x80000000u) >> 31)) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos;
+    }
+    const unsigned long long at = E.btp[pos / kScanBlock] + E.lp[pos] + step;
+    E.hitb[at] = hit ? 1 : 0;
+    E.where[at] = (uint32_t)j;
+  }
+}
+
+// last = 0: the new lengths become current at once (nothing reads lengths or A in this launch); last = 1: they are the NEXT
+// lengths of round 0 (cnt_b, the change list, B) and k_eo2_propagate makes them current
+__global__ void __launch_bounds__(256) k_eo2_stopv(EoBatch Bt, uint32_t last) {
+  const EoView& E = Bt.v[blockIdx.y];
+  EoCtl* ctl = E.ctl;
+  if (ctl->fail) return;
+  const uint32_t n = E.C->n_rays;
+  const int lim = E.F->max_collisions;
+  for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
+    const uint32_t pos = E.ray_list[r];
+    const uint32_t cv = E.cnt_a[pos], vo = eo_visited(cv);
+    const uint4 ri = E.rinfo[pos];
+    const uint32_t view = ri.x, full = ri.z;
+    const unsigned long long base = E.btp[pos / kScanBlock] + E.lp[pos];
+    const uint8_t* hb = E.hitb + base;
+    int c = 0, stop = -1;
+    for (uint32_t k = 0; k < view; ++k) {
+      c = hb[k] ? c + 1 : 0;
+      if (c > lim) {
+        stop = (int)k;
+        break;
+      }
+    }
+    uint32_t now, pad;
+    if (stop >= 0) {
+      now = (uint32_t)stop | kCntBroke;
+      pad = kEoPadBroken;
+    } else if (view >= full) {
+      now = full;
+      pad = 0u;
+    } else {   // the view ends before the ray does: every step of it is visited, and the next view is longer
+      now = view;
+      pad = ri.y * 2u < kEoPadGrow ? kEoPadGrow : (ri.y * 2u > kEoPadMax ? kEoPadMax : ri.y * 2u);
+    }
+    if (pad != ri.y) E.rinfo[pos].y = pad;
+    if (now != cv) {
+      const uint32_t vn = eo_visited(now);
+      const uint32_t lo = vo < vn ? vo : vn, hi = vo < vn ? vn : vo;
+      for (uint32_t k = lo; k < hi; ++k) {
+        const uint32_t j = E.where[base + k];
+        if (vn > vo) {
+          atomicOr(&E.bits_b[j >> 6], 1ull << (j & 63u));
+          if (!last) atomicOr(&E.bits_a[j >> 6], 1ull << (j & 63u));
+        } else {
+          atomicAnd(&E.bits_b[j >> 6], ~(1ull << (j & 63u)));
+          if (!last) atomicAnd(&E.bits_a[j >> 6], ~(1ull << (j & 63u)));
+        }
+      }
+      E.cnt_b[pos] = now;
+      if (!last) E.cnt_a[pos] = now;
+      else E.chg[atomicAdd(&ctl->n_chg[0], 1u)] = pos;
+    }
+    // a ray that is still going when its marks end is cast on in round 1 (X marks from there)
+    if (last && stop < 0 && view < full) eo2_mark_dirty(E, pos, view, E.list[1], &ctl->n_in[1]);
+  }
 }
 
 // LDS of a wavefront of the round kernels

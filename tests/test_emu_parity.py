@@ -70,7 +70,9 @@ def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_lib):
     dict(method=0, size=[64, 48], frames=4, cfg=dict(clear_checks_every_n_frames=3)),   # a frame's marks are inputs of the next frame
     dict(method=0, size=[96, 72], frames=2, cloud="axis", max_tiles=8192),       # axis-parallel rays: the serial caster inside the rounds
     dict(method=0, size=[48, 27], frames=2, max_tiles=32768, cfg=dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0)),
-], ids=["default", "pipelined", "batched", "clear_every_3", "axis_parallel", "long_rays"])
+    # long rays, frames in flight, batches of four: marks over the rays' views, dense iterations, then the rounds (ks_k_exact.h)
+    dict(method=0, size=[48, 27], frames=6, pipeline=8, max_tiles=32768, cfg=dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0)),
+], ids=["default", "pipelined", "batched", "clear_every_3", "axis_parallel", "long_rays", "long_rays_batched"])
 def test_event_driven_exact_early_out_equals_serial_oracle(emu_lib, spec):
     run_case(emu_lib, spec)
 

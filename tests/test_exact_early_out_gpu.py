@@ -235,3 +235,34 @@ def test_full_size_c4_frame_exact_early_out_vs_real_reference(tmp_path):
     assert np.array_equal(rt["distance"].view(np.uint32), ht["distance"].view(np.uint32))
     assert np.array_equal(rt["weight"].view(np.uint32), ht["weight"].view(np.uint32))
     assert np.array_equal(rt["color"], ht["color"]) and np.array_equal(rs["color"], hs["color"])
+
+
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
+def test_three_full_size_c4_frames_on_the_device_vs_real_reference(tmp_path):
+    """Three consecutive FULL-SIZE C4 frames (1280x720, 2 cm voxels, 10 m rays), default `fast`: the reference's serial result
+    from the DEVICE loop — marks over the rays' views, dense iterations, then the event-driven rounds (csrc/ks_k_exact.h) —
+    not from the host-driven one: at most the first frame may repeat on the host (its mark buffers grow from their initial size),
+    and the context must still be event-driven afterwards.  HIP == the real reference sources, every voxel."""
+    geom = dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=10.0)
+    csv = str(tmp_path / "labels.csv")
+    R.write_label_csv(csv, synth.default_label_colors())
+    r = R.Reference("fast", csv, voxel_size=geom["voxel_size"], truncation=geom["truncation_distance"], max_ray=geom["max_ray_length_m"])
+    h = B.HipIntegrator(B.default_config(max_tiles=1 << 17, max_points=1280 * 720, **dict(COMMON, method=0, **geom)))
+    sc = synth.make_scene("hall")
+    for k in range(3):
+        f = synth.render_frame(sc, synth.trajectory_pose(3 + k, radius=3.0), 1280, 720, hfov_deg=75.0, seed=3 + k)
+        r.integrate(f.T_G_C, f.xyz, f.rgba)
+        st = h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        assert st.n_voxel_updates > 1e7
+    eo = h.early_out_stats()
+    print("three C4 frames, default mode:", eo)
+    assert eo["event_driven"] and eo["frames"] == 3 and eo["fallbacks"] <= 1, eo
+    ri, hi = r.block_indices(), h.block_indices()
+    assert np.array_equal(ri, hi)
+    _, rt, rs = r.download(ri)
+    _, ht, hs = h.download(ri)
+    assert np.array_equal(rs["label"], hs["label"])
+    assert np.array_equal(rs["priors"].view(np.uint32), hs["priors"].view(np.uint32))
+    assert np.array_equal(rt["distance"].view(np.uint32), ht["distance"].view(np.uint32))
+    assert np.array_equal(rt["weight"].view(np.uint32), ht["weight"].view(np.uint32))
+    assert np.array_equal(rt["color"], ht["color"]) and np.array_equal(rs["color"], hs["color"])
