@@ -472,14 +472,20 @@ def adapter_record(wl_frames):
             fh.write(f.xyz.astype("<f4").tobytes())
             fh.write(f.rgba.tobytes())
     out = {"config": "adapter", "workload": f"{len(wl_frames)} 640x480 host clouds through kimera::HipSemanticTsdfIntegrator "
-                                            "(TsdfIntegratorBase virtual), steady state = last third of the frames"}
-    for method in ("fast", "merged"):
-        for pipe, key in (("0", "every_frame_sync"), ("1", "on_demand_sync_pipelined")):
-            res = subprocess.run([demo, method, csv, fin, fout, "1", "2", "-1", pipe], capture_output=True, text=True, timeout=600)
-            mm = re.search(r"integratePointCloud ([0-9.]+) ms/frame over (\d+) frames, ([0-9.]+) ms/frame over the last (\d+)", res.stdout)
-            out[f"{method}_{key}_ms_per_frame"] = float(mm.group(3)) if mm else None
-            if not mm:
-                out[f"{method}_{key}_error"] = (res.stdout + res.stderr)[-300:]
+                                            "(TsdfIntegratorBase virtual), steady state = last third of the frames; every_frame_sync = what an "
+                                            "unmodified SemanticTsdfServer gets, on_demand = the sequence of integration/server.patch"}
+    real = os.path.join(ROOT, "integration", "_build", "adapter_demo_real")
+    runs = [(demo, m, pipe, f"{m}_{key}") for m in ("fast", "merged") for pipe, key in (("0", "every_frame_sync"), ("1", "on_demand_sync_pipelined"))]
+    if os.path.exists(real):
+        # the reference's OWN factory (its source + integration/factory.patch) hands the integrator out with default options,
+        # then the server-side patch's sequence: setSyncPolicy(kOnDemand), syncLayers() where the Layers are read
+        runs.append((real, "fast_hip", "1", "fast_hip_real_factory_patched_server_sequence"))
+    for exe, method, pipe, key in runs:
+        res = subprocess.run([exe, method, csv, fin, fout, "1", "2", "-1", pipe], capture_output=True, text=True, timeout=600)
+        mm = re.search(r"integratePointCloud ([0-9.]+) ms/frame over (\d+) frames, ([0-9.]+) ms/frame over the last (\d+)", res.stdout)
+        out[f"{key}_ms_per_frame"] = float(mm.group(3)) if mm else None
+        if not mm:
+            out[f"{key}_error"] = (res.stdout + res.stderr)[-300:]
     for p in (fin, fout):
         try:
             os.remove(p)
@@ -885,7 +891,7 @@ def main():
             torch.cuda.empty_cache()
             if want("adapter") and args.method == "fast":
                 try:
-                    sec.append(adapter_record([ring.host(i) for i in range(12)]))
+                    sec.append(adapter_record([ring.host(i) for i in range(2 * len(ring))]))   # two turns of the ring: the last third is steady state
                 except Exception as e:
                     sec.append({"config": "adapter", "error": f"{type(e).__name__}: {e}"})
             out["secondary"] = sec

@@ -255,7 +255,7 @@ struct ks_ctx {
   // ... event-driven (the default; KS_EXACT_HOST_LOOP=1: every frame through the host-driven loop above)
   bool eo_device = false;
   int eo_bulk_rounds = 6;                // rounds enqueued as launches before the one-workgroup finisher takes over
-  int eo_epochs = 3, eo_dense = 5;       // long rays: emissions of the marks over the rays' views, dense iterations per emission (ks_k_exact.h)
+  std::vector<int> eo_dense_list{3, 10, 14};   // long rays: one entry per emission of the marks over the rays' views = the dense iterations that follow it (ks_k_exact.h)
   std::atomic<int> eo_want_bulk{0};      // ... as a frame whose finisher was handed too long a list asks for (applied by the caller's thread between frames)
   uint32_t* d_eo_committed = nullptr;    // frames [0, *d_eo_committed) of the exact path have entered d_eo_plain
   uint32_t eo_frame_no = 0;              // frames launched through the exact path
@@ -266,6 +266,7 @@ struct ks_ctx {
   uint64_t eo_fallbacks_seen = 0;        // ... as of the caller's last look
   std::atomic<int> eo_hopeless{0};       // consecutive frames the device loop gave up on for reasons growing a buffer does not cure
   bool eo_device_off = false;            // ... three of them: the context stays with the host-driven loop (one frame at a time)
+  bool eo_trace = false;                 // KS_EXACT_TRACE=1: a line on stderr for every frame the device loop gives up (diagnostics)
   // merged in the reference's bundle order (ks_k_bundle_order.h): scratch of the rank computation, one slab
   bool use_bundle_rank = false;
   BoCtx bo{};
@@ -907,16 +908,21 @@ int enqueue_exact_rounds(ks_ctx* c, FrameSlot* const* slots, uint32_t nb, hipStr
     // long rays: marks over the rays' VIEWS, and dense iterations (two streaming passes per Jacobi step) over what has been
     // sorted once per epoch; the last of them hands over to the event-driven rounds through k_eo2_propagate (ks_k_exact.h)
     hipLaunchKernelGGL(k_eo2_full, dim3(gn, nb), dim3(256), 0, st, Bt);
-    for (int e = 0; e < c->eo_epochs; ++e) {
+    const int n_epochs = (int)c->eo_dense_list.size();
+    int it_no = 0;
+    for (int e = 0; e < n_epochs; ++e) {
       if (e > 0)   // the slots' ranges in the previous epoch's M (a slot may have no mark in this one)
         for (uint32_t k = 0; k < nb; ++k) HIPCHK(c, hipMemsetAsync(slots[k]->d_eo_tab, 0, sizeof(uint4) << kSetBits, st));
       hipLaunchKernelGGL(k_eo2_scan, dim3(nb4k, nb), dim3(1024), 0, st, Bt);
       hipLaunchKernelGGL(k_eo2_emit<8>, dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, Bt);
       HIPCHK(c, ksrs::sort_dev_batch<uint64_t>(Rs, (int)nb, S0.eo_sort_words, S0.eo_cap_marks, 44, 64, st));
       hipLaunchKernelGGL(k_eo2_bits, dim3(gm, nb), dim3(256), 0, st, Bt, 0u);
-      for (int d = 0; d < c->eo_dense; ++d) {
-        hipLaunchKernelGGL(k_eo2_hits_b, dim3(gm, nb), dim3(256), 0, st, Bt);
-        hipLaunchKernelGGL(k_eo2_stopv, dim3(gn, nb), dim3(256), 0, st, Bt, (e + 1 == c->eo_epochs && d + 1 == c->eo_dense) ? 1u : 0u);
+      // (the first epoch only has to find the rays that outgrow their views: a few iterations; the later ones iterate on)
+      const int n_dense = c->eo_dense_list[e];
+      for (int d = 0; d < n_dense; ++d, ++it_no) {
+        hipLaunchKernelGGL(k_eo2_hits_b, dim3(gm, nb), dim3(256), 0, st, Bt, d == 0 ? 1u : 0u);
+        hipLaunchKernelGGL(k_eo2_stopv, dim3((uint32_t)std::min<size_t>((n + 3) / 4, 4096), nb), dim3(256), 0, st, Bt,
+                           (e + 1 == n_epochs && d + 1 == n_dense) ? 1u : 0u, (uint32_t)it_no);
       }
     }
     hipLaunchKernelGGL(k_eo2_propagate, dim3((uint32_t)std::min<size_t>((n + 3) / 4, 2048), nb), dim3(256), 0, st, Bt, 0u);
@@ -1276,6 +1282,18 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     c->eo_iterations += S.h_snap->pad[2];   // rounds of the event-driven fix point (k_publish)
   }
   if (c->eo_device && !c->eo_device_off && !(cnt.err & kErrExact)) c->eo_hopeless.store(0, std::memory_order_relaxed);
+  if (c->eo_trace && c->eo_device && !c->eo_device_off && !(cnt.err & kErrExact) && S.d_eo_ctl) {   // KS_EXACT_TRACE=1 (diagnostics; a host wait)
+    EoCtl hctl;
+    (void)hipStreamSynchronize(st);
+    if (hipMemcpy(&hctl, S.d_eo_ctl, sizeof(hctl), hipMemcpyDeviceToHost) == hipSuccess) {
+      fprintf(stderr, "[ks exact] frame %llu on the device: marks %llu / cap %zu, X %u / cap %zu, rounds %u; lists:", (unsigned long long)S.frame_no,
+              (unsigned long long)hctl.st.n_marks, c->eo_cap_marks, hctl.n_x, c->eo_cap_x, hctl.rounds);
+      for (int r = 1; r <= c->eo_bulk_rounds + 1 && r < (int)kEoBulkMax + 2; ++r) fprintf(stderr, " %u", hctl.n_in[r]);
+      fprintf(stderr, "; dense iterations (changed/open):");
+      for (int i = 0; i < 32; ++i) fprintf(stderr, " %u/%u", hctl.dense_chg[i], hctl.dense_open[i]);
+      fprintf(stderr, "\n");
+    }
+  }
   if ((cnt.err & kErrExact) && !(cnt.err & (kErrLabel | kErrIndex))) {
     // The device-driven fix point gave up (marks or X marks did not fit, the finisher ran out of rounds, or the frame
     // before this one fell back and had not entered its marks yet): the host-driven loop repeats the fix point from
@@ -1310,6 +1328,14 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     if (dense) c->eo_hopeless.fetch_add(1, std::memory_order_relaxed);
     else if (!(hctl.fail & kEoFailChain)) c->eo_hopeless.store(0, std::memory_order_relaxed);
     c->eo_fallbacks.fetch_add(1, std::memory_order_relaxed);
+    if (c->eo_trace) {   // KS_EXACT_TRACE=1 (diagnostics): why the device loop gave this frame up
+      fprintf(stderr, "[ks exact] frame %llu falls back: fail %x (1 marks, 2 X marks, 4 rounds, 8 chain) marks %llu / cap %zu, X %u / cap %zu, rounds %u, dense %d; lists:",
+              (unsigned long long)S.frame_no, hctl.fail, (unsigned long long)hctl.st.n_marks, c->eo_cap_marks, hctl.n_x, c->eo_cap_x, hctl.rounds, (int)dense);
+      for (int r = 1; r <= c->eo_bulk_rounds + 1 && r < (int)kEoBulkMax + 2; ++r) fprintf(stderr, " %u", hctl.n_in[r]);
+      fprintf(stderr, "; dense iterations (changed/open):");
+      for (int i = 0; i < 32; ++i) fprintf(stderr, " %u/%u", hctl.dense_chg[i], hctl.dense_open[i]);
+      fprintf(stderr, "\n");
+    }
     Counters rcnt{};
     rcnt.n_rays = cnt.n_rays;
     HIPCHK(c, hipMemcpyAsync(c->d_retry_counters, &rcnt, sizeof(rcnt), hipMemcpyHostToDevice, st));
@@ -1917,8 +1943,20 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // is handed too long a list asks for more rounds as launches: eo_want_bulk)
     c->eo_bulk_rounds = wide_rays ? 32 : cfg->integration_order_mode == KS_ORDER_MIXED ? 8 : 14;
     if (const char* br = getenv("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
-    if (const char* ep = getenv("KS_EXACT_EPOCHS")) c->eo_epochs = std::min(8, std::max(1, atoi(ep)));      // (tuning runs: any value gives the same map)
-    if (const char* dn = getenv("KS_EXACT_DENSE")) c->eo_dense = std::min(16, std::max(1, atoi(dn)));
+    if (const char* tr = getenv("KS_EXACT_TRACE")) c->eo_trace = tr[0] == '1';
+    if (const char* dl = getenv("KS_EXACT_DENSE")) {   // tuning runs, e.g. "3,10,14" (any schedule gives the same map): at most 32 iterations in all
+      std::vector<int> v;
+      int total = 0;
+      for (const char* p = dl; *p && v.size() < 8;) {
+        const int d = std::max(1, atoi(p));
+        if (total + d > 32) break;
+        v.push_back(d);
+        total += d;
+        while (*p && *p != ',') ++p;
+        if (*p == ',') ++p;
+      }
+      if (!v.empty()) c->eo_dense_list = v;
+    }
   }
   c->uses_early_out = uses_early_out;
   c->use_bundle_rank = cfg->method == KS_METHOD_MERGED && cfg->bundle_order == KS_BUNDLE_ORDER_REFERENCE;

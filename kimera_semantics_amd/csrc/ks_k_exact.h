@@ -411,6 +411,8 @@ struct EoCtl {
   unsigned long long assumed0;    // what the slot of hash 0 held (as earlier frames left it) when the fix point began — see k_eo2_finish
   uint32_t n_in[kEoBulkMax + 2];  // dirty rays entering bulk round r
   uint32_t n_chg[kEoBulkMax + 2]; // rays whose length changed in bulk round r
+  uint32_t dense_chg[32];         // long rays: rays whose length changed in dense iteration i (statistics)
+  uint32_t dense_open[32];        // ... rays still going when their view ended
 };
 
 struct EoView {
@@ -653,12 +655,12 @@ __device__ __forceinline__ uint32_t eo2_lower_bound(const EoView& E, uint32_t sl
 //                  left) -> hit bit at the mark's place in emission order
 //   k_eo2_stopv  : per ray, the reference's stop rule over the view's contiguous hit bits -> new length; the marks between
 //                  the old and the new length change their bit in A
-// A few of these per EPOCH (emission + sort); a ray whose view ends before it stops gets a larger pad in the next epoch.
+// A few of these per EPOCH (emission + sort); a ray whose view ends before it stops gets its whole length as its next view
+// (rays that stop too early in the seed are the ones everything behind them waits for: measured on full-size 1280x720 frames,
+// a sixth of the rays outgrow a 16-step pad, and with views that only doubled the rounds afterwards made 5e6 X marks).
 // The last k_eo2_stopv leaves its changes to k_eo2_propagate (round 0), from where the event-driven rounds take over —
 // with few rays left to look at, and few steps left without a mark.
 constexpr uint32_t kEoPadBroken = 16;     // view of a ray that stops: this many steps past its stop
-constexpr uint32_t kEoPadGrow = 64;       // a ray whose view ended before it stopped: at least this much more, doubling
-constexpr uint32_t kEoPadMax = 4096;
 
 // per position: the ray's length in steps and its first pad (dead positions: an empty view)
 __global__ void __launch_bounds__(256) k_eo2_full(EoBatch Bt) {
@@ -676,64 +678,80 @@ __global__ void __launch_bounds__(256) k_eo2_full(EoBatch Bt) {
   }
 }
 
-__global__ void __launch_bounds__(256) k_eo2_hits_b(EoBatch Bt) {
+// `first`: the first iteration after an emission also records where[] (a mark's place in emission order -> its index in M)
+// and the slots' ranges in M.  The hit bits stay in M's order (a wavefront's ballot is a word of `hbits`: coalesced); the
+// ray-side kernel finds them through where[].
+__global__ void __launch_bounds__(256) k_eo2_hits_b(EoBatch Bt, uint32_t first) {
   const EoView& E = Bt.v[blockIdx.y];
   const unsigned long long n = E.ctl->st.n_marks;
   if (E.ctl->fail) return;
-  for (unsigned long long j = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * 256ull) {
-    const uint64_t key = E.keys[j];
-    const uint32_t slot = (uint32_t)(key >> 44), pos = (uint32_t)(key >> 22) & 0x3fffffu, step = (uint32_t)key & 0x3fffffu;
-    const uint32_t h = E.vals[j];
-    long long i = -1;
-    bool first_of_slot = true;
-    if (j > 0) {
-      const uint64_t kp = E.keys[j - 1];
-      if ((uint32_t)(kp >> 44) == slot) {
-        first_of_slot = false;
-        if (((uint32_t)(kp >> 22) & 0x3fffffu) == pos) i = (long long)j - 1;   // the ray's own previous visit of the slot
-        else {
-          i = eo2_prev_set(E.bits_a, (uint32_t)j);
-          if (i >= 0 && (uint32_t)(E.keys[i] >> 44) != slot) i = -1;
+  unsigned long long* __restrict__ hbits = (unsigned long long*)E.hitb;
+  const unsigned long long n_pad = (n + 63ull) & ~63ull;
+  const uint32_t lane = lane_id();
+  for (unsigned long long j = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; j < n_pad; j += (unsigned long long)gridDim.x * 256ull) {
+    bool hit = false;
+    if (j < n) {
+      const uint64_t key = E.keys[j];
+      const uint32_t slot = (uint32_t)(key >> 44), pos = (uint32_t)(key >> 22) & 0x3fffffu, step = (uint32_t)key & 0x3fffffu;
+      const uint32_t h = E.vals[j];
+      long long i = -1;
+      bool first_of_slot = true;
+      if (j > 0) {
+        const uint64_t kp = E.keys[j - 1];
+        if ((uint32_t)(kp >> 44) == slot) {
+          first_of_slot = false;
+          // the ray's own previous visit of the slot, or the mark right before if it counts: the common cases, without a scan
+          if (((uint32_t)(kp >> 22) & 0x3fffffu) == pos || ((E.bits_a[(j - 1) >> 6] >> ((j - 1) & 63ull)) & 1ull)) i = (long long)j - 1;
+          else {
+            i = eo2_prev_set(E.bits_a, (uint32_t)j);
+            if (i >= 0 && (uint32_t)(E.keys[i] >> 44) != slot) i = -1;
+          }
         }
       }
+      if (first) {
+        if (first_of_slot) E.tab[slot].x = (uint32_t)j;
+        if (j + 1 == n || (uint32_t)(E.keys[j + 1] >> 44) != slot) E.tab[slot].y = (uint32_t)(j + 1);
+        E.where[E.btp[pos / kScanBlock] + E.lp[pos] + step] = (uint32_t)j;
+      }
+      if (i >= 0) {
+        hit = E.vals[i] == h;
+      } else {   // (as k_eo2_hits: the zero-initialised slot is the one entry of an earlier offset that can match)
+        hit = h == 0u ? E.ctl->assumed0 == 0ull : E.plain[slot] == (uint64_t)h;
+        if (h == 0u && !(atomicOr(&E.ux[pos], 0x80000000u) >> 31)) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos;
+      }
     }
-    if (first_of_slot) E.tab[slot].x = (uint32_t)j;
-    if (j + 1 == n || (uint32_t)(E.keys[j + 1] >> 44) != slot) E.tab[slot].y = (uint32_t)(j + 1);
-    bool hit;
-    if (i >= 0) {
-      hit = E.vals[i] == h;
-    } else {   // (as k_eo2_hits: the zero-initialised slot is the one entry of an earlier offset that can match)
-      hit = h == 0u ? E.ctl->assumed0 == 0ull : E.plain[slot] == (uint64_t)h;
-      if (h == 0u && !(atomicOr(&E.ux[pos], 0x80000000u) >> 31)) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos;
-    }
-    const unsigned long long at = E.btp[pos / kScanBlock] + E.lp[pos] + step;
-    E.hitb[at] = hit ? 1 : 0;
-    E.where[at] = (uint32_t)j;
+    const unsigned long long word = __ballot(hit);
+    if (lane == 0) hbits[j >> 6] = word;
   }
 }
 
+// A wavefront per ray, 64 steps of its view per batch.
 // last = 0: the new lengths become current at once (nothing reads lengths or A in this launch); last = 1: they are the NEXT
 // lengths of round 0 (cnt_b, the change list, B) and k_eo2_propagate makes them current
-__global__ void __launch_bounds__(256) k_eo2_stopv(EoBatch Bt, uint32_t last) {
+__global__ void __launch_bounds__(256) k_eo2_stopv(EoBatch Bt, uint32_t last, uint32_t iter) {
   const EoView& E = Bt.v[blockIdx.y];
   EoCtl* ctl = E.ctl;
   if (ctl->fail) return;
   const uint32_t n = E.C->n_rays;
   const int lim = E.F->max_collisions;
-  for (uint32_t r = blockIdx.x * 256u + threadIdx.x; r < n; r += gridDim.x * 256u) {
+  const unsigned long long* __restrict__ hbits = (const unsigned long long*)E.hitb;
+  const uint32_t lane = lane_id(), w0 = blockIdx.x * 4u + (threadIdx.x >> 6), nw = gridDim.x * 4u;
+  for (uint32_t r = w0; r < n; r += nw) {
     const uint32_t pos = E.ray_list[r];
     const uint32_t cv = E.cnt_a[pos], vo = eo_visited(cv);
     const uint4 ri = E.rinfo[pos];
     const uint32_t view = ri.x, full = ri.z;
     const unsigned long long base = E.btp[pos / kScanBlock] + E.lp[pos];
-    const uint8_t* hb = E.hitb + base;
     int c = 0, stop = -1;
-    for (uint32_t k = 0; k < view; ++k) {
-      c = hb[k] ? c + 1 : 0;
-      if (c > lim) {
-        stop = (int)k;
-        break;
+    for (uint32_t k0 = 0; k0 < view && stop < 0; k0 += 64u) {
+      const bool act = k0 + lane < view;
+      bool hit = false;
+      if (act) {
+        const uint32_t j = E.where[base + k0 + lane];
+        hit = (hbits[j >> 6] >> (j & 63u)) & 1ull;
       }
+      const int st_r = early_out_stop(__ballot(act && hit), __ballot(act), lim, c);
+      if (st_r >= 0) stop = (int)k0 + st_r;
     }
     uint32_t now, pad;
     if (stop >= 0) {
@@ -742,15 +760,18 @@ __global__ void __launch_bounds__(256) k_eo2_stopv(EoBatch Bt, uint32_t last) {
     } else if (view >= full) {
       now = full;
       pad = 0u;
-    } else {   // the view ends before the ray does: every step of it is visited, and the next view is longer
+    } else {   // the view ends before the ray does: every step of it is visited, and the next view is the whole ray
       now = view;
-      pad = ri.y * 2u < kEoPadGrow ? kEoPadGrow : (ri.y * 2u > kEoPadMax ? kEoPadMax : ri.y * 2u);
+      pad = full;
     }
-    if (pad != ri.y) E.rinfo[pos].y = pad;
+    if (lane == 0) {
+      if (pad != ri.y) E.rinfo[pos].y = pad;
+      if (stop < 0 && view < full) atomicAdd(&ctl->dense_open[iter & 31u], 1u);
+    }
     if (now != cv) {
       const uint32_t vn = eo_visited(now);
       const uint32_t lo = vo < vn ? vo : vn, hi = vo < vn ? vn : vo;
-      for (uint32_t k = lo; k < hi; ++k) {
+      for (uint32_t k = lo + lane; k < hi; k += 64u) {
         const uint32_t j = E.where[base + k];
         if (vn > vo) {
           atomicOr(&E.bits_b[j >> 6], 1ull << (j & 63u));
@@ -760,12 +781,15 @@ __global__ void __launch_bounds__(256) k_eo2_stopv(EoBatch Bt, uint32_t last) {
           if (!last) atomicAnd(&E.bits_a[j >> 6], ~(1ull << (j & 63u)));
         }
       }
-      E.cnt_b[pos] = now;
-      if (!last) E.cnt_a[pos] = now;
-      else E.chg[atomicAdd(&ctl->n_chg[0], 1u)] = pos;
+      if (lane == 0) {
+        atomicAdd(&ctl->dense_chg[iter & 31u], 1u);
+        E.cnt_b[pos] = now;
+        if (!last) E.cnt_a[pos] = now;
+        else E.chg[atomicAdd(&ctl->n_chg[0], 1u)] = pos;
+      }
     }
     // a ray that is still going when its marks end is cast on in round 1 (X marks from there)
-    if (last && stop < 0 && view < full) eo2_mark_dirty(E, pos, view, E.list[1], &ctl->n_in[1]);
+    if (last && stop < 0 && view < full && lane == 0) eo2_mark_dirty(E, pos, view, E.list[1], &ctl->n_in[1]);
   }
 }
 

@@ -2,8 +2,8 @@
 // create the integrator through the factory, feed colour-encoded clouds through the
 // TsdfIntegratorBase virtual, then dump the host Layers.  Used by tests/test_host_adapter_gpu.py.
 //   adapter_demo <method> <labels.csv> <in.bin> <out.bin> [color_mode] [max_consecutive_ray_collisions] [restart_after] [pipeline]
-// pipeline = 1: SyncPolicy::kOnDemand + DeviceOptions::pipeline_frames (frames overlap on the GPU, the host
-// Layers are filled by one syncLayers() at the end, as a mesh timer would).
+// pipeline = 1: the patched server's sequence — factory with default options, THEN setSyncPolicy(kOnDemand) — frames
+// overlap on the GPU, the host Layers are filled by one syncLayers() at the end, as a mesh timer would.
 // restart_after = k: after frame k the integrator is destroyed and a new one is created on the
 // same, now non-empty, Layers (the loadMap / re-configure case): it must pick the map up from the host.
 // in.bin : u32 n_frames, then per frame { f32 T[7]; u32 n; f32 xyz[3n]; u8 rgba[4n] }
@@ -56,11 +56,9 @@ int main(int argc, char** argv) {
   kimera::HipSemanticTsdfIntegrator::DeviceOptions opt;
   opt.max_tiles = 4096;
   opt.max_points = 1u << 18;
+  // pipeline != 0: the sequence of a server with integration/server.patch — the factory hands the integrator out with its
+  // default options (strict policy), THEN the server selects kOnDemand and syncs where it reads the Layers
   const bool pipeline = argc > 8 && std::atoi(argv[8]) != 0;
-  if (pipeline) {
-    opt.sync_policy = kimera::HipSemanticTsdfIntegrator::SyncPolicy::kOnDemand;
-    opt.pipeline_frames = true;
-  }
 #ifdef KS_DEMO_REAL_FACTORY
   // integration/build_real_kimera.sh: the REAL kimera::SemanticTsdfIntegratorFactory (reference source +
   // integration/factory.patch) hands the integrator out, as SemanticTsdfServer's constructor gets it
@@ -79,6 +77,12 @@ int main(int argc, char** argv) {
   };
 #endif
   std::unique_ptr<vxb::TsdfIntegratorBase> integrator = make();
+  auto on_demand = [&]() {
+    if (!pipeline) return;
+    if (auto* hip = dynamic_cast<kimera::HipSemanticTsdfIntegrator*>(integrator.get()))
+      hip->setSyncPolicy(kimera::HipSemanticTsdfIntegrator::SyncPolicy::kOnDemand);
+  };
+  on_demand();
 
   FILE* in = std::fopen(argv[3], "rb");
   if (!in) return 3;
@@ -89,8 +93,11 @@ int main(int argc, char** argv) {
   uint32_t tail_frames = 0;
   for (uint32_t f = 0; f < n_frames; ++f) {
     if ((int)f == restart_after) {
+      if (pipeline)   // (a server syncs before it lets go of the integrator: the Layers are what the next one starts from)
+        if (auto* hip = dynamic_cast<kimera::HipSemanticTsdfIntegrator*>(integrator.get())) hip->syncLayers();
       integrator.reset();
       integrator = make();
+      on_demand();
     }
     float T[7];
     uint32_t n;

@@ -98,7 +98,7 @@ ks_config makeConfig(HipSemanticTsdfIntegrator::Method method, const vxb::TsdfIn
   k.device_id = o.device_id;
   k.max_tiles = o.max_tiles;
   k.max_points = o.max_points;
-  k.pipeline_frames = (o.pipeline_frames && o.sync_policy == HipSemanticTsdfIntegrator::SyncPolicy::kOnDemand) ? 2 : 0;
+  k.pipeline_frames = std::min(8, std::max(0, o.pipeline_frames));
   return k;
 }
 }  // namespace
@@ -184,6 +184,8 @@ void HipSemanticTsdfIntegrator::integratePointCloud(const vxb::Transformation& T
   merged_timer.Stop();
   if (options_.sync_policy == SyncPolicy::kEveryFrame) {
     vxb::timing::Timer insertion_timer("inserting_missed_blocks");
+    // (a context that can pipeline: the frame is completed here, and its statistics are this call's)
+    check(ks_flush(ctx_, &last_stats_), "ks_flush");
     syncLayers();
   }
 }
@@ -207,9 +209,12 @@ void HipSemanticTsdfIntegrator::integratePointCloud(const vxb::Transformation& T
   integrate_timer.Stop();
   if (options_.sync_policy == SyncPolicy::kEveryFrame) {
     vxb::timing::Timer insertion_timer("inserting_missed_blocks");
+    check(ks_flush(ctx_, &last_stats_), "ks_flush");
     syncLayers();
   }
 }
+
+void HipSemanticTsdfIntegrator::clearDeviceMap() { check(ks_clear(ctx_), "ks_clear"); }
 
 HipSemanticTsdfIntegrator::Workers::~Workers() {
   {

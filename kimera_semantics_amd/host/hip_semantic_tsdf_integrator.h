@@ -39,10 +39,11 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
     uint32_t max_tiles = 1u << 16;   ///< 8^3-voxel tiles (49.7 KB each)
     uint32_t max_points = 1u << 20;
     SyncPolicy sync_policy = SyncPolicy::kEveryFrame;
-    /// ks_config.pipeline_frames: overlap the host wait of frame i with the GPU work of frame i+1.
-    /// Only takes effect with kOnDemand (kEveryFrame reads the map back after every frame, which
-    /// completes the frame first).
-    bool pipeline_frames = false;
+    /// ks_config.pipeline_frames (0 .. 8): how many calls the second half of a frame may lag behind.  The context is
+    /// created able to pipeline whatever the policy: under kEveryFrame every call completes its frame anyway (the layer sync
+    /// does), and a server that switches to kOnDemand AFTER the factory handed the integrator out (integration/server.patch)
+    /// gets overlapping frames without the integrator being rebuilt.  0: never pipeline.
+    int pipeline_frames = 8;
     /// syncLayers() moves only the VOXELS written since the previous sync (ks_download_updated_voxels: 120-byte
     /// records scattered into the host blocks) instead of whole updated blocks (ks_download_blocks).
     bool voxel_sync = true;
@@ -89,6 +90,8 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
   /// Switch between the strict and the on-demand policy at run time (integration/server.patch: a server that calls
   /// syncLayers() where it reads the Layers selects kOnDemand right after the factory handed the integrator out).
   void setSyncPolicy(SyncPolicy policy) { options_.sync_policy = policy; }
+  /// Empties the GPU map (vxb::TsdfServer::clear() empties the host Layers: integration/server.patch calls both).
+  void clearDeviceMap();
   SyncPolicy syncPolicy() const { return options_.sync_policy; }
 
   ks_ctx* context() { return ctx_; }

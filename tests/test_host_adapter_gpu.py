@@ -212,3 +212,32 @@ def test_real_factory_default_fast_early_out_is_the_reference_result(tmp_path, m
     assert np.array_equal(t["distance"].view(np.uint32), ot["distance"].view(np.uint32))
     assert np.array_equal(t["weight"].view(np.uint32), ot["weight"].view(np.uint32))
     assert np.array_equal(t["color"], ot["color"]) and np.array_equal(s["color"], os_["color"])
+
+
+@pytest.mark.skipif(not os.path.exists(REAL_DEMO), reason="integration/_build not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("method,restart", [("fast_hip", -1), ("merged_hip", -1), ("fast_hip", 6)])
+def test_patched_server_sequence_through_the_real_factory_is_pipelined_and_exact(tmp_path, method, restart):
+    """What a SemanticTsdfServer with integration/server.patch does: the reference's own factory hands the integrator out with
+    default options (strict policy), THEN setSyncPolicy(kOnDemand); 11 frames (more than the pipeline's lag of 8 plus a batch
+    of four) with the reference's default early-out, one syncLayers() at the end (and before the integrator is replaced,
+    restart = 6).  The context was created able to pipeline, so the frames overlap — and the map is the serial oracle's."""
+    sc = synth.make_scene("room")
+    frames = [synth.render_frame(sc, synth.trajectory_pose(3 * k), 160, 120, seed=140 + k) for k in range(11)]
+    csv, fin, fout = str(tmp_path / "labels.csv"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    R.write_label_csv(csv, synth.default_label_colors())
+    _write_in(fin, frames)
+    res = subprocess.run([REAL_DEMO, method, csv, fin, fout, "1", "2", str(restart), "1"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "kOnDemand + pipeline_frames" in res.stdout
+    idx, t, s = _read_out(fout)
+    is_merged = method == "merged_hip"
+    o = O.Oracle(O.default_config(**dict(COMMON, method=1 if is_merged else 0, color_mode=1, integrator_threads=1)))
+    for f in frames:
+        o.integrate(f.T_G_C, f.xyz, None if is_merged else f.rgba, f.labels)
+    oi, ot, os_ = o.download()
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(s["label"], os_["label"])
+    assert np.array_equal(s["priors"].view(np.uint32), os_["priors"].view(np.uint32))
+    assert np.array_equal(t["distance"].view(np.uint32), ot["distance"].view(np.uint32))
+    assert np.array_equal(t["weight"].view(np.uint32), ot["weight"].view(np.uint32))
+    assert np.array_equal(t["color"], ot["color"]) and np.array_equal(s["color"], os_["color"])
