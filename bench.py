@@ -848,9 +848,8 @@ def main():
                     sec.append({"config": name, "error": f"{type(e).__name__}: {e}"})
             # ---- C4: 1280x720, 2 cm voxels, 10 m rays (both integrators on the same frames) ----
             c4_ring = None
-            # (C4-fast in the default mode: at 2 cm voxels / 10 m rays the approximate set is overwhelmed — ~30 marks per slot and
-            # frame — and the serial early-out is reproduced by the host-driven loop, tens of full iterations per frame: a few
-            # frames only)
+            # (C4-fast in the default mode: the reference's serial result from the device loop for long rays — whole-ray marks
+            # sorted once, then sweeps along the chains of the integration order, DESIGN.md 3.8 — one frame at a time)
             for name, steps, tiles, c4cfg in (("C4-fast", C4_STEPS, 1 << 16, {}), ("C4-fast-ordered-phases", C4_STEPS, 1 << 16, dict(early_out_phase_growth=32)),
                                               ("C4-merged", C4_STEPS, 1 << 16, {})):
                 if not want(name):
@@ -863,12 +862,12 @@ def main():
                         sec.append({"config": name, "skipped": f"the run is {time.time() - t_start:.0f} s old"})
                         continue
                     light = name == "C4-fast"
-                    sm = measure(B, torch, dist, dev, swl, c4_ring, 1 if light else 2, steps, 3 if light else MIN_REPEATS, pipeline, tiles, 1,
-                                 prime=4 if light else None, **c4cfg)
+                    sm = measure(B, torch, dist, dev, swl, c4_ring, 2, steps, MIN_REPEATS, pipeline, tiles, 1,
+                                 prime=steps if light else None, **c4cfg)
                     scale, show = 1.0, "GPU's own count (oracle count skipped)"
                     if light:
                         show = ("GPU's own count = the serial reference's: the default mode is the reference's result bit for bit "
-                                "(tests/test_exact_early_out_gpu.py::test_full_size_c4_frame_exact_early_out_vs_real_reference)")
+                                "(tests/test_exact_early_out_gpu.py::test_three_full_size_c4_frames_on_the_device_vs_real_reference)")
                     elif not args.no_oracle_count:
                         # the serial oracle needs ~10 s per C4 frame: count ONE timed frame, compare with the GPU's count of it
                         i0 = 2

@@ -255,7 +255,10 @@ struct ks_ctx {
   // ... event-driven (the default; KS_EXACT_HOST_LOOP=1: every frame through the host-driven loop above)
   bool eo_device = false;
   int eo_bulk_rounds = 6;                // rounds enqueued as launches before the one-workgroup finisher takes over
-  std::vector<int> eo_dense_list{3, 10, 14};   // long rays: one entry per emission of the marks over the rays' views = the dense iterations that follow it (ks_k_exact.h)
+  int eo_sweeps = 12;                    // long rays: sweeps enqueued at a time (they end themselves once one changes nothing); the host looks
+                                         // at the count once per such chunk (launch_batch) and enqueues more while rays still change
+  int eo_sweep_chunks = 16;              // ... at most this many chunks, then the host-driven loop takes the frame
+  int eo_sweep_order = 1;                // 0: rays in integration order; 1: a wavefront per chain segment, its rays one after the other   // long rays: one entry per emission of the marks over the rays' views = the dense iterations that follow it (ks_k_exact.h)
   std::atomic<int> eo_want_bulk{0};      // ... as a frame whose finisher was handed too long a list asks for (applied by the caller's thread between frames)
   uint32_t* d_eo_committed = nullptr;    // frames [0, *d_eo_committed) of the exact path have entered d_eo_plain
   uint32_t eo_frame_no = 0;              // frames launched through the exact path
@@ -882,6 +885,22 @@ EoView eo_view(ks_ctx* c, const FrameSlot& S) {
   E.ctl = S.d_eo_ctl;
   return E;
 }
+// long rays: `count` sweeps (each ends at once when the one before it changed nothing), ks_k_exact.h
+void enqueue_sweeps(ks_ctx* c, const EoBatch& Bt, uint32_t nb, int count, hipStream_t st) {
+  const size_t n = c->cap_points;
+  uint32_t grid;
+  if (c->eo_sweep_order == 0) {
+    grid = (uint32_t)std::min<size_t>((n + 3) / 4, 1 << 20);
+  } else {
+    const size_t waves = (size_t)order_chains_cap(c->cfg.integration_order_mode, n) *
+                         ((order_generations_cap(c->cfg.integration_order_mode, n) + kEoSweepSegment - 1) / kEoSweepSegment);
+    grid = (uint32_t)std::min<size_t>((waves + 3) / 4, 1 << 16);
+  }
+  for (int i = 0; i < count; ++i) {
+    hipLaunchKernelGGL(k_eo2_sweep, dim3(grid, nb), dim3(256), 0, st, Bt, (uint32_t)c->eo_sweep_order);
+    hipLaunchKernelGGL(k_eo2_sweep_next, dim3(nb), dim3(64), 0, st, Bt);
+  }
+}
 // part 1: the seeds' marks, sorted by slot, the full first iteration and the bulk rounds — for all nb frames of the batch
 // per launch (after the ordered phases, which leave the seeds in the slots' d_cnt)
 int enqueue_exact_rounds(ks_ctx* c, FrameSlot* const* slots, uint32_t nb, hipStream_t st) {
@@ -905,27 +924,16 @@ int enqueue_exact_rounds(ks_ctx* c, FrameSlot* const* slots, uint32_t nb, hipStr
   const uint32_t gm = (uint32_t)std::min<size_t>((S0.eo_cap_marks + 255) / 256, 2048);
   const uint32_t gn = (uint32_t)std::min<size_t>((n + 255) / 256, 2048);
   if (S0.wide) {
-    // long rays: marks over the rays' VIEWS, and dense iterations (two streaming passes per Jacobi step) over what has been
-    // sorted once per epoch; the last of them hands over to the event-driven rounds through k_eo2_propagate (ks_k_exact.h)
-    hipLaunchKernelGGL(k_eo2_full, dim3(gn, nb), dim3(256), 0, st, Bt);
-    const int n_epochs = (int)c->eo_dense_list.size();
-    int it_no = 0;
-    for (int e = 0; e < n_epochs; ++e) {
-      if (e > 0)   // the slots' ranges in the previous epoch's M (a slot may have no mark in this one)
-        for (uint32_t k = 0; k < nb; ++k) HIPCHK(c, hipMemsetAsync(slots[k]->d_eo_tab, 0, sizeof(uint4) << kSetBits, st));
-      hipLaunchKernelGGL(k_eo2_scan, dim3(nb4k, nb), dim3(1024), 0, st, Bt);
-      hipLaunchKernelGGL(k_eo2_emit<8>, dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, Bt);
-      HIPCHK(c, ksrs::sort_dev_batch<uint64_t>(Rs, (int)nb, S0.eo_sort_words, S0.eo_cap_marks, 44, 64, st));
-      hipLaunchKernelGGL(k_eo2_bits, dim3(gm, nb), dim3(256), 0, st, Bt, 0u);
-      // (the first epoch only has to find the rays that outgrow their views: a few iterations; the later ones iterate on)
-      const int n_dense = c->eo_dense_list[e];
-      for (int d = 0; d < n_dense; ++d, ++it_no) {
-        hipLaunchKernelGGL(k_eo2_hits_b, dim3(gm, nb), dim3(256), 0, st, Bt, d == 0 ? 1u : 0u);
-        hipLaunchKernelGGL(k_eo2_stopv, dim3((uint32_t)std::min<size_t>((n + 3) / 4, 4096), nb), dim3(256), 0, st, Bt,
-                           (e + 1 == n_epochs && d + 1 == n_dense) ? 1u : 0u, (uint32_t)it_no);
-      }
-    }
-    hipLaunchKernelGGL(k_eo2_propagate, dim3((uint32_t)std::min<size_t>((n + 3) / 4, 2048), nb), dim3(256), 0, st, Bt, 0u);
+    // long rays: ONE emission whose views are the whole rays, then sweeps in integration order over the live bitmap, every
+    // change applied at once (ks_k_exact.h); the sweeps end themselves when one of them changes nothing
+    hipLaunchKernelGGL(k_eo2_full, dim3(gn, nb), dim3(256), 0, st, Bt, 0u);
+    hipLaunchKernelGGL(k_eo2_scan, dim3(nb4k, nb), dim3(1024), 0, st, Bt);
+    hipLaunchKernelGGL(k_eo2_emit<8>, dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, Bt);
+    HIPCHK(c, ksrs::sort_dev_batch<uint64_t>(Rs, (int)nb, S0.eo_sort_words, S0.eo_cap_marks, 44, 64, st));
+    hipLaunchKernelGGL(k_eo2_bits, dim3(gm, nb), dim3(256), 0, st, Bt, 0u);
+    hipLaunchKernelGGL(k_eo2_where, dim3(gm, nb), dim3(256), 0, st, Bt);
+    enqueue_sweeps(c, Bt, nb, c->eo_sweeps, st);
+    return KS_OK;
   } else {
     hipLaunchKernelGGL(k_eo2_scan, dim3(nb4k, nb), dim3(1024), 0, st, Bt);
     hipLaunchKernelGGL(k_eo2_emit<64>, dim3((uint32_t)((n + 255) / 256), nb), dim3(256), lds, st, Bt);
@@ -990,7 +998,7 @@ int launch_batch(ks_ctx* c) {
   if (c->exact_early_out && c->eo_device && !c->eo_device_off) {
     // (batches of one) the ordered phases give the seed; the event-driven fix point makes it the serial result, on the
     // device: three replayed graphs, the wait for the previous frame's marks between the first two
-    bool graphs = c->use_graphs;
+    bool graphs = c->use_graphs && !S0.wide;   // (long rays: the host looks at the sweeps' progress between chunks of them)
     if (graphs && (S0.b_graph_key != key || !S0.b_graph || !S0.b_graph2 || !S0.b_graph3)) {
       std::lock_guard<std::mutex> cap(c->capture_mu);
       for (hipGraphExec_t* g : {&S0.b_graph, &S0.b_graph2, &S0.b_graph3}) {
@@ -1032,6 +1040,25 @@ int launch_batch(ks_ctx* c) {
     else {
       enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
       if ((rc = enqueue_exact_rounds(c, slots.data(), nb, sm))) return rc;
+      if (S0.wide) {
+        // the sweeps go on until one of them changes nothing: the host reads two words per chunk of sweeps (a frame is tens of
+        // milliseconds of GPU work here, and one frame at a time: ks_create)
+        EoBatch Bt{};
+        for (uint32_t k = 0; k < nb; ++k) Bt.v[k] = eo_view(c, *slots[k]);
+        for (int chunk = 1;; ++chunk) {
+          bool going = false;
+          for (uint32_t k = 0; k < nb; ++k) {
+            uint32_t w[2] = {0u, 0u};   // {sw_prev, fail}
+            HIPCHK(c, hipMemcpyAsync(&w[0], &slots[k]->d_eo_ctl->sw_prev, sizeof(uint32_t), hipMemcpyDeviceToHost, sm));
+            HIPCHK(c, hipMemcpyAsync(&w[1], &slots[k]->d_eo_ctl->fail, sizeof(uint32_t), hipMemcpyDeviceToHost, sm));
+            HIPCHK(c, hipStreamSynchronize(sm));
+            going = going || (w[0] != 0u && w[1] == 0u);
+          }
+          if (!going || chunk >= c->eo_sweep_chunks) break;
+          enqueue_sweeps(c, Bt, nb, c->eo_sweeps, sm);
+        }
+        hipLaunchKernelGGL(k_eo2_sweep_done, dim3(nb), dim3(64), 0, sm, Bt);
+      }
     }
     if (c->eo_last_commit && c->eo_last_commit != S0.eo_committed) HIPCHK(c, hipStreamWaitEvent(sm, c->eo_last_commit, 0));
     if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph2, sm));
@@ -1289,8 +1316,8 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
       fprintf(stderr, "[ks exact] frame %llu on the device: marks %llu / cap %zu, X %u / cap %zu, rounds %u; lists:", (unsigned long long)S.frame_no,
               (unsigned long long)hctl.st.n_marks, c->eo_cap_marks, hctl.n_x, c->eo_cap_x, hctl.rounds);
       for (int r = 1; r <= c->eo_bulk_rounds + 1 && r < (int)kEoBulkMax + 2; ++r) fprintf(stderr, " %u", hctl.n_in[r]);
-      fprintf(stderr, "; dense iterations (changed/open):");
-      for (int i = 0; i < 32; ++i) fprintf(stderr, " %u/%u", hctl.dense_chg[i], hctl.dense_open[i]);
+      fprintf(stderr, "; sweeps (rays changed):");
+      for (int i = 0; i < 32; ++i) fprintf(stderr, " %u%s", hctl.dense_chg[i] & 0x7fffffffu, (hctl.dense_chg[i] >> 31) ? "F" : "");
       fprintf(stderr, "\n");
     }
   }
@@ -1332,8 +1359,8 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
       fprintf(stderr, "[ks exact] frame %llu falls back: fail %x (1 marks, 2 X marks, 4 rounds, 8 chain) marks %llu / cap %zu, X %u / cap %zu, rounds %u, dense %d; lists:",
               (unsigned long long)S.frame_no, hctl.fail, (unsigned long long)hctl.st.n_marks, c->eo_cap_marks, hctl.n_x, c->eo_cap_x, hctl.rounds, (int)dense);
       for (int r = 1; r <= c->eo_bulk_rounds + 1 && r < (int)kEoBulkMax + 2; ++r) fprintf(stderr, " %u", hctl.n_in[r]);
-      fprintf(stderr, "; dense iterations (changed/open):");
-      for (int i = 0; i < 32; ++i) fprintf(stderr, " %u/%u", hctl.dense_chg[i], hctl.dense_open[i]);
+      fprintf(stderr, "; sweeps (rays changed):");
+      for (int i = 0; i < 32; ++i) fprintf(stderr, " %u%s", hctl.dense_chg[i] & 0x7fffffffu, (hctl.dense_chg[i] >> 31) ? "F" : "");
       fprintf(stderr, "\n");
     }
     Counters rcnt{};
@@ -1938,25 +1965,17 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // of the dependence between frames — the zero-initialised slot — is carried by the commit events.
     if (c->exact_early_out && (!c->eo_device || c->cfg.clear_checks_every_n_frames > 1)) c->cfg.pipeline_frames = 0;
     const bool wide_rays = steps_max_of(c->cfg, (float)(1.0 / cfg->voxel_size)) > 400;
+    // (long rays: a frame's marks cover whole rays — 2e8 marks of 33 bytes at 1280x720 / 2 cm — and a frame is tens of
+    // milliseconds of GPU work: one frame at a time, one set of mark buffers)
+    if (c->exact_early_out && wide_rays) c->cfg.pipeline_frames = 0;
     // (rounds the fix point needs from the doubling seed, 640x480 / 5 cm, tools/fixpoint_study.py: 7 in the upstream form of the
     // "mixed" order, 11-13 in the 1024-group form; a frame that needs more hands the rest to the finisher, and a finisher that
     // is handed too long a list asks for more rounds as launches: eo_want_bulk)
     c->eo_bulk_rounds = wide_rays ? 32 : cfg->integration_order_mode == KS_ORDER_MIXED ? 8 : 14;
     if (const char* br = getenv("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
     if (const char* tr = getenv("KS_EXACT_TRACE")) c->eo_trace = tr[0] == '1';
-    if (const char* dl = getenv("KS_EXACT_DENSE")) {   // tuning runs, e.g. "3,10,14" (any schedule gives the same map): at most 32 iterations in all
-      std::vector<int> v;
-      int total = 0;
-      for (const char* p = dl; *p && v.size() < 8;) {
-        const int d = std::max(1, atoi(p));
-        if (total + d > 32) break;
-        v.push_back(d);
-        total += d;
-        while (*p && *p != ',') ++p;
-        if (*p == ',') ++p;
-      }
-      if (!v.empty()) c->eo_dense_list = v;
-    }
+    if (const char* sw = getenv("KS_EXACT_SWEEPS")) c->eo_sweeps = std::min(64, std::max(1, atoi(sw)));   // (tuning runs: any value gives the same map)
+    if (const char* so = getenv("KS_EXACT_SWEEP_ORDER")) c->eo_sweep_order = so[0] == '0' ? 0 : 1;
   }
   c->uses_early_out = uses_early_out;
   c->use_bundle_rank = cfg->method == KS_METHOD_MERGED && cfg->bundle_order == KS_BUNDLE_ORDER_REFERENCE;

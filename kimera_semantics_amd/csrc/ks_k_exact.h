@@ -411,8 +411,9 @@ struct EoCtl {
   unsigned long long assumed0;    // what the slot of hash 0 held (as earlier frames left it) when the fix point began — see k_eo2_finish
   uint32_t n_in[kEoBulkMax + 2];  // dirty rays entering bulk round r
   uint32_t n_chg[kEoBulkMax + 2]; // rays whose length changed in bulk round r
-  uint32_t dense_chg[32];         // long rays: rays whose length changed in dense iteration i (statistics)
-  uint32_t dense_open[32];        // ... rays still going when their view ended
+  uint32_t dense_chg[32];         // long rays: rays whose length changed in sweep i (mod 32; statistics)
+  uint32_t sw_prev, sw_cur;       // ... 0: a full sweep changed nothing — the fixed point / rays changed by the sweep that is running
+  uint32_t sw_full, sw_pad;       // the next sweep looks at every ray (else: at the flagged ones)
 };
 
 struct EoView {
@@ -583,6 +584,18 @@ __device__ __forceinline__ long long eo2_prev_set(const unsigned long long* __re
     x = bits[w];
   }
 }
+// (the same, reading past the L1: for kernels that read bits other wavefronts — or they themselves — flip while they run)
+__device__ __forceinline__ long long eo2_prev_set_live(const unsigned long long* bits, uint32_t j) {
+  if (j == 0u) return -1;
+  uint32_t w = (j - 1u) >> 6;
+  unsigned long long x = eo2_ld64(&bits[w]) & (~0ull >> (63u - ((j - 1u) & 63u)));
+  for (;;) {
+    if (x != 0ull) return (long long)w * 64 + (63 - __clzll((long long)x));
+    if (w == 0u) return -1;
+    --w;
+    x = eo2_ld64(&bits[w]);
+  }
+}
 __device__ __forceinline__ unsigned long long eo2_next_set(const unsigned long long* __restrict__ bits, unsigned long long j, unsigned long long n) {
   const unsigned long long n_words = (n + 63ull) >> 6;
   unsigned long long w = j >> 6;
@@ -645,25 +658,17 @@ __device__ __forceinline__ uint32_t eo2_lower_bound(const EoView& E, uint32_t sl
   return lo;
 }
 
-// ---- long rays (2 cm voxels, 10 m: stage B is "wide"): DENSE iterations before the event-driven rounds ------------------
+// ---- long rays (2 cm voxels, 10 m: stage B is "wide") ----------------------------------------------------------------------
 // At that geometry the approximate set is overwhelmed (tens of marks per slot and frame), the seed is wrong on most rays,
 // and a third of the final marks lie beyond the steps the seed walked: as X marks they would make every slot's chain tens
-// of nodes long.  So the marks of M cover a ray's VIEW — its visited steps plus a pad (k_eo2_scan / k_eo2_emit) — and a
-// full Jacobi step is two streaming passes over what has been sorted ONCE:
-//   k_eo2_hits_b : per mark of M (valid or not: the ray may get there), is the visit a hit?  Its slot's content is the mark
-//                  of the highest set bit of A below it (or the ray's own previous visit of the slot, or what earlier frames
-//                  left) -> hit bit at the mark's place in emission order
-//   k_eo2_stopv  : per ray, the reference's stop rule over the view's contiguous hit bits -> new length; the marks between
-//                  the old and the new length change their bit in A
-// A few of these per EPOCH (emission + sort); a ray whose view ends before it stops gets its whole length as its next view
-// (rays that stop too early in the seed are the ones everything behind them waits for: measured on full-size 1280x720 frames,
-// a sixth of the rays outgrow a 16-step pad, and with views that only doubled the rounds afterwards made 5e6 X marks).
-// The last k_eo2_stopv leaves its changes to k_eo2_propagate (round 0), from where the event-driven rounds take over —
-// with few rays left to look at, and few steps left without a mark.
-constexpr uint32_t kEoPadBroken = 16;     // view of a ray that stops: this many steps past its stop
+// of nodes long.  So the marks of M cover a ray's VIEW — here the whole ray (k_eo2_full; k_eo2_scan / k_eo2_emit) — emitted
+// and sorted ONCE per frame; a mark counts while its step is below its ray's current length (bitmap A), and no step is
+// ever without a mark.
+constexpr uint32_t kEoPadBroken = 16;     // (a first pad other than the whole ray: k_eo2_full)
 
-// per position: the ray's length in steps and its first pad (dead positions: an empty view)
-__global__ void __launch_bounds__(256) k_eo2_full(EoBatch Bt) {
+// per position: the ray's length in steps and its pad (dead positions: an empty view)
+// (first_pad = 0: the whole ray is the view)
+__global__ void __launch_bounds__(256) k_eo2_full(EoBatch Bt, uint32_t first_pad) {
   const EoView& E = Bt.v[blockIdx.y];
   const FrameParams F = *E.F;
   for (uint32_t pos = blockIdx.x * 256u + threadIdx.x; pos < F.n; pos += gridDim.x * 256u) {
@@ -672,125 +677,202 @@ __global__ void __launch_bounds__(256) k_eo2_full(EoBatch Bt) {
       const RayDesc d = E.rays[ray_index(F, pos)];
       Dda dda{};
       dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, false);
-      ri = make_uint4(0u, kEoPadBroken, (uint32_t)dda.steps + 1u, 0u);
+      ri = make_uint4(0u, first_pad ? first_pad : (uint32_t)dda.steps + 1u, (uint32_t)dda.steps + 1u, 0u);
     }
     E.rinfo[pos] = ri;
   }
 }
 
-// `first`: the first iteration after an emission also records where[] (a mark's place in emission order -> its index in M)
-// and the slots' ranges in M.  The hit bits stay in M's order (a wavefront's ballot is a word of `hbits`: coalesced); the
-// ray-side kernel finds them through where[].
-__global__ void __launch_bounds__(256) k_eo2_hits_b(EoBatch Bt, uint32_t first) {
+// per sorted mark: where[] of its place in emission order = its index in M; the slots' ranges in M
+__global__ void __launch_bounds__(256) k_eo2_where(EoBatch Bt) {
   const EoView& E = Bt.v[blockIdx.y];
   const unsigned long long n = E.ctl->st.n_marks;
   if (E.ctl->fail) return;
-  unsigned long long* __restrict__ hbits = (unsigned long long*)E.hitb;
-  const unsigned long long n_pad = (n + 63ull) & ~63ull;
-  const uint32_t lane = lane_id();
-  for (unsigned long long j = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; j < n_pad; j += (unsigned long long)gridDim.x * 256ull) {
+  for (unsigned long long j = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; j < n; j += (unsigned long long)gridDim.x * 256ull) {
+    const uint64_t key = E.keys[j];
+    const uint32_t slot = (uint32_t)(key >> 44), pos = (uint32_t)(key >> 22) & 0x3fffffu, step = (uint32_t)key & 0x3fffffu;
+    if (j == 0 || (uint32_t)(E.keys[j - 1] >> 44) != slot) E.tab[slot].x = (uint32_t)j;
+    if (j + 1 == n || (uint32_t)(E.keys[j + 1] >> 44) != slot) E.tab[slot].y = (uint32_t)(j + 1);
+    E.where[E.btp[pos / kScanBlock] + E.lp[pos] + step] = (uint32_t)j;
+  }
+}
+
+// ---- long rays: SWEEPS ------------------------------------------------------------------------------------------------------
+// Jacobi steps (k_eo2_hits_b + k_eo2_stopv, or the rounds) move a change ONE ray further per step, and at 2 cm / 10 m a
+// change travels far: measured on full-size 1280x720 frames, 1e4 rays still change after 32 steps and the host-driven loop
+// needs ~90.  The reference's loop is a single pass because every ray sees what the rays before it left.  A sweep is the
+// parallel version of that: a wavefront per ray, rays taken in INTEGRATION ORDER (the hardware starts workgroups in order,
+// and ~8000 wavefronts are resident of 6.5e5 rays), every visit looked up in the live bitmap A (through where[]: the
+// marks of M cover the whole ray), and a changed length applied AT ONCE — so a ray that starts later sees it.  What a
+// wavefront reads may be stale or half applied (plain loads, other wavefronts' atomics): that only costs another sweep,
+// because a sweep in which NO length changed has read one unchanging state, the fixed point — and only that ends the
+// iteration (k_eo2_sweep_done turns anything else into a failure: the host-driven loop takes the frame).
+__device__ __forceinline__ unsigned long long eo2_next_set_live(const unsigned long long* bits, unsigned long long j, unsigned long long n) {
+  const unsigned long long n_words = (n + 63ull) >> 6;
+  unsigned long long w = j >> 6;
+  if (w >= n_words) return n;
+  unsigned long long x = eo2_ld64(&bits[w]) & (~0ull << (j & 63ull));
+  for (;;) {
+    if (x != 0ull) {
+      const unsigned long long at = w * 64ull + (unsigned long long)(__ffsll((long long)x) - 1);
+      return at < n ? at : n;
+    }
+    if (++w >= n_words) return n;
+    x = eo2_ld64(&bits[w]);
+  }
+}
+// One ray of a sweep, by a whole wavefront; returns (wave-uniform) whether its length changed.
+__device__ __forceinline__ bool eo2_sweep_ray(const EoView& E, EoCtl* ctl, const FrameParams& F, uint32_t pos, uint32_t lane) {
+  const int lim = F.max_collisions;
+  const uint64_t offset = F.observed_offset;
+  const uint32_t cv = E.cnt_a[pos], vo = eo_visited(cv);
+  const uint4 ri = E.rinfo[pos];
+  const uint32_t view = ri.x, full = ri.z;
+  const unsigned long long base = E.btp[pos / kScanBlock] + E.lp[pos];
+  int c = 0, stop = -1;
+  bool consulted = false;
+  for (uint32_t k0 = 0; k0 < view && stop < 0; k0 += 64u) {
+    const bool act = k0 + lane < view;
     bool hit = false;
-    if (j < n) {
-      const uint64_t key = E.keys[j];
-      const uint32_t slot = (uint32_t)(key >> 44), pos = (uint32_t)(key >> 22) & 0x3fffffu, step = (uint32_t)key & 0x3fffffu;
-      const uint32_t h = E.vals[j];
+    if (act) {
+      const uint32_t j = E.where[base + k0 + lane], h = E.hseq[base + k0 + lane];
+      const uint32_t slot = (uint32_t)(((uint64_t)h + offset) & kSetMask);
       long long i = -1;
-      bool first_of_slot = true;
-      if (j > 0) {
-        const uint64_t kp = E.keys[j - 1];
+      if (j > 0u) {
+        const uint64_t kp = E.keys[j - 1u];
         if ((uint32_t)(kp >> 44) == slot) {
-          first_of_slot = false;
-          // the ray's own previous visit of the slot, or the mark right before if it counts: the common cases, without a scan
-          if (((uint32_t)(kp >> 22) & 0x3fffffu) == pos || ((E.bits_a[(j - 1) >> 6] >> ((j - 1) & 63ull)) & 1ull)) i = (long long)j - 1;
+          // (the bitmap is read past the L1: a wavefront that walks a chain reads the bits it has just written itself)
+          if (((uint32_t)(kp >> 22) & 0x3fffffu) == pos || ((eo2_ld64(&E.bits_a[(j - 1u) >> 6]) >> ((j - 1u) & 63u)) & 1ull)) i = (long long)j - 1;
           else {
-            i = eo2_prev_set(E.bits_a, (uint32_t)j);
+            i = eo2_prev_set_live(E.bits_a, j);
             if (i >= 0 && (uint32_t)(E.keys[i] >> 44) != slot) i = -1;
           }
         }
       }
-      if (first) {
-        if (first_of_slot) E.tab[slot].x = (uint32_t)j;
-        if (j + 1 == n || (uint32_t)(E.keys[j + 1] >> 44) != slot) E.tab[slot].y = (uint32_t)(j + 1);
-        E.where[E.btp[pos / kScanBlock] + E.lp[pos] + step] = (uint32_t)j;
-      }
-      if (i >= 0) {
-        hit = E.vals[i] == h;
-      } else {   // (as k_eo2_hits: the zero-initialised slot is the one entry of an earlier offset that can match)
-        hit = h == 0u ? E.ctl->assumed0 == 0ull : E.plain[slot] == (uint64_t)h;
-        if (h == 0u && !(atomicOr(&E.ux[pos], 0x80000000u) >> 31)) E.consulted[atomicAdd(&E.ctl->n_consulted, 1u)] = pos;
+      if (i >= 0) hit = E.vals[i] == h;
+      else {
+        hit = h == 0u ? ctl->assumed0 == 0ull : E.plain[slot] == (uint64_t)h;
+        consulted |= h == 0u;
       }
     }
-    const unsigned long long word = __ballot(hit);
-    if (lane == 0) hbits[j >> 6] = word;
+    const int st_r = early_out_stop(__ballot(act && hit), __ballot(act), lim, c);
+    if (st_r >= 0) stop = (int)k0 + st_r;
   }
+  // (whole-ray views: a ray that does not stop ends with its view)
+  const uint32_t now = stop >= 0 ? ((uint32_t)stop | kCntBroke) : (view >= full ? full : view);
+  if (__ballot(consulted) != 0ull && lane == 0 && !(atomicOr(&E.ux[pos], 0x80000000u) >> 31)) E.consulted[atomicAdd(&ctl->n_consulted, 1u)] = pos;
+  if (now == cv) return false;
+  const uint32_t vn = eo_visited(now);
+  const uint32_t lo = vo < vn ? vo : vn, hi = vo < vn ? vn : vo;
+  for (uint32_t k = lo + lane; k < hi; k += 64u) {
+    const uint32_t j = E.where[base + k];
+    if (vn > vo) {
+      atomicOr(&E.bits_a[j >> 6], 1ull << (j & 63u));
+      atomicOr(&E.bits_b[j >> 6], 1ull << (j & 63u));
+    } else {
+      atomicAnd(&E.bits_a[j >> 6], ~(1ull << (j & 63u)));
+      atomicAnd(&E.bits_b[j >> 6], ~(1ull << (j & 63u)));
+    }
+  }
+  if (lane == 0) {
+    __hip_atomic_store(&E.cnt_a[pos], now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    E.cnt_b[pos] = now;
+  }
+  // HINTS for the filtered sweeps (k_eo2_sweep): the ray that reads each flipped mark next — the owner of the next mark of
+  // the slot that counts — is flagged, once the flips are in place.  Only hints: a reader that starts to count while this
+  // runs can be missed, which is why a filtered sweep that changes nothing is followed by a full one.
+  KS_WAIT_VMEM();
+  const unsigned long long n_m = ctl->st.n_marks;
+  for (uint32_t k = lo + lane; k < hi; k += 64u) {
+    const uint32_t j = E.where[base + k];
+    const unsigned long long m = eo2_next_set_live(E.bits_a, (unsigned long long)j + 1ull, n_m);
+    if (m < n_m) {
+      const uint64_t key = E.keys[m];
+      const uint32_t p = (uint32_t)(key >> 22) & 0x3fffffu;
+      if ((uint32_t)(key >> 44) == (uint32_t)(E.keys[j] >> 44) && p != pos) __hip_atomic_store(&E.dirty[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  return true;
 }
 
-// A wavefront per ray, 64 steps of its view per batch.
-// last = 0: the new lengths become current at once (nothing reads lengths or A in this launch); last = 1: they are the NEXT
-// lengths of round 0 (cnt_b, the change list, B) and k_eo2_propagate makes them current
-__global__ void __launch_bounds__(256) k_eo2_stopv(EoBatch Bt, uint32_t last, uint32_t iter) {
+// order 0: rays in integration order, a wavefront per ray (grid-stride).  order 1: a wavefront per (chain, segment of
+// kEoSweepSegment generations): it takes ITS rays one after the other, generation by generation, waiting for its own bit
+// flips before the next one — the reference's loop along a chain of neighbouring pixels, which is the direction changes
+// travel in (ks_k_march.h: the chains of the "mixed" order); chains and segments run side by side.
+// ctl->sw_prev = rays the previous sweep changed (k_eo2_sweep_next rotates the counters between two sweeps).
+constexpr uint32_t kEoSweepSegment = 128;
+// FULL and FILTERED sweeps: a full sweep looks at every ray (the first one, and the one that CONFIRMS the fixed point: nothing
+// else ends the iteration); a filtered sweep only at the rays flagged since they were last looked at (E.dirty: hints, see
+// eo2_sweep_ray) — after the first few sweeps a few thousand of 6.5e5.  ctl->sw_full says which kind runs (k_eo2_sweep_next).
+__device__ __forceinline__ bool eo2_sweep_wants(const EoView& E, uint32_t pos, bool full, uint32_t lane) {
+  // (the flag goes down before the ray is looked at: a change that lands meanwhile flags it again)
+  uint32_t d = 0u;
+  if (lane == 0) d = atomicExch(&E.dirty[pos], 0u);
+  d = (uint32_t)__shfl((int)d, 0);
+  return full || d != 0u;
+}
+__global__ void __launch_bounds__(256) k_eo2_sweep(EoBatch Bt, uint32_t order) {
   const EoView& E = Bt.v[blockIdx.y];
   EoCtl* ctl = E.ctl;
-  if (ctl->fail) return;
-  const uint32_t n = E.C->n_rays;
-  const int lim = E.F->max_collisions;
-  const unsigned long long* __restrict__ hbits = (const unsigned long long*)E.hitb;
+  if (ctl->fail || ctl->sw_prev == 0u) return;   // a full sweep changed nothing: the fixed point
+  const bool full = ctl->sw_full != 0u;
+  const FrameParams& F = *E.F;
   const uint32_t lane = lane_id(), w0 = blockIdx.x * 4u + (threadIdx.x >> 6), nw = gridDim.x * 4u;
-  for (uint32_t r = w0; r < n; r += nw) {
-    const uint32_t pos = E.ray_list[r];
-    const uint32_t cv = E.cnt_a[pos], vo = eo_visited(cv);
-    const uint4 ri = E.rinfo[pos];
-    const uint32_t view = ri.x, full = ri.z;
-    const unsigned long long base = E.btp[pos / kScanBlock] + E.lp[pos];
-    int c = 0, stop = -1;
-    for (uint32_t k0 = 0; k0 < view && stop < 0; k0 += 64u) {
-      const bool act = k0 + lane < view;
-      bool hit = false;
-      if (act) {
-        const uint32_t j = E.where[base + k0 + lane];
-        hit = (hbits[j >> 6] >> (j & 63u)) & 1ull;
-      }
-      const int st_r = early_out_stop(__ballot(act && hit), __ballot(act), lim, c);
-      if (st_r >= 0) stop = (int)k0 + st_r;
+  uint32_t changed = 0;
+  if (order == 0u) {
+    const uint32_t n = E.C->n_rays;
+    for (uint32_t r = w0; r < n; r += nw) {
+      const uint32_t pos = E.ray_list[r];
+      if (eo2_sweep_wants(E, pos, full, lane)) changed += eo2_sweep_ray(E, ctl, F, pos, lane) ? 1u : 0u;
     }
-    uint32_t now, pad;
-    if (stop >= 0) {
-      now = (uint32_t)stop | kCntBroke;
-      pad = kEoPadBroken;
-    } else if (view >= full) {
-      now = full;
-      pad = 0u;
-    } else {   // the view ends before the ray does: every step of it is visited, and the next view is the whole ray
-      now = view;
-      pad = full;
-    }
-    if (lane == 0) {
-      if (pad != ri.y) E.rinfo[pos].y = pad;
-      if (stop < 0 && view < full) atomicAdd(&ctl->dense_open[iter & 31u], 1u);
-    }
-    if (now != cv) {
-      const uint32_t vn = eo_visited(now);
-      const uint32_t lo = vo < vn ? vo : vn, hi = vo < vn ? vn : vo;
-      for (uint32_t k = lo + lane; k < hi; k += 64u) {
-        const uint32_t j = E.where[base + k];
-        if (vn > vo) {
-          atomicOr(&E.bits_b[j >> 6], 1ull << (j & 63u));
-          if (!last) atomicOr(&E.bits_a[j >> 6], 1ull << (j & 63u));
-        } else {
-          atomicAnd(&E.bits_b[j >> 6], ~(1ull << (j & 63u)));
-          if (!last) atomicAnd(&E.bits_a[j >> 6], ~(1ull << (j & 63u)));
+  } else {
+    const uint32_t n_chains = F.chains, n_gen = (F.n + n_chains - 1u) / n_chains;
+    const uint32_t n_seg = (n_gen + kEoSweepSegment - 1u) / kEoSweepSegment;
+    for (uint32_t w = w0; w < n_chains * n_seg; w += nw) {
+      // (segment-major: the workgroups that start first hold the chains' first segments)
+      const uint32_t chain = w % n_chains, seg = w / n_chains;
+      const uint32_t g1 = (seg + 1u) * kEoSweepSegment < n_gen ? (seg + 1u) * kEoSweepSegment : n_gen;
+      for (uint32_t g0 = seg * kEoSweepSegment; g0 < g1; g0 += 64u) {
+        const uint32_t g = g0 + lane;
+        const uint64_t p = (uint64_t)g * n_chains + chain;
+        // (filtered: the flags of the segment's rays, 64 at a time; a ray flagged while the wavefront is on its way is caught
+        // by the look at its own flag below)
+        const bool mine = g < g1 && p < F.n && E.live[p < F.n ? p : 0u] != 0;
+        unsigned long long todo = __ballot(mine);
+        for (; todo != 0ull; todo &= todo - 1ull) {
+          const uint32_t gi = g0 + (uint32_t)(__ffsll((long long)todo) - 1);
+          if (!eo2_sweep_wants(E, gi * n_chains + chain, full, lane)) continue;
+          if (eo2_sweep_ray(E, ctl, F, gi * n_chains + chain, lane)) {
+            ++changed;
+            KS_WAIT_VMEM();   // the bits of this ray's marks are in place before the chain's next ray looks
+          }
         }
       }
-      if (lane == 0) {
-        atomicAdd(&ctl->dense_chg[iter & 31u], 1u);
-        E.cnt_b[pos] = now;
-        if (!last) E.cnt_a[pos] = now;
-        else E.chg[atomicAdd(&ctl->n_chg[0], 1u)] = pos;
-      }
     }
-    // a ray that is still going when its marks end is cast on in round 1 (X marks from there)
-    if (last && stop < 0 && view < full && lane == 0) eo2_mark_dirty(E, pos, view, E.list[1], &ctl->n_in[1]);
   }
+  if (lane == 0 && changed) atomicAdd(&ctl->sw_cur, changed);
+}
+// between two sweeps: what the last one changed becomes "previous"
+__global__ void __launch_bounds__(64) k_eo2_sweep_next(EoBatch Bt) {
+  EoCtl* ctl = Bt.v[blockIdx.x].ctl;
+  if (threadIdx.x != 0 || ctl->fail || ctl->sw_prev == 0u) return;
+  const uint32_t i = ctl->rounds, chg = ctl->sw_cur;
+  ctl->dense_chg[i & 31u] = chg | (ctl->sw_full ? 0x80000000u : 0u);   // (statistics: KS_EXACT_TRACE; bit 31: a full sweep)
+  ctl->rounds = i + 1u;
+  // a full sweep that changed nothing ends the iteration; a filtered one that changed nothing asks for the full one
+  if (ctl->sw_full) {
+    ctl->sw_prev = chg;
+    ctl->sw_full = 0u;
+  } else {
+    ctl->sw_prev = 1u;
+    ctl->sw_full = chg == 0u ? 1u : 0u;
+  }
+  ctl->sw_cur = 0u;
+}
+// after the last sweep the host is willing to enqueue: a frame that is still changing has not reached the fixed point
+__global__ void __launch_bounds__(64) k_eo2_sweep_done(EoBatch Bt) {
+  EoCtl* ctl = Bt.v[blockIdx.x].ctl;
+  if (threadIdx.x == 0 && !ctl->fail && ctl->sw_prev != 0u) atomicOr(&ctl->fail, kEoFailRounds);
 }
 
 // LDS of a wavefront of the round kernels
@@ -1205,6 +1287,8 @@ __global__ void __launch_bounds__(64) k_eo2_begin(EoBatch Bt) {
   __syncthreads();
   if (threadIdx.x == 0) {
     ctl->n_x = 1u;
+    ctl->sw_prev = 1u;   // (long rays: "not at the fixed point yet" — the first sweep runs, and looks at every ray)
+    ctl->sw_full = 1u;
     ctl->assumed0 = E.plain[(uint32_t)(E.F->observed_offset & kSetMask)];
   }
 }

@@ -1,5 +1,6 @@
 """C4-`fast` in the default mode (the reference's serial result) on the device: ms per frame, fix-point rounds and fallbacks, for
-the launch-shape knobs that do not change the map (KS_EXACT_EPOCHS / KS_EXACT_DENSE / KS_EXACT_BULK_ROUNDS from the environment).
+the launch-shape knobs that do not change the map (KS_EXACT_SWEEPS / KS_EXACT_SWEEP_ORDER from the environment; KS_EXACT_TRACE=1
+prints every frame's sweeps).
 usage: python tools/c4_fast_ab.py [frames=8] [pipeline=0]"""
 import os
 import sys
@@ -37,7 +38,7 @@ def main():
         upd = turn()
         ts.append((time.perf_counter() - t0) * 1e3 / n)
     s1 = integ.early_out_stats()
-    print({k: os.environ.get(k) for k in ("KS_EXACT_EPOCHS", "KS_EXACT_DENSE", "KS_EXACT_BULK_ROUNDS", "KS_EXACT_SEED_GROWTH") if os.environ.get(k)},
+    print({k: os.environ.get(k) for k in ("KS_EXACT_SWEEPS", "KS_EXACT_SWEEP_ORDER", "KS_EXACT_SEED_GROWTH") if os.environ.get(k)},
           "pipeline", pipe, "ms/frame", [round(t, 2) for t in ts], "updates/frame", upd // n,
           "rounds/frame", (s1["rounds"] - s0["rounds"]) / (3 * n), "fallbacks", s1["fallbacks"] - s0["fallbacks"], "first turn fallbacks", s0["fallbacks"],
           "event_driven", s1["event_driven"], flush=True)

@@ -1,0 +1,11 @@
+# Round 5, seventh GPU call: full-size C4 frames, default `fast` mode: sweeps along the chains vs in ray order (KS_EXACT_TRACE=1)
+set -x
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/call7_r05
+rm -rf $O; mkdir -p $O
+cd $R
+for v in KS_EXACT_SWEEP_ORDER=1 KS_EXACT_SWEEP_ORDER=0; do
+  env KS_EXACT_TRACE=1 $v timeout 300 python tools/c4_fast_ab.py 4 0 2>&1 | grep -v amdgpu.ids | grep "ks exact\|ms/frame" | tail -3 | cut -c1-700 | tee -a $O/c4_trace.txt
+done
+sh tools/frame_trace.sh C4-fast > $O/c4_frame.log 2>&1; cp gpurun_out/frame_trace_C4-fast/one_frame.txt $O/c4_fast_one_frame.txt
+grep -c . $O/c4_fast_one_frame.txt
