@@ -355,7 +355,7 @@ def early_out_fidelity(B, dev, wl, frames, max_tiles):
 def pmc_traffic(name):
     """HBM bytes per k_apply launch from the committed PMC pass of this command (profiles/r03_pmc_<name>.json,
     written by tools/pmc_bench.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 unit correction applied)."""
-    for tag in ("r04", "r03"):
+    for tag in ("r05", "r04", "r03"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{name}.json")))
         except Exception:
@@ -696,6 +696,11 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         try:
             comm = PAR.rccl_comm(rank, world, ddev)   # an ncclComm_t of the librccl ks_reduce loads (id broadcast over torch.distributed)
+        except PAR.RcclBootstrapStuck as e:
+            # a thread of this process is stuck inside librccl with the unique id consumed: no collective can be started from
+            # here any more (the other ranks would wait for it) — the run ends HERE, loudly, and that is bench.py's decision
+            sys.stderr.write(f"bench: {e}\n")
+            os._exit(3)
         except Exception as e:   # (never take the line down: the same protocol also runs over torch.distributed)
             sys.stderr.write(f"bench: ctypes RCCL communicator unavailable ({type(e).__name__}: {e}); exchange through torch.distributed\n")
             comm = None
@@ -881,7 +886,8 @@ def main():
                             scale = ratio
                             show = (f"GPU count x (serial-oracle / GPU) measured on the first timed frame: x{ratio:.4f} "
                                     f"(oracle {oc}, GPU {g})")
-                    srec, _ = record(name, swl, sm, steps, None, show, credit_scale=scale)
+                    srec, _ = record(name, swl, sm, steps, None, show, credit_scale=scale,
+                                     pmc_name={"C4-fast": "c4_fast", "C4-merged": "c4_merged"}.get(name))
                     sec.append(srec)
                     torch.cuda.empty_cache()
                 except Exception as e:

@@ -98,10 +98,12 @@ typedef struct ks_config {
    *    with an event-driven iteration on the device (csrc/ks_k_exact.h: the seed's marks sorted once, then only rays
    *    whose inputs changed are re-evaluated; no host read in the loop), pipelined like every other mode when
    *    clear_checks_every_n_frames = 1 (with a larger value a frame's marks are inputs of the next frame's loop:
-   *    pipeline_frames is then treated as 0).
+   *    pipeline_frames is then treated as 0).  Long rays (more than 400 voxels: 2 cm voxels / 10 m rays): whole-ray marks
+   *    sorted once, then sweeps along the chains of the integration order on the device; one frame at a time
+   *    (pipeline_frames treated as 0), the host reads two words per dozen sweeps.
    * 16 .. 4096: the ORDERED-PHASE schedule alone (restated for the CPU in oracle/ks_oracle.cpp, against
    *    which it is bit-exact): integration positions are cut into phases whose length grows by this factor (in
-   *    1/16ths) — 32 = doubling, 16 = one generation of 1024 positions per phase.  Deterministic for every value, a few
+   *    1/16ths) — 32 = doubling, 16 = one generation (one integration position per chain = per group of the integration order) per phase.  Deterministic for every value, a few
    *    launches cheaper per frame than the exact mode, and NOT the reference's map (touched-voxel Jaccard 0.976-0.995
    *    against the serial order): a throughput option for callers who accept that. */
   int32_t early_out_phase_growth;

@@ -167,8 +167,8 @@ def rccl_comm(rank: int, world: int, device, timeout: float = 120.0):
     on_gpu = getattr(device, "type", str(device)) == "cuda" or str(device).startswith("cuda")
     if on_gpu:
         torch.cuda.set_device(device)
-    # the collective initialisation runs on a helper thread with a deadline: a caller (bench.py) can fall back to the
-    # torch.distributed exchange instead of hanging if the bootstrap of a second communicator does not complete
+    # the collective initialisation runs on a helper thread with a deadline: a bootstrap that does not complete raises
+    # RcclBootstrapStuck instead of hanging the caller for ever
     import threading
     box = {}
 
@@ -180,15 +180,18 @@ def rccl_comm(rank: int, world: int, device, timeout: float = 120.0):
     th.start()
     th.join(timeout)
     if th.is_alive():
-        # the bootstrap is stuck inside the library with the unique id consumed: there is no way to take part in a later
-        # collective cleanly from this process, so say so and leave (the caller's fallback would hang on the next barrier
-        # while other ranks may still complete their side of the bootstrap)
-        import sys
-        sys.stderr.write(f"ncclCommInitRank did not return within {timeout} s on rank {rank}: exiting\n")
-        os._exit(3)
+        # The bootstrap is stuck inside the library with the unique id consumed: this process cannot take part in a later
+        # collective cleanly (a fallback exchange would hang on its next barrier while other ranks may still complete their
+        # side of the bootstrap).  What to do about that is the caller's decision — a library helper does not end the process.
+        raise RcclBootstrapStuck(f"ncclCommInitRank did not return within {timeout} s on rank {rank}; the helper thread is still inside "
+                                 "librccl and the unique id is consumed: do not start another collective from this process")
     if box.get("rc", -1) != 0:
         raise RuntimeError(f"ncclCommInitRank: {box.get('rc')}")
     return comm.value
+
+
+class RcclBootstrapStuck(RuntimeError):
+    """rccl_comm: ncclCommInitRank did not return before the deadline (see there)."""
 
 
 def rccl_abort(comm: int) -> None:

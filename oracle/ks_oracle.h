@@ -83,8 +83,8 @@ typedef struct ko_config {
   /* fast, early-out enabled: 0 = the reference's serial order (one ray after the other,
    * semantic_tsdf_integrator_fast.cpp:110-122).  >= 16 = the GPU path's ORDERED-PHASE schedule, restated
    * here so the HIP kernels can be checked bit for bit against it (see integrate_fast_phased in
-   * ks_oracle.cpp for the definition): phase boundaries grow by this factor / 16 (16 = one generation of
-   * 1024 integration positions per phase, 32 = doubling). */
+   * ks_oracle.cpp for the definition): phase boundaries grow by this factor / 16 (16 = one generation — one
+   * integration position per chain, see ko_mixed_chains — per phase, 32 = doubling). */
   int32_t early_out_phase_growth;
 } ko_config;
 

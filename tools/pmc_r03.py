@@ -76,8 +76,8 @@ def main():
         if not fe_rows or not wr_rows:
             print(f"# {wl}: no counters")
             continue
-        # bench commands: frames [PRIME + W, PRIME + W + R * K) = [22, 122) are the timed regions
-        lo, hi = (22, 122) if timed else (None, None)
+        # bench commands (--steps 20 --warmup 2): 40 untimed frames, then the timed regions: frames [40, 140) = five of them
+        lo, hi = (40, 140) if timed else (None, None)
         fe, wr = per_kernel(fe_rows, lo=lo, hi=hi), per_kernel(wr_rows, lo=lo, hi=hi)
         tdir = os.path.join(root, wl if timed else f"time_{wl}")
         du = collections.OrderedDict()
