@@ -30,7 +30,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 120 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_calib_$C -o run -- python $R/tools/probe.py calib 3 > $O/pmc_calib_$C.log 2>&1
 done
 cd $R
-PMC_TAG=r05 python tools/pmc_r03.py $O | tee $O/pmc_summary.txt | cut -c1-160 | head -90
+PMC_TAG=r05 PMC_SCRIPT=final_r05.sh python tools/pmc_r03.py $O | tee $O/pmc_summary.txt | cut -c1-160 | head -90
 cp $O/r05_pmc_*.json profiles/ 2>/dev/null
 for W in C2 C3 C4-fast C4-merged; do
   sh tools/frame_trace.sh $W > $O/frame_$W.log 2>&1; cp gpurun_out/frame_trace_$W/one_frame.txt $O/one_frame_$W.txt
