@@ -55,6 +55,7 @@ def per_kernel(rows, key="Counter_Value", lo=None, hi=None):
 
 
 TAG = os.environ.get("PMC_TAG", "r03")
+SCRIPT = os.environ.get("PMC_SCRIPT", "profile_" + TAG + ".sh")
 
 
 def main():
@@ -104,7 +105,7 @@ def main():
             json.dump({"k_apply_hbm_bytes_per_launch": r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"],
                        "fetch_bytes_per_launch": r["fetch_bytes_per_launch"], "write_bytes_per_launch": r["write_bytes_per_launch"],
                        "launches_averaged": r["calls_averaged"], "calibration": out["calibration"],
-                       "source": f"profiles/{TAG}_pmc_{tag}.json <- tools/{os.environ.get("PMC_SCRIPT", "profile_" + TAG + ".sh")}: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- "
+                       "source": f"profiles/{TAG}_pmc_{tag}.json <- tools/{SCRIPT}: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- "
                                  + ("python bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-secondary --no-oracle-count" + (" --method merged" if wl == "merged" else "")
                                     if timed else f"python tools/probe.py {wl} 3")},
                       open(os.path.join(root, f"{TAG}_pmc_{tag}.json"), "w"), indent=1)
