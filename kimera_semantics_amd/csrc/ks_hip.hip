@@ -1968,10 +1968,11 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // (long rays: a frame's marks cover whole rays — 2e8 marks of 33 bytes at 1280x720 / 2 cm — and a frame is tens of
     // milliseconds of GPU work: one frame at a time, one set of mark buffers)
     if (c->exact_early_out && wide_rays) c->cfg.pipeline_frames = 0;
-    // (rounds the fix point needs from the doubling seed, 640x480 / 5 cm, tools/fixpoint_study.py: 7 in the upstream form of the
-    // "mixed" order, 11-13 in the 1024-group form; a frame that needs more hands the rest to the finisher, and a finisher that
-    // is handed too long a list asks for more rounds as launches: eo_want_bulk)
-    c->eo_bulk_rounds = wide_rays ? 32 : cfg->integration_order_mode == KS_ORDER_MIXED ? 8 : 14;
+    // (rounds the fix point needs from the doubling seed at 640x480 / 5 cm: 7 - 20 per frame over the bench trajectory, 9 - 12
+    // on average.  A round that finds its list empty costs a launch of ~2 us; a round the ONE-workgroup finisher has to run in its
+    // place costs ~0.1 ms: measured on a ring of 40 frames, 8 rounds as launches 0.681 ms/frame, 14 rounds 0.569
+    // (profiles/r05_bulk_rounds_ab.txt).  A finisher that is handed too long a list asks for more: eo_want_bulk.)
+    c->eo_bulk_rounds = wide_rays ? 32 : 20;
     if (const char* br = getenv("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
     if (const char* tr = getenv("KS_EXACT_TRACE")) c->eo_trace = tr[0] == '1';
     if (const char* sw = getenv("KS_EXACT_SWEEPS")) c->eo_sweeps = std::min(64, std::max(1, atoi(sw)));   // (tuning runs: any value gives the same map)

@@ -835,13 +835,19 @@ __global__ void __launch_bounds__(256) k_eo2_sweep(EoBatch Bt, uint32_t order) {
       for (uint32_t g0 = seg * kEoSweepSegment; g0 < g1; g0 += 64u) {
         const uint32_t g = g0 + lane;
         const uint64_t p = (uint64_t)g * n_chains + chain;
-        // (filtered: the flags of the segment's rays, 64 at a time; a ray flagged while the wavefront is on its way is caught
-        // by the look at its own flag below)
+        // The flags of the segment's next 64 rays, all lanes at once (one atomic per ray, one after the other, is what a
+        // filtered sweep with a handful of flagged rays would otherwise consist of); a flagged ray's flag goes down BEFORE the
+        // rays are looked at, so a change that lands while the wavefront is on its way flags the ray again for the next sweep.
         const bool mine = g < g1 && p < F.n && E.live[p < F.n ? p : 0u] != 0;
-        unsigned long long todo = __ballot(mine);
+        bool want = mine && full;
+        if (mine && __hip_atomic_load(&E.dirty[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          (void)atomicExch(&E.dirty[p], 0u);
+          want = true;
+        }
+        unsigned long long todo = __ballot(want);
+        if (todo != 0ull) KS_WAIT_VMEM();
         for (; todo != 0ull; todo &= todo - 1ull) {
           const uint32_t gi = g0 + (uint32_t)(__ffsll((long long)todo) - 1);
-          if (!eo2_sweep_wants(E, gi * n_chains + chain, full, lane)) continue;
           if (eo2_sweep_ray(E, ctl, F, gi * n_chains + chain, lane)) {
             ++changed;
             KS_WAIT_VMEM();   // the bits of this ray's marks are in place before the chain's next ray looks

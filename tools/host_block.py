@@ -17,25 +17,25 @@ def main():
     dev = torch.device("cuda:0")
     wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "C2"]
     pipe = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    ring = bench.FrameRing(bench.make_frames(wl, range(12)), torch, dev)
+    ring = bench.FrameRing(bench.make_frames(wl, range(40)), torch, dev)
     cfg = B.default_config(device_id=0, max_tiles=1 << 13, max_points=max(f.xyz.shape[0] for f in ring.frames),
                            pipeline_frames=pipe, **bench.integ_cfg(wl))
     integ = B.HipIntegrator(cfg)
-    for i in range(24):
+    for i in range(40):
         x, c, l = ring.dev(i)
         integ.integrate_device(ring.host(i).T_G_C, x.data_ptr(), c.data_ptr(), l.data_ptr(), x.shape[0])
     integ.flush()
     integ.synchronize()
     t_all = time.perf_counter()
     ts = []
-    for i in range(24, 24 + 48):
+    for i in range(40, 40 + 80):
         x, c, l = ring.dev(i)
         t0 = time.perf_counter()
         integ.integrate_device(ring.host(i).T_G_C, x.data_ptr(), c.data_ptr(), l.data_ptr(), x.shape[0])
         ts.append((time.perf_counter() - t0) * 1e3)
     integ.flush()
     integ.synchronize()
-    print("ms per frame %.3f" % ((time.perf_counter() - t_all) * 1e3 / 48))
+    print("ms per frame %.3f" % ((time.perf_counter() - t_all) * 1e3 / 80))
     print("call ms:", " ".join("%.2f" % t for t in ts))
     print(integ.early_out_stats())
     integ.close()
