@@ -584,8 +584,11 @@ __device__ __forceinline__ long long eo2_prev_set(const unsigned long long* __re
     x = bits[w];
   }
 }
-// (the same, reading past the L1: for kernels that read bits other wavefronts — or they themselves — flip while they run)
-__device__ __forceinline__ long long eo2_prev_set_live(const unsigned long long* bits, uint32_t j) {
+// (the same, reading past the L1: for kernels that read bits other wavefronts — or they themselves — flip while they run.
+// Another XCD's flips of a line this XCD's L2 holds may not be seen: the per-XCD L2s are not coherent with each other.  Reading
+// through returning atomics instead — performed where the flips are — was measured in the filtered sweeps and changed nothing:
+// the rays a confirming sweep still finds are not victims of stale lines.)
+__device__ __forceinline__ long long eo2_prev_set_live(unsigned long long* bits, uint32_t j) {
   if (j == 0u) return -1;
   uint32_t w = (j - 1u) >> 6;
   unsigned long long x = eo2_ld64(&bits[w]) & (~0ull >> (63u - ((j - 1u) & 63u)));
@@ -707,7 +710,7 @@ __global__ void __launch_bounds__(256) k_eo2_where(EoBatch Bt) {
 // wavefront reads may be stale or half applied (plain loads, other wavefronts' atomics): that only costs another sweep,
 // because a sweep in which NO length changed has read one unchanging state, the fixed point — and only that ends the
 // iteration (k_eo2_sweep_done turns anything else into a failure: the host-driven loop takes the frame).
-__device__ __forceinline__ unsigned long long eo2_next_set_live(const unsigned long long* bits, unsigned long long j, unsigned long long n) {
+__device__ __forceinline__ unsigned long long eo2_next_set_live(unsigned long long* bits, unsigned long long j, unsigned long long n) {
   const unsigned long long n_words = (n + 63ull) >> 6;
   unsigned long long w = j >> 6;
   if (w >= n_words) return n;
@@ -722,7 +725,7 @@ __device__ __forceinline__ unsigned long long eo2_next_set_live(const unsigned l
   }
 }
 // One ray of a sweep, by a whole wavefront; returns (wave-uniform) whether its length changed.
-__device__ __forceinline__ bool eo2_sweep_ray(const EoView& E, EoCtl* ctl, const FrameParams& F, uint32_t pos, uint32_t lane) {
+__device__ __forceinline__ bool eo2_sweep_ray_once(const EoView& E, EoCtl* ctl, const FrameParams& F, uint32_t pos, uint32_t lane, bool* extended) {
   const int lim = F.max_collisions;
   const uint64_t offset = F.observed_offset;
   const uint32_t cv = E.cnt_a[pos], vo = eo_visited(cv);
@@ -763,6 +766,7 @@ __device__ __forceinline__ bool eo2_sweep_ray(const EoView& E, EoCtl* ctl, const
   if (__ballot(consulted) != 0ull && lane == 0 && !(atomicOr(&E.ux[pos], 0x80000000u) >> 31)) E.consulted[atomicAdd(&ctl->n_consulted, 1u)] = pos;
   if (now == cv) return false;
   const uint32_t vn = eo_visited(now);
+  *extended = vn > vo;
   const uint32_t lo = vo < vn ? vo : vn, hi = vo < vn ? vn : vo;
   for (uint32_t k = lo + lane; k < hi; k += 64u) {
     const uint32_t j = E.where[base + k];
@@ -793,6 +797,20 @@ __device__ __forceinline__ bool eo2_sweep_ray(const EoView& E, EoCtl* ctl, const
     }
   }
   return true;
+}
+// A ray that gets FURTHER has looked at its new steps before their marks counted: a neighbour that flipped a mark in between
+// looked for the next reader of that mark and could not find this ray yet.  So such a ray looks again once its own flips are
+// in place — from then on every flip finds it.
+__device__ __forceinline__ bool eo2_sweep_ray(const EoView& E, EoCtl* ctl, const FrameParams& F, uint32_t pos, uint32_t lane) {
+  bool changed = false;
+  for (int pass = 0; pass < 3; ++pass) {
+    bool extended = false;
+    if (!eo2_sweep_ray_once(E, ctl, F, pos, lane, &extended)) break;
+    changed = true;
+    if (!extended) break;
+    KS_WAIT_VMEM();
+  }
+  return changed;
 }
 
 // order 0: rays in integration order, a wavefront per ray (grid-stride).  order 1: a wavefront per (chain, segment of
@@ -838,19 +856,31 @@ __global__ void __launch_bounds__(256) k_eo2_sweep(EoBatch Bt, uint32_t order) {
         // The flags of the segment's next 64 rays, all lanes at once (one atomic per ray, one after the other, is what a
         // filtered sweep with a handful of flagged rays would otherwise consist of); a flagged ray's flag goes down BEFORE the
         // rays are looked at, so a change that lands while the wavefront is on its way flags the ray again for the next sweep.
+        // A ray that CHANGES is what flags the rays behind it — most of all its own chain's next ray: that one is looked at
+        // whatever its flag says, and the flags of the rest of the group are read again (measured: reading them once per group
+        // lets a change travel one group per sweep along its chain — 45 sweeps per frame instead of 36).
         const bool mine = g < g1 && p < F.n && E.live[p < F.n ? p : 0u] != 0;
-        bool want = mine && full;
-        if (mine && __hip_atomic_load(&E.dirty[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-          (void)atomicExch(&E.dirty[p], 0u);
-          want = true;
-        }
-        unsigned long long todo = __ballot(want);
-        if (todo != 0ull) KS_WAIT_VMEM();
-        for (; todo != 0ull; todo &= todo - 1ull) {
-          const uint32_t gi = g0 + (uint32_t)(__ffsll((long long)todo) - 1);
-          if (eo2_sweep_ray(E, ctl, F, gi * n_chains + chain, lane)) {
+        auto take_flags = [&](uint32_t from) -> unsigned long long {   // the flags of the group's rays of generation >= from
+          bool want = false;
+          if (mine && g >= from && __hip_atomic_load(&E.dirty[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            (void)atomicExch(&E.dirty[p], 0u);
+            want = true;
+          }
+          const unsigned long long m = __ballot(want);
+          if (m != 0ull) KS_WAIT_VMEM();
+          return m;
+        };
+        unsigned long long todo = full ? __ballot(mine) : 0ull;
+        todo |= take_flags(g0);
+        bool prev_changed = false;
+        for (unsigned long long rest = __ballot(mine); rest != 0ull; rest &= rest - 1ull) {
+          const uint32_t bit = (uint32_t)(__ffsll((long long)rest) - 1), gi = g0 + bit;
+          if (!((todo >> bit) & 1ull) && !prev_changed) continue;
+          prev_changed = eo2_sweep_ray(E, ctl, F, gi * n_chains + chain, lane);
+          if (prev_changed) {
             ++changed;
             KS_WAIT_VMEM();   // the bits of this ray's marks are in place before the chain's next ray looks
+            todo |= take_flags(gi + 1u);
           }
         }
       }
