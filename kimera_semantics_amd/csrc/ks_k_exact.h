@@ -725,10 +725,12 @@ __device__ __forceinline__ unsigned long long eo2_next_set_live(unsigned long lo
   }
 }
 // One ray of a sweep, by a whole wavefront; returns (wave-uniform) whether its length changed.
-__device__ __forceinline__ bool eo2_sweep_ray_once(const EoView& E, EoCtl* ctl, const FrameParams& F, uint32_t pos, uint32_t lane, bool* extended) {
+// cv: the ray's current length word (in: as the caller knows it; out: as this look leaves it)
+__device__ __forceinline__ bool eo2_sweep_ray_once(const EoView& E, EoCtl* ctl, const FrameParams& F, uint32_t pos, uint32_t lane, uint32_t* cv_io,
+                                                   bool* extended) {
   const int lim = F.max_collisions;
   const uint64_t offset = F.observed_offset;
-  const uint32_t cv = E.cnt_a[pos], vo = eo_visited(cv);
+  const uint32_t cv = *cv_io, vo = eo_visited(cv);
   const uint4 ri = E.rinfo[pos];
   const uint32_t view = ri.x, full = ri.z;
   const unsigned long long base = E.btp[pos / kScanBlock] + E.lp[pos];
@@ -767,6 +769,7 @@ __device__ __forceinline__ bool eo2_sweep_ray_once(const EoView& E, EoCtl* ctl, 
   if (now == cv) return false;
   const uint32_t vn = eo_visited(now);
   *extended = vn > vo;
+  *cv_io = now;
   const uint32_t lo = vo < vn ? vo : vn, hi = vo < vn ? vn : vo;
   for (uint32_t k = lo + lane; k < hi; k += 64u) {
     const uint32_t j = E.where[base + k];
@@ -803,9 +806,12 @@ __device__ __forceinline__ bool eo2_sweep_ray_once(const EoView& E, EoCtl* ctl, 
 // in place — from then on every flip finds it.
 __device__ __forceinline__ bool eo2_sweep_ray(const EoView& E, EoCtl* ctl, const FrameParams& F, uint32_t pos, uint32_t lane) {
   bool changed = false;
+  // (the length word travels in a register from one look to the next: the store of lane 0 is neither ordered against the other
+  // lanes' next load nor certain to have left this CU's L1)
+  uint32_t cv = eo2_ld(&E.cnt_a[pos]);
   for (int pass = 0; pass < 3; ++pass) {
     bool extended = false;
-    if (!eo2_sweep_ray_once(E, ctl, F, pos, lane, &extended)) break;
+    if (!eo2_sweep_ray_once(E, ctl, F, pos, lane, &cv, &extended)) break;
     changed = true;
     if (!extended) break;
     KS_WAIT_VMEM();

@@ -54,6 +54,9 @@ def main():
         tot_g += sg.n_voxel_updates
     tot_g += g.flush().n_voxel_updates
     assert tot_o == tot_g, (tot_o, tot_g)
+    if spec.get("fallbacks_exactly") is not None:
+        st = g.early_out_stats()
+        assert st["fallbacks"] == spec["fallbacks_exactly"] and st["event_driven"], st
     if spec.get("fallbacks_below") is not None:
         st = g.early_out_stats()
         assert 0 < st["fallbacks"] < spec["fallbacks_below"], st   # (some frames repeat on the host, then the device loop takes over again)
