@@ -256,14 +256,17 @@ def measure(B, torch, dist, dev, wl, ring, W, K, R, pipeline, max_tiles, world, 
         except Exception:
             return {}
 
-    for r in range(R):
+    # one UNTIMED region first, run exactly like the timed ones (K steps, flush, synchronize): the first region after the priming
+    # turns was 10 - 15 % slower than the rest in every run (clocks, the first replay of the graphs with the k_apply events attached)
+    for r in range(-1, R):
         eo0 = eo_stats()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         t0 = time.perf_counter()
         updates = points = rays = 0
-        for i in range(base + r * K, base + (r + 1) * K):
+        first = base + max(r, 0) * K
+        for i in range(first, first + K):
             st = step(i)          # pipelined: statistics of the frame(s) completed by this call
             updates += st.n_voxel_updates
             points += st.n_points
@@ -278,11 +281,13 @@ def measure(B, torch, dist, dev, wl, ring, W, K, R, pipeline, max_tiles, world, 
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t0
-        want_points = sum(int(ring.host(i).xyz.shape[0]) for i in range(base + r * K, base + (r + 1) * K))
+        want_points = sum(int(ring.host(i).xyz.shape[0]) for i in range(first, first + K))
         assert points == want_points, f"statistics cover {points} points, the timed frames hold {want_points}"
+        if r < 0:
+            continue
         eo1 = eo_stats()
         regions.append(dict(dt=dt, updates=updates, points=points, rays=rays, reduce=reduce_stats,
-                            frames=list(range(base + r * K, base + (r + 1) * K)),
+                            frames=list(range(first, first + K)),
                             early_out={k: eo1[k] - eo0[k] for k in ("frames", "rounds", "fallbacks") if k in eo0 and k in eo1}))
     prof = integ.profile(reset=True)
     # per-stage breakdown: separate untimed pass over a few frames with events around every stage
@@ -775,7 +780,8 @@ def main():
             "frames_per_s": rec["frames_per_s"],
             "gpu_counted_value": rec["gpu_counted_value"],
             "updates_counted_by": rec["updates_counted_by"],
-            "timing": {"untimed_frames_before_t0": -(-(PRIME + W) // K) * K, "timed_regions": R, "steps_per_region": K,
+            "timing": {"untimed_frames_before_t0": -(-(PRIME + W) // K) * K + K, "timed_regions": R, "steps_per_region": K,
+                       "untimed": "whole turns of the ring covering PRIME + warm-up frames, then one more turn run exactly like a timed region",
                        "every_region_integrates": "the same K frames, in the same order (one turn of the ring)",
                        "reported": "median region", "spread_max_minus_min_over_median": rec["spread"],
                        "ms_per_step_all_regions": rec["ms_per_step_all_regions"],

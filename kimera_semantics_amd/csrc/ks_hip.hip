@@ -926,7 +926,7 @@ int enqueue_exact_rounds(ks_ctx* c, FrameSlot* const* slots, uint32_t nb, hipStr
   if (S0.wide) {
     // long rays: ONE emission whose views are the whole rays, then sweeps in integration order over the live bitmap, every
     // change applied at once (ks_k_exact.h); the sweeps end themselves when one of them changes nothing
-    hipLaunchKernelGGL(k_eo2_full, dim3(gn, nb), dim3(256), 0, st, Bt, 0u);
+    hipLaunchKernelGGL(k_eo2_full, dim3(gn, nb), dim3(256), 0, st, Bt);
     hipLaunchKernelGGL(k_eo2_scan, dim3(nb4k, nb), dim3(1024), 0, st, Bt);
     hipLaunchKernelGGL(k_eo2_emit<8>, dim3((uint32_t)((n + 31) / 32), nb), dim3(256), lds, st, Bt);
     HIPCHK(c, ksrs::sort_dev_batch<uint64_t>(Rs, (int)nb, S0.eo_sort_words, S0.eo_cap_marks, 44, 64, st));

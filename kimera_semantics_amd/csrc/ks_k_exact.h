@@ -1,5 +1,9 @@
-// ks_k_exact.h — `fast` with the early-out enabled, in the reference's SERIAL order (opt-in:
-// ks_config.early_out_phase_growth = KS_EARLY_OUT_EXACT).
+// ks_k_exact.h — `fast` with the early-out enabled, in the reference's SERIAL order: the library default
+// (ks_config.early_out_phase_growth = 0 / KS_EARLY_OUT_EXACT).  Three loops live here, all reaching the same fixed point:
+//   * the HOST-DRIVEN loop (k_eo_*: this comment and the first third of the file) — the fallback when a buffer of the device
+//     loops overflows, and KS_EXACT_HOST_LOOP=1;
+//   * the EVENT-DRIVEN loop on the device (k_eo2_hits .. k_eo2_commit): what runs at 5 cm / 5 m, pipelined;
+//   * the SWEEPS along the chains of the integration order (k_eo2_full .. k_eo2_sweep_done): long rays (2 cm / 10 m).
 //
 // The reference's loop [K:src/semantic_tsdf_integrator_fast.cpp:110-122] is serial by construction: ray s
 // stops after max_consecutive_ray_collisions + 1 consecutive voxels whose slot of
@@ -18,9 +22,9 @@
 //                           precedes (position, step) — binary search in the slot's range — or, if none, what
 //                           earlier frames left in the reference's table (kept verbatim in `plain`, including
 //                           the zero-initialised slots that "contain" hash 0 and the SIZE_MAX poison)
-// until no ray's length changes (640x480 / 5 cm: ~10 iterations from the seed; 2 cm voxels: ~25).  Errors
-// die out geometrically: the effective dependency chains between rays are short.  The iteration count is
-// data dependent, so the host reads one counter back per iteration: this mode is not pipelined.
+// until no ray's length changes (640x480 / 5 cm: ~10 iterations from the seed; 1280x720 / 2 cm: ~90 — a change travels
+// one ray per iteration).  The iteration count is data dependent, so the host reads one counter back per iteration: this
+// loop is not pipelined.
 #pragma once
 #include "ks_k_march.h"
 
@@ -667,11 +671,9 @@ __device__ __forceinline__ uint32_t eo2_lower_bound(const EoView& E, uint32_t sl
 // of nodes long.  So the marks of M cover a ray's VIEW — here the whole ray (k_eo2_full; k_eo2_scan / k_eo2_emit) — emitted
 // and sorted ONCE per frame; a mark counts while its step is below its ray's current length (bitmap A), and no step is
 // ever without a mark.
-constexpr uint32_t kEoPadBroken = 16;     // (a first pad other than the whole ray: k_eo2_full)
 
-// per position: the ray's length in steps and its pad (dead positions: an empty view)
-// (first_pad = 0: the whole ray is the view)
-__global__ void __launch_bounds__(256) k_eo2_full(EoBatch Bt, uint32_t first_pad) {
+// per position: the ray's length in steps and its view's pad = the whole ray (dead positions: an empty view)
+__global__ void __launch_bounds__(256) k_eo2_full(EoBatch Bt) {
   const EoView& E = Bt.v[blockIdx.y];
   const FrameParams F = *E.F;
   for (uint32_t pos = blockIdx.x * 256u + threadIdx.x; pos < F.n; pos += gridDim.x * 256u) {
@@ -680,7 +682,7 @@ __global__ void __launch_bounds__(256) k_eo2_full(EoBatch Bt, uint32_t first_pad
       const RayDesc d = E.rays[ray_index(F, pos)];
       Dda dda{};
       dda.setup(F.T.t, {d.px, d.py, d.pz}, ((d.info >> 10) & 1u) != 0, F.carving != 0, F.max_ray, F.voxel_size_inv, F.trunc, false);
-      ri = make_uint4(0u, first_pad ? first_pad : (uint32_t)dda.steps + 1u, (uint32_t)dda.steps + 1u, 0u);
+      ri = make_uint4(0u, (uint32_t)dda.steps + 1u, (uint32_t)dda.steps + 1u, 0u);
     }
     E.rinfo[pos] = ri;
   }

@@ -77,8 +77,8 @@ def main():
         if not fe_rows or not wr_rows:
             print(f"# {wl}: no counters")
             continue
-        # bench commands (--steps 20 --warmup 2): 40 untimed frames, then the timed regions: frames [40, 140) = five of them
-        lo, hi = (40, 140) if timed else (None, None)
+        # bench commands (--steps 20 --warmup 2): 60 untimed frames, then the timed regions: frames [60, 160) = five of them
+        lo, hi = (60, 160) if timed else (None, None)
         fe, wr = per_kernel(fe_rows, lo=lo, hi=hi), per_kernel(wr_rows, lo=lo, hi=hi)
         tdir = os.path.join(root, wl if timed else f"time_{wl}")
         du = collections.OrderedDict()

@@ -28,10 +28,10 @@ def main():
         last = t
         depth += dlt
     # frame markers: the first kernel of a frame (k_points_fast / k_points_merged).  bench.py --steps 20 --warmup 2:
-    # 40 untimed frames (two turns of the ring of 20: >= PRIME + warm-up), then the timed regions: frames [40, 140) = five of them
+    # 60 untimed frames (two turns of the ring of 20: >= PRIME + warm-up, and one untimed region), then the timed regions: frames [60, 160) = five of them
     first = sorted(int(r["Start_Timestamp"]) for r in tr if "k_points_" in r["Kernel_Name"])
     hist = {}
-    B0, B1 = 40, 140
+    B0, B1 = 60, 160
     if len(first) >= B1:
         per = (first[B1 - 1] - first[B0]) / (B1 - 1 - B0) / 1e3
         print(f"\n# frame period inside the timed regions (k_points start to start, frames {B0}..{B1 - 1}), with tracing on: {per:.1f} us")
