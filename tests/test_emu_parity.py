@@ -65,14 +65,14 @@ def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_lib):
 
 @pytest.mark.parametrize("spec", [
     dict(method=0, size=[128, 96], frames=2),                                    # the default: the reference's serial result, event-driven
-    dict(method=0, size=[64, 48], frames=5, pipeline=4),                         # frames in flight, commit chain
-    dict(method=0, size=[64, 48], frames=6, pipeline=8),                         # batches of four frames per launch
+    dict(method=0, size=[64, 48], frames=4, pipeline=3),                         # frames in flight, commit chain
+    dict(method=0, size=[64, 48], frames=5, pipeline=8),                         # batches of four frames per launch (and one left over)
     dict(method=0, size=[64, 48], frames=4, cfg=dict(clear_checks_every_n_frames=3)),   # a frame's marks are inputs of the next frame
     dict(method=0, size=[96, 72], frames=2, cloud="axis", max_tiles=8192),       # axis-parallel rays: the serial caster inside the rounds
     # long rays, pipelining asked for (such contexts run one frame at a time): whole-ray marks, sweeps along the chains (ks_k_exact.h);
-    # the mark buffers start large enough, so that BOTH frames run on the device (the growth path: the overflow test below)
+    # BOTH frames on the device, no fallback (the mark buffers of such a context start at a third of the longest ray per point)
     dict(method=0, size=[48, 27], frames=2, pipeline=8, max_tiles=32768, cfg=dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0),
-         env={"KS_EXACT_CAP_MARKS": "2000000"}, fallbacks_exactly=0),
+         fallbacks_exactly=0),
 ], ids=["default", "pipelined", "batched", "clear_every_3", "axis_parallel", "long_rays"])
 def test_event_driven_exact_early_out_equals_serial_oracle(emu_lib, spec):
     spec = dict(spec)
@@ -83,7 +83,7 @@ def test_overflow_falls_back_to_the_host_loop_and_the_device_loop_takes_over_aga
     """Marks that do not fit their buffer: host-driven loop for the frame AND for the frames in flight behind it (their
     predecessor's marks are not in the table when their finisher runs); the next call completes them all once, the buffers
     grow, and the frames after that run on the device again: fewer fallbacks than frames, same map."""
-    run_case(emu_lib, dict(method=0, size=[40, 30], frames=8, pipeline=4, fallbacks_below=7),
+    run_case(emu_lib, dict(method=0, size=[40, 30], frames=6, pipeline=2, fallbacks_below=5),
              env_extra={"KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "16384"})
 
 
