@@ -117,25 +117,28 @@ def test_bench_line_is_one_short_parseable_line():
                        "rays_per_frame": 47900, "updates_per_frame": 611496, "gpu_updates_per_frame": 611496, "early_out": "e" * 300,
                        "bundle_order": "n/a (fast)", "parallelism": "frame-sharded x1"},
             "roofline": roof, "host_ms_per_frame": {"in_call": 0.2, "of_which_waiting_for_snapshot": 0.05},
+            "host_inputs_h2d_inside": {"value": 1800.5, "unit": "Mvoxel-updates/s", "ms_per_step": 0.34, "frames_per_s": 2941.2, "spread": 0.01, "note": "n" * 120},
             "early_out_fidelity": {"frames": 2, "touched_jaccard": 1.0, "block_jaccard": 1.0, "label_agreement_common_voxels": 1.0,
                                    "updates_gpu_over_serial": 1.0, "how": "h" * 200},
             "cpu_baseline": {"value": 5.2, "unit": "Mvoxel-updates/s", "cores": 8, "kind": "reference", "frames_per_s": 8.5, "host_cores": 192,
                              "spread": 0.02, "by_threads": {"1": 4.8, "8": 5.2, "192": 1.9}, "reference_default_all_cores_value": 1.9, "sample": "s" * 400},
             "secondary": [dict(sub, config=c) for c in ("C2-ordered-phases", "C3", "C2-host-inputs", "C4-fast", "C4-fast-exact", "C4-merged")]
             + [{"config": "adapter", "workload": "a" * 200, "fast_every_frame_sync_ms_per_frame": 3.56, "fast_on_demand_sync_pipelined_ms_per_frame": 0.31,
-                "merged_every_frame_sync_ms_per_frame": 4.4, "merged_on_demand_sync_pipelined_ms_per_frame": 0.33},
+                "merged_every_frame_sync_ms_per_frame": 4.4, "merged_on_demand_sync_pipelined_ms_per_frame": 0.33,
+                "fast_hip_real_factory_patched_server_sequence_ms_per_frame": 0.21},
                {"config": "C5", "frames": 8, "batch_ms": 3.2, "gpu_counted_value": 1000.0, "reduce": {"tiles_sent": 100, "bytes_sent": 6553600}},
                switches, dict(switches, config="C4-fast-switches"), dict(switches, config="C4-merged-switches")],
             "library": "/root/repo/kimera_semantics_amd/libks_hip.so", "bench_seconds": 120.0}
     assert len(json.dumps(full)) > 8000                      # the canned record is of the size that broke the driver's parser
-    line = bench.compact_line(full, "profiles/bench_full_r04.json")
+    line = bench.compact_line(full, "profiles/bench_full_r05.json")
     assert "\n" not in line and len(line) < 4096
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
         assert k in d, k
     assert d["config"]["workload"] and set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind")) <= set(d["cpu_baseline"])
-    assert d["full_record"] == "profiles/bench_full_r04.json"
+    assert d["host_inputs_h2d_inside"]["ms_per_step"] == 0.34   # SURVEY.md 8(d)'s frames/s (H2D inside), beside the device-resident headline
+    assert d["full_record"] == "profiles/bench_full_r05.json"
     # degenerate: nothing optional present
     assert json.loads(bench.compact_line({"metric": "m", "value": 1.0}, None))["value"] == 1.0
 
