@@ -1,3 +1,4 @@
+# (HISTORIC: a script of the round-5 search for the C4 device loop, kept as the provenance of profiles/r05_c4_fast_device_path.txt.  The switches it sets — KS_EXACT_EPOCHS, KS_EXACT_DENSE — existed only in the commits of that search; HEAD has KS_EXACT_SWEEPS / KS_EXACT_SWEEP_ORDER, see tools/call8_r05.sh, tools/call10_r05.sh.)
 # Round 5, second GPU call (gpurun, repo root:  bash tools/call2_r05.sh): the default `fast` mode at C4 geometry ON THE DEVICE
 # (views + dense iterations), and the C2 chain's launch-shape knobs.
 set -x

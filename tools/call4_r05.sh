@@ -1,3 +1,4 @@
+# (HISTORIC: a script of the round-5 search for the C4 device loop, kept as the provenance of profiles/r05_c4_fast_device_path.txt.  The switches it sets — KS_EXACT_EPOCHS, KS_EXACT_DENSE — existed only in the commits of that search; HEAD has KS_EXACT_SWEEPS / KS_EXACT_SWEEP_ORDER, see tools/call8_r05.sh, tools/call10_r05.sh.)
 # Round 5, fourth GPU call: full-size C4 frames, default `fast` mode on the device — dense-iteration schedules (KS_EXACT_TRACE=1)
 set -x
 R=$GRAFT_REPO_ROOT
