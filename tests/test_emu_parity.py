@@ -8,28 +8,76 @@ import json
 import os
 import subprocess
 import sys
+import threading
+from concurrent.futures import ThreadPoolExecutor
 
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "tools", "emu", "_build", "libks_hip_emu.so")
 
+# Every test of this module is ONE child process (seconds to a minute of single-threaded emulation): JOBS maps a test's
+# node name to its command line, the `emu_jobs` fixture starts the selected ones side by side (one per core) as soon as the
+# library is built, and a test only collects its own child's verdict — the same cases, the same assertions, a fifth of the
+# wall-clock time on 8 cores.
+JOBS = {}   # pytest node name -> (argv, extra environment, timeout in seconds, expected seconds: the long ones start first)
+
+
+def case_job(node, spec, env_extra=None, timeout=900, weight=10):
+    JOBS[node] = ([sys.executable, "-m", "tests.emu_case", json.dumps(spec)], dict(env_extra or {}), timeout, weight)
+
+
+class _Jobs:
+    def __init__(self, lib, nodes):
+        self.lib, self.lock, self.children = lib, threading.Lock(), set()
+        self.pool = ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 1, 16)))
+        self.futures = {n: self.pool.submit(self._run, *JOBS[n][:3]) for n in nodes}
+
+    def _run(self, argv, env_extra, timeout):
+        child = subprocess.Popen(argv, cwd=ROOT, env=dict(os.environ, KS_HIP_LIB=self.lib, **env_extra), stdout=subprocess.PIPE,
+                                 stderr=subprocess.PIPE, text=True)
+        with self.lock:
+            self.children.add(child)
+        try:
+            out, err = child.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            child.kill()
+            out, err = child.communicate()
+            err += "\n[timed out after %d s]" % timeout
+        finally:
+            with self.lock:
+                self.children.discard(child)
+        return child.returncode, out, err
+
+    def result(self, node):
+        if node not in self.futures:   # (a test selected in a way the fixture did not foresee: run it now)
+            self.futures[node] = self.pool.submit(self._run, *JOBS[node][:3])
+        return self.futures[node].result()
+
+    def close(self):
+        for f in self.futures.values():
+            f.cancel()
+        with self.lock:
+            for child in list(self.children):   # (exactly the children started here)
+                child.kill()
+        self.pool.shutdown(wait=True)
+
 
 @pytest.fixture(scope="module")
-def emu_lib():
+def emu_jobs(request):
     if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
         pytest.skip("host clang++ of the ROCm toolchain not found")
     r = subprocess.run(["bash", os.path.join(ROOT, "tools", "emu", "build_emu.sh")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    return LIB
+    mine = [it.name for it in request.session.items if str(it.fspath) == str(request.fspath) and it.name in JOBS]
+    jobs = _Jobs(LIB, sorted(mine, key=lambda n: -JOBS[n][3]))   # (the long ones first)
+    yield jobs
+    jobs.close()
 
 
-def run_case(lib, spec, env_extra=None, timeout=900):
-    env = dict(os.environ, KS_HIP_LIB=lib)
-    env.update(env_extra or {})
-    r = subprocess.run([sys.executable, "-m", "tests.emu_case", json.dumps(spec)], cwd=ROOT, env=env, capture_output=True, text=True,
-                       timeout=timeout)
-    assert r.returncode == 0 and "EMU_CASE_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+def check_case(emu_jobs, request):
+    rc, out, err = emu_jobs.result(request.node.name)
+    assert rc == 0 and "EMU_CASE_OK" in out, out[-3000:] + err[-3000:]
 
 
 CASES = {
@@ -53,55 +101,78 @@ CASES = {
 }
 
 
+for _name, _spec in CASES.items():
+    case_job("test_device_code_on_the_host_equals_oracle[%s]" % _name, _spec, weight=50 if "long_bundles" in _name else 10)
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_device_code_on_the_host_equals_oracle(emu_lib, name):
-    run_case(emu_lib, CASES[name])
+def test_device_code_on_the_host_equals_oracle(emu_jobs, request, name):
+    check_case(emu_jobs, request)
 
 
-def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_lib):
+case_job("test_late_phases_with_several_sub_runs_per_chain_equal_oracle",
+         dict(method=0, size=[320, 240], frames=2, max_tiles=8192, cfg=dict(early_out_phase_growth=32)), weight=30)
+
+
+def test_late_phases_with_several_sub_runs_per_chain_equal_oracle(emu_jobs, request):
     """320x240 = 75 generations: the phases [32, 64) and [64, 75) have up to two sub-runs per chain, cut over the chain's LIVE rays."""
-    run_case(emu_lib, dict(method=0, size=[320, 240], frames=2, max_tiles=8192, cfg=dict(early_out_phase_growth=32)))
+    check_case(emu_jobs, request)
 
 
-@pytest.mark.parametrize("spec", [
-    dict(method=0, size=[128, 96], frames=2),                                    # the default: the reference's serial result, event-driven
-    dict(method=0, size=[64, 48], frames=4, pipeline=3),                         # frames in flight, commit chain
-    dict(method=0, size=[64, 48], frames=5, pipeline=8),                         # batches of four frames per launch (and one left over)
-    dict(method=0, size=[64, 48], frames=4, cfg=dict(clear_checks_every_n_frames=3)),   # a frame's marks are inputs of the next frame
-    dict(method=0, size=[96, 72], frames=2, cloud="axis", max_tiles=8192),       # axis-parallel rays: the serial caster inside the rounds
+EXACT_CASES = {
+    "default": dict(method=0, size=[128, 96], frames=2),                                    # the default: the reference's serial result, event-driven
+    "pipelined": dict(method=0, size=[64, 48], frames=4, pipeline=3),                       # frames in flight, commit chain
+    "batched": dict(method=0, size=[64, 48], frames=5, pipeline=8),                         # batches of four frames per launch (and one left over)
+    "clear_every_3": dict(method=0, size=[64, 48], frames=4, cfg=dict(clear_checks_every_n_frames=3)),   # a frame's marks are inputs of the next frame
+    "axis_parallel": dict(method=0, size=[96, 72], frames=2, cloud="axis", max_tiles=8192),   # axis-parallel rays: the serial caster inside the rounds
     # long rays, pipelining asked for (such contexts run one frame at a time): whole-ray marks, sweeps along the chains (ks_k_exact.h);
     # BOTH frames on the device, no fallback (the mark buffers of such a context start at a third of the longest ray per point)
-    dict(method=0, size=[48, 27], frames=2, pipeline=8, max_tiles=32768, cfg=dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0),
-         fallbacks_exactly=0),
-], ids=["default", "pipelined", "batched", "clear_every_3", "axis_parallel", "long_rays"])
-def test_event_driven_exact_early_out_equals_serial_oracle(emu_lib, spec):
-    spec = dict(spec)
-    run_case(emu_lib, spec, env_extra=spec.pop("env", None))
+    "long_rays": dict(method=0, size=[48, 27], frames=2, pipeline=8, max_tiles=32768,
+                      cfg=dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0), fallbacks_exactly=0),
+}
+for _name, _spec in EXACT_CASES.items():
+    case_job("test_event_driven_exact_early_out_equals_serial_oracle[%s]" % _name, _spec, weight=60)
 
 
-def test_overflow_falls_back_to_the_host_loop_and_the_device_loop_takes_over_again(emu_lib):
+@pytest.mark.parametrize("name", list(EXACT_CASES))
+def test_event_driven_exact_early_out_equals_serial_oracle(emu_jobs, request, name):
+    check_case(emu_jobs, request)
+
+
+case_job("test_overflow_falls_back_to_the_host_loop_and_the_device_loop_takes_over_again",
+         dict(method=0, size=[40, 30], frames=6, pipeline=2, fallbacks_below=5),
+         env_extra={"KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "16384"}, weight=65)
+
+
+def test_overflow_falls_back_to_the_host_loop_and_the_device_loop_takes_over_again(emu_jobs, request):
     """Marks that do not fit their buffer: host-driven loop for the frame AND for the frames in flight behind it (their
     predecessor's marks are not in the table when their finisher runs); the next call completes them all once, the buffers
     grow, and the frames after that run on the device again: fewer fallbacks than frames, same map."""
-    run_case(emu_lib, dict(method=0, size=[40, 30], frames=6, pipeline=2, fallbacks_below=5),
-             env_extra={"KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "16384"})
+    check_case(emu_jobs, request)
+
+
+for _overlap in ("1", "0"):
+    case_job("test_axis_parallel_rays_under_the_early_out_equal_oracle[%s]" % _overlap,
+             dict(method=0, size=[96, 72] if _overlap == "1" else [64, 48], frames=1, max_tiles=8192, cloud="axis",
+                  cfg=dict(early_out_phase_growth=32)), env_extra={"KS_TEST_OVERLAP": _overlap}, weight=15)
 
 
 @pytest.mark.parametrize("overlap", ["1", "0"])
-def test_axis_parallel_rays_under_the_early_out_equal_oracle(emu_lib, overlap):
+def test_axis_parallel_rays_under_the_early_out_equal_oracle(emu_jobs, request, overlap):
     """Long rays with zero components (the owner lane's serial caster inside k_test's 64-voxel rounds), with the next round
     cast while the current round's shared-set entries are in flight (default) and one after the other (KS_TEST_OVERLAP=0)."""
-    run_case(emu_lib, dict(method=0, size=[96, 72] if overlap == "1" else [64, 48], frames=1, max_tiles=8192, cloud="axis",
-                           cfg=dict(early_out_phase_growth=32)), env_extra={"KS_TEST_OVERLAP": overlap})
+    check_case(emu_jobs, request)
 
 
-def test_gpu_tier_cases_unchanged_on_the_functional_model(emu_lib):
+JOBS["test_gpu_tier_cases_unchanged_on_the_functional_model"] = (
+    [sys.executable, "-m", "pytest", "tests/test_parity_gpu.py", "-m", "gpu", "-q", "-x", "-k",
+     "error_codes or saturated or degenerate or depth_image_u16"], {"KS_TESTS_ON_FUNCTIONAL_MODEL": "1"}, 1200, 55)
+
+
+def test_gpu_tier_cases_unchanged_on_the_functional_model(emu_jobs, request):
     """A selection of the GPU tier's own tests (tests/test_parity_gpu.py), UNCHANGED, against the functional model:
     the reference's CHECKs as error codes, saturated weights, degenerate inputs (NaN / zero-length / out-of-range rays),
     the depth-image entry with u16 depth and colour-coded labels.  (Any other `-m gpu` test runs the same way —
     minutes instead of seconds: KS_TESTS_ON_FUNCTIONAL_MODEL=1 KS_HIP_LIB=tools/emu/_build/libks_hip_emu.so pytest -m gpu -k ...)"""
-    env = dict(os.environ, KS_HIP_LIB=emu_lib, KS_TESTS_ON_FUNCTIONAL_MODEL="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_parity_gpu.py", "-m", "gpu", "-q", "-x", "-k",
-                        "error_codes or saturated or degenerate or depth_image_u16"], cwd=ROOT, env=env, capture_output=True,
-                       text=True, timeout=1200)
-    assert r.returncode == 0 and " passed" in r.stdout and "skipped" not in r.stdout.splitlines()[-1], r.stdout[-3000:] + r.stderr[-2000:]
+    rc, out, err = emu_jobs.result(request.node.name)
+    assert rc == 0 and " passed" in out and "skipped" not in out.splitlines()[-1], out[-3000:] + err[-2000:]
