@@ -115,13 +115,13 @@ typedef struct ks_config {
                                        KS_ERR_POOL_FULL remains for a single frame that needs more than the free half. */
   uint32_t max_points;              /* largest cloud per call (buffers grow on demand if exceeded) */
   /* 0 (default): an integrate call returns with its frame fully enqueued and its own statistics.
-   * 1 .. 8: frame pipelining for streams of frames (bag replay): the value is how many calls the second
+   * 1 .. 16: frame pipelining for streams of frames (bag replay): the value is how many calls the second
    *    half of a frame (pair sort + voxel update) lags behind.  A call enqueues stages A and B of its frame
    *    (points .. early-out phases and pair emission) and finishes the frame `pipeline_frames` calls back; the
    *    one host wait of a frame then overlaps GPU work of later frames, and stage B of up to four consecutive
-   *    frames runs concurrently: on four streams (values below 8), or — value 8 — as one batched launch sequence
-   *    per four frames (every kernel of stage B covers the batch).  Larger values keep the host further ahead at
-   *    the price of that many frames of latency.
+   *    frames runs concurrently: on four streams (values below 8), or — values 8 .. 15 — as one batched launch sequence
+   *    per four frames (every kernel of stage B covers the batch), or — value 16 — per eight frames.  Larger values
+   *    keep the host further ahead at the price of that many frames of latency (and of frame slots: 12 up to 8, 24 above).
    *    The statistics a call returns are those of the frames completed since statistics were last
    *    returned (summed if several), i.e. they lag by `pipeline_frames` calls; so do KS_ERR_LABEL_RANGE /
    *    pool errors.  Every other entry point (queries, download, export, ks_synchronize, ks_flush)

@@ -86,9 +86,11 @@ std::string g_create_error;
 // update by memory latency, and neither A nor B touches voxel data.  The host's one wait per frame (for the
 // snapshot that sizes T) never idles the GPU.  Twelve slots rotate; stage A of a frame waits for the tail (and
 // the long runs) that last used its slot.
-constexpr int kMaxLag = 8;           // largest ks_config.pipeline_frames
-constexpr int kSlots = kMaxLag + 4;  // frame slots: the tail may lag up to kMaxLag calls
+constexpr int kMaxLag = 16;          // largest ks_config.pipeline_frames
+constexpr int kSlots = kMaxLag + 8;  // frame slots at most; a context uses ks_ctx::n_slots of them: 12 up to a lag of 8 (three batches
+                                     // of four), 24 above (three batches of eight) — the tail may lag up to kMaxLag calls
 constexpr int kMarchStreams = 8;
+constexpr int kObsTables = 16;       // early-out tables: one per frame whose stage B can be in flight (two batches of eight)
 struct HostSnap {
   Counters c;
   uint32_t n_tiles;
@@ -107,12 +109,16 @@ struct FrameSlot {
   bool wide = false;                // stage B uses a whole wavefront per ray (long rays)
   FrameParams* d_F = nullptr;       // the frame's parameters in device memory (stage B reads them from there)
   uint64_t *d_gkeys = nullptr, *d_rkeys = nullptr;  // anti-grazing: this frame's sorted end-voxel keys / key per bundle
-  hipGraphExec_t b_graph = nullptr; // stage B of this slot as a captured graph ...
-  uint64_t b_graph_key = 0;         // ... valid for this (point count, buffers) key
-  // exact early-out, event-driven fix point (ks_k_exact.h): the slot's marks, per-slot table, X marks, lists; stage B is
-  // then THREE graphs (seed + marks + bulk rounds | finisher + commit | scan + emission) with the wait for the previous
-  // frame's commit between the first two
-  hipGraphExec_t b_graph2 = nullptr, b_graph3 = nullptr;
+  // stage B of the batch that STARTS on this slot as captured graphs, valid for a (point count, buffers, batch size) key.
+  // Exact early-out, event-driven fix point (ks_k_exact.h): THREE graphs (seed + marks + bulk rounds | finisher + commit |
+  // scan + emission) with the wait for the previous frame's commit between the first two; otherwise g1 alone.
+  // Two sets: [0] full batches, [1] partial ones (a flush ends a batch early: a stream that is flushed every K frames, K no
+  // multiple of the batch, would otherwise re-capture on every change of the size).
+  struct GraphSet {
+    hipGraphExec_t g1 = nullptr, g2 = nullptr, g3 = nullptr;
+    uint64_t key = 0;
+  } b_graphs[2];
+  // exact early-out, event-driven fix point (ks_k_exact.h): the slot's marks, per-slot table, X marks, lists
   uint64_t* d_eo_keys[2] = {nullptr, nullptr};
   uint32_t* d_eo_vals[2] = {nullptr, nullptr};
   size_t eo_cap_marks = 0;
@@ -154,7 +160,7 @@ struct FrameSlot {
 
 // HIP-event sets for ks_profile: recorded in stream order, resolved lazily (before reuse or in
 // ks_profile_get) so that profiling never adds a host wait to a frame.
-constexpr int kProfSets = 16;
+constexpr int kProfSets = 32;   // > 2 x the largest lag
 constexpr int kStageEvents = KS_STAGE_COUNT + 3;  // 0..3 stage A | 4,5 march begin/end | 6 tail begin, 7..10
 struct ProfSet {
   hipEvent_t ev[kStageEvents]{};
@@ -186,7 +192,7 @@ struct ks_ctx {
   TileTable table{};
   Pool pool{};
   uint64_t* d_start_set = nullptr;
-  uint64_t* d_observed_[kMarchStreams] = {};
+  uint64_t* d_observed_[kObsTables] = {};
   int n_obs = 1;
   uint64_t start_offset = 0, observed_offset = 0;
   int64_t reset_counter = 0;
@@ -290,6 +296,7 @@ struct ks_ctx {
   // Device words: Counters of slot k at 64 * k, the persistent tile count at 64 * kSlots.
   uint8_t* d_state = nullptr;
   FrameSlot slot[kSlots];
+  int n_slots = 1;   // slots in use: 1 (unpipelined), 12 or 24 (ks_create)
   uint64_t frame_no = 0;
   ks_frame_stats owed{};  // statistics of frames completed but not yet handed to the caller (summed)
   int32_t* d_block_idx = nullptr;
@@ -469,7 +476,7 @@ int ensure_points(ks_ctx* c, size_t n) {
   if ((rc = dev_alloc(c, &c->d_labels, cap))) return rc;
   ++c->buffers_epoch;
   const size_t scan_cap = (c->cfg.method == KS_METHOD_MERGED ? 2 : 1) * cap;
-  for (int i = 0; i < (c->cfg.pipeline_frames ? kSlots : 1); ++i) {
+  for (int i = 0; i < (c->cfg.pipeline_frames ? c->n_slots : 1); ++i) {
     if ((rc = dev_alloc(c, &c->slot[i].d_rays, cap))) return rc;
     if ((rc = dev_alloc(c, &c->slot[i].d_ray_list, cap))) return rc;
     if ((rc = dev_alloc(c, &c->slot[i].d_cnt, scan_cap))) return rc;
@@ -797,7 +804,7 @@ int exact_early_out(ks_ctx* c, FrameSlot& S, hipStream_t st, Counters* counters 
 int ensure_exact_slots(ks_ctx* c, size_t cap_marks, size_t cap_x) {
   if (!c->eo_device) return KS_OK;
   int rc;
-  const int n_slots = c->cfg.pipeline_frames ? kSlots : 1;
+  const int n_slots = c->cfg.pipeline_frames ? c->n_slots : 1;
   for (int i = 0; i < n_slots; ++i) {
     FrameSlot& S = c->slot[i];
     if (!S.d_eo_ctl) {
@@ -834,7 +841,7 @@ int ensure_exact_slots(ks_ctx* c, size_t cap_marks, size_t cap_x) {
 int ensure_exact_points(ks_ctx* c, size_t cap) {   // the per-position arrays (called by ensure_points)
   if (!c->eo_device) return KS_OK;
   int rc;
-  for (int i = 0; i < (c->cfg.pipeline_frames ? kSlots : 1); ++i) {
+  for (int i = 0; i < (c->cfg.pipeline_frames ? c->n_slots : 1); ++i) {
     FrameSlot& S = c->slot[i];
     for (uint32_t** p : {&S.d_eo_cnt_b, &S.d_eo_ux, &S.d_eo_dirty, &S.d_eo_list[0], &S.d_eo_list[1], &S.d_eo_chg, &S.d_eo_consulted, &S.d_eo_lp})
       if ((rc = dev_alloc(c, p, cap))) return rc;
@@ -993,19 +1000,20 @@ int launch_batch(ks_ctx* c) {
     steps_max = std::max(steps_max, S.steps_max);
   }
   const uint64_t key = ((uint64_t)c->cap_points << 24) ^ (c->buffers_epoch.load() << 4) ^ (S0.wide ? 1u : 0u) ^ ((uint64_t)nb << 1);
+  FrameSlot::GraphSet& G = S0.b_graphs[nb == (uint32_t)c->batch ? 0 : 1];
   bool replayed = false;
   int rc;
   if (c->exact_early_out && c->eo_device && !c->eo_device_off) {
     // (batches of one) the ordered phases give the seed; the event-driven fix point makes it the serial result, on the
     // device: three replayed graphs, the wait for the previous frame's marks between the first two
     bool graphs = c->use_graphs && !S0.wide;   // (long rays: the host looks at the sweeps' progress between chunks of them)
-    if (graphs && (S0.b_graph_key != key || !S0.b_graph || !S0.b_graph2 || !S0.b_graph3)) {
+    if (graphs && (G.key != key || !G.g1 || !G.g2 || !G.g3)) {
       std::lock_guard<std::mutex> cap(c->capture_mu);
-      for (hipGraphExec_t* g : {&S0.b_graph, &S0.b_graph2, &S0.b_graph3}) {
+      for (hipGraphExec_t* g : {&G.g1, &G.g2, &G.g3}) {
         if (*g) (void)hipGraphExecDestroy(*g);
         *g = nullptr;
       }
-      S0.b_graph_key = 0;
+      G.key = 0;
       int part_rc = KS_OK;
       auto capture = [&](hipGraphExec_t* out, int part) -> bool {
         hipGraph_t g = nullptr;
@@ -1025,18 +1033,18 @@ int launch_batch(ks_ctx* c) {
         if (g) (void)hipGraphDestroy(g);
         return ok;
       };
-      if (capture(&S0.b_graph, 1) && capture(&S0.b_graph2, 2) && capture(&S0.b_graph3, 3)) {
-        S0.b_graph_key = key;
+      if (capture(&G.g1, 1) && capture(&G.g2, 2) && capture(&G.g3, 3)) {
+        G.key = key;
       } else {
         (void)hipGetLastError();
-        for (hipGraphExec_t* g : {&S0.b_graph, &S0.b_graph2, &S0.b_graph3}) {
+        for (hipGraphExec_t* g : {&G.g1, &G.g2, &G.g3}) {
           if (*g) (void)hipGraphExecDestroy(*g);
           *g = nullptr;
         }
         c->use_graphs = graphs = false;  // plain launches from now on
       }
     }
-    if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph, sm));
+    if (graphs) HIPCHK(c, hipGraphLaunch(G.g1, sm));
     else {
       enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 1);
       if ((rc = enqueue_exact_rounds(c, slots.data(), nb, sm))) return rc;
@@ -1061,12 +1069,12 @@ int launch_batch(ks_ctx* c) {
       }
     }
     if (c->eo_last_commit && c->eo_last_commit != S0.eo_committed) HIPCHK(c, hipStreamWaitEvent(sm, c->eo_last_commit, 0));
-    if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph2, sm));
+    if (graphs) HIPCHK(c, hipGraphLaunch(G.g2, sm));
     else
       for (uint32_t k = 0; k < nb; ++k) enqueue_exact_finish(c, *slots[k], sm);
     HIPCHK(c, hipEventRecord(S0.eo_committed, sm));   // (after the LAST frame's commit: the batch's frames finish in order on this stream)
     c->eo_last_commit = S0.eo_committed;
-    if (graphs) HIPCHK(c, hipGraphLaunch(S0.b_graph3, sm));
+    if (graphs) HIPCHK(c, hipGraphLaunch(G.g3, sm));
     else enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 2);
     replayed = true;
   } else if (c->exact_early_out) {
@@ -1076,29 +1084,29 @@ int launch_batch(ks_ctx* c) {
     enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max, 2);
     replayed = true;
   } else if (c->use_graphs) {
-    if (S0.b_graph_key != key || !S0.b_graph) {
+    if (G.key != key || !G.g1) {
       std::lock_guard<std::mutex> cap(c->capture_mu);  // (rare: once per group of slots)
-      if (S0.b_graph) (void)hipGraphExecDestroy(S0.b_graph);
-      S0.b_graph = nullptr;
-      S0.b_graph_key = 0;
+      if (G.g1) (void)hipGraphExecDestroy(G.g1);
+      G.g1 = nullptr;
+      G.key = 0;
       hipGraph_t g = nullptr;
       bool ok = hipStreamBeginCapture(sm, hipStreamCaptureModeRelaxed) == hipSuccess;
       if (ok) {
         enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max);
         ok = hipStreamEndCapture(sm, &g) == hipSuccess && g != nullptr;
       }
-      if (ok) ok = hipGraphInstantiate(&S0.b_graph, g, nullptr, nullptr, 0) == hipSuccess;
+      if (ok) ok = hipGraphInstantiate(&G.g1, g, nullptr, nullptr, 0) == hipSuccess;
       if (g) (void)hipGraphDestroy(g);
       if (ok) {
-        S0.b_graph_key = key;
+        G.key = key;
       } else {
         (void)hipGetLastError();
-        S0.b_graph = nullptr;
+        G.g1 = nullptr;
         c->use_graphs = false;  // plain launches from now on
       }
     }
-    if (S0.b_graph) {
-      HIPCHK(c, hipGraphLaunch(S0.b_graph, sm));
+    if (G.g1) {
+      HIPCHK(c, hipGraphLaunch(G.g1, sm));
       replayed = true;
     }
   }
@@ -1545,8 +1553,8 @@ void deliver_stats(ks_ctx* c, ks_frame_stats* stats) {
 // run the tail of a frame whose front is still waiting for it (pipelined mode)
 int flush_pending(ks_ctx* c) {
   // up to two slots are pending between calls; oldest frame first
-  for (int k = 0; k < kSlots; ++k) {
-    FrameSlot& S = c->slot[(c->frame_no + k) % kSlots];
+  for (int k = 0; k < c->n_slots; ++k) {
+    FrameSlot& S = c->slot[(c->frame_no + k) % (uint64_t)c->n_slots];
     if (S.pending) {
       const int rc = frame_tail(c, S);
       if (rc) return rc;
@@ -1771,10 +1779,10 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
   // next call can enqueue stage A while this frame's march is in flight); the statistics returned
   // are those of the frames completed here
   const uint64_t lag = (uint64_t)std::min(std::max(cfg.pipeline_frames, 1), kMaxLag);
-  FrameSlot& S = c->slot[c->frame_no % kSlots];
+  FrameSlot& S = c->slot[c->frame_no % (uint64_t)c->n_slots];
   if (S.pending && (rc = frame_tail(c, S))) return rc;  // cannot happen: the slot's frame is 4 calls old
   const uint64_t this_frame = c->frame_no;
-  FrameSlot* due = (this_frame >= lag) ? &c->slot[(this_frame - lag) % kSlots] : nullptr;
+  FrameSlot* due = (this_frame >= lag) ? &c->slot[(this_frame - lag) % (uint64_t)c->n_slots] : nullptr;
   if (due && !due->pending) due = nullptr;
   if (due && !due->b_launched && (rc = launch_batch(c))) return rc;  // (only with a lag shorter than the batch)
   if (due && c->use_tail_thread) {
@@ -2018,9 +2026,12 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   if (c->cfg.pipeline_frames >= 2 && frames_independent && (!c->exact_early_out || c->eo_device) && c->cfg.integration_order_mode != KS_ORDER_SORTED) {
     // (measured, 640x480: a batch of 4 behind 8 frames of lag ~ four single-frame sequences on four streams behind 4
     // frames of lag; batches of 2 or 3 lose to both: DESIGN.md)
-    c->batch = c->cfg.pipeline_frames >= 8 ? kBatchMax : 1;
+    c->batch = c->cfg.pipeline_frames >= 16 ? 8 : c->cfg.pipeline_frames >= 8 ? 4 : 1;
     if (const char* bs = getenv("KS_BATCH")) c->batch = std::min(kBatchMax, std::max(1, atoi(bs)));  // diagnostics
   }
+  // slots: the lag plus one batch being filled, a multiple of the batch (a batch then always starts on the same slots: its
+  // captured launch sequence is found again)
+  c->n_slots = !c->cfg.pipeline_frames ? 1 : (c->cfg.pipeline_frames > 8 || c->batch > 4) ? kSlots : 12;
   if (c->cfg.pipeline_frames) {
     // (shared early-out table: stage B of consecutive frames stays in order on one stream)
     c->n_march = (!frames_independent || c->batch > 1) ? 1 : std::min(kMarchStreams, std::max(4, c->cfg.pipeline_frames));
@@ -2080,7 +2091,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   CRCHK(hipMalloc((void**)&c->pool.dirty, mt));
   CRCHK(hipMemset(c->pool.dirty, 0, mt));
   CRCHK(hipMalloc((void**)&c->d_start_set, sizeof(uint64_t) << kSetBits));
-  c->n_obs = (uses_early_out && frames_independent) ? std::min(kMarchStreams, std::max(c->n_march, c->batch * c->n_march)) : 1;
+  c->n_obs = (uses_early_out && frames_independent) ? std::min(kObsTables, std::max(c->n_march, c->batch * c->n_march)) : 1;
   for (int t = 0; t < c->n_obs; ++t) {
     CRCHK(hipMalloc((void**)&c->d_observed_[t], 2 * (sizeof(uint64_t) << kSetBits)));   // {newest, older} per slot
     CRCHK(hipMemset(c->d_observed_[t], 0, 2 * (sizeof(uint64_t) << kSetBits)));
@@ -2166,7 +2177,7 @@ void ks_destroy(ks_ctx* c) {
     if (sm && sm != c->stream) (void)hipStreamSynchronize(sm);
   if (c->stream_long) (void)hipStreamSynchronize(c->stream_long);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->pool.dirty, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_observed_[3], c->d_observed_[4], c->d_observed_[5], c->d_observed_[6], c->d_observed_[7], c->d_color_lut,
+  void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->pool.dirty, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_observed_[3], c->d_observed_[4], c->d_observed_[5], c->d_observed_[6], c->d_observed_[7], c->d_observed_[8], c->d_observed_[9], c->d_observed_[10], c->d_observed_[11], c->d_observed_[12], c->d_observed_[13], c->d_observed_[14], c->d_observed_[15], c->d_color_lut,
                   c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list_[0], c->d_long_list_[1], c->d_blong, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_pairs2_[0], c->d_pairs2_[1], c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
@@ -2182,8 +2193,6 @@ void ks_destroy(ks_ctx* c) {
                     (void*)S.d_eo_cnt_b, (void*)S.d_eo_ux, (void*)S.d_eo_dirty, (void*)S.d_eo_list[0], (void*)S.d_eo_list[1], (void*)S.d_eo_chg,
                     (void*)S.d_eo_consulted, (void*)S.d_eo_lp, (void*)S.d_eo_bt, (void*)S.d_eo_ctl, (void*)S.d_eo_sort_ws, (void*)S.d_eo_hitb, (void*)S.d_eo_bits_a, (void*)S.d_eo_bits_b, (void*)S.d_eo_btp, (void*)S.d_eo_hseq, (void*)S.d_eo_where, (void*)S.d_eo_rinfo, (void*)S.d_eo_ckpt})
       if (p) (void)hipFree(p);
-    if (S.b_graph2) (void)hipGraphExecDestroy(S.b_graph2);
-    if (S.b_graph3) (void)hipGraphExecDestroy(S.b_graph3);
     if (S.eo_committed) (void)hipEventDestroy(S.eo_committed);
   }
   if (c->d_eo_committed) (void)hipFree(c->d_eo_committed);
@@ -2191,7 +2200,9 @@ void ks_destroy(ks_ctx* c) {
   ksrs::release(c->sort_ws);
   ksrs::release(c->sort_ws_tail);
   for (auto& S : c->slot) {
-    if (S.b_graph) (void)hipGraphExecDestroy(S.b_graph);
+    for (auto& G : S.b_graphs)
+      for (hipGraphExec_t g : {G.g1, G.g2, G.g3})
+        if (g) (void)hipGraphExecDestroy(g);
     if (S.h_snap) (void)hipHostFree(S.h_snap);
     if (S.ready) (void)hipEventDestroy(S.ready);
     if (S.tail_done) (void)hipEventDestroy(S.tail_done);

@@ -175,7 +175,7 @@ __device__ __forceinline__ Dda dda_bcast(const Dda& d, int src) {
 // launched once for the whole batch (blockIdx.y = frame of the batch).  The chains of small dependent launches that
 // decide the early-out are latency bound — a launch costs the same for one frame or four — and the hardware runs at
 // most a couple of such chains side by side when they sit on different streams.
-constexpr int kBatchMax = 4;
+constexpr int kBatchMax = 8;
 struct SlotView {
   const FrameParams* F;          // the frame's parameters in device memory
   const uint8_t* live;           // fast: position holds a ray that survived the start-voxel dedup

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) k_rs_hist(const K* __restrict__ keys, uin
 }
 // Up to kRsBatch independent sorts of the same capacity per launch (blockIdx.y = sort): their launches are latency bound,
 // and a launch costs the same for one sort or four.
-constexpr int kRsBatch = 4;
+constexpr int kRsBatch = 8;
 template <typename K>
 struct DevBatch {
   K* keys_a[kRsBatch];

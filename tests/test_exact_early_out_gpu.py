@@ -162,16 +162,18 @@ def test_default_configuration_is_the_serial_result():
     assert st["event_driven"] and st["frames"] == 3 and st["fallbacks"] == 0 and st["rounds"] >= 3, st
 
 
-@pytest.mark.parametrize("pipe", [2, 4, 8])
+@pytest.mark.parametrize("pipe", [2, 4, 8, 16])
 def test_exact_early_out_pipelined(pipe):
     """frames in flight: the fix point of frame i + 1 runs beside that of frame i; what is left of the dependence
-    between frames (the table earlier frames leave behind) is carried by the commit events."""
+    between frames (the table earlier frames leave behind) is carried by the commit events.  (8: batches of four frames
+    per launch sequence; 16: batches of eight, 24 frame slots — two full batches and a partial one.)"""
     okw = dict(COMMON, method=0)
     o = O.Oracle(O.default_config(**okw))
     h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 17, pipeline_frames=pipe, **okw))
-    _totals(o, h, _frames(14))
+    n = 14 if pipe < 16 else 21
+    _totals(o, h, _frames(n))
     st = h.early_out_stats()
-    assert st["event_driven"] and st["pipelined"] and st["frames"] == 14 and st["fallbacks"] == 0, st
+    assert st["event_driven"] and st["pipelined"] and st["frames"] == n and st["fallbacks"] == 0, st
     print(f"pipeline {pipe}: {st['rounds'] / st['frames']:.1f} rounds per frame")
 
 

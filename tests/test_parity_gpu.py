@@ -191,7 +191,7 @@ def test_full_size_c4_default_early_out_exact():
         assert a.tobytes() == b.tobytes()
 
 
-@pytest.mark.parametrize("pipe,growth", [(1, 32), (8, 32), (8, 0)])
+@pytest.mark.parametrize("pipe,growth", [(1, 32), (8, 32), (8, 0), (16, 0)])
 def test_observed_set_tag_wrap(pipe, growth):
     """The early-out set's entries carry a 10-bit frame tag; every ~1000 frames the stale entries are retired
     and the tags restart.  1100 small frames stay bit-exact against the oracle — also with batches of four frames per
@@ -208,7 +208,7 @@ def test_observed_set_tag_wrap(pipe, growth):
         o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
         h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
         if pipe > 1 and k in (5, 1001, 1015):
-            h.block_indices()   # (completes the frames in flight: the next batch starts off the multiple of four)
+            h.block_indices()   # (completes the frames in flight: the next batch starts off the multiple of four / eight)
     h.flush()
     compare_maps(o, h, exact=True)
 
@@ -902,17 +902,18 @@ def test_benched_configuration_map_is_exact(method):
         assert st["event_driven"] and st["pipelined"] and st["fallbacks"] == 0, st
 
 
+@pytest.mark.parametrize("pipe", [8, 16])
 @pytest.mark.parametrize("method", [0, 1])
-def test_batched_stage_b_equals_unpipelined(method):
-    """pipeline_frames = 8: stage B of four consecutive frames is ONE batched launch sequence (blockIdx.y = frame).
-    22 frames (full batches, a partial one at the flush, a query in between that forces a partial batch): same map
+def test_batched_stage_b_equals_unpipelined(method, pipe):
+    """pipeline_frames = 8 / 16: stage B of four / eight consecutive frames is ONE batched launch sequence (blockIdx.y = frame).
+    22 / 38 frames (full batches, a partial one at the flush, a query in between that forces a partial batch): same map
     and statistics as the unpipelined context; fast runs the default early-out schedule."""
     kw = dict(COMMON, method=method)
     a = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 15, pipeline_frames=0, **kw))
-    b = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 15, pipeline_frames=8, **kw))
+    b = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 15, pipeline_frames=pipe, **kw))
     sc = synth.make_scene("room")
     ua = ub = 0
-    for k in range(22):
+    for k in range(22 if pipe == 8 else 38):
         f = synth.render_frame(sc, synth.trajectory_pose(k), 128, 96, seed=k)
         ua += a.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
         ub += b.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
