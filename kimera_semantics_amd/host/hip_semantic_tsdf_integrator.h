@@ -39,7 +39,7 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
     uint32_t max_tiles = 1u << 16;   ///< 8^3-voxel tiles (49.7 KB each)
     uint32_t max_points = 1u << 20;
     SyncPolicy sync_policy = SyncPolicy::kEveryFrame;
-    /// ks_config.pipeline_frames (0 .. 8): how many calls the second half of a frame may lag behind.  The context is
+    /// ks_config.pipeline_frames (0 .. 16; 16 = batches of eight frames, twice the frame slots): how many calls the second half of a frame may lag behind.  The context is
     /// created able to pipeline whatever the policy: under kEveryFrame every call completes its frame anyway (the layer sync
     /// does), and a server that switches to kOnDemand AFTER the factory handed the integrator out (integration/server.patch)
     /// gets overlapping frames without the integrator being rebuilt.  0: never pipeline.
