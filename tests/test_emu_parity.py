@@ -123,6 +123,7 @@ EXACT_CASES = {
     "default": dict(method=0, size=[128, 96], frames=2),                                    # the default: the reference's serial result, event-driven
     "pipelined": dict(method=0, size=[64, 48], frames=4, pipeline=3),                       # frames in flight, commit chain
     "batched": dict(method=0, size=[64, 48], frames=5, pipeline=8),                         # batches of four frames per launch (and one left over)
+    "batched_8": dict(method=0, size=[48, 36], frames=10, pipeline=16),                     # batches of eight (24 slots, 16 tables) and a partial one at the flush
     "clear_every_3": dict(method=0, size=[64, 48], frames=4, cfg=dict(clear_checks_every_n_frames=3)),   # a frame's marks are inputs of the next frame
     "axis_parallel": dict(method=0, size=[96, 72], frames=2, cloud="axis", max_tiles=8192),   # axis-parallel rays: the serial caster inside the rounds
     # long rays, pipelining asked for (such contexts run one frame at a time): whole-ray marks, sweeps along the chains (ks_k_exact.h);
@@ -131,7 +132,7 @@ EXACT_CASES = {
                       cfg=dict(voxel_size=0.02, truncation_distance=0.08, max_ray_length_m=9.0), fallbacks_exactly=0),
 }
 for _name, _spec in EXACT_CASES.items():
-    case_job("test_event_driven_exact_early_out_equals_serial_oracle[%s]" % _name, _spec, weight=60)
+    case_job("test_event_driven_exact_early_out_equals_serial_oracle[%s]" % _name, _spec, weight=110 if _name == "batched_8" else 60)
 
 
 @pytest.mark.parametrize("name", list(EXACT_CASES))
