@@ -51,7 +51,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_UPDATE = 208         # R+W of TsdfVoxel (12 B) + SemanticVoxel (92 B), SURVEY.md §8d
 BYTES_PER_POINT = 17           # xyz 12 B + rgba 4 B + label 1 B
-PRIME = 20                     # untimed frames per context before the warm-up: >= frame slots (12) + pipeline_frames (<= 8)
+PRIME = 20                     # untimed frames per context before the warm-up: >= frame slots (12) + pipeline_frames (8); with KS_BENCH_PIPE=16 (24 slots) the whole untimed turns of the ring before t0 cover the rest
 MIN_REPEATS = 5
 MIN_REPEATS_PRIMARY = 9        # timed regions of the headline: the stretches of the trajectory differ by +-30 % (fix-point rounds), the median of nine moves less between runs than the median of five
 MIN_TIMED_FRAMES = 100

@@ -84,7 +84,7 @@ std::string g_create_error;
 // so that A, B and T of neighbouring frames execute concurrently: B is a chain of small dependent launches
 // (replayed as a graph captured once per slot), the sorts are bound by dependent-launch latency, the voxel
 // update by memory latency, and neither A nor B touches voxel data.  The host's one wait per frame (for the
-// snapshot that sizes T) never idles the GPU.  Twelve slots rotate; stage A of a frame waits for the tail (and
+// snapshot that sizes T) never idles the GPU.  Twelve slots rotate (24 above a lag of 8); stage A of a frame waits for the tail (and
 // the long runs) that last used its slot.
 constexpr int kMaxLag = 16;          // largest ks_config.pipeline_frames
 constexpr int kSlots = kMaxLag + 8;  // frame slots at most; a context uses ks_ctx::n_slots of them: 12 up to a lag of 8 (three batches
