@@ -269,6 +269,11 @@ int ks_get_tile_keys(ks_ctx* ctx, uint64_t* out, size_t cap, size_t* n);
 int ks_export_tiles_device(ks_ctx* ctx, const uint32_t* slots, size_t n, void* d_payload);
 int ks_merge_tiles_device(ks_ctx* ctx, const uint64_t* keys, size_t n, const void* d_payload);
 int ks_clear(ks_ctx* ctx);
+/* Empties the MAP only: frames in flight are completed first, then every tile goes; the integrator's own state — the two
+ * approximate sets of `fast`, their offsets, the clear_checks_every_n_frames counter — stays as the frames so far left it.
+ * This is what voxblox::TsdfServer::clear() does to the reference's integrator (nothing); integration/server.patch calls
+ * it, then uploads the semantic layer that survives clear() in the reference. */
+int ks_clear_voxels(ks_ctx* ctx);
 /* Resets the tiles at the given slots to the empty state (a rank that has handed tiles to their owner keeps
  * them as empty deltas). */
 int ks_reset_tiles(ks_ctx* ctx, const uint32_t* slots, size_t n);
@@ -309,6 +314,9 @@ int ks_early_out_iterations(ks_ctx* ctx, uint64_t* frames, uint64_t* iterations)
  * grow, round limit), out[3] = 1 if the event-driven loop is in use, out[4] = 1 if frames are pipelined (returns KS_OK). */
 int ks_early_out_stats(ks_ctx* ctx, uint64_t out[5]);
 int ks_profile_get(ks_ctx* ctx, ks_profile* out, int reset);
+/* How the context pipelines: out[0] = frames of lag in effect (0: one frame at a time — what ks_create made of
+ * ks_config.pipeline_frames), out[1] = frame slots, out[2] = frames per stage-B batch, out[3] = march streams. */
+int ks_pipeline_shape(ks_ctx* ctx, int32_t out[4]);
 
 #ifdef __cplusplus
 }

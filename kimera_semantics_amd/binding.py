@@ -33,9 +33,9 @@ SEM_DTYPE = np.dtype([("label", "u1"), ("pad", "u1", (3,)), ("priors", "<f4", (N
 ABI_SYMBOLS = [
     "ks_default_config", "ks_create", "ks_destroy", "ks_last_error", "ks_set_color_to_label",
     "ks_integrate_points", "ks_integrate_points_device", "ks_integrate_depth", "ks_integrate_depth_device", "ks_num_blocks", "ks_get_block_indices",
-    "ks_get_updated_block_indices", "ks_count_updated_voxels", "ks_download_updated_voxels", "ks_download_blocks", "ks_upload_blocks", "ks_host_alloc", "ks_host_free", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear", "ks_reset_tiles", "ks_tile_owner", "ks_reduce",
+    "ks_get_updated_block_indices", "ks_count_updated_voxels", "ks_download_updated_voxels", "ks_download_blocks", "ks_upload_blocks", "ks_host_alloc", "ks_host_free", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear", "ks_clear_voxels", "ks_reset_tiles", "ks_tile_owner", "ks_reduce",
     "ks_debug_radix_sort", "ks_synchronize", "ks_flush", "ks_stream",
-    "ks_profile_enable", "ks_profile_get", "ks_early_out_iterations", "ks_early_out_stats",
+    "ks_profile_enable", "ks_profile_get", "ks_early_out_iterations", "ks_early_out_stats", "ks_pipeline_shape",
 ]
 
 
@@ -127,6 +127,7 @@ def lib():
         L.ks_export_tiles_device.argtypes = [vp, vp, C.c_size_t, vp]
         L.ks_merge_tiles_device.argtypes = [vp, vp, C.c_size_t, vp]
         L.ks_clear.argtypes = [vp]
+        L.ks_clear_voxels.argtypes = [vp]
         L.ks_reset_tiles.argtypes = [vp, vp, C.c_size_t]
         L.ks_tile_owner.argtypes = [C.c_uint64, C.c_int]
         L.ks_reduce.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(KsReduceStats)]
@@ -139,6 +140,7 @@ def lib():
         L.ks_profile_get.argtypes = [vp, C.POINTER(KsProfile), C.c_int]
         L.ks_early_out_iterations.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.ks_early_out_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.ks_pipeline_shape.argtypes = [vp, C.POINTER(C.c_int32)]
         _lib = L
     return _lib
 
@@ -331,6 +333,10 @@ class HipIntegrator:
     def clear(self):
         self._chk(lib().ks_clear(self._h))
 
+    def clear_voxels(self):
+        """The map goes, the integrator's sets and counters stay (ks_clear_voxels)."""
+        self._chk(lib().ks_clear_voxels(self._h))
+
     def reset_tiles(self, slots: np.ndarray):
         s = np.ascontiguousarray(slots, dtype=np.uint32)
         self._chk(lib().ks_reset_tiles(self._h, _ptr(s), len(s)))
@@ -366,6 +372,12 @@ class HipIntegrator:
         out = (C.c_uint64 * 5)()
         self._chk(lib().ks_early_out_stats(self._h, out))
         return dict(frames=int(out[0]), rounds=int(out[1]), fallbacks=int(out[2]), event_driven=bool(out[3]), pipelined=bool(out[4]))
+
+    def pipeline_shape(self):
+        """dict(lag, slots, batch, march_streams): what ks_create made of ks_config.pipeline_frames."""
+        out = (C.c_int32 * 4)()
+        self._chk(lib().ks_pipeline_shape(self._h, out))
+        return dict(lag=int(out[0]), slots=int(out[1]), batch=int(out[2]), march_streams=int(out[3]))
 
     def early_out_iterations(self):
         """(frames, fix-point iterations) of a KS_EARLY_OUT_EXACT context."""

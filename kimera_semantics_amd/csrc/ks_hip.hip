@@ -70,6 +70,14 @@ namespace {
 
 std::string g_create_error;
 
+// Every diagnostic / A-B switch of the library sits behind ONE gate: without KS_DEBUG=1 in the environment none of them is
+// read.  None changes a map (equivalent launch strategies, test sizes of buffers, traces); tests and tools that use one
+// set KS_DEBUG=1 beside it.
+const char* dbg_env(const char* name) {
+  const char* g = getenv("KS_DEBUG");   // (read per ks_create: a test process sets and clears it between contexts)
+  return (g && g[0] == '1') ? getenv(name) : nullptr;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -1705,7 +1713,7 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
     c->cfg.pipeline_frames = 0;
   }
   // sorted integration order keeps its permutation in single buffers: not pipelined
-  const bool pipelined = cfg.pipeline_frames && cfg.integration_order_mode != KS_ORDER_SORTED;
+  bool pipelined = cfg.pipeline_frames && cfg.integration_order_mode != KS_ORDER_SORTED;
   if (pipelined && c->eo_device && !c->eo_device_off) {
     // A frame that fell back enters its marks when its tail runs, `pipeline_frames` calls after its stage B — so the frames
     // in flight behind it find their predecessor's marks missing when their finisher runs and follow it to the host-driven
@@ -1755,6 +1763,8 @@ int integrate_device_impl(ks_ctx* c, const float Tq[7], const float* d_xyz, cons
         (void)hipGetLastError();
         c->eo_device_off = true;
         c->cfg.pipeline_frames = 0;
+        c->batch = 1;          // (one frame at a time from here on — this frame included: nothing is in flight after the quiesce above)
+        pipelined = false;
         c->err.clear();
       }
       c->eo_want_x.store(0, std::memory_order_relaxed);   // (what was asked for has been looked at: a clamped request must not come back every frame)
@@ -1968,10 +1978,10 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // 24: 0.541 / 0.461, 22 (23 phases): 0.523 / 0.465, 20: 0.525 / 0.484, 18: 0.558 / 0.544; coarser ones lose more (64: +12 %),
     // and so does a longest phase of 64 / 96 / 128 generations on top of any of them (equal steps at the end: +1 ... +8 %).
     c->cfg.early_out_phase_growth = 22;
-    if (const char* sg = getenv("KS_EXACT_SEED_GROWTH")) c->cfg.early_out_phase_growth = std::min(4096, std::max(16, atoi(sg)));   // tuning runs
+    if (const char* sg = dbg_env("KS_EXACT_SEED_GROWTH")) c->cfg.early_out_phase_growth = std::min(4096, std::max(16, atoi(sg)));   // tuning runs
   }
   {
-    const char* hl = getenv("KS_EXACT_HOST_LOOP");   // diagnostics / A-B: the host-driven fix-point loop of round 3 for every frame
+    const char* hl = dbg_env("KS_EXACT_HOST_LOOP");   // diagnostics / A-B: the host-driven fix-point loop of round 3 for every frame
     c->eo_device = c->exact_early_out && !(hl && hl[0] == '1');
     // The host-driven loop waits for the device per iteration: one frame at a time.  The event-driven fix point is
     // pipelined as long as a frame's marks are never seen by the next one (every frame bumps the set offset): what is left
@@ -1986,17 +1996,17 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // place costs ~0.1 ms: measured on a ring of 40 frames, 8 rounds as launches 0.681 ms/frame, 14 rounds 0.569
     // (profiles/r05_bulk_rounds_ab.txt).  A finisher that is handed too long a list asks for more: eo_want_bulk.)
     c->eo_bulk_rounds = wide_rays ? 32 : 20;
-    if (const char* br = getenv("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
-    if (const char* tr = getenv("KS_EXACT_TRACE")) c->eo_trace = tr[0] == '1';
-    if (const char* sw = getenv("KS_EXACT_SWEEPS")) c->eo_sweeps = std::min(64, std::max(1, atoi(sw)));   // (tuning runs: any value gives the same map)
-    if (const char* so = getenv("KS_EXACT_SWEEP_ORDER")) c->eo_sweep_order = so[0] == '0' ? 0 : 1;
+    if (const char* br = dbg_env("KS_EXACT_BULK_ROUNDS")) c->eo_bulk_rounds = std::min((int)kEoBulkMax, std::max(1, atoi(br)));
+    if (const char* tr = dbg_env("KS_EXACT_TRACE")) c->eo_trace = tr[0] == '1';
+    if (const char* sw = dbg_env("KS_EXACT_SWEEPS")) c->eo_sweeps = std::min(64, std::max(1, atoi(sw)));   // (tuning runs: any value gives the same map)
+    if (const char* so = dbg_env("KS_EXACT_SWEEP_ORDER")) c->eo_sweep_order = so[0] == '0' ? 0 : 1;
   }
   c->uses_early_out = uses_early_out;
   c->use_bundle_rank = cfg->method == KS_METHOD_MERGED && cfg->bundle_order == KS_BUNDLE_ORDER_REFERENCE;
   {
-    const char* hpf = getenv("KS_HOST_PROF");
+    const char* hpf = dbg_env("KS_HOST_PROF");
     c->host_prof = hpf && hpf[0] == '1';
-    const char* ng = getenv("KS_NO_GRAPH");
+    const char* ng = dbg_env("KS_NO_GRAPH");
     c->use_graphs = !(ng && ng[0] == '1');
     c->defer_join = true;
   }
@@ -2022,12 +2032,12 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   // own.  Otherwise stage B stays strictly in frame order.
   const bool frames_independent = !uses_early_out || c->cfg.clear_checks_every_n_frames <= 1;
   c->batch = 1;
-  if (const char* ov = getenv("KS_TEST_OVERLAP")) c->test_overlap = atoi(ov) != 0;   // diagnostics: the same schedule and result, rounds one after the other
+  if (const char* ov = dbg_env("KS_TEST_OVERLAP")) c->test_overlap = atoi(ov) != 0;   // diagnostics: the same schedule and result, rounds one after the other
   if (c->cfg.pipeline_frames >= 2 && frames_independent && (!c->exact_early_out || c->eo_device) && c->cfg.integration_order_mode != KS_ORDER_SORTED) {
     // (measured, 640x480: a batch of 4 behind 8 frames of lag ~ four single-frame sequences on four streams behind 4
     // frames of lag; batches of 2 or 3 lose to both: DESIGN.md)
     c->batch = c->cfg.pipeline_frames >= 16 ? 8 : c->cfg.pipeline_frames >= 8 ? 4 : 1;
-    if (const char* bs = getenv("KS_BATCH")) c->batch = std::min(kBatchMax, std::max(1, atoi(bs)));  // diagnostics
+    if (const char* bs = dbg_env("KS_BATCH")) c->batch = std::min(kBatchMax, std::max(1, atoi(bs)));  // diagnostics
   }
   // slots: the lag plus one batch being filled, a multiple of the batch (a batch then always starts on the same slots: its
   // captured launch sequence is found again)
@@ -2040,7 +2050,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // the four frames of a batch, and two batches alternate over two streams.)
     if (c->exact_early_out && c->n_march > 4) c->n_march = 4;
     if (c->exact_early_out && c->batch > 1) c->n_march = 2;
-    if (const char* ms = getenv("KS_MARCH_STREAMS")) c->n_march = std::min(kMarchStreams, std::max(1, atoi(ms)));  // diagnostics
+    if (const char* ms = dbg_env("KS_MARCH_STREAMS")) c->n_march = std::min(kMarchStreams, std::max(1, atoi(ms)));  // diagnostics
     {
       auto mk = [&](hipStream_t* st, char) { return hipStreamCreateWithFlags(st, hipStreamNonBlocking); };
       // without an early-out stage B is short (scan + emission): it follows stage A on the same stream, and the three
@@ -2063,12 +2073,12 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     // share a hardware queue run one after the other: the heavy chains (stage B, stage T) must not share one.  With
     // the default of four hardware queues — one of which other streams of the process use — stage A and the long
     // runs (the two lightest: ~90 + ~65 us per 640x480 frame) are the pair that shares.
-    const char* nl = getenv("KS_NO_LONG_STREAM");   // diagnostics: long runs on the tail stream, after k_apply
+    const char* nl = dbg_env("KS_NO_LONG_STREAM");   // diagnostics: long runs on the tail stream, after k_apply
     if (nl && nl[0] == '1') c->stream_long = nullptr;
     else CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
     // the runs of more than kXLongRun updates (the voxels next to the sensor) on a stream of their own, four waves per run
     // (k_apply_xlong).  Same arithmetic, same order: the map does not change.  KS_XLONG=0 (diagnostics): one list, k_apply_long.
-    const char* xp = getenv("KS_XLONG");
+    const char* xp = dbg_env("KS_XLONG");
     c->xlong = xp ? atoi(xp) != 0 : true;
     if (c->xlong && c->stream_long) CRCHK(hipStreamCreateWithFlags(&c->stream_xlong, hipStreamNonBlocking));
   }
@@ -2142,15 +2152,15 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   if (c->exact_early_out && c->eo_device && steps_max_of(c->cfg, c->voxel_size_inv) > 400)
     eo_marks0 = std::max<size_t>(eo_marks0, (size_t)cfg->max_points * (steps_max_of(c->cfg, c->voxel_size_inv) / 3 + 32));
   // (tests: start small, so that the overflow -> host-driven loop -> grow path is exercised)
-  if (const char* e = getenv("KS_EXACT_CAP_MARKS")) eo_marks0 = std::max<size_t>(64, (size_t)atoll(e));
-  if (const char* e = getenv("KS_EXACT_CAP_X")) eo_x0 = std::max<size_t>(8, (size_t)atoll(e));
+  if (const char* e = dbg_env("KS_EXACT_CAP_MARKS")) eo_marks0 = std::max<size_t>(64, (size_t)atoll(e));
+  if (const char* e = dbg_env("KS_EXACT_CAP_X")) eo_x0 = std::max<size_t>(8, (size_t)atoll(e));
   if (ensure_points(c, cfg->max_points) != KS_OK || ensure_exact_slots(c, eo_marks0, eo_x0) != KS_OK) {
     g_create_error = c->err;
     ks_destroy(c);
     return KS_ERR_HIP;
   }
   {
-    const char* nt = getenv("KS_NO_TAIL_THREAD");
+    const char* nt = dbg_env("KS_NO_TAIL_THREAD");
     c->use_tail_thread = c->cfg.pipeline_frames > 0 && !(nt && nt[0] == '1');
     if (c->use_tail_thread) c->tail_thread = std::thread(tail_worker, c);
   }
@@ -2863,8 +2873,15 @@ int ks_reduce(ks_ctx* c, void* rccl_comm, int rank, int world, ks_reduce_stats* 
   return KS_OK;
 }
 
-int ks_clear(ks_ctx* c) {
-  if (!c) return KS_ERR_INVALID_ARG;
+// keep_integrator_state: only the MAP goes (tile table, pool flags); the two approximate sets, their offsets, the
+// frame counters and the early-out table stay as the frames so far left them — what vxb::TsdfServer::clear() does to the
+// reference's integrator, which it does not touch.  Frames in flight are completed first (their stage B has already
+// entered its marks); without it a frame that was never applied is dropped with the map.
+static int clear_impl(ks_ctx* c, bool keep_integrator_state) {
+  if (keep_integrator_state) {
+    if (int rc = quiesce(c)) return rc;
+    c->owed = ks_frame_stats{};
+  }
   for (auto& S : c->slot) S.pending = false;  // a frame that was never applied is dropped with the map
   c->batch_slots.clear();
   c->owed = ks_frame_stats{};
@@ -2877,30 +2894,42 @@ int ks_clear(ks_ctx* c) {
   HIPCHK(c, hipMemset(c->pool.updated, 0, c->cfg.max_tiles));
   HIPCHK(c, hipMemset(c->pool.dirty, 0, c->cfg.max_tiles));
   HIPCHK(c, hipMemset(c->d_state, 0, 64 * (kSlots + 1)));
-  // a cleared context behaves like a fresh one: both approximate sets as their constructor leaves them
-  HIPCHK(c, hipMemset(c->d_start_set, 0, sizeof(uint64_t) << kSetBits));
-  for (int t = 0; t < c->n_obs; ++t) {
-    HIPCHK(c, hipMemset(c->d_observed_[t], 0, 2 * (sizeof(uint64_t) << kSetBits)));
-    HIPCHK(c, hipMemcpy(c->d_observed_[t], &kObsPoison, 8, hipMemcpyHostToDevice));
+  if (!keep_integrator_state) {
+    // a cleared context behaves like a fresh one: both approximate sets as their constructor leaves them
+    HIPCHK(c, hipMemset(c->d_start_set, 0, sizeof(uint64_t) << kSetBits));
+    for (int t = 0; t < c->n_obs; ++t) {
+      HIPCHK(c, hipMemset(c->d_observed_[t], 0, 2 * (sizeof(uint64_t) << kSetBits)));
+      HIPCHK(c, hipMemcpy(c->d_observed_[t], &kObsPoison, 8, hipMemcpyHostToDevice));
+    }
+    const uint64_t poison = ~0ull;
+    HIPCHK(c, hipMemcpy(c->d_start_set, &poison, 8, hipMemcpyHostToDevice));
+    if (c->d_eo_plain) {
+      HIPCHK(c, hipMemset(c->d_eo_plain, 0, sizeof(uint64_t) << kSetBits));
+      HIPCHK(c, hipMemcpy(c->d_eo_plain, &poison, 8, hipMemcpyHostToDevice));
+      HIPCHK(c, hipMemset(c->d_eo_committed, 0, 64));
+      c->eo_frame_no = 0;
+      c->eo_last_commit = nullptr;
+    }
+    c->start_offset = c->observed_offset = 0;
+    c->reset_counter = 0;
+    c->obs_tag = 0;
+    c->obs_tag_lo = 1;
   }
-  const uint64_t poison = ~0ull;
-  HIPCHK(c, hipMemcpy(c->d_start_set, &poison, 8, hipMemcpyHostToDevice));
-  if (c->d_eo_plain) {
-    HIPCHK(c, hipMemset(c->d_eo_plain, 0, sizeof(uint64_t) << kSetBits));
-    HIPCHK(c, hipMemcpy(c->d_eo_plain, &poison, 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemset(c->d_eo_committed, 0, 64));
-    c->eo_frame_no = 0;
-    c->eo_last_commit = nullptr;
-  }
-  c->start_offset = c->observed_offset = 0;
-  c->reset_counter = 0;
-  c->obs_tag = 0;
-  c->obs_tag_lo = 1;
   c->tiles_initialised = 0;
   for (auto& S : c->slot)
     if (S.h_snap) std::memset(S.h_snap, 0, sizeof(HostSnap));  // (the pool-growth trigger reads the snapshots' tile counts)
   c->fatal = false;
   return KS_OK;
+}
+
+int ks_clear(ks_ctx* c) {
+  if (!c) return KS_ERR_INVALID_ARG;
+  return clear_impl(c, false);
+}
+
+int ks_clear_voxels(ks_ctx* c) {
+  if (!c) return KS_ERR_INVALID_ARG;
+  return clear_impl(c, true);
 }
 
 int ks_flush(ks_ctx* c, ks_frame_stats* stats) {
@@ -2944,6 +2973,15 @@ int ks_early_out_stats(ks_ctx* c, uint64_t out[5]) {
   out[2] = c->eo_fallbacks.load(std::memory_order_relaxed);
   out[3] = (c->eo_device && !c->eo_device_off) ? 1 : 0;
   out[4] = (c->exact_early_out && c->cfg.pipeline_frames > 0) ? 1 : 0;
+  return KS_OK;
+}
+
+int ks_pipeline_shape(ks_ctx* c, int32_t out[4]) {
+  if (!c || !out) return KS_ERR_INVALID_ARG;
+  out[0] = c->cfg.pipeline_frames;
+  out[1] = c->n_slots;
+  out[2] = c->batch;
+  out[3] = c->n_march;
   return KS_OK;
 }
 

@@ -56,6 +56,7 @@ int main(int argc, char** argv) {
   kimera::HipSemanticTsdfIntegrator::DeviceOptions opt;
   opt.max_tiles = 4096;
   opt.max_points = 1u << 18;
+  if (const char* pf = std::getenv("KS_DEMO_PIPELINE_FRAMES")) opt.pipeline_frames = std::atoi(pf);  // (tests: DeviceOptions::pipeline_frames, 0 .. 16)
   // pipeline != 0: the sequence of a server with integration/server.patch — the factory hands the integrator out with its
   // default options (strict policy), THEN the server selects kOnDemand and syncs where it reads the Layers
   const bool pipeline = argc > 8 && std::atoi(argv[8]) != 0;
@@ -83,6 +84,11 @@ int main(int argc, char** argv) {
       hip->setSyncPolicy(kimera::HipSemanticTsdfIntegrator::SyncPolicy::kOnDemand);
   };
   on_demand();
+  if (auto* hip = dynamic_cast<kimera::HipSemanticTsdfIntegrator*>(integrator.get())) {
+    int32_t shape[4] = {0, 0, 0, 0};
+    ks_pipeline_shape(hip->context(), shape);
+    std::printf("adapter_demo: pipeline shape: lag %d slots %d batch %d march streams %d\n", shape[0], shape[1], shape[2], shape[3]);
+  }
 
   FILE* in = std::fopen(argv[3], "rb");
   if (!in) return 3;
@@ -98,6 +104,18 @@ int main(int argc, char** argv) {
       integrator.reset();
       integrator = make();
       on_demand();
+    }
+    if (const char* ca = std::getenv("KS_DEMO_CLEAR_AFTER")) {
+      if ((int)f == std::atoi(ca)) {
+        // SemanticTsdfServer::clear() with integration/server.patch: sync, the base class removes the TSDF blocks (the
+        // semantic layer and the integrator survive), the GPU map follows
+        auto* hip = dynamic_cast<kimera::HipSemanticTsdfIntegrator*>(integrator.get());
+        if (!hip) return 7;
+        hip->syncLayers();
+        tsdf_layer.removeAllBlocks();   // vxb::TsdfServer::clear()
+        hip->clearDeviceMap(/*keep_integrator_state=*/true);
+        hip->uploadLayers();
+      }
     }
     float T[7];
     uint32_t n;

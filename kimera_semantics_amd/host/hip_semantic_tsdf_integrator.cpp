@@ -71,7 +71,7 @@ ks_config makeConfig(HipSemanticTsdfIntegrator::Method method, const vxb::TsdfIn
   k.clear_checks_every_n_frames = c.clear_checks_every_n_frames;
   if (c.integration_order_mode == "mixed") {
     static const int probed = HipSemanticTsdfIntegrator::probeMixedOrder();
-    if (probed == -1)
+    if (probed == -1 && o.mixed_order < 0)  // (an explicit DeviceOptions::mixed_order is the caller's own answer)
       LOG(FATAL) << "vxb::ThreadSafeIndexFactory::get(\"mixed\", ...) of this build produces neither of the two permutations the "
                     "GPU integrator implements (include/ks_hip.h: KS_ORDER_MIXED, KS_ORDER_MIXED_1024_GROUPS): its results would "
                     "not be the CPU integrators'.";
@@ -98,7 +98,7 @@ ks_config makeConfig(HipSemanticTsdfIntegrator::Method method, const vxb::TsdfIn
   k.device_id = o.device_id;
   k.max_tiles = o.max_tiles;
   k.max_points = o.max_points;
-  k.pipeline_frames = std::min(8, std::max(0, o.pipeline_frames));
+  k.pipeline_frames = std::min(16, std::max(0, o.pipeline_frames));  // 0..16 (kMaxLag): above 8 = batches of eight frames
   return k;
 }
 }  // namespace
@@ -214,7 +214,10 @@ void HipSemanticTsdfIntegrator::integratePointCloud(const vxb::Transformation& T
   }
 }
 
-void HipSemanticTsdfIntegrator::clearDeviceMap() { check(ks_clear(ctx_), "ks_clear"); }
+void HipSemanticTsdfIntegrator::clearDeviceMap(bool keep_integrator_state) {
+  if (keep_integrator_state) check(ks_clear_voxels(ctx_), "ks_clear_voxels");
+  else check(ks_clear(ctx_), "ks_clear");
+}
 
 HipSemanticTsdfIntegrator::Workers::~Workers() {
   {

@@ -90,8 +90,10 @@ class HipSemanticTsdfIntegrator : public vxb::TsdfIntegratorBase, public Semanti
   /// Switch between the strict and the on-demand policy at run time (integration/server.patch: a server that calls
   /// syncLayers() where it reads the Layers selects kOnDemand right after the factory handed the integrator out).
   void setSyncPolicy(SyncPolicy policy) { options_.sync_policy = policy; }
-  /// Empties the GPU map (vxb::TsdfServer::clear() empties the host Layers: integration/server.patch calls both).
-  void clearDeviceMap();
+  /// Empties the GPU map.  keep_integrator_state: only the voxels go, the approximate sets and frame counters of `fast` stay
+  /// (ks_clear_voxels) — vxb::TsdfServer::clear() removes the TSDF blocks and leaves the integrator and the semantic layer
+  /// alone: integration/server.patch syncs, lets the base class clear, empties the GPU map this way and uploads what survived.
+  void clearDeviceMap(bool keep_integrator_state = false);
   SyncPolicy syncPolicy() const { return options_.sync_policy; }
 
   ks_ctx* context() { return ctx_; }

@@ -30,6 +30,7 @@ def lib():
         L.kr_create.argtypes = [C.c_char_p, C.c_float, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p,
                                 C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_char_p, C.c_char_p]
         L.kr_destroy.argtypes = [C.c_void_p]
+        L.kr_clear_tsdf_layer.argtypes = [C.c_void_p]
         L.kr_integrate.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         L.kr_num_blocks.argtypes = [C.c_void_p]
         L.kr_num_blocks.restype = C.c_size_t
@@ -81,6 +82,10 @@ class Reference:
                                   dyn.ctypes.data if len(dyn) else None, len(dyn), threads,
                                   max_consecutive_ray_collisions, order_mode.encode(), label_csv.encode(),
                                   ";".join(f"{k}={float(v)}" for k, v in extra.items()).encode())
+
+    def clear_tsdf_layer(self):
+        """vxb::TsdfServer::clear(): the TSDF blocks go, the semantic layer and the integrator stay."""
+        lib().kr_clear_tsdf_layer(self._h)
 
     def close(self):
         if self._h:

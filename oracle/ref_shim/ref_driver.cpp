@@ -21,6 +21,26 @@ struct kr_ctx {
   bool merged;
 };
 
+namespace {
+// FastSemanticTsdfIntegrator::integratePointCloud counts frames in a FUNCTION-STATIC `reset_counter`
+// ([K:src/semantic_tsdf_integrator_fast.cpp:165-170]): it outlives every integrator of the process, so what a kr_ctx with
+// clear_checks_every_n_frames > 1 computes would depend on how many frames earlier contexts of the same process integrated
+// (k mod n of them are still on the counter).  A checker must not depend on the order its tests run in: before a context is
+// handed out, ONE empty frame through a throw-away `fast` integrator with clear_checks_every_n_frames = 1 takes the branch
+// `++reset_counter >= 1` and leaves the counter at 0 — the state of a fresh process.
+void realign_static_reset_counter(const std::shared_ptr<kimera::SemanticLabel2Color>& label_to_color) {
+  vxb::Layer<vxb::TsdfVoxel> tsdf_layer(0.1f, 8);
+  vxb::Layer<kimera::SemanticVoxel> semantic_layer(0.1f, 8);
+  vxb::TsdfIntegratorBase::Config cfg;
+  cfg.integrator_threads = 1;
+  cfg.clear_checks_every_n_frames = 1;
+  kimera::SemanticIntegratorBase::SemanticConfig sc;
+  sc.semantic_label_to_color_ = label_to_color;
+  auto scratch = kimera::SemanticTsdfIntegratorFactory::create(std::string("fast"), cfg, sc, &tsdf_layer, &semantic_layer);
+  scratch->integratePointCloud(vxb::Transformation(), vxb::Pointcloud(), vxb::Colors(), false);
+}
+}  // namespace
+
 extern "C" {
 
 // label_csv: path of a "name,red,green,blue,alpha,id" file (SemanticLabel2Color input)
@@ -70,12 +90,16 @@ kr_ctx* kr_create(const char* method, float voxel_size, int vps, float truncatio
   sc.color_mode = static_cast<kimera::ColorMode>(color_mode);
   sc.semantic_label_to_color_ = std::make_shared<kimera::SemanticLabel2Color>(std::string(label_csv));
   for (int i = 0; i < n_dynamic; ++i) sc.dynamic_labels_.push_back(dynamic_labels[i]);
+  realign_static_reset_counter(sc.semantic_label_to_color_);
   c->integrator = kimera::SemanticTsdfIntegratorFactory::create(std::string(method), cfg, sc, c->tsdf_layer.get(),
                                                                 c->semantic_layer.get());
   return c;
 }
 
 void kr_destroy(kr_ctx* c) { delete c; }
+// What vxb::TsdfServer::clear() does to the map the integrator writes: the TSDF blocks go, the semantic layer and the
+// integrator stay (tests of integration/server.patch's clear()).
+void kr_clear_tsdf_layer(kr_ctx* c) { c->tsdf_layer->removeAllBlocks(); }
 
 // Which permutation the shim's MixedThreadSafeIndex produces (0 = upstream as published, 1 = 1024 groups; see
 // voxblox/integrator/integrator_utils.h).  Process-wide; read when an index is constructed, i.e. per frame.

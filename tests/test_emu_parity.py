@@ -30,7 +30,9 @@ def case_job(node, spec, env_extra=None, timeout=900, weight=10):
 class _Jobs:
     def __init__(self, lib, nodes):
         self.lib, self.lock, self.children = lib, threading.Lock(), set()
-        self.pool = ThreadPoolExecutor(max_workers=max(1, min(os.cpu_count() or 1, 16)))
+        # one child per core — of THIS worker's share of them when pytest-xdist runs several workers side by side
+        share = max(1, int(os.environ.get("PYTEST_XDIST_WORKER_COUNT", "1")))
+        self.pool = ThreadPoolExecutor(max_workers=max(1, min((os.cpu_count() or 1) // share, 16)))
         self.futures = {n: self.pool.submit(self._run, *JOBS[n][:3]) for n in nodes}
 
     def _run(self, argv, env_extra, timeout):
@@ -142,7 +144,7 @@ def test_event_driven_exact_early_out_equals_serial_oracle(emu_jobs, request, na
 
 case_job("test_overflow_falls_back_to_the_host_loop_and_the_device_loop_takes_over_again",
          dict(method=0, size=[40, 30], frames=6, pipeline=2, fallbacks_below=5),
-         env_extra={"KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "16384"}, weight=65)
+         env_extra={"KS_DEBUG": "1", "KS_EXACT_CAP_MARKS": "8000", "KS_EXACT_CAP_X": "16384"}, weight=65)
 
 
 def test_overflow_falls_back_to_the_host_loop_and_the_device_loop_takes_over_again(emu_jobs, request):
@@ -155,7 +157,7 @@ def test_overflow_falls_back_to_the_host_loop_and_the_device_loop_takes_over_aga
 for _overlap in ("1", "0"):
     case_job("test_axis_parallel_rays_under_the_early_out_equal_oracle[%s]" % _overlap,
              dict(method=0, size=[96, 72] if _overlap == "1" else [64, 48], frames=1, max_tiles=8192, cloud="axis",
-                  cfg=dict(early_out_phase_growth=32)), env_extra={"KS_TEST_OVERLAP": _overlap}, weight=15)
+                  cfg=dict(early_out_phase_growth=32)), env_extra={"KS_DEBUG": "1", "KS_TEST_OVERLAP": _overlap}, weight=15)
 
 
 @pytest.mark.parametrize("overlap", ["1", "0"])

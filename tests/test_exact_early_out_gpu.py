@@ -191,6 +191,7 @@ def test_exact_early_out_zero_hash_slot_artefact_pipelined():
 def test_exact_early_out_falls_back_to_the_host_loop_and_grows(monkeypatch, pipe):
     """marks / X marks that do not fit: the frame (and the frames in flight behind it) repeat their fix point through
     the host-driven loop, the buffers grow, later frames run on the device again — same map."""
+    monkeypatch.setenv("KS_DEBUG", "1")   # the one gate in front of the library's diagnostic switches
     monkeypatch.setenv("KS_EXACT_CAP_MARKS", "30000")
     monkeypatch.setenv("KS_EXACT_CAP_X", "16")
     okw = dict(COMMON, method=0)
@@ -204,6 +205,7 @@ def test_exact_early_out_falls_back_to_the_host_loop_and_grows(monkeypatch, pipe
 
 
 def test_exact_early_out_host_loop_switch(monkeypatch):
+    monkeypatch.setenv("KS_DEBUG", "1")
     monkeypatch.setenv("KS_EXACT_HOST_LOOP", "1")
     okw = dict(COMMON, method=0)
     o = O.Oracle(O.default_config(**okw))
@@ -268,3 +270,38 @@ def test_three_full_size_c4_frames_on_the_device_vs_real_reference(tmp_path):
     assert np.array_equal(rt["distance"].view(np.uint32), ht["distance"].view(np.uint32))
     assert np.array_equal(rt["weight"].view(np.uint32), ht["weight"].view(np.uint32))
     assert np.array_equal(rt["color"], ht["color"]) and np.array_equal(rs["color"], hs["color"])
+
+
+@pytest.mark.parametrize("pipe", [8, 16])
+def test_full_reset_of_the_sets_after_10000_frames_pipelined_with_a_fallback_beside_it(monkeypatch, pipe):
+    """ApproxHashSet::resetApproxSet clears the whole table every 10 000 offsets ([K:include/kimera_semantics/
+    semantic_tsdf_integrator_fast.h:107]; kFullResetThreshold): with clear_checks_every_n_frames = 1 that is frame 10 000.  A
+    pipelined default-mode stream of 10 050 small frames crosses it with frames in flight — reset_set completes the pending tails
+    first — and FOUR much larger frames sit right at the crossing: their marks do not fit buffers sized (KS_EXACT_CAP_*) for the
+    small ones, so a fallback to the host-driven loop, the growth of the buffers and the drain of the pipeline coincide with the
+    full reset.  Every frame's counts and the final map equal the serial oracle's, bit for bit."""
+    monkeypatch.setenv("KS_DEBUG", "1")
+    monkeypatch.setenv("KS_EXACT_CAP_MARKS", "120000")
+    monkeypatch.setenv("KS_EXACT_CAP_X", "4096")
+    okw = dict(COMMON, method=0)
+    o = O.Oracle(O.default_config(integrator_threads=1, **okw))
+    h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 14, pipeline_frames=pipe, **okw))
+    monkeypatch.delenv("KS_EXACT_CAP_MARKS")
+    monkeypatch.delenv("KS_EXACT_CAP_X")
+    assert h.pipeline_shape()["lag"] == pipe and h.pipeline_shape()["batch"] == (8 if pipe == 16 else 4)
+    sc = synth.make_scene("room")
+    small = [synth.render_frame(sc, synth.trajectory_pose(k), 48, 36, seed=k) for k in range(8)]
+    big = [synth.render_frame(sc, synth.trajectory_pose(2 * k), 128, 96, seed=500 + k) for k in range(4)]
+    n_frames, first_big = 10050, 9998   # the table is cleared when the 10 000th offset is reached
+    fallbacks_before = None
+    for k in range(n_frames):
+        f = big[k - first_big] if first_big <= k < first_big + 4 else small[k % 8]
+        if k == first_big:
+            fallbacks_before = h.early_out_stats()["fallbacks"]
+        o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    st_h = h.flush()
+    st = h.early_out_stats()
+    assert st["frames"] == n_frames and st["pipelined"], st
+    assert st["fallbacks"] > fallbacks_before, (st, fallbacks_before)   # the large frames did overflow, at the crossing
+    compare_maps(o, h, exact=True)

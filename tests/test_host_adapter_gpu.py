@@ -125,6 +125,66 @@ def test_adapter_resumes_from_host_layers(tmp_path, method):
     assert np.array_equal(s["color"], os_["color"])
 
 
+@pytest.mark.skipif(not R.available(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("pipeline", ["0", "1"])
+def test_patched_server_clear_matches_the_reference_clear(tmp_path, pipeline):
+    """vxb::TsdfServer::clear() removes the TSDF blocks; the semantic layer and the integrator (approximate sets, frame
+    counter) survive it, and later frames go on adding to the old class sums.  integration/server.patch's clear() — sync,
+    base-class clear, ks_clear_voxels, upload of what survived — leaves the GPU map in exactly that state: the REAL
+    reference sources with the same clear after frame 2 produce the same layers, bit for bit (default `fast`, early-out on:
+    the sets' offsets matter)."""
+    sc = synth.make_scene("room")
+    frames = [synth.render_frame(sc, synth.trajectory_pose(4 * k), 128, 96, seed=400 + k) for k in range(5)]
+    csv, fin, fout = str(tmp_path / "labels.csv"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    R.write_label_csv(csv, synth.default_label_colors())
+    _write_in(fin, frames)
+    res = subprocess.run([DEMO, "fast", csv, fin, fout, "1", "2", "-1", pipeline], capture_output=True, text=True,
+                         env=dict(os.environ, KS_DEMO_CLEAR_AFTER="2"))
+    assert res.returncode == 0, res.stdout + res.stderr
+    idx, t, s = _read_out(fout)
+    r = R.Reference("fast", csv, max_consecutive_ray_collisions=2, color_mode=1)
+    for k, f in enumerate(frames):
+        if k == 2:
+            r.clear_tsdf_layer()
+        r.integrate(f.T_G_C, f.xyz, f.rgba)
+    ri = r.block_indices()
+    assert r.n_semantic_blocks() > len(ri) > 0     # the semantic layer kept blocks the TSDF layer lost
+    order = np.lexsort((ri[:, 2], ri[:, 1], ri[:, 0]))
+    ri = ri[order]
+    assert np.array_equal(idx, ri)
+    _, rt, rs = r.download(ri)
+    assert np.array_equal(s["label"], rs["label"])
+    assert np.array_equal(s["priors"].view(np.uint32), rs["priors"].view(np.uint32))
+    assert np.array_equal(t["distance"].view(np.uint32), rt["distance"].view(np.uint32))
+    assert np.array_equal(t["weight"].view(np.uint32), rt["weight"].view(np.uint32))
+    assert np.array_equal(t["color"], rt["color"])
+    assert np.array_equal(s["color"], rs["color"])
+
+
+def test_adapter_device_options_pipeline_frames_16_reaches_the_library(tmp_path):
+    """DeviceOptions::pipeline_frames = 16 (batches of EIGHT frames, 24 slots) is what the context gets — the adapter used to
+    clamp it to 8 — and the reference's default `fast` configuration (early-out on) through it is the serial result."""
+    sc = synth.make_scene("room")
+    frames = [synth.render_frame(sc, synth.trajectory_pose(3 * k), 128, 96, seed=300 + k) for k in range(19)]   # two batches of 8 and a partial one
+    csv, fin, fout = str(tmp_path / "labels.csv"), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    R.write_label_csv(csv, synth.default_label_colors())
+    _write_in(fin, frames)
+    res = subprocess.run([DEMO, "fast", csv, fin, fout, "1", "2", "-1", "1"], capture_output=True, text=True,
+                         env=dict(os.environ, KS_DEMO_PIPELINE_FRAMES="16"))
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "pipeline shape: lag 16 slots 24 batch 8" in res.stdout, res.stdout
+    idx, t, s = _read_out(fout)
+    o = O.Oracle(O.default_config(**dict(COMMON, method=0, color_mode=1, integrator_threads=1)))
+    for f in frames:
+        o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    oi, ot, os_ = o.download()
+    assert np.array_equal(idx, oi)
+    assert np.array_equal(s["label"], os_["label"])
+    assert np.array_equal(s["priors"].view(np.uint32), os_["priors"].view(np.uint32))
+    assert np.array_equal(t["distance"].view(np.uint32), ot["distance"].view(np.uint32))
+    assert np.array_equal(t["weight"].view(np.uint32), ot["weight"].view(np.uint32))
+
+
 @pytest.mark.parametrize("method", ["fast", "merged"])
 def test_adapter_pipelined_on_demand_sync(tmp_path, method):
     """DeviceOptions::pipeline_frames + SyncPolicy::kOnDemand: frames overlap on the GPU, one

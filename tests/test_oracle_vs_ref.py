@@ -173,3 +173,24 @@ def test_random_knob_combinations_match_reference(tmp_path, seed, method):
         o.integrate(f.T_G_C, f.xyz, f.rgba if method == "fast" else None, f.labels, freespace=fs)
         r.integrate(f.T_G_C, f.xyz, f.rgba, freespace=fs)
     assert _same(o, r) > 100, v
+
+
+@pytest.mark.parametrize("left_over", [1, 2])
+def test_reference_contexts_do_not_inherit_the_static_reset_counter(tmp_path, left_over):
+    """[K:src/semantic_tsdf_integrator_fast.cpp:165] counts frames in a function-static: a context with
+    clear_checks_every_n_frames = 3 that integrated 1 or 2 frames leaves them on the counter for every later integrator of the
+    process.  The checker (oracle/ref_shim/ref_driver.cpp: kr_create) realigns the counter, so what a Reference computes
+    does not depend on which tests ran before it in the same (xdist worker) process."""
+    csv = _csv(tmp_path)
+    sc = synth.make_scene("room")
+    frames = [synth.render_frame(sc, synth.trajectory_pose(7 * k), 80, 60, seed=60 + k) for k in range(4)]
+    polluter = R.Reference("fast", csv, clear_checks_every_n_frames=3)
+    for f in frames[:left_over]:
+        polluter.integrate(f.T_G_C, f.xyz, f.rgba)
+    polluter.close()
+    o = O.Oracle(O.default_config(**dict(COMMON, method=0, clear_checks_every_n_frames=3)))
+    r = R.Reference("fast", csv, clear_checks_every_n_frames=3)
+    for f in frames:
+        o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        r.integrate(f.T_G_C, f.xyz, f.rgba)
+    assert _same(o, r) > 300

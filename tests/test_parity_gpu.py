@@ -74,6 +74,7 @@ def test_fast_early_out_rounds_one_after_the_other_exact(monkeypatch):
     sc = synth.make_scene("hall")
     frames = [synth.render_frame(sc, synth.trajectory_pose(3 * k), 320, 180, hfov_deg=75.0, seed=70 + k) for k in range(2)]
     for overlap in ("0", "1"):
+        monkeypatch.setenv("KS_DEBUG", "1")
         monkeypatch.setenv("KS_TEST_OVERLAP", overlap)
         okw = dict(COMMON, method=0, early_out_phase_growth=32, **geom)
         o = O.Oracle(O.default_config(**okw))
@@ -240,6 +241,7 @@ def test_runs_next_to_the_sensor_on_their_own_list_exact(monkeypatch, method, co
     and walked by k_apply_xlong — four waves per run: two prepare the batches alternately, one walks the TSDF recurrences, one
     the class sums — on a stream of its own (KS_XLONG=0: one list, k_apply_long).  Same arithmetic in the same order: the map
     is the oracle's bit for bit, over frames that share voxels."""
+    monkeypatch.setenv("KS_DEBUG", "1")
     monkeypatch.setenv("KS_XLONG", xlong)
     sc = synth.make_scene("room")
     okw = dict(COMMON, method=method, max_consecutive_ray_collisions=NO_EARLY_OUT, color_mode=color_mode)

@@ -13,8 +13,17 @@ FLAGS="-std=c++17 -O1 -fPIC -ffp-contract=off -Wno-unused-value -Wno-unknown-att
 #   LD_PRELOAD=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so) ASAN_OPTIONS=detect_leaks=0
 if [ -n "$EMU_SAN" ]; then FLAGS="$FLAGS -g -fsanitize=$EMU_SAN -shared-libsan -fno-omit-frame-pointer"; fi
 cd "$R/kimera_semantics_amd/csrc"
+# One build at a time per output (pytest-xdist workers all ask for it), nothing to do when the library is newer than every
+# source it is made of, and the output appears ATOMICALLY (a reader never maps a half-written file).
+exec 9>"$OUT.lock"
+flock 9
+if [ -z "$EMU_SAN" ] && [ -f "$OUT" ] && [ -z "$(find "$R/kimera_semantics_amd/csrc" "$R/tools/emu" "$R/include" -maxdepth 2 -newer "$OUT" \( -name '*.h' -o -name '*.hip' -o -name '*.cpp' -o -name '*.sh' \) -print -quit)" ]; then
+  echo "up to date: $OUT"
+  exit 0
+fi
 $CXX -x c++ $FLAGS -c -o /tmp/ks_hip_emu.$$.o ks_hip.hip
 $CXX $FLAGS -c -o /tmp/ks_emu_lds.$$.o "$R/tools/emu/emu_lds.cpp"
-$CXX -shared ${EMU_SAN:+-fsanitize=$EMU_SAN -shared-libsan} -o "$OUT" /tmp/ks_hip_emu.$$.o /tmp/ks_emu_lds.$$.o -lpthread -ldl
+$CXX -shared ${EMU_SAN:+-fsanitize=$EMU_SAN -shared-libsan} -o "$OUT.$$.tmp" /tmp/ks_hip_emu.$$.o /tmp/ks_emu_lds.$$.o -lpthread -ldl
+mv -f "$OUT.$$.tmp" "$OUT"
 rm -f /tmp/ks_hip_emu.$$.o /tmp/ks_emu_lds.$$.o
 echo "built $OUT"

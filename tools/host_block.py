@@ -7,6 +7,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("KS_DEBUG", "1")
 os.environ.setdefault("KS_HOST_PROF", "1")
 
 

@@ -33,6 +33,7 @@ def main():
     for name, wl, n_frames, K, tiles in plans:
         ring = bench.FrameRing(bench.make_frames(wl, range(n_frames)), torch, dev)
         for pf in args.variants.split(","):
+            os.environ["KS_DEBUG"] = "1"
             os.environ["KS_XLONG"] = pf
             m = bench.measure(B, torch, None, dev, wl, ring, 2, K, args.repeats, 8, tiles, 1, prime=8 if name != "C3" else None)
             ms = sorted(r["dt"] / K * 1e3 for r in m["regions"])
