@@ -314,6 +314,11 @@ int ks_early_out_iterations(ks_ctx* ctx, uint64_t* frames, uint64_t* iterations)
  * grow, round limit), out[3] = 1 if the event-driven loop is in use, out[4] = 1 if frames are pipelined (returns KS_OK). */
 int ks_early_out_stats(ks_ctx* ctx, uint64_t out[5]);
 int ks_profile_get(ks_ctx* ctx, ks_profile* out, int reset);
+/* The voxel update's handling of the runs of more than 1024 updates (the voxels next to the sensor) since the context was
+ * created: out[0] = runs whose class sums went through the integer-sum path (csrc/ks_k_apply_xl.h), out[1] = runs the serial
+ * kernel took, out[2] = 64-update chunks on the first path, out[3] = of them, replayed update by update.  Completes the frames
+ * in flight first. */
+int ks_update_stats(ks_ctx* ctx, uint64_t out[4]);
 /* How the context pipelines: out[0] = frames of lag in effect (0: one frame at a time — what ks_create made of
  * ks_config.pipeline_frames), out[1] = frame slots, out[2] = frames per stage-B batch, out[3] = march streams. */
 int ks_pipeline_shape(ks_ctx* ctx, int32_t out[4]);

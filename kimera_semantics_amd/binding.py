@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "ks_integrate_points", "ks_integrate_points_device", "ks_integrate_depth", "ks_integrate_depth_device", "ks_num_blocks", "ks_get_block_indices",
     "ks_get_updated_block_indices", "ks_count_updated_voxels", "ks_download_updated_voxels", "ks_download_blocks", "ks_upload_blocks", "ks_host_alloc", "ks_host_free", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear", "ks_clear_voxels", "ks_reset_tiles", "ks_tile_owner", "ks_reduce",
     "ks_debug_radix_sort", "ks_synchronize", "ks_flush", "ks_stream",
-    "ks_profile_enable", "ks_profile_get", "ks_early_out_iterations", "ks_early_out_stats", "ks_pipeline_shape",
+    "ks_profile_enable", "ks_profile_get", "ks_early_out_iterations", "ks_early_out_stats", "ks_pipeline_shape", "ks_update_stats",
 ]
 
 
@@ -141,6 +141,7 @@ def lib():
         L.ks_early_out_iterations.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.ks_early_out_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.ks_pipeline_shape.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.ks_update_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
         _lib = L
     return _lib
 
@@ -372,6 +373,12 @@ class HipIntegrator:
         out = (C.c_uint64 * 5)()
         self._chk(lib().ks_early_out_stats(self._h, out))
         return dict(frames=int(out[0]), rounds=int(out[1]), fallbacks=int(out[2]), event_driven=bool(out[3]), pipelined=bool(out[4]))
+
+    def update_stats(self):
+        """Runs of more than 1024 updates: dict(walked, serial, chunks, replayed) — ks_update_stats."""
+        out = (C.c_uint64 * 4)()
+        self._chk(lib().ks_update_stats(self._h, out))
+        return dict(walked=int(out[0]), serial=int(out[1]), chunks=int(out[2]), replayed=int(out[3]))
 
     def pipeline_shape(self):
         """dict(lag, slots, batch, march_streams): what ks_create made of ks_config.pipeline_frames."""

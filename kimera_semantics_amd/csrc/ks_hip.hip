@@ -62,6 +62,7 @@ using namespace ksd;
 #include "ks_k_march.h"
 #include "ks_k_exact.h"
 #include "ks_k_apply.h"
+#include "ks_k_apply_xl.h"
 #include "ks_k_io.h"
 
 using namespace ksk;
@@ -321,6 +322,16 @@ struct ks_ctx {
   size_t cap_img_depth = 0, cap_img_aux = 0;
 
   int profiling = 0;  // 0 off, 1 all stages + every k_apply, 2 every 4th k_apply only
+  // the voxel update of the short runs: k_apply_runs (a lane per run, runs bucketed by length: ks_k_apply.h) from this many
+  // pairs per frame on, k_apply (eight lanes per voxel) below — the same records either way
+  unsigned long long apply_runs_min_pairs = 1ull << 20;
+  // the runs of more than kXLongRun updates through integer sums per chunk (ks_k_apply_xl.h); one set of buffers: all of it
+  // runs in order on stream_xlong
+  bool xl_parallel = true;
+  XlRun* d_xl_runs = nullptr;
+  XlHeader* d_xl_hdr = nullptr;
+  XlChunk* d_xl_chunks = nullptr;
+  uint32_t cap_xl_chunks = 1u << 15;   // 2 M updates in such runs per frame (more: the serial kernel takes the rest)
   ks_profile prof{};
   ProfSet pset[kProfSets];
   bool fatal = false;
@@ -1476,6 +1487,8 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     if ((rc = sort_keys(c, S.d_pairs, d_pairs2, n_pairs, std::min(56u, end_bit), &sp, F.seq_bits, /*tail=*/true))) return rc;
     stage_mark(c, set, 8);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
+    const uint32_t rb = (uint32_t)((n_pairs + kRunTile - 1) / kRunTile);
+    const bool by_runs = n_pairs >= c->apply_runs_min_pairs;
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
     const bool time_apply = set >= 0 && c->pset[set].apply;
     if (time_apply) c->pset[set].applied = true;
@@ -1497,7 +1510,13 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
       if (sx) HIPCHK(c, hipStreamWaitEvent(sx, S.fork, 0));
     }
 #define KS_LAUNCH_APPLY_M(MODE, MERGED)                                                                              \
-  if (time_apply)                                                                                                    \
+  if (by_runs && time_apply)                                                                                         \
+    hipExtLaunchKernelGGL((k_apply_runs<MODE, MERGED>), dim3(rb), dim3(kRunThreads), 0, st, c->pset[set].k0, c->pset[set].k1, \
+                          0, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut);                \
+  else if (by_runs)                                                                                                  \
+    hipLaunchKernelGGL((k_apply_runs<MODE, MERGED>), dim3(rb), dim3(kRunThreads), 0, st, F, n_pairs, sp, S.d_rays,            \
+                       S.d_deltas, c->table, c->pool, c->d_label_lut);                                                \
+  else if (time_apply)                                                                                               \
     hipExtLaunchKernelGGL((k_apply<MODE, MERGED>), dim3(ab), dim3(256), 0, st, c->pset[set].k0, c->pset[set].k1, 0,   \
                           F, n_pairs, sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut, d_long_list,       \
                           S.d_counters);                                                                              \
@@ -1511,9 +1530,21 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     KS_LAUNCH_APPLY_M(MODE, false);                                                                                  \
   }                                                                                                                  \
   stage_mark(c, set, 9);                                                                                             \
-  if (sx)                                                                                                            \
+  if (sx && c->xl_parallel) {                                                                                        \
+    /* the class sums of such runs as integer sums per chunk, chunks side by side (ks_k_apply_xl.h); what the shortcut   \
+       cannot carry stays on the list for k_apply_xlong */                                                              \
+    hipLaunchKernelGGL(k_xl_plan<MODE>, dim3(1), dim3(256), 0, sx, F, n_pairs, (const uint64_t*)sp, c->pool,           \
+                       d_xlong_list, (const Counters*)S.d_counters, c->d_xl_runs, c->d_xl_hdr, c->cap_xl_chunks);      \
+    hipLaunchKernelGGL(k_xl_chunks, dim3(512), dim3(256), 0, sx, F, (const uint64_t*)sp, (const RayDesc*)S.d_rays,     \
+                       (const float*)S.d_deltas, c->table, c->d_xl_runs, (const XlHeader*)c->d_xl_hdr, c->d_xl_chunks); \
+    hipLaunchKernelGGL(k_xl_walk<MODE>, dim3(kXlMaxRuns), dim3(64), 0, sx, F, (const uint64_t*)sp,                     \
+                       (const RayDesc*)S.d_rays, (const float*)S.d_deltas, c->pool, (const uint32_t*)c->d_label_lut,   \
+                       c->d_xl_runs, c->d_xl_hdr, (const XlChunk*)c->d_xl_chunks, d_xlong_list);                       \
+    hipLaunchKernelGGL(k_apply_xlong<MODE>, dim3(xb), dim3(256), 0, sx, F, n_pairs, sp, S.d_rays, S.d_deltas,          \
+                       c->table, c->pool, c->d_label_lut, d_xlong_list, (const uint32_t*)&c->d_xl_hdr->n_fallback);    \
+  } else if (sx)                                                                                                     \
     hipLaunchKernelGGL(k_apply_xlong<MODE>, dim3(xb), dim3(256), 0, sx, F, n_pairs, sp, S.d_rays, S.d_deltas,            \
-                       c->table, c->pool, c->d_label_lut, d_xlong_list, S.d_counters);                                 \
+                       c->table, c->pool, c->d_label_lut, d_xlong_list, (const uint32_t*)&S.d_counters->n_xlong);      \
   hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(128), 0, sl, F, n_pairs, sp, S.d_rays, S.d_deltas,               \
                      c->table, c->pool, c->d_label_lut, d_long_list, S.d_counters)
     switch (c->cfg.color_mode) {
@@ -2078,9 +2109,17 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     else CRCHK(hipStreamCreateWithFlags(&c->stream_long, hipStreamNonBlocking));
     // the runs of more than kXLongRun updates (the voxels next to the sensor) on a stream of their own, four waves per run
     // (k_apply_xlong).  Same arithmetic, same order: the map does not change.  KS_XLONG=0 (diagnostics): one list, k_apply_long.
+    if (const char* ar = dbg_env("KS_APPLY_RUNS")) c->apply_runs_min_pairs = atoi(ar) ? 0ull : ~0ull;   // tests / A-B: always / never
     const char* xp = dbg_env("KS_XLONG");
     c->xlong = xp ? atoi(xp) != 0 : true;
     if (c->xlong && c->stream_long) CRCHK(hipStreamCreateWithFlags(&c->stream_xlong, hipStreamNonBlocking));
+    if (const char* xl = dbg_env("KS_XL_PARALLEL")) c->xl_parallel = atoi(xl) != 0;   // A/B: 0 = every such run through k_apply_xlong
+    if (c->stream_xlong && c->xl_parallel) {
+      CRCHK(hipMalloc((void**)&c->d_xl_runs, kXlMaxRuns * sizeof(XlRun)));
+      CRCHK(hipMalloc((void**)&c->d_xl_hdr, sizeof(XlHeader)));
+      CRCHK(hipMemset(c->d_xl_hdr, 0, sizeof(XlHeader)));
+      CRCHK(hipMalloc((void**)&c->d_xl_chunks, (size_t)c->cap_xl_chunks * sizeof(XlChunk)));
+    }
   }
   for (auto& P : c->pset) {
     for (auto& e : P.ev) CRCHK(hipEventCreate(&e));
@@ -2193,7 +2232,7 @@ void ks_destroy(ks_ctx* c) {
                   c->d_pairs2_[0], c->d_pairs2_[1], c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux, c->d_bo_slab,
                   c->d_eo_keys[0], c->d_eo_keys[1], c->d_eo_vals[0], c->d_eo_vals[1], c->d_eo_range, c->d_eo_plain, c->d_eo_lp, c->d_eo_bt,
-                  c->d_eo_state, c->d_rx_counts, c->d_tx_keys, c->d_rx_keys, c->d_tx_slots, c->d_tx_payload, c->d_rx_payload};
+                  c->d_eo_state, c->d_xl_runs, c->d_xl_hdr, c->d_xl_chunks, c->d_rx_counts, c->d_tx_keys, c->d_rx_keys, c->d_tx_slots, c->d_tx_payload, c->d_rx_payload};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& S : c->slot) {
@@ -2973,6 +3012,21 @@ int ks_early_out_stats(ks_ctx* c, uint64_t out[5]) {
   out[2] = c->eo_fallbacks.load(std::memory_order_relaxed);
   out[3] = (c->eo_device && !c->eo_device_off) ? 1 : 0;
   out[4] = (c->exact_early_out && c->cfg.pipeline_frames > 0) ? 1 : 0;
+  return KS_OK;
+}
+
+int ks_update_stats(ks_ctx* c, uint64_t out[4]) {
+  if (!c || !out) return KS_ERR_INVALID_ARG;
+  out[0] = out[1] = out[2] = out[3] = 0;
+  if (!c->d_xl_hdr) return KS_OK;
+  if (int rc = quiesce(c)) return rc;
+  if (c->stream_xlong) HIPCHK(c, hipStreamSynchronize(c->stream_xlong));
+  XlHeader h;
+  HIPCHK(c, hipMemcpy(&h, c->d_xl_hdr, sizeof(h), hipMemcpyDeviceToHost));
+  out[0] = h.tot_walked;
+  out[1] = h.tot_fallback;
+  out[2] = h.tot_chunks;
+  out[3] = h.tot_replayed;
   return KS_OK;
 }
 

@@ -276,6 +276,281 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_apply_runs — the same update as k_apply, ONE LANE PER VOXEL RUN, runs bucketed by length inside a tile of pairs.
+//
+// Why (round 6, profiles/r06_sq_c4_merged.txt): k_apply is bound by instruction issue, not by HBM.  Eight lanes share a voxel
+// and all eight groups of a wavefront step in lockstep to the LONGEST of their runs, 8 heads at a time: ~20 wave
+// instructions per update at 1280x720 / 2 cm, of which the arithmetic itself is ~1.5.  Here a lane owns a whole voxel record
+// (dist, weight, colour, 21 class sums in registers) and walks its own run; the runs of a tile of 2048 consecutive pairs are
+// counting-sorted by length in LDS first, so the 64 lanes of a wavefront walk runs of (nearly) the same length and the
+// lockstep costs little.  The state-independent half of every update of the tile (ray gather, computeDistance, weight
+// drop-off) is evaluated lane-per-pair, coalesced, all gathers in flight at once, and parked in LDS — the step loop itself
+// touches no global memory.
+//   phase A   lane per pair of the tile (+ a halo of 32: a run of <= 32 updates that starts in the tile ends there):
+//             operands -> LDS (structure of arrays), run boundaries -> a bit per pair
+//   listing   lane per pair: a head finds its run's length in the bit mask (distance to the next set bit); runs of more
+//             than 32 updates are k_apply_long's / k_apply_xlong's (listed by k_find_long, on their own streams);
+//             counting sort by length, longest first
+//   tasks     a wavefront takes 64 runs at a time (dynamic, longest first): records in (7 x 16 B per lane), the steps,
+//             first-maximum label, colour, records out
+// Same operations in the same order per voxel as k_apply: bit for bit the same records.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kRunTile = 2048;   // pairs per workgroup
+constexpr uint32_t kRunThreads = 512; // eight wavefronts: a tile has ~ 6 - 12 tasks of 64 runs, and what bounds the kernel is how many
+                                      // wavefronts a CU holds against the latency of gather -> record -> steps (LDS limits the workgroups)
+constexpr uint32_t kRunPer = kRunTile / kRunThreads;
+constexpr uint32_t kRunHalo = 32;     // = kLongRun: the longest run this kernel takes
+constexpr uint32_t kRunSlots = kRunTile + kRunHalo;
+constexpr uint32_t kRunMixSlots = 96;  // merged: increment vectors of mixed-label bundles parked in LDS per tile (more: read from global in the step)
+
+template <int COLOR_MODE, bool MERGED>
+__global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsigned long long n_pairs,
+                                                            const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
+                                                            const float* __restrict__ deltas, TileTable T, Pool P,
+                                                            const uint32_t* __restrict__ label_lut) {
+  constexpr bool HOT_ONLY = !MERGED && COLOR_MODE != KS_COLOR_MODE_COLOR;
+  constexpr bool BLEND = COLOR_MODE == KS_COLOR_MODE_COLOR;
+  static_assert(kRunHalo == kLongRun, "a short run must end inside the halo");
+  static_assert(kRunHalo <= 64 && kRunTile % kRunThreads == 0, "tile shape");
+  __shared__ float s_sdf[kRunSlots], s_uw[kRunSlots];
+  __shared__ uint32_t s_info[kRunSlots];                     // [7:0] label, [9:8] kind (1 pure, 2 mixed: vector in s_mix, 3 mixed: vector in global memory)
+  __shared__ float s_dm[MERGED ? kRunSlots : 1], s_dn[MERGED ? kRunSlots : 1];   // merged: per-bundle increments (mixed: s_dm = slot in s_mix / bundle position)
+  __shared__ uint32_t s_col[BLEND ? kRunSlots : 1];
+  __shared__ unsigned long long s_bounds[kRunSlots / 64 + 3 + kRunThreads / 64];  // bit j: pair j of the tile starts a run, or lies past the end of the list
+  __shared__ uint32_t s_run[kRunTile];                        // the tile's short runs, longest first: start | length << 16
+  __shared__ uint32_t s_run_vox[kRunTile];                    // ... and their voxels
+  __shared__ uint32_t s_hist[kLongRun + 2];
+  __shared__ uint32_t s_lut[256];
+  __shared__ float s_mix[MERGED ? kRunMixSlots : 1][kNumLabels];
+  __shared__ uint32_t s_n_mix, s_next_task;
+  const uint32_t lane = lane_id(), tid = threadIdx.x;
+  const unsigned long long base = (unsigned long long)blockIdx.x * kRunTile;
+  if (tid < 256u) s_lut[tid] = label_lut[tid];
+  if (tid < kLongRun + 2) s_hist[tid] = 0u;
+  if (tid == 0) {
+    s_n_mix = 0u;
+    s_next_task = 0u;
+  }
+  if (tid < 2) s_bounds[kRunSlots / 64 + 1 + tid] = ~0ull;
+
+  // ---- phase A: every load of the thread's pairs is requested before the first is used (key -> {tile key, ray}: two
+  //      memory round trips for the whole tile instead of two per pair) ----
+  constexpr uint32_t NA = kRunPer + 1;   // the last one is the halo: pairs [kRunTile, kRunTile + 32), threads 0..31
+  uint64_t key[NA], pkey[NA];
+  bool valid[NA];
+#pragma unroll
+  for (uint32_t k = 0; k < NA; ++k) {
+    const uint32_t j = k * kRunThreads + tid;
+    const unsigned long long i = base + j;
+    valid[k] = j < kRunSlots && i < n_pairs;
+    key[k] = valid[k] ? pairs[i] : 0ull;
+    pkey[k] = (valid[k] && i > 0) ? pairs[i - 1] : ~0ull;
+  }
+  uint64_t tkey[NA];
+  uint4 d0[NA], d1[NA];
+  uint32_t voxs[NA];
+#pragma unroll
+  for (uint32_t k = 0; k < NA; ++k) {
+    voxs[k] = (uint32_t)(key[k] >> F.seq_bits);
+    const uint32_t rp = (uint32_t)key[k] & F.point_mask;
+    const uint4* r4 = (const uint4*)rays + (size_t)(valid[k] ? ray_index(F, rp) : 0u) * 2;
+    tkey[k] = T.slot_keys[valid[k] ? (voxs[k] >> 9) : 0u];
+    d0[k] = r4[0];
+    if (!HOT_ONLY) d1[k] = r4[1];
+  }
+  __syncthreads();   // (the initial values above)
+#pragma unroll
+  for (uint32_t k = 0; k < NA; ++k) {
+    const uint32_t j = k * kRunThreads + tid;
+    bool head = false;
+    if (valid[k]) {
+      const uint32_t vox = voxs[k];
+      head = (base + j == 0) || ((uint32_t)(pkey[k] >> F.seq_bits) != vox);
+      int tx, ty, tz;
+      unpack_tile(tkey[k], tx, ty, tz);
+      const uint32_t local = vox & 511u;
+      float sdf, uw;
+      tsdf_operands(F.tsdf, F.T.t, {__uint_as_float(d0[k].x), __uint_as_float(d0[k].y), __uint_as_float(d0[k].z)},
+                    tx * 8 + (int)(local & 7u), ty * 8 + (int)((local >> 3) & 7u), tz * 8 + (int)(local >> 6), __uint_as_float(d0[k].w), sdf, uw);
+      s_sdf[j] = sdf;
+      s_uw[j] = uw;
+      uint32_t info;
+      if (HOT_ONLY) {   // (load_update_ops: label / kind / clearing ride in the top byte of the pair key)
+        const uint32_t b = (uint32_t)(key[k] >> 56);
+        info = (b & 0x1fu) | (((b >> 5) & 3u) << 8);
+      } else {
+        info = d1[k].w & 0x3ffu;
+      }
+      if (MERGED) {
+        float dm = __uint_as_float(d1[k].y);
+        if (((info >> 8) & 3u) == 2u) {
+          // mixed-label bundle: its 21 increments wait in LDS for the step that needs them
+          const uint32_t rp = (uint32_t)key[k] & F.point_mask;
+          const uint32_t slot = atomicAdd(&s_n_mix, 1u);
+          const float* dl = deltas + (size_t)rp * kNumLabels;
+          if (slot < kRunMixSlots) {
+#pragma unroll
+            for (int l = 0; l < kNumLabels; ++l) s_mix[slot][l] = dl[l];
+            dm = __uint_as_float(slot);
+          } else {
+            info |= 0x300u;   // kind 3
+            dm = __uint_as_float(rp);
+          }
+        }
+        s_dm[j] = dm;
+        s_dn[j] = __uint_as_float(d1[k].z);
+      }
+      if (BLEND) s_col[j] = d1[k].x;
+      s_info[j] = info;
+    }
+    const unsigned long long m = __ballot(head || !valid[k]);
+    if (lane == 0) s_bounds[j >> 6] = m;   // (the halo round: wavefront 0 writes word 32, the others all-ones past it)
+  }
+  __syncthreads();
+
+  // ---- listing: heads, lengths, counting sort (longest first) ----
+  uint32_t my_len[kRunPer];
+#pragma unroll
+  for (uint32_t k = 0; k < kRunPer; ++k) {
+    const uint32_t j = k * kRunThreads + tid;
+    my_len[k] = 0u;
+    if ((s_bounds[j >> 6] >> (j & 63u)) & 1ull) {
+      if (valid[k]) {
+        const uint32_t q = j + 1u, sh = q & 63u;
+        const unsigned long long lo = s_bounds[q >> 6], hi = s_bounds[(q >> 6) + 1u];
+        const unsigned long long w = sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
+        // next boundary at distance d = ffs(w): the run has d updates; none within 32: k_apply_long's (k_find_long)
+        if ((uint32_t)w != 0u) {
+          my_len[k] = (uint32_t)__ffs((int)(uint32_t)w);
+          atomicAdd(&s_hist[my_len[k]], 1u);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t acc = 0u;
+    for (uint32_t l = kLongRun; l >= 1u; --l) {
+      const uint32_t c = s_hist[l];
+      s_hist[l] = acc;
+      acc += c;
+    }
+    s_hist[0] = acc;   // runs in all
+  }
+  __syncthreads();
+  const uint32_t n_runs = s_hist[0];
+  __syncthreads();     // (s_hist[0] read by everyone before the cursors move)
+#pragma unroll
+  for (uint32_t k = 0; k < kRunPer; ++k)
+    if (my_len[k]) {
+      const uint32_t pos = atomicAdd(&s_hist[my_len[k]], 1u);
+      s_run[pos] = (k * kRunThreads + tid) | (my_len[k] << 16);
+      s_run_vox[pos] = voxs[k];
+    }
+  __syncthreads();
+
+  // ---- tasks ----
+  const uint32_t n_tasks = (n_runs + 63u) >> 6;
+  for (;;) {
+    uint32_t t = 0;
+    if (lane == 0) t = atomicAdd(&s_next_task, 1u);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    if (t >= n_tasks) break;
+    const uint32_t r = t * 64u + lane;
+    const bool has = r < n_runs;
+    const uint32_t rj = has ? s_run[r] : 0u;
+    const uint32_t j0 = rj & 0xffffu, len = has ? (rj >> 16) : 0u;
+    const uint32_t vox = has ? s_run_vox[r] : 0u;
+    uint4* rec = P.vox + (size_t)vox * 8;
+    float p[kNumLabels];
+    float dist = 0.f, weight = 0.f;
+    uint32_t color = 0u;
+    if (has) {
+      const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
+      const uint32_t q6 = ((const uint32_t*)rec)[24];
+      dist = __uint_as_float(q0.x);
+      weight = __uint_as_float(q0.y);
+      color = q0.z;
+      p[0] = __uint_as_float(q1.x); p[1] = __uint_as_float(q1.y); p[2] = __uint_as_float(q1.z); p[3] = __uint_as_float(q1.w);
+      p[4] = __uint_as_float(q2.x); p[5] = __uint_as_float(q2.y); p[6] = __uint_as_float(q2.z); p[7] = __uint_as_float(q2.w);
+      p[8] = __uint_as_float(q3.x); p[9] = __uint_as_float(q3.y); p[10] = __uint_as_float(q3.z); p[11] = __uint_as_float(q3.w);
+      p[12] = __uint_as_float(q4.x); p[13] = __uint_as_float(q4.y); p[14] = __uint_as_float(q4.z); p[15] = __uint_as_float(q4.w);
+      p[16] = __uint_as_float(q5.x); p[17] = __uint_as_float(q5.y); p[18] = __uint_as_float(q5.z); p[19] = __uint_as_float(q5.w);
+      p[20] = __uint_as_float(q6);
+    } else {
+#pragma unroll
+      for (int l = 0; l < kNumLabels; ++l) p[l] = 0.f;
+    }
+    // the operands of step s + 1 are requested from LDS before step s is applied
+    float sdf_n = s_sdf[j0], uw_n = s_uw[j0];
+    uint32_t info_n = s_info[j0];
+    float dm_n = MERGED ? s_dm[j0] : F.log_match, dn_n = MERGED ? s_dn[j0] : F.log_non_match;
+    uint32_t col_n = BLEND ? s_col[j0] : 0u;
+    for (uint32_t s = 0;; ++s) {
+      const bool on = s < len;
+      if (__ballot(on) == 0ull) break;
+      const float sdf_s = sdf_n, uw_s = uw_n, dm_s = dm_n, dn_s = dn_n;
+      const uint32_t info_s = info_n, col_s = col_n;
+      const uint32_t jn = j0 + ((s + 1u < len) ? s + 1u : 0u);
+      sdf_n = s_sdf[jn];
+      uw_n = s_uw[jn];
+      info_n = s_info[jn];
+      if (MERGED) {
+        dm_n = s_dm[jn];
+        dn_n = s_dn[jn];
+      }
+      if (BLEND) col_n = s_col[jn];
+      if (on) {
+        // updateTsdfVoxel's state half (tsdf_combine), [K:src/semantic_tsdf_integrator_fast.cpp:128]
+        const float nw = weight + uw_s;
+        if (!(nw < kEps)) {
+          const float ns = (sdf_s * uw_s + dist * weight) / nw;
+          if (BLEND) {
+            if (fabsf(sdf_s) < F.tsdf.trunc) color = blend_two_colors(color, weight, col_s, uw_s);
+          }
+          dist = __builtin_amdgcn_fmed3f(ns, -F.tsdf.trunc, F.tsdf.trunc);   // (k_apply: the median IS the reference's clamp, NaN included)
+          weight = std_min(F.tsdf.max_weight, nw);
+        }
+        // updateSemanticVoxelProbabilities, [K:src/semantic_integrator_base.cpp:283-380]
+        const uint32_t kind = (info_s >> 8) & 3u, lab = info_s & 0xffu;
+        if (kind == 1u) {
+#pragma unroll
+          for (int l = 0; l < kNumLabels; ++l) p[l] += ((uint32_t)l == lab) ? dm_s : dn_s;
+        } else if (MERGED && kind == 2u) {
+          const float* dl = s_mix[__float_as_uint(dm_s)];
+#pragma unroll
+          for (int l = 0; l < kNumLabels; ++l) p[l] += dl[l];
+        } else if (MERGED && kind == 3u) {
+          const float* dl = deltas + (size_t)__float_as_uint(dm_s) * kNumLabels;
+#pragma unroll
+          for (int l = 0; l < kNumLabels; ++l) p[l] += dl[l];
+        }
+      }
+    }
+    if (has) {
+      // calculateMaximumLikelihoodLabel: first strict maximum [K:src/semantic_integrator_base.cpp:352-367]
+      float bv = p[0];
+      uint32_t bi = 0u;
+#pragma unroll
+      for (int l = 1; l < kNumLabels; ++l)
+        if (p[l] > bv) {
+          bv = p[l];
+          bi = (uint32_t)l;
+        }
+      if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = s_lut[bi & 255u];
+      else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY) color = rainbow_color_map((double)(float)exp((double)bv));
+      rec[0] = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, bi);
+      rec[1] = make_uint4(__float_as_uint(p[0]), __float_as_uint(p[1]), __float_as_uint(p[2]), __float_as_uint(p[3]));
+      rec[2] = make_uint4(__float_as_uint(p[4]), __float_as_uint(p[5]), __float_as_uint(p[6]), __float_as_uint(p[7]));
+      rec[3] = make_uint4(__float_as_uint(p[8]), __float_as_uint(p[9]), __float_as_uint(p[10]), __float_as_uint(p[11]));
+      rec[4] = make_uint4(__float_as_uint(p[12]), __float_as_uint(p[13]), __float_as_uint(p[14]), __float_as_uint(p[15]));
+      rec[5] = make_uint4(__float_as_uint(p[16]), __float_as_uint(p[17]), __float_as_uint(p[18]), __float_as_uint(p[19]));
+      rec[6] = make_uint4(__float_as_uint(p[20]), 1u, 0u, 0u);   // dword 25 = 1: updated since the last voxel-level host sync
+    }
+  }
+}
+
 // Heads of runs of >= kLongRun updates, found before either apply kernel runs: k_apply (short runs) and
 // k_apply_long (long runs) touch disjoint voxels and are launched side by side on two streams.  Runs of more than
 // kXLongRun updates go to a list of their own when the caller passes one (xlong_list != nullptr): the handful of voxels
@@ -542,13 +817,13 @@ __global__ void __launch_bounds__(256) k_apply_xlong(FrameParams F, unsigned lon
                                                     const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
                                                     const float* __restrict__ deltas, TileTable T, Pool P,
                                                     const uint32_t* __restrict__ label_lut,
-                                                    const unsigned long long* __restrict__ xlong_list, const Counters* C) {
+                                                    const unsigned long long* __restrict__ xlong_list, const uint32_t* __restrict__ n_runs_ptr) {
   __shared__ float s_inc[2][16][kNumLabels][4];  // [batch parity][update / 4][class][update % 4]
   __shared__ float4 s_tab[3][64];                // per update of a batch: sdf, update weight, colour
   __shared__ int s_cnt[3];                       // updates in the batch (< 64: the run ends with it)
   __shared__ uint32_t s_best;
   __shared__ float s_best_val;
-  const uint32_t n_x = C->n_xlong;
+  const uint32_t n_x = *n_runs_ptr;   // (C->n_xlong, or what k_xl_plan / k_xl_walk left for this kernel: ks_k_apply_xl.h)
   const int lane = (int)lane_id();
   const int role = (int)(threadIdx.x >> 6);
   const int cls = lane < kNumLabels ? lane : 0;

@@ -30,7 +30,7 @@ def main():
     sc = synth.make_scene("room")
     tot_o = tot_g = 0
     for k in range(spec.get("frames", 1)):
-        T = synth.pose_to_T((3.5, 0.3, 1.2), 0.1) if (spec.get("close_up_first") and k == 0) else synth.trajectory_pose(5 * k)
+        T = synth.pose_to_T((3.5, 0.3, 1.2), 0.1) if (spec.get("close_up_first") and k == 0) else synth.trajectory_pose(0 if spec.get("fixed_pose") else 5 * k)
         f = synth.render_frame(sc, T, w, h, seed=40 + k)   # (close_up_first: 0.45 m from a wall — bundles of thousands of points)
         if spec.get("cloud") == "axis":
             # rays with one or two zero components seen from an unrotated sensor (crossing times inf / NaN: the serial
@@ -60,6 +60,10 @@ def main():
     if spec.get("fallbacks_below") is not None:
         st = g.early_out_stats()
         assert 0 < st["fallbacks"] < spec["fallbacks_below"], st   # (some frames repeat on the host, then the device loop takes over again)
+    if spec.get("xl_walked_at_least") is not None:
+        st = g.update_stats()
+        assert st["walked"] >= spec["xl_walked_at_least"] and st["chunks"] > 0, st
+        print("update_stats", st)
     rep = compare_maps(o, g, exact=True)
     assert rep["oracle_touched"] > 500, rep
     print("EMU_CASE_OK", json.dumps({"updates": tot_g, "voxels": rep["oracle_touched"]}))

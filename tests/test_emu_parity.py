@@ -167,6 +167,30 @@ def test_axis_parallel_rays_under_the_early_out_equal_oracle(emu_jobs, request, 
     check_case(emu_jobs, request)
 
 
+# k_apply_runs (a lane per voxel run, runs bucketed by length in a tile of 2048 pairs) instead of k_apply: forced for frames of
+# any size (the library takes it from 2^20 pairs per frame on); the records must be the same bit for bit
+RUNS_CASES = {
+    "fast_no_early_out": dict(method=0, size=[64, 48], frames=2, no_early_out=True),
+    "fast_colour_blend": dict(method=0, size=[64, 48], frames=2, no_early_out=True, cfg=dict(color_mode=0)),
+    "fast_default_pipelined": dict(method=0, size=[64, 48], frames=3, pipeline=2),
+    "merged": dict(method=1, size=[64, 48], frames=2),
+    "merged_colour_blend": dict(method=1, size=[64, 48], frames=2, cfg=dict(color_mode=0)),
+    "merged_probability_colours_random_knobs": dict(method=1, size=[64, 48], frames=2, random_combo=5),
+    "merged_close_up_long_runs_beside": dict(method=1, size=[160, 120], frames=2, pipeline=2, max_tiles=8192, close_up_first=True),
+    # four frames from one pose, weights saturating at once: the sensor voxel's runs of more than 1024 updates through the chunked
+    # integer sums of ks_k_apply_xl.h (binade crossings and replays included), the first frame's through k_apply_xlong
+    "merged_sensor_voxel_integer_sums": dict(method=1, size=[96, 72], frames=4, fixed_pose=True, cfg=dict(max_weight=2.0), xl_walked_at_least=1),
+}
+for _name, _spec in RUNS_CASES.items():
+    case_job("test_lane_per_run_update_kernel_equals_oracle[%s]" % _name, _spec, env_extra={"KS_DEBUG": "1", "KS_APPLY_RUNS": "1"},
+             weight=40 if "close_up" in _name else 10)
+
+
+@pytest.mark.parametrize("name", sorted(RUNS_CASES))
+def test_lane_per_run_update_kernel_equals_oracle(emu_jobs, request, name):
+    check_case(emu_jobs, request)
+
+
 JOBS["test_gpu_tier_cases_unchanged_on_the_functional_model"] = (
     [sys.executable, "-m", "pytest", "tests/test_parity_gpu.py", "-m", "gpu", "-q", "-x", "-k",
      "error_codes or saturated or degenerate or depth_image_u16"], {"KS_TESTS_ON_FUNCTIONAL_MODEL": "1"}, 1200, 55)
