@@ -331,7 +331,9 @@ struct ks_ctx {
   XlRun* d_xl_runs = nullptr;
   XlHeader* d_xl_hdr = nullptr;
   XlChunk* d_xl_chunks = nullptr;
-  uint32_t cap_xl_chunks = 1u << 15;   // 2 M updates in such runs per frame (more: the serial kernel takes the rest)
+  uint32_t* d_xl_idx = nullptr;
+  unsigned long long* d_xl_fb = nullptr;
+  uint32_t cap_xl_chunks = 1u << 17;   // 8 M updates in such runs per frame (more: the serial kernel takes the rest)
   ks_profile prof{};
   ProfSet pset[kProfSets];
   bool fatal = false;
@@ -561,6 +563,7 @@ int ensure_pairs_out(ks_ctx* c, size_t n) {
     // heads of the long runs, then (from cap / kLongRun + 64 on) the heads of the runs of more than kXLongRun updates
     if ((rc = dev_alloc(c, &c->d_long_list_[b], cap / kLongRun + 64 + cap / kXLongRun + 64))) return rc;
   }
+  if (c->d_xl_hdr && (rc = dev_alloc(c, &c->d_xl_fb, cap / kXLongRun + 64))) return rc;   // (the runs the integer-sum path leaves to k_apply_xlong)
   c->cap_pairs = cap;
   return KS_OK;
 }
@@ -1531,17 +1534,22 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   }                                                                                                                  \
   stage_mark(c, set, 9);                                                                                             \
   if (sx && c->xl_parallel) {                                                                                        \
-    /* the class sums of such runs as integer sums per chunk, chunks side by side (ks_k_apply_xl.h); what the shortcut   \
-       cannot carry stays on the list for k_apply_xlong */                                                              \
-    hipLaunchKernelGGL(k_xl_plan<MODE>, dim3(1), dim3(256), 0, sx, F, n_pairs, (const uint64_t*)sp, c->pool,           \
-                       d_xlong_list, (const Counters*)S.d_counters, c->d_xl_runs, c->d_xl_hdr, c->cap_xl_chunks);      \
-    hipLaunchKernelGGL(k_xl_chunks, dim3(512), dim3(256), 0, sx, F, (const uint64_t*)sp, (const RayDesc*)S.d_rays,     \
-                       (const float*)S.d_deltas, c->table, c->d_xl_runs, (const XlHeader*)c->d_xl_hdr, c->d_xl_chunks); \
-    hipLaunchKernelGGL(k_xl_walk<MODE>, dim3(kXlMaxRuns), dim3(64), 0, sx, F, (const uint64_t*)sp,                     \
-                       (const RayDesc*)S.d_rays, (const float*)S.d_deltas, c->pool, (const uint32_t*)c->d_label_lut,   \
-                       c->d_xl_runs, c->d_xl_hdr, (const XlChunk*)c->d_xl_chunks, d_xlong_list);                       \
+    /* the class sums and the weight of such runs as integer sums per chunk, chunks side by side (ks_k_apply_xl.h); what \
+       the shortcut cannot carry goes to k_apply_xlong through the fall-back list */                                    \
+    hipLaunchKernelGGL(k_xl_measure<MODE>, dim3(kXlMaxRuns / 256), dim3(256), 0, sx, F, n_pairs, (const uint64_t*)sp,  \
+                       c->pool, (const unsigned long long*)d_xlong_list, (const Counters*)S.d_counters, c->d_xl_runs); \
+    hipLaunchKernelGGL(k_xl_number, dim3(1), dim3(1024), 0, sx, (const unsigned long long*)d_xlong_list,               \
+                       (const Counters*)S.d_counters, c->d_xl_runs, c->d_xl_idx, c->d_xl_fb, c->d_xl_hdr,              \
+                       c->cap_xl_chunks);                                                                               \
+    hipLaunchKernelGGL(k_xl_chunks, dim3(1024), dim3(256), 0, sx, F, (const uint64_t*)sp, (const RayDesc*)S.d_rays,    \
+                       (const float*)S.d_deltas, c->table, c->d_xl_runs, (const uint32_t*)c->d_xl_idx,                 \
+                       (const XlHeader*)c->d_xl_hdr, c->d_xl_chunks);                                                   \
+    hipLaunchKernelGGL(k_xl_walk<MODE>, dim3(2048), dim3(64), 0, sx, F, (const uint64_t*)sp, (const RayDesc*)S.d_rays, \
+                       (const float*)S.d_deltas, c->table, c->pool, (const uint32_t*)c->d_label_lut, c->d_xl_runs,     \
+                       (const uint32_t*)c->d_xl_idx, c->d_xl_hdr, (const XlChunk*)c->d_xl_chunks, c->d_xl_fb);         \
     hipLaunchKernelGGL(k_apply_xlong<MODE>, dim3(xb), dim3(256), 0, sx, F, n_pairs, sp, S.d_rays, S.d_deltas,          \
-                       c->table, c->pool, c->d_label_lut, d_xlong_list, (const uint32_t*)&c->d_xl_hdr->n_fallback);    \
+                       c->table, c->pool, c->d_label_lut, (const unsigned long long*)c->d_xl_fb,                        \
+                       (const uint32_t*)&c->d_xl_hdr->n_fallback);                                                      \
   } else if (sx)                                                                                                     \
     hipLaunchKernelGGL(k_apply_xlong<MODE>, dim3(xb), dim3(256), 0, sx, F, n_pairs, sp, S.d_rays, S.d_deltas,            \
                        c->table, c->pool, c->d_label_lut, d_xlong_list, (const uint32_t*)&S.d_counters->n_xlong);      \
@@ -2116,6 +2124,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     if (const char* xl = dbg_env("KS_XL_PARALLEL")) c->xl_parallel = atoi(xl) != 0;   // A/B: 0 = every such run through k_apply_xlong
     if (c->stream_xlong && c->xl_parallel) {
       CRCHK(hipMalloc((void**)&c->d_xl_runs, kXlMaxRuns * sizeof(XlRun)));
+      CRCHK(hipMalloc((void**)&c->d_xl_idx, kXlMaxRuns * sizeof(uint32_t)));
       CRCHK(hipMalloc((void**)&c->d_xl_hdr, sizeof(XlHeader)));
       CRCHK(hipMemset(c->d_xl_hdr, 0, sizeof(XlHeader)));
       CRCHK(hipMalloc((void**)&c->d_xl_chunks, (size_t)c->cap_xl_chunks * sizeof(XlChunk)));
@@ -2232,7 +2241,7 @@ void ks_destroy(ks_ctx* c) {
                   c->d_pairs2_[0], c->d_pairs2_[1], c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux, c->d_bo_slab,
                   c->d_eo_keys[0], c->d_eo_keys[1], c->d_eo_vals[0], c->d_eo_vals[1], c->d_eo_range, c->d_eo_plain, c->d_eo_lp, c->d_eo_bt,
-                  c->d_eo_state, c->d_xl_runs, c->d_xl_hdr, c->d_xl_chunks, c->d_rx_counts, c->d_tx_keys, c->d_rx_keys, c->d_tx_slots, c->d_tx_payload, c->d_rx_payload};
+                  c->d_eo_state, c->d_xl_runs, c->d_xl_hdr, c->d_xl_chunks, c->d_xl_idx, c->d_xl_fb, c->d_rx_counts, c->d_tx_keys, c->d_rx_keys, c->d_tx_slots, c->d_tx_payload, c->d_rx_payload};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& S : c->slot) {

@@ -334,39 +334,95 @@ __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsig
   }
   if (tid < 2) s_bounds[kRunSlots / 64 + 1 + tid] = ~0ull;
 
-  // ---- phase A: every load of the thread's pairs is requested before the first is used (key -> {tile key, ray}: two
-  //      memory round trips for the whole tile instead of two per pair) ----
+  // ---- phase A1: the tile's keys -> where its runs begin (a bit per pair) ----
   constexpr uint32_t NA = kRunPer + 1;   // the last one is the halo: pairs [kRunTile, kRunTile + 32), threads 0..31
-  uint64_t key[NA], pkey[NA];
+  uint64_t key[NA];
   bool valid[NA];
+  {
+    uint64_t pkey[NA];
+#pragma unroll
+    for (uint32_t k = 0; k < NA; ++k) {
+      const uint32_t j = k * kRunThreads + tid;
+      const unsigned long long i = base + j;
+      valid[k] = j < kRunSlots && i < n_pairs;
+      key[k] = valid[k] ? pairs[i] : 0ull;
+      pkey[k] = (valid[k] && i > 0) ? pairs[i - 1] : ~0ull;
+    }
+    __syncthreads();   // (the initial values above)
+#pragma unroll
+    for (uint32_t k = 0; k < NA; ++k) {
+      const uint32_t j = k * kRunThreads + tid;
+      const bool head = valid[k] && ((base + j == 0) || ((uint32_t)(pkey[k] >> F.seq_bits) != (uint32_t)(key[k] >> F.seq_bits)));
+      const unsigned long long m = __ballot(head || !valid[k]);
+      if (lane == 0) s_bounds[j >> 6] = m;   // (the halo round: wavefront 0 writes word 32, the others all-ones past it)
+    }
+  }
+  __syncthreads();
+
+  // ---- listing: every pair finds the run it is part of — d1 pairs back to its head, d2 on to the next boundary.  A run of
+  //      more than 32 updates is k_apply_long's / k_apply_xlong's (k_find_long lists exactly those), a run that began in
+  //      the tile before this one is that tile's (its halo).  Heads of the tile's own short runs are counted by length. ----
+  uint32_t my_len[kRunPer];
+  bool need[NA];
 #pragma unroll
   for (uint32_t k = 0; k < NA; ++k) {
     const uint32_t j = k * kRunThreads + tid;
-    const unsigned long long i = base + j;
-    valid[k] = j < kRunSlots && i < n_pairs;
-    key[k] = valid[k] ? pairs[i] : 0ull;
-    pkey[k] = (valid[k] && i > 0) ? pairs[i - 1] : ~0ull;
-  }
-  uint64_t tkey[NA];
-  uint4 d0[NA], d1[NA];
-  uint32_t voxs[NA];
-#pragma unroll
-  for (uint32_t k = 0; k < NA; ++k) {
-    voxs[k] = (uint32_t)(key[k] >> F.seq_bits);
-    const uint32_t rp = (uint32_t)key[k] & F.point_mask;
-    const uint4* r4 = (const uint4*)rays + (size_t)(valid[k] ? ray_index(F, rp) : 0u) * 2;
-    tkey[k] = T.slot_keys[valid[k] ? (voxs[k] >> 9) : 0u];
-    d0[k] = r4[0];
-    if (!HOT_ONLY) d1[k] = r4[1];
-  }
-  __syncthreads();   // (the initial values above)
-#pragma unroll
-  for (uint32_t k = 0; k < NA; ++k) {
-    const uint32_t j = k * kRunThreads + tid;
-    bool head = false;
+    need[k] = false;
+    if (k < kRunPer) my_len[k] = 0u;
     if (valid[k]) {
-      const uint32_t vox = voxs[k];
-      head = (base + j == 0) || ((uint32_t)(pkey[k] >> F.seq_bits) != vox);
+      // boundaries at j - 31 .. j (bit 31 = pair j itself) and at j + 1 .. j + 32 (bit 0 = pair j + 1)
+      const uint32_t q = j + 1u, sh = q & 63u;
+      const unsigned long long lo = s_bounds[q >> 6], hi = s_bounds[(q >> 6) + 1u];
+      const uint32_t fwd = (uint32_t)(sh ? ((lo >> sh) | (hi << (64u - sh))) : lo);
+      uint32_t back;
+      {
+        // 32 bits ending at j: positions before the tile's first pair hold no boundary (a run from before the tile: not ours)
+        const int p0 = (int)j - 31;
+        const uint32_t w0 = (uint32_t)(p0 >= 0 ? p0 : 0) >> 6;
+        const unsigned long long a0 = s_bounds[w0], a1 = s_bounds[w0 + 1u];
+        if (p0 >= 0) {
+          const uint32_t s0 = (uint32_t)p0 & 63u;
+          back = (uint32_t)(s0 ? ((a0 >> s0) | (a1 << (64u - s0))) : a0);
+        } else {
+          back = (uint32_t)(a0 << (uint32_t)(-p0));   // (j < 31: word 0 holds them all)
+        }
+      }
+      if (back != 0u && fwd != 0u) {
+        const uint32_t d1 = (uint32_t)__clz((int)back);        // pairs back to the head (0: j is the head)
+        const uint32_t d2 = (uint32_t)__ffs((int)fwd);         // pairs on to the next boundary
+        const uint32_t len = d1 + d2;
+        const bool head_in_tile = j - d1 < kRunTile;
+        if (len <= kLongRun && head_in_tile) {
+          need[k] = true;
+          if (d1 == 0u && k < kRunPer) {
+            my_len[k] = len;
+            atomicAdd(&s_hist[len], 1u);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- phase A2: the operands of the pairs that are part of this tile's short runs (at 1280x720 / 2 cm most pairs are
+  //      part of longer ones): every gather is requested before the first is used ----
+  uint64_t tkey[NA];
+  uint4 d0[NA], d1v[NA];
+#pragma unroll
+  for (uint32_t k = 0; k < NA; ++k) {
+    const uint32_t vox = (uint32_t)(key[k] >> F.seq_bits);
+    const uint32_t rp = (uint32_t)key[k] & F.point_mask;
+    const uint4* r4 = (const uint4*)rays + (size_t)(need[k] ? ray_index(F, rp) : 0u) * 2;
+    if (need[k]) {
+      tkey[k] = T.slot_keys[vox >> 9];
+      d0[k] = r4[0];
+      if (!HOT_ONLY) d1v[k] = r4[1];
+    }
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < NA; ++k) {
+    const uint32_t j = k * kRunThreads + tid;
+    if (need[k]) {
+      const uint32_t vox = (uint32_t)(key[k] >> F.seq_bits);
       int tx, ty, tz;
       unpack_tile(tkey[k], tx, ty, tz);
       const uint32_t local = vox & 511u;
@@ -380,10 +436,10 @@ __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsig
         const uint32_t b = (uint32_t)(key[k] >> 56);
         info = (b & 0x1fu) | (((b >> 5) & 3u) << 8);
       } else {
-        info = d1[k].w & 0x3ffu;
+        info = d1v[k].w & 0x3ffu;
       }
       if (MERGED) {
-        float dm = __uint_as_float(d1[k].y);
+        float dm = __uint_as_float(d1v[k].y);
         if (((info >> 8) & 3u) == 2u) {
           // mixed-label bundle: its 21 increments wait in LDS for the step that needs them
           const uint32_t rp = (uint32_t)key[k] & F.point_mask;
@@ -399,33 +455,10 @@ __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsig
           }
         }
         s_dm[j] = dm;
-        s_dn[j] = __uint_as_float(d1[k].z);
+        s_dn[j] = __uint_as_float(d1v[k].z);
       }
-      if (BLEND) s_col[j] = d1[k].x;
+      if (BLEND) s_col[j] = d1v[k].x;
       s_info[j] = info;
-    }
-    const unsigned long long m = __ballot(head || !valid[k]);
-    if (lane == 0) s_bounds[j >> 6] = m;   // (the halo round: wavefront 0 writes word 32, the others all-ones past it)
-  }
-  __syncthreads();
-
-  // ---- listing: heads, lengths, counting sort (longest first) ----
-  uint32_t my_len[kRunPer];
-#pragma unroll
-  for (uint32_t k = 0; k < kRunPer; ++k) {
-    const uint32_t j = k * kRunThreads + tid;
-    my_len[k] = 0u;
-    if ((s_bounds[j >> 6] >> (j & 63u)) & 1ull) {
-      if (valid[k]) {
-        const uint32_t q = j + 1u, sh = q & 63u;
-        const unsigned long long lo = s_bounds[q >> 6], hi = s_bounds[(q >> 6) + 1u];
-        const unsigned long long w = sh ? ((lo >> sh) | (hi << (64u - sh))) : lo;
-        // next boundary at distance d = ffs(w): the run has d updates; none within 32: k_apply_long's (k_find_long)
-        if ((uint32_t)w != 0u) {
-          my_len[k] = (uint32_t)__ffs((int)(uint32_t)w);
-          atomicAdd(&s_hist[my_len[k]], 1u);
-        }
-      }
     }
   }
   __syncthreads();
@@ -446,7 +479,7 @@ __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsig
     if (my_len[k]) {
       const uint32_t pos = atomicAdd(&s_hist[my_len[k]], 1u);
       s_run[pos] = (k * kRunThreads + tid) | (my_len[k] << 16);
-      s_run_vox[pos] = voxs[k];
+      s_run_vox[pos] = (uint32_t)(key[k] >> F.seq_bits);
     }
   __syncthreads();
 

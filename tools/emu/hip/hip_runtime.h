@@ -410,6 +410,12 @@ inline void launch_named(const char* name, dim3 grid, dim3 block, const std::fun
 // DPP wave_shr:1 — lane k reads lane k-1's value, lane 0 (no source lane) keeps `first` (bound_ctrl off)
 #define KS_LANE_BELOW(first_i, x_i) (emu::lane() == 0u ? ((void)emu::shfl_from((int)(x_i), 0, EMU_SITE), (int)(first_i)) : emu::shfl_from((int)(x_i), (int)emu::lane() - 1, EMU_SITE))
 #define KS_WAIT_VMEM()
+// sum over the wavefront, in every lane (ks_k_apply_xl.h: six DPP adds on the GPU)
+inline int emu_wave_sum_i32(int v) {
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+#define KS_WAVE_SUM_I32(v) emu_wave_sum_i32(v)
 #define KS_WAIT_LOADS()
 #define KS_VALUE_BARRIER(x) (void)(x)
 
