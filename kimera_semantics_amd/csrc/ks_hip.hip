@@ -332,6 +332,11 @@ struct ks_ctx {
   XlHeader* d_xl_hdr = nullptr;
   XlChunk* d_xl_chunks = nullptr;
   uint32_t* d_xl_idx = nullptr;
+  // the runs of 33 .. 1024 updates a lane per run, bucketed by length over the frame (k_apply_long_lanes); by parity, like the lists
+  bool long_lanes = true;
+  unsigned long long long_lanes_min_pairs = 1ull << 24;   // (below: too few such runs to fill wavefronts with — k_apply_long takes them all)
+  unsigned long long* d_long_sorted_[2] = {nullptr, nullptr};
+  LongHdr* d_long_hdr_[2] = {nullptr, nullptr};
   unsigned long long* d_xl_fb = nullptr;
   uint32_t cap_xl_chunks = 1u << 17;   // 8 M updates in such runs per frame (more: the serial kernel takes the rest)
   ks_profile prof{};
@@ -562,6 +567,7 @@ int ensure_pairs_out(ks_ctx* c, size_t n) {
     if ((rc = dev_alloc(c, &c->d_pairs2_[b], cap))) return rc;
     // heads of the long runs, then (from cap / kLongRun + 64 on) the heads of the runs of more than kXLongRun updates
     if ((rc = dev_alloc(c, &c->d_long_list_[b], cap / kLongRun + 64 + cap / kXLongRun + 64))) return rc;
+    if (c->long_lanes && (rc = dev_alloc(c, &c->d_long_sorted_[b], cap / kLongRun + 64))) return rc;
   }
   if (c->d_xl_hdr && (rc = dev_alloc(c, &c->d_xl_fb, cap / kXLongRun + 64))) return rc;   // (the runs the integer-sum path leaves to k_apply_xlong)
   c->cap_pairs = cap;
@@ -1510,6 +1516,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
       c->pending_join = nullptr;
       HIPCHK(c, hipEventRecord(S.fork, st));
       HIPCHK(c, hipStreamWaitEvent(sl, S.fork, 0));
+      if (sx && c->long_lanes && n_pairs >= c->long_lanes_min_pairs) HIPCHK(c, hipMemsetAsync(c->d_long_hdr_[par], 0, sizeof(LongHdr), sl));
       if (sx) HIPCHK(c, hipStreamWaitEvent(sx, S.fork, 0));
     }
 #define KS_LAUNCH_APPLY_M(MODE, MERGED)                                                                              \
@@ -1541,7 +1548,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     hipLaunchKernelGGL(k_xl_number, dim3(1), dim3(1024), 0, sx, (const unsigned long long*)d_xlong_list,               \
                        (const Counters*)S.d_counters, c->d_xl_runs, c->d_xl_idx, c->d_xl_fb, c->d_xl_hdr,              \
                        c->cap_xl_chunks);                                                                               \
-    hipLaunchKernelGGL(k_xl_chunks, dim3(1024), dim3(256), 0, sx, F, (const uint64_t*)sp, (const RayDesc*)S.d_rays,    \
+    hipLaunchKernelGGL(k_xl_chunks, dim3(4096), dim3(256), 0, sx, F, (const uint64_t*)sp, (const RayDesc*)S.d_rays,    \
                        (const float*)S.d_deltas, c->table, c->d_xl_runs, (const uint32_t*)c->d_xl_idx,                 \
                        (const XlHeader*)c->d_xl_hdr, c->d_xl_chunks);                                                   \
     hipLaunchKernelGGL(k_xl_walk<MODE>, dim3(2048), dim3(64), 0, sx, F, (const uint64_t*)sp, (const RayDesc*)S.d_rays, \
@@ -1553,6 +1560,22 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   } else if (sx)                                                                                                     \
     hipLaunchKernelGGL(k_apply_xlong<MODE>, dim3(xb), dim3(256), 0, sx, F, n_pairs, sp, S.d_rays, S.d_deltas,            \
                        c->table, c->pool, c->d_label_lut, d_xlong_list, (const uint32_t*)&S.d_counters->n_xlong);      \
+  if (sl != st && sx && c->long_lanes && n_pairs >= c->long_lanes_min_pairs) {                                       \
+    const uint32_t cap_long = (uint32_t)(n_pairs / (kLongRun + 1) + 1);                                               \
+    hipLaunchKernelGGL(k_long_measure, dim3((cap_long + 255) / 256), dim3(256), 0, sl, F.seq_bits, n_pairs,           \
+                       (const uint64_t*)sp, d_long_list, (const Counters*)S.d_counters, c->d_long_hdr_[par]);         \
+    hipLaunchKernelGGL(k_long_bucket, dim3((cap_long + 255) / 256), dim3(256), 0, sl,                                 \
+                       (const unsigned long long*)d_long_list, (const Counters*)S.d_counters, c->d_long_hdr_[par],    \
+                       c->d_long_sorted_[par]);                                                                        \
+    hipLaunchKernelGGL(k_apply_long_lanes<MODE>, dim3((cap_long / 64 + kLongClasses + 3) / 4), dim3(256), 0, sl, F,   \
+                       (const uint64_t*)sp, (const RayDesc*)S.d_rays, (const float*)S.d_deltas, c->table, c->pool,     \
+                       (const uint32_t*)c->d_label_lut, (const LongHdr*)c->d_long_hdr_[par],                           \
+                       (const unsigned long long*)c->d_long_sorted_[par]);                                             \
+    hipLaunchKernelGGL(k_apply_long<MODE>, dim3(std::min<uint32_t>(lb, 2048u)), dim3(128), 0, sl, F, n_pairs, sp,     \
+                       S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut,                                        \
+                       (const unsigned long long*)c->d_long_sorted_[par], (const Counters*)S.d_counters,               \
+                       (const LongHdr*)c->d_long_hdr_[par]);                                                           \
+  } else                                                                                                             \
   hipLaunchKernelGGL(k_apply_long<MODE>, dim3(lb), dim3(128), 0, sl, F, n_pairs, sp, S.d_rays, S.d_deltas,               \
                      c->table, c->pool, c->d_label_lut, d_long_list, S.d_counters)
     switch (c->cfg.color_mode) {
@@ -2121,6 +2144,12 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     const char* xp = dbg_env("KS_XLONG");
     c->xlong = xp ? atoi(xp) != 0 : true;
     if (c->xlong && c->stream_long) CRCHK(hipStreamCreateWithFlags(&c->stream_xlong, hipStreamNonBlocking));
+    if (const char* ll = dbg_env("KS_LONG_LANES")) {   // A/B: 0 = k_apply_long (two wavefronts per run) for all of them, 2 = lanes for frames of any size (tests)
+      c->long_lanes = atoi(ll) != 0;
+      if (atoi(ll) == 2) c->long_lanes_min_pairs = 0ull;
+    }
+    if (c->stream_long && c->long_lanes)
+      for (int b = 0; b < 2; ++b) CRCHK(hipMalloc((void**)&c->d_long_hdr_[b], sizeof(LongHdr)));
     if (const char* xl = dbg_env("KS_XL_PARALLEL")) c->xl_parallel = atoi(xl) != 0;   // A/B: 0 = every such run through k_apply_xlong
     if (c->stream_xlong && c->xl_parallel) {
       CRCHK(hipMalloc((void**)&c->d_xl_runs, kXlMaxRuns * sizeof(XlRun)));
@@ -2241,7 +2270,7 @@ void ks_destroy(ks_ctx* c) {
                   c->d_pairs2_[0], c->d_pairs2_[1], c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux, c->d_bo_slab,
                   c->d_eo_keys[0], c->d_eo_keys[1], c->d_eo_vals[0], c->d_eo_vals[1], c->d_eo_range, c->d_eo_plain, c->d_eo_lp, c->d_eo_bt,
-                  c->d_eo_state, c->d_xl_runs, c->d_xl_hdr, c->d_xl_chunks, c->d_xl_idx, c->d_xl_fb, c->d_rx_counts, c->d_tx_keys, c->d_rx_keys, c->d_tx_slots, c->d_tx_payload, c->d_rx_payload};
+                  c->d_eo_state, c->d_xl_runs, c->d_xl_hdr, c->d_xl_chunks, c->d_xl_idx, c->d_xl_fb, c->d_long_sorted_[0], c->d_long_sorted_[1], c->d_long_hdr_[0], c->d_long_hdr_[1], c->d_rx_counts, c->d_tx_keys, c->d_rx_keys, c->d_tx_slots, c->d_tx_payload, c->d_rx_payload};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& S : c->slot) {

@@ -629,12 +629,230 @@ __global__ void __launch_bounds__(256) k_find_long(uint32_t seq_bits, unsigned l
   if (threadIdx.x < n_x) xlong_list[s_xbase + threadIdx.x] = s_xlist[threadIdx.x];
 }
 
+// ------------------------------------------------------------------------------------------
+// The runs of 33 .. kXLongRun updates, A LANE PER RUN (round 6).  At 1280x720 / 2 cm they hold most of a frame's updates
+// (every voxel within a few decimetres of the sensor), and k_apply_long spends two wavefronts on each of them — ~8 wave
+// instructions per update.  Here the runs are bucketed by length over the whole frame (ten classes, lengths within a class
+// within a factor 1.5), 64 runs of a class share a wavefront, and every lane walks its own run with its voxel's record in
+// registers: ~4 wave instructions per update, nothing serial beyond a run's own 33 .. 1024 steps.
+//   k_long_measure   thread per listed run (k_find_long lists where they start): its length by bisection, class counts
+//   k_long_bucket    the list again, class by class (offsets from the ten counts; cursors per class)
+//   k_apply_long_lanes  wavefront per 64 runs of a class; per step and lane: the pair key (the lane's own stream, two steps
+//                    ahead), its ray (one step ahead), computeDistance + weight, the voxel-state update
+// Same operations in the same order per voxel as k_apply_long.
+// ------------------------------------------------------------------------------------------
+constexpr int kLongClasses = 10;
+constexpr int kLongLaneClasses = 6;   // classes 0 .. 5 (33 .. 256 updates) a lane per run; the longer ones two wavefronts per run (k_apply_long)
+struct LongHdr {
+  uint32_t count[kLongClasses];    // runs per class (k_long_measure)
+  uint32_t cursor[kLongClasses];   // k_long_bucket's
+  uint32_t pad[12];
+};
+__device__ __forceinline__ int long_class(uint32_t len) {   // len in kLongRun + 1 .. kXLongRun
+  return len <= 48u ? 0 : len <= 64u ? 1 : len <= 96u ? 2 : len <= 128u ? 3 : len <= 192u ? 4 : len <= 256u ? 5 : len <= 384u ? 6 : len <= 512u ? 7 : len <= 768u ? 8 : 9;
+}
+
+__global__ void __launch_bounds__(256) k_long_measure(uint32_t seq_bits, unsigned long long n_pairs, const uint64_t* __restrict__ pairs,
+                                                      unsigned long long* __restrict__ long_list, const Counters* C, LongHdr* __restrict__ H) {
+  __shared__ uint32_t s_cnt[kLongClasses];
+  if (threadIdx.x < kLongClasses) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t n_long = C->n_long, r = blockIdx.x * 256u + threadIdx.x;
+  if (blockIdx.x * 256u >= n_long) return;
+  if (r < n_long) {
+    const unsigned long long start = long_list[r];
+    const uint32_t vox = (uint32_t)(pairs[start] >> seq_bits);
+    // element kLongRun is this voxel's, element kXLongRun (if it exists) is not (k_find_long): bisect in between
+    unsigned long long lo = kLongRun, hi = kXLongRun;
+    if (start + hi > n_pairs) hi = n_pairs - start;
+    // invariant: element lo belongs to the run, element hi does not (or is the end of the list)
+    while (hi - lo > 1ull) {
+      const unsigned long long mid = lo + ((hi - lo) >> 1);
+      if ((uint32_t)(pairs[start + mid] >> seq_bits) == vox) lo = mid;
+      else hi = mid;
+    }
+    const uint32_t len = (uint32_t)hi;
+    long_list[r] = start | ((unsigned long long)len << 48);
+    atomicAdd(&s_cnt[long_class(len)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kLongClasses && s_cnt[threadIdx.x]) atomicAdd(&H->count[threadIdx.x], s_cnt[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(256) k_long_bucket(const unsigned long long* __restrict__ long_list, const Counters* C,
+                                                     LongHdr* __restrict__ H, unsigned long long* __restrict__ sorted) {
+  __shared__ uint32_t s_cnt[kLongClasses], s_base[kLongClasses];
+  if (threadIdx.x < kLongClasses) s_cnt[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t n_long = C->n_long, r = blockIdx.x * 256u + threadIdx.x;
+  if (blockIdx.x * 256u >= n_long) return;
+  unsigned long long e = 0ull;
+  int c = 0;
+  uint32_t rank = 0u;
+  if (r < n_long) {
+    e = long_list[r];
+    c = long_class((uint32_t)(e >> 48));
+    rank = atomicAdd(&s_cnt[c], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < kLongClasses) {
+    uint32_t off = 0u;
+    for (int k = 0; k < (int)threadIdx.x; ++k) off += H->count[k];
+    s_base[threadIdx.x] = off + (s_cnt[threadIdx.x] ? atomicAdd(&H->cursor[threadIdx.x], s_cnt[threadIdx.x]) : 0u);
+  }
+  __syncthreads();
+  if (r < n_long) sorted[s_base[c] + rank] = e;
+}
+
+template <int COLOR_MODE>
+__global__ void __launch_bounds__(256) k_apply_long_lanes(FrameParams F, const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
+                                                          const float* __restrict__ deltas, TileTable T, Pool P,
+                                                          const uint32_t* __restrict__ label_lut, const LongHdr* __restrict__ H,
+                                                          const unsigned long long* __restrict__ sorted) {
+  constexpr bool BLEND = COLOR_MODE == KS_COLOR_MODE_COLOR;
+  __shared__ uint32_t s_lut[256];
+  s_lut[threadIdx.x] = label_lut[threadIdx.x];
+  __syncthreads();
+  // this wavefront's 64 runs: wavefronts are dealt class by class, ceil(count / 64) each
+  const uint32_t lane = lane_id();
+  uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6), first = 0u, n_mine = 0u;
+  bool found = false;
+#pragma unroll
+  for (int c = 0; c < kLongLaneClasses; ++c) {
+    const uint32_t cnt = H->count[c], waves = (cnt + 63u) >> 6;
+    if (!found) {
+      if (w < waves) {
+        found = true;
+        first += w * 64u;
+        n_mine = cnt - w * 64u < 64u ? cnt - w * 64u : 64u;
+      } else {
+        w -= waves;
+        first += cnt;
+      }
+    }
+  }
+  if (!found) return;
+  const bool has = lane < n_mine;
+  const unsigned long long e = has ? sorted[first + lane] : 0ull;
+  const unsigned long long start = e & 0xffffffffffffull;
+  const uint32_t len = has ? (uint32_t)(e >> 48) : 0u;
+  // A lane's step is a chain key -> ray -> arithmetic, and a run is up to 1024 of them: the keys of the next 2 D steps and the
+  // rays of the next D are in flight while a step is applied (with one step of look-ahead a step cost the latency of its
+  // gather: 0.85 us — a 640x480 frame waited 0.9 ms for its handful of 1000-update runs).  Compile-time slots: the step loop
+  // is unrolled D times.
+  constexpr uint32_t D = 6;
+  uint64_t kq[2 * D];
+  RayDesc dq[D];
+#pragma unroll
+  for (uint32_t i = 0; i < 2 * D; ++i) kq[i] = (i < len) ? pairs[start + i] : 0ull;
+  const uint32_t vox = (uint32_t)(kq[0] >> F.seq_bits);
+  uint4* rec = P.vox + (size_t)vox * 8;
+#pragma unroll
+  for (uint32_t i = 0; i < D; ++i) dq[i] = rays[(i < len) ? ray_index(F, (uint32_t)kq[i] & F.point_mask) : 0u];
+  float p[kNumLabels];
+  float dist = 0.f, weight = 0.f;
+  uint32_t color = 0u;
+  f3 v_voxel_origin = {0.f, 0.f, 0.f};
+  if (has) {
+    const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2], q3 = rec[3], q4 = rec[4], q5 = rec[5];
+    const uint32_t q6 = ((const uint32_t*)rec)[24];
+    dist = __uint_as_float(q0.x);
+    weight = __uint_as_float(q0.y);
+    color = q0.z;
+    p[0] = __uint_as_float(q1.x); p[1] = __uint_as_float(q1.y); p[2] = __uint_as_float(q1.z); p[3] = __uint_as_float(q1.w);
+    p[4] = __uint_as_float(q2.x); p[5] = __uint_as_float(q2.y); p[6] = __uint_as_float(q2.z); p[7] = __uint_as_float(q2.w);
+    p[8] = __uint_as_float(q3.x); p[9] = __uint_as_float(q3.y); p[10] = __uint_as_float(q3.z); p[11] = __uint_as_float(q3.w);
+    p[12] = __uint_as_float(q4.x); p[13] = __uint_as_float(q4.y); p[14] = __uint_as_float(q4.z); p[15] = __uint_as_float(q4.w);
+    p[16] = __uint_as_float(q5.x); p[17] = __uint_as_float(q5.y); p[18] = __uint_as_float(q5.z); p[19] = __uint_as_float(q5.w);
+    p[20] = __uint_as_float(q6);
+    const VoxelRef v = voxel_ref(T, vox);
+    const float vs = F.tsdf.voxel_size;
+    v_voxel_origin = sub3({((float)v.vx + 0.5f) * vs, ((float)v.vy + 0.5f) * vs, ((float)v.vz + 0.5f) * vs}, F.T.t);
+  } else {
+#pragma unroll
+    for (int l = 0; l < kNumLabels; ++l) p[l] = 0.f;
+  }
+  const TsdfParams& Pm = F.tsdf;
+  for (uint32_t g = 0; __ballot(g < len) != 0ull; g += D) {
+#pragma unroll
+    for (uint32_t j = 0; j < D; ++j) {
+      const uint32_t s = g + j;
+      const bool on = s < len;
+      const RayDesc d = dq[j];
+      const uint32_t rp = (uint32_t)kq[j] & F.point_mask;
+      // the slot takes the ray of step s + D (its key arrived a group ago)
+      dq[j] = rays[(s + D < len) ? ray_index(F, (uint32_t)kq[j + D] & F.point_mask) : 0u];
+      if (on) {
+        // computeDistance + weight drop-off (tsdf_operands with the voxel's origin vector hoisted)
+        const f3 v_point_origin = sub3({d.px, d.py, d.pz}, F.T.t);
+        const float dist_G = norm3(v_point_origin);
+        const float dist_G_V = dot3(v_voxel_origin, v_point_origin) / dist_G;
+        const float sdf = dist_G - dist_G_V;
+        float uw = d.weight;
+        if (Pm.use_dropoff && sdf < -Pm.voxel_size) {
+          uw = d.weight * (Pm.trunc + sdf) / Pm.dropoff_denominator;
+          uw = std_max(uw, 0.0f);
+        }
+        if (Pm.use_sparsity) {
+          if (fabsf(sdf) < Pm.trunc) uw *= Pm.sparsity_factor;
+        }
+        // updateTsdfVoxel's state half
+        const float nw = weight + uw;
+        if (!(nw < kEps)) {
+          const float ns = (sdf * uw + dist * weight) / nw;
+          if (BLEND) {
+            if (fabsf(sdf) < Pm.trunc) color = blend_two_colors(color, weight, d.color, uw);
+          }
+          dist = __builtin_amdgcn_fmed3f(ns, -Pm.trunc, Pm.trunc);
+          weight = std_min(Pm.max_weight, nw);
+        }
+        const uint32_t kind = (d.info >> 8) & 3u, lab = d.info & 0xffu;
+        if (kind == 1u) {
+          const float dm = d.d_match, dn = d.d_non;   // (as k_apply_long reads them)
+#pragma unroll
+          for (int l = 0; l < kNumLabels; ++l) p[l] += ((uint32_t)l == lab) ? dm : dn;
+        } else if (kind == 2u) {
+          const float* dl = deltas + (size_t)rp * kNumLabels;
+#pragma unroll
+          for (int l = 0; l < kNumLabels; ++l) p[l] += dl[l];
+        }
+      }
+    }
+    // the keys move up a group; the keys of the group after the next are requested
+#pragma unroll
+    for (uint32_t j = 0; j < D; ++j) {
+      kq[j] = kq[j + D];
+      kq[j + D] = (g + 2 * D + j < len) ? pairs[start + g + 2 * D + j] : 0ull;
+    }
+  }
+  if (has) {
+    float bv = p[0];
+    uint32_t bi = 0u;
+#pragma unroll
+    for (int l = 1; l < kNumLabels; ++l)
+      if (p[l] > bv) {
+        bv = p[l];
+        bi = (uint32_t)l;
+      }
+    if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC) color = s_lut[bi & 255u];
+    else if (COLOR_MODE == KS_COLOR_MODE_SEMANTIC_PROBABILITY) color = rainbow_color_map((double)(float)exp((double)bv));
+    rec[0] = make_uint4(__float_as_uint(dist), __float_as_uint(weight), color, bi);
+    rec[1] = make_uint4(__float_as_uint(p[0]), __float_as_uint(p[1]), __float_as_uint(p[2]), __float_as_uint(p[3]));
+    rec[2] = make_uint4(__float_as_uint(p[4]), __float_as_uint(p[5]), __float_as_uint(p[6]), __float_as_uint(p[7]));
+    rec[3] = make_uint4(__float_as_uint(p[8]), __float_as_uint(p[9]), __float_as_uint(p[10]), __float_as_uint(p[11]));
+    rec[4] = make_uint4(__float_as_uint(p[12]), __float_as_uint(p[13]), __float_as_uint(p[14]), __float_as_uint(p[15]));
+    rec[5] = make_uint4(__float_as_uint(p[16]), __float_as_uint(p[17]), __float_as_uint(p[18]), __float_as_uint(p[19]));
+    rec[6] = make_uint4(__float_as_uint(p[20]), 1u, 0u, 0u);   // dword 25 = 1: updated since the last voxel-level host sync
+  }
+}
+
 template <int COLOR_MODE>
 __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long long n_pairs,
                                                    const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
                                                    const float* __restrict__ deltas, TileTable T, Pool P,
                                                    const uint32_t* __restrict__ label_lut,
-                                                   const unsigned long long* __restrict__ long_list, const Counters* C) {
+                                                   const unsigned long long* __restrict__ long_list, const Counters* C,
+                                                   const LongHdr* __restrict__ H = nullptr) {
   // TWO wavefronts per run.  A lone wave is bound by instruction issue (one instruction every four
   // cycles): wave 0 (producer) gathers the rays of a 64-update batch, evaluates the state-
   // independent half of the update per lane, walks the weight / distance recurrences and writes
@@ -646,13 +864,22 @@ __global__ void __launch_bounds__(128) k_apply_long(FrameParams F, unsigned long
   __shared__ uint32_t s_best;
   __shared__ float s_best_val;
   constexpr int PF = 4;  // batches (of 64 updates) whose ray descriptors are in flight while one batch is applied (8 / 16: measured no faster)
-  const uint32_t n_long = C->n_long;
+  // H != nullptr: `long_list` is k_long_bucket's list, by length class; this kernel takes the classes from kLongLaneClasses on
+  // (the runs of more than 256 updates: a lane per run would walk them for up to 0.6 ms), k_apply_long_lanes the others
+  uint32_t n_long = C->n_long, list_base = 0u;
+  if (H) {
+    n_long = 0u;
+    for (int c = 0; c < kLongClasses; ++c) {
+      if (c < kLongLaneClasses) list_base += H->count[c];
+      else n_long += H->count[c];
+    }
+  }
   const int lane = (int)lane_id();
   const bool consumer = (threadIdx.x >> 6) != 0u;
   const int cls = lane < kNumLabels ? lane : 0;
   const TsdfParams& Pm = F.tsdf;
   for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
-    const unsigned long long start = long_list[run];
+    const unsigned long long start = long_list[list_base + run] & 0xffffffffffffull;   // (bits 48..: the length, in k_long_bucket's list)
     const uint32_t vox = (uint32_t)(pairs[start] >> F.seq_bits);
     const VoxelRef v = voxel_ref(T, vox);
     uint32_t* rec = (uint32_t*)(P.vox + (size_t)vox * 8);

@@ -346,8 +346,8 @@ __global__ void __launch_bounds__(64) k_xl_walk(FrameParams F, const uint64_t* _
                                                 const float* __restrict__ deltas, TileTable T, Pool P, const uint32_t* __restrict__ label_lut,
                                                 XlRun* __restrict__ runs, const uint32_t* __restrict__ xl_idx, XlHeader* __restrict__ hdr,
                                                 const XlChunk* __restrict__ chunks, unsigned long long* __restrict__ fb_list) {
-  __shared__ float s_inc[kXlChunk][kNumLabels];
-  __shared__ float s_uw[kXlChunk];
+  __shared__ float s_inc[64][kNumLabels];   // (a replay takes 64 updates of the chunk at a time)
+  __shared__ float s_uw[64];
   const uint32_t n_runs = hdr->n_runs;
   const int lane = (int)lane_id();
   const int cls = lane < kXlChains ? lane : 0;

@@ -75,8 +75,18 @@ __device__ __forceinline__ void rs_hist_body(const K* __restrict__ keys, uint32_
         if (__ballot(valid && d != d0) == 0ull) {
           if (active && lane == (uint32_t)(__ffsll((long long)active) - 1))
             atomicAdd(&s_hist[p * kBins + d0], (uint32_t)__popcll(active));
-        } else if (valid) {
-          atomicAdd(&s_hist[p * kBins + d], 1u);
+        } else {
+          // neighbouring keys mostly share their upper digits (a ray's consecutive voxels, a voxel's consecutive updates):
+          // ONE add per run of equal digits in lane order — per-lane adds to a handful of counters serialise in LDS
+          // (SQ counters, round 6: 0.92 bank-conflict cycles per LDS cycle, the kernel 2x its streaming time)
+          const uint32_t dp = __shfl_up(d, 1);
+          const unsigned long long lead = __ballot(valid && (lane == 0u || d != dp));
+          if (valid && ((lead >> lane) & 1ull)) {
+            const unsigned long long rest = (lane < 63u) ? (lead >> (lane + 1u)) : 0ull;
+            const uint32_t stop = rest ? lane + (uint32_t)__ffsll((long long)rest) : 64u;      // first lane of the next run
+            const unsigned long long in_run = (stop < 64u ? ((1ull << stop) - 1ull) : ~0ull) & ~((1ull << lane) - 1ull);
+            atomicAdd(&s_hist[p * kBins + d], (uint32_t)__popcll(in_run & active));
+          }
         }
       }
     }

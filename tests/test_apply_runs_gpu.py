@@ -1,6 +1,7 @@
 """-m gpu: k_apply_runs — the voxel update with ONE LANE PER RUN, a tile's runs bucketed by length (csrc/ks_k_apply.h) — is
-what the library uses from 2^20 pairs per frame on (the full-size C4 tests reach it by themselves); here it is forced for
-frames of every size (KS_DEBUG=1 KS_APPLY_RUNS=1) and must leave the oracle's records, bit for bit: both integrators, the
+what the library uses from 2^20 pairs per frame on, and k_apply_long_lanes (the runs of 33 .. 256 updates, a lane per run, bucketed
+by length over the frame) from 2^24 on (the full-size C4 tests reach both by themselves); here they are forced for
+frames of every size (KS_DEBUG=1 KS_APPLY_RUNS=1 KS_LONG_LANES=2) and must leave the oracle's records, bit for bit: both integrators, the
 three colour modes, mixed-label bundles, runs beside the long-run kernels, 2 cm geometry, frames in flight, and A/B against
 k_apply (KS_APPLY_RUNS=0) on the same frames."""
 import pytest
@@ -18,8 +19,10 @@ def _pair(monkeypatch, method, force="1", pipe=0, max_tiles=8192, **kw):
     o = O.Oracle(O.default_config(integrator_threads=1, **okw))
     monkeypatch.setenv("KS_DEBUG", "1")
     monkeypatch.setenv("KS_APPLY_RUNS", force)
+    monkeypatch.setenv("KS_LONG_LANES", "2" if force == "1" else "0")   # the runs of 33 .. 256 updates a lane per run, whatever the frame's size
     h = B.HipIntegrator(B.default_config(max_tiles=max_tiles, max_points=1 << 18, pipeline_frames=pipe, **okw))
     monkeypatch.delenv("KS_APPLY_RUNS")
+    monkeypatch.delenv("KS_LONG_LANES")
     monkeypatch.delenv("KS_DEBUG")
     return o, h
 

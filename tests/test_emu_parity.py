@@ -167,8 +167,9 @@ def test_axis_parallel_rays_under_the_early_out_equal_oracle(emu_jobs, request, 
     check_case(emu_jobs, request)
 
 
-# k_apply_runs (a lane per voxel run, runs bucketed by length in a tile of 2048 pairs) instead of k_apply: forced for frames of
-# any size (the library takes it from 2^20 pairs per frame on); the records must be the same bit for bit
+# k_apply_runs (a lane per voxel run, runs bucketed by length in a tile of 2048 pairs) instead of k_apply, and k_apply_long_lanes
+# (the runs of 33 .. 256 updates a lane per run, bucketed by length over the frame) beside k_apply_long: forced for frames of
+# any size (the library takes them from 2^20 / 2^24 pairs per frame on); the records must be the same bit for bit
 RUNS_CASES = {
     "fast_no_early_out": dict(method=0, size=[64, 48], frames=2, no_early_out=True),
     "fast_colour_blend": dict(method=0, size=[64, 48], frames=2, no_early_out=True, cfg=dict(color_mode=0)),
@@ -182,7 +183,7 @@ RUNS_CASES = {
     "merged_sensor_voxel_integer_sums": dict(method=1, size=[96, 72], frames=4, fixed_pose=True, cfg=dict(max_weight=2.0), xl_walked_at_least=1),
 }
 for _name, _spec in RUNS_CASES.items():
-    case_job("test_lane_per_run_update_kernel_equals_oracle[%s]" % _name, _spec, env_extra={"KS_DEBUG": "1", "KS_APPLY_RUNS": "1"},
+    case_job("test_lane_per_run_update_kernel_equals_oracle[%s]" % _name, _spec, env_extra={"KS_DEBUG": "1", "KS_APPLY_RUNS": "1", "KS_LONG_LANES": "2"},
              weight=40 if "close_up" in _name else 10)
 
 

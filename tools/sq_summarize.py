@@ -34,7 +34,7 @@ def main():
         for r in csv.DictReader(open(f[0])):
             dur[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     print(f"# workload {sys.argv[2] if len(sys.argv) > 2 else ''}: per kernel, mean over its launches (us from the un-instrumented timing pass)")
-    want = ["k_apply", "k_apply_xlong", "k_apply_long", "k_emit_lane", "k_rs_pass", "k_rs_hist", "k_find_long", "k_apply_runs", "k_list_runs", "k_eo2_sweep", "k_test"]
+    want = ["k_xl", "k_apply", "k_apply_xlong", "k_apply_long", "k_emit_lane", "k_rs_pass", "k_rs_hist", "k_find_long", "k_apply_runs", "k_list_runs", "k_eo2_sweep", "k_test"]
     for k in sorted(per, key=lambda k: -sum(dur.get(k, [0]))):
         if not any(k.startswith(w) for w in want):
             continue
