@@ -295,6 +295,26 @@ typedef struct ks_reduce_stats {
 } ks_reduce_stats;
 int ks_reduce(ks_ctx* ctx, void* rccl_comm, int rank, int world, ks_reduce_stats* stats);
 
+/* EXACT frame-sharded integration of `fast` — one ROUND: `world` consecutive frames, frame first_frame + r marched by rank r.
+ * COLLECTIVE: every rank calls it once per round (a rank without a frame passes n = 0), rounds in frame order.
+ * `marcher` casts this rank's frame — stage A, the early-out, the emission, with the approximate sets' offsets of that GLOBAL
+ * frame number — against a slot numbering of its own and evaluates the state-independent half of every update; each update
+ * travels to the rank that owns its voxel's tile (ks_tile_owner) as 20 bytes { tile key << 9 | voxel in tile, info byte <<
+ * 24 | integration position, sdf, update weight }; `owner` applies the frames of the round in frame order.  The tiles a rank
+ * owns are then, bit for bit, what ONE context integrating all frames in order holds for them (new: the reference is a
+ * single process; replaces merging per-rank maps with ks_reduce, which is a different arithmetic — SURVEY.md par. 8e).
+ * Both contexts: method fast, colours from the labels, pipeline_frames = 0, "mixed" order, clear_checks_every_n_frames = 1 (or the
+ * early-out off); same configuration on every rank; `marcher` is used for nothing else (its map stays empty of data).
+ * origin_voxel_touched: a frame of the round updated the voxel whose index hashes to 0 (the world origin) — the one place
+ * where the reference's approximate sets couple frames (their zero-initialised slots "contain" hash 0), i.e. where the
+ * result may differ from the sequential one.  world = 1 needs no communicator. */
+typedef struct ks_round_stats {
+  uint64_t updates_marched, updates_applied, bytes_sent, origin_voxel_touched, rays_cast;
+} ks_round_stats;
+int ks_integrate_round_exact(ks_ctx* marcher, ks_ctx* owner, void* rccl_comm, int rank, int world, uint64_t first_frame,
+                             const float T_G_C[7], const float* xyz, const uint8_t* rgba, const uint8_t* labels, size_t n,
+                             int freespace_points, ks_round_stats* stats);
+
 /* Diagnostics (used by tests): stable LSD radix sort of n HOST keys (key_bits = 32 or 64, bits
  * [0,end_bit)) and optional u32 payload with the library's own GPU sort. */
 int ks_debug_radix_sort(ks_ctx* ctx, void* keys, uint32_t* vals, size_t n, int key_bits, unsigned end_bit);

@@ -35,7 +35,7 @@ ABI_SYMBOLS = [
     "ks_integrate_points", "ks_integrate_points_device", "ks_integrate_depth", "ks_integrate_depth_device", "ks_num_blocks", "ks_get_block_indices",
     "ks_get_updated_block_indices", "ks_count_updated_voxels", "ks_download_updated_voxels", "ks_download_blocks", "ks_upload_blocks", "ks_host_alloc", "ks_host_free", "ks_get_tile_keys", "ks_export_tiles_device", "ks_merge_tiles_device", "ks_clear", "ks_clear_voxels", "ks_reset_tiles", "ks_tile_owner", "ks_reduce",
     "ks_debug_radix_sort", "ks_synchronize", "ks_flush", "ks_stream",
-    "ks_profile_enable", "ks_profile_get", "ks_early_out_iterations", "ks_early_out_stats", "ks_pipeline_shape", "ks_update_stats",
+    "ks_profile_enable", "ks_profile_get", "ks_early_out_iterations", "ks_early_out_stats", "ks_pipeline_shape", "ks_update_stats", "ks_integrate_round_exact",
 ]
 
 
@@ -57,6 +57,11 @@ class KsConfig(C.Structure):
         ("early_out_phase_growth", C.c_int32),
         ("device_id", C.c_int32), ("max_tiles", C.c_uint32), ("max_points", C.c_uint32), ("pipeline_frames", C.c_int32),
     ]
+
+
+class KsRoundStats(C.Structure):
+    _fields_ = [("updates_marched", C.c_uint64), ("updates_applied", C.c_uint64), ("bytes_sent", C.c_uint64),
+                ("origin_voxel_touched", C.c_uint64), ("rays_cast", C.c_uint64)]
 
 
 class KsFrameStats(C.Structure):
@@ -142,6 +147,7 @@ def lib():
         L.ks_early_out_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
         L.ks_pipeline_shape.argtypes = [vp, C.POINTER(C.c_int32)]
         L.ks_update_stats.argtypes = [vp, C.POINTER(C.c_uint64)]
+        L.ks_integrate_round_exact.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_uint64, vp, vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(KsRoundStats)]
         _lib = L
     return _lib
 
@@ -373,6 +379,21 @@ class HipIntegrator:
         out = (C.c_uint64 * 5)()
         self._chk(lib().ks_early_out_stats(self._h, out))
         return dict(frames=int(out[0]), rounds=int(out[1]), fallbacks=int(out[2]), event_driven=bool(out[3]), pipelined=bool(out[4]))
+
+    def integrate_round_exact(self, marcher: "HipIntegrator", rccl_comm, rank: int, world: int, first_frame: int, T_G_C, xyz, rgba, labels,
+                              freespace=False) -> dict:
+        """self = the OWNER context of this rank; `marcher` casts this rank's frame of the round (ks_integrate_round_exact)."""
+        T = np.ascontiguousarray(T_G_C, dtype=np.float32)
+        n = 0 if xyz is None else len(xyz)
+        x = None if xyz is None else np.ascontiguousarray(xyz, dtype=np.float32)
+        c = None if rgba is None else np.ascontiguousarray(rgba, dtype=np.uint8)
+        l = None if labels is None else np.ascontiguousarray(labels, dtype=np.uint8)
+        st = KsRoundStats()
+        self._chk(lib().ks_integrate_round_exact(marcher._h, self._h, rccl_comm, int(rank), int(world), int(first_frame), _ptr(T),
+                                                 _ptr(x) if x is not None else None, _ptr(c) if c is not None else None,
+                                                 _ptr(l) if l is not None else None, n, int(bool(freespace)), C.byref(st)))
+        return dict(updates_marched=int(st.updates_marched), updates_applied=int(st.updates_applied), bytes_sent=int(st.bytes_sent),
+                    origin_voxel_touched=bool(st.origin_voxel_touched), rays_cast=int(st.rays_cast))
 
     def update_stats(self):
         """Runs of more than 1024 updates: dict(walked, serial, chunks, replayed) — ks_update_stats."""

@@ -63,6 +63,7 @@ using namespace ksd;
 #include "ks_k_exact.h"
 #include "ks_k_apply.h"
 #include "ks_k_apply_xl.h"
+#include "ks_k_shard.h"
 #include "ks_k_io.h"
 
 using namespace ksk;
@@ -332,6 +333,24 @@ struct ks_ctx {
   XlHeader* d_xl_hdr = nullptr;
   XlChunk* d_xl_chunks = nullptr;
   uint32_t* d_xl_idx = nullptr;
+  // ks_integrate_round_exact (ks_k_shard.h).  A MARCHER context: frame_tail ends with the frame's updates as records grouped by
+  // owner (sh_out[*]), nothing is applied; an OWNER context: scratch for the records of one frame of a round.
+  bool shard_export = false;
+  int shard_world = 1;
+  uint64_t shard_frames_seen = 0;        // global frames this marcher has accounted for (its own, and empty ones for the other ranks')
+  uint64_t* d_sh_okey[2] = {nullptr, nullptr};
+  uint64_t* d_sh_gkey[2] = {nullptr, nullptr};
+  uint32_t* d_sh_seq[2] = {nullptr, nullptr};
+  float* d_sh_sdf[2] = {nullptr, nullptr};
+  float* d_sh_uw[2] = {nullptr, nullptr};
+  uint32_t* d_sh_counts = nullptr;       // [64] per owner + [64] the origin-voxel flag
+  size_t cap_sh = 0;
+  uint32_t sh_counts[65] = {0};          // the last exported frame's
+  uint64_t sh_exported = 0;              // its update count
+  uint64_t* d_sh_tk = nullptr;           // owner: tile keys / pair keys / record numbers of the segment being applied
+  uint64_t* d_sh_pairs[2] = {nullptr, nullptr};
+  uint32_t* d_sh_vals[2] = {nullptr, nullptr};
+  size_t cap_sh_rx = 0;
   // the runs of 33 .. 1024 updates a lane per run, bucketed by length over the frame (k_apply_long_lanes); by parity, like the lists
   bool long_lanes = true;
   unsigned long long long_lanes_min_pairs = 1ull << 24;   // (below: too few such runs to fill wavefronts with — k_apply_long takes them all)
@@ -1318,6 +1337,42 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
 }
 
 // ---- tail half: sized by the snapshot --------------------------------------------------------
+// Marcher: records of the frame in S (ks_k_shard.h), stable-partitioned by owner into d_sh_*[1]; counts on the host.
+int shard_export_frame(ks_ctx* c, FrameSlot& S, unsigned long long n_pairs, hipStream_t st) {
+  const int world = c->shard_world;
+  int rc;
+  if (n_pairs > c->cap_sh) {
+    const size_t cap = std::max<size_t>(n_pairs + n_pairs / 4, 1 << 20);
+    for (int b = 0; b < 2; ++b) {
+      if ((rc = dev_alloc(c, &c->d_sh_okey[b], cap))) return rc;
+      if ((rc = dev_alloc(c, &c->d_sh_gkey[b], cap))) return rc;
+      if ((rc = dev_alloc(c, &c->d_sh_seq[b], cap))) return rc;
+      if ((rc = dev_alloc(c, &c->d_sh_sdf[b], cap))) return rc;
+      if ((rc = dev_alloc(c, &c->d_sh_uw[b], cap))) return rc;
+    }
+    c->cap_sh = cap;
+  }
+  if (!c->d_sh_counts && (rc = dev_alloc(c, &c->d_sh_counts, 128))) return rc;
+  HIPCHK(c, hipMemsetAsync(c->d_sh_counts, 0, 128 * sizeof(uint32_t), st));
+  std::memset(c->sh_counts, 0, sizeof(c->sh_counts));
+  c->sh_exported = n_pairs;
+  if (n_pairs) {
+    const uint32_t nb = (uint32_t)((n_pairs + 255) / 256);
+    hipLaunchKernelGGL(k_shard_export, dim3(nb), dim3(256), 0, st, S.F, n_pairs, (const uint64_t*)S.d_pairs, (const RayDesc*)S.d_rays,
+                       (const uint64_t*)c->table.slot_keys, (uint32_t)world, c->d_sh_okey[0], c->d_sh_gkey[0], c->d_sh_seq[0],
+                       c->d_sh_sdf[0], c->d_sh_uw[0], c->d_sh_counts);
+    uint64_t* sorted = nullptr;
+    HIPCHK(c, (ksrs::sort<uint64_t, false>(c->sort_ws_tail, c->d_sh_okey[0], c->d_sh_okey[1], nullptr, nullptr, (size_t)n_pairs, 64, st,
+                                           &sorted, nullptr, 56)));
+    hipLaunchKernelGGL(k_shard_gather, dim3(nb), dim3(256), 0, st, n_pairs, (const uint64_t*)sorted, (const uint64_t*)c->d_sh_gkey[0],
+                       (const uint32_t*)c->d_sh_seq[0], (const float*)c->d_sh_sdf[0], (const float*)c->d_sh_uw[0], c->d_sh_gkey[1],
+                       c->d_sh_seq[1], c->d_sh_sdf[1], c->d_sh_uw[1]);
+    HIPCHK(c, hipMemcpyAsync(c->sh_counts, c->d_sh_counts, 65 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(c, hipStreamSynchronize(st));
+  return KS_OK;
+}
+
 int frame_tail(ks_ctx* c, FrameSlot& S) {
   if (!S.pending) return KS_OK;
   S.pending = false;
@@ -1476,6 +1531,19 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     return KS_ERR_INDEX_RANGE;
   }
   const unsigned long long n_pairs = cnt.n_pairs;
+  if (c->shard_export) {
+    // a marcher of ks_integrate_round_exact: the frame's updates leave as records, grouped by the rank that owns their tile
+    for (int e = 7; e < kStageEvents - 1; ++e) stage_mark(c, set, e);
+    if (int rc = shard_export_frame(c, S, n_pairs, st)) return rc;
+    finish_prof(n_pairs);
+    HIPCHK(c, hipEventRecord(S.tail_done, st));
+    S.tail_recorded = true;
+    c->owed.n_points += S.n;
+    c->owed.n_valid_points += cnt.n_valid;
+    c->owed.n_rays_cast += cnt.n_rays;
+    c->owed.n_voxel_updates += n_pairs;
+    return KS_OK;
+  }
   if (n_pairs == 0 && c->pending_join) {
     // a frame without updates still separates the frame before it from the one after it, which share a parity
     // buffer set: the long runs of the previous frame end before anything later is enqueued on the tail stream
@@ -1571,7 +1639,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
                        (const uint64_t*)sp, (const RayDesc*)S.d_rays, (const float*)S.d_deltas, c->table, c->pool,     \
                        (const uint32_t*)c->d_label_lut, (const LongHdr*)c->d_long_hdr_[par],                           \
                        (const unsigned long long*)c->d_long_sorted_[par]);                                             \
-    hipLaunchKernelGGL(k_apply_long<MODE>, dim3(std::min<uint32_t>(lb, 2048u)), dim3(128), 0, sl, F, n_pairs, sp,     \
+    hipLaunchKernelGGL(k_apply_long<MODE>, dim3(std::min<uint32_t>(lb, 1024u)), dim3(128), 0, sl, F, n_pairs, sp,     \
                        S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut,                                        \
                        (const unsigned long long*)c->d_long_sorted_[par], (const Counters*)S.d_counters,               \
                        (const LongHdr*)c->d_long_hdr_[par]);                                                           \
@@ -2270,7 +2338,7 @@ void ks_destroy(ks_ctx* c) {
                   c->d_pairs2_[0], c->d_pairs2_[1], c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux, c->d_bo_slab,
                   c->d_eo_keys[0], c->d_eo_keys[1], c->d_eo_vals[0], c->d_eo_vals[1], c->d_eo_range, c->d_eo_plain, c->d_eo_lp, c->d_eo_bt,
-                  c->d_eo_state, c->d_xl_runs, c->d_xl_hdr, c->d_xl_chunks, c->d_xl_idx, c->d_xl_fb, c->d_long_sorted_[0], c->d_long_sorted_[1], c->d_long_hdr_[0], c->d_long_hdr_[1], c->d_rx_counts, c->d_tx_keys, c->d_rx_keys, c->d_tx_slots, c->d_tx_payload, c->d_rx_payload};
+                  c->d_eo_state, c->d_xl_runs, c->d_xl_hdr, c->d_xl_chunks, c->d_xl_idx, c->d_xl_fb, c->d_long_sorted_[0], c->d_long_sorted_[1], c->d_long_hdr_[0], c->d_long_hdr_[1], c->d_sh_okey[0], c->d_sh_okey[1], c->d_sh_gkey[0], c->d_sh_gkey[1], c->d_sh_seq[0], c->d_sh_seq[1], c->d_sh_sdf[0], c->d_sh_sdf[1], c->d_sh_uw[0], c->d_sh_uw[1], c->d_sh_counts, c->d_sh_tk, c->d_sh_pairs[0], c->d_sh_pairs[1], c->d_sh_vals[0], c->d_sh_vals[1], c->d_rx_counts, c->d_tx_keys, c->d_rx_keys, c->d_tx_slots, c->d_tx_payload, c->d_rx_payload};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& S : c->slot) {
@@ -2946,6 +3014,182 @@ int ks_reduce(ks_ctx* c, void* rccl_comm, int rank, int world, ks_reduce_stats* 
     stats->tiles_sent = n_send;
     stats->tiles_received = n_recv;
     stats->bytes_sent = n_send * (uint64_t)(KS_TILE_BYTES + 8);
+  }
+  return KS_OK;
+}
+
+// Owner: one frame's records (of the tiles this rank owns, in integration order) into the map.
+static int shard_apply_segment(ks_ctx* o, const uint64_t* d_gkey, const uint32_t* d_seq, const float* d_sdf, const float* d_uw, size_t n) {
+  if (n == 0) return KS_OK;
+  if (n >= (size_t)1 << 31) { o->err = "ks_integrate_round_exact: more than 2^31 updates of one frame for one owner"; return KS_ERR_INVALID_ARG; }
+  int rc;
+  if (n > o->cap_sh_rx) {
+    const size_t cap = std::max<size_t>(n + n / 4, 1 << 18);
+    if ((rc = dev_alloc(o, &o->d_sh_tk, cap))) return rc;
+    for (int b = 0; b < 2; ++b) {
+      if ((rc = dev_alloc(o, &o->d_sh_pairs[b], cap))) return rc;
+      if ((rc = dev_alloc(o, &o->d_sh_vals[b], cap))) return rc;
+    }
+    o->cap_sh_rx = cap;
+  }
+  hipStream_t st = o->stream;
+  const uint32_t nb = (uint32_t)((n + 255) / 256);
+  hipLaunchKernelGGL(k_shard_tile_keys, dim3(nb), dim3(256), 0, st, (uint32_t)n, d_gkey, o->d_sh_tk);
+  if ((rc = insert_tiles(o, o->d_sh_tk, n))) return rc;   // get-or-insert + initialisation of the new tiles (the pool grows if it must)
+  hipLaunchKernelGGL(k_shard_import, dim3(nb), dim3(256), 0, st, (uint32_t)n, o->table, o->pool, d_gkey, d_seq, o->d_sh_pairs[0], o->d_sh_vals[0]);
+  const unsigned end_bit = kShardSeqBits + 9 + bits_for(o->tiles_initialised);
+  uint64_t* kres = nullptr;
+  uint32_t* vres = nullptr;
+  // stable: a voxel's updates stay in the order they were emitted in = the integration order
+  HIPCHK(o, (ksrs::sort<uint64_t, true>(o->sort_ws, o->d_sh_pairs[0], o->d_sh_pairs[1], o->d_sh_vals[0], o->d_sh_vals[1], n, std::min(56u, end_bit), st,
+                                        &kres, &vres, kShardSeqBits)));
+  FrameParams F{};
+  const ks_config& cfg = o->cfg;
+  F.log_match = o->log_match;
+  F.log_non_match = o->log_non_match;
+  F.tsdf.voxel_size = cfg.voxel_size;
+  F.tsdf.trunc = cfg.truncation_distance;
+  F.tsdf.max_weight = cfg.max_weight;
+  F.tsdf.dropoff_denominator = cfg.truncation_distance - cfg.voxel_size;
+  F.tsdf.sparsity_factor = cfg.sparsity_compensation_factor;
+  F.tsdf.use_dropoff = cfg.use_weight_dropoff;
+  F.tsdf.use_sparsity = cfg.use_sparsity_compensation_factor;
+  if (cfg.color_mode == KS_COLOR_MODE_SEMANTIC)
+    hipLaunchKernelGGL(k_shard_apply<KS_COLOR_MODE_SEMANTIC>, dim3(nb), dim3(256), 0, st, F, (uint32_t)n, (const uint64_t*)kres, (const uint32_t*)vres, d_sdf,
+                       d_uw, o->pool, (const uint32_t*)o->d_label_lut);
+  else
+    hipLaunchKernelGGL(k_shard_apply<KS_COLOR_MODE_SEMANTIC_PROBABILITY>, dim3(nb), dim3(256), 0, st, F, (uint32_t)n, (const uint64_t*)kres,
+                       (const uint32_t*)vres, d_sdf, d_uw, o->pool, (const uint32_t*)o->d_label_lut);
+  HIPCHK(o, hipStreamSynchronize(st));
+  HIPCHK(o, hipGetLastError());
+  return KS_OK;
+}
+
+int ks_integrate_round_exact(ks_ctx* m, ks_ctx* o, void* rccl_comm, int rank, int world, uint64_t first_frame, const float T[7],
+                             const float* xyz, const uint8_t* rgba, const uint8_t* labels, size_t n, int freespace, ks_round_stats* stats) {
+  if (!m || !o || m == o || !T || world < 1 || world > 64 || rank < 0 || rank >= world || (world > 1 && !rccl_comm) || (n && !xyz))
+    return KS_ERR_INVALID_ARG;
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (m->fatal || o->fatal) return KS_ERR_INVALID_ARG;
+  for (ks_ctx* c : {m, o}) {
+    const ks_config& k = c->cfg;
+    const bool frames_independent = !c->uses_early_out || k.clear_checks_every_n_frames <= 1;
+    if (k.method != KS_METHOD_FAST || k.color_mode == KS_COLOR_MODE_COLOR || k.pipeline_frames != 0 || !frames_independent ||
+        k.integration_order_mode == KS_ORDER_SORTED) {
+      c->err = "ks_integrate_round_exact: `fast`, colours from the labels, one frame at a time, mixed order, clear_checks_every_n_frames = 1 "
+               "(anything else: integrate per rank and ks_reduce)";
+      return KS_ERR_UNSUPPORTED;
+    }
+  }
+  int rc;
+  const uint64_t my_frame = first_frame + (uint64_t)rank;
+  if (m->shard_frames_seen > my_frame) {
+    m->err = "ks_integrate_round_exact: rounds must come in frame order";
+    return KS_ERR_INVALID_ARG;
+  }
+  m->shard_export = true;
+  m->shard_world = world;
+  // the frames other ranks march in between advance this marcher's set offsets and frame counters like empty clouds
+  // ([K:src/semantic_tsdf_integrator_fast.cpp:165-170]: the bookkeeping is per call)
+  static const uint8_t no_label = 0;
+  const float T0[7] = {1.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (; m->shard_frames_seen < my_frame; ++m->shard_frames_seen)
+    if ((rc = ks_integrate_points(m, T0, nullptr, nullptr, &no_label, 0, 0, nullptr))) return rc;
+  std::memset(m->sh_counts, 0, sizeof(m->sh_counts));
+  m->sh_exported = 0;
+  ks_frame_stats fst{};
+  if ((rc = ks_integrate_points(m, T, xyz, rgba, labels ? labels : (rgba ? nullptr : &no_label), n, freespace, &fst))) return rc;
+  ++m->shard_frames_seen;
+  // where this frame's records sit, by owner
+  std::vector<size_t> send_counts(world), send_off(world + 1, 0);
+  for (int p = 0; p < world; ++p) {
+    send_counts[p] = m->sh_counts[p];
+    send_off[p + 1] = send_off[p] + send_counts[p];
+  }
+  if (send_off[world] != m->sh_exported) {
+    m->err = "ks_integrate_round_exact: the per-owner counts do not add up to the frame's updates";
+    return KS_ERR_HIP;
+  }
+  uint64_t applied = 0, origin = m->sh_counts[world];
+  if (world == 1) {
+    if ((rc = shard_apply_segment(o, m->d_sh_gkey[1], m->d_sh_seq[1], m->d_sh_sdf[1], m->d_sh_uw[1], send_counts[0]))) return rc;
+    applied = send_counts[0];
+  } else {
+    std::string why;
+    if (!g_rccl.load(&why)) {
+      o->err = why;
+      return KS_ERR_UNSUPPORTED;
+    }
+    ncclComm_t comm = (ncclComm_t)rccl_comm;
+    hipStream_t st = o->stream;
+    // 1) everybody's counts (and origin-voxel flags): (world + 1) x world
+    if ((rc = ensure_reduce_scratch(o, 0, 0, world + 1))) return rc;
+    int32_t* d_own = o->d_rx_counts;
+    int32_t* d_all = d_own + (world + 1);
+    std::vector<int32_t> own(world + 1);
+    for (int p = 0; p < world; ++p) own[p] = (int32_t)send_counts[p];
+    own[world] = (int32_t)m->sh_counts[world];
+    HIPCHK(o, hipMemcpyAsync(d_own, own.data(), own.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    NCCLCHK(o, g_rccl.all_gather(d_own, d_all, (size_t)world + 1, ncclInt32, comm, st));
+    std::vector<int32_t> all((size_t)(world + 1) * world);
+    HIPCHK(o, hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(o, hipStreamSynchronize(st));
+    std::vector<size_t> recv_counts(world), recv_off(world + 1, 0);
+    for (int p = 0; p < world; ++p) {
+      recv_counts[p] = p == rank ? 0 : (size_t)all[(size_t)p * (world + 1) + rank];
+      recv_off[p + 1] = recv_off[p] + recv_counts[p];
+      origin |= (uint64_t)all[(size_t)p * (world + 1) + world];
+    }
+    const size_t n_recv = recv_off[world];
+    // 2) receive buffers on the owner context (its own d_sh_*[0]: an owner context never exports)
+    if (n_recv > o->cap_sh) {
+      const size_t cap = std::max<size_t>(n_recv + n_recv / 4, 1 << 18);
+      if ((rc = dev_alloc(o, &o->d_sh_gkey[0], cap))) return rc;
+      if ((rc = dev_alloc(o, &o->d_sh_seq[0], cap))) return rc;
+      if ((rc = dev_alloc(o, &o->d_sh_sdf[0], cap))) return rc;
+      if ((rc = dev_alloc(o, &o->d_sh_uw[0], cap))) return rc;
+      o->cap_sh = cap;
+    }
+    // 3) one grouped exchange: every rank talks to all its peers at once (xGMI is point to point)
+    NCCLCHK(o, g_rccl.group_start());
+    for (int peer = 0; peer < world; ++peer) {
+      if (peer == rank) continue;
+      if (send_counts[peer]) {
+        NCCLCHK(o, g_rccl.send(m->d_sh_gkey[1] + send_off[peer], send_counts[peer], ncclUint64, peer, comm, st));
+        NCCLCHK(o, g_rccl.send(m->d_sh_seq[1] + send_off[peer], send_counts[peer], ncclUint32, peer, comm, st));
+        NCCLCHK(o, g_rccl.send(m->d_sh_sdf[1] + send_off[peer], send_counts[peer], ncclFloat32, peer, comm, st));
+        NCCLCHK(o, g_rccl.send(m->d_sh_uw[1] + send_off[peer], send_counts[peer], ncclFloat32, peer, comm, st));
+      }
+      if (recv_counts[peer]) {
+        NCCLCHK(o, g_rccl.recv(o->d_sh_gkey[0] + recv_off[peer], recv_counts[peer], ncclUint64, peer, comm, st));
+        NCCLCHK(o, g_rccl.recv(o->d_sh_seq[0] + recv_off[peer], recv_counts[peer], ncclUint32, peer, comm, st));
+        NCCLCHK(o, g_rccl.recv(o->d_sh_sdf[0] + recv_off[peer], recv_counts[peer], ncclFloat32, peer, comm, st));
+        NCCLCHK(o, g_rccl.recv(o->d_sh_uw[0] + recv_off[peer], recv_counts[peer], ncclFloat32, peer, comm, st));
+      }
+    }
+    NCCLCHK(o, g_rccl.group_end());
+    HIPCHK(o, hipStreamSynchronize(st));
+    // 4) the frames of the round in frame order = in the order of the ranks that marched them
+    for (int src = 0; src < world; ++src) {
+      if (src == rank) {
+        if ((rc = shard_apply_segment(o, m->d_sh_gkey[1] + send_off[rank], m->d_sh_seq[1] + send_off[rank], m->d_sh_sdf[1] + send_off[rank],
+                                      m->d_sh_uw[1] + send_off[rank], send_counts[rank])))
+          return rc;
+        applied += send_counts[rank];
+      } else {
+        if ((rc = shard_apply_segment(o, o->d_sh_gkey[0] + recv_off[src], o->d_sh_seq[0] + recv_off[src], o->d_sh_sdf[0] + recv_off[src],
+                                      o->d_sh_uw[0] + recv_off[src], recv_counts[src])))
+          return rc;
+        applied += recv_counts[src];
+      }
+    }
+    if (stats) stats->bytes_sent = (m->sh_exported - send_counts[rank]) * 20ull;
+  }
+  if (stats) {
+    stats->updates_marched = m->sh_exported;
+    stats->updates_applied = applied;
+    stats->origin_voxel_touched = origin ? 1 : 0;
+    stats->rays_cast = fst.n_rays_cast;
   }
   return KS_OK;
 }

@@ -44,6 +44,39 @@ def export_all(h, torch=None):
     return keys, rec
 
 
+def round_config_kw():
+    from kimera_semantics_amd import synth
+    return dict(semantic_measurement_probability=0.8, dynamic_labels=[20], label_rgba=synth.default_label_colors(),
+                method=0, voxels_per_side=8)   # `fast`, the reference's default early-out: the library's default mode
+
+
+def round_frames(n_frames, w=160, h=120):
+    """The frames of tests/test_reduce_multiprocess_gpu.py::test_exact_round_*: overlapping views of one wall, by GLOBAL frame number."""
+    from kimera_semantics_amd import synth
+    sc = synth.make_scene("room")
+    return [synth.render_frame(sc, synth.arc_pose(k, n_frames, spacing=0.25), w, h, seed=800 + k) for k in range(n_frames)]
+
+
+def main_round(rank, world, comm, out, n_rounds):
+    """ks_integrate_round_exact: this rank marches frame round * world + rank of every round and applies, per round, what the
+    tiles it owns receive from every rank, in frame order."""
+    from kimera_semantics_amd import binding as B
+    frames = round_frames(world * n_rounds)
+    marcher = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **round_config_kw()))
+    owner = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **round_config_kw()))
+    stats = []
+    for r in range(n_rounds):
+        f = frames[r * world + rank]
+        stats.append(owner.integrate_round_exact(marcher, comm, rank, world, r * world, f.T_G_C, f.xyz, f.rgba, f.labels))
+    keys, rec = export_all(owner)
+    np.savez(os.path.join(out, f"round_rank{rank}.npz"), keys=keys, rec=rec[:, :, :25],
+             marched=np.array([s["updates_marched"] for s in stats]), applied=np.array([s["updates_applied"] for s in stats]),
+             sent=np.array([s["bytes_sent"] for s in stats]), origin=np.array([int(s["origin_voxel_touched"]) for s in stats]))
+    marcher.close()
+    owner.close()
+    print("round worker", rank, "ok", stats)
+
+
 def main():
     import time
     t0 = time.time()
@@ -58,6 +91,8 @@ def main():
     comm = C.c_void_p()
     lib.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
     assert lib.ncclCommInitRank(C.byref(comm), world, uid, rank) == 0
+    if len(sys.argv) > 5 and sys.argv[5].startswith("round"):
+        return main_round(rank, world, comm.value, out, int(sys.argv[5].split(":")[1]))
     t1 = time.time()
     h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **config_kw()))   # small pool: it has to grow (frames and received tiles)
     t2 = time.time()

@@ -281,8 +281,8 @@ def test_full_reset_of_the_sets_after_10000_frames_pipelined_with_a_fallback_bes
     small ones, so a fallback to the host-driven loop, the growth of the buffers and the drain of the pipeline coincide with the
     full reset.  Every frame's counts and the final map equal the serial oracle's, bit for bit."""
     monkeypatch.setenv("KS_DEBUG", "1")
-    monkeypatch.setenv("KS_EXACT_CAP_MARKS", "120000")
-    monkeypatch.setenv("KS_EXACT_CAP_X", "4096")
+    monkeypatch.setenv("KS_EXACT_CAP_MARKS", "60000")
+    monkeypatch.setenv("KS_EXACT_CAP_X", "2048")
     okw = dict(COMMON, method=0)
     o = O.Oracle(O.default_config(integrator_threads=1, **okw))
     h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 14, pipeline_frames=pipe, **okw))
@@ -290,7 +290,7 @@ def test_full_reset_of_the_sets_after_10000_frames_pipelined_with_a_fallback_bes
     monkeypatch.delenv("KS_EXACT_CAP_X")
     assert h.pipeline_shape()["lag"] == pipe and h.pipeline_shape()["batch"] == (8 if pipe == 16 else 4)
     sc = synth.make_scene("room")
-    small = [synth.render_frame(sc, synth.trajectory_pose(k), 48, 36, seed=k) for k in range(8)]
+    small = [synth.render_frame(sc, synth.trajectory_pose(k), 24, 18, seed=k) for k in range(8)]   # (the serial oracle is the cost: ~5 ms per such frame)
     big = [synth.render_frame(sc, synth.trajectory_pose(2 * k), 128, 96, seed=500 + k) for k in range(4)]
     n_frames, first_big = 10050, 9998   # the table is cleared when the 10 000th offset is reached
     fallbacks_before = None

@@ -110,6 +110,86 @@ def test_ks_reduce_multi_rank_equals_emulation(tmp_path, world):
     assert total_sent == total_recv
 
 
+def _sequential_tiles(n_frames):
+    """All frames in order on ONE context: tile key -> [512, 25] u32 records."""
+    from tests.reduce_worker import round_config_kw, round_frames
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **round_config_kw()))
+    for f in round_frames(n_frames):
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    keys, rec = export_all(h)
+    h.close()
+    return dict(zip(keys.tolist(), rec[:, :, :25]))
+
+
+def test_exact_round_on_one_rank_equals_sequential_integration():
+    """ks_integrate_round_exact with world = 1: the frame is marched by one context (records: voxel, position, sdf, weight),
+    applied by another — the map must be the plain integration's, bit for bit, and the serial oracle's."""
+    from kimera_semantics_amd import synth
+    from oracle import oracle_py as O
+    from tests.reduce_worker import round_config_kw, round_frames
+    from tests.util import compare_maps
+    frames = round_frames(4)
+    marcher = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **round_config_kw()))
+    owner = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **round_config_kw()))
+    o = O.Oracle(O.default_config(integrator_threads=1, **round_config_kw()))
+    for k, f in enumerate(frames):
+        so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        st = owner.integrate_round_exact(marcher, None, 0, 1, k, f.T_G_C, f.xyz, f.rgba, f.labels)
+        assert st["updates_marched"] == st["updates_applied"] == so.n_voxel_updates and not st["origin_voxel_touched"], st
+    compare_maps(o, owner, exact=True)
+    want = _sequential_tiles(4)
+    keys, rec = export_all(owner)
+    assert sorted(keys.tolist()) == sorted(want)
+    for i, k in enumerate(keys.tolist()):
+        assert np.array_equal(rec[i][:, :25], want[k]), k
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exact_round_multi_rank_is_the_sequential_map_bit_for_bit(tmp_path, world):
+    """The frames of two rounds sharded over 2 / 3 ranks (processes sharing the GPU, the librccl test double): every rank marches
+    its frames, every update travels to the owner of its tile as a 20-byte record, the owner applies the frames in frame order —
+    the tiles a rank owns are EXACTLY those of the one-GPU sequential integration of all frames (SURVEY.md par. 8e asked for a
+    reduce of overlapping blocks; merging maps cannot be exact, shipping the updates is)."""
+    if not os.path.exists(MOCK):
+        pytest.fail("tests/mock_rccl/libmock_rccl.so not built: run __graft_entry__.build()")
+    lib = C.CDLL(MOCK)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_byte * 128)]
+    uid = UniqueId()
+    assert lib.ncclGetUniqueId(C.byref(uid)) == 0
+    env = dict(os.environ, KS_RCCL_LIB=MOCK)
+    n_rounds = 2
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "reduce_worker.py"), str(r), str(world), bytes(uid).hex(), str(tmp_path),
+                               f"round:{n_rounds}"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung")
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    want = _sequential_tiles(world * n_rounds)
+    want_owner = PAR.owner_of(np.array(sorted(want), dtype=np.uint64), world)
+    want_by_rank = {r: {k for k, ow in zip(sorted(want), want_owner.tolist()) if ow == r} for r in range(world)}
+    marched = applied = 0
+    for r in range(world):
+        with np.load(os.path.join(str(tmp_path), f"round_rank{r}.npz")) as npz:
+            got = {k: npz[k] for k in npz.files}
+        assert not got["origin"].any(), "the test scene must stay away from the world origin's voxel (see ks_k_shard.h)"
+        marched += int(got["marched"].sum())
+        applied += int(got["applied"].sum())
+        assert int(got["sent"].sum()) > 0
+        gk = got["keys"].tolist()
+        assert set(gk) == want_by_rank[r], f"rank {r}: the tiles it holds are not the tiles it owns of the sequential map"
+        for i, k in enumerate(gk):
+            assert np.array_equal(got["rec"][i], want[k]), f"rank {r} tile {k}"
+    assert marched == applied > 0
+
+
 def test_bench_gpus_2_spawns_its_ranks_and_reports_the_exchange(tmp_path):
     """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under torch.distributed.run with two
     ranks (here: two processes sharing the one GPU, torch.distributed over gloo, ks_reduce through the librccl test double —
