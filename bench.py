@@ -360,7 +360,7 @@ def early_out_fidelity(B, dev, wl, frames, max_tiles):
 def pmc_traffic(name):
     """HBM bytes per k_apply launch from the committed PMC pass of this command (profiles/r03_pmc_<name>.json,
     written by tools/pmc_bench.sh: separate FETCH_SIZE / WRITE_SIZE passes, gfx950 unit correction applied)."""
-    for tag in ("r05", "r04", "r03"):
+    for tag in ("r06", "r05", "r04", "r03"):
         try:
             return json.load(open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{name}.json")))
         except Exception:
@@ -391,13 +391,16 @@ def roofline_of(m, region, K, upd_counted, world=1, pmc_name=None):
     upd_per_launch = prof["apply_kernel_updates"] / max(1, prof["apply_kernel_launches"])
     a_gbs = BYTES_PER_UPDATE * upd_per_launch / (apply_ms * 1e-3) / 1e9 if apply_ms > 0 else 0.0
     pmc = pmc_traffic(pmc_name) if pmc_name else None
-    traffic = pmc.get("k_apply_hbm_bytes_per_launch") if pmc else None
+    # round 6: `traffic` is the WHOLE frame's HBM bytes (every kernel, per frame) — the scope of `kernel` / `achieved`; the update
+    # kernel's own counter bytes sit with its figures under k_apply
+    traffic = (pmc.get("whole_frame_hbm_bytes_per_frame") or None) if pmc else None
+    k_apply_traffic = pmc.get("k_apply_hbm_bytes_per_launch") if pmc else None
     return {
         "bound": "hbm", "kernel": "whole frame (all stages, wall clock of the median timed region)",
         "achieved": round(whole_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(whole_gbs / HBM_PEAK_GBS, 5),
         "traffic": traffic,
-        "traffic_note": (f"k_apply, HBM bytes per launch (FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command, "
-                         f"gfx950 correction applied): {pmc.get('source', 'profiles/')}" if pmc else
+        "traffic_note": (f"whole frame: HBM bytes of every kernel per frame (FETCH_SIZE + WRITE_SIZE, separate --pmc passes of this command, "
+                         f"gfx950 correction applied; null = the committed pass predates round 6): {pmc.get('source', 'profiles/')}" if pmc else
                          "no committed PMC pass for this workload (profiles/r0N_pmc_*.json)"),
         "algorithmic_bytes_per_frame": int(whole_bytes),
         "dominant_stage": dominant,
@@ -406,6 +409,7 @@ def roofline_of(m, region, K, upd_counted, world=1, pmc_name=None):
                       "back); march = early-out phases + scan + pair emission, sort_* = radix sorts, apply(+_long) = per-voxel update",
         "k_apply": {"achieved": round(a_gbs, 2), "frac": round(a_gbs / HBM_PEAK_GBS, 5), "avg_launch_ms": round(apply_ms, 5),
                     "algorithmic_bytes_per_launch": int(BYTES_PER_UPDATE * upd_per_launch),
+                    "traffic": k_apply_traffic, "kernel": (pmc or {}).get("update_kernel", "k_apply"),
                     "timed_launches": prof["apply_kernel_launches"],
                     "note": "events attached to the k_apply dispatch of every 4th timed frame (GPU's own update count); other "
                             "stages of neighbouring frames share the GPU (pipelined)"},
@@ -500,10 +504,12 @@ def adapter_record(wl_frames):
 
 
 def c5_record(B, torch, dist, dev, rank, world, comm, ddev=None):
-    """BASELINE.json configs[4]: a batch of 8 overlapping 640x480 frames (arc poses looking at the same wall),
-    frame-sharded over the ranks, ONE ks_reduce of the dirty tiles to their owner ranks inside the timed
-    region; the owner-sharded result is compared with the same frames integrated sequentially on one GPU
-    (merging per-rank maps is not the same arithmetic as sequential integration: SURVEY.md §8e)."""
+    """BASELINE.json configs[4]: a batch of 8 overlapping 640x480 frames (arc poses looking at the same wall), frame-sharded over
+    the ranks.  EXACT split (ks_integrate_round_exact): rank r marches frames r, r + world, ... — ray casting, early-out, emission —
+    and every voxel update travels, as a 20-byte record, to the rank that owns the voxel's tile, which applies the frames in frame
+    order: the tiles a rank owns are compared, record by record, with the same frames integrated sequentially on one GPU
+    (`bit_exact_vs_sequential`).  The timed region is the whole batch (march + exchange + apply on every rank).  The older
+    map-merging exchange (ks_reduce: a different arithmetic, labels agree to ~99 %) is kept as `tile_merge_reduce` beside it."""
     import numpy as np
     from kimera_semantics_amd import parallel as PAR
     from kimera_semantics_amd import synth
@@ -512,22 +518,80 @@ def c5_record(B, torch, dist, dev, rank, world, comm, ddev=None):
     scene = synth.make_scene("room")
     frames = [synth.render_frame(scene, synth.arc_pose(k, n=n_frames), wl["w"], wl["h"], seed=100 + k) for k in range(n_frames)]
     kw = dict(integ_cfg(wl), voxels_per_side=8)   # host block = device tile: ownership is per block
-    h = B.HipIntegrator(B.default_config(device_id=dev.index or 0, max_tiles=1 << 13, max_points=wl["w"] * wl["h"], **kw))
+    mk = lambda: B.HipIntegrator(B.default_config(device_id=dev.index or 0, max_tiles=1 << 13, max_points=wl["w"] * wl["h"], **kw))   # noqa: E731
+    rec = {"config": "C5", "workload": f"{n_frames} arc-pose 640x480 frames looking at the same wall, frame-sharded x{world}: every rank marches "
+                                       "its frames, updates travel to the tile owners as 20-byte records (RCCL send / recv, all peers at once), "
+                                       "owners apply in frame order (ks_integrate_round_exact)",
+           "frames": n_frames, "unit": "Mvoxel-updates/s"}
+    # the same batch sequentially on this GPU (untimed): what the owners' tiles must be
+    seq = mk()
+    for f in frames:
+        seq.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    seq.synchronize()
+
+    def tiles_of(h):
+        keys = h.tile_keys()
+        buf = torch.empty((len(keys), 16384), dtype=torch.int32, device=dev)
+        if len(keys):
+            h.export_tiles(np.arange(len(keys), dtype=np.uint32), buf.data_ptr())
+        torch.cuda.synchronize()
+        return keys, buf.cpu().numpy().view(np.uint32).reshape(len(keys), 512, 32)[:, :, :25]
+
+    if comm is not None or world == 1:
+        marcher, owner = mk(), mk()
+        # one untimed round on throw-away contexts (buffers, communicator paths), then the timed batch
+        wm, wo = mk(), mk()
+        wo.integrate_round_exact(wm, comm, rank, world, 0, frames[rank].T_G_C, frames[rank].xyz, frames[rank].rgba, frames[rank].labels)
+        wm.close()
+        wo.close()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        stats = []
+        for r0 in range(0, n_frames, world):
+            f = frames[r0 + rank]
+            stats.append(owner.integrate_round_exact(marcher, comm, rank, world, r0, f.T_G_C, f.xyz, f.rgba, f.labels))
+        owner.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t0
+        sk, srec = tiles_of(seq)
+        want = {int(k): srec[i] for i, k in enumerate(sk.tolist()) if PAR.owner_of(np.array([k], dtype=np.uint64), world)[0] == rank}
+        gk, grec = tiles_of(owner)
+        same_set = sorted(int(k) for k in gk.tolist()) == sorted(want)
+        diff = 0 if same_set else -1
+        if same_set:
+            for i, k in enumerate(gk.tolist()):
+                diff += int((grec[i] != want[int(k)]).any(axis=1).sum())
+        agg = torch.tensor([float(sum(s["updates_marched"] for s in stats)), float(sum(s["bytes_sent"] for s in stats)),
+                            float(len(want)), float(0 if (same_set and diff == 0) else 1), float(max(diff, 0)),
+                            float(any(s["origin_voxel_touched"] for s in stats))], device=ddev or dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], device=ddev or dev, dtype=torch.float64)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        a, dtm = agg.tolist(), float(tmax.item())
+        marcher.close()
+        owner.close()
+        rec.update({"batch_ms": round(dtm * 1e3, 3), "frames_per_s": round(n_frames / dtm, 2), "gpu_counted_value": round(a[0] / dtm / 1e6, 3),
+                    "exchange": {"bytes_sent": int(a[1]), "bytes_per_update": 20},
+                    "bit_exact_vs_sequential": bool(a[3] == 0), "owned_tiles_compared": int(a[2]), "voxel_records_differing": int(a[4]),
+                    "origin_voxel_touched": bool(a[5] > 0)})
+    else:
+        rec["skipped_exact_split"] = "no ctypes RCCL communicator in this run: ks_integrate_round_exact needs one"
+    # ---- the map-merging exchange (rounds 2-5), for comparison: per-rank maps, ONE ks_reduce of the dirty tiles ----
+    h = mk()
     mine = list(range(rank, n_frames, world))
     torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    upd = sum(int(h.integrate(frames[k].T_G_C, frames[k].xyz, frames[k].rgba, frames[k].labels).n_voxel_updates) for k in mine)
+    for k in mine:
+        h.integrate(frames[k].T_G_C, frames[k].xyz, frames[k].rgba, frames[k].labels)
     h.synchronize()
     rstats = h.reduce(comm, rank, world) if comm is not None else PAR.reduce_maps(PAR.HipTileStore(h, dev))
     h.synchronize()
     torch.cuda.synchronize()
     dist.barrier()
     dt = time.perf_counter() - t0
-    # the same batch sequentially on this GPU (untimed), compared on the tiles this rank owns
-    seq = B.HipIntegrator(B.default_config(device_id=dev.index or 0, max_tiles=1 << 13, max_points=wl["w"] * wl["h"], **kw))
-    for f in frames:
-        seq.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
     keys = h.tile_keys()
     own = keys[PAR.owned_tile_mask(keys, rank, world)]
     bias = 1 << 17
@@ -538,7 +602,7 @@ def c5_record(B, torch, dist, dev, rank, world, comm, ddev=None):
     _, st, ss = seq.download(idx)
     touched = st["weight"] > 0
     agg = torch.tensor([float(touched.sum()), float(((hs["label"] == ss["label"]) & touched).sum()),
-                        float(np.abs(ht["distance"] - st["distance"])[touched].sum()), float(upd), dt,
+                        float(np.abs(ht["distance"] - st["distance"])[touched].sum()), dt,
                         float(rstats["tiles_sent"]), float(rstats["bytes_sent"])], device=ddev or dev, dtype=torch.float64)
     tmax = torch.tensor([dt], device=ddev or dev, dtype=torch.float64)
     dist.all_reduce(agg, op=dist.ReduceOp.SUM)
@@ -546,14 +610,10 @@ def c5_record(B, torch, dist, dev, rank, world, comm, ddev=None):
     h.close()
     seq.close()
     a = agg.tolist()
-    dtm = float(tmax.item())
-    return {"config": "C5", "workload": f"{n_frames} arc-pose 640x480 frames looking at the same wall, frame-sharded x{world}, "
-                                        "one ks_reduce (RCCL all-to-all of the dirty tiles to their hash-owners) inside the timed region",
-            "frames": n_frames, "batch_ms": round(dtm * 1e3, 3), "frames_per_s": round(n_frames / dtm, 2),
-            "gpu_counted_value": round(a[3] / dtm / 1e6, 3), "unit": "Mvoxel-updates/s",
-            "reduce": {"tiles_sent": int(a[5]), "bytes_sent": int(a[6])},
-            "vs_sequential_1gpu": {"voxels_compared": int(a[0]), "label_agreement": round(a[1] / max(1.0, a[0]), 6),
-                                   "mean_abs_distance_diff": a[2] / max(1.0, a[0])}}
+    rec["reduce"] = {"tiles_sent": int(a[4]), "bytes_sent": int(a[5])}
+    rec["tile_merge_reduce"] = {"batch_ms": round(float(tmax.item()) * 1e3, 3), "label_agreement_vs_sequential": round(a[1] / max(1.0, a[0]), 6),
+                                "mean_abs_distance_diff_vs_sequential": a[2] / max(1.0, a[0]), "voxels_compared": int(a[0])}
+    return rec
 
 
 def launch_ranks(args):
@@ -581,7 +641,7 @@ def mapped_library():
     return None
 
 
-LINE_LIMIT = 4000   # bytes of the ONE stdout line; everything else goes to the full record (profiles/bench_full_r05.json)
+LINE_LIMIT = 4000   # bytes of the ONE stdout line; everything else goes to the full record (profiles/bench_full_r06.json)
 
 
 def compact_line(out, full_path):
@@ -591,13 +651,13 @@ def compact_line(out, full_path):
         return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
     rf = out.get("roofline") or {}
     line = pick(out, ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                      "vs_baseline", "dtype", "data", "frames_per_s", "gpu_counted_value"])
+                      "vs_baseline", "dtype", "data", "frames_per_s", "frames_per_s_device_resident", "gpu_counted_value"])
     cfg = out.get("config") or {}
     line["config"] = pick(cfg, ["workload", "early_out", "pipeline_frames", "parallelism", "points_per_frame", "rays_per_frame",
                                 "updates_per_frame"])
     line["roofline"] = pick(rf, ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "dominant_stage"])
     if "k_apply" in rf:
-        line["roofline"]["k_apply"] = pick(rf["k_apply"], ["achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch"])
+        line["roofline"]["k_apply"] = pick(rf["k_apply"], ["achieved", "frac", "avg_launch_ms", "algorithmic_bytes_per_launch", "traffic", "kernel"])
     if "stages" in rf:
         line["roofline"]["stage_ms"] = {k: v.get("ms_per_frame") for k, v in rf["stages"].items()}
     if "timing" in out:
@@ -622,7 +682,7 @@ def compact_line(out, full_path):
         if r.get("config") == "adapter":
             e.update({k: v for k, v in r.items() if k.endswith("_ms_per_frame")})
         if r.get("config") == "C5":
-            e.update(pick(r, ["reduce", "gpu_counted_value"]))
+            e.update(pick(r, ["reduce", "gpu_counted_value", "bit_exact_vs_sequential", "exchange"]))
         sec.append(e)
     if sec:
         line["secondary"] = sec
@@ -913,10 +973,16 @@ def main():
                     out["host_inputs_h2d_inside"] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
                                                      "frames_per_s": r["frames_per_s"], "spread": r["spread"],
                                                      "note": "same K frames as the headline, ks_integrate_points on page-locked host buffers"}
+                    # `value` stays the device-resident rate (the measurement contract: inputs in HBM when the region starts, the
+                    # PCIe-inclusive rate is never `value`); `frames_per_s` is what SURVEY.md 8(d) defines — H2D of the frame inside
+                    out["frames_per_s_device_resident"] = out["frames_per_s"]
+                    out["frames_per_s"] = r["frames_per_s"]
+                    out["frames_per_s_definition"] = ("SURVEY.md 8(d): the call including the H2D copy of the frame (host-pointer entry, page-locked "
+                                                      "buffers); frames_per_s_device_resident / value / ms_per_step: inputs resident in HBM")
         out["library"] = mapped_library()
         out["bench_seconds"] = round(time.time() - t_start, 1)
         # the full record (every sub-record, stage table, A/B record) goes to a file; stdout carries ONE short line
-        full_path = os.environ.get("KS_BENCH_FULL") or os.path.join("profiles", "bench_full_r05.json" if world == 1 else f"bench_full_r05_n{world}.json")
+        full_path = os.environ.get("KS_BENCH_FULL") or os.path.join("profiles", "bench_full_r06.json" if world == 1 else f"bench_full_r06_n{world}.json")
         try:
             with open(os.path.join(ROOT, full_path) if not os.path.isabs(full_path) else full_path, "w") as fh:
                 json.dump(out, fh, indent=1)

@@ -155,6 +155,7 @@ struct FrameSlot {
   hipEvent_t tail_done = nullptr;   // the tail has consumed this slot's buffers
   hipEvent_t fork = nullptr, join = nullptr;  // tail: pairs sorted and long runs listed | long runs applied
   hipEvent_t join_x = nullptr;                // the runs of more than kXLongRun updates applied (stream_xlong)
+  hipEvent_t found = nullptr;                 // the long runs listed on the long-run stream (k_find_long beside k_apply_runs)
   bool tail_recorded = false;
   bool join_recorded = false;
   bool b_launched = false;    // stage B of the frame has been enqueued (with its batch)
@@ -353,7 +354,8 @@ struct ks_ctx {
   size_t cap_sh_rx = 0;
   // the runs of 33 .. 1024 updates a lane per run, bucketed by length over the frame (k_apply_long_lanes); by parity, like the lists
   bool long_lanes = true;
-  unsigned long long long_lanes_min_pairs = 1ull << 24;   // (below: too few such runs to fill wavefronts with — k_apply_long takes them all)
+  unsigned long long long_lanes_min_pairs = 1ull << 24;
+  bool long_min_lanes = false;   // (below: too few such runs to fill wavefronts with — k_apply_long takes them all)
   unsigned long long* d_long_sorted_[2] = {nullptr, nullptr};
   LongHdr* d_long_hdr_[2] = {nullptr, nullptr};
   unsigned long long* d_xl_fb = nullptr;
@@ -584,9 +586,9 @@ int ensure_pairs_out(ks_ctx* c, size_t n) {
   if (c->stream_tail) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
   for (int b = 0; b < 2; ++b) {
     if ((rc = dev_alloc(c, &c->d_pairs2_[b], cap))) return rc;
-    // heads of the long runs, then (from cap / kLongRun + 64 on) the heads of the runs of more than kXLongRun updates
-    if ((rc = dev_alloc(c, &c->d_long_list_[b], cap / kLongRun + 64 + cap / kXLongRun + 64))) return rc;
-    if (c->long_lanes && (rc = dev_alloc(c, &c->d_long_sorted_[b], cap / kLongRun + 64))) return rc;
+    // heads of the long runs, then (from cap / kLongRunLanes + 64 on) the heads of the runs of more than kXLongRun updates
+    if ((rc = dev_alloc(c, &c->d_long_list_[b], cap / kLongRunLanes + 64 + cap / kXLongRun + 64))) return rc;
+    if (c->long_lanes && (rc = dev_alloc(c, &c->d_long_sorted_[b], cap / kLongRunLanes + 64))) return rc;
   }
   if (c->d_xl_hdr && (rc = dev_alloc(c, &c->d_xl_fb, cap / kXLongRun + 64))) return rc;   // (the runs the integer-sum path leaves to k_apply_xlong)
   c->cap_pairs = cap;
@@ -1573,10 +1575,19 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     // k_apply on the tail stream, k_apply_long on its own stream (disjoint voxels)
     hipStream_t sl = c->stream_long ? c->stream_long : st;
     hipStream_t sx = (sl != st && c->stream_xlong) ? c->stream_xlong : nullptr;
-    unsigned long long* const d_xlong_list = sx ? d_long_list + (c->cap_pairs / kLongRun + 64) : nullptr;
-    hipLaunchKernelGGL(k_find_long, dim3((uint32_t)((n_pairs + 256 * kFindLongItems - 1) / (256 * kFindLongItems))), dim3(256), 0, st,
-                       F.seq_bits, n_pairs, (const uint64_t*)sp, d_long_list, d_xlong_list,
-                       S.d_counters);
+    unsigned long long* const d_xlong_list = sx ? d_long_list + (c->cap_pairs / kLongRunLanes + 64) : nullptr;
+    const bool lanes_on = by_runs && sl != st && sx && c->long_lanes && n_pairs >= c->long_lanes_min_pairs;
+    // ("long" could begin at kLongRunLanes = 17 updates where the lanes kernel takes the long runs — k_find_long, k_long_measure and
+    // k_apply_runs take the threshold as an argument — but measured at 1280x720 / 2 cm it buys nothing: k_apply_runs 2.83 vs 2.79 ms,
+    // the lanes kernel 1.47 vs 0.93 ms, the frame 6.42 vs 6.24 ms: profiles/r06_c4_merged_ab.txt.  KS_LONG_MIN=16 selects it.)
+    const uint32_t long_min = (lanes_on && c->long_min_lanes) ? kLongRunLanes : kLongRun;
+    // k_apply_runs decides which runs are its own by itself: the listing of the long runs (a pass over all pairs, 0.3 ms at
+    // 1280x720 / 2 cm) then runs BESIDE it, on the long-run stream, instead of in front of it
+    const bool find_beside = by_runs && sl != st && sx;
+    const dim3 find_grid((uint32_t)((n_pairs + 256 * kFindLongItems - 1) / (256 * kFindLongItems)));
+    if (!find_beside)
+      hipLaunchKernelGGL(k_find_long, find_grid, dim3(256), 0, st, F.seq_bits, n_pairs, (const uint64_t*)sp, d_long_list, d_xlong_list,
+                         S.d_counters, long_min);
     const uint32_t xb = (uint32_t)std::min<unsigned long long>(n_pairs / kXLongRun + 1, 512);
     if (sl != st) {
       // the previous frame's long runs end before any voxel of this frame is touched
@@ -1584,16 +1595,23 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
       c->pending_join = nullptr;
       HIPCHK(c, hipEventRecord(S.fork, st));
       HIPCHK(c, hipStreamWaitEvent(sl, S.fork, 0));
-      if (sx && c->long_lanes && n_pairs >= c->long_lanes_min_pairs) HIPCHK(c, hipMemsetAsync(c->d_long_hdr_[par], 0, sizeof(LongHdr), sl));
-      if (sx) HIPCHK(c, hipStreamWaitEvent(sx, S.fork, 0));
+      if (lanes_on) HIPCHK(c, hipMemsetAsync(c->d_long_hdr_[par], 0, sizeof(LongHdr), sl));
+      if (find_beside) {
+        hipLaunchKernelGGL(k_find_long, find_grid, dim3(256), 0, sl, F.seq_bits, n_pairs, (const uint64_t*)sp, d_long_list, d_xlong_list,
+                           S.d_counters, long_min);
+        HIPCHK(c, hipEventRecord(S.found, sl));
+        HIPCHK(c, hipStreamWaitEvent(sx, S.found, 0));
+      } else if (sx) {
+        HIPCHK(c, hipStreamWaitEvent(sx, S.fork, 0));
+      }
     }
 #define KS_LAUNCH_APPLY_M(MODE, MERGED)                                                                              \
   if (by_runs && time_apply)                                                                                         \
     hipExtLaunchKernelGGL((k_apply_runs<MODE, MERGED>), dim3(rb), dim3(kRunThreads), 0, st, c->pset[set].k0, c->pset[set].k1, \
-                          0, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut);                \
+                          0, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut, long_min);      \
   else if (by_runs)                                                                                                  \
     hipLaunchKernelGGL((k_apply_runs<MODE, MERGED>), dim3(rb), dim3(kRunThreads), 0, st, F, n_pairs, sp, S.d_rays,            \
-                       S.d_deltas, c->table, c->pool, c->d_label_lut);                                                \
+                       S.d_deltas, c->table, c->pool, c->d_label_lut, long_min);                                      \
   else if (time_apply)                                                                                               \
     hipExtLaunchKernelGGL((k_apply<MODE, MERGED>), dim3(ab), dim3(256), 0, st, c->pset[set].k0, c->pset[set].k1, 0,   \
                           F, n_pairs, sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut, d_long_list,       \
@@ -1628,10 +1646,10 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   } else if (sx)                                                                                                     \
     hipLaunchKernelGGL(k_apply_xlong<MODE>, dim3(xb), dim3(256), 0, sx, F, n_pairs, sp, S.d_rays, S.d_deltas,            \
                        c->table, c->pool, c->d_label_lut, d_xlong_list, (const uint32_t*)&S.d_counters->n_xlong);      \
-  if (sl != st && sx && c->long_lanes && n_pairs >= c->long_lanes_min_pairs) {                                       \
-    const uint32_t cap_long = (uint32_t)(n_pairs / (kLongRun + 1) + 1);                                               \
+  if (lanes_on) {                                                                                                    \
+    const uint32_t cap_long = (uint32_t)(n_pairs / (long_min + 1) + 1);                                               \
     hipLaunchKernelGGL(k_long_measure, dim3((cap_long + 255) / 256), dim3(256), 0, sl, F.seq_bits, n_pairs,           \
-                       (const uint64_t*)sp, d_long_list, (const Counters*)S.d_counters, c->d_long_hdr_[par]);         \
+                       (const uint64_t*)sp, d_long_list, (const Counters*)S.d_counters, c->d_long_hdr_[par], long_min); \
     hipLaunchKernelGGL(k_long_bucket, dim3((cap_long + 255) / 256), dim3(256), 0, sl,                                 \
                        (const unsigned long long*)d_long_list, (const Counters*)S.d_counters, c->d_long_hdr_[par],    \
                        c->d_long_sorted_[par]);                                                                        \
@@ -2218,6 +2236,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     }
     if (c->stream_long && c->long_lanes)
       for (int b = 0; b < 2; ++b) CRCHK(hipMalloc((void**)&c->d_long_hdr_[b], sizeof(LongHdr)));
+    if (const char* lm = dbg_env("KS_LONG_MIN")) c->long_min_lanes = atoi(lm) == 16;
     if (const char* xl = dbg_env("KS_XL_PARALLEL")) c->xl_parallel = atoi(xl) != 0;   // A/B: 0 = every such run through k_apply_xlong
     if (c->stream_xlong && c->xl_parallel) {
       CRCHK(hipMalloc((void**)&c->d_xl_runs, kXlMaxRuns * sizeof(XlRun)));
@@ -2285,6 +2304,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     CRCHK(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.join_x, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&S.found, hipEventDisableTiming));
   }
 #undef CRCHK
   // pair buffers start at 4 updates per point of the largest cloud (a frame that needs more grows its buffer and
@@ -2364,6 +2384,7 @@ void ks_destroy(ks_ctx* c) {
     if (S.fork) (void)hipEventDestroy(S.fork);
     if (S.join) (void)hipEventDestroy(S.join);
     if (S.join_x) (void)hipEventDestroy(S.join_x);
+    if (S.found) (void)hipEventDestroy(S.found);
     if (S.a_done) (void)hipEventDestroy(S.a_done);
   }
   for (auto& P : c->pset) {

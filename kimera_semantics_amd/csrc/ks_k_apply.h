@@ -308,7 +308,9 @@ template <int COLOR_MODE, bool MERGED>
 __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsigned long long n_pairs,
                                                             const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
                                                             const float* __restrict__ deltas, TileTable T, Pool P,
-                                                            const uint32_t* __restrict__ label_lut) {
+                                                            const uint32_t* __restrict__ label_lut, uint32_t max_len) {
+  // max_len: the longest run this kernel takes (kLongRun, or kLongRunLanes where the lane-per-run long kernel takes over earlier);
+  // k_find_long lists exactly the longer ones
   constexpr bool HOT_ONLY = !MERGED && COLOR_MODE != KS_COLOR_MODE_COLOR;
   constexpr bool BLEND = COLOR_MODE == KS_COLOR_MODE_COLOR;
   static_assert(kRunHalo == kLongRun, "a short run must end inside the halo");
@@ -392,7 +394,7 @@ __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsig
         const uint32_t d2 = (uint32_t)__ffs((int)fwd);         // pairs on to the next boundary
         const uint32_t len = d1 + d2;
         const bool head_in_tile = j - d1 < kRunTile;
-        if (len <= kLongRun && head_in_tile) {
+        if (len <= max_len && head_in_tile) {
           need[k] = true;
           if (d1 == 0u && k < kRunPer) {
             my_len[k] = len;
@@ -592,12 +594,13 @@ constexpr uint32_t kFindLongItems = 8;  // pairs per thread
 __global__ void __launch_bounds__(256) k_find_long(uint32_t seq_bits, unsigned long long n_pairs,
                                                    const uint64_t* __restrict__ pairs,
                                                    unsigned long long* __restrict__ long_list,
-                                                   unsigned long long* __restrict__ xlong_list, Counters* C) {
+                                                   unsigned long long* __restrict__ xlong_list, Counters* C, uint32_t long_min = kLongRun) {
+  // long_min: runs of MORE than long_min updates are listed (kLongRun, or kLongRunLanes)
   // heads of long runs are more than kLongRun apart: at most 2048 / 33 + 1 of them per workgroup
-  __shared__ unsigned long long s_list[2048 / kLongRun + 2];
+  __shared__ unsigned long long s_list[2048 / kLongRunLanes + 2];
   __shared__ unsigned long long s_xlist[2048 / kXLongRun + 2];
   __shared__ uint32_t s_n, s_base, s_xn, s_xbase;
-  static_assert(kLongRun >= 32, "s_list size");
+  static_assert(kLongRun >= kLongRunLanes, "s_list size");
   if (threadIdx.x == 0) {
     s_n = 0u;
     s_xn = 0u;
@@ -610,7 +613,7 @@ __global__ void __launch_bounds__(256) k_find_long(uint32_t seq_bits, unsigned l
     if (i < n_pairs) {
       const uint32_t vox = (uint32_t)(pairs[i] >> seq_bits);
       const bool head = (i == 0) || ((uint32_t)(pairs[i - 1] >> seq_bits) != vox);
-      if (head && (i + kLongRun < n_pairs) && ((uint32_t)(pairs[i + kLongRun] >> seq_bits) == vox)) {
+      if (head && (i + long_min < n_pairs) && ((uint32_t)(pairs[i + long_min] >> seq_bits) == vox)) {
         const bool xl = xlong_list != nullptr && (i + kXLongRun < n_pairs) && ((uint32_t)(pairs[i + kXLongRun] >> seq_bits) == vox);
         if (xl) s_xlist[atomicAdd(&s_xn, 1u)] = i;
         else s_list[atomicAdd(&s_n, 1u)] = i;
@@ -641,19 +644,21 @@ __global__ void __launch_bounds__(256) k_find_long(uint32_t seq_bits, unsigned l
 //                    ahead), its ray (one step ahead), computeDistance + weight, the voxel-state update
 // Same operations in the same order per voxel as k_apply_long.
 // ------------------------------------------------------------------------------------------
-constexpr int kLongClasses = 10;
-constexpr int kLongLaneClasses = 6;   // classes 0 .. 5 (33 .. 256 updates) a lane per run; the longer ones two wavefronts per run (k_apply_long)
+constexpr int kLongClasses = 12;
+constexpr int kLongLaneClasses = 8;   // classes 0 .. 7 (17 .. 256 updates) a lane per run; the longer ones two wavefronts per run (k_apply_long)
 struct LongHdr {
   uint32_t count[kLongClasses];    // runs per class (k_long_measure)
   uint32_t cursor[kLongClasses];   // k_long_bucket's
-  uint32_t pad[12];
+  uint32_t pad[8];
 };
-__device__ __forceinline__ int long_class(uint32_t len) {   // len in kLongRun + 1 .. kXLongRun
-  return len <= 48u ? 0 : len <= 64u ? 1 : len <= 96u ? 2 : len <= 128u ? 3 : len <= 192u ? 4 : len <= 256u ? 5 : len <= 384u ? 6 : len <= 512u ? 7 : len <= 768u ? 8 : 9;
+__device__ __forceinline__ int long_class(uint32_t len) {   // len in kLongRunLanes + 1 .. kXLongRun
+  return len <= 24u ? 0 : len <= 32u ? 1 : len <= 48u ? 2 : len <= 64u ? 3 : len <= 96u ? 4 : len <= 128u ? 5 : len <= 192u ? 6 : len <= 256u ? 7 :
+         len <= 384u ? 8 : len <= 512u ? 9 : len <= 768u ? 10 : 11;
 }
 
 __global__ void __launch_bounds__(256) k_long_measure(uint32_t seq_bits, unsigned long long n_pairs, const uint64_t* __restrict__ pairs,
-                                                      unsigned long long* __restrict__ long_list, const Counters* C, LongHdr* __restrict__ H) {
+                                                      unsigned long long* __restrict__ long_list, const Counters* C, LongHdr* __restrict__ H,
+                                                      uint32_t long_min) {
   __shared__ uint32_t s_cnt[kLongClasses];
   if (threadIdx.x < kLongClasses) s_cnt[threadIdx.x] = 0u;
   __syncthreads();
@@ -662,8 +667,8 @@ __global__ void __launch_bounds__(256) k_long_measure(uint32_t seq_bits, unsigne
   if (r < n_long) {
     const unsigned long long start = long_list[r];
     const uint32_t vox = (uint32_t)(pairs[start] >> seq_bits);
-    // element kLongRun is this voxel's, element kXLongRun (if it exists) is not (k_find_long): bisect in between
-    unsigned long long lo = kLongRun, hi = kXLongRun;
+    // element long_min is this voxel's, element kXLongRun (if it exists) is not (k_find_long): bisect in between
+    unsigned long long lo = long_min, hi = kXLongRun;
     if (start + hi > n_pairs) hi = n_pairs - start;
     // invariant: element lo belongs to the run, element hi does not (or is the end of the list)
     while (hi - lo > 1ull) {

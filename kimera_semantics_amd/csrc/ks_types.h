@@ -34,6 +34,8 @@ struct Counters {
 };
 
 constexpr uint32_t kLongRun = 32;        // runs of >= kLongRun updates get a whole wavefront
+constexpr uint32_t kLongRunLanes = 16;   // ... where the long runs are taken a lane per run, bucketed by length over the frame (k_apply_long_lanes: frames of
+                                         // 2^24 pairs and more), already from 17 updates on: what bounds a tile of k_apply_runs is its longest run
 constexpr uint32_t kXLongRun = 1024;     // runs of more than this many updates: the voxels next to the sensor (one chain of 1e4..1e5 updates)
 constexpr uint32_t kInvalidSlot = 1u << kSetBits;  // sort key of dropped points (sorts last)
 

@@ -126,7 +126,9 @@ def test_bench_line_is_one_short_parseable_line():
             + [{"config": "adapter", "workload": "a" * 200, "fast_every_frame_sync_ms_per_frame": 3.56, "fast_on_demand_sync_pipelined_ms_per_frame": 0.31,
                 "merged_every_frame_sync_ms_per_frame": 4.4, "merged_on_demand_sync_pipelined_ms_per_frame": 0.33,
                 "fast_hip_real_factory_patched_server_sequence_ms_per_frame": 0.21},
-               {"config": "C5", "frames": 8, "batch_ms": 3.2, "gpu_counted_value": 1000.0, "reduce": {"tiles_sent": 100, "bytes_sent": 6553600}},
+               {"config": "C5", "frames": 8, "batch_ms": 3.2, "gpu_counted_value": 1000.0, "reduce": {"tiles_sent": 100, "bytes_sent": 6553600},
+                "bit_exact_vs_sequential": True, "exchange": {"bytes_sent": 56000000, "bytes_per_update": 20},
+                "tile_merge_reduce": {"batch_ms": 3.0, "label_agreement_vs_sequential": 0.995, "mean_abs_distance_diff_vs_sequential": 1e-4, "voxels_compared": 100000}},
                switches, dict(switches, config="C4-fast-switches"), dict(switches, config="C4-merged-switches")],
             "library": "/root/repo/kimera_semantics_amd/libks_hip.so", "bench_seconds": 120.0}
     assert len(json.dumps(full)) > 8000                      # the canned record is of the size that broke the driver's parser
@@ -138,6 +140,8 @@ def test_bench_line_is_one_short_parseable_line():
     assert d["config"]["workload"] and set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert set(("value", "unit", "cores", "kind")) <= set(d["cpu_baseline"])
     assert d["host_inputs_h2d_inside"]["ms_per_step"] == 0.34   # SURVEY.md 8(d)'s frames/s (H2D inside), beside the device-resident headline
+    c5 = [e for e in d["secondary"] if e["config"] == "C5"][0]
+    assert c5["bit_exact_vs_sequential"] is True and c5["exchange"]["bytes_per_update"] == 20
     assert d["full_record"] == "profiles/bench_full_r05.json"
     # degenerate: nothing optional present
     assert json.loads(bench.compact_line({"metric": "m", "value": 1.0}, None))["value"] == 1.0

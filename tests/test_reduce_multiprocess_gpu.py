@@ -214,5 +214,7 @@ def test_bench_gpus_2_spawns_its_ranks_and_reports_the_exchange(tmp_path):
     c5 = [s for s in d["secondary"] if s["config"] == "C5"]
     assert len(c5) == 1 and "error" not in c5[0], c5
     assert c5[0]["reduce"]["tiles_sent"] > 0 and c5[0]["reduce"]["bytes_sent"] == c5[0]["reduce"]["tiles_sent"] * (65536 + 8)
+    # the exact split (ks_integrate_round_exact through the same communicator): the owners' tiles ARE the sequential map
+    assert c5[0]["bit_exact_vs_sequential"] is True and c5[0]["exchange"]["bytes_sent"] > 0, c5
     fullrec = json.load(open(full))
     assert fullrec["n_gpus"] == 2 and "ks_reduce" in fullrec["config"]["parallelism"]

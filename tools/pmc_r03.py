@@ -99,10 +99,16 @@ def main():
             if sum(d) > 0.01 * tot_t:
                 print(f"{k[:44]:44s} {len(fe[k]):6d} {avg_us:9.1f} {f_b / 1e6:9.2f} {w_b / 1e6:9.2f} {gbs:10.1f} {gbs / 8000.0:10.4f}")
         out[wl] = rows
-        ka = [k for k in rows if k.startswith("k_apply<")]
+        # whole frame (round 6): every kernel's bytes per launch x its launches per frame (a kernel launched once per frame
+        # defines the frame count of the averaged window)
+        n_frames_avg = max(1, len(fe.get("k_publish", fe.get("k_scan_local", [0]))))
+        whole = sum((sum(fe[k]) * corr_f + sum(wr.get(k, [0])) * corr_w) * 1024 for k in fe) / n_frames_avg
+        print(f"# {wl}: whole frame, all kernels: {whole / 1e6:.1f} MB of HBM traffic per frame (FETCH x {corr_f:.3f} + WRITE, averaged over {n_frames_avg} frames)")
+        ka = [k for k in rows if k.startswith("k_apply<")] or [k for k in rows if k.startswith("k_apply_runs<")]
         if ka:
             r = rows[ka[0]]
-            json.dump({"k_apply_hbm_bytes_per_launch": r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"],
+            json.dump({"whole_frame_hbm_bytes_per_frame": int(whole), "frames_averaged": n_frames_avg, "update_kernel": ka[0],
+                       "k_apply_hbm_bytes_per_launch": r["fetch_bytes_per_launch"] + r["write_bytes_per_launch"],
                        "fetch_bytes_per_launch": r["fetch_bytes_per_launch"], "write_bytes_per_launch": r["write_bytes_per_launch"],
                        "launches_averaged": r["calls_averaged"], "calibration": out["calibration"],
                        "source": f"profiles/{TAG}_pmc_{tag}.json <- tools/{SCRIPT}: rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- "
