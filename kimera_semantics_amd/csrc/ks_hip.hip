@@ -156,6 +156,7 @@ struct FrameSlot {
   hipEvent_t fork = nullptr, join = nullptr;  // tail: pairs sorted and long runs listed | long runs applied
   hipEvent_t join_x = nullptr;                // the runs of more than kXLongRun updates applied (stream_xlong)
   hipEvent_t found = nullptr;                 // the long runs listed on the long-run stream (k_find_long beside k_apply_runs)
+  hipEvent_t applied = nullptr;               // k_apply_runs done (stream_apply); S.join waits for it
   bool tail_recorded = false;
   bool join_recorded = false;
   bool b_launched = false;    // stage B of the frame has been enqueued (with its batch)
@@ -196,6 +197,7 @@ struct ks_ctx {
   hipStream_t stream_tail = nullptr;   // stage T; == stream unless pipelined
   hipStream_t stream_long = nullptr;   // the long-run voxel update, beside k_apply (always its own stream)
   hipStream_t stream_xlong = nullptr;  // the runs of more than kXLongRun updates, beside both (k_apply_xlong)
+  hipStream_t stream_apply = nullptr;  // k_apply_runs, so that the tail stream goes on with the NEXT frame's pair sort while it runs (round 6)
   bool xlong = true;
   float voxel_size_inv = 0.f, log_match = 0.f, log_non_match = 0.f;
   int vps_shift = 1;  // log2(vps / 8)
@@ -330,6 +332,7 @@ struct ks_ctx {
   // the runs of more than kXLongRun updates through integer sums per chunk (ks_k_apply_xl.h); one set of buffers: all of it
   // runs in order on stream_xlong
   bool xl_parallel = true;
+  unsigned long long xl_min_pairs = 1ull << 23;   // (below: the five launches of the path cost a 640x480 frame more than its handful of such runs through k_apply_xlong)
   XlRun* d_xl_runs = nullptr;
   XlHeader* d_xl_hdr = nullptr;
   XlChunk* d_xl_chunks = nullptr;
@@ -355,7 +358,12 @@ struct ks_ctx {
   // the runs of 33 .. 1024 updates a lane per run, bucketed by length over the frame (k_apply_long_lanes); by parity, like the lists
   bool long_lanes = true;
   unsigned long long long_lanes_min_pairs = 1ull << 24;
-  bool long_min_lanes = false;   // (below: too few such runs to fill wavefronts with — k_apply_long takes them all)
+  bool long_min_lanes = false;
+  // k_apply_runs: 256 threads (tiles of 1024 pairs) or 512 (tiles of 2048).  Measured at 1280x720 / 2 cm beside the long-run kernels:
+  // 2.45 vs 3.08 ms, the frame 5.98 vs 6.26 ms (profiles/r06_c4_merged_ab.txt) — a workgroup of one wavefront per SIMD finds room
+  // where one of two per SIMD does not
+  uint32_t run_threads = 256u;
+  uint32_t lanes_depth = 6u;   // k_apply_long_lanes: rays in flight per lane   // (below: too few such runs to fill wavefronts with — k_apply_long takes them all)
   unsigned long long* d_long_sorted_[2] = {nullptr, nullptr};
   LongHdr* d_long_hdr_[2] = {nullptr, nullptr};
   unsigned long long* d_xl_fb = nullptr;
@@ -1566,7 +1574,8 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     if ((rc = sort_keys(c, S.d_pairs, d_pairs2, n_pairs, std::min(56u, end_bit), &sp, F.seq_bits, /*tail=*/true))) return rc;
     stage_mark(c, set, 8);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
-    const uint32_t rb = (uint32_t)((n_pairs + kRunTile - 1) / kRunTile);
+    const uint32_t run_tile = kRunPer * c->run_threads;
+    const uint32_t rb = (uint32_t)((n_pairs + run_tile - 1) / run_tile);
     const bool by_runs = n_pairs >= c->apply_runs_min_pairs;
     const uint32_t lb = (uint32_t)std::min<unsigned long long>(n_pairs / kLongRun + 1, 4096);
     const bool time_apply = set >= 0 && c->pset[set].apply;
@@ -1605,13 +1614,25 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
         HIPCHK(c, hipStreamWaitEvent(sx, S.fork, 0));
       }
     }
+    // k_apply_runs on a stream of its own (pipelined contexts with the long-run streams; not while the stages are being timed):
+    // the sort is bound by HBM, this kernel by resident workgroups — the next frame's sort runs beside it instead of behind it.
+    // It is ordered like the long-run kernels: after this frame's fork, before S.join (which the next frame's fork waits for).
+    const bool apply_beside = find_beside && c->stream_apply && c->defer_join && !(set >= 0 && c->pset[set].stages);
+    hipStream_t sa = apply_beside ? c->stream_apply : st;
+    if (apply_beside) HIPCHK(c, hipStreamWaitEvent(sa, S.fork, 0));
+#define KS_LAUNCH_RUNS(MODE, MERGED, TH)                                                                              \
+  if (time_apply)                                                                                                     \
+    hipExtLaunchKernelGGL((k_apply_runs<MODE, MERGED, TH>), dim3(rb), dim3(TH), 0, sa, c->pset[set].k0, c->pset[set].k1, \
+                          0, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut, long_min);       \
+  else                                                                                                                \
+    hipLaunchKernelGGL((k_apply_runs<MODE, MERGED, TH>), dim3(rb), dim3(TH), 0, sa, F, n_pairs, sp, S.d_rays,          \
+                       S.d_deltas, c->table, c->pool, c->d_label_lut, long_min)
 #define KS_LAUNCH_APPLY_M(MODE, MERGED)                                                                              \
-  if (by_runs && time_apply)                                                                                         \
-    hipExtLaunchKernelGGL((k_apply_runs<MODE, MERGED>), dim3(rb), dim3(kRunThreads), 0, st, c->pset[set].k0, c->pset[set].k1, \
-                          0, F, n_pairs, sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut, long_min);      \
-  else if (by_runs)                                                                                                  \
-    hipLaunchKernelGGL((k_apply_runs<MODE, MERGED>), dim3(rb), dim3(kRunThreads), 0, st, F, n_pairs, sp, S.d_rays,            \
-                       S.d_deltas, c->table, c->pool, c->d_label_lut, long_min);                                      \
+  if (by_runs && c->run_threads == 256u) {                                                                           \
+    KS_LAUNCH_RUNS(MODE, MERGED, 256u);                                                                              \
+  } else if (by_runs) {                                                                                              \
+    KS_LAUNCH_RUNS(MODE, MERGED, 512u);                                                                              \
+  }                                                                                                                  \
   else if (time_apply)                                                                                               \
     hipExtLaunchKernelGGL((k_apply<MODE, MERGED>), dim3(ab), dim3(256), 0, st, c->pset[set].k0, c->pset[set].k1, 0,   \
                           F, n_pairs, sp, S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut, d_long_list,       \
@@ -1626,7 +1647,7 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     KS_LAUNCH_APPLY_M(MODE, false);                                                                                  \
   }                                                                                                                  \
   stage_mark(c, set, 9);                                                                                             \
-  if (sx && c->xl_parallel) {                                                                                        \
+  if (sx && c->xl_parallel && n_pairs >= c->xl_min_pairs) {                                                          \
     /* the class sums and the weight of such runs as integer sums per chunk, chunks side by side (ks_k_apply_xl.h); what \
        the shortcut cannot carry goes to k_apply_xlong through the fall-back list */                                    \
     hipLaunchKernelGGL(k_xl_measure<MODE>, dim3(kXlMaxRuns / 256), dim3(256), 0, sx, F, n_pairs, (const uint64_t*)sp,  \
@@ -1653,10 +1674,16 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     hipLaunchKernelGGL(k_long_bucket, dim3((cap_long + 255) / 256), dim3(256), 0, sl,                                 \
                        (const unsigned long long*)d_long_list, (const Counters*)S.d_counters, c->d_long_hdr_[par],    \
                        c->d_long_sorted_[par]);                                                                        \
-    hipLaunchKernelGGL(k_apply_long_lanes<MODE>, dim3((cap_long / 64 + kLongClasses + 3) / 4), dim3(256), 0, sl, F,   \
-                       (const uint64_t*)sp, (const RayDesc*)S.d_rays, (const float*)S.d_deltas, c->table, c->pool,     \
-                       (const uint32_t*)c->d_label_lut, (const LongHdr*)c->d_long_hdr_[par],                           \
-                       (const unsigned long long*)c->d_long_sorted_[par]);                                             \
+    if (c->lanes_depth == 4u)                                                                                        \
+      hipLaunchKernelGGL((k_apply_long_lanes<MODE, 4u>), dim3((cap_long / 64 + kLongClasses + 3) / 4), dim3(256), 0, sl, F, \
+                         (const uint64_t*)sp, (const RayDesc*)S.d_rays, (const float*)S.d_deltas, c->table, c->pool,   \
+                         (const uint32_t*)c->d_label_lut, (const LongHdr*)c->d_long_hdr_[par],                         \
+                         (const unsigned long long*)c->d_long_sorted_[par]);                                           \
+    else                                                                                                             \
+      hipLaunchKernelGGL((k_apply_long_lanes<MODE, 6u>), dim3((cap_long / 64 + kLongClasses + 3) / 4), dim3(256), 0, sl, F, \
+                         (const uint64_t*)sp, (const RayDesc*)S.d_rays, (const float*)S.d_deltas, c->table, c->pool,   \
+                         (const uint32_t*)c->d_label_lut, (const LongHdr*)c->d_long_hdr_[par],                         \
+                         (const unsigned long long*)c->d_long_sorted_[par]);                                           \
     hipLaunchKernelGGL(k_apply_long<MODE>, dim3(std::min<uint32_t>(lb, 1024u)), dim3(128), 0, sl, F, n_pairs, sp,     \
                        S.d_rays, S.d_deltas, c->table, c->pool, c->d_label_lut,                                        \
                        (const unsigned long long*)c->d_long_sorted_[par], (const Counters*)S.d_counters,               \
@@ -1671,10 +1698,15 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     }
 #undef KS_LAUNCH_APPLY
 #undef KS_LAUNCH_APPLY_M
+#undef KS_LAUNCH_RUNS
     if (sl != st) {
       if (sx) {  // S.join stands for both lists
         HIPCHK(c, hipEventRecord(S.join_x, sx));
         HIPCHK(c, hipStreamWaitEvent(sl, S.join_x, 0));
+      }
+      if (apply_beside) {  // ... and for k_apply_runs
+        HIPCHK(c, hipEventRecord(S.applied, sa));
+        HIPCHK(c, hipStreamWaitEvent(sl, S.applied, 0));
       }
       HIPCHK(c, hipEventRecord(S.join, sl));
       S.join_recorded = true;
@@ -1996,11 +2028,13 @@ int collect_block_indices(ks_ctx* c, bool only_updated, bool reset, std::vector<
 }  // namespace
 
 // find-or-insert n tile keys (device array) and initialise the newly allocated tiles
-static int insert_tiles(ks_ctx* c, const uint64_t* d_keys, size_t n) {
+static int insert_tiles(ks_ctx* c, const uint64_t* d_keys, size_t n, size_t distinct_at_most = ~(size_t)0) {
   int rc;
   if ((rc = quiesce(c))) return rc;
-  // as for frames: keep at least half of the pool free for what is coming (all n keys may be new tiles)
-  while ((size_t)c->tiles_initialised + n > (size_t)c->cfg.max_tiles / 2) {
+  // as for frames: keep at least half of the pool free for what is coming (all n keys may be new tiles — unless the caller knows
+  // how many DISTINCT keys there can be: the records of a frame name a few thousand tiles a hundred times each)
+  const size_t may_be_new = std::min(n, distinct_at_most);
+  while ((size_t)c->tiles_initialised + may_be_new > (size_t)c->cfg.max_tiles / 2) {
     const uint32_t before = c->cfg.max_tiles;
     if ((rc = grow_pool(c))) return rc;
     if (c->cfg.max_tiles == before) break;  // at the limit, or no memory: exhaustion is reported if it happens
@@ -2230,6 +2264,10 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     const char* xp = dbg_env("KS_XLONG");
     c->xlong = xp ? atoi(xp) != 0 : true;
     if (c->xlong && c->stream_long) CRCHK(hipStreamCreateWithFlags(&c->stream_xlong, hipStreamNonBlocking));
+    {
+      const char* as = dbg_env("KS_APPLY_STREAM");   // A/B: 0 = k_apply_runs on the tail stream, in front of the next frame's sort
+      if (c->stream_xlong && !(as && as[0] == '0')) CRCHK(hipStreamCreateWithFlags(&c->stream_apply, hipStreamNonBlocking));
+    }
     if (const char* ll = dbg_env("KS_LONG_LANES")) {   // A/B: 0 = k_apply_long (two wavefronts per run) for all of them, 2 = lanes for frames of any size (tests)
       c->long_lanes = atoi(ll) != 0;
       if (atoi(ll) == 2) c->long_lanes_min_pairs = 0ull;
@@ -2237,7 +2275,12 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     if (c->stream_long && c->long_lanes)
       for (int b = 0; b < 2; ++b) CRCHK(hipMalloc((void**)&c->d_long_hdr_[b], sizeof(LongHdr)));
     if (const char* lm = dbg_env("KS_LONG_MIN")) c->long_min_lanes = atoi(lm) == 16;
-    if (const char* xl = dbg_env("KS_XL_PARALLEL")) c->xl_parallel = atoi(xl) != 0;   // A/B: 0 = every such run through k_apply_xlong
+    if (const char* ld = dbg_env("KS_LANES_DEPTH")) c->lanes_depth = atoi(ld) == 4 ? 4u : 6u;
+    if (const char* rt = dbg_env("KS_RUN_THREADS")) c->run_threads = atoi(rt) == 512 ? 512u : 256u;
+    if (const char* xl = dbg_env("KS_XL_PARALLEL")) {   // A/B: 0 = every such run through k_apply_xlong, 2 = the integer-sum path for frames of any size (tests)
+      c->xl_parallel = atoi(xl) != 0;
+      if (atoi(xl) == 2) c->xl_min_pairs = 0ull;
+    }   // A/B: 0 = every such run through k_apply_xlong
     if (c->stream_xlong && c->xl_parallel) {
       CRCHK(hipMalloc((void**)&c->d_xl_runs, kXlMaxRuns * sizeof(XlRun)));
       CRCHK(hipMalloc((void**)&c->d_xl_idx, kXlMaxRuns * sizeof(uint32_t)));
@@ -2305,6 +2348,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     CRCHK(hipEventCreateWithFlags(&S.join, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.join_x, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.found, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&S.applied, hipEventDisableTiming));
   }
 #undef CRCHK
   // pair buffers start at 4 updates per point of the largest cloud (a frame that needs more grows its buffer and
@@ -2385,6 +2429,7 @@ void ks_destroy(ks_ctx* c) {
     if (S.join) (void)hipEventDestroy(S.join);
     if (S.join_x) (void)hipEventDestroy(S.join_x);
     if (S.found) (void)hipEventDestroy(S.found);
+    if (S.applied) (void)hipEventDestroy(S.applied);
     if (S.a_done) (void)hipEventDestroy(S.a_done);
   }
   for (auto& P : c->pset) {
@@ -2398,6 +2443,7 @@ void ks_destroy(ks_ctx* c) {
     if (sm && sm != c->stream) (void)hipStreamDestroy(sm);
   if (c->stream_long) (void)hipStreamDestroy(c->stream_long);
   if (c->stream_xlong) (void)hipStreamDestroy(c->stream_xlong);
+  if (c->stream_apply) (void)hipStreamDestroy(c->stream_apply);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -3040,7 +3086,8 @@ int ks_reduce(ks_ctx* c, void* rccl_comm, int rank, int world, ks_reduce_stats* 
 }
 
 // Owner: one frame's records (of the tiles this rank owns, in integration order) into the map.
-static int shard_apply_segment(ks_ctx* o, const uint64_t* d_gkey, const uint32_t* d_seq, const float* d_sdf, const float* d_uw, size_t n) {
+static int shard_apply_segment(ks_ctx* o, const uint64_t* d_gkey, const uint32_t* d_seq, const float* d_sdf, const float* d_uw, size_t n,
+                               size_t tiles_at_most) {
   if (n == 0) return KS_OK;
   if (n >= (size_t)1 << 31) { o->err = "ks_integrate_round_exact: more than 2^31 updates of one frame for one owner"; return KS_ERR_INVALID_ARG; }
   int rc;
@@ -3056,7 +3103,9 @@ static int shard_apply_segment(ks_ctx* o, const uint64_t* d_gkey, const uint32_t
   hipStream_t st = o->stream;
   const uint32_t nb = (uint32_t)((n + 255) / 256);
   hipLaunchKernelGGL(k_shard_tile_keys, dim3(nb), dim3(256), 0, st, (uint32_t)n, d_gkey, o->d_sh_tk);
-  if ((rc = insert_tiles(o, o->d_sh_tk, n))) return rc;   // get-or-insert + initialisation of the new tiles (the pool grows if it must)
+  // get-or-insert + initialisation of the new tiles (the pool grows if it must; the records cannot name more tiles than the rank
+  // that marched the frame has ever numbered)
+  if ((rc = insert_tiles(o, o->d_sh_tk, n, tiles_at_most))) return rc;
   hipLaunchKernelGGL(k_shard_import, dim3(nb), dim3(256), 0, st, (uint32_t)n, o->table, o->pool, d_gkey, d_seq, o->d_sh_pairs[0], o->d_sh_vals[0]);
   const unsigned end_bit = kShardSeqBits + 9 + bits_for(o->tiles_initialised);
   uint64_t* kres = nullptr;
@@ -3133,7 +3182,7 @@ int ks_integrate_round_exact(ks_ctx* m, ks_ctx* o, void* rccl_comm, int rank, in
   }
   uint64_t applied = 0, origin = m->sh_counts[world];
   if (world == 1) {
-    if ((rc = shard_apply_segment(o, m->d_sh_gkey[1], m->d_sh_seq[1], m->d_sh_sdf[1], m->d_sh_uw[1], send_counts[0]))) return rc;
+    if ((rc = shard_apply_segment(o, m->d_sh_gkey[1], m->d_sh_seq[1], m->d_sh_sdf[1], m->d_sh_uw[1], send_counts[0], m->tiles_initialised))) return rc;
     applied = send_counts[0];
   } else {
     std::string why;
@@ -3143,23 +3192,25 @@ int ks_integrate_round_exact(ks_ctx* m, ks_ctx* o, void* rccl_comm, int rank, in
     }
     ncclComm_t comm = (ncclComm_t)rccl_comm;
     hipStream_t st = o->stream;
-    // 1) everybody's counts (and origin-voxel flags): (world + 1) x world
-    if ((rc = ensure_reduce_scratch(o, 0, 0, world + 1))) return rc;
+    // 1) everybody's counts, origin-voxel flags and marchers' tile counts: (world + 2) x world
+    const int W2 = world + 2;
+    if ((rc = ensure_reduce_scratch(o, 0, 0, W2))) return rc;
     int32_t* d_own = o->d_rx_counts;
-    int32_t* d_all = d_own + (world + 1);
-    std::vector<int32_t> own(world + 1);
+    int32_t* d_all = d_own + W2;
+    std::vector<int32_t> own(W2);
     for (int p = 0; p < world; ++p) own[p] = (int32_t)send_counts[p];
     own[world] = (int32_t)m->sh_counts[world];
+    own[world + 1] = (int32_t)m->tiles_initialised;
     HIPCHK(o, hipMemcpyAsync(d_own, own.data(), own.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    NCCLCHK(o, g_rccl.all_gather(d_own, d_all, (size_t)world + 1, ncclInt32, comm, st));
-    std::vector<int32_t> all((size_t)(world + 1) * world);
+    NCCLCHK(o, g_rccl.all_gather(d_own, d_all, (size_t)W2, ncclInt32, comm, st));
+    std::vector<int32_t> all((size_t)W2 * world);
     HIPCHK(o, hipMemcpyAsync(all.data(), d_all, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(o, hipStreamSynchronize(st));
     std::vector<size_t> recv_counts(world), recv_off(world + 1, 0);
     for (int p = 0; p < world; ++p) {
-      recv_counts[p] = p == rank ? 0 : (size_t)all[(size_t)p * (world + 1) + rank];
+      recv_counts[p] = p == rank ? 0 : (size_t)all[(size_t)p * W2 + rank];
       recv_off[p + 1] = recv_off[p] + recv_counts[p];
-      origin |= (uint64_t)all[(size_t)p * (world + 1) + world];
+      origin |= (uint64_t)all[(size_t)p * W2 + world];
     }
     const size_t n_recv = recv_off[world];
     // 2) receive buffers on the owner context (its own d_sh_*[0]: an owner context never exports)
@@ -3194,12 +3245,12 @@ int ks_integrate_round_exact(ks_ctx* m, ks_ctx* o, void* rccl_comm, int rank, in
     for (int src = 0; src < world; ++src) {
       if (src == rank) {
         if ((rc = shard_apply_segment(o, m->d_sh_gkey[1] + send_off[rank], m->d_sh_seq[1] + send_off[rank], m->d_sh_sdf[1] + send_off[rank],
-                                      m->d_sh_uw[1] + send_off[rank], send_counts[rank])))
+                                      m->d_sh_uw[1] + send_off[rank], send_counts[rank], m->tiles_initialised)))
           return rc;
         applied += send_counts[rank];
       } else {
         if ((rc = shard_apply_segment(o, o->d_sh_gkey[0] + recv_off[src], o->d_sh_seq[0] + recv_off[src], o->d_sh_sdf[0] + recv_off[src],
-                                      o->d_sh_uw[0] + recv_off[src], recv_counts[src])))
+                                      o->d_sh_uw[0] + recv_off[src], recv_counts[src], (size_t)all[(size_t)src * W2 + world + 1])))
           return rc;
         applied += recv_counts[src];
       }

@@ -296,16 +296,15 @@ __global__ void __launch_bounds__(256) k_apply(FrameParams F, unsigned long long
 //             first-maximum label, colour, records out
 // Same operations in the same order per voxel as k_apply: bit for bit the same records.
 // ------------------------------------------------------------------------------------------
-constexpr uint32_t kRunTile = 2048;   // pairs per workgroup
-constexpr uint32_t kRunThreads = 512; // eight wavefronts: a tile has ~ 6 - 12 tasks of 64 runs, and what bounds the kernel is how many
-                                      // wavefronts a CU holds against the latency of gather -> record -> steps (LDS limits the workgroups)
-constexpr uint32_t kRunPer = kRunTile / kRunThreads;
+constexpr uint32_t kRunPer = 4;       // pairs per thread: a tile is 4 x THREADS pairs
+constexpr uint32_t kRunThreads = 512; // the default shape: eight wavefronts, tiles of 2048 pairs (~ 6 - 12 tasks of 64 runs); what bounds the kernel is how
+                                      // many wavefronts a CU holds against the latency of gather -> record -> steps.  256 (tiles of 1024) is the other
+                                      // instantiation: half the LDS and one wavefront per SIMD per workgroup — packs better beside the long-run kernels
+constexpr uint32_t kRunTile = kRunPer * kRunThreads;
 constexpr uint32_t kRunHalo = 32;     // = kLongRun: the longest run this kernel takes
-constexpr uint32_t kRunSlots = kRunTile + kRunHalo;
-constexpr uint32_t kRunMixSlots = 96;  // merged: increment vectors of mixed-label bundles parked in LDS per tile (more: read from global in the step)
 
-template <int COLOR_MODE, bool MERGED>
-__global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsigned long long n_pairs,
+template <int COLOR_MODE, bool MERGED, uint32_t THREADS = kRunThreads>
+__global__ void __launch_bounds__(THREADS) k_apply_runs(FrameParams F, unsigned long long n_pairs,
                                                             const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
                                                             const float* __restrict__ deltas, TileTable T, Pool P,
                                                             const uint32_t* __restrict__ label_lut, uint32_t max_len) {
@@ -313,47 +312,49 @@ __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsig
   // k_find_long lists exactly the longer ones
   constexpr bool HOT_ONLY = !MERGED && COLOR_MODE != KS_COLOR_MODE_COLOR;
   constexpr bool BLEND = COLOR_MODE == KS_COLOR_MODE_COLOR;
+  constexpr uint32_t kTile = kRunPer * THREADS, kSlots = kTile + kRunHalo;
+  constexpr uint32_t kMixSlots = kTile / 21;   // merged: increment vectors of mixed-label bundles parked in LDS per tile (more: read from global in the step)
   static_assert(kRunHalo == kLongRun, "a short run must end inside the halo");
-  static_assert(kRunHalo <= 64 && kRunTile % kRunThreads == 0, "tile shape");
-  __shared__ float s_sdf[kRunSlots], s_uw[kRunSlots];
-  __shared__ uint32_t s_info[kRunSlots];                     // [7:0] label, [9:8] kind (1 pure, 2 mixed: vector in s_mix, 3 mixed: vector in global memory)
-  __shared__ float s_dm[MERGED ? kRunSlots : 1], s_dn[MERGED ? kRunSlots : 1];   // merged: per-bundle increments (mixed: s_dm = slot in s_mix / bundle position)
-  __shared__ uint32_t s_col[BLEND ? kRunSlots : 1];
-  __shared__ unsigned long long s_bounds[kRunSlots / 64 + 3 + kRunThreads / 64];  // bit j: pair j of the tile starts a run, or lies past the end of the list
-  __shared__ uint32_t s_run[kRunTile];                        // the tile's short runs, longest first: start | length << 16
-  __shared__ uint32_t s_run_vox[kRunTile];                    // ... and their voxels
+  static_assert(kRunHalo <= 64 && THREADS % 64 == 0 && THREADS >= 256, "tile shape");
+  __shared__ float s_sdf[kSlots], s_uw[kSlots];
+  __shared__ uint32_t s_info[kSlots];                     // [7:0] label, [9:8] kind (1 pure, 2 mixed: vector in s_mix, 3 mixed: vector in global memory)
+  __shared__ float s_dm[MERGED ? kSlots : 1], s_dn[MERGED ? kSlots : 1];   // merged: per-bundle increments (mixed: s_dm = slot in s_mix / bundle position)
+  __shared__ uint32_t s_col[BLEND ? kSlots : 1];
+  __shared__ unsigned long long s_bounds[kSlots / 64 + 3 + THREADS / 64];  // bit j: pair j of the tile starts a run, or lies past the end of the list
+  __shared__ uint32_t s_run[kTile];                        // the tile's short runs, longest first: start | length << 16
+  __shared__ uint32_t s_run_vox[kTile];                    // ... and their voxels
   __shared__ uint32_t s_hist[kLongRun + 2];
   __shared__ uint32_t s_lut[256];
-  __shared__ float s_mix[MERGED ? kRunMixSlots : 1][kNumLabels];
+  __shared__ float s_mix[MERGED ? kMixSlots : 1][kNumLabels];
   __shared__ uint32_t s_n_mix, s_next_task;
   const uint32_t lane = lane_id(), tid = threadIdx.x;
-  const unsigned long long base = (unsigned long long)blockIdx.x * kRunTile;
+  const unsigned long long base = (unsigned long long)blockIdx.x * kTile;
   if (tid < 256u) s_lut[tid] = label_lut[tid];
   if (tid < kLongRun + 2) s_hist[tid] = 0u;
   if (tid == 0) {
     s_n_mix = 0u;
     s_next_task = 0u;
   }
-  if (tid < 2) s_bounds[kRunSlots / 64 + 1 + tid] = ~0ull;
+  if (tid < 2) s_bounds[kSlots / 64 + 1 + tid] = ~0ull;
 
   // ---- phase A1: the tile's keys -> where its runs begin (a bit per pair) ----
-  constexpr uint32_t NA = kRunPer + 1;   // the last one is the halo: pairs [kRunTile, kRunTile + 32), threads 0..31
+  constexpr uint32_t NA = kRunPer + 1;   // the last one is the halo: pairs [kTile, kTile + 32), threads 0..31
   uint64_t key[NA];
   bool valid[NA];
   {
     uint64_t pkey[NA];
 #pragma unroll
     for (uint32_t k = 0; k < NA; ++k) {
-      const uint32_t j = k * kRunThreads + tid;
+      const uint32_t j = k * THREADS + tid;
       const unsigned long long i = base + j;
-      valid[k] = j < kRunSlots && i < n_pairs;
+      valid[k] = j < kSlots && i < n_pairs;
       key[k] = valid[k] ? pairs[i] : 0ull;
       pkey[k] = (valid[k] && i > 0) ? pairs[i - 1] : ~0ull;
     }
     __syncthreads();   // (the initial values above)
 #pragma unroll
     for (uint32_t k = 0; k < NA; ++k) {
-      const uint32_t j = k * kRunThreads + tid;
+      const uint32_t j = k * THREADS + tid;
       const bool head = valid[k] && ((base + j == 0) || ((uint32_t)(pkey[k] >> F.seq_bits) != (uint32_t)(key[k] >> F.seq_bits)));
       const unsigned long long m = __ballot(head || !valid[k]);
       if (lane == 0) s_bounds[j >> 6] = m;   // (the halo round: wavefront 0 writes word 32, the others all-ones past it)
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsig
   bool need[NA];
 #pragma unroll
   for (uint32_t k = 0; k < NA; ++k) {
-    const uint32_t j = k * kRunThreads + tid;
+    const uint32_t j = k * THREADS + tid;
     need[k] = false;
     if (k < kRunPer) my_len[k] = 0u;
     if (valid[k]) {
@@ -393,7 +394,7 @@ __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsig
         const uint32_t d1 = (uint32_t)__clz((int)back);        // pairs back to the head (0: j is the head)
         const uint32_t d2 = (uint32_t)__ffs((int)fwd);         // pairs on to the next boundary
         const uint32_t len = d1 + d2;
-        const bool head_in_tile = j - d1 < kRunTile;
+        const bool head_in_tile = j - d1 < kTile;
         if (len <= max_len && head_in_tile) {
           need[k] = true;
           if (d1 == 0u && k < kRunPer) {
@@ -422,7 +423,7 @@ __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsig
   }
 #pragma unroll
   for (uint32_t k = 0; k < NA; ++k) {
-    const uint32_t j = k * kRunThreads + tid;
+    const uint32_t j = k * THREADS + tid;
     if (need[k]) {
       const uint32_t vox = (uint32_t)(key[k] >> F.seq_bits);
       int tx, ty, tz;
@@ -447,7 +448,7 @@ __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsig
           const uint32_t rp = (uint32_t)key[k] & F.point_mask;
           const uint32_t slot = atomicAdd(&s_n_mix, 1u);
           const float* dl = deltas + (size_t)rp * kNumLabels;
-          if (slot < kRunMixSlots) {
+          if (slot < kMixSlots) {
 #pragma unroll
             for (int l = 0; l < kNumLabels; ++l) s_mix[slot][l] = dl[l];
             dm = __uint_as_float(slot);
@@ -480,7 +481,7 @@ __global__ void __launch_bounds__(kRunThreads) k_apply_runs(FrameParams F, unsig
   for (uint32_t k = 0; k < kRunPer; ++k)
     if (my_len[k]) {
       const uint32_t pos = atomicAdd(&s_hist[my_len[k]], 1u);
-      s_run[pos] = (k * kRunThreads + tid) | (my_len[k] << 16);
+      s_run[pos] = (k * THREADS + tid) | (my_len[k] << 16);
       s_run_vox[pos] = (uint32_t)(key[k] >> F.seq_bits);
     }
   __syncthreads();
@@ -709,7 +710,7 @@ __global__ void __launch_bounds__(256) k_long_bucket(const unsigned long long* _
   if (r < n_long) sorted[s_base[c] + rank] = e;
 }
 
-template <int COLOR_MODE>
+template <int COLOR_MODE, uint32_t D = 6>
 __global__ void __launch_bounds__(256) k_apply_long_lanes(FrameParams F, const uint64_t* __restrict__ pairs, const RayDesc* __restrict__ rays,
                                                           const float* __restrict__ deltas, TileTable T, Pool P,
                                                           const uint32_t* __restrict__ label_lut, const LongHdr* __restrict__ H,
@@ -745,7 +746,6 @@ __global__ void __launch_bounds__(256) k_apply_long_lanes(FrameParams F, const u
   // rays of the next D are in flight while a step is applied (with one step of look-ahead a step cost the latency of its
   // gather: 0.85 us — a 640x480 frame waited 0.9 ms for its handful of 1000-update runs).  Compile-time slots: the step loop
   // is unrolled D times.
-  constexpr uint32_t D = 6;
   uint64_t kq[2 * D];
   RayDesc dq[D];
 #pragma unroll

@@ -100,7 +100,11 @@ def test_sensor_voxel_runs_as_integer_sums_are_exact(monkeypatch, method, kw):
     okw = dict(COMMON, method=method)
     okw.update(kw)
     o = O.Oracle(O.default_config(integrator_threads=1, **okw))
+    monkeypatch.setenv("KS_DEBUG", "1")
+    monkeypatch.setenv("KS_XL_PARALLEL", "2")   # (the library takes this path from 2^23 pairs per frame on)
     h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 18, **okw))
+    monkeypatch.delenv("KS_XL_PARALLEL")
+    monkeypatch.delenv("KS_DEBUG")
     prob = okw.get("color_mode") == 2
     rep = _run(o, h, _fixed_pose_frames(5), exact=not prob)
     if prob:
@@ -115,7 +119,7 @@ def test_sensor_voxel_runs_both_ways_leave_the_same_map(monkeypatch):
     frames = _fixed_pose_frames(4, 640, 480)
     okw = dict(COMMON, method=1, max_weight=50.0)
     maps = []
-    for par in ("1", "0"):
+    for par in ("2", "0"):
         monkeypatch.setenv("KS_DEBUG", "1")
         monkeypatch.setenv("KS_XL_PARALLEL", par)
         h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 19, pipeline_frames=2, **okw))
@@ -125,6 +129,6 @@ def test_sensor_voxel_runs_both_ways_leave_the_same_map(monkeypatch):
             h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
         h.flush()
         st = h.update_stats()
-        assert (st["walked"] > 0) == (par == "1"), st
+        assert (st["walked"] > 0) == (par == "2"), st
         maps.append(h)
     compare_maps(maps[0], maps[1], exact=True)

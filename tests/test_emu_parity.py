@@ -183,7 +183,7 @@ RUNS_CASES = {
     "merged_sensor_voxel_integer_sums": dict(method=1, size=[96, 72], frames=4, fixed_pose=True, cfg=dict(max_weight=2.0), xl_walked_at_least=1),
 }
 for _name, _spec in RUNS_CASES.items():
-    case_job("test_lane_per_run_update_kernel_equals_oracle[%s]" % _name, _spec, env_extra={"KS_DEBUG": "1", "KS_APPLY_RUNS": "1", "KS_LONG_LANES": "2"},
+    case_job("test_lane_per_run_update_kernel_equals_oracle[%s]" % _name, _spec, env_extra={"KS_DEBUG": "1", "KS_APPLY_RUNS": "1", "KS_LONG_LANES": "2", "KS_XL_PARALLEL": "2"},
              weight=40 if "close_up" in _name else 10)
 
 
