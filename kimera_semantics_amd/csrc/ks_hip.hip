@@ -2265,8 +2265,10 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     c->xlong = xp ? atoi(xp) != 0 : true;
     if (c->xlong && c->stream_long) CRCHK(hipStreamCreateWithFlags(&c->stream_xlong, hipStreamNonBlocking));
     {
-      const char* as = dbg_env("KS_APPLY_STREAM");   // A/B: 0 = k_apply_runs on the tail stream, in front of the next frame's sort
-      if (c->stream_xlong && !(as && as[0] == '0')) CRCHK(hipStreamCreateWithFlags(&c->stream_apply, hipStreamNonBlocking));
+      // A/B only (KS_APPLY_STREAM=1): measured, it LOSES — C4-merged 6.12 vs 6.00 ms/frame, C3 0.75 vs 0.60 (one more stream for the
+      // runtime's hardware queues to share) — so k_apply_runs stays on the tail stream
+      const char* as = dbg_env("KS_APPLY_STREAM");
+      if (c->stream_xlong && as && as[0] == '1') CRCHK(hipStreamCreateWithFlags(&c->stream_apply, hipStreamNonBlocking));
     }
     if (const char* ll = dbg_env("KS_LONG_LANES")) {   // A/B: 0 = k_apply_long (two wavefronts per run) for all of them, 2 = lanes for frames of any size (tests)
       c->long_lanes = atoi(ll) != 0;
