@@ -104,8 +104,8 @@ typedef struct ks_config {
    * 16 .. 4096: the ORDERED-PHASE schedule alone (restated for the CPU in oracle/ks_oracle.cpp, against
    *    which it is bit-exact): integration positions are cut into phases whose length grows by this factor (in
    *    1/16ths) — 32 = doubling, 16 = one generation (one integration position per chain = per group of the integration order) per phase.  Deterministic for every value, a few
-   *    launches cheaper per frame than the exact mode, and NOT the reference's map (touched-voxel Jaccard 0.976-0.995
-   *    against the serial order): a throughput option for callers who accept that. */
+   *    launches cheaper per frame than the exact mode, and NOT the reference's map (touched-voxel Jaccard against the serial order, 640x480 / 5 cm, "mixed" order in upstream's
+   *    form: 0.9998 for 16, 0.976 for 24, 0.962 for 32, 0.916 for 64 — DESIGN.md §3.2; tests/test_early_out_fidelity.py asserts >= 0.93 for 32): a throughput option for callers who accept that. */
   int32_t early_out_phase_growth;
   /* ---- device sizing ---- */
   int32_t device_id;                /* HIP device ordinal */

@@ -100,7 +100,8 @@ constexpr int kMaxLag = 16;          // largest ks_config.pipeline_frames
 constexpr int kSlots = kMaxLag + 8;  // frame slots at most; a context uses ks_ctx::n_slots of them: 12 up to a lag of 8 (three batches
                                      // of four), 24 above (three batches of eight) — the tail may lag up to kMaxLag calls
 constexpr int kMarchStreams = 8;
-constexpr int kObsTables = 16;       // early-out tables: one per frame whose stage B can be in flight (two batches of eight)
+constexpr int kObsTables = 16;       // early-out tables at most; a context uses n_obs = batch x march streams of them: one per frame whose stage B
+                                     // can be in flight (8 today: two batches of four, or one of eight)
 struct HostSnap {
   Counters c;
   uint32_t n_tiles;
@@ -172,7 +173,7 @@ struct FrameSlot {
 
 // HIP-event sets for ks_profile: recorded in stream order, resolved lazily (before reuse or in
 // ks_profile_get) so that profiling never adds a host wait to a frame.
-constexpr int kProfSets = 32;   // > 2 x the largest lag
+constexpr int kProfSets = 32;   // 2 x the largest lag (kMaxLag = 16): a set is reused 32 frames later, long after its frame's tail
 constexpr int kStageEvents = KS_STAGE_COUNT + 3;  // 0..3 stage A | 4,5 march begin/end | 6 tail begin, 7..10
 struct ProfSet {
   hipEvent_t ev[kStageEvents]{};
