@@ -229,7 +229,26 @@ def measure(B, torch, dist, dev, wl, ring, W, K, R, pipeline, max_tiles, world, 
                 bufs.append((p, v))
             pinned.append((n, bufs))
 
+    if entry == "depth":
+        # the depth + label IMAGES from page-locked host buffers (4 + 1 bytes per pixel instead of 17 per point);
+        # the back-projection runs on the GPU, the result is the same cloud
+        import ctypes
+        import numpy as np
+        pinned = []
+        for f in ring.frames:
+            bufs = []
+            for arr in (np.ascontiguousarray(f.depth, dtype=np.float32), np.ascontiguousarray(f.label_img, dtype=np.uint8)):
+                p = B.lib().ks_host_alloc(arr.nbytes)
+                v = np.frombuffer((ctypes.c_uint8 * arr.nbytes).from_address(p), dtype=arr.dtype).reshape(arr.shape)
+                v[...] = arr
+                bufs.append((p, v))
+            pinned.append((0, bufs))
+
     def step(i):
+        if entry == "depth":
+            f = ring.host(i)
+            _, bufs = pinned[i % len(ring)]
+            return integ.integrate_depth(f.T_G_C, bufs[0][1], f.K, label_img=bufs[1][1])
         if entry == "host":
             f = ring.host(i)
             n, bufs = pinned[i % len(ring)]
@@ -887,7 +906,8 @@ def main():
             for name, swl, kw in (("C2-ordered-phases", WORKLOADS["C2"], dict(cfg=dict(early_out_phase_growth=32), pipe=pipeline)),
                                   ("C2-unpipelined", WORKLOADS["C2"], dict(cfg={}, pipe=0)),
                                   ("C3", WORKLOADS["C3"], dict(cfg={}, pipe=pipeline)),
-                                  ("C2-host-inputs", WORKLOADS["C2"], dict(cfg={}, pipe=pipeline, entry="host"))):
+                                  ("C2-host-inputs", WORKLOADS["C2"], dict(cfg={}, pipe=pipeline, entry="host")),
+                                  ("C2-depth-host-inputs", WORKLOADS["C2"], dict(cfg={}, pipe=pipeline, entry="depth"))):
                 if not want(name) or args.method != "fast" or (args.width, args.height) != (640, 480):
                     continue
                 try:
@@ -908,6 +928,9 @@ def main():
                     elif name == "C2-host-inputs":
                         note = ("ks_integrate_points on page-locked HOST buffers: the H2D copy of every frame is inside the call "
                                 "(SURVEY.md §8d's frames/s definition); never the headline value")
+                    elif name == "C2-depth-host-inputs":
+                        note = ("ks_integrate_depth on page-locked HOST images (f32 depth + u8 labels: 5 bytes per pixel instead of 17 per point), "
+                                "H2D copy and back-projection inside the call; the same frames, the same cloud")
                     elif name == "C3":
                         note = "bundles integrated in the reference's std::unordered_map iteration order (bit-exact vs the real sources)"
                     srec, _ = record(name, swl, sm, sK, cof, show, note=note, pmc_name="c3" if name == "C3" else None)

@@ -101,7 +101,8 @@ def main():
         out[wl] = rows
         # whole frame (round 6): every kernel's bytes per launch x its launches per frame (a kernel launched once per frame
         # defines the frame count of the averaged window)
-        n_frames_avg = max(1, len(fe.get("k_publish", fe.get("k_scan_local", [0]))))
+        kp = [k for k in fe if k.startswith("k_points_")]   # one launch per frame (k_publish is one per BATCH of frames in pipelined contexts)
+        n_frames_avg = max(1, len(fe[kp[0]]) if kp else len(fe.get("k_publish", [0])))
         whole = sum((sum(fe[k]) * corr_f + sum(wr.get(k, [0])) * corr_w) * 1024 for k in fe) / n_frames_avg
         print(f"# {wl}: whole frame, all kernels: {whole / 1e6:.1f} MB of HBM traffic per frame (FETCH x {corr_f:.3f} + WRITE, averaged over {n_frames_avg} frames)")
         ka = [k for k in rows if k.startswith("k_apply<")] or [k for k in rows if k.startswith("k_apply_runs<")]
