@@ -34,7 +34,10 @@ def export_all(h, torch=None):
     keys = h.tile_keys()
     n = len(keys)
     rec = np.zeros((n, 512, 32), dtype=np.uint32)
-    if n:
+    if n and os.environ.get("KS_HIP_LIB", "").endswith("libks_hip_emu.so"):
+        # the host functional model (tools/emu): "device" memory is host memory
+        h.export_tiles(np.arange(n, dtype=np.uint32), rec.ctypes.data)
+    elif n:
         hip = C.CDLL("libamdhip64.so")
         d = C.c_void_p()
         assert hip.hipMalloc(C.byref(d), C.c_size_t(n * 65536)) == 0
@@ -53,6 +56,8 @@ def round_config_kw():
 def round_frames(n_frames, w=160, h=120):
     """The frames of tests/test_reduce_multiprocess_gpu.py::test_exact_round_*: overlapping views of one wall, by GLOBAL frame number."""
     from kimera_semantics_amd import synth
+    if os.environ.get("KS_ROUND_WH"):   # (the CPU tier runs the same test on the functional model, on small frames)
+        w, h = (int(x) for x in os.environ["KS_ROUND_WH"].split("x"))
     sc = synth.make_scene("room")
     return [synth.render_frame(sc, synth.arc_pose(k, n_frames, spacing=0.25), w, h, seed=800 + k) for k in range(n_frames)]
 
@@ -77,9 +82,23 @@ def main_round(rank, world, comm, out, n_rounds):
     print("round worker", rank, "ok", stats)
 
 
+def main_seq(out, n_frames):
+    """All frames in order on ONE context (what the owners' tiles of the exact rounds must equal)."""
+    from kimera_semantics_amd import binding as B
+    h = B.HipIntegrator(B.default_config(max_tiles=4096, max_points=1 << 15, **round_config_kw()))
+    for f in round_frames(n_frames):
+        h.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+    keys, rec = export_all(h)
+    np.savez(os.path.join(out, "round_seq.npz"), keys=keys, rec=rec[:, :, :25])
+    h.close()
+    print("sequential ok", len(keys), "tiles")
+
+
 def main():
     import time
     t0 = time.time()
+    if sys.argv[1] == "seq":
+        return main_seq(sys.argv[2], int(sys.argv[3]))
     rank, world, uid_hex, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
     from kimera_semantics_amd import binding as B
     lib = C.CDLL(os.environ["KS_RCCL_LIB"])

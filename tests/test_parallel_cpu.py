@@ -117,3 +117,64 @@ def test_merge_rule_properties():
     # weight clamp
     big = b.copy(); big[0, 1] = np.float32(9999.5).view(np.uint32)
     assert M.merge_records(big, a, 10000.0, 1, lut)[0, 1].view(np.float32) == 10000.0
+
+
+def test_exact_round_two_ranks_on_the_functional_model_is_the_sequential_map(tmp_path):
+    """ks_integrate_round_exact with world = 2, WITHOUT a GPU: two processes drive the host functional model of the library
+    (tools/emu: the device code compiled for the CPU) and exchange their update records through the librccl test double built
+    against the same stand-in runtime; a third process integrates the four frames in order on one context.  The tiles a rank
+    owns must be the sequential ones, bit for bit (the GPU tier runs the same worker with 2 and 3 ranks on the real device)."""
+    import ctypes as C
+    import subprocess
+    import sys
+    import numpy as np
+    from kimera_semantics_amd import parallel as PAR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        pytest.skip("host clang++ of the ROCm toolchain not found")
+    r = subprocess.run(["bash", os.path.join(root, "tools", "emu", "build_emu.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    emu = os.path.join(root, "tools", "emu", "_build", "libks_hip_emu.so")
+    mock = str(tmp_path / "libmock_rccl_emu.so")
+    r = subprocess.run([cxx, "-std=c++17", "-O1", "-fPIC", "-shared", "-DKS_EMU_BUILD", "-Wno-unknown-attributes", "-I", os.path.join(root, "tools", "emu"),
+                        "-o", mock, os.path.join(root, "tests", "mock_rccl", "mock_rccl.cpp"), "-lpthread"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lib = C.CDLL(mock)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_byte * 128)]
+    uid = UniqueId()
+    assert lib.ncclGetUniqueId(C.byref(uid)) == 0
+    world, n_rounds = 2, 2
+    env = dict(os.environ, KS_HIP_LIB=emu, KS_RCCL_LIB=mock, KS_ROUND_WH="48x36")
+    worker = os.path.join(root, "tests", "reduce_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(rk), str(world), bytes(uid).hex(), str(tmp_path), f"round:{n_rounds}"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for rk in range(world)]
+    procs.append(subprocess.Popen([sys.executable, worker, "seq", str(tmp_path), str(world * n_rounds)], env=env, stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung")
+        outs.append(o)
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    with np.load(os.path.join(str(tmp_path), "round_seq.npz")) as npz:
+        want = dict(zip(npz["keys"].tolist(), npz["rec"]))
+    owners = PAR.owner_of(np.array(sorted(want), dtype=np.uint64), world)
+    total = 0
+    for rk in range(world):
+        with np.load(os.path.join(str(tmp_path), f"round_rank{rk}.npz")) as npz:
+            got = {k: npz[k] for k in npz.files}
+        assert not got["origin"].any()
+        mine = {k for k, ow in zip(sorted(want), owners.tolist()) if ow == rk}
+        assert set(got["keys"].tolist()) == mine
+        for i, k in enumerate(got["keys"].tolist()):
+            assert np.array_equal(got["rec"][i], want[k]), f"rank {rk} tile {k}"
+        total += int(got["applied"].sum())
+        assert int(got["sent"].sum()) > 0
+    assert total > 0
