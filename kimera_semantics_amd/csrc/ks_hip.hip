@@ -158,6 +158,7 @@ struct FrameSlot {
   hipEvent_t join_x = nullptr;                // the runs of more than kXLongRun updates applied (stream_xlong)
   hipEvent_t found = nullptr;                 // the long runs listed on the long-run stream (k_find_long beside k_apply_runs)
   hipEvent_t applied = nullptr;               // k_apply_runs done (stream_apply); S.join waits for it
+  hipEvent_t sorted = nullptr;                // the pair sort done on the front stream (sort_on_front)
   bool tail_recorded = false;
   bool join_recorded = false;
   bool b_launched = false;    // stage B of the frame has been enqueued (with its batch)
@@ -364,7 +365,9 @@ struct ks_ctx {
   // 2.45 vs 3.08 ms, the frame 5.98 vs 6.26 ms (profiles/r06_c4_merged_ab.txt) — a workgroup of one wavefront per SIMD finds room
   // where one of two per SIMD does not
   uint32_t run_threads = 256u;
-  uint32_t lanes_depth = 6u;   // k_apply_long_lanes: rays in flight per lane   // (below: too few such runs to fill wavefronts with — k_apply_long takes them all)
+  uint32_t lanes_depth = 6u;   // k_apply_long_lanes: rays in flight per lane
+  bool sort_on_front = false;          // the pair sort of pipelined contexts without an early-out on the front stream (frame_tail)
+  FrameSlot* last_tail_of_parity[2] = {nullptr, nullptr};   // (below: too few such runs to fill wavefronts with — k_apply_long takes them all)
   unsigned long long* d_long_sorted_[2] = {nullptr, nullptr};
   LongHdr* d_long_hdr_[2] = {nullptr, nullptr};
   unsigned long long* d_xl_fb = nullptr;
@@ -591,6 +594,7 @@ int ensure_pairs_out(ks_ctx* c, size_t n) {
   const size_t cap = std::max<size_t>(n + n / 4, 1 << 20);
   int rc;
   if (c->stream_long) HIPCHK(c, hipStreamSynchronize(c->stream_long));  // long runs of the previous frame may still read them
+  if (c->sort_on_front && c->stream) HIPCHK(c, hipStreamSynchronize(c->stream));   // (the previous frame's pair sort may still write them)
   if (c->stream_xlong) HIPCHK(c, hipStreamSynchronize(c->stream_xlong));
   if (c->stream_tail) HIPCHK(c, hipStreamSynchronize(c->stream_tail));
   for (int b = 0; b < 2; ++b) {
@@ -1572,7 +1576,27 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
     const int par = (int)(S.frame_no & 1u);
     uint64_t* const d_pairs2 = c->d_pairs2_[par];
     unsigned long long* const d_long_list = c->d_long_list_[par];
-    if ((rc = sort_keys(c, S.d_pairs, d_pairs2, n_pairs, std::min(56u, end_bit), &sp, F.seq_bits, /*tail=*/true))) return rc;
+    // Pipelined contexts without an early-out (stage B follows stage A on the front stream): the pair sort — bound by HBM — goes to
+    // the FRONT stream, the update — bound by resident workgroups — stays on the tail stream, so that the sort of frame f runs beside
+    // the update of frame f - 1 (on one stream they ran one after the other: the tail stream was the frame period).  The sort waits for
+    // the update that last read the buffer set it writes (frame f - 2: the sets alternate), the tail stream for the sort.
+    const bool sort_front = c->sort_on_front && st != c->stream && !c->uses_early_out && !(set >= 0 && c->pset[set].stages);
+    if (sort_front) {
+      hipStream_t ss = c->stream;
+      FrameSlot* prev = c->last_tail_of_parity[par];
+      if (prev && prev != &S) {
+        if (prev->tail_recorded) HIPCHK(c, hipStreamWaitEvent(ss, prev->tail_done, 0));
+        if (prev->join_recorded) HIPCHK(c, hipStreamWaitEvent(ss, prev->join, 0));
+      }
+      HostTimer ht(&c->hp_sort);
+      HIPCHK(c, (ksrs::sort<uint64_t, false>(c->sort_ws_tail, S.d_pairs, d_pairs2, nullptr, nullptr, (size_t)n_pairs, std::min(56u, end_bit), ss, &sp,
+                                             nullptr, F.seq_bits)));
+      HIPCHK(c, hipEventRecord(S.sorted, ss));
+      HIPCHK(c, hipStreamWaitEvent(st, S.sorted, 0));
+    } else if ((rc = sort_keys(c, S.d_pairs, d_pairs2, n_pairs, std::min(56u, end_bit), &sp, F.seq_bits, /*tail=*/true))) {
+      return rc;
+    }
+    c->last_tail_of_parity[par] = &S;
     stage_mark(c, set, 8);
     const uint32_t ab = (uint32_t)((n_pairs + 255) / 256);
     const uint32_t run_tile = kRunPer * c->run_threads;
@@ -2278,6 +2302,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     if (c->stream_long && c->long_lanes)
       for (int b = 0; b < 2; ++b) CRCHK(hipMalloc((void**)&c->d_long_hdr_[b], sizeof(LongHdr)));
     if (const char* lm = dbg_env("KS_LONG_MIN")) c->long_min_lanes = atoi(lm) == 16;
+    if (const char* sf = dbg_env("KS_SORT_FRONT")) c->sort_on_front = atoi(sf) != 0;
     if (const char* ld = dbg_env("KS_LANES_DEPTH")) c->lanes_depth = atoi(ld) == 4 ? 4u : 6u;
     if (const char* rt = dbg_env("KS_RUN_THREADS")) c->run_threads = atoi(rt) == 512 ? 512u : 256u;
     if (const char* xl = dbg_env("KS_XL_PARALLEL")) {   // A/B: 0 = every such run through k_apply_xlong, 2 = the integer-sum path for frames of any size (tests)
@@ -2352,6 +2377,7 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     CRCHK(hipEventCreateWithFlags(&S.join_x, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.found, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.applied, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&S.sorted, hipEventDisableTiming));
   }
 #undef CRCHK
   // pair buffers start at 4 updates per point of the largest cloud (a frame that needs more grows its buffer and
@@ -2433,6 +2459,7 @@ void ks_destroy(ks_ctx* c) {
     if (S.join_x) (void)hipEventDestroy(S.join_x);
     if (S.found) (void)hipEventDestroy(S.found);
     if (S.applied) (void)hipEventDestroy(S.applied);
+    if (S.sorted) (void)hipEventDestroy(S.sorted);
     if (S.a_done) (void)hipEventDestroy(S.a_done);
   }
   for (auto& P : c->pset) {
