@@ -2385,13 +2385,17 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   c->pairs_hint.store((size_t)cfg->max_points * 4, std::memory_order_relaxed);
   size_t eo_marks0 = std::max<size_t>((size_t)1 << 20, 4 * (size_t)cfg->max_points), eo_x0 = std::max<size_t>((size_t)1 << 17, (size_t)cfg->max_points);
   // long rays: the marks cover whole rays (measured at 1280x720 / 2 cm / 10 m: 250 marks per point of the cloud; room for a third of
-  // the longest possible ray) — room for that from the start, instead of a first frame that repeats on the host while the
-  // buffers grow (one frame at a time there: one set of buffers, 33 bytes per mark)
+  // the longest possible ray = ~10 GB there).  Asked for here, allocated by the first integrate call (the growth path at the top of
+  // integrate_device_impl, before the frame is enqueued): a context that is created and never integrates (a map that is only loaded, merged into
+  // or read back) does not hold it, and a device without the room falls back to the host-driven loop instead of failing
+  // ks_create.
+  size_t eo_marks_first = 0;
   if (c->exact_early_out && c->eo_device && steps_max_of(c->cfg, c->voxel_size_inv) > 400)
-    eo_marks0 = std::max<size_t>(eo_marks0, (size_t)cfg->max_points * (steps_max_of(c->cfg, c->voxel_size_inv) / 3 + 32));
+    eo_marks_first = (size_t)cfg->max_points * (steps_max_of(c->cfg, c->voxel_size_inv) / 3 + 32);
   // (tests: start small, so that the overflow -> host-driven loop -> grow path is exercised)
-  if (const char* e = dbg_env("KS_EXACT_CAP_MARKS")) eo_marks0 = std::max<size_t>(64, (size_t)atoll(e));
+  if (const char* e = dbg_env("KS_EXACT_CAP_MARKS")) eo_marks0 = std::max<size_t>(64, (size_t)atoll(e)), eo_marks_first = 0;
   if (const char* e = dbg_env("KS_EXACT_CAP_X")) eo_x0 = std::max<size_t>(8, (size_t)atoll(e));
+  if (eo_marks_first > eo_marks0) c->eo_want_marks.store(eo_marks_first, std::memory_order_relaxed);
   if (ensure_points(c, cfg->max_points) != KS_OK || ensure_exact_slots(c, eo_marks0, eo_x0) != KS_OK) {
     g_create_error = c->err;
     ks_destroy(c);
