@@ -10,9 +10,17 @@ print(d["value"], d["ms_per_step"])
 for r in d.get("secondary", []): print("   ", r)
 PY
 python - <<PY
-import torch, time
+import torch, numpy as np
 from kimera_semantics_amd import binding as B
-import inspect
-free0 = torch.cuda.mem_get_info()[0]
-print("free before create", free0 / 2**30)
+g = lambda: torch.cuda.mem_get_info()[0] / 2**30
+torch.zeros(1, device="cuda"); f0 = g()
+h = B.HipIntegrator(B.default_config(device_id=0, max_tiles=1 << 13, max_points=1280 * 720, voxel_size=0.02, max_ray_length_m=10.0))
+f1 = g()
+n = 1280 * 720
+rng = np.random.default_rng(0)
+xyz = rng.random((n, 3), dtype=np.float32) * np.float32(4.0) - np.float32(2.0); xyz[:, 2] = 3.0; rgba = np.zeros((n, 4), np.uint8); lab = np.zeros(n, np.uint8)
+h.integrate(np.eye(4, dtype=np.float32), xyz, rgba, lab)
+f2 = g()
+print("free GiB: before create %.2f, after create %.2f (create holds %.2f), after the first frame %.2f (the frame added %.2f)" % (f0, f1, f0 - f1, f2, f1 - f2))
+h.close()
 PY
