@@ -435,6 +435,19 @@ def roofline_of(m, region, K, upd_counted, world=1, pmc_name=None):
     }
 
 
+
+def steady_state(B, torch, dist, dev, wl, ring, n_frames, pipeline, max_tiles, **cfg_extra):
+    """The same stream in ONE long region: a region of K frames pays the pipeline's fill and drain once per K (flush + synchronize are
+    inside it, as the measurement contract wants), which at 12 frames per region is 3 % of a C4 frame."""
+    m = measure(B, torch, dist, dev, wl, ring, 0, n_frames, 2, pipeline, max_tiles, 1, **cfg_extra)
+    dts = sorted(r["dt"] for r in m["regions"])
+    reg = min(m["regions"], key=lambda r: r["dt"])
+    return {"frames_in_one_region": n_frames, "ms_per_step": round(dts[0] / n_frames * 1e3, 4),
+            "ms_per_step_all_regions": [round(d / n_frames * 1e3, 4) for d in dts],
+            "gpu_counted_value": round(reg["updates"] / reg["dt"] / 1e6, 3), "unit": "Mvoxel-updates/s",
+            "note": "one region of that many frames (flush + synchronize inside): the stream's steady-state rate; never `value`"}
+
+
 def record(name, wl, m, K, count_of_frame, how, world=1, pmc_name=None, note=None, credit_scale=1.0):
     """One result record from the MEDIAN timed region (the primary line's core fields; also the secondary configs).
     count_of_frame(i) = reference-order update count of frame i, or None: the GPU's own count (x credit_scale <= 1)."""
@@ -881,6 +894,11 @@ def main():
             "host_ms_per_frame": {"in_call": round(m["prof"]["host_ms"] / max(1, m["prof"]["frames"]), 4),
                                   "of_which_waiting_for_snapshot": round(m["prof"]["host_wait_ms"] / max(1, m["prof"]["frames"]), 4)},
         }
+        if world == 1 and not args.no_secondary:
+            try:
+                out["steady_state"] = steady_state(B, torch, dist, dev, wl, ring, 10 * len(ring), pipeline, 1 << 13)
+            except Exception as e:
+                out["steady_state"] = {"error": f"{type(e).__name__}: {e}"}
         if reg["reduce"] is not None:
             out["reduce"] = reg["reduce"]
         if c5 is not None:
@@ -934,6 +952,8 @@ def main():
                     elif name == "C3":
                         note = "bundles integrated in the reference's std::unordered_map iteration order (bit-exact vs the real sources)"
                     srec, _ = record(name, swl, sm, sK, cof, show, note=note, pmc_name="c3" if name == "C3" else None)
+                    if name == "C3":
+                        srec["steady_state"] = steady_state(B, torch, dist, dev, swl, sub_ring, 10 * len(sub_ring), kw["pipe"], 1 << 13)
                     if name == "C2-unpipelined" and cof is not None:
                         srec["gpu_count_equals_serial_reference_count"] = all(
                             r["updates"] == sum(cof(i) for i in r["frames"]) for r in sm["regions"])
@@ -977,6 +997,8 @@ def main():
                                     f"(oracle {oc}, GPU {g})")
                     srec, _ = record(name, swl, sm, steps, None, show, credit_scale=scale,
                                      pmc_name={"C4-fast": "c4_fast", "C4-merged": "c4_merged"}.get(name))
+                    if name == "C4-merged":
+                        srec["steady_state"] = steady_state(B, torch, dist, dev, swl, c4_ring, 6 * steps, pipeline, tiles, **c4cfg)
                     sec.append(srec)
                     torch.cuda.empty_cache()
                 except Exception as e:

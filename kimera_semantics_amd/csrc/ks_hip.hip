@@ -152,6 +152,7 @@ struct FrameSlot {
   uint32_t* d_ray_list = nullptr;   // rays to march (written by stage A, read by B)
   HostSnap* h_snap = nullptr;       // pinned + device-visible: written by k_publish at the end of B
   hipEvent_t a_done = nullptr;      // stage A complete
+  hipEvent_t bl_fork = nullptr, bl_join = nullptr;   // merged: the long bundles' merge beside the bundle order (stream_bundles)
   hipEvent_t ready = nullptr;       // snapshot has landed
   hipEvent_t tail_done = nullptr;   // the tail has consumed this slot's buffers
   hipEvent_t fork = nullptr, join = nullptr;  // tail: pairs sorted and long runs listed | long runs applied
@@ -199,6 +200,9 @@ struct ks_ctx {
   hipStream_t stream_tail = nullptr;   // stage T; == stream unless pipelined
   hipStream_t stream_long = nullptr;   // the long-run voxel update, beside k_apply (always its own stream)
   hipStream_t stream_xlong = nullptr;  // the runs of more than kXLongRun updates, beside both (k_apply_xlong)
+  hipStream_t stream_bundles = nullptr; // merged, pipelined: k_bundles_long beside k_bo_* / k_bundles (round 6); == stream_long unless KS_BUNDLE_STREAM=1
+  hipStream_t stream_bundles_own = nullptr;
+  std::vector<hipStream_t> stream_pad;
   hipStream_t stream_apply = nullptr;  // k_apply_runs, so that the tail stream goes on with the NEXT frame's pair sort while it runs (round 6)
   bool xlong = true;
   float voxel_size_inv = 0.f, log_match = 0.f, log_non_match = 0.f;
@@ -250,6 +254,7 @@ struct ks_ctx {
   // set f & 1 while frame f+1 sorts its pairs and lists its long runs into the other set (deferred join)
   unsigned long long* d_long_list_[2] = {nullptr, nullptr};
   uint32_t* d_blong = nullptr;
+  float* d_blong_merged = nullptr;     // k_bundles_long -> k_bundles_long_finish: kBundleLongRec floats per long bundle
   uint64_t *d_pkeys = nullptr, *d_pkeys2 = nullptr;
   uint32_t *d_pvals = nullptr, *d_pvals2 = nullptr;
   uint32_t* d_order = nullptr;
@@ -257,6 +262,11 @@ struct ks_ctx {
   uint32_t *d_okeys = nullptr, *d_okeys2 = nullptr, *d_ovals = nullptr;
   size_t cap_pairs = 0;
   uint64_t* d_pairs2_[2] = {nullptr, nullptr};
+  // no early-out, pipelined: stage B (scan + emission) of frames of fewer than emit_on_tail_max_pairs updates goes to the TAIL stream —
+  // at 640x480 `merged` the front stream is the one that is busy all the time (stage A 0.4 ms + emission 0.09 ms per frame) and the
+  // tail stream idles two thirds of it; at 1280x720 / 2 cm it is the other way round (round 6)
+  bool emit_on_tail = false;
+  unsigned long long emit_on_tail_max_pairs = 1ull << 23;
   bool defer_join = false;               // k_apply_long of frame f overlaps the pair sort of frame f+1 (pipelined contexts)
   hipEvent_t pending_join = nullptr;     // recorded on stream_long; the next k_apply / k_apply_long wait for it
   ksrs::Workspace sort_ws, sort_ws_tail;
@@ -565,6 +575,7 @@ int ensure_points(ks_ctx* c, size_t n) {
     if ((rc = dev_alloc(c, &c->d_glc, cap))) return rc;
     if ((rc = dev_alloc(c, &c->d_ray_keys, cap))) return rc;
     if ((rc = dev_alloc(c, &c->d_blong, cap / kLongRun + 64))) return rc;
+    if ((rc = dev_alloc(c, &c->d_blong_merged, (cap / kLongRun + 64) * (size_t)kBundleLongRec))) return rc;
   }
   if (c->use_bundle_rank && (rc = ensure_bundle_order(c, cap))) return rc;
   if (c->exact_early_out) {
@@ -1045,6 +1056,8 @@ int launch_batch(ks_ctx* c) {
   FrameSlot& S0 = *slots[0];
   hipStream_t st = c->stream;
   hipStream_t sm = c->batch > 1 ? c->stream_march_[(S0.frame_no / (uint64_t)c->batch) % (uint64_t)c->n_march] : march_stream(c, S0.frame_no);
+  const bool on_tail = c->emit_on_tail && c->profiling != 1 && (unsigned long long)c->pairs_hint.load(std::memory_order_relaxed) < c->emit_on_tail_max_pairs;
+  if (on_tail) sm = c->stream_tail;
   c->prof_march_stream = sm;
   if (sm != st) HIPCHK(c, hipStreamWaitEvent(sm, slots[nb - 1]->a_done, 0));  // stage A is one in-order stream: the last frame's event covers all
   const bool stage_events = nb == 1 && S0.prof_set >= 0 && c->pset[S0.prof_set].stages;
@@ -1152,10 +1165,12 @@ int launch_batch(ks_ctx* c) {
       G.g1 = nullptr;
       G.key = 0;
       hipGraph_t g = nullptr;
-      bool ok = hipStreamBeginCapture(sm, hipStreamCaptureModeRelaxed) == hipSuccess;
+      // (captured on a stream only this thread enqueues on: the tail stream is the helper thread's as well)
+      hipStream_t sc = on_tail ? st : sm;
+      bool ok = hipStreamBeginCapture(sc, hipStreamCaptureModeRelaxed) == hipSuccess;
       if (ok) {
-        enqueue_stage_b(c, V, nb, S0.wide, sm, steps_max);
-        ok = hipStreamEndCapture(sm, &g) == hipSuccess && g != nullptr;
+        enqueue_stage_b(c, V, nb, S0.wide, sc, steps_max);
+        ok = hipStreamEndCapture(sc, &g) == hipSuccess && g != nullptr;
       }
       if (ok) ok = hipGraphInstantiate(&G.g1, g, nullptr, nullptr, 0) == hipSuccess;
       if (g) (void)hipGraphDestroy(g);
@@ -1305,7 +1320,18 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
     if ((rc = sort_pairs(c, c->d_pkeys, c->d_pkeys2, c->d_pvals, c->d_pvals2, n, 64, &sk, &sv))) return rc;
     stage_mark(c, S.prof_set, 2);
     hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       order_ptr, sk, sv, c->d_gpw, c->d_glc, c->use_bundle_rank ? c->bo.flag : nullptr);
+                       order_ptr, sk, sv, c->d_gpw, c->d_glc, c->use_bundle_rank ? c->bo.flag : nullptr, c->d_blong, S.d_counters);
+    // the bundles of kLongRun points and more: their merge is one serial chain per bundle (0.16 ms at 640x480 with a wall
+    // close to the sensor) that needs nothing of the bundle order — pipelined, it runs on a stream of its own beside k_bo_* and
+    // k_bundles, and only what needs the integration id (k_bundles_long_finish) waits for both
+    const uint32_t grid_bl = (uint32_t)std::min<size_t>(n / kLongRun + 1, 2048);
+    hipStream_t sb = c->stream_bundles ? c->stream_bundles : st;
+    if (sb != st) {
+      HIPCHK(c, hipEventRecord(S.bl_fork, st));
+      HIPCHK(c, hipStreamWaitEvent(sb, S.bl_fork, 0));
+      hipLaunchKernelGGL(k_bundles_long, dim3(grid_bl), dim3(128), 0, sb, F, sk, c->d_gpw, c->d_glc, c->d_blong, c->d_blong_merged, S.d_counters);
+      HIPCHK(c, hipEventRecord(S.bl_join, sb));
+    }
     if (c->use_bundle_rank) {
       // the bundles' ranks in the iteration order of the reference's unordered_map (ks_k_bundle_order.h):
       // insertion indices, then one walk + link launch per rehash epoch the slot capacity can reach
@@ -1331,10 +1357,11 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
     uint64_t* ray_keys = cfg.enable_anti_grazing ? S.d_rkeys : nullptr;
     if (cfg.enable_anti_grazing) HIPCHK(c, hipMemcpyAsync(S.d_gkeys, sk, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas,
-                       S.d_ray_list, c->d_blong, ray_keys, S.d_cnt, c->bo, c->use_bundle_rank, S.d_counters);
-    hipLaunchKernelGGL(k_bundles_long, dim3((uint32_t)std::min<size_t>(n / kLongRun + 1, 2048)), dim3(128), 0, st, F,
-                       sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas, S.d_ray_list, c->d_blong, ray_keys, S.d_cnt,
-                       c->bo, c->use_bundle_rank, S.d_counters);
+                       S.d_ray_list, ray_keys, S.d_cnt, c->bo, c->use_bundle_rank, S.d_counters);
+    if (sb != st) HIPCHK(c, hipStreamWaitEvent(st, S.bl_join, 0));
+    else hipLaunchKernelGGL(k_bundles_long, dim3(grid_bl), dim3(128), 0, st, F, sk, c->d_gpw, c->d_glc, c->d_blong, c->d_blong_merged, S.d_counters);
+    hipLaunchKernelGGL(k_bundles_long_finish, dim3(std::min<uint32_t>((grid_bl + 3) / 4, 64)), dim3(256), 0, st, F, sk, sv, c->d_blong, c->d_blong_merged,
+                       S.d_rays, S.d_deltas, S.d_ray_list, ray_keys, S.d_cnt, c->bo, c->use_bundle_rank, S.d_counters);
     if (cfg.enable_anti_grazing) {
       F.grazing_keys = S.d_gkeys;
       F.ray_keys = S.d_rkeys;
@@ -1342,7 +1369,7 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
   }
   stage_mark(c, S.prof_set, 3);
   // ---- stage B (early-out phases, scan, pair emission) is enqueued per BATCH of frames: launch_batch
-  if (c->stream_march_[0] != st) HIPCHK(c, hipEventRecord(S.a_done, st));
+  if (c->stream_march_[0] != st || c->emit_on_tail) HIPCHK(c, hipEventRecord(S.a_done, st));
   S.steps_max = steps_max;
   S.b_launched = false;
   S.pending = true;
@@ -2231,7 +2258,14 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     }                                                                      \
   } while (0)
   CRCHK(hipSetDevice(cfg->device_id));
-  CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  {
+    // (experiment, KS_FRONT_PRIO = 1 / 2: the front stream at the runtime's high / low priority)
+    const char* fp = dbg_env("KS_FRONT_PRIO");
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (fp && (fp[0] == '1' || fp[0] == '2')) CRCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, fp[0] == '1' ? hi : lo));
+    else CRCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  }
   // Frames in flight share nothing in stage B when a frame's early-out marks can never be seen by the next frame
   // (every frame bumps the set offset).  Then either (pipeline_frames < 8) every frame's stage B is its own launch
   // sequence and up to four of them run side by side on four streams, or (pipeline_frames = 8) stage B of four
@@ -2265,11 +2299,19 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
       if (!uses_early_out) {
         c->n_march = 1;
         c->stream_march_[0] = c->stream;
+        const char* et = dbg_env("KS_EMIT_ON_TAIL");   // A/B: 0 = always after stage A on the front stream, 1 = always on the tail stream
+        c->emit_on_tail = et && et[0] != '0';
+        if (et && et[0] == '1') c->emit_on_tail_max_pairs = ~0ull;
       } else {
         for (int i = 0; i < c->n_march; ++i) CRCHK(mk(&c->stream_march_[i], 'm'));
       }
       {
-        CRCHK(mk(&c->stream_tail, 't'));
+        // (experiment, KS_TAIL_PRIO = 1 / 2: the tail stream at the runtime's high / low priority)
+        const char* tp = dbg_env("KS_TAIL_PRIO");
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (tp && (tp[0] == '1' || tp[0] == '2')) CRCHK(hipStreamCreateWithPriority(&c->stream_tail, hipStreamNonBlocking, tp[0] == '1' ? hi : lo));
+        else CRCHK(mk(&c->stream_tail, 't'));
       }
     }
   } else {
@@ -2293,7 +2335,16 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
       // A/B only (KS_APPLY_STREAM=1): measured, it LOSES — C4-merged 6.12 vs 6.00 ms/frame, C3 0.75 vs 0.60 (one more stream for the
       // runtime's hardware queues to share) — so k_apply_runs stays on the tail stream
       const char* as = dbg_env("KS_APPLY_STREAM");
-      if (c->stream_xlong && as && as[0] == '1') CRCHK(hipStreamCreateWithFlags(&c->stream_apply, hipStreamNonBlocking));
+      if (c->stream_xlong && as && as[0] == '1') {
+        // (experiment: which hardware queue / pipe the stream lands on — streams created and never used in front of it)
+        if (const char* pad = dbg_env("KS_STREAM_PAD"))
+          for (int i = 0; i < atoi(pad) && i < 8; ++i) {
+            hipStream_t dummy = nullptr;
+            CRCHK(hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking));
+            c->stream_pad.push_back(dummy);
+          }
+        CRCHK(hipStreamCreateWithFlags(&c->stream_apply, hipStreamNonBlocking));
+      }
     }
     if (const char* ll = dbg_env("KS_LONG_LANES")) {   // A/B: 0 = k_apply_long (two wavefronts per run) for all of them, 2 = lanes for frames of any size (tests)
       c->long_lanes = atoi(ll) != 0;
@@ -2302,6 +2353,27 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     if (c->stream_long && c->long_lanes)
       for (int b = 0; b < 2; ++b) CRCHK(hipMalloc((void**)&c->d_long_hdr_[b], sizeof(LongHdr)));
     if (const char* lm = dbg_env("KS_LONG_MIN")) c->long_min_lanes = atoi(lm) == 16;
+    {
+      // merged, pipelined: the long bundles' merge beside the bundle order (integrate_device_impl) — on the stream of the long
+      // voxel runs, which is idle four fifths of a 640x480 frame.  NOT on a stream of its own: a fifth active hardware queue
+      // costs every other kernel of the front stream ~40 us (measured: C3 1.24 ms/frame instead of 0.62; the kernel trace shows
+      // the bumps, with GPU_MAX_HW_QUEUES = 8 as with 4 — profiles/r06_bundle_stream_ab.txt).
+      // KS_BUNDLE_STREAM = 0: in line, 1: its own stream (the A/B above)
+      const char* bs = dbg_env("KS_BUNDLE_STREAM");
+      const int mode = bs ? atoi(bs) : 0;
+      if (c->cfg.method == KS_METHOD_MERGED && c->cfg.pipeline_frames && mode == 1) {
+        // (experiment: which hardware queue / pipe the stream lands on — streams created and never used in front of it)
+        if (const char* pad = dbg_env("KS_STREAM_PAD"))
+          for (int i = 0; i < atoi(pad) && i < 8 && !c->stream_apply; ++i) {
+            hipStream_t dummy = nullptr;
+            CRCHK(hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking));
+            c->stream_pad.push_back(dummy);
+          }
+        CRCHK(hipStreamCreateWithFlags(&c->stream_bundles_own, hipStreamNonBlocking));
+      }
+      if (c->cfg.method == KS_METHOD_MERGED && c->cfg.pipeline_frames && mode != 0)
+        c->stream_bundles = c->stream_bundles_own ? c->stream_bundles_own : c->stream_long;
+    }
     if (const char* sf = dbg_env("KS_SORT_FRONT")) c->sort_on_front = atoi(sf) != 0;
     if (const char* ld = dbg_env("KS_LANES_DEPTH")) c->lanes_depth = atoi(ld) == 4 ? 4u : 6u;
     if (const char* rt = dbg_env("KS_RUN_THREADS")) c->run_threads = atoi(rt) == 512 ? 512u : 256u;
@@ -2370,6 +2442,8 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
     CRCHK(hipMalloc((void**)&S.d_F, sizeof(FrameParams)));
     std::memset(S.h_snap, 0, sizeof(HostSnap));
     CRCHK(hipEventCreateWithFlags(&S.a_done, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&S.bl_fork, hipEventDisableTiming));
+    CRCHK(hipEventCreateWithFlags(&S.bl_join, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.tail_done, hipEventDisableTiming));
     CRCHK(hipEventCreateWithFlags(&S.fork, hipEventDisableTiming));
@@ -2428,9 +2502,10 @@ void ks_destroy(ks_ctx* c) {
   for (auto sm : c->stream_march_)
     if (sm && sm != c->stream) (void)hipStreamSynchronize(sm);
   if (c->stream_long) (void)hipStreamSynchronize(c->stream_long);
+  if (c->stream_bundles_own) (void)hipStreamSynchronize(c->stream_bundles_own);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->pool.dirty, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_observed_[3], c->d_observed_[4], c->d_observed_[5], c->d_observed_[6], c->d_observed_[7], c->d_observed_[8], c->d_observed_[9], c->d_observed_[10], c->d_observed_[11], c->d_observed_[12], c->d_observed_[13], c->d_observed_[14], c->d_observed_[15], c->d_color_lut,
-                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list_[0], c->d_long_list_[1], c->d_blong, c->d_pkeys,
+                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list_[0], c->d_long_list_[1], c->d_blong, c->d_blong_merged, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_pairs2_[0], c->d_pairs2_[1], c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux, c->d_bo_slab,
@@ -2465,6 +2540,8 @@ void ks_destroy(ks_ctx* c) {
     if (S.applied) (void)hipEventDestroy(S.applied);
     if (S.sorted) (void)hipEventDestroy(S.sorted);
     if (S.a_done) (void)hipEventDestroy(S.a_done);
+    if (S.bl_fork) (void)hipEventDestroy(S.bl_fork);
+    if (S.bl_join) (void)hipEventDestroy(S.bl_join);
   }
   for (auto& P : c->pset) {
     for (auto& e : P.ev)
@@ -2478,6 +2555,8 @@ void ks_destroy(ks_ctx* c) {
   if (c->stream_long) (void)hipStreamDestroy(c->stream_long);
   if (c->stream_xlong) (void)hipStreamDestroy(c->stream_xlong);
   if (c->stream_apply) (void)hipStreamDestroy(c->stream_apply);
+  if (c->stream_bundles_own) (void)hipStreamDestroy(c->stream_bundles_own);
+  for (hipStream_t d : c->stream_pad) (void)hipStreamDestroy(d);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

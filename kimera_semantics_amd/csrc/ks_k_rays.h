@@ -180,12 +180,18 @@ __global__ void __launch_bounds__(256) k_gather_sorted(FrameParams F, const floa
                                                        const uint32_t* __restrict__ order,
                                                        const uint64_t* __restrict__ skeys,
                                                        const uint32_t* __restrict__ svals, float4* __restrict__ g_pw,
-                                                       uint2* __restrict__ g_lc, uint32_t* __restrict__ bo_flag) {
+                                                       uint2* __restrict__ g_lc, uint32_t* __restrict__ bo_flag,
+                                                       uint32_t* __restrict__ long_list, Counters* C) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= F.n) return;
   if (skeys[i] == kEmpty64) return;
-  if (bo_flag && (i == 0 || skeys[i - 1] != skeys[i]))  // a bundle's first point in integration order: its insertion
-    bo_flag[svals[i] + (uint32_t)(skeys[i] >> 63) * F.n] = 1u;
+  if (i == 0 || skeys[i - 1] != skeys[i]) {
+    // a bundle's first point in integration order: its insertion
+    if (bo_flag) bo_flag[svals[i] + (uint32_t)(skeys[i] >> 63) * F.n] = 1u;
+    // the bundles of >= kLongRun points (a handful per frame), listed here so that their merge can start before the
+    // bundle order is known (k_bundles_long beside k_bo_* and k_bundles)
+    if (i + kLongRun < F.n && skeys[i + kLongRun] == skeys[i]) long_list[atomicAdd(&C->n_long_bundles, 1u)] = i;
+  }
   const uint32_t idx = point_order(F, order, svals[i]);
   const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
   const uint32_t color = rgba ? ((const uint32_t*)rgba)[idx] : 0u;
@@ -234,7 +240,7 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
                                                  const uint32_t* __restrict__ svals, const float4* __restrict__ g_pw,
                                                  const uint2* __restrict__ g_lc, RayDesc* __restrict__ rays,
                                                  float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
-                                                 uint32_t* __restrict__ long_list, uint64_t* __restrict__ ray_keys,
+                                                 uint64_t* __restrict__ ray_keys,
                                                  uint32_t* __restrict__ cnt, BoCtx X, bool use_rank, Counters* C) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   bool head = false, is_long = false;
@@ -245,9 +251,7 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
     head = (key != kEmpty64) && (i == 0 || skeys[i - 1] != key);
     if (head) is_long = (i + kLongRun < F.n) && (skeys[i + kLongRun] == key);
   }
-  const uint32_t lpos = block_append(head && is_long, &C->n_long_bundles);
-  if (head && is_long) long_list[lpos] = i;
-  const bool work = head && !is_long;
+  const bool work = head && !is_long;   // (the long ones: listed by k_gather_sorted, merged by k_bundles_long)
   if (work) {
     const bool clearing = (key >> 63) != 0;
     uint32_t merged_color = 0;
@@ -301,6 +305,8 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
   if (work) ray_list[pos] = first_p;
 }
 
+constexpr uint32_t kBundleLongRec = 32;   // floats per merged long bundle between k_bundles_long and k_bundles_long_finish
+
 // Two wavefronts per long bundle (>= kLongRun points in one voxel: thousands when a wall is close).  The merge is the
 // reference's serial recurrence [K:src/semantic_tsdf_integrator_merged.cpp:231-262 via voxblox's weighted mean]:
 //     den = w + pw;  mean = (mean * w + p * pw) / den;  w = den           (per point, in input order, f32, no FMA)
@@ -313,13 +319,9 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
 //           and the three of the division by a known reciprocal).  The exponent-window test of that division is taken
 //           off the chain: eight points are applied without it, and repeated one by one if any of them fell outside.
 __global__ void __launch_bounds__(128) k_bundles_long(FrameParams F, const uint64_t* __restrict__ skeys,
-                                                      const uint32_t* __restrict__ svals,
                                                       const float4* __restrict__ g_pw, const uint2* __restrict__ g_lc,
-                                                      RayDesc* __restrict__ rays, float* __restrict__ deltas,
-                                                      uint32_t* __restrict__ ray_list,
-                                                      const uint32_t* __restrict__ long_list,
-                                                      uint64_t* __restrict__ ray_keys, uint32_t* __restrict__ cnt,
-                                                      BoCtx X, bool use_rank, Counters* C) {
+                                                      const uint32_t* __restrict__ long_list, float* __restrict__ merged,
+                                                      const Counters* C) {
   __shared__ float4 s_w[2][64];  // per point of the batch: weight before it, weight after it, reciprocal of that, its own weight
   __shared__ float4 s_a[2][64];  // x * w, y * w, z * w, colour
   __shared__ unsigned long long s_use[2];  // the points of the batch that are merged
@@ -466,8 +468,35 @@ __global__ void __launch_bounds__(128) k_bundles_long(FrameParams F, const uint6
       }
     }
     __syncthreads();  // wave 1 has the merged point
-    const f3 mp = {s_mp[0], s_mp[1], s_mp[2]};
-    const uint32_t merged_color = __float_as_uint(s_mp[3]);
+    // the merged bundle for k_bundles_long_finish: label counts in lanes 0..20, then the point, the weight, the colour
+    {
+      float v = freq;
+      if (lane >= kNumLabels) v = (lane < kNumLabels + 4) ? s_mp[lane - kNumLabels] : mw;
+      if (lane <= kNumLabels + 4) merged[(size_t)run * kBundleLongRec + (uint32_t)lane] = v;
+    }
+    __syncthreads();  // LDS free for the next bundle
+  }
+}
+
+// ... and what needs the bundle's integration id (k_bo_*): the ray descriptor, the increments, the lists.  A wavefront per bundle.
+__global__ void __launch_bounds__(256) k_bundles_long_finish(FrameParams F, const uint64_t* __restrict__ skeys,
+                                                             const uint32_t* __restrict__ svals,
+                                                             const uint32_t* __restrict__ long_list,
+                                                             const float* __restrict__ merged, RayDesc* __restrict__ rays,
+                                                             float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
+                                                             uint64_t* __restrict__ ray_keys, uint32_t* __restrict__ cnt,
+                                                             BoCtx X, bool use_rank, Counters* C) {
+  const uint32_t n_long = C->n_long_bundles;
+  const int lane = (int)lane_id();
+  for (uint32_t run = blockIdx.x * 4u + (threadIdx.x >> 6); run < n_long; run += gridDim.x * 4u) {
+    const uint32_t start = long_list[run];
+    const uint64_t key = skeys[start];
+    const bool clearing = (key >> 63) != 0;
+    const float* rec = merged + (size_t)run * kBundleLongRec;
+    const float freq = lane < kNumLabels ? rec[lane] : 0.0f;
+    const f3 mp = {rec[kNumLabels], rec[kNumLabels + 1], rec[kNumLabels + 2]};
+    const uint32_t merged_color = __float_as_uint(rec[kNumLabels + 3]);
+    const float mw = rec[kNumLabels + 4];
     const uint32_t first_p = bundle_id(X, use_rank, svals, start, clearing);
     const unsigned long long present = __ballot(lane >= 1 && lane < kNumLabels && freq > 0.0f);
     const int n_labels = (int)__popcll(present);
@@ -486,7 +515,6 @@ __global__ void __launch_bounds__(128) k_bundles_long(FrameParams F, const uint6
       if (ray_keys) ray_keys[first_p] = key & ~(1ull << 63);
       ray_list[atomicAdd(&C->n_rays, 1u)] = first_p;
     }
-    __syncthreads();  // LDS free for the next bundle
   }
 }
 

@@ -1,40 +1,30 @@
-# Kernel-level view of the PIPELINED headline run: per kernel name the average duration (to compare with the
-# unpipelined chain of tools/phase_trace.sh), how many kernels run concurrently, busy fraction.
-set -x
+# A pipelined stretch of one bench workload, kernel by kernel with the hardware queue each ran on.   sh tools/pipe_trace.sh <workload> <out dir> <tag> [env...]
+W=${1:-C3}; O=$2; TAG=$3; shift 3
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/pipe_trace
-rm -rf $O; mkdir -p $O
+rm -rf $R/$O/pt_$TAG; mkdir -p $R/$O
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d $O -o run -- env KS_BENCH_PIPE=${KS_BENCH_PIPE:-4} python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-secondary --no-oracle-count > $O/log.txt 2>&1
-tail -c 600 $O/log.txt
+env KS_PROBE_PIPE=8 "$@" timeout 300 rocprofv3 --kernel-trace --output-format csv -d $R/$O/pt_$TAG -o run -- python $R/tools/probe_ring.py $W 8 > $R/$O/pt_$TAG.log 2>&1
 cd $R
-python - <<'PY'
-import csv, glob, os, collections
-root = os.environ["GRAFT_REPO_ROOT"]
-f = glob.glob(root + "/gpurun_out/pipe_trace/**/run_kernel_trace.csv", recursive=True)[0]
+TAG=$TAG O=$O python - <<'PY'
+import csv, glob, os
+tag = os.environ["TAG"]; o = os.environ["O"]
+f = glob.glob(f"{o}/pt_{tag}/**/run_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-sp = [i for i, r in enumerate(rows) if "k_set_params" in r["Kernel_Name"]]
-# timed part: the last 100 frames (5 regions x 20)
-a, b = sp[-101], sp[-1]
-seg = rows[a:b]
-t0, t1 = int(seg[0]["Start_Timestamp"]), int(seg[-1]["End_Timestamp"])
-by = collections.defaultdict(lambda: [0, 0.0])
-ev = []
-for r in seg:
-    n = r["Kernel_Name"].split("(")[0]
-    n = n.replace("void ", "")[:44]
-    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    by[n][0] += 1; by[n][1] += (e - s) / 1e3
-    ev.append((s, 1)); ev.append((e, -1))
-ev.sort()
-cur, last, hist = 0, t0, collections.Counter()
-for t, d in ev:
-    hist[cur] += t - last
-    last = t; cur += d
-tot = t1 - t0
-print(f"window {tot/1e6:.2f} ms for 100 frames -> {tot/1e5:.1f} us/frame; sum of kernel time {sum(v[1] for v in by.values())/100:.1f} us/frame")
-print("concurrency:", {k: round(v / tot, 3) for k, v in sorted(hist.items())})
-for n, (c, us) in sorted(by.items(), key=lambda kv: -kv[1][1]):
-    print(f"{n:46s} calls/frame {c/100:5.2f}  avg {us/c:7.1f} us   per frame {us/100:7.1f} us")
+idx = [i for i, r in enumerate(rows) if "k_points_" in r["Kernel_Name"]]
+start = idx[-16]; end = idx[-12]
+t0 = int(rows[start]["Start_Timestamp"])
+qcol = "Queue_Id" if "Queue_Id" in rows[0] else None
+scol = "Stream_Id" if "Stream_Id" in rows[0] else None
+with open(f"{o}/pipe_{tag}.txt", "w") as out:
+    out.write("# columns: start, duration, queue, stream, kernel   (four steady-state frames, pipelined)\n")
+    for r in rows[start:end]:
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")[-44:]
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        out.write(f"{(s - t0) / 1e3:9.1f} us  +{(e - s) / 1e3:8.1f} us  q{r[qcol] if qcol else '?':>3} s{r[scol] if scol else '?':>3}  {name}\n")
+    ts = [int(rows[i]["Start_Timestamp"]) for i in idx[-24:-4]]
+    out.write("# k_points_* to k_points_*: " + " ".join(f"{(b - a) / 1e3:.0f}" for a, b in zip(ts, ts[1:])) + " us\n")
 PY
+grep -v amdgpu $R/$O/pt_$TAG.log | tail -1
+tail -1 $R/$O/pipe_$TAG.txt
+find $R/$O/pt_$TAG -name "*.csv" -size +2M -delete
