@@ -1356,12 +1356,18 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
     // buffers while this frame's emission — or its repetition after a pair-buffer overflow — may still run)
     uint64_t* ray_keys = cfg.enable_anti_grazing ? S.d_rkeys : nullptr;
     if (cfg.enable_anti_grazing) HIPCHK(c, hipMemcpyAsync(S.d_gkeys, sk, n * sizeof(uint64_t), hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas,
-                       S.d_ray_list, ray_keys, S.d_cnt, c->bo, c->use_bundle_rank, S.d_counters);
-    if (sb != st) HIPCHK(c, hipStreamWaitEvent(st, S.bl_join, 0));
-    else hipLaunchKernelGGL(k_bundles_long, dim3(grid_bl), dim3(128), 0, st, F, sk, c->d_gpw, c->d_glc, c->d_blong, c->d_blong_merged, S.d_counters);
-    hipLaunchKernelGGL(k_bundles_long_finish, dim3(std::min<uint32_t>((grid_bl + 3) / 4, 64)), dim3(256), 0, st, F, sk, sv, c->d_blong, c->d_blong_merged,
-                       S.d_rays, S.d_deltas, S.d_ray_list, ray_keys, S.d_cnt, c->bo, c->use_bundle_rank, S.d_counters);
+    if (sb != st) {
+      hipLaunchKernelGGL(k_bundles, dim3(nb), dim3(256), 0, st, F, sk, sv, c->d_gpw, c->d_glc, S.d_rays, S.d_deltas,
+                         S.d_ray_list, ray_keys, S.d_cnt, c->bo, c->use_bundle_rank, S.d_counters);
+      HIPCHK(c, hipStreamWaitEvent(st, S.bl_join, 0));
+      hipLaunchKernelGGL(k_bundles_long_finish, dim3(std::min<uint32_t>((grid_bl + 3) / 4, 64)), dim3(256), 0, st, F, sk, sv, c->d_blong, c->d_blong_merged,
+                         S.d_rays, S.d_deltas, S.d_ray_list, ray_keys, S.d_cnt, c->bo, c->use_bundle_rank, S.d_counters);
+    } else {
+      // one launch: the long bundles' serial chains in the first workgroups, the short bundles under them
+      const uint32_t n_long_blocks = std::min<uint32_t>(grid_bl, 512);
+      hipLaunchKernelGGL(k_bundles_all, dim3(n_long_blocks + (uint32_t)((n + 127) / 128)), dim3(128), 0, st, F, sk, sv, c->d_gpw, c->d_glc, c->d_blong,
+                         S.d_rays, S.d_deltas, S.d_ray_list, ray_keys, S.d_cnt, c->bo, c->use_bundle_rank, S.d_counters, n_long_blocks);
+    }
     if (cfg.enable_anti_grazing) {
       F.grazing_keys = S.d_gkeys;
       F.ray_keys = S.d_rkeys;

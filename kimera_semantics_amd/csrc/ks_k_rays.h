@@ -236,13 +236,13 @@ __device__ __forceinline__ void finish_bundle(const FrameParams& F, f3 mp, float
   *out = d;
 }
 
-__global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* __restrict__ skeys,
-                                                 const uint32_t* __restrict__ svals, const float4* __restrict__ g_pw,
-                                                 const uint2* __restrict__ g_lc, RayDesc* __restrict__ rays,
-                                                 float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
-                                                 uint64_t* __restrict__ ray_keys,
-                                                 uint32_t* __restrict__ cnt, BoCtx X, bool use_rank, Counters* C) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void bundles_body(const FrameParams& F, const uint64_t* __restrict__ skeys,
+                                             const uint32_t* __restrict__ svals, const float4* __restrict__ g_pw,
+                                             const uint2* __restrict__ g_lc, RayDesc* __restrict__ rays,
+                                             float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
+                                             uint64_t* __restrict__ ray_keys, uint32_t* __restrict__ cnt, const BoCtx& X,
+                                             bool use_rank, Counters* C, uint32_t block) {
+  const uint32_t i = block * blockDim.x + threadIdx.x;
   bool head = false, is_long = false;
   uint32_t first_p = 0;
   uint64_t key = 0;
@@ -304,6 +304,41 @@ __global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* 
   const uint32_t pos = block_append(work, &C->n_rays);
   if (work) ray_list[pos] = first_p;
 }
+__global__ void __launch_bounds__(256) k_bundles(FrameParams F, const uint64_t* __restrict__ skeys,
+                                                 const uint32_t* __restrict__ svals, const float4* __restrict__ g_pw,
+                                                 const uint2* __restrict__ g_lc, RayDesc* __restrict__ rays,
+                                                 float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
+                                                 uint64_t* __restrict__ ray_keys,
+                                                 uint32_t* __restrict__ cnt, BoCtx X, bool use_rank, Counters* C) {
+  bundles_body(F, skeys, svals, g_pw, g_lc, rays, deltas, ray_list, ray_keys, cnt, X, use_rank, C, blockIdx.x);
+}
+
+// A merged long bundle -> its ray (one wavefront; freq: lane l < kNumLabels holds the count of label l).
+__device__ __forceinline__ void bundle_long_finish(const FrameParams& F, uint64_t key, uint32_t start, float freq, f3 mp, uint32_t merged_color,
+                                                   float mw, const uint32_t* __restrict__ svals, RayDesc* __restrict__ rays,
+                                                   float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
+                                                   uint64_t* __restrict__ ray_keys, uint32_t* __restrict__ cnt, const BoCtx& X,
+                                                   bool use_rank, Counters* C) {
+  const int lane = (int)lane_id();
+  const bool clearing = (key >> 63) != 0;
+  const uint32_t first_p = bundle_id(X, use_rank, svals, start, clearing);
+  const unsigned long long present = __ballot(lane >= 1 && lane < kNumLabels && freq > 0.0f);
+  const int n_labels = (int)__popcll(present);
+  const int the_label = present ? (63 - __clzll((long long)present)) : 0;
+  const float c = bcast_f(freq, the_label);
+  if (n_labels > 1 && lane < kNumLabels) {
+    float acc = 0.0f;
+    acc += 0.0f * bcast_f(freq, 0);
+#pragma unroll
+    for (int l = 1; l < kNumLabels; ++l) acc += ((lane == l) ? F.log_match : F.log_non_match) * bcast_f(freq, l);
+    deltas[(size_t)first_p * kNumLabels + lane] = acc;
+  }
+  if (lane == 0) {
+    finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p], &cnt[first_p + (clearing ? F.n : 0u)], C);
+    if (ray_keys) ray_keys[first_p] = key & ~(1ull << 63);
+    ray_list[atomicAdd(&C->n_rays, 1u)] = first_p;
+  }
+}
 
 constexpr uint32_t kBundleLongRec = 32;   // floats per merged long bundle between k_bundles_long and k_bundles_long_finish
 
@@ -318,10 +353,14 @@ constexpr uint32_t kBundleLongRec = 32;   // floats per merged long bundle betwe
 //           4-byte read per point, requested eight points ahead, then five dependent operations per point (multiply, add,
 //           and the three of the division by a known reciprocal).  The exponent-window test of that division is taken
 //           off the chain: eight points are applied without it, and repeated one by one if any of them fell outside.
-__global__ void __launch_bounds__(128) k_bundles_long(FrameParams F, const uint64_t* __restrict__ skeys,
-                                                      const float4* __restrict__ g_pw, const uint2* __restrict__ g_lc,
-                                                      const uint32_t* __restrict__ long_list, float* __restrict__ merged,
-                                                      const Counters* C) {
+template <bool FINISH>
+__device__ __forceinline__ void bundles_long_body(const FrameParams& F, const uint64_t* __restrict__ skeys,
+                                                  const uint32_t* __restrict__ svals, const float4* __restrict__ g_pw,
+                                                  const uint2* __restrict__ g_lc, const uint32_t* __restrict__ long_list,
+                                                  float* __restrict__ merged, RayDesc* __restrict__ rays,
+                                                  float* __restrict__ deltas, uint32_t* __restrict__ ray_list,
+                                                  uint64_t* __restrict__ ray_keys, uint32_t* __restrict__ cnt, const BoCtx& X,
+                                                  bool use_rank, Counters* C, uint32_t block, uint32_t n_blocks) {
   __shared__ float4 s_w[2][64];  // per point of the batch: weight before it, weight after it, reciprocal of that, its own weight
   __shared__ float4 s_a[2][64];  // x * w, y * w, z * w, colour
   __shared__ unsigned long long s_use[2];  // the points of the batch that are merged
@@ -332,7 +371,7 @@ __global__ void __launch_bounds__(128) k_bundles_long(FrameParams F, const uint6
   const bool back = (threadIdx.x >> 6) != 0u;
   const int comp = lane < 3 ? lane : 0;
   const bool colour = F.color_mode == KS_COLOR_MODE_COLOR;
-  for (uint32_t run = blockIdx.x; run < n_long; run += gridDim.x) {
+  for (uint32_t run = block; run < n_long; run += n_blocks) {
     if (back) {
       // ---- wave 1: the weighted-mean recurrence, lanes 0,1,2 one component each ----
       float mpc = 0.0f;
@@ -468,14 +507,41 @@ __global__ void __launch_bounds__(128) k_bundles_long(FrameParams F, const uint6
       }
     }
     __syncthreads();  // wave 1 has the merged point
-    // the merged bundle for k_bundles_long_finish: label counts in lanes 0..20, then the point, the weight, the colour
-    {
+    if (FINISH) {
+      // (the bundle order is known: k_bundles_all, after k_bo_*)
+      const f3 mp = {s_mp[0], s_mp[1], s_mp[2]};
+      bundle_long_finish(F, skeys[start], start, freq, mp, __float_as_uint(s_mp[3]), mw, svals, rays, deltas, ray_list, ray_keys, cnt, X, use_rank, C);
+    } else {
+      // the merged bundle for k_bundles_long_finish: label counts in lanes 0..20, then the point, the weight, the colour
       float v = freq;
       if (lane >= kNumLabels) v = (lane < kNumLabels + 4) ? s_mp[lane - kNumLabels] : mw;
       if (lane <= kNumLabels + 4) merged[(size_t)run * kBundleLongRec + (uint32_t)lane] = v;
     }
     __syncthreads();  // LDS free for the next bundle
   }
+}
+__global__ void __launch_bounds__(128) k_bundles_long(FrameParams F, const uint64_t* __restrict__ skeys,
+                                                      const float4* __restrict__ g_pw, const uint2* __restrict__ g_lc,
+                                                      const uint32_t* __restrict__ long_list, float* __restrict__ merged,
+                                                      Counters* C) {
+  bundles_long_body<false>(F, skeys, nullptr, g_pw, g_lc, long_list, merged, nullptr, nullptr, nullptr, nullptr, nullptr, BoCtx{}, false, C,
+                           blockIdx.x, gridDim.x);
+}
+
+// Both in one launch, after the bundle order: the first n_long_blocks workgroups walk the long bundles (a serial chain each,
+// 0.13-0.16 ms at 640x480 with a wall close to the sensor), the others merge the short ones under it (0.04 ms).
+__global__ void __launch_bounds__(128) k_bundles_all(FrameParams F, const uint64_t* __restrict__ skeys,
+                                                     const uint32_t* __restrict__ svals, const float4* __restrict__ g_pw,
+                                                     const uint2* __restrict__ g_lc, const uint32_t* __restrict__ long_list,
+                                                     RayDesc* __restrict__ rays, float* __restrict__ deltas,
+                                                     uint32_t* __restrict__ ray_list, uint64_t* __restrict__ ray_keys,
+                                                     uint32_t* __restrict__ cnt, BoCtx X, bool use_rank, Counters* C,
+                                                     uint32_t n_long_blocks) {
+  if (blockIdx.x < n_long_blocks)
+    bundles_long_body<true>(F, skeys, svals, g_pw, g_lc, long_list, nullptr, rays, deltas, ray_list, ray_keys, cnt, X, use_rank, C, blockIdx.x,
+                            n_long_blocks);
+  else
+    bundles_body(F, skeys, svals, g_pw, g_lc, rays, deltas, ray_list, ray_keys, cnt, X, use_rank, C, blockIdx.x - n_long_blocks);
 }
 
 // ... and what needs the bundle's integration id (k_bo_*): the ray descriptor, the increments, the lists.  A wavefront per bundle.
@@ -490,31 +556,11 @@ __global__ void __launch_bounds__(256) k_bundles_long_finish(FrameParams F, cons
   const int lane = (int)lane_id();
   for (uint32_t run = blockIdx.x * 4u + (threadIdx.x >> 6); run < n_long; run += gridDim.x * 4u) {
     const uint32_t start = long_list[run];
-    const uint64_t key = skeys[start];
-    const bool clearing = (key >> 63) != 0;
     const float* rec = merged + (size_t)run * kBundleLongRec;
     const float freq = lane < kNumLabels ? rec[lane] : 0.0f;
     const f3 mp = {rec[kNumLabels], rec[kNumLabels + 1], rec[kNumLabels + 2]};
-    const uint32_t merged_color = __float_as_uint(rec[kNumLabels + 3]);
-    const float mw = rec[kNumLabels + 4];
-    const uint32_t first_p = bundle_id(X, use_rank, svals, start, clearing);
-    const unsigned long long present = __ballot(lane >= 1 && lane < kNumLabels && freq > 0.0f);
-    const int n_labels = (int)__popcll(present);
-    const int the_label = present ? (63 - __clzll((long long)present)) : 0;
-    const float c = bcast_f(freq, the_label);
-    if (n_labels > 1 && lane < kNumLabels) {
-      float acc = 0.0f;
-      acc += 0.0f * bcast_f(freq, 0);
-#pragma unroll
-      for (int l = 1; l < kNumLabels; ++l) acc += ((lane == l) ? F.log_match : F.log_non_match) * bcast_f(freq, l);
-      deltas[(size_t)first_p * kNumLabels + lane] = acc;
-    }
-    if (lane == 0) {
-      finish_bundle(F, mp, mw, merged_color, clearing, n_labels, the_label, c, &rays[first_p],
-                    &cnt[first_p + (clearing ? F.n : 0u)], C);
-      if (ray_keys) ray_keys[first_p] = key & ~(1ull << 63);
-      ray_list[atomicAdd(&C->n_rays, 1u)] = first_p;
-    }
+    bundle_long_finish(F, skeys[start], start, freq, mp, __float_as_uint(rec[kNumLabels + 3]), rec[kNumLabels + 4], svals, rays, deltas, ray_list,
+                       ray_keys, cnt, X, use_rank, C);
   }
 }
 
