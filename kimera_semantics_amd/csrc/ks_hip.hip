@@ -254,6 +254,9 @@ struct ks_ctx {
   // set f & 1 while frame f+1 sorts its pairs and lists its long runs into the other set (deferred join)
   unsigned long long* d_long_list_[2] = {nullptr, nullptr};
   uint32_t* d_blong = nullptr;
+  uint64_t* d_key_overflow = nullptr;   // merged, compact grouping keys: the table of the end voxels outside the key window (k_points_merged)
+  uint32_t key_overflow_mask = 0;
+  uint32_t key_bits = 0;                // bits per axis of the key window; 0: the 64-bit keys are sorted (FrameParams::key_bits)
   float* d_blong_merged = nullptr;     // k_bundles_long -> k_bundles_long_finish: kBundleLongRec floats per long bundle
   uint64_t *d_pkeys = nullptr, *d_pkeys2 = nullptr;
   uint32_t *d_pvals = nullptr, *d_pvals2 = nullptr;
@@ -576,6 +579,13 @@ int ensure_points(ks_ctx* c, size_t n) {
     if ((rc = dev_alloc(c, &c->d_ray_keys, cap))) return rc;
     if ((rc = dev_alloc(c, &c->d_blong, cap / kLongRun + 64))) return rc;
     if ((rc = dev_alloc(c, &c->d_blong_merged, (cap / kLongRun + 64) * (size_t)kBundleLongRec))) return rc;
+    if (c->key_bits) {
+      size_t slots = 1024;
+      while (slots < 2 * cap) slots <<= 1;
+      if ((rc = dev_alloc(c, &c->d_key_overflow, slots))) return rc;
+      HIPCHK(c, hipMemsetAsync(c->d_key_overflow, 0, slots * sizeof(uint64_t), c->stream));
+      c->key_overflow_mask = (uint32_t)(slots - 1);
+    }
   }
   if (c->use_bundle_rank && (rc = ensure_bundle_order(c, cap))) return rc;
   if (c->exact_early_out) {
@@ -1312,15 +1322,35 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
     hipLaunchKernelGGL(k_dedup_commit, dim3(nb1k), dim3(1024), 0, st, F, sk, sv, c->d_hash, c->d_start_set,
                        S.d_counters);
   } else {
+    if (c->key_bits) {
+      // the key window of this frame: every point within max_ray of the sensor (all but far clearing points) is inside
+      const float reach = cfg.max_ray_length_m + 2.0f * cfg.voxel_size;
+      const float tq[3] = {F.T.t.x, F.T.t.y, F.T.t.z};
+      for (int a = 0; a < 3; ++a) {
+        const float lo = std::floor((tq[a] - reach) * c->voxel_size_inv) - 2.0f;
+        F.key_base[a] = (int32_t)std::min(std::max(lo, -2.0e9f), 2.0e9f);
+      }
+      F.key_bits = c->key_bits;
+    }
     hipLaunchKernelGGL(k_points_merged, dim3(nb1k), dim3(1024), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       c->d_pkeys, c->d_pvals, S.d_cnt, c->use_bundle_rank ? c->bo.flag : nullptr, S.d_counters);
+                       c->d_pkeys, c->d_skeys32, c->d_pvals, S.d_cnt, c->use_bundle_rank ? c->bo.flag : nullptr, c->d_key_overflow,
+                       c->key_overflow_mask, S.d_counters);
     stage_mark(c, S.prof_set, 1);
     uint64_t* sk = nullptr;
+    uint32_t* sk32 = nullptr;
     uint32_t* sv = nullptr;
-    if ((rc = sort_pairs(c, c->d_pkeys, c->d_pkeys2, c->d_pvals, c->d_pvals2, n, 64, &sk, &sv))) return rc;
+    if (c->key_bits) {
+      // four passes over 32-bit grouping keys instead of eight over the 64-bit end-voxel keys; k_gather_sorted writes the
+      // sorted 64-bit keys for everything downstream
+      if ((rc = sort_pairs(c, c->d_skeys32, c->d_skeys32b, c->d_pvals, c->d_pvals2, n, 32, &sk32, &sv))) return rc;
+      sk = c->d_pkeys;
+    } else {
+      if ((rc = sort_pairs(c, c->d_pkeys, c->d_pkeys2, c->d_pvals, c->d_pvals2, n, 64, &sk, &sv))) return rc;
+    }
     stage_mark(c, S.prof_set, 2);
     hipLaunchKernelGGL(k_gather_sorted, dim3(nb), dim3(256), 0, st, F, d_xyz, d_rgba, d_labels, c->d_color_lut,
-                       order_ptr, sk, sv, c->d_gpw, c->d_glc, c->use_bundle_rank ? c->bo.flag : nullptr, c->d_blong, S.d_counters);
+                       order_ptr, (const uint64_t*)sk, (const uint32_t*)sk32, sk, sv, c->d_gpw, c->d_glc, c->use_bundle_rank ? c->bo.flag : nullptr, c->d_blong,
+                       c->d_key_overflow, S.d_counters);
     // the bundles of kLongRun points and more: their merge is one serial chain per bundle (0.16 ms at 640x480 with a wall
     // close to the sensor) that needs nothing of the bundle order — pipelined, it runs on a stream of its own beside k_bo_* and
     // k_bundles, and only what needs the integration id (k_bundles_long_finish) waits for both
@@ -2243,6 +2273,16 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   }
   c->uses_early_out = uses_early_out;
   c->use_bundle_rank = cfg->method == KS_METHOD_MERGED && cfg->bundle_order == KS_BUNDLE_ORDER_REFERENCE;
+  if (cfg->method == KS_METHOD_MERGED && !cfg->enable_anti_grazing) {
+    // stage A groups the points by end voxel: a 32-bit key (the voxel relative to a window around the sensor that holds every
+    // point within max_ray; anything else through a small hash table) sorts in four passes instead of the 64-bit key's eight.
+    // Not with anti-grazing (its binary search wants the 64-bit keys in order), not for windows wider than 10 bits per axis.
+    const double extent = 2.0 * std::ceil(((double)cfg->max_ray_length_m + 2.0 * (double)cfg->voxel_size) / (double)cfg->voxel_size) + 8.0;
+    unsigned w = 1;
+    while (w < 32 && (double)(1u << w) < extent) ++w;
+    if (const char* kb = dbg_env("KS_KEY_WINDOW_BITS")) w = (unsigned)std::max(0, atoi(kb));   // tests: 1..10 = a window that small (the overflow path), 0 = 64-bit keys
+    c->key_bits = (w >= 1 && w <= 10) ? w : 0;
+  }
   {
     const char* hpf = dbg_env("KS_HOST_PROF");
     c->host_prof = hpf && hpf[0] == '1';
@@ -2511,7 +2551,7 @@ void ks_destroy(ks_ctx* c) {
   if (c->stream_bundles_own) (void)hipStreamSynchronize(c->stream_bundles_own);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->table.ent, c->table.slot_keys, c->pool.vox, c->pool.updated, c->pool.dirty, c->d_start_set, c->d_observed_[0], c->d_observed_[1], c->d_observed_[2], c->d_observed_[3], c->d_observed_[4], c->d_observed_[5], c->d_observed_[6], c->d_observed_[7], c->d_observed_[8], c->d_observed_[9], c->d_observed_[10], c->d_observed_[11], c->d_observed_[12], c->d_observed_[13], c->d_observed_[14], c->d_observed_[15], c->d_color_lut,
-                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list_[0], c->d_long_list_[1], c->d_blong, c->d_blong_merged, c->d_pkeys,
+                  c->d_label_lut, c->d_xyz, c->d_rgba, c->d_labels, c->d_hash, c->d_skeys32, c->d_skeys32b, c->d_gpw, c->d_glc, c->d_ray_keys, c->d_long_list_[0], c->d_long_list_[1], c->d_blong, c->d_blong_merged, c->d_key_overflow, c->d_pkeys,
                   c->d_pkeys2, c->d_pvals, c->d_pvals2, c->d_order, c->d_inv_order, c->d_okeys, c->d_okeys2, c->d_ovals,
                   c->d_pairs2_[0], c->d_pairs2_[1], c->d_state, c->d_xchg_u32, c->d_xchg_u64, c->d_retry_counters,
                   c->d_block_idx, c->d_tsdf_out, c->d_sem_out, c->d_vox_out, c->d_depth_blocks, c->d_img_depth, c->d_img_aux, c->d_bo_slab,

@@ -126,13 +126,55 @@ __global__ void __launch_bounds__(1024) k_dedup_commit(FrameParams F, const uint
 // K4 (merged): per point — validity, point_G, end-voxel key.  vxb::MergedTsdfIntegrator::bundleRays,
 // called at [K:src/semantic_tsdf_integrator_merged.cpp:119-124].
 // ------------------------------------------------------------------------------------------
+// validity + end-voxel key of point idx: kEmpty64 = not integrated, else clearing << 63 | x << 42 | y << 21 | z (biased by kCoordBias)
+__device__ __forceinline__ uint64_t merged_point_key(const FrameParams& F, const float* __restrict__ xyz, const uint8_t* __restrict__ rgba,
+                                                     const uint8_t* __restrict__ labels, const uint8_t* __restrict__ color_lut,
+                                                     uint32_t idx, Counters* C, bool report) {
+  const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
+  uint32_t label;
+  if (labels) label = labels[idx];
+  else label = (color_lut && rgba) ? color_lut[((const uint32_t*)rgba)[idx] & 0xffffffu] : 0u;
+  if (label >= (uint32_t)kNumLabels) {
+    if (report) atomicOr(&C->err, kErrLabel);
+    return kEmpty64;
+  }
+  const int valid = point_validity(pc, F.min_ray, F.max_ray, F.allow_clear != 0, F.freespace != 0);
+  if (!valid) return kEmpty64;
+  const f3 pg = transform_point(F.T, pc);
+  const float gx = grid_coord(pg.x, F.voxel_size_inv), gy = grid_coord(pg.y, F.voxel_size_inv), gz = grid_coord(pg.z, F.voxel_size_inv);
+  const float lim = (float)(kCoordBias - 1);
+  if (!(fabsf(gx) < lim && fabsf(gy) < lim && fabsf(gz) < lim)) {
+    if (report) atomicOr(&C->err, kErrIndex);
+    return kEmpty64;
+  }
+  return ((uint64_t)(valid == 2 ? 1u : 0u) << 63) | ((uint64_t)(uint32_t)((int)gx + kCoordBias) << 42) |
+         ((uint64_t)(uint32_t)((int)gy + kCoordBias) << 21) | (uint64_t)(uint32_t)((int)gz + kCoordBias);
+}
+
+// The voxels outside the key window (FrameParams::key_base / key_bits): a slot per distinct end-voxel key in an open-addressing
+// table of >= 2 n entries (0 = free: no valid key is 0), the slot number is the group's key.  Which slot a voxel gets depends on
+// who came first; that it is the same slot for every point of the voxel, and no other voxel's, does not.  k_gather_sorted frees
+// the slots again.
+__device__ __forceinline__ uint32_t key_overflow_slot(uint64_t* __restrict__ tab, uint32_t mask, uint64_t key) {
+  uint64_t x = key + 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  uint32_t h = (uint32_t)(x ^ (x >> 31)) & mask;
+  for (;;) {
+    const unsigned long long prev = atomicCAS((unsigned long long*)&tab[h], 0ull, (unsigned long long)key);
+    if (prev == 0ull || prev == (unsigned long long)key) return h;
+    h = (h + 1u) & mask;
+  }
+}
+
 __global__ void __launch_bounds__(1024) k_points_merged(FrameParams F, const float* __restrict__ xyz,
                                                         const uint8_t* __restrict__ rgba,
                                                         const uint8_t* __restrict__ labels,
                                                         const uint8_t* __restrict__ color_lut,
-                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ vals,
-                                                        uint32_t* __restrict__ cnt, uint32_t* __restrict__ bo_flag,
-                                                        Counters* C) {
+                                                        uint64_t* __restrict__ keys, uint32_t* __restrict__ keys32,
+                                                        uint32_t* __restrict__ vals, uint32_t* __restrict__ cnt,
+                                                        uint32_t* __restrict__ bo_flag, uint64_t* __restrict__ overflow_tab,
+                                                        uint32_t overflow_mask, Counters* C) {
   const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
   bool counted = false;
   if (idx < F.n) {
@@ -142,30 +184,23 @@ __global__ void __launch_bounds__(1024) k_points_merged(FrameParams F, const flo
       bo_flag[idx] = 0u;
       bo_flag[idx + F.n] = 0u;
     }
-    const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};
-    uint32_t label;
-    if (labels) label = labels[idx];
-    else label = (color_lut && rgba) ? color_lut[((const uint32_t*)rgba)[idx] & 0xffffffu] : 0u;
-    uint64_t key = kEmpty64;
-    if (label >= (uint32_t)kNumLabels) {
-      atomicOr(&C->err, kErrLabel);
-    } else {
-      const int valid = point_validity(pc, F.min_ray, F.max_ray, F.allow_clear != 0, F.freespace != 0);
-      if (valid) {
-        const f3 pg = transform_point(F.T, pc);
-        const float gx = grid_coord(pg.x, F.voxel_size_inv), gy = grid_coord(pg.y, F.voxel_size_inv),
-                    gz = grid_coord(pg.z, F.voxel_size_inv);
-        const float lim = (float)(kCoordBias - 1);
-        if (!(fabsf(gx) < lim && fabsf(gy) < lim && fabsf(gz) < lim)) {
-          atomicOr(&C->err, kErrIndex);
-        } else {
-          key = ((uint64_t)(valid == 2 ? 1u : 0u) << 63) | ((uint64_t)(uint32_t)((int)gx + kCoordBias) << 42) |
-                ((uint64_t)(uint32_t)((int)gy + kCoordBias) << 21) | (uint64_t)(uint32_t)((int)gz + kCoordBias);
-          counted = true;
-        }
+    const uint64_t key = merged_point_key(F, xyz, rgba, labels, color_lut, idx, C, true);
+    counted = key != kEmpty64;
+    const uint32_t pos = point_position(F, F.inv_order, idx);
+    if (F.key_bits) {
+      uint32_t kw = kEmpty32;
+      if (counted) {
+        const uint32_t w = F.key_bits;
+        const uint32_t rx = (uint32_t)((int)((key >> 42) & 0x1fffffu) - kCoordBias - F.key_base[0]);
+        const uint32_t ry = (uint32_t)((int)((key >> 21) & 0x1fffffu) - kCoordBias - F.key_base[1]);
+        const uint32_t rz = (uint32_t)((int)(key & 0x1fffffu) - kCoordBias - F.key_base[2]);
+        if (((rx | ry | rz) >> w) == 0u) kw = ((uint32_t)(key >> 63) << (3u * w)) | (rx << (2u * w)) | (ry << w) | rz;
+        else kw = 0x80000000u | key_overflow_slot(overflow_tab, overflow_mask, key);
       }
+      keys32[pos] = kw;
+    } else {
+      keys[pos] = key;
     }
-    keys[point_position(F, F.inv_order, idx)] = key;
     vals[idx] = idx;  // identity: vals[p] = p
   }
   block_count(counted, &C->n_valid);
@@ -178,19 +213,40 @@ __global__ void __launch_bounds__(256) k_gather_sorted(FrameParams F, const floa
                                                        const uint8_t* __restrict__ labels,
                                                        const uint8_t* __restrict__ color_lut,
                                                        const uint32_t* __restrict__ order,
-                                                       const uint64_t* __restrict__ skeys,
+                                                       const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ skeys32,
+                                                       uint64_t* __restrict__ skeys_out,
                                                        const uint32_t* __restrict__ svals, float4* __restrict__ g_pw,
                                                        uint2* __restrict__ g_lc, uint32_t* __restrict__ bo_flag,
-                                                       uint32_t* __restrict__ long_list, Counters* C) {
+                                                       uint32_t* __restrict__ long_list, uint64_t* __restrict__ overflow_tab, Counters* C) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= F.n) return;
-  if (skeys[i] == kEmpty64) return;
-  if (i == 0 || skeys[i - 1] != skeys[i]) {
+  uint64_t key;
+  bool head, is_long;
+  if (skeys32) {
+    // compact grouping keys: the 64-bit end-voxel key of the sorted point is computed again (the same arithmetic on the same
+    // operands as k_points_merged) for everything downstream
+    const uint32_t kw = skeys32[i];
+    if (kw == kEmpty32) {
+      skeys_out[i] = kEmpty64;
+      return;
+    }
+    key = merged_point_key(F, xyz, rgba, labels, color_lut, point_order(F, order, svals[i]), C, false);
+    skeys_out[i] = key;
+    if (kw >> 31) overflow_tab[kw & 0x7fffffffu] = 0ull;   // (the slot is free again for the next frame)
+    head = i == 0 || skeys32[i - 1] != kw;
+    is_long = head && i + kLongRun < F.n && skeys32[i + kLongRun] == kw;
+  } else {
+    key = skeys[i];
+    if (key == kEmpty64) return;
+    head = i == 0 || skeys[i - 1] != key;
+    is_long = head && i + kLongRun < F.n && skeys[i + kLongRun] == key;
+  }
+  if (head) {
     // a bundle's first point in integration order: its insertion
-    if (bo_flag) bo_flag[svals[i] + (uint32_t)(skeys[i] >> 63) * F.n] = 1u;
+    if (bo_flag) bo_flag[svals[i] + (uint32_t)(key >> 63) * F.n] = 1u;
     // the bundles of >= kLongRun points (a handful per frame), listed here so that their merge can start before the
     // bundle order is known (k_bundles_long beside k_bo_* and k_bundles)
-    if (i + kLongRun < F.n && skeys[i + kLongRun] == skeys[i]) long_list[atomicAdd(&C->n_long_bundles, 1u)] = i;
+    if (is_long) long_list[atomicAdd(&C->n_long_bundles, 1u)] = i;
   }
   const uint32_t idx = point_order(F, order, svals[i]);
   const f3 pc = {xyz[3 * idx], xyz[3 * idx + 1], xyz[3 * idx + 2]};

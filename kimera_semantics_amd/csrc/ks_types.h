@@ -12,6 +12,7 @@ namespace ksk {
 using namespace ksd;
 
 constexpr uint64_t kEmpty64 = ~0ull;
+constexpr uint32_t kEmpty32 = ~0u;
 constexpr int kSetBits = 20;                                   // [K:semantic_tsdf_integrator_fast.h:102]
 constexpr uint64_t kSetMask = (1ull << kSetBits) - 1;
 constexpr uint64_t kFullResetThreshold = 10000;                // [K:semantic_tsdf_integrator_fast.h:107]
@@ -171,6 +172,11 @@ struct FrameParams {
   uint32_t point_mask;       // (1 << bits_for(n)) - 1
   uint32_t clear_bit;        // merged: sequence bit that orders clearing bundles last
   uint32_t eo_frame;         // fast, exact early-out: number of the frame among those of the exact path (ks_k_exact.h)
+  // merged stage A: the points are grouped by a 32-bit key — the end voxel relative to key_base, key_bits bits per axis, bit
+  // 3 * key_bits = clearing; a voxel outside that window gets bit 31 | its slot in a small hash table (ks_k_rays.h).  0: the 64-bit
+  // end-voxel keys themselves are sorted (anti-grazing searches them; windows wider than 10 bits per axis)
+  int32_t key_base[3];
+  uint32_t key_bits;
   uint8_t dynamic_labels[32];
 };
 

@@ -192,6 +192,25 @@ def test_lane_per_run_update_kernel_equals_oracle(emu_jobs, request, name):
     check_case(emu_jobs, request)
 
 
+# merged stage A groups the points by a 32-bit key (the end voxel inside a window around the sensor, anything else through a hash
+# table: FrameParams::key_bits): a window of 3 bits per axis (nearly every voxel through the table), short rays (clearing points far
+# outside the window), and the 64-bit keys of rounds 1-5 — all the same map
+KEY_CASES = {
+    "window_of_3_bits": (dict(method=1, size=[64, 48], frames=2), {"KS_DEBUG": "1", "KS_KEY_WINDOW_BITS": "3"}),
+    "window_of_3_bits_pipelined_colour_blend": (dict(method=1, size=[64, 48], frames=3, pipeline=2, cfg=dict(color_mode=0)),
+                                                {"KS_DEBUG": "1", "KS_KEY_WINDOW_BITS": "3"}),
+    "clearing_points_outside_the_window": (dict(method=1, size=[64, 48], frames=2, cfg=dict(max_ray_length_m=1.5)), {}),
+    "sorted_64_bit_keys": (dict(method=1, size=[64, 48], frames=2), {"KS_DEBUG": "1", "KS_KEY_WINDOW_BITS": "0"}),
+}
+for _name, (_spec, _env) in KEY_CASES.items():
+    case_job("test_merged_grouping_keys_equal_oracle[%s]" % _name, _spec, env_extra=_env, weight=10)
+
+
+@pytest.mark.parametrize("name", sorted(KEY_CASES))
+def test_merged_grouping_keys_equal_oracle(emu_jobs, request, name):
+    check_case(emu_jobs, request)
+
+
 JOBS["test_gpu_tier_cases_unchanged_on_the_functional_model"] = (
     [sys.executable, "-m", "pytest", "tests/test_parity_gpu.py", "-m", "gpu", "-q", "-x", "-k",
      "error_codes or saturated or degenerate or depth_image_u16"], {"KS_TESTS_ON_FUNCTIONAL_MODEL": "1"}, 1200, 55)
