@@ -506,17 +506,24 @@ __device__ __forceinline__ void bundles_long_body(const FrameParams& F, const ui
     float freq = 0.0f;  // lane l < 21 counts label l
     uint32_t base = start;
     int buf = 0;
-    // prefetch one batch ahead (contiguous, coalesced)
+    // prefetch one batch ahead (contiguous, coalesced; two ahead measured the same: the chain, not memory, is what a batch waits for).
+    // (key, point and label of a batch are requested TOGETHER, from a clamped index, and masked afterwards: a point load that waits
+    // for its key's comparison puts two memory latencies on every batch of the chain: 171 -> 150 us at 640x480)
     uint32_t j = base + (uint32_t)lane;
-    bool in = (j < F.n) && (skeys[j] == key);
-    float4 q = in ? g_pw[j] : make_float4(0.f, 0.f, 0.f, 0.f);
-    uint2 lc = in ? g_lc[j] : make_uint2(0u, 0u);
+    const uint32_t jc0 = j < F.n ? j : F.n - 1u;
+    const uint64_t k0 = skeys[jc0];
+    const float4 q0 = g_pw[jc0];
+    const uint2 lc0 = g_lc[jc0];
+    bool in = (j < F.n) && (k0 == key);
+    float4 q = in ? q0 : make_float4(0.f, 0.f, 0.f, 0.f);
+    uint2 lc = in ? lc0 : make_uint2(0u, 0u);
     for (;;) {
       const int n_in = (int)__popcll(__ballot(in));  // >= 1 in the first batch (a long bundle has >= kLongRun points)
       const uint32_t jn = base + 64u + (uint32_t)lane;
-      const bool in_n = (jn < F.n) && (skeys[jn] == key);
-      const float4 q_n = in_n ? g_pw[jn] : make_float4(0.f, 0.f, 0.f, 0.f);
-      const uint2 lc_n = in_n ? g_lc[jn] : make_uint2(0u, 0u);
+      const uint32_t jc = jn < F.n ? jn : F.n - 1u;
+      const uint64_t k_n = skeys[jc];
+      const float4 q_r = g_pw[jc];
+      const uint2 lc_r = g_lc[jc];
 
       const bool valid = in && !(q.w < kEps);
       unsigned long long vmask = __ballot(valid);
@@ -549,9 +556,9 @@ __device__ __forceinline__ void bundles_long_body(const FrameParams& F, const ui
       __syncthreads();  // hand the batch to wave 1
       buf ^= 1;
       if (last) break;
-      in = in_n;
-      q = q_n;
-      lc = lc_n;
+      in = (jn < F.n) && (k_n == key);
+      q = in ? q_r : make_float4(0.f, 0.f, 0.f, 0.f);
+      lc = in ? lc_r : make_uint2(0u, 0u);
       base += 64u;
       if (__ballot(in) == 0ull) {  // the bundle ended on a batch boundary: an empty last batch
         if (lane == 0) {
