@@ -449,16 +449,20 @@ __device__ __forceinline__ void bundles_long_body(const FrameParams& F, const ui
           }
           auto eight = [&](const float4 (&w)[8], const float (&a)[8]) {
             const float at_start = mpc;
-            bool in_window = true;
+            // the exponent window of div_by_recip over the eight numerators as a running min / max: vector instructions only
+            // (a compare per point writes scalar registers, and the scalar AND that collects them waits for the vector pipe in the
+            // middle of the chain).  A NaN numerator passes — and gives NaN on either path.
+            float an_lo = 1.0f, an_hi = 1.0f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
               const float num = mpc * w[i].x + a[i];
-              const float an = fabsf(num);
-              in_window = in_window && (an >= 1e-20f) && (an <= 1e20f);
+              an_lo = fminf(an_lo, fabsf(num));
+              an_hi = fmaxf(an_hi, fabsf(num));
               const float q0 = num * w[i].z;
               const float rem = __builtin_fmaf(-q0, w[i].y, num);
               mpc = __builtin_fmaf(rem, w[i].z, q0);
             }
+            const bool in_window = (an_lo >= 1e-20f) && (an_hi <= 1e20f);
             if (__ballot(!in_window) != 0ull) {  // (a coordinate that is exactly 0, ...): one by one, with the test
               mpc = at_start;
 #pragma unroll
