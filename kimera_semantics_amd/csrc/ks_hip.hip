@@ -254,6 +254,10 @@ struct ks_ctx {
   // set f & 1 while frame f+1 sorts its pairs and lists its long runs into the other set (deferred join)
   unsigned long long* d_long_list_[2] = {nullptr, nullptr};
   uint32_t* d_blong = nullptr;
+  // merged, reference bundle order: the epochs of the rehash recurrence are launched for this many bundles (the counts of the
+  // frames before, with a margin; ~0: as many as the frame has points) — k_bo_rest completes a frame that has more
+  std::atomic<uint32_t> bo_hint{~0u};
+  bool bo_hint_fixed = false;
   uint64_t* d_key_overflow = nullptr;   // merged, compact grouping keys: the table of the end voxels outside the key window (k_points_merged)
   uint32_t key_overflow_mask = 0;
   uint32_t key_bits = 0;                // bits per axis of the key window; 0: the 64-bit keys are sorted (FrameParams::key_bits)
@@ -1375,12 +1379,20 @@ int frame_front(ks_ctx* c, FrameSlot& S, const float Tq[7], const float* d_xyz, 
       int e_small = 0;
       while (e_small < c->bo_epochs && c->bo_sched.b[e_small] <= kBoSmallBuckets) ++e_small;
       if (e_small > 0) hipLaunchKernelGGL(k_bo_small, dim3(2), dim3(kBoBlock), 0, st, c->bo, e_small);
+      // (at least the first launch pair's k_bo_link goes out: it takes over from k_bo_small)
+      const size_t nh_floor = c->bo_hint_fixed ? (e_small > 0 ? (size_t)c->bo_sched.t[e_small - 1] + 1 : 1) : 2 * (size_t)kBoSmallBuckets;
+      const size_t nh = std::min<size_t>(n, std::max<size_t>(c->bo_hint.load(std::memory_order_relaxed), nh_floor));
+      int e_last = -1;   // the epoch whose k_bo_link went out without its k_bo_walk
       for (int e = e_small; e <= c->bo_epochs; ++e) {
-        if (e > 0 && c->bo_sched.t[e - 1] >= n) break;  // no map of this frame reaches epoch e - 1
+        if (e > 0 && c->bo_sched.t[e - 1] >= nh) break;  // no map of nh bundles reaches epoch e - 1
         hipLaunchKernelGGL(k_bo_link, dim3(nbb, 2), dim3(kBoBlock), lds_e, st, c->bo, e, (e == e_small && e_small > 0) ? 1 : 0);
-        if (e < c->bo_epochs && c->bo_sched.t[e] < n)
+        if (e < c->bo_epochs && c->bo_sched.t[e] < nh)
           hipLaunchKernelGGL(k_bo_walk, dim3(nbb, 2), dim3(kBoBlock), 0, st, c->bo, e);
+        else
+          e_last = e;
       }
+      // (a map with more bundles than the hint: the rest of the recurrence, one workgroup per map)
+      if (nh < n && e_last >= 0 && e_last < c->bo_epochs) hipLaunchKernelGGL(k_bo_rest, dim3(2), dim3(kBoBlock), lds_e, st, c->bo, e_last);
     }
     // anti-grazing: the frame keeps its own copy of the keys (the next frame's stage A reuses the sort
     // buffers while this frame's emission — or its repetition after a pair-buffer overflow — may still run)
@@ -1817,6 +1829,12 @@ int frame_tail(ks_ctx* c, FrameSlot& S) {
   c->owed.n_rays_cast += cnt.n_rays;
   c->owed.n_voxel_updates += n_pairs;
   c->owed.n_blocks_allocated += new_tiles > tiles_before ? new_tiles - tiles_before : 0u;  // (marches of later frames run ahead)
+  if (c->use_bundle_rank && !c->bo_hint_fixed) {
+    // the bundle count the next frames' epochs are launched for: this frame's rays (= bundles of both maps) + 25 % + 2048, decaying slowly
+    const uint32_t want = cnt.n_rays + cnt.n_rays / 4u + 2048u;
+    const uint32_t cur = c->bo_hint.load(std::memory_order_relaxed);
+    c->bo_hint.store(cur == ~0u ? want : std::max(want, cur - cur / 64u), std::memory_order_relaxed);
+  }
   return KS_OK;
 }
 
@@ -2273,6 +2291,10 @@ int ks_create(const ks_config* cfg, ks_ctx** out) {
   }
   c->uses_early_out = uses_early_out;
   c->use_bundle_rank = cfg->method == KS_METHOD_MERGED && cfg->bundle_order == KS_BUNDLE_ORDER_REFERENCE;
+  if (const char* bh = dbg_env("KS_BO_HINT")) {   // tests / A-B: a fixed bundle-count hint (0: as many as the frame has points)
+    c->bo_hint_fixed = true;
+    c->bo_hint.store(atoi(bh) > 0 ? (uint32_t)atoi(bh) : ~0u, std::memory_order_relaxed);
+  }
   if (cfg->method == KS_METHOD_MERGED && !cfg->enable_anti_grazing) {
     // stage A groups the points by end voxel: a 32-bit key (the voxel relative to a window around the sensor that holds every
     // point within max_ray; anything else through a small hash table) sorts in four passes instead of the 64-bit key's eight.

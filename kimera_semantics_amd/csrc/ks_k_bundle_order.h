@@ -150,18 +150,17 @@ __global__ void __launch_bounds__(kBoBlock) k_bo_init(uint32_t n, const uint64_t
 
 // one epoch transition: ranks of epoch e-1 (-> final result, or positions of epoch e) and the chains of epoch e
 // prev_small: epochs [0, e) were evaluated by k_bo_small, which left every element's rank in M.rank
-__global__ void __launch_bounds__(kBoBlock) k_bo_link(BoCtx X, int e, int prev_small) {
-  extern __shared__ uint32_t s_tot[];
+__device__ __forceinline__ void bo_link_body(const BoCtx& X, int e, int prev_small, uint32_t map, uint32_t block, uint32_t* s_tot) {
   const BoSchedule& S = *X.sched;
-  const BoMap& M = X.m[blockIdx.y];
-  const uint32_t Bm = X.B[blockIdx.y];
+  const BoMap& M = X.m[map];
+  const uint32_t Bm = X.B[map];
   const bool prev_active = e >= 1 && Bm > S.t[e - 1];
   const bool cur_active = e < (int)S.n_epochs && Bm > S.t[e];
   if (!prev_active && !cur_active) return;
   if (prev_small && !cur_active) return;  // the ranks k_bo_small left are this map's final ranks
   const uint32_t prev_total = prev_active ? (S.t[e] < Bm ? S.t[e] : Bm) : 0u;
   const uint32_t cur_total = cur_active ? (S.t[e + 1] < Bm ? S.t[e + 1] : Bm) : 0u;
-  const uint32_t i0 = blockIdx.x * kBoBlock;
+  const uint32_t i0 = block * kBoBlock;
   const uint32_t n_new = cur_active ? cur_total - S.t[e] : 0u;
   if (i0 >= prev_total && i0 >= n_new) return;
   const int cur = e & 1, prv = cur ^ 1;
@@ -189,16 +188,20 @@ __global__ void __launch_bounds__(kBoBlock) k_bo_link(BoCtx X, int e, int prev_s
   }
   if (i < n_new) insert(S.t[e] + i, S.t[e] + i);
 }
+__global__ void __launch_bounds__(kBoBlock) k_bo_link(BoCtx X, int e, int prev_small) {
+  extern __shared__ uint32_t s_tot[];
+  bo_link_body(X, e, prev_small, blockIdx.y, blockIdx.x, s_tot);
+}
 
-__global__ void __launch_bounds__(kBoBlock) k_bo_walk(BoCtx X, int e) {
+__device__ __forceinline__ void bo_walk_body(const BoCtx& X, int e, uint32_t map, uint32_t block) {
   const BoSchedule& S = *X.sched;
-  const BoMap& M = X.m[blockIdx.y];
-  const uint32_t Bm = X.B[blockIdx.y];
+  const BoMap& M = X.m[map];
+  const uint32_t Bm = X.B[map];
   if (!(Bm > S.t[e])) return;
   const uint32_t total = S.t[e + 1] < Bm ? S.t[e + 1] : Bm;
-  if (blockIdx.x * kBoBlock >= total) return;
+  if (block * kBoBlock >= total) return;
   const int cur = e & 1;
-  const uint32_t j = blockIdx.x * kBoBlock + threadIdx.x;
+  const uint32_t j = block * kBoBlock + threadIdx.x;
   uint32_t w = 0;
   if (j < total) {
     const uint32_t* nxt = M.next[cur];
@@ -215,7 +218,33 @@ __global__ void __launch_bounds__(kBoBlock) k_bo_walk(BoCtx X, int e) {
   uint32_t tot;
   const uint32_t ex = bo_block_scan(w, &tot);
   if (j < total) M.lp[j] = ex;
-  if (threadIdx.x == 0) M.bt[blockIdx.x] = tot;
+  if (threadIdx.x == 0) M.bt[block] = tot;
+}
+__global__ void __launch_bounds__(kBoBlock) k_bo_walk(BoCtx X, int e) { bo_walk_body(X, e, blockIdx.y, blockIdx.x); }
+
+// The host launches the epochs a frame of `hint` bundles can reach — the bundle counts of the frames before it, with a margin —
+// instead of those a frame of n POINTS could (a 640x480 / 5 cm frame has 1.5e4 bundles of 3e5 points: four of its seven launch
+// pairs did nothing).  This kernel, launched last, is the rest of the recurrence for a map that has MORE bundles than the hint: one
+// workgroup per map walks the remaining epochs, workgroup-sized block after block (slow — a frame that jumps past the margin
+// pays for it once — and exact: the same bodies in the same order).  e_last = the epoch whose k_bo_link was launched without
+// its k_bo_walk.
+__global__ void __launch_bounds__(kBoBlock) k_bo_rest(BoCtx X, int e_last) {
+  extern __shared__ uint32_t s_tot[];
+  const BoSchedule& S = *X.sched;
+  const uint32_t map = blockIdx.x;
+  const uint32_t Bm = X.B[map];
+  if (e_last >= (int)S.n_epochs || !(Bm > S.t[e_last])) return;   // (the common case: the launched epochs were all of them)
+  const uint32_t nblk = (Bm + kBoBlock - 1u) / kBoBlock;
+  for (int e = e_last;;) {
+    for (uint32_t b = 0; b < nblk; ++b) bo_walk_body(X, e, map, b);
+    __threadfence();
+    __syncthreads();
+    ++e;
+    for (uint32_t b = 0; b < nblk; ++b) bo_link_body(X, e, 0, map, b, s_tot);
+    __threadfence();
+    __syncthreads();
+    if (!(e < (int)S.n_epochs && Bm > S.t[e])) break;
+  }
 }
 
 // The epochs that fit one workgroup's LDS — bucket counts up to kBoSmallBuckets, i.e. the first kBoSmallBuckets

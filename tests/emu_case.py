@@ -50,6 +50,8 @@ def main():
             f.T_G_C = np.array([1, 0, 0, 0, 0.3 * k, -0.2 * k, 0.025 * k], np.float32)
         so = o.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
         sg = g.integrate(f.T_G_C, f.xyz, f.rgba, f.labels)
+        if spec.get("rays_at_least") is not None:   # (merged: rays = bundles — the case is meant to reach the bundle order's large epochs)
+            assert so.n_rays_cast >= spec["rays_at_least"], so.n_rays_cast
         tot_o += so.n_voxel_updates
         tot_g += sg.n_voxel_updates
     tot_g += g.flush().n_voxel_updates

@@ -201,9 +201,13 @@ KEY_CASES = {
                                                 {"KS_DEBUG": "1", "KS_KEY_WINDOW_BITS": "3"}),
     "clearing_points_outside_the_window": (dict(method=1, size=[64, 48], frames=2, cfg=dict(max_ray_length_m=1.5)), {}),
     "sorted_64_bit_keys": (dict(method=1, size=[64, 48], frames=2), {"KS_DEBUG": "1", "KS_KEY_WINDOW_BITS": "0"}),
+    # more than kBoSmallBuckets bundles: the large epochs of the bundle order, every one of them through k_bo_rest (hint 1) / through
+    # the launches a frame of n points could need (hint 0)
+    "bundle_order_epochs_beyond_the_hint": (dict(method=1, size=[224, 168], frames=2, max_tiles=4096, rays_at_least=8000), {"KS_DEBUG": "1", "KS_BO_HINT": "1"}),
+    "bundle_order_epochs_for_n_points": (dict(method=1, size=[224, 168], frames=2, max_tiles=4096, rays_at_least=8000), {"KS_DEBUG": "1", "KS_BO_HINT": "0"}),
 }
 for _name, (_spec, _env) in KEY_CASES.items():
-    case_job("test_merged_grouping_keys_equal_oracle[%s]" % _name, _spec, env_extra=_env, weight=10)
+    case_job("test_merged_grouping_keys_equal_oracle[%s]" % _name, _spec, env_extra=_env, weight=30 if "bundle_order" in _name else 10)
 
 
 @pytest.mark.parametrize("name", sorted(KEY_CASES))

@@ -69,3 +69,39 @@ def test_full_size_frames_both_key_forms_same_map(monkeypatch):
     assert compare_maps(o, h64, exact=True)["voxels_compared"] > 10000
     h32.close()
     h64.close()
+
+
+def _pair_env(monkeypatch, env, pipe=0, **kw):
+    okw = dict(COMMON, method=1, **kw)
+    o = O.Oracle(O.default_config(integrator_threads=1, **okw))
+    monkeypatch.setenv("KS_DEBUG", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 19, pipeline_frames=pipe, **okw))
+    for k in env:
+        monkeypatch.delenv(k)
+    monkeypatch.delenv("KS_DEBUG")
+    return o, h
+
+
+@pytest.mark.parametrize("hint,pipe", [("1", 0), ("1", 4), ("12000", 4), ("0", 0)])
+def test_bundle_order_epochs_beyond_the_hint(monkeypatch, hint, pipe):
+    """The rehash recurrence of the bundle order is launched for the bundle counts of the frames before (a hint); a frame with more
+    bundles finishes in k_bo_rest.  640x480 frames have 1-1.5e4 bundles: hint 1 = every epoch past k_bo_small through k_bo_rest,
+    12000 = the last one or two, 0 = the launches a frame of n points could need (rounds 3-5)."""
+    o, h = _pair_env(monkeypatch, {"KS_BO_HINT": hint}, pipe)
+    rep = _run(o, h, _frames(3, 640, 480))
+    assert rep["oracle_touched"] > 10000
+    h.close()
+
+
+def test_bundle_order_hint_follows_the_stream(monkeypatch):
+    """No fixed hint: the first frames are launched for n points, later ones for the counts seen; a jump from 160x120 frames to
+    640x480 ones (10x the bundles) goes through k_bo_rest once and through the launches afterwards."""
+    okw = dict(COMMON, method=1)
+    o = O.Oracle(O.default_config(integrator_threads=1, **okw))
+    h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 19, pipeline_frames=0, **okw))
+    frames = _frames(3, 160, 120, seed=40) + _frames(3, 640, 480, seed=50) + _frames(2, 160, 120, seed=60)
+    rep = _run(o, h, frames)
+    assert rep["oracle_touched"] > 10000
+    h.close()
