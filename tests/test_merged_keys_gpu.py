@@ -105,3 +105,18 @@ def test_bundle_order_hint_follows_the_stream(monkeypatch):
     rep = _run(o, h, frames)
     assert rep["oracle_touched"] > 10000
     h.close()
+
+
+def test_point_buffers_grow_with_the_key_table(monkeypatch):
+    """A context created for 1000 points takes 160x120, then 320x240 frames: stage A's buffers — the key table and the bundle
+    order's slab among them — are re-allocated between frames; window of 3 bits so that the table is in use when it happens."""
+    okw = dict(COMMON, method=1)
+    o = O.Oracle(O.default_config(integrator_threads=1, **okw))
+    monkeypatch.setenv("KS_DEBUG", "1")
+    monkeypatch.setenv("KS_KEY_WINDOW_BITS", "3")
+    h = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1000, pipeline_frames=4, **okw))
+    monkeypatch.delenv("KS_KEY_WINDOW_BITS")
+    monkeypatch.delenv("KS_DEBUG")
+    rep = _run(o, h, _frames(2, 160, 120, seed=70) + _frames(2, 320, 240, seed=80) + _frames(1, 160, 120, seed=90))
+    assert rep["oracle_touched"] > 10000
+    h.close()
