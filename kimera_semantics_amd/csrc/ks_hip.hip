@@ -1080,14 +1080,18 @@ int launch_batch(ks_ctx* c) {
   // their launch sequence depends only on the capacity: it is captured once per group of slots and replayed.
   BatchView V{};
   size_t steps_max = 0;
+  ParamsBatch PB;
   for (uint32_t k = 0; k < nb; ++k) {
     FrameSlot& S = *slots[k];
     S.F.observed = observed_table(c, S.frame_no);
     if (c->exact_early_out) S.F.eo_frame = c->eo_frame_no++;
-    hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sm, S.F, S.d_F);
+    PB.F[k] = S.F;
+    PB.out[k] = S.d_F;
     V.s[k] = slot_view(S);
     steps_max = std::max(steps_max, S.steps_max);
   }
+  if (nb == 1) hipLaunchKernelGGL(k_set_params, dim3(1), dim3(64), 0, sm, slots[0]->F, slots[0]->d_F);
+  else hipLaunchKernelGGL(k_set_params_batch, dim3(nb), dim3(64), 0, sm, PB);   // (one launch at the head of the batch's chain instead of nb)
   const uint64_t key = ((uint64_t)c->cap_points << 24) ^ (c->buffers_epoch.load() << 4) ^ (S0.wide ? 1u : 0u) ^ ((uint64_t)nb << 1);
   FrameSlot::GraphSet& G = S0.b_graphs[nb == (uint32_t)c->batch ? 0 : 1];
   bool replayed = false;

@@ -916,6 +916,18 @@ __global__ void __launch_bounds__(256) k_count_grazing(BatchView V) {
 __global__ void __launch_bounds__(64) k_set_params(FrameParams F, FrameParams* __restrict__ out) {
   if (threadIdx.x == 0) *out = F;
 }
+// ... of all the frames of a batch in one launch (the kernel arguments hold them: 8 x sizeof(FrameParams) < 4 KB)
+struct ParamsBatch {
+  FrameParams F[kBatchMax];
+  FrameParams* out[kBatchMax];
+};
+static_assert(sizeof(ParamsBatch) <= 3840, "kernel arguments");
+__global__ void __launch_bounds__(64) k_set_params_batch(ParamsBatch P) {
+  const uint32_t* src = (const uint32_t*)&P.F[blockIdx.x];
+  uint32_t* dst = (uint32_t*)P.out[blockIdx.x];
+  for (uint32_t i = threadIdx.x; i < sizeof(FrameParams) / 4u; i += 64u) dst[i] = src[i];
+}
+static_assert(sizeof(FrameParams) % 4 == 0, "copied as words");
 
 // End of stage B: the frame's counters and the persistent tile count go to pinned host memory,
 // and the counters are cleared for the slot's next frame (the tail only uses n_long, which it
