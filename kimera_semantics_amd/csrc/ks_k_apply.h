@@ -313,11 +313,11 @@ __global__ void __launch_bounds__(THREADS) k_apply_runs(FrameParams F, unsigned 
   constexpr bool HOT_ONLY = !MERGED && COLOR_MODE != KS_COLOR_MODE_COLOR;
   constexpr bool BLEND = COLOR_MODE == KS_COLOR_MODE_COLOR;
   constexpr uint32_t kTile = kRunPer * THREADS, kSlots = kTile + kRunHalo;
-  constexpr uint32_t kMixSlots = kTile / 21;   // merged: increment vectors of mixed-label bundles parked in LDS per tile (more: read from global in the step)
+  constexpr uint32_t kMixSlots = kTile / 32;   // merged: increment vectors of mixed-label bundles parked in LDS per tile (more: read from global in the step)
   static_assert(kRunHalo == kLongRun, "a short run must end inside the halo");
   static_assert(kRunHalo <= 64 && THREADS % 64 == 0 && THREADS >= 256, "tile shape");
   __shared__ float s_sdf[kSlots], s_uw[kSlots];
-  __shared__ uint32_t s_info[kSlots];                     // [7:0] label, [9:8] kind (1 pure, 2 mixed: vector in s_mix, 3 mixed: vector in global memory)
+  __shared__ uint16_t s_info[kSlots];                     // (with 16-bit entries and kMixSlots = kTile / 32 a workgroup's LDS is 31 KB: five per CU instead of four)  [7:0] label, [9:8] kind (1 pure, 2 mixed: vector in s_mix, 3 mixed: vector in global memory)
   __shared__ float s_dm[MERGED ? kSlots : 1], s_dn[MERGED ? kSlots : 1];   // merged: per-bundle increments (mixed: s_dm = slot in s_mix / bundle position)
   __shared__ uint32_t s_col[BLEND ? kSlots : 1];
   __shared__ unsigned long long s_bounds[kSlots / 64 + 3 + THREADS / 64];  // bit j: pair j of the tile starts a run, or lies past the end of the list
@@ -461,7 +461,7 @@ __global__ void __launch_bounds__(THREADS) k_apply_runs(FrameParams F, unsigned 
         s_dn[j] = __uint_as_float(d1v[k].z);
       }
       if (BLEND) s_col[j] = d1v[k].x;
-      s_info[j] = info;
+      s_info[j] = (uint16_t)info;
     }
   }
   __syncthreads();
