@@ -923,6 +923,7 @@ def main():
             sub_ring = ring
             for name, swl, kw in (("C2-ordered-phases", WORKLOADS["C2"], dict(cfg=dict(early_out_phase_growth=32), pipe=pipeline)),
                                   ("C2-unpipelined", WORKLOADS["C2"], dict(cfg={}, pipe=0)),
+                                  ("C2-pipeline-16", WORKLOADS["C2"], dict(cfg={}, pipe=16)),
                                   ("C3", WORKLOADS["C3"], dict(cfg={}, pipe=pipeline)),
                                   ("C2-host-inputs", WORKLOADS["C2"], dict(cfg={}, pipe=pipeline, entry="host")),
                                   ("C2-depth-host-inputs", WORKLOADS["C2"], dict(cfg={}, pipe=pipeline, entry="depth"))):
@@ -943,6 +944,9 @@ def main():
                                 "NOT the reference's map: touched-voxel Jaccard ~0.98 against the serial order)")
                     elif name == "C2-unpipelined":
                         note = "pipeline_frames = 0: every call completes its own frame (the latency of one frame, host wait included)"
+                    elif name == "C2-pipeline-16":
+                        note = ("pipeline_frames = 16: stage B of EIGHT frames per launch sequence, sixteen calls of lag (the headline runs with 8: "
+                                "four per sequence, eight calls of lag); the same map")
                     elif name == "C2-host-inputs":
                         note = ("ks_integrate_points on page-locked HOST buffers: the H2D copy of every frame is inside the call "
                                 "(SURVEY.md §8d's frames/s definition); never the headline value")
@@ -952,7 +956,7 @@ def main():
                     elif name == "C3":
                         note = "bundles integrated in the reference's std::unordered_map iteration order (bit-exact vs the real sources)"
                     srec, _ = record(name, swl, sm, sK, cof, show, note=note, pmc_name="c3" if name == "C3" else None)
-                    if name == "C3":
+                    if name in ("C3", "C2-pipeline-16"):
                         srec["steady_state"] = steady_state(B, torch, dist, dev, swl, sub_ring, 10 * len(sub_ring), kw["pipe"], 1 << 13)
                     if name == "C2-unpipelined" and cof is not None:
                         srec["gpu_count_equals_serial_reference_count"] = all(

@@ -122,7 +122,7 @@ def test_bench_line_is_one_short_parseable_line():
                                    "updates_gpu_over_serial": 1.0, "how": "h" * 200},
             "cpu_baseline": {"value": 5.2, "unit": "Mvoxel-updates/s", "cores": 8, "kind": "reference", "frames_per_s": 8.5, "host_cores": 192,
                              "spread": 0.02, "by_threads": {"1": 4.8, "8": 5.2, "192": 1.9}, "reference_default_all_cores_value": 1.9, "sample": "s" * 400},
-            "secondary": [dict(sub, config=c) for c in ("C2-ordered-phases", "C3", "C2-host-inputs", "C4-fast", "C4-fast-exact", "C4-merged")]
+            "secondary": [dict(sub, config=c) for c in ("C2-ordered-phases", "C2-unpipelined", "C2-pipeline-16", "C3", "C2-host-inputs", "C2-depth-host-inputs", "C4-fast", "C4-fast-ordered-phases", "C4-merged")]
             + [{"config": "adapter", "workload": "a" * 200, "fast_every_frame_sync_ms_per_frame": 3.56, "fast_on_demand_sync_pipelined_ms_per_frame": 0.31,
                 "merged_every_frame_sync_ms_per_frame": 4.4, "merged_on_demand_sync_pipelined_ms_per_frame": 0.33,
                 "fast_hip_real_factory_patched_server_sequence_ms_per_frame": 0.21},
