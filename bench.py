@@ -51,7 +51,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 BYTES_PER_UPDATE = 208         # R+W of TsdfVoxel (12 B) + SemanticVoxel (92 B), SURVEY.md §8d
 BYTES_PER_POINT = 17           # xyz 12 B + rgba 4 B + label 1 B
-PRIME = 20                     # untimed frames per context before the warm-up: >= frame slots (12) + pipeline_frames (8); with KS_BENCH_PIPE=16 (24 slots) the whole untimed turns of the ring before t0 cover the rest
+PRIME = 20                     # untimed frames per context before the warm-up: >= frame slots (12) + pipeline_frames (8); with 12 or 16 calls of lag (24 slots) the whole untimed turns of the ring before t0 cover the rest
 MIN_REPEATS = 5
 MIN_REPEATS_PRIMARY = 9        # timed regions of the headline: the stretches of the trajectory differ by +-30 % (fix-point rounds), the median of nine moves less between runs than the median of five
 MIN_TIMED_FRAMES = 100
@@ -781,7 +781,11 @@ def main():
     n_distinct = K
     frames = make_frames(wl, [rank + world * k for k in range(n_distinct)])
     ring = FrameRing(frames, torch, dev)
-    pipeline = 0 if args.no_pipeline else int(os.environ.get("KS_BENCH_PIPE", "8"))   # bag replay = a stream of frames: frame pipelining on
+    # bag replay = a stream of frames: frame pipelining on.  `fast` (the headline): 12 calls of lag = THREE batches of four frames in
+    # flight (with 8 — rounds 4 / 5 — the call that needs frame f - 8's snapshot finds its batch just finishing and the GPU's queues run
+    # dry: 0.52 vs 0.47 ms/frame; sub-record C2-pipeline-8); `merged` is indifferent (0.506 / 0.505 / 0.495 at 8 / 12 / 16): 8
+    PIPE_FAST, PIPE_MERGED = 12, 8
+    pipeline = 0 if args.no_pipeline else int(os.environ.get("KS_BENCH_PIPE", str(PIPE_FAST if args.method == "fast" else PIPE_MERGED)))
 
     reduce_fn = None
     comm = None
@@ -923,8 +927,9 @@ def main():
             sub_ring = ring
             for name, swl, kw in (("C2-ordered-phases", WORKLOADS["C2"], dict(cfg=dict(early_out_phase_growth=32), pipe=pipeline)),
                                   ("C2-unpipelined", WORKLOADS["C2"], dict(cfg={}, pipe=0)),
+                                  ("C2-pipeline-8", WORKLOADS["C2"], dict(cfg={}, pipe=8)),
                                   ("C2-pipeline-16", WORKLOADS["C2"], dict(cfg={}, pipe=16)),
-                                  ("C3", WORKLOADS["C3"], dict(cfg={}, pipe=pipeline)),
+                                  ("C3", WORKLOADS["C3"], dict(cfg={}, pipe=min(pipeline, PIPE_MERGED))),
                                   ("C2-host-inputs", WORKLOADS["C2"], dict(cfg={}, pipe=pipeline, entry="host")),
                                   ("C2-depth-host-inputs", WORKLOADS["C2"], dict(cfg={}, pipe=pipeline, entry="depth"))):
                 if not want(name) or args.method != "fast" or (args.width, args.height) != (640, 480):
@@ -944,9 +949,11 @@ def main():
                                 "NOT the reference's map: touched-voxel Jaccard ~0.98 against the serial order)")
                     elif name == "C2-unpipelined":
                         note = "pipeline_frames = 0: every call completes its own frame (the latency of one frame, host wait included)"
+                    elif name == "C2-pipeline-8":
+                        note = "pipeline_frames = 8: the headline's configuration of rounds 4 and 5 (two batches of four frames in flight); the same map"
                     elif name == "C2-pipeline-16":
-                        note = ("pipeline_frames = 16: stage B of EIGHT frames per launch sequence, sixteen calls of lag (the headline runs with 8: "
-                                "four per sequence, eight calls of lag); the same map")
+                        note = ("pipeline_frames = 16: stage B of EIGHT frames per launch sequence, sixteen calls of lag (the headline runs with 12: "
+                                "four per sequence, twelve calls of lag); the same map")
                     elif name == "C2-host-inputs":
                         note = ("ks_integrate_points on page-locked HOST buffers: the H2D copy of every frame is inside the call "
                                 "(SURVEY.md §8d's frames/s definition); never the headline value")
@@ -956,7 +963,7 @@ def main():
                     elif name == "C3":
                         note = "bundles integrated in the reference's std::unordered_map iteration order (bit-exact vs the real sources)"
                     srec, _ = record(name, swl, sm, sK, cof, show, note=note, pmc_name="c3" if name == "C3" else None)
-                    if name in ("C3", "C2-pipeline-16"):
+                    if name in ("C3", "C2-pipeline-8", "C2-pipeline-16"):
                         srec["steady_state"] = steady_state(B, torch, dist, dev, swl, sub_ring, 10 * len(sub_ring), kw["pipe"], 1 << 13)
                     if name == "C2-unpipelined" and cof is not None:
                         srec["gpu_count_equals_serial_reference_count"] = all(
@@ -980,7 +987,8 @@ def main():
                         sec.append({"config": name, "skipped": f"the run is {time.time() - t_start:.0f} s old"})
                         continue
                     light = name == "C4-fast"
-                    sm = measure(B, torch, dist, dev, swl, c4_ring, 2, steps, MIN_REPEATS, pipeline, tiles, 1,
+                    c4pipe = min(pipeline, PIPE_MERGED)   # (1280x720: 8 calls of lag measured best for `merged` and for the ordered phases; the default `fast` mode runs one frame at a time there)
+                    sm = measure(B, torch, dist, dev, swl, c4_ring, 2, steps, MIN_REPEATS, c4pipe, tiles, 1,
                                  prime=steps if light else None, **c4cfg)
                     scale, show = 1.0, "GPU's own count (oracle count skipped)"
                     if light:
@@ -1002,7 +1010,7 @@ def main():
                     srec, _ = record(name, swl, sm, steps, None, show, credit_scale=scale,
                                      pmc_name={"C4-fast": "c4_fast", "C4-merged": "c4_merged"}.get(name))
                     if name == "C4-merged":
-                        srec["steady_state"] = steady_state(B, torch, dist, dev, swl, c4_ring, 6 * steps, pipeline, tiles, **c4cfg)
+                        srec["steady_state"] = steady_state(B, torch, dist, dev, swl, c4_ring, 6 * steps, c4pipe, tiles, **c4cfg)
                     sec.append(srec)
                     torch.cuda.empty_cache()
                 except Exception as e:

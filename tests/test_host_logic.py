@@ -113,7 +113,7 @@ def test_bench_line_is_one_short_parseable_line():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "frames_per_s": 3301.2,
             "gpu_counted_value": 2200.5, "updates_counted_by": "c" * 200,
             "timing": {"spread_max_minus_min_over_median": 0.03, "ms_per_step_all_regions": [0.3] * 5},
-            "config": {"workload": "bag-replay stand-in: " + "w" * 150, "frames_per_gpu": 40, "pipeline_frames": 8, "points_per_frame": 305667,
+            "config": {"workload": "bag-replay stand-in: " + "w" * 150, "frames_per_gpu": 40, "pipeline_frames": 12, "points_per_frame": 305667,
                        "rays_per_frame": 47900, "updates_per_frame": 611496, "gpu_updates_per_frame": 611496, "early_out": "e" * 300,
                        "bundle_order": "n/a (fast)", "parallelism": "frame-sharded x1"},
             "roofline": roof, "host_ms_per_frame": {"in_call": 0.2, "of_which_waiting_for_snapshot": 0.05},
@@ -122,7 +122,7 @@ def test_bench_line_is_one_short_parseable_line():
                                    "updates_gpu_over_serial": 1.0, "how": "h" * 200},
             "cpu_baseline": {"value": 5.2, "unit": "Mvoxel-updates/s", "cores": 8, "kind": "reference", "frames_per_s": 8.5, "host_cores": 192,
                              "spread": 0.02, "by_threads": {"1": 4.8, "8": 5.2, "192": 1.9}, "reference_default_all_cores_value": 1.9, "sample": "s" * 400},
-            "secondary": [dict(sub, config=c) for c in ("C2-ordered-phases", "C2-unpipelined", "C2-pipeline-16", "C3", "C2-host-inputs", "C2-depth-host-inputs", "C4-fast", "C4-fast-ordered-phases", "C4-merged")]
+            "secondary": [dict(sub, config=c) for c in ("C2-ordered-phases", "C2-unpipelined", "C2-pipeline-8", "C2-pipeline-16", "C3", "C2-host-inputs", "C2-depth-host-inputs", "C4-fast", "C4-fast-ordered-phases", "C4-merged")]
             + [{"config": "adapter", "workload": "a" * 200, "fast_every_frame_sync_ms_per_frame": 3.56, "fast_on_demand_sync_pipelined_ms_per_frame": 0.31,
                 "merged_every_frame_sync_ms_per_frame": 4.4, "merged_on_demand_sync_pipelined_ms_per_frame": 0.33,
                 "fast_hip_real_factory_patched_server_sequence_ms_per_frame": 0.21},

@@ -874,18 +874,18 @@ def test_cloud_outgrows_max_points_with_frames_in_flight(method, early_out):
     compare_maps(o, h, exact=True)
 
 
-@pytest.mark.parametrize("method", [0, 1])
-def test_benched_configuration_map_is_exact(method):
-    """EXACTLY what bench.py times: pipeline_frames = 8, 640x480, reference defaults (fast: early-out on, the library's
+@pytest.mark.parametrize("method,pipe", [(0, 12), (0, 8), (1, 8)])
+def test_benched_configuration_map_is_exact(method, pipe):
+    """EXACTLY what bench.py times: pipeline_frames = 12 (`fast`, the headline; 8 = rounds 4 / 5 and the sub-record) / 8 (`merged`), 640x480, reference defaults (fast: early-out on, the library's
     default mode = the reference's serial result; merged: reference bundle order), device-pointer entry, 18 trajectory
     frames so that every frame slot, march stream and captured stage-B graph is reused — final map bit-for-bit against
     the oracle (fast: the serial loop, one thread; merged: unordered_map order)."""
     import torch
     kw = dict(COMMON, method=method, voxel_size=0.05, voxels_per_side=16, truncation_distance=0.2, max_ray_length_m=5.0)
     o = O.Oracle(O.default_config(integrator_threads=1, **kw))
-    h = B.HipIntegrator(B.default_config(max_tiles=1 << 13, max_points=640 * 480, pipeline_frames=8, **kw))
+    h = B.HipIntegrator(B.default_config(max_tiles=1 << 13, max_points=640 * 480, pipeline_frames=pipe, **kw))
     sc = synth.make_scene("room")
-    n_frames = 18 if method == 0 else 8
+    n_frames = (18 if pipe == 8 else 30) if method == 0 else 8
     upd_o = upd_h = 0
     keep = []
     for k in range(n_frames):
@@ -904,10 +904,10 @@ def test_benched_configuration_map_is_exact(method):
         assert st["event_driven"] and st["pipelined"] and st["fallbacks"] == 0, st
 
 
-@pytest.mark.parametrize("pipe", [8, 16])
+@pytest.mark.parametrize("pipe", [8, 12, 16])
 @pytest.mark.parametrize("method", [0, 1])
 def test_batched_stage_b_equals_unpipelined(method, pipe):
-    """pipeline_frames = 8 / 16: stage B of four / eight consecutive frames is ONE batched launch sequence (blockIdx.y = frame).
+    """pipeline_frames = 8 / 12 / 16: stage B of four / eight consecutive frames is ONE batched launch sequence (blockIdx.y = frame).
     22 / 38 frames (full batches, a partial one at the flush, a query in between that forces a partial batch): same map
     and statistics as the unpipelined context; fast runs the default early-out schedule."""
     kw = dict(COMMON, method=method)
@@ -915,7 +915,7 @@ def test_batched_stage_b_equals_unpipelined(method, pipe):
     b = B.HipIntegrator(B.default_config(max_tiles=8192, max_points=1 << 15, pipeline_frames=pipe, **kw))
     sc = synth.make_scene("room")
     ua = ub = 0
-    for k in range(22 if pipe == 8 else 38):
+    for k in range(22 if pipe == 8 else 30 if pipe == 12 else 38):
         f = synth.render_frame(sc, synth.trajectory_pose(k), 128, 96, seed=k)
         ua += a.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
         ub += b.integrate(f.T_G_C, f.xyz, f.rgba, f.labels).n_voxel_updates
